@@ -1,0 +1,100 @@
+"""Mirror of `halo2_proofs::arithmetic` for the two functions on the hot path.
+
+best_multiexp(coeffs, bases) -> G1   and   best_fft(a, omega, log_n)  [UPSTREAM crate absent
+from /root/reference; reached from zk_prover/src/circuits/utils.rs:75,76,94-101].  Same
+argument meaning and error behaviour: length mismatch is an assertion failure upstream and a
+ValueError here; results are returned in halo2curves' byte layout (numpy uint8).
+
+Each function accepts either host buffers (numpy uint8 / bytes) or device-resident torch
+uint8 CUDA tensors; device inputs are consumed in place with no PCIe traffic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+
+
+def _is_torch_cuda(x) -> bool:
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def best_multiexp(coeffs, bases, timings: bool = False):
+    """sum_i coeffs[i] * bases[i]; coeffs n x 32 B Fr (Montgomery), bases n x 64 B G1Affine.
+    Returns the 64-byte affine point (identity = zeros)."""
+    L = ffi.lib()
+    out = np.zeros(64, dtype=np.uint8)
+    if _is_torch_cuda(coeffs):
+        n = coeffs.numel() // 32
+        if bases.numel() != 64 * n:
+            raise ValueError("best_multiexp: coeffs.len() != bases.len()")
+        if timings:
+            tm = ffi.MsmTimings()
+            ffi.check(L.sg_msm_g1_dev_timed(ffi.dev_ptr(coeffs), ffi.dev_ptr(bases), C.c_size_t(n),
+                                            ffi.current_stream_ptr(), ffi.ptr(out), C.byref(tm)))
+            return out, tm.as_dict()
+        ffi.check(L.sg_msm_g1_dev(ffi.dev_ptr(coeffs), ffi.dev_ptr(bases), C.c_size_t(n), ffi.current_stream_ptr(),
+                                  ffi.ptr(out)))
+        return out
+    s, b = ffi.u8(coeffs), ffi.u8(bases)
+    if s.size % 32 or b.size % 64 or s.size // 32 != b.size // 64:
+        raise ValueError("best_multiexp: coeffs.len() != bases.len()")
+    ffi.check(L.sg_msm_g1(ffi.ptr(s), ffi.ptr(b), C.c_size_t(s.size // 32), ffi.ptr(out)))
+    return out
+
+
+def best_fft(a, omega, log_n: int):
+    """Forward DFT of 2^log_n Fr values with generator `omega`, natural order in and out.
+    Host input: returns a new numpy buffer.  Device tensor: transformed in place (like the
+    `&mut [Fr]` upstream) and returned."""
+    L = ffi.lib()
+    w = ffi.u8(omega)
+    if w.size != 32:
+        raise ValueError("best_fft: omega must be one 32-byte Fr")
+    if _is_torch_cuda(a):
+        if a.numel() != 32 << log_n:
+            raise ValueError("best_fft: a.len() != 1 << log_n")
+        ffi.check(L.sg_ntt_fr_dev(ffi.dev_ptr(a), ffi.ptr(w), C.c_uint32(log_n), ffi.current_stream_ptr()))
+        return a
+    buf = ffi.u8(a).copy()
+    if buf.size != 32 << log_n:
+        raise ValueError("best_fft: a.len() != 1 << log_n")
+    ffi.check(L.sg_ntt_fr(ffi.ptr(buf), ffi.ptr(w), C.c_uint32(log_n)))
+    return buf
+
+
+def g1_fixed_base_mul(scalars):
+    """out[i] = scalars[i] * G (what ParamsKZG::setup computes for g[]); host or device."""
+    L = ffi.lib()
+    if _is_torch_cuda(scalars):
+        import torch
+        n = scalars.numel() // 32
+        out = torch.empty(64 * n, dtype=torch.uint8, device=scalars.device)
+        ffi.check(L.sg_g1_fixed_base_mul_dev(ffi.dev_ptr(scalars), C.c_size_t(n), ffi.dev_ptr(out),
+                                             ffi.current_stream_ptr()))
+        return out
+    s = ffi.u8(scalars)
+    out = np.zeros(2 * s.size, dtype=np.uint8)
+    ffi.check(L.sg_g1_fixed_base_mul(ffi.ptr(s), C.c_size_t(s.size // 32), ffi.ptr(out)))
+    return out
+
+
+def fr_to_montgomery(canon):
+    """canonical 32-B LE integers (< r) -> Montgomery Fr, on the device (torch tensor in/out)."""
+    import torch
+    L = ffi.lib()
+    out = torch.empty_like(canon)
+    ffi.check(L.sg_fr_to_montgomery_dev(ffi.dev_ptr(canon), ffi.dev_ptr(out), C.c_size_t(canon.numel() // 32),
+                                        ffi.current_stream_ptr()))
+    return out
+
+
+def fr_from_montgomery(mont):
+    import torch
+    L = ffi.lib()
+    out = torch.empty_like(mont)
+    ffi.check(L.sg_fr_from_montgomery_dev(ffi.dev_ptr(mont), ffi.dev_ptr(out), C.c_size_t(mont.numel() // 32),
+                                          ffi.current_stream_ptr()))
+    return out

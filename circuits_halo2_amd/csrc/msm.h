@@ -1,0 +1,62 @@
+// Host-side interface of the MSM engine (see msm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bn254_curve.cuh"
+
+namespace sg {
+
+struct MsmConfig {
+  uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
+  uint32_t log_seg = 6;        // L = 64 entries per accumulation task
+  uint32_t log_red_chunk = 3;  // G = 8 buckets per thread in the bucket reduction
+};
+
+struct MsmTimings {
+  float digits_ms = 0, sort_ms = 0, accumulate_ms = 0, reduce_ms = 0, total_ms = 0;
+  uint32_t window_bits = 0, windows = 0, tasks = 0, max_bucket = 0;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t need) {
+    if (p && need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = need + need / 8 + 64;
+    hipError_t e = hipMalloc(&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+class MsmEngine {
+ public:
+  ~MsmEngine();
+  hipError_t init();
+  void release();
+  MsmConfig& config() { return cfg_; }
+  uint32_t window_bits_for(size_t n) const;
+  // d_scalars: n x 32 B Montgomery Fr, d_bases: n x 64 B affine; result: 64 B affine on the host
+  hipError_t run(const fp_t* d_scalars, const g1_affine* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
+                 MsmTimings* tm);
+
+ private:
+  MsmConfig cfg_;
+  DevBuf<uint32_t> keys_, sorted_, counts_, off_, ntask_[2], toff_[2], cursor_, meta_;
+  DevBuf<g1_xyzz> partial_[2], red_acc_[2], red_run_[2];
+  uint32_t* h_meta_ = nullptr;
+  g1_xyzz* h_win_ = nullptr;
+};
+
+hipError_t fixed_base_mul(const fp_t* d_scalars, size_t n, g1_affine* d_out, hipStream_t stream);
+
+}  // namespace sg

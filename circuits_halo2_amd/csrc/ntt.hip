@@ -1,0 +1,414 @@
+// Radix-2 NTT / iNTT over BN254 Fr for gfx950 -- the GPU side of halo2's `best_fft`
+// and `EvaluationDomain::{ifft, coeff_to_extended, extended_to_coeff}` (SURVEY.md §8a N1-N4;
+// reference call sites zk_prover/src/circuits/utils.rs:75,76,94-101).
+//
+// Layout: natural order in, natural order out, elements are 32-byte Montgomery Fr exactly
+// as halo2curves stores them.  A transform of n = 2^L points is factored into 1-3 passes
+// (four-step / six-step Cooley-Tukey).  Every pass is one launch of `ntt_pass`: a workgroup
+// stages a tile of T contiguous columns x R strided rows in LDS, runs log2(R) radix-2 DIT
+// stages there (one butterfly per thread per stage, twiddles = powers of omega_R from an LDS
+// tile), multiplies by the inter-pass twiddle (table in the pass's output order, fully
+// coalesced) and writes the tile back.  The first pass of a multi-pass plan writes each
+// column as a contiguous run ("transposing" store) so that no bit-reversal or separate
+// transpose pass ever touches HBM.
+//
+// HBM traffic per pass: 32 B read + 32 B write per element (+32 B twiddle on twiddled
+// passes).  Arithmetic: (n/2) log2 n Montgomery products + one per element per twiddled pass.
+#include "ntt.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace sg {
+
+// ------------------------------------------------------------------ device kernels
+struct PassArgs {
+  const fp_t* in;
+  fp_t* out;
+  const fp_t* tw_local;  // omega_R^k, k < R/2
+  const fp_t* tw_pass;   // per-element twiddle in output order (nullptr: none)
+  uint32_t log_r;        // log2 R  (DFT length of this pass)
+  uint32_t log_t;        // log2 T  (contiguous columns per tile)
+  uint32_t log_b;        // log2 B  (contiguous inner extent)
+  uint32_t kind;         // 0: in-place-like (Y), 1: transposing first pass (X)
+  uint32_t sig_lo;       // X only: b = lo + 2^sig_lo * hi  ->  b' = hi + 2^sig_hi * lo
+  uint32_t sig_hi;
+  uint32_t in_len;       // elements present in `in`; beyond that the input reads as zero
+  uint32_t pre3;         // multiply input i by pre[i % 3]   (coeff_to_extended)
+  uint32_t post3;        // multiply output j by post[j % 3] (extended_to_coeff / plain scale)
+  fp_t pre[3];
+  fp_t post[3];
+};
+
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const fp_t& v) {
+  lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ fp_t lds_get(const uint4* lo, const uint4* hi, uint32_t i) {
+  uint4 a = lo[i], b = hi[i];
+  fp_t r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+
+// One pass.  grid.x = number of tiles = (2^log_b / T) * A  where A = n / (B*R).
+// Dynamic LDS: (T*R + R/2) * 32 bytes.
+__global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
+  extern __shared__ uint4 lds[];
+  const uint32_t R = 1u << p.log_r, T = 1u << p.log_t;
+  const uint32_t E = R << p.log_t;
+  uint4* d_lo = lds;
+  uint4* d_hi = lds + E;
+  uint4* w_lo = lds + 2 * E;
+  uint4* w_hi = w_lo + (R >> 1);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+
+  const uint32_t tiles_per_row = 1u << (p.log_b - p.log_t);
+  const uint32_t a = blockIdx.x >> (p.log_b - p.log_t);  // outer index (Y only; 0 for X)
+  const uint32_t b0 = (blockIdx.x & (tiles_per_row - 1)) << p.log_t;
+  const size_t base = ((size_t)a << (p.log_b + p.log_r)) + b0;
+
+  // stage the local twiddles
+  for (uint32_t k = tid; k < (R >> 1); k += nthr) {
+    fp_t w = fp_load(p.tw_local + k);
+    lds_put(w_lo, w_hi, k, w);
+  }
+  // load the tile: rows are bit-reversed on the way in so that the DIT stages below leave
+  // natural order
+  const uint32_t rshift = 32 - p.log_r;
+  for (uint32_t e = tid; e < E; e += nthr) {
+    uint32_t t = e & (T - 1), r = e >> p.log_t;
+    size_t gi = base + t + ((size_t)r << p.log_b);
+    fp_t v;
+    if (gi < p.in_len) {
+      v = fp_load(p.in + gi);
+      if (p.pre3) {
+        uint32_t m = (uint32_t)(gi % 3);
+        if (m) v = fp_mul<FrP>(v, p.pre[m]);
+      }
+    } else {
+      v = fp_zero<FrP>();
+    }
+    uint32_t rr = p.log_r ? (__brev(r) >> rshift) : 0;
+    lds_put(d_lo, d_hi, (rr << p.log_t) + t, v);
+  }
+  __syncthreads();
+
+  // log2(R) radix-2 DIT stages, one butterfly per thread per sweep
+  for (uint32_t s = 0; s < p.log_r; s++) {
+    const uint32_t h = 1u << s;
+    for (uint32_t q = tid; q < (E >> 1); q += nthr) {
+      uint32_t t = q & (T - 1), pr = q >> p.log_t;
+      uint32_t j = pr & (h - 1), blk = pr >> s;
+      uint32_t row = (blk << (s + 1)) + j;
+      uint32_t i0 = (row << p.log_t) + t, i1 = i0 + (h << p.log_t);
+      fp_t u = lds_get(d_lo, d_hi, i0);
+      fp_t v = lds_get(d_lo, d_hi, i1);
+      if (j) {  // omega^0 butterflies skip the product, as best_fft does
+        fp_t w = lds_get(w_lo, w_hi, j << (p.log_r - s - 1));
+        v = fp_mul<FrP>(v, w);
+      }
+      lds_put(d_lo, d_hi, i0, fp_add<FrP>(u, v));
+      lds_put(d_lo, d_hi, i1, fp_sub<FrP>(u, v));
+    }
+    __syncthreads();
+  }
+
+  // write back
+  if (p.kind == 0) {
+    for (uint32_t e = tid; e < E; e += nthr) {
+      uint32_t t = e & (T - 1), r = e >> p.log_t;
+      size_t go = base + t + ((size_t)r << p.log_b);
+      fp_t v = lds_get(d_lo, d_hi, e);
+      if (p.tw_pass) v = fp_mul<FrP>(v, fp_load(p.tw_pass + go));
+      if (p.post3) v = fp_mul<FrP>(v, p.post[go % 3]);
+      fp_store(p.out + go, v);
+    }
+  } else {
+    for (uint32_t e = tid; e < E; e += nthr) {
+      uint32_t r = e & (R - 1), t = e >> p.log_r;
+      uint32_t b = b0 + t;
+      uint32_t bp = (b >> p.sig_lo) + ((b & ((1u << p.sig_lo) - 1)) << p.sig_hi);
+      size_t go = ((size_t)bp << p.log_r) + r;
+      fp_t v = lds_get(d_lo, d_hi, (r << p.log_t) + t);
+      if (p.tw_pass) v = fp_mul<FrP>(v, fp_load(p.tw_pass + go));
+      if (p.post3) v = fp_mul<FrP>(v, p.post[go % 3]);
+      fp_store(p.out + go, v);
+    }
+  }
+}
+
+// tw[k] = w^k for k < count
+__global__ void fill_powers(fp_t* tw, fp_t w, uint32_t count) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < count) fp_store(tw + k, fp_pow_u64<FrP>(w, k));
+}
+
+// inter-pass twiddle tables, in the output order of the pass they are applied in
+//  mode 0 (2-pass, pass X):   idx = j2 + n2*i1            -> w^(i1*j2) * scale
+//  mode 1 (3-pass, pass A):   idx = j3 + n3*(i2 + n2*i1)  -> w^(n1*i2*j3) * scale
+//  mode 2 (3-pass, pass B):   idx = j3 + n3*j2 + n2n3*i1  -> w^(i1*(j3 + n3*j2))
+__global__ void fill_pass_twiddles(fp_t* tw, fp_t w, fp_t scale, uint32_t has_scale, uint32_t mode,
+                                   uint32_t l1, uint32_t l2, uint32_t l3, uint32_t log_n) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >> log_n) return;
+  uint64_t e;
+  if (mode == 0) {
+    uint64_t j2 = idx & ((1ull << l2) - 1), i1 = idx >> l2;
+    e = i1 * j2;
+  } else if (mode == 1) {
+    uint64_t j3 = idx & ((1ull << l3) - 1), i2 = (idx >> l3) & ((1ull << l2) - 1);
+    e = (i2 * j3) << l1;
+  } else {
+    uint64_t jj = idx & ((1ull << (l2 + l3)) - 1), i1 = idx >> (l2 + l3);
+    e = i1 * jj;
+  }
+  e &= (1ull << log_n) - 1;
+  fp_t v = fp_pow_u64<FrP>(w, e);
+  if (has_scale) v = fp_mul<FrP>(v, scale);
+  fp_store(tw + idx, v);
+}
+
+__global__ void scale_kernel(fp_t* a, fp_t s, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fp_store(a + i, fp_mul<FrP>(fp_load(a + i), s));
+}
+// a[i] *= tab[i & (period-1)]   (divide_by_vanishing_poly; period = 2^(ext_k-k))
+__global__ void scale_periodic_kernel(fp_t* a, const fp_t* tab, uint32_t period, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fp_store(a + i, fp_mul<FrP>(fp_load(a + i), fp_load(tab + (i & (period - 1)))));
+}
+__global__ void to_mont_kernel(const fp_t* in, fp_t* out, size_t n, int dir) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    fp_t v = fp_load(in + i);
+    fp_store(out + i, dir ? fp_to_mont<FrP>(v) : fp_from_mont<FrP>(v));
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static bool fp_host_eq(const fp_t& a, const fp_t& b) { return std::memcmp(&a, &b, sizeof(fp_t)) == 0; }
+
+NttEngine::~NttEngine() { clear(); }
+
+void NttEngine::clear() {
+  for (auto& pl : plans_) {
+    for (int i = 0; i < 3; i++) {
+      if (pl.tw_pass[i]) (void)hipFree(pl.tw_pass[i]);
+    }
+  }
+  plans_.clear();
+  for (auto& kv : local_tw_) (void)hipFree(kv.tw);
+  local_tw_.clear();
+}
+
+hipError_t NttEngine::local_twiddles(const fp_t& omega_r, uint32_t log_r, hipStream_t stream, fp_t** out) {
+  for (auto& e : local_tw_) {
+    if (e.log_r == log_r && fp_host_eq(e.omega_r, omega_r)) {
+      *out = e.tw;
+      return hipSuccess;
+    }
+  }
+  uint32_t count = log_r ? (1u << (log_r - 1)) : 1;
+  fp_t* d = nullptr;
+  hipError_t err = hipMalloc(&d, sizeof(fp_t) * count);
+  if (err != hipSuccess) return err;
+  fill_powers<<<(count + 255) / 256, 256, 0, stream>>>(d, omega_r, count);
+  local_tw_.push_back({log_r, omega_r, d});
+  *out = d;
+  return hipGetLastError();
+}
+
+// choose the pass factorisation for a 2^log_n transform
+static void factor(uint32_t log_n, uint32_t max_single, uint32_t max_multi, int* npass, uint32_t l[3]) {
+  l[0] = l[1] = l[2] = 0;
+  if (log_n <= max_single) {
+    *npass = 1;
+    l[0] = log_n;
+  } else if (log_n <= 2 * max_multi) {
+    *npass = 2;
+    l[0] = (log_n + 1) / 2;  // n1 (second pass DFT length)
+    l[1] = log_n - l[0];     // n2 (first pass DFT length)
+  } else {
+    *npass = 3;
+    l[0] = (log_n + 2) / 3;
+    l[1] = (log_n - l[0] + 1) / 2;
+    l[2] = log_n - l[0] - l[1];
+  }
+}
+
+hipError_t NttEngine::get_plan(uint32_t log_n, const fp_t& omega, const fp_t* scale, hipStream_t stream,
+                               const NttPlan** out) {
+  for (auto& pl : plans_) {
+    if (pl.log_n == log_n && fp_host_eq(pl.omega, omega) && pl.has_scale == (scale != nullptr) &&
+        (!scale || fp_host_eq(pl.scale, *scale))) {
+      *out = &pl;
+      return hipSuccess;
+    }
+  }
+  NttPlan pl{};
+  pl.log_n = log_n;
+  pl.omega = omega;
+  pl.has_scale = scale != nullptr;
+  if (scale) pl.scale = *scale;
+  factor(log_n, cfg_.max_single_log, cfg_.max_multi_log, &pl.npass, pl.l);
+  const size_t n = (size_t)1 << log_n;
+  hipError_t err;
+  // omega_R for a length-R sub-transform is omega^(n/R): square omega (log_n - log_r) times
+  // on the device via fill_powers' pow (host has no field arithmetic on purpose)
+  auto omega_pow2 = [&](uint32_t times, fp_t* res) -> hipError_t {
+    fp_t* d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(fp_t) * 2);
+    if (e != hipSuccess) return e;
+    // fill_powers computes w^k; k = 2^times fits 32 bits (times <= 28)
+    pow_single<<<1, 1, 0, stream>>>(d, omega, 1ull << times);
+    e = hipMemcpyAsync(res, d, sizeof(fp_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    return e;
+  };
+  for (int i = 0; i < pl.npass; i++) {
+    fp_t wr;
+    err = omega_pow2(log_n - pl.l[i], &wr);
+    if (err != hipSuccess) return err;
+    err = local_twiddles(wr, pl.l[i], stream, &pl.tw_local[i]);
+    if (err != hipSuccess) return err;
+  }
+  fp_t one_or_scale = scale ? *scale : omega;  // placeholder when unused
+  if (pl.npass == 2) {
+    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_t) * n);
+    if (err != hipSuccess) return err;
+    fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
+                                                                         scale ? 1 : 0, 0, pl.l[0], pl.l[1], 0, log_n);
+  } else if (pl.npass == 3) {
+    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_t) * n);
+    if (err != hipSuccess) return err;
+    err = hipMalloc(&pl.tw_pass[1], sizeof(fp_t) * n);
+    if (err != hipSuccess) return err;
+    fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
+                                                                         scale ? 1 : 0, 1, pl.l[0], pl.l[1], pl.l[2], log_n);
+    fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[1], omega, one_or_scale, 0, 2,
+                                                                         pl.l[0], pl.l[1], pl.l[2], log_n);
+  }
+  err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  // tables must be complete before any other stream may use the cached plan
+  err = hipStreamSynchronize(stream);
+  if (err != hipSuccess) return err;
+  plans_.push_back(pl);
+  *out = &plans_.back();
+  return hipSuccess;
+}
+
+__global__ void pow_single(fp_t* out, fp_t w, uint64_t e) { fp_store(out, fp_pow_u64<FrP>(w, e)); }
+
+static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n, hipStream_t stream) {
+  // tile width: as many contiguous columns as the LDS budget allows
+  uint32_t log_e = std::min<uint32_t>(cfg.tile_log, log_n);
+  if (log_e < a.log_r) log_e = a.log_r;
+  uint32_t log_t = std::min<uint32_t>(log_e - a.log_r, a.log_b);
+  a.log_t = log_t;
+  size_t E = (size_t)1 << (a.log_r + log_t);
+  size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 1) * 32;
+  uint32_t threads = (uint32_t)std::min<size_t>(cfg.threads, std::max<size_t>(64, E / 2));
+  uint32_t tiles = 1u << (log_n - a.log_r - log_t);
+  hipLaunchKernelGGL(ntt_pass, dim3(tiles), dim3(threads), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t NttEngine::init() {
+  // allow the large dynamic-LDS tiles (up to the full 160 KiB of a CU)
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024);
+}
+
+hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* scratch, uint32_t log_n,
+                                const fp_t& omega, const fp_t* scale, const fp_t* pre3, const fp_t* post3,
+                                hipStream_t stream) {
+  const NttPlan* pl;
+  // a plain scale is folded into the first inter-pass twiddle table when there is one
+  bool fold_scale = scale && !post3 && log_n > cfg_.max_single_log;
+  hipError_t err = get_plan(log_n, omega, fold_scale ? scale : nullptr, stream, &pl);
+  if (err != hipSuccess) return err;
+  if (log_n == 0) {
+    if (in != out) err = hipMemcpyAsync(out, in, sizeof(fp_t), hipMemcpyDeviceToDevice, stream);
+    if (err == hipSuccess && scale && !post3) scale_kernel<<<1, 64, 0, stream>>>(out, *scale, 1);
+    return err;
+  }
+  PassArgs a{};
+  auto set_prepost = [&](bool first, bool last) {
+    a.pre3 = 0;
+    a.post3 = 0;
+    if (first && pre3) {
+      a.pre3 = 1;
+      for (int i = 0; i < 3; i++) a.pre[i] = pre3[i];
+    }
+    if (last && post3) {
+      a.post3 = 1;
+      for (int i = 0; i < 3; i++) a.post[i] = post3[i];
+    } else if (last && scale && !fold_scale) {
+      a.post3 = 1;
+      for (int i = 0; i < 3; i++) a.post[i] = *scale;
+    }
+  };
+  const bool inplace = (in == out);
+  if (pl->npass == 1) {
+    a.in = in; a.out = out; a.tw_local = pl->tw_local[0]; a.tw_pass = nullptr;
+    a.log_r = log_n; a.log_b = 0; a.kind = 0; a.in_len = (uint32_t)std::min<size_t>(in_len, (size_t)1 << log_n);
+    set_prepost(true, true);
+    return launch_pass(cfg_, a, log_n, stream);
+  }
+  if (pl->npass == 2) {
+    const uint32_t l1 = pl->l[0], l2 = pl->l[1];
+    fp_t* mid = inplace ? scratch : out;
+    // pass X: DFT over i2 (length n2, stride n1), columns i1 contiguous
+    a.in = in; a.out = mid; a.tw_local = pl->tw_local[1]; a.tw_pass = pl->tw_pass[0];
+    a.log_r = l2; a.log_b = l1; a.kind = 1; a.sig_lo = l1; a.sig_hi = 0;
+    a.in_len = (uint32_t)std::min<size_t>(in_len, (size_t)1 << log_n);
+    set_prepost(true, false);
+    err = launch_pass(cfg_, a, log_n, stream);
+    if (err != hipSuccess) return err;
+    // pass Y: DFT over i1 (length n1, stride n2), columns j2 contiguous
+    a.in = mid; a.out = out; a.tw_local = pl->tw_local[0]; a.tw_pass = nullptr;
+    a.log_r = l1; a.log_b = l2; a.kind = 0; a.in_len = 1u << log_n;
+    set_prepost(false, true);
+    return launch_pass(cfg_, a, log_n, stream);
+  }
+  const uint32_t l1 = pl->l[0], l2 = pl->l[1], l3 = pl->l[2];
+  fp_t* mid = inplace ? scratch : out;
+  // pass A: DFT over i3 (length n3, stride n1 n2); writes j3 + n3*(i2 + n2*i1)
+  a.in = in; a.out = mid; a.tw_local = pl->tw_local[2]; a.tw_pass = pl->tw_pass[0];
+  a.log_r = l3; a.log_b = l1 + l2; a.kind = 1; a.sig_lo = l1; a.sig_hi = l2;
+  a.in_len = (uint32_t)std::min<size_t>(in_len, (size_t)1 << log_n);
+  set_prepost(true, false);
+  err = launch_pass(cfg_, a, log_n, stream);
+  if (err != hipSuccess) return err;
+  // pass B: DFT over i2 (length n2, stride n3) for each i1, in place
+  a.in = mid; a.out = mid; a.tw_local = pl->tw_local[1]; a.tw_pass = pl->tw_pass[1];
+  a.log_r = l2; a.log_b = l3; a.kind = 0; a.in_len = 1u << log_n;
+  set_prepost(false, false);
+  err = launch_pass(cfg_, a, log_n, stream);
+  if (err != hipSuccess) return err;
+  // pass C: DFT over i1 (length n1, stride n2 n3)
+  a.in = mid; a.out = out; a.tw_local = pl->tw_local[0]; a.tw_pass = nullptr;
+  a.log_r = l1; a.log_b = l2 + l3; a.kind = 0;
+  set_prepost(false, true);
+  return launch_pass(cfg_, a, log_n, stream);
+}
+
+hipError_t ntt_scale(fp_t* a, const fp_t& s, size_t n, hipStream_t stream) {
+  scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, s, n);
+  return hipGetLastError();
+}
+hipError_t ntt_scale_periodic(fp_t* a, const fp_t* tab, uint32_t period, size_t n, hipStream_t stream) {
+  scale_periodic_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, tab, period, n);
+  return hipGetLastError();
+}
+hipError_t fr_montgomery(const fp_t* in, fp_t* out, size_t n, int to_mont, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  to_mont_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(in, out, n, to_mont);
+  return hipGetLastError();
+}
+
+}  // namespace sg

@@ -1,0 +1,570 @@
+// C ABI of the MI355X back-end (include/summa_gpu.h).  Thin: argument checks, staging of
+// host buffers, per-device context (stream, workspaces, twiddle / SRS caches), dispatch to
+// the NTT and MSM engines.  No CPU implementation of the path exists in this library: if
+// HIP is unusable every entry point fails with SG_ERR_NO_DEVICE / SG_ERR_HIP.
+#include "../../include/summa_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "msm.h"
+#include "ntt.h"
+
+using namespace sg;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess) std::snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  else std::snprintf(g_err, sizeof g_err, "%s", what);
+  return code;
+}
+int hip_fail(const char* what, hipError_t e) {
+  return fail(e == hipErrorOutOfMemory ? SG_ERR_NOMEM : SG_ERR_HIP, what, e);
+}
+#define CHECK_HIP(call, what)                  \
+  do {                                         \
+    hipError_t _e = (call);                    \
+    if (_e != hipSuccess) return hip_fail(what, _e); \
+  } while (0)
+
+// BN254 Fr constants in Montgomery form (32-bit limbs)
+__device__ const uint32_t ROOT_OF_UNITY_M[8] = {0xb639feb8u, 0x9632c7c5u, 0x0d0ff299u, 0x985ce340u,
+                                                0x01b0ecd8u, 0xb2dd8800u, 0x6d98ce29u, 0x1d69070du};  // order 2^28
+__device__ const uint32_t ZETA_M[8] = {0x55fcd653u, 0x0363f299u, 0x5fc1e200u, 0x73e7950bu,
+                                       0x576d9d24u, 0xc5fce83eu, 0xa1c3a4d4u, 0x059c805du};  // Fr::ZETA
+
+struct DomainConsts {
+  fp_t omega, omega_inv, n_inv, zeta, zeta2, ninv_zeta2, ninv_zeta, one;
+};
+// EvaluationDomain::new constants for 2^k
+__global__ void domain_kernel(uint32_t k, DomainConsts* out) {
+  fp_t w, z;
+  for (int i = 0; i < 8; i++) { w.l[i] = ROOT_OF_UNITY_M[i]; z.l[i] = ZETA_M[i]; }
+  for (uint32_t i = k; i < 28; i++) w = fp_sqr<FrP>(w);
+  fp_t n = fp_zero<FrP>();
+  n.l[k >> 5] = 1u << (k & 31);
+  fp_t ninv = fp_inv<FrP>(fp_to_mont<FrP>(n));
+  fp_t z2 = fp_sqr<FrP>(z);
+  out->omega = w;
+  out->omega_inv = fp_inv<FrP>(w);
+  out->n_inv = ninv;
+  out->zeta = z;
+  out->zeta2 = z2;
+  out->ninv_zeta2 = fp_mul<FrP>(ninv, z2);
+  out->ninv_zeta = fp_mul<FrP>(ninv, z);
+  out->one = fp_one<FrP>();
+}
+// t_evaluations[i] = 1 / ((zeta * omega_ext^i)^(2^k) - 1), i < 2^(ext_k - k)
+__global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, fp_t omega_ext, fp_t* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (ext_k - k)) return;
+  fp_t z;
+  for (int j = 0; j < 8; j++) z.l[j] = ZETA_M[j];
+  fp_t x = fp_mul<FrP>(z, fp_pow_u64<FrP>(omega_ext, i));
+  for (uint32_t s = 0; s < k; s++) x = fp_sqr<FrP>(x);
+  x = fp_sub<FrP>(x, fp_one<FrP>());
+  fp_store(out + i, fp_inv<FrP>(x));
+}
+
+struct Srs {
+  uint32_t k;
+  g1_affine* g;
+  g1_affine* g_lagrange;
+};
+
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  NttEngine ntt;
+  MsmEngine msm;
+  DevBuf<uint8_t> stage_a, stage_b, scratch;
+  DomainConsts* d_consts = nullptr;
+  std::map<uint32_t, DomainConsts> consts;
+  std::map<uint64_t, fp_t*> t_evals;  // key = k << 32 | ext_k
+  std::map<uint64_t, Srs> srs;
+  uint64_t next_handle = 1;
+};
+
+std::mutex g_mu;
+Context* g_ctx = nullptr;
+
+int need_ctx() {
+  if (!g_ctx) {
+    // lazy default initialisation on device 0 keeps the seam a pure function call, like
+    // best_multiexp / best_fft
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
+    Context* c = new Context();
+    hipError_t e = hipSetDevice(0);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = c->ntt.init();
+    if (e == hipSuccess) e = c->msm.init();
+    if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
+    if (e != hipSuccess) {
+      delete c;
+      return hip_fail("sg_init", e);
+    }
+    c->device = 0;
+    g_ctx = c;
+  }
+  hipError_t e = hipSetDevice(g_ctx->device);
+  if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+  return SG_OK;
+}
+
+int get_consts(uint32_t k, const DomainConsts** out) {
+  Context& c = *g_ctx;
+  auto it = c.consts.find(k);
+  if (it == c.consts.end()) {
+    domain_kernel<<<1, 1, 0, c.stream>>>(k, c.d_consts);
+    DomainConsts h;
+    CHECK_HIP(hipMemcpyAsync(&h, c.d_consts, sizeof h, hipMemcpyDeviceToHost, c.stream), "domain constants");
+    CHECK_HIP(hipStreamSynchronize(c.stream), "domain constants");
+    it = c.consts.emplace(k, h).first;
+  }
+  *out = &it->second;
+  return SG_OK;
+}
+
+hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : g_ctx->stream; }
+
+// order the library's own stream work (plan/twiddle generation) before a caller stream
+int sync_own_stream_into(hipStream_t s) {
+  if (s == g_ctx->stream) return SG_OK;
+  CHECK_HIP(hipStreamSynchronize(g_ctx->stream), "stream sync");
+  return SG_OK;
+}
+
+int ntt_dev(const fp_t* in, size_t in_len, fp_t* out, uint32_t log_n, const fp_t& omega, const fp_t* scale,
+            const fp_t* pre3, const fp_t* post3, hipStream_t s) {
+  Context& c = *g_ctx;
+  if (log_n > 28) return fail(SG_ERR_INVALID, "log_n exceeds the 2-adicity (28) of BN254 Fr");
+  fp_t* scratch = nullptr;
+  if (in == out && log_n > c.ntt.config().max_single_log) {
+    hipError_t e = c.scratch.reserve((size_t)32 << log_n);
+    if (e != hipSuccess) return hip_fail("ntt scratch", e);
+    scratch = reinterpret_cast<fp_t*>(c.scratch.p);
+  }
+  // plans are generated on the same stream the transform runs on
+  hipError_t e = c.ntt.transform(in, in_len, out, scratch, log_n, omega, scale, pre3, post3, s);
+  if (e != hipSuccess) return hip_fail("ntt", e);
+  return SG_OK;
+}
+
+int upload(DevBuf<uint8_t>& buf, const uint8_t* host, size_t bytes, hipStream_t s) {
+  hipError_t e = buf.reserve(bytes ? bytes : 1);
+  if (e != hipSuccess) return hip_fail("staging buffer", e);
+  if (bytes) CHECK_HIP(hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, s), "H2D copy");
+  return SG_OK;
+}
+int download(uint8_t* host, const void* dev, size_t bytes, hipStream_t s) {
+  CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s), "D2H copy");
+  CHECK_HIP(hipStreamSynchronize(s), "stream sync");
+  return SG_OK;
+}
+
+#define LOCKED_CTX()                          \
+  std::lock_guard<std::mutex> _lk(g_mu);      \
+  {                                           \
+    int _rc = need_ctx();                     \
+    if (_rc != SG_OK) return _rc;             \
+  }
+#define TRY(x)                  \
+  do {                          \
+    int _rc = (x);              \
+    if (_rc != SG_OK) return _rc; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int sg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* sg_version(void) { return "summa_gpu 0.1.0 gfx950"; }
+const char* sg_last_error(void) { return g_err; }
+
+int sg_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ctx && g_ctx->device == device) return SG_OK;
+  if (g_ctx) return fail(SG_ERR_INVALID, "sg_init: already bound to another device (one process per GPU)");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(SG_ERR_INVALID, "sg_init: device index out of range");
+  Context* c = new Context();
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = c->ntt.init();
+  if (e == hipSuccess) e = c->msm.init();
+  if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail("sg_init", e);
+  }
+  c->device = device;
+  g_ctx = c;
+  return SG_OK;
+}
+
+void sg_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx) return;
+  (void)hipSetDevice(g_ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g_ctx->srs) {
+    (void)hipFree(kv.second.g);
+    (void)hipFree(kv.second.g_lagrange);
+  }
+  for (auto& kv : g_ctx->t_evals) (void)hipFree(kv.second);
+  g_ctx->ntt.clear();
+  g_ctx->msm.release();
+  g_ctx->stage_a.release();
+  g_ctx->stage_b.release();
+  g_ctx->scratch.release();
+  if (g_ctx->d_consts) (void)hipFree(g_ctx->d_consts);
+  if (g_ctx->stream) (void)hipStreamDestroy(g_ctx->stream);
+  delete g_ctx;
+  g_ctx = nullptr;
+}
+
+// ------------------------------------------------------------------ MSM
+int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64],
+                        sg_msm_timings* timings) {
+  if (!out_affine || (n && (!d_scalars || !d_bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
+  LOCKED_CTX();
+  MsmTimings tm;
+  hipError_t e = g_ctx->msm.run(static_cast<const fp_t*>(d_scalars), static_cast<const g1_affine*>(d_bases), n,
+                                pick_stream(stream), out_affine, timings ? &tm : nullptr);
+  if (e != hipSuccess) return hip_fail("msm", e);
+  if (timings) {
+    timings->digits_ms = tm.digits_ms; timings->sort_ms = tm.sort_ms; timings->accumulate_ms = tm.accumulate_ms;
+    timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
+    timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
+  }
+  return SG_OK;
+}
+int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]) {
+  return sg_msm_g1_dev_timed(d_scalars, d_bases, n, stream, out_affine, nullptr);
+}
+int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]) {
+  if (!out_affine || (n && (!scalars || !bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
+  {
+    LOCKED_CTX();
+    TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
+    TRY(upload(g_ctx->stage_b, bases, n * 64, g_ctx->stream));
+    hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p),
+                                  reinterpret_cast<const g1_affine*>(g_ctx->stage_b.p), n, g_ctx->stream, out_affine,
+                                  nullptr);
+    if (e != hipSuccess) return hip_fail("msm", e);
+  }
+  return SG_OK;
+}
+
+int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint64_t* handle_out) {
+  if (!g || !g_lagrange || !handle_out || k > 28) return fail(SG_ERR_INVALID, "sg_srs_upload: bad argument");
+  LOCKED_CTX();
+  const size_t bytes = (size_t)64 << k;
+  Srs s{k, nullptr, nullptr};
+  hipError_t e = hipMalloc(&s.g, bytes);
+  if (e == hipSuccess) e = hipMalloc(&s.g_lagrange, bytes);
+  if (e == hipSuccess) e = hipMemcpy(s.g, g, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s.g_lagrange, g_lagrange, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (s.g) (void)hipFree(s.g);
+    if (s.g_lagrange) (void)hipFree(s.g_lagrange);
+    return hip_fail("sg_srs_upload", e);
+  }
+  uint64_t h = g_ctx->next_handle++;
+  g_ctx->srs[h] = s;
+  *handle_out = h;
+  return SG_OK;
+}
+int sg_srs_free(uint64_t handle) {
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "sg_srs_free: unknown handle");
+  (void)hipFree(it->second.g);
+  (void)hipFree(it->second.g_lagrange);
+  g_ctx->srs.erase(it);
+  return SG_OK;
+}
+int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k) {
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (d_g) *d_g = it->second.g;
+  if (d_g_lagrange) *d_g_lagrange = it->second.g_lagrange;
+  if (k) *k = it->second.k;
+  return SG_OK;
+}
+int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
+                  uint8_t out_affine[64]) {
+  if (!out_affine || (n && !d_scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(srs_handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  hipError_t e = g_ctx->msm.run(static_cast<const fp_t*>(d_scalars), basis ? it->second.g_lagrange : it->second.g, n,
+                                pick_stream(stream), out_affine, nullptr);
+  if (e != hipSuccess) return hip_fail("msm", e);
+  return SG_OK;
+}
+int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
+  if (!out_affine || (n && !scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(srs_handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
+  hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p),
+                                basis ? it->second.g_lagrange : it->second.g, n, g_ctx->stream, out_affine, nullptr);
+  if (e != hipSuccess) return hip_fail("msm", e);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ NTT family
+int sg_ntt_fr_dev(void* d_a, const uint8_t omega[32], uint32_t log_n, void* stream) {
+  if (!d_a || !omega) return fail(SG_ERR_INVALID, "sg_ntt_fr: null argument");
+  LOCKED_CTX();
+  fp_t w;
+  std::memcpy(&w, omega, 32);
+  fp_t* a = static_cast<fp_t*>(d_a);
+  return ntt_dev(a, (size_t)1 << log_n, a, log_n, w, nullptr, nullptr, nullptr, pick_stream(stream));
+}
+int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n) {
+  if (!a || !omega || log_n > 28) return fail(SG_ERR_INVALID, "sg_ntt_fr: bad argument");
+  LOCKED_CTX();
+  const size_t bytes = (size_t)32 << log_n;
+  TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
+  fp_t w;
+  std::memcpy(&w, omega, 32);
+  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  TRY(ntt_dev(d, (size_t)1 << log_n, d, log_n, w, nullptr, nullptr, nullptr, g_ctx->stream));
+  return download(a, d, bytes, g_ctx->stream);
+}
+int sg_intt_fr_dev(void* d_a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n, void* stream) {
+  if (!d_a || !omega_inv || !divisor) return fail(SG_ERR_INVALID, "sg_intt_fr: null argument");
+  LOCKED_CTX();
+  fp_t w, d;
+  std::memcpy(&w, omega_inv, 32);
+  std::memcpy(&d, divisor, 32);
+  fp_t* a = static_cast<fp_t*>(d_a);
+  return ntt_dev(a, (size_t)1 << log_n, a, log_n, w, &d, nullptr, nullptr, pick_stream(stream));
+}
+int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n) {
+  if (!a || !omega_inv || !divisor || log_n > 28) return fail(SG_ERR_INVALID, "sg_intt_fr: bad argument");
+  LOCKED_CTX();
+  const size_t bytes = (size_t)32 << log_n;
+  TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
+  fp_t w, dv;
+  std::memcpy(&w, omega_inv, 32);
+  std::memcpy(&dv, divisor, 32);
+  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  TRY(ntt_dev(d, (size_t)1 << log_n, d, log_n, w, &dv, nullptr, nullptr, g_ctx->stream));
+  return download(a, d, bytes, g_ctx->stream);
+}
+int sg_lagrange_to_coeff_dev(void* d_a, uint32_t k, void* stream) {
+  if (!d_a || k > 28) return fail(SG_ERR_INVALID, "sg_lagrange_to_coeff: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(k, &dc));
+  TRY(sync_own_stream_into(pick_stream(stream)));
+  fp_t* a = static_cast<fp_t*>(d_a);
+  return ntt_dev(a, (size_t)1 << k, a, k, dc->omega_inv, &dc->n_inv, nullptr, nullptr, pick_stream(stream));
+}
+int sg_lagrange_to_coeff(uint8_t* a, uint32_t k) {
+  if (!a || k > 28) return fail(SG_ERR_INVALID, "sg_lagrange_to_coeff: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(k, &dc));
+  const size_t bytes = (size_t)32 << k;
+  TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
+  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  TRY(ntt_dev(d, (size_t)1 << k, d, k, dc->omega_inv, &dc->n_inv, nullptr, nullptr, g_ctx->stream));
+  return download(a, d, bytes, g_ctx->stream);
+}
+
+int sg_coeff_to_extended_dev(const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out, void* stream) {
+  if (!d_coeffs || !d_out || ext_k > 28 || k > ext_k || d_coeffs == d_out)
+    return fail(SG_ERR_INVALID, "sg_coeff_to_extended: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(ext_k, &dc));
+  TRY(sync_own_stream_into(pick_stream(stream)));
+  fp_t pre[3] = {dc->one, dc->zeta, dc->zeta2};
+  return ntt_dev(static_cast<const fp_t*>(d_coeffs), (size_t)1 << k, static_cast<fp_t*>(d_out), ext_k, dc->omega,
+                 nullptr, pre, nullptr, pick_stream(stream));
+}
+int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint8_t* out) {
+  if (!coeffs || !out || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_coeff_to_extended: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(ext_k, &dc));
+  TRY(upload(g_ctx->stage_a, coeffs, (size_t)32 << k, g_ctx->stream));
+  hipError_t e = g_ctx->stage_b.reserve((size_t)32 << ext_k);
+  if (e != hipSuccess) return hip_fail("staging buffer", e);
+  fp_t pre[3] = {dc->one, dc->zeta, dc->zeta2};
+  TRY(ntt_dev(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p), (size_t)1 << k, reinterpret_cast<fp_t*>(g_ctx->stage_b.p),
+              ext_k, dc->omega, nullptr, pre, nullptr, g_ctx->stream));
+  return download(out, g_ctx->stage_b.p, (size_t)32 << ext_k, g_ctx->stream);
+}
+int sg_extended_to_coeff_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream) {
+  if (!d_ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_extended_to_coeff: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(ext_k, &dc));
+  TRY(sync_own_stream_into(pick_stream(stream)));
+  // undo the coset: a[i] *= zeta^-(i mod 3) = {1, zeta^2, zeta}; the 2^-ext_k divisor rides along
+  fp_t post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
+  fp_t* a = static_cast<fp_t*>(d_ext);
+  return ntt_dev(a, (size_t)1 << ext_k, a, ext_k, dc->omega_inv, nullptr, nullptr, post, pick_stream(stream));
+}
+int sg_extended_to_coeff(uint8_t* ext, uint32_t k, uint32_t ext_k) {
+  if (!ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_extended_to_coeff: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(ext_k, &dc));
+  const size_t bytes = (size_t)32 << ext_k;
+  TRY(upload(g_ctx->stage_a, ext, bytes, g_ctx->stream));
+  fp_t post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
+  fp_t* a = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  TRY(ntt_dev(a, (size_t)1 << ext_k, a, ext_k, dc->omega_inv, nullptr, nullptr, post, g_ctx->stream));
+  return download(ext, a, bytes, g_ctx->stream);
+}
+
+static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_t** out) {
+  Context& c = *g_ctx;
+  uint64_t key = ((uint64_t)k << 32) | ext_k;
+  auto it = c.t_evals.find(key);
+  if (it == c.t_evals.end()) {
+    const DomainConsts* dc;
+    TRY(get_consts(ext_k, &dc));
+    uint32_t cnt = 1u << (ext_k - k);
+    fp_t* d = nullptr;
+    CHECK_HIP(hipMalloc(&d, sizeof(fp_t) * cnt), "t_evaluations");
+    t_eval_kernel<<<(cnt + 63) / 64, 64, 0, c.stream>>>(k, ext_k, dc->omega, d);
+    CHECK_HIP(hipStreamSynchronize(c.stream), "t_evaluations");
+    it = c.t_evals.emplace(key, d).first;
+  }
+  *out = it->second;
+  return SG_OK;
+}
+int sg_divide_by_vanishing_poly_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream) {
+  if (!d_ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_divide_by_vanishing_poly: bad argument");
+  LOCKED_CTX();
+  const fp_t* tab;
+  TRY(t_eval_table(k, ext_k, &tab));
+  hipError_t e = ntt_scale_periodic(static_cast<fp_t*>(d_ext), tab, 1u << (ext_k - k), (size_t)1 << ext_k,
+                                    pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("divide_by_vanishing_poly", e);
+  return SG_OK;
+}
+int sg_divide_by_vanishing_poly(uint8_t* ext, uint32_t k, uint32_t ext_k) {
+  if (!ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_divide_by_vanishing_poly: bad argument");
+  LOCKED_CTX();
+  const fp_t* tab;
+  TRY(t_eval_table(k, ext_k, &tab));
+  const size_t bytes = (size_t)32 << ext_k;
+  TRY(upload(g_ctx->stage_a, ext, bytes, g_ctx->stream));
+  hipError_t e = ntt_scale_periodic(reinterpret_cast<fp_t*>(g_ctx->stage_a.p), tab, 1u << (ext_k - k),
+                                    (size_t)1 << ext_k, g_ctx->stream);
+  if (e != hipSuccess) return hip_fail("divide_by_vanishing_poly", e);
+  return download(ext, g_ctx->stage_a.p, bytes, g_ctx->stream);
+}
+
+int sg_domain_constant(uint32_t k, int which, uint8_t out[32]) {
+  if (!out || k > 28 || which < 0 || which > 3) return fail(SG_ERR_INVALID, "sg_domain_constant: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(k, &dc));
+  const fp_t* src = which == 0 ? &dc->omega : which == 1 ? &dc->omega_inv : which == 2 ? &dc->n_inv : &dc->zeta;
+  std::memcpy(out, src, 32);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ misc
+int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, void* stream) {
+  if (n && (!d_scalars || !d_out_affine)) return fail(SG_ERR_INVALID, "sg_g1_fixed_base_mul: null argument");
+  LOCKED_CTX();
+  hipError_t e = fixed_base_mul(static_cast<const fp_t*>(d_scalars), n, static_cast<g1_affine*>(d_out_affine),
+                                pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fixed_base_mul", e);
+  return SG_OK;
+}
+int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) {
+  if (n && (!scalars || !out_affine)) return fail(SG_ERR_INVALID, "sg_g1_fixed_base_mul: null argument");
+  LOCKED_CTX();
+  TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
+  hipError_t e = g_ctx->stage_b.reserve(n * 64 + 64);
+  if (e != hipSuccess) return hip_fail("staging buffer", e);
+  e = fixed_base_mul(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p), n, reinterpret_cast<g1_affine*>(g_ctx->stage_b.p),
+                     g_ctx->stream);
+  if (e != hipSuccess) return hip_fail("fixed_base_mul", e);
+  if (!n) return SG_OK;
+  return download(out_affine, g_ctx->stage_b.p, n * 64, g_ctx->stream);
+}
+int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
+  if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
+  LOCKED_CTX();
+  hipError_t e = fr_montgomery(static_cast<const fp_t*>(d_in), static_cast<fp_t*>(d_out), n, 1, pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fr_to_montgomery", e);
+  return SG_OK;
+}
+int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
+  if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
+  LOCKED_CTX();
+  hipError_t e = fr_montgomery(static_cast<const fp_t*>(d_in), static_cast<fp_t*>(d_out), n, 0, pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fr_from_montgomery", e);
+  return SG_OK;
+}
+
+int sg_set_param(const char* name, int value) {
+  if (!name || value < 0) return fail(SG_ERR_INVALID, "sg_set_param: bad argument");
+  LOCKED_CTX();
+  std::string s(name);
+  if (s == "msm.window_bits") g_ctx->msm.config().window_bits = (uint32_t)value;
+  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = (uint32_t)std::max(1, std::min(12, value));
+  else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = (uint32_t)std::min(8, value);
+  else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
+  else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));
+  else if (s == "ntt.max_single_log") { g_ctx->ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); g_ctx->ntt.clear(); }
+  else if (s == "ntt.max_multi_log") { g_ctx->ntt.config().max_multi_log = (uint32_t)std::max(4, std::min(12, value)); g_ctx->ntt.clear(); }
+  else return fail(SG_ERR_INVALID, "sg_set_param: unknown parameter");
+  return SG_OK;
+}
+
+int sg_time_ntt_dev(void* d_a, uint32_t log_n, int reps, float* ms_out) {
+  if (!d_a || !ms_out || reps < 1 || log_n > 28) return fail(SG_ERR_INVALID, "sg_time_ntt_dev: bad argument");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(log_n, &dc));
+  fp_t* a = static_cast<fp_t*>(d_a);
+  hipStream_t s = g_ctx->stream;
+  TRY(ntt_dev(a, (size_t)1 << log_n, a, log_n, dc->omega, nullptr, nullptr, nullptr, s));  // warm plan + caches
+  hipEvent_t e0, e1;
+  CHECK_HIP(hipEventCreate(&e0), "event");
+  CHECK_HIP(hipEventCreate(&e1), "event");
+  CHECK_HIP(hipEventRecord(e0, s), "event");
+  for (int r = 0; r < reps; r++) TRY(ntt_dev(a, (size_t)1 << log_n, a, log_n, dc->omega, nullptr, nullptr, nullptr, s));
+  CHECK_HIP(hipEventRecord(e1, s), "event");
+  CHECK_HIP(hipEventSynchronize(e1), "event");
+  float ms = 0;
+  CHECK_HIP(hipEventElapsedTime(&ms, e0, e1), "event");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_out = ms / reps;
+  return SG_OK;
+}
+
+}  // extern "C"

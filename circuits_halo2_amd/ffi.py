@@ -1,0 +1,89 @@
+"""ctypes binding of libsumma_gpu.so (C ABI: include/summa_gpu.h).
+
+This is the binding a maintainer of the reference would write in Rust; the
+Python flavour exists because this pipeline has no Rust toolchain.  Loading fails loudly if
+the library is missing -- there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SG_OK = 0
+EXPORTS = [
+    "sg_init", "sg_shutdown", "sg_last_error", "sg_device_count", "sg_version",
+    "sg_msm_g1", "sg_msm_g1_dev", "sg_srs_upload", "sg_srs_free", "sg_commit", "sg_commit_dev",
+    "sg_srs_device_ptrs", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_intt_fr", "sg_intt_fr_dev",
+    "sg_lagrange_to_coeff", "sg_lagrange_to_coeff_dev", "sg_coeff_to_extended", "sg_coeff_to_extended_dev",
+    "sg_extended_to_coeff", "sg_extended_to_coeff_dev", "sg_divide_by_vanishing_poly",
+    "sg_divide_by_vanishing_poly_dev", "sg_domain_constant", "sg_g1_fixed_base_mul", "sg_g1_fixed_base_mul_dev",
+    "sg_fr_to_montgomery_dev", "sg_fr_from_montgomery_dev", "sg_msm_g1_dev_timed", "sg_set_param", "sg_time_ntt_dev",
+]
+
+
+class SummaGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"summa_gpu error {code}: {msg}")
+        self.code = code
+
+
+class MsmTimings(C.Structure):
+    _fields_ = [("digits_ms", C.c_float), ("sort_ms", C.c_float), ("accumulate_ms", C.c_float),
+                ("reduce_ms", C.c_float), ("total_ms", C.c_float), ("window_bits", C.c_uint32),
+                ("windows", C.c_uint32), ("tasks", C.c_uint32), ("max_bucket", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libsumma_gpu.so")
+
+
+def lib():
+    """Load the HIP library (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise SummaGpuError(-2, f"{path} not built: run `make -C circuits_halo2_amd/csrc` "
+                                    "(there is no CPU fallback for the MSM/NTT path)")
+        L = C.CDLL(path)
+        L.sg_last_error.restype = C.c_char_p
+        L.sg_version.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)  # fail now if a declared symbol is missing
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int):
+    if rc != SG_OK:
+        raise SummaGpuError(rc, lib().sg_last_error().decode())
+
+
+def u8(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8:
+        a = a.view(np.uint8)
+    return a.reshape(-1)
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dev_ptr(t):
+    """torch CUDA tensor -> raw device pointer"""
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,91 @@
+"""Mirror of `halo2_proofs::poly::kzg::commitment::ParamsKZG<Bn256>` for the methods the
+reference calls (zk_prover/src/circuits/utils.rs:55 read, :58-66 k()/downsize, :70 setup) and
+the two commitment methods every MSM of the prover goes through (commit, commit_lagrange).
+
+SRS container layout (halo2 `SerdeFormat::RawBytes`):
+    k:u32 LE || g[2^k] || g_lagrange[2^k] || g2 || s_g2      (G1 64 B, G2 128 B, Montgomery)
+The bases are uploaded once and stay resident in HBM (handle in the C ABI's SRS cache).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import ffi
+from .arithmetic import _is_torch_cuda, g1_fixed_base_mul
+
+
+class ParamsKZG:
+    def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2: bytes = b"", s_g2: bytes = b""):
+        self.k = k
+        self.n = 1 << k
+        self.g = ffi.u8(g)
+        self.g_lagrange = ffi.u8(g_lagrange)
+        if self.g.size != 64 * self.n or self.g_lagrange.size != 64 * self.n:
+            raise ValueError("ParamsKZG: basis length != 2^k")
+        self.g2, self.s_g2 = g2, s_g2
+        self._handle = None
+
+    # --- construction -------------------------------------------------------------------
+    @classmethod
+    def read(cls, reader) -> "ParamsKZG":
+        """ParamsKZG::read (RawBytes).  `reader`: bytes or a binary file object."""
+        raw = reader if isinstance(reader, (bytes, bytearray)) else reader.read()
+        if len(raw) < 4:
+            raise ValueError("Failed to read params")
+        (k,) = struct.unpack_from("<I", raw, 0)
+        n = 1 << k
+        if k > 28 or len(raw) != 4 + 2 * n * 64 + 256:
+            raise ValueError("Failed to read params")
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        return cls(k, buf[4:4 + 64 * n].copy(), buf[4 + 64 * n:4 + 128 * n].copy(),
+                   bytes(raw[4 + 128 * n:4 + 128 * n + 128]), bytes(raw[4 + 128 * n + 128:]))
+
+    @classmethod
+    def setup_from_tau_powers(cls, k: int, tau_powers_mont: np.ndarray, lagrange_evals_mont: np.ndarray):
+        """ParamsKZG::setup's group part: g[i] = tau^i * G, g_lagrange[i] = L_i(tau) * G, both
+        as fixed-base products on the GPU (the scalar side -- powers of tau and L_i(tau) -- is
+        supplied by the caller)."""
+        return cls(k, g1_fixed_base_mul(tau_powers_mont), g1_fixed_base_mul(lagrange_evals_mont))
+
+    # --- device cache -------------------------------------------------------------------
+    def handle(self) -> int:
+        if self._handle is None:
+            h = C.c_uint64(0)
+            ffi.check(ffi.lib().sg_srs_upload(C.c_uint32(self.k), ffi.ptr(self.g), ffi.ptr(self.g_lagrange),
+                                              C.byref(h)))
+            self._handle = h.value
+        return self._handle
+
+    def free(self):
+        if self._handle is not None:
+            ffi.check(ffi.lib().sg_srs_free(C.c_uint64(self._handle)))
+            self._handle = None
+
+    # --- commitments --------------------------------------------------------------------
+    def _commit(self, basis: int, poly):
+        L = ffi.lib()
+        out = np.zeros(64, dtype=np.uint8)
+        if _is_torch_cuda(poly):
+            n = poly.numel() // 32
+            if n > self.n:
+                raise ValueError("polynomial longer than the SRS")
+            ffi.check(L.sg_commit_dev(C.c_uint64(self.handle()), C.c_int(basis), ffi.dev_ptr(poly), C.c_size_t(n),
+                                      ffi.current_stream_ptr(), ffi.ptr(out)))
+            return out
+        s = ffi.u8(poly)
+        if s.size % 32 or s.size // 32 > self.n:
+            raise ValueError("polynomial longer than the SRS")
+        ffi.check(L.sg_commit(C.c_uint64(self.handle()), C.c_int(basis), ffi.ptr(s), C.c_size_t(s.size // 32),
+                              ffi.ptr(out)))
+        return out
+
+    def commit(self, poly):
+        """commit to a polynomial in coefficient form: best_multiexp(poly, g)"""
+        return self._commit(0, poly)
+
+    def commit_lagrange(self, poly):
+        """commit to a polynomial in Lagrange form: best_multiexp(poly, g_lagrange)"""
+        return self._commit(1, poly)

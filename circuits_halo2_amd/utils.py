@@ -1,0 +1,63 @@
+"""Host-side helpers: seeded synthetic inputs and byte-layout utilities.
+Nothing here computes the MSM/NTT path."""
+from __future__ import annotations
+
+import numpy as np
+
+R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_R_LIMBS = np.array([(R_MODULUS >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+DEFAULT_SEED = 0x53554D4D41  # "SUMMA"
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _splitmix_block(start_state: int, count: int) -> np.ndarray:
+    """outputs 1..count of SplitMix64 started at start_state (vectorised)"""
+    with np.errstate(over="ignore"):
+        s = np.uint64(start_state & 0xFFFFFFFFFFFFFFFF) + _GOLD * np.arange(1, count + 1, dtype=np.uint64)
+        z = (s ^ (s >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _lt_r(limbs: np.ndarray) -> np.ndarray:
+    """limbs: (n,4) uint64 LE -> bool mask value < r"""
+    lt = np.zeros(limbs.shape[0], dtype=bool)
+    eq = np.ones(limbs.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        lt |= eq & (limbs[:, i] < _R_LIMBS[i])
+        eq &= limbs[:, i] == _R_LIMBS[i]
+    return lt
+
+
+def random_fr_canonical(seed: int, n: int) -> np.ndarray:
+    """n uniform values in [0, r) as canonical 32-B little-endian integers (numpy uint8,
+    length 32 n).  Same stream rule as the oracle's generators (oracle/pyref.py::random_fr)."""
+    limbs = _splitmix_block(seed, 4 * n).reshape(n, 4).copy()
+    limbs[:, 3] &= np.uint64((1 << 62) - 1)
+    bad = np.nonzero(~_lt_r(limbs))[0]
+    for i in bad:  # ~24 % of candidates; each retried from its own stream
+        j = 0
+        while True:
+            w = _splitmix_block(((seed ^ (int(i) + 1)) + (j << 32)) & 0xFFFFFFFFFFFFFFFF, 4)
+            w[3] &= np.uint64((1 << 62) - 1)
+            if _lt_r(w.reshape(1, 4))[0]:
+                limbs[i] = w
+                break
+            j += 1
+    return limbs.view(np.uint8).reshape(-1)
+
+
+def to_montgomery_host(canon: np.ndarray) -> np.ndarray:
+    """canonical -> Montgomery with Python integers (small inputs / CPU-only tests)."""
+    out = bytearray(canon.size)
+    raw = canon.tobytes()
+    for i in range(0, len(raw), 32):
+        v = (int.from_bytes(raw[i:i + 32], "little") << 256) % R_MODULUS
+        out[i:i + 32] = v.to_bytes(32, "little")
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+def ints_to_fr(values) -> np.ndarray:
+    """list of Python ints -> Montgomery Fr buffer"""
+    return np.frombuffer(b"".join(((v % R_MODULUS) << 256).__mod__(R_MODULUS).to_bytes(32, "little") for v in values),
+                         dtype=np.uint8).copy()

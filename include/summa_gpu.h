@@ -1,0 +1,136 @@
+/*
+ * summa_gpu.h -- C ABI of the MI355X (gfx950) back-end for the Halo2/KZG hot path of
+ * summa-dev/circuits-halo2's zk_prover: BN254 G1 multi-scalar multiplication and BN254 Fr
+ * radix-2 NTT/iNTT.
+ *
+ * What it replaces.  The reference reaches this arithmetic only through
+ *   zk_prover/src/circuits/utils.rs:75-76   keygen_vk / keygen_pk
+ *   zk_prover/src/circuits/utils.rs:94-101  create_proof (full_prover)
+ *   zk_prover/src/circuits/utils.rs:171-178 create_proof (create_proof_checked)
+ *   zk_prover/src/circuits/utils.rs:55,64,70 ParamsKZG::{read, downsize, setup}
+ * and the code itself lives in the un-vendored crates halo2_proofs 0.2.0
+ * (summa-dev/halo2#8386d6e) and halo2curves 0.1.0 (zk_prover/Cargo.lock:2223-2276).  The seam
+ * is two free functions of `halo2_proofs::arithmetic` plus the `EvaluationDomain` /
+ * `ParamsKZG` methods built on them; each entry point below names the one it stands in for.
+ * INTEGRATION.md shows the Rust-side binding (extern "C" block + [patch] of halo2_proofs).
+ *
+ * Data conventions (identical to halo2curves' in-memory layout, so `&[Fr]` / `&[G1Affine]`
+ * are passed as raw pointers with zero copies or conversions):
+ *   Fr        32 bytes: 4 x u64 little-endian limbs, Montgomery form (x * 2^256 mod r)
+ *   G1Affine  64 bytes: x || y, each a Montgomery Fq as above; identity = 64 zero bytes
+ * All results are fully reduced and, for points, affine-normalised, hence canonical and
+ * bit-comparable with the CPU prover's.
+ *
+ * Conventions: every function returns SG_OK (0) or a negative sg_status; nothing throws or
+ * aborts; pointers are borrowed for the duration of the call; the library is thread-safe
+ * (calls from several host threads are serialised per device context).  "host" entry points
+ * take host pointers and move data themselves; "_dev" entry points take HIP device pointers
+ * (e.g. torch tensors' data_ptr()) and a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef SUMMA_GPU_H
+#define SUMMA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SG_OK = 0,
+  SG_ERR_INVALID = -1,   /* bad argument (null pointer, size/length mismatch, k out of range) */
+  SG_ERR_NO_DEVICE = -2, /* no usable HIP device / sg_init not called */
+  SG_ERR_HIP = -3,       /* a HIP runtime call failed; see sg_last_error() */
+  SG_ERR_NOMEM = -4      /* device or host allocation failed */
+} sg_status;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Binds the calling process to one GPU (one process per GPU is the intended deployment;
+ * under torch.distributed pass LOCAL_RANK).  Idempotent for the same device. */
+int sg_init(int device);
+void sg_shutdown(void);
+/* Message of the last failure on the calling thread (static storage, never NULL). */
+const char* sg_last_error(void);
+/* Number of HIP devices visible (0 when there is none; never fails). */
+int sg_device_count(void);
+/* "summa_gpu <version> gfx950" */
+const char* sg_version(void);
+
+/* ---- M1: halo2_proofs::arithmetic::best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1
+ * (reached via ParamsKZG::commit / commit_lagrange).  upstream asserts
+ * coeffs.len() == bases.len(); here a single n covers both.  n = 0 yields the identity. */
+int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]);
+int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]);
+
+/* SRS cache: keeps ParamsKZG's g[] / g_lagrange[] resident in HBM across proofs
+ * (the reference re-reads the file per Snapshot: backend/src/apis/round.rs:136-145). */
+int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint64_t* handle_out);
+int sg_srs_free(uint64_t handle);
+/* ParamsKZG::commit (basis = 0, monomial g[]) / commit_lagrange (basis = 1): n <= 2^k scalars */
+int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]);
+int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
+                  uint8_t out_affine[64]);
+/* Device pointers of a cached SRS (for callers that drive the *_dev entry points). */
+int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k);
+
+/* ---- N1: halo2_proofs::arithmetic::best_fft(a: &mut [Fr], omega: Fr, log_n: u32)
+ * in place, natural order in and out: A[j] = sum_i a[i] * omega^(i*j). */
+int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n);
+int sg_ntt_fr_dev(void* d_a, const uint8_t omega[32], uint32_t log_n, void* stream);
+
+/* ---- N2: EvaluationDomain::ifft(a, omega_inv, log_n, divisor): best_fft with omega_inv,
+ * then every element times `divisor` (n^-1 for lagrange_to_coeff). */
+int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n);
+int sg_intt_fr_dev(void* d_a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n, void* stream);
+/* EvaluationDomain::lagrange_to_coeff with the domain's own constants for 2^k. */
+int sg_lagrange_to_coeff(uint8_t* a, uint32_t k);
+int sg_lagrange_to_coeff_dev(void* d_a, uint32_t k, void* stream);
+
+/* ---- N3: EvaluationDomain::coeff_to_extended: coeffs[2^k] -> out[2^ext_k]
+ * (a[i] *= zeta^(i mod 3), zero-pad, best_fft with omega_ext); fused into one transform. */
+int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint8_t* out);
+int sg_coeff_to_extended_dev(const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out, void* stream);
+
+/* ---- N4: EvaluationDomain::extended_to_coeff: in place over 2^ext_k elements (iNTT with
+ * omega_ext^-1 and 2^-ext_k, then a[i] *= zeta^-(i mod 3)); the caller truncates to
+ * n * quotient_poly_degree as halo2 does.  divide_by_vanishing_poly multiplies element i by
+ * t_evaluations[i mod 2^(ext_k-k)] = 1/((zeta*omega_ext^i)^n - 1). */
+int sg_extended_to_coeff(uint8_t* ext, uint32_t k, uint32_t ext_k);
+int sg_extended_to_coeff_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream);
+int sg_divide_by_vanishing_poly(uint8_t* ext, uint32_t k, uint32_t ext_k);
+int sg_divide_by_vanishing_poly_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream);
+
+/* ---- domain constants (EvaluationDomain::new): omega = ROOT_OF_UNITY^(2^(28-k)) etc.
+ * which: 0 omega, 1 omega^-1, 2 (2^k)^-1, 3 zeta (Fr::ZETA, the extended-coset shift). */
+int sg_domain_constant(uint32_t k, int which, uint8_t out[32]);
+
+/* ---- row S: ParamsKZG::setup's fixed-base products out[i] = scalars[i] * G1::generator()
+ * (affine); also used to synthesise bases for benchmarks. */
+int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine);
+int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, void* stream);
+
+/* ---- helpers: Fr canonical <-> Montgomery (PrimeField::from_repr / to_repr in bulk) */
+int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
+int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
+
+/* ---- tuning / introspection (not part of the reference seam) */
+typedef struct {
+  float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream */
+  uint32_t window_bits, windows, tasks, max_bucket;
+} sg_msm_timings;
+/* as sg_msm_g1_dev, additionally fills per-phase HIP event timings */
+int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64],
+                        sg_msm_timings* timings);
+/* name: "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "ntt.tile_log", "ntt.threads",
+ * "ntt.max_single_log", "ntt.max_multi_log" */
+int sg_set_param(const char* name, int value);
+/* Time `reps` back-to-back launches of the operation with HIP events on the library's
+ * stream; returns average milliseconds per launch in *ms_out (used by bench.py for the
+ * roofline block). op: 0 = ntt (d_a in place, forward with the domain omega of log_n). */
+int sg_time_ntt_dev(void* d_a, uint32_t log_n, int reps, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMMA_GPU_H */

@@ -1,0 +1,664 @@
+/*
+ * bn254_oracle.c -- CPU restatement of the BN254 MSM / NTT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker / the timed CPU
+ * baseline ("port"). The product path (circuits_halo2_amd/csrc) never links or calls it.
+ *
+ * Where the algorithm comes from: the reference (summa-dev/circuits-halo2) only CALLS the
+ * arithmetic (zk_prover/src/circuits/utils.rs:55,64,70,75,76,94-101,171-178); the code
+ * lives in un-vendored crates halo2_proofs 0.2.0 @ summa-dev/halo2#8386d6e and
+ * halo2curves 0.1.0 (zk_prover/Cargo.lock:2223-2276), absent from /root/reference.
+ * This file restates their published algorithms:
+ *   T1/T2  4x64-bit-limb Montgomery Fq/Fr, G1 affine 64 B / Jacobian
+ *   M1     best_multiexp: per-thread contiguous chunks, each multiexp_serial with window
+ *          c = 1 (n<4), 3 (n<32), ceil(ln n); 256/c+1 segments high->low, unsigned digits,
+ *          zero digits skipped, running-sum bucket reduction; chunk results summed
+ *   N1     best_fft: bit-reverse permutation, twiddle table, radix-2 DIT; threaded as a
+ *          depth-first recursive split
+ *   N2-N4  EvaluationDomain::{ifft, coeff_to_extended, extended_to_coeff,
+ *          divide_by_vanishing_poly}
+ * Parity pin: pinned against the reference's own artefacts -- SRS file
+ * backend/ptau/hermez-raw-11 (K1,K3) and contracts/src/InclusionVerifier.sol:217-271
+ * (K2 fixed_comms[4], K4 omega/omega_inv/n_inv) -- by tests/test_oracle_golden.py, and
+ * against the independent big-integer twin oracle/pyref.py.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+typedef struct { u64 l[4]; } fe;            /* field element, Montgomery form, LE limbs */
+typedef struct { u64 p[4]; u64 inv; fe r1; fe r2; } field_t;
+
+/* moduli, R mod p, R^2 mod p, -p^-1 mod 2^64 */
+static const field_t FQ = {
+    {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    0x87d20782e4866389ULL,
+    {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}},
+    {{0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}}};
+static const field_t FR = {
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    0xc2e1f593efffffffULL,
+    {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}},
+    {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}}};
+
+/* ---------------------------------------------------------------- field arithmetic */
+static inline int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe *a, const fe *b) {
+    return ((a->l[0] ^ b->l[0]) | (a->l[1] ^ b->l[1]) | (a->l[2] ^ b->l[2]) | (a->l[3] ^ b->l[3])) == 0;
+}
+static inline int geq_p(const u64 a[4], const u64 p[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > p[i]) return 1;
+        if (a[i] < p[i]) return 0;
+    }
+    return 1;
+}
+static inline void sub_p(u64 a[4], const u64 p[4]) {
+    u128 b = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - p[i] - (u64)b;
+        a[i] = (u64)d;
+        b = (d >> 64) & 1;
+    }
+}
+static inline void fe_add(const field_t *F, fe *o, const fe *a, const fe *b) {
+    u128 c = 0;
+    u64 t[4];
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a->l[i] + b->l[i];
+        t[i] = (u64)c;
+        c >>= 64;
+    }
+    /* p < 2^254 so no carry out of 256 bits */
+    if (geq_p(t, F->p)) sub_p(t, F->p);
+    memcpy(o->l, t, 32);
+}
+static inline void fe_sub(const field_t *F, fe *o, const fe *a, const fe *b) {
+    u64 t[4];
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - (u64)br;
+        t[i] = (u64)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)t[i] + F->p[i];
+            t[i] = (u64)c;
+            c >>= 64;
+        }
+    }
+    memcpy(o->l, t, 32);
+}
+static inline void fe_neg(const field_t *F, fe *o, const fe *a) {
+    fe z = {{0, 0, 0, 0}};
+    fe_sub(F, o, &z, a);
+}
+static inline void fe_dbl(const field_t *F, fe *o, const fe *a) { fe_add(F, o, a, a); }
+
+/* Montgomery product a*b*2^-256 mod p, CIOS over 4 64-bit limbs */
+static inline void fe_mul(const field_t *F, fe *o, const fe *a, const fe *b) {
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a->l[j] * b->l[i] + t[j];
+            t[j] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (u64)c;
+        t[5] = (u64)(c >> 64);
+        u64 m = t[0] * F->inv;
+        c = (u128)m * F->p[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * F->p[j] + t[j];
+            t[j - 1] = (u64)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (u64)c;
+        t[4] = t[5] + (u64)(c >> 64);
+    }
+    if (t[4] || geq_p(t, F->p)) sub_p(t, F->p);
+    memcpy(o->l, t, 32);
+}
+static inline void fe_sqr(const field_t *F, fe *o, const fe *a) { fe_mul(F, o, a, a); }
+static void fe_to_mont(const field_t *F, fe *o, const fe *canon) { fe_mul(F, o, canon, &F->r2); }
+static void fe_from_mont(const field_t *F, fe *o, const fe *m) {
+    fe one = {{1, 0, 0, 0}};
+    fe_mul(F, o, m, &one);
+}
+/* x^e, e given as 4 LE limbs (plain integer) */
+static void fe_pow(const field_t *F, fe *o, const fe *x, const u64 e[4]) {
+    fe acc = F->r1;
+    for (int i = 255; i >= 0; i--) {
+        fe_sqr(F, &acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fe_mul(F, &acc, &acc, x);
+    }
+    *o = acc;
+}
+static void fe_inv(const field_t *F, fe *o, const fe *x) {
+    u64 e[4] = {F->p[0] - 2, F->p[1], F->p[2], F->p[3]}; /* p[0] >= 2, no borrow */
+    fe_pow(F, o, x, e);
+}
+
+/* ---------------------------------------------------------------- G1 (y^2 = x^3 + 3) */
+typedef struct { fe x, y; } g1a;        /* affine; identity = (0,0) */
+typedef struct { fe x, y, z; } g1j;     /* Jacobian; identity: z == 0 */
+
+static inline int g1a_is_id(const g1a *p) { return fe_is_zero(&p->x) && fe_is_zero(&p->y); }
+static inline void g1j_set_id(g1j *p) { memset(p, 0, sizeof *p); p->x = FQ.r1; p->y = FQ.r1; }
+static inline int g1j_is_id(const g1j *p) { return fe_is_zero(&p->z); }
+
+static void g1j_double(g1j *o, const g1j *p) {
+    if (g1j_is_id(p)) { *o = *p; return; }
+    const field_t *F = &FQ;
+    fe a, b, c, d, e, f, t, x3, y3, z3;
+    fe_sqr(F, &a, &p->x);
+    fe_sqr(F, &b, &p->y);
+    fe_sqr(F, &c, &b);
+    fe_add(F, &t, &p->x, &b);
+    fe_sqr(F, &t, &t);
+    fe_sub(F, &t, &t, &a);
+    fe_sub(F, &t, &t, &c);
+    fe_dbl(F, &d, &t);
+    fe_dbl(F, &e, &a);
+    fe_add(F, &e, &e, &a);
+    fe_sqr(F, &f, &e);
+    fe_dbl(F, &t, &d);
+    fe_sub(F, &x3, &f, &t);
+    fe_sub(F, &t, &d, &x3);
+    fe_mul(F, &y3, &e, &t);
+    fe_dbl(F, &t, &c);
+    fe_dbl(F, &t, &t);
+    fe_dbl(F, &t, &t);
+    fe_sub(F, &y3, &y3, &t);
+    fe_mul(F, &z3, &p->y, &p->z);
+    fe_dbl(F, &z3, &z3);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+/* o = p + q (q affine), all corner cases */
+static void g1j_add_affine(g1j *o, const g1j *p, const g1a *q) {
+    const field_t *F = &FQ;
+    if (g1a_is_id(q)) { *o = *p; return; }
+    if (g1j_is_id(p)) { o->x = q->x; o->y = q->y; o->z = F->r1; return; }
+    fe z1z1, u2, s2, h, hh, hhh, r, v, t, x3, y3, z3;
+    fe_sqr(F, &z1z1, &p->z);
+    fe_mul(F, &u2, &q->x, &z1z1);
+    fe_mul(F, &s2, &q->y, &p->z);
+    fe_mul(F, &s2, &s2, &z1z1);
+    if (fe_eq(&u2, &p->x)) {
+        if (fe_eq(&s2, &p->y)) { g1j_double(o, p); return; }
+        g1j_set_id(o);
+        return;
+    }
+    fe_sub(F, &h, &u2, &p->x);
+    fe_sqr(F, &hh, &h);
+    fe_mul(F, &hhh, &h, &hh);
+    fe_sub(F, &r, &s2, &p->y);
+    fe_mul(F, &v, &p->x, &hh);
+    fe_sqr(F, &x3, &r);
+    fe_sub(F, &x3, &x3, &hhh);
+    fe_dbl(F, &t, &v);
+    fe_sub(F, &x3, &x3, &t);
+    fe_sub(F, &t, &v, &x3);
+    fe_mul(F, &y3, &r, &t);
+    fe_mul(F, &t, &p->y, &hhh);
+    fe_sub(F, &y3, &y3, &t);
+    fe_mul(F, &z3, &p->z, &h);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+/* o = p + q, both Jacobian */
+static void g1j_add(g1j *o, const g1j *p, const g1j *q) {
+    const field_t *F = &FQ;
+    if (g1j_is_id(q)) { *o = *p; return; }
+    if (g1j_is_id(p)) { *o = *q; return; }
+    fe z1z1, z2z2, u1, u2, s1, s2, h, hh, hhh, r, v, t, x3, y3, z3;
+    fe_sqr(F, &z1z1, &p->z);
+    fe_sqr(F, &z2z2, &q->z);
+    fe_mul(F, &u1, &p->x, &z2z2);
+    fe_mul(F, &u2, &q->x, &z1z1);
+    fe_mul(F, &s1, &p->y, &q->z);
+    fe_mul(F, &s1, &s1, &z2z2);
+    fe_mul(F, &s2, &q->y, &p->z);
+    fe_mul(F, &s2, &s2, &z1z1);
+    if (fe_eq(&u1, &u2)) {
+        if (fe_eq(&s1, &s2)) { g1j_double(o, p); return; }
+        g1j_set_id(o);
+        return;
+    }
+    fe_sub(F, &h, &u2, &u1);
+    fe_sqr(F, &hh, &h);
+    fe_mul(F, &hhh, &h, &hh);
+    fe_sub(F, &r, &s2, &s1);
+    fe_mul(F, &v, &u1, &hh);
+    fe_sqr(F, &x3, &r);
+    fe_sub(F, &x3, &x3, &hhh);
+    fe_dbl(F, &t, &v);
+    fe_sub(F, &x3, &x3, &t);
+    fe_sub(F, &t, &v, &x3);
+    fe_mul(F, &y3, &r, &t);
+    fe_mul(F, &t, &s1, &hhh);
+    fe_sub(F, &y3, &y3, &t);
+    fe_mul(F, &z3, &p->z, &q->z);
+    fe_mul(F, &z3, &z3, &h);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+static void g1j_to_affine(g1a *o, const g1j *p) {
+    if (g1j_is_id(p)) { memset(o, 0, sizeof *o); return; }
+    const field_t *F = &FQ;
+    fe zi, zi2, zi3;
+    fe_inv(F, &zi, &p->z);
+    fe_sqr(F, &zi2, &zi);
+    fe_mul(F, &zi3, &zi2, &zi);
+    fe_mul(F, &o->x, &p->x, &zi2);
+    fe_mul(F, &o->y, &p->y, &zi3);
+}
+
+/* ---------------------------------------------------------------- M1: best_multiexp */
+static inline unsigned get_digit(const u64 canon[4], unsigned seg, unsigned c) {
+    unsigned skip = seg * c;
+    if (skip >= 256) return 0;
+    unsigned limb = skip >> 6, off = skip & 63;
+    u64 v = canon[limb] >> off;
+    if (off + c > 64 && limb < 3) v |= canon[limb + 1] << (64 - off);
+    return (unsigned)(v & ((1ULL << c) - 1));
+}
+static unsigned window_for(size_t n) {
+    if (n < 4) return 1;
+    if (n < 32) return 3;
+    return (unsigned)ceil(log((double)n));
+}
+static void multiexp_serial(const fe *canon, const g1a *bases, size_t n, g1j *acc) {
+    unsigned c = window_for(n);
+    unsigned segments = 256 / c + 1;
+    size_t nb = ((size_t)1 << c) - 1;
+    g1j *buckets = (g1j *)malloc(nb * sizeof(g1j));
+    for (int seg = (int)segments - 1; seg >= 0; seg--) {
+        for (unsigned i = 0; i < c; i++) g1j_double(acc, acc);
+        for (size_t b = 0; b < nb; b++) g1j_set_id(&buckets[b]);
+        for (size_t i = 0; i < n; i++) {
+            unsigned d = get_digit(canon[i].l, (unsigned)seg, c);
+            if (d) g1j_add_affine(&buckets[d - 1], &buckets[d - 1], &bases[i]);
+        }
+        g1j running;
+        g1j_set_id(&running);
+        for (size_t b = nb; b-- > 0;) {
+            g1j_add(&running, &running, &buckets[b]);
+            g1j_add(acc, acc, &running);
+        }
+    }
+    free(buckets);
+}
+typedef struct { const fe *canon; const g1a *bases; size_t n; g1j acc; } msm_job;
+static void *msm_worker(void *arg) {
+    msm_job *j = (msm_job *)arg;
+    multiexp_serial(j->canon, j->bases, j->n, &j->acc);
+    return NULL;
+}
+/* scalars: n x 32 B Fr Montgomery; bases: n x 64 B affine Montgomery; out: affine 64 B */
+int orc_best_multiexp(const uint8_t *scalars, const uint8_t *bases, size_t n, int threads,
+                      uint8_t out_affine[64]) {
+    if (threads < 1) threads = 1;
+    fe *canon = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    for (size_t i = 0; i < n; i++) fe_from_mont(&FR, &canon[i], (const fe *)(scalars + 32 * i));
+    const g1a *pts = (const g1a *)bases;
+    g1j total;
+    g1j_set_id(&total);
+    if (n > (size_t)threads && threads > 1) {
+        size_t chunk = n / (size_t)threads;
+        size_t nchunks = (n + chunk - 1) / chunk;
+        msm_job *jobs = (msm_job *)calloc(nchunks, sizeof(msm_job));
+        pthread_t *tid = (pthread_t *)calloc(nchunks, sizeof(pthread_t));
+        for (size_t k = 0; k < nchunks; k++) {
+            size_t s = k * chunk, e = s + chunk > n ? n : s + chunk;
+            jobs[k].canon = canon + s; jobs[k].bases = pts + s; jobs[k].n = e - s;
+            g1j_set_id(&jobs[k].acc);
+            pthread_create(&tid[k], NULL, msm_worker, &jobs[k]);
+        }
+        for (size_t k = 0; k < nchunks; k++) {
+            pthread_join(tid[k], NULL);
+            g1j_add(&total, &total, &jobs[k].acc);
+        }
+        free(jobs); free(tid);
+    } else {
+        multiexp_serial(canon, pts, n, &total);
+    }
+    free(canon);
+    g1j_to_affine((g1a *)out_affine, &total);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- N1: best_fft */
+static inline u64 bitrev64(u64 x, unsigned bits) {
+    u64 r = 0;
+    for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+typedef struct { fe *a; size_t n; size_t tchunk; const fe *tw; int depth; } fft_job;
+static void butterfly_combine(fe *a, size_t n, size_t tchunk, const fe *tw) {
+    size_t half = n / 2;
+    fe *l = a, *r = a + half;
+    fe t = r[0];
+    fe_sub(&FR, &r[0], &l[0], &t);
+    fe_add(&FR, &l[0], &l[0], &t);
+    for (size_t i = 1; i < half; i++) {
+        fe_mul(&FR, &t, &r[i], &tw[i * tchunk]);
+        fe_sub(&FR, &r[i], &l[i], &t);
+        fe_add(&FR, &l[i], &l[i], &t);
+    }
+}
+static void *fft_rec(void *arg) {
+    fft_job *j = (fft_job *)arg;
+    if (j->n == 2) {
+        fe t = j->a[1];
+        fe_sub(&FR, &j->a[1], &j->a[0], &t);
+        fe_add(&FR, &j->a[0], &j->a[0], &t);
+        return NULL;
+    }
+    fft_job L = {j->a, j->n / 2, j->tchunk * 2, j->tw, j->depth - 1};
+    fft_job Rj = {j->a + j->n / 2, j->n / 2, j->tchunk * 2, j->tw, j->depth - 1};
+    if (j->depth > 0) {
+        pthread_t t;
+        pthread_create(&t, NULL, fft_rec, &L);
+        fft_rec(&Rj);
+        pthread_join(t, NULL);
+    } else {
+        fft_rec(&L);
+        fft_rec(&Rj);
+    }
+    butterfly_combine(j->a, j->n, j->tchunk, j->tw);
+    return NULL;
+}
+static void best_fft_fe(fe *a, const fe *omega, unsigned log_n, int threads) {
+    size_t n = (size_t)1 << log_n;
+    if (log_n == 0) return;
+    for (size_t k = 0; k < n; k++) {
+        size_t rk = bitrev64(k, log_n);
+        if (k < rk) { fe t = a[k]; a[k] = a[rk]; a[rk] = t; }
+    }
+    fe *tw = (fe *)malloc((n / 2 ? n / 2 : 1) * sizeof(fe));
+    tw[0] = FR.r1;
+    for (size_t i = 1; i < n / 2; i++) fe_mul(&FR, &tw[i], &tw[i - 1], omega);
+    int depth = 0;
+    while ((1 << (depth + 1)) <= threads) depth++;
+    if ((unsigned)depth > log_n - 1) depth = (int)log_n - 1;
+    fft_job j = {a, n, 1, tw, depth};
+    fft_rec(&j);
+    free(tw);
+}
+void orc_best_fft(uint8_t *a, const uint8_t omega[32], uint32_t log_n, int threads) {
+    fe w;
+    memcpy(&w, omega, 32);
+    best_fft_fe((fe *)a, &w, log_n, threads);
+}
+
+/* ---------------------------------------------------------------- domain constants */
+static const u64 ROOT_CANON[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL,
+                                  0x03ddb9f5166d18b7ULL}; /* 2^28-th root of unity */
+static const u64 ZETA_CANON[4] = {0xb8ca0b2d36636f23ULL, 0xcc37a73fec2bc5e9ULL, 0x048b6e193fd84104ULL,
+                                  0x30644e72e131a029ULL}; /* Fr::ZETA */
+static void fr_omega(unsigned k, fe *o) {
+    fe root;
+    fe c;
+    memcpy(c.l, ROOT_CANON, 32);
+    fe_to_mont(&FR, &root, &c);
+    for (unsigned i = k; i < 28; i++) fe_sqr(&FR, &root, &root);
+    *o = root;
+}
+void orc_omega(uint32_t k, uint8_t out[32]) { fe w; fr_omega(k, &w); memcpy(out, &w, 32); }
+void orc_omega_inv(uint32_t k, uint8_t out[32]) { fe w; fr_omega(k, &w); fe_inv(&FR, &w, &w); memcpy(out, &w, 32); }
+void orc_n_inv(uint32_t k, uint8_t out[32]) {
+    fe c = {{0, 0, 0, 0}}, m;
+    c.l[0] = 1ULL << k;
+    fe_to_mont(&FR, &m, &c);
+    fe_inv(&FR, &m, &m);
+    memcpy(out, &m, 32);
+}
+void orc_zeta(uint8_t out[32]) {
+    fe c, m;
+    memcpy(c.l, ZETA_CANON, 32);
+    fe_to_mont(&FR, &m, &c);
+    memcpy(out, &m, 32);
+}
+
+/* ---------------------------------------------------------------- N2-N4 */
+static void scale_all(fe *a, size_t n, const fe *f) {
+    for (size_t i = 0; i < n; i++) fe_mul(&FR, &a[i], &a[i], f);
+}
+/* EvaluationDomain::ifft: best_fft(omega_inv) then multiply by divisor */
+void orc_ifft(uint8_t *a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n,
+              int threads) {
+    fe w, d;
+    memcpy(&w, omega_inv, 32);
+    memcpy(&d, divisor, 32);
+    best_fft_fe((fe *)a, &w, log_n, threads);
+    scale_all((fe *)a, (size_t)1 << log_n, &d);
+}
+/* EvaluationDomain::lagrange_to_coeff with the domain's own constants */
+void orc_lagrange_to_coeff(uint8_t *a, uint32_t k, int threads) {
+    uint8_t wi[32], ni[32];
+    orc_omega_inv(k, wi);
+    orc_n_inv(k, ni);
+    orc_ifft(a, wi, ni, k, threads);
+}
+static void distribute_powers_zeta(fe *a, size_t n, int into_coset) {
+    fe z, z2, zc;
+    memcpy(zc.l, ZETA_CANON, 32);
+    fe_to_mont(&FR, &z, &zc);
+    fe_sqr(&FR, &z2, &z); /* zeta^2 = zeta^-1 */
+    const fe *p1 = into_coset ? &z : &z2, *p2 = into_coset ? &z2 : &z;
+    for (size_t i = 0; i < n; i++) {
+        size_t m = i % 3;
+        if (m == 1) fe_mul(&FR, &a[i], &a[i], p1);
+        else if (m == 2) fe_mul(&FR, &a[i], &a[i], p2);
+    }
+}
+/* coeffs: 2^k x 32 B -> out: 2^ext_k x 32 B */
+void orc_coeff_to_extended(const uint8_t *coeffs, uint32_t k, uint32_t ext_k, uint8_t *out, int threads) {
+    size_t n = (size_t)1 << k, en = (size_t)1 << ext_k;
+    memcpy(out, coeffs, n * 32);
+    memset(out + n * 32, 0, (en - n) * 32);
+    distribute_powers_zeta((fe *)out, n, 1);
+    fe w;
+    fr_omega(ext_k, &w);
+    best_fft_fe((fe *)out, &w, ext_k, threads);
+}
+/* 1/(X^n - 1) on the coset zeta*<omega_ext>: table of 2^(ext_k-k) entries */
+void orc_t_evaluations(uint32_t k, uint32_t ext_k, uint8_t *out) {
+    size_t t = (size_t)1 << (ext_k - k);
+    fe w, z, zc, cur;
+    fr_omega(ext_k, &w);
+    memcpy(zc.l, ZETA_CANON, 32);
+    fe_to_mont(&FR, &z, &zc);
+    cur = z;
+    for (size_t i = 0; i < t; i++) {
+        fe v = cur;
+        for (uint32_t s = 0; s < k; s++) fe_sqr(&FR, &v, &v); /* x^(2^k) */
+        fe_sub(&FR, &v, &v, &FR.r1);
+        fe_inv(&FR, &v, &v);
+        memcpy(out + 32 * i, &v, 32);
+        fe_mul(&FR, &cur, &cur, &w);
+    }
+}
+void orc_divide_by_vanishing_poly(uint8_t *ext, uint32_t k, uint32_t ext_k) {
+    size_t t = (size_t)1 << (ext_k - k), en = (size_t)1 << ext_k;
+    fe *tab = (fe *)malloc(t * sizeof(fe));
+    orc_t_evaluations(k, ext_k, (uint8_t *)tab);
+    fe *a = (fe *)ext;
+    for (size_t i = 0; i < en; i++) fe_mul(&FR, &a[i], &a[i], &tab[i % t]);
+    free(tab);
+}
+/* in place over 2^ext_k elements; caller truncates to n*quotient_degree */
+void orc_extended_to_coeff(uint8_t *ext, uint32_t k, uint32_t ext_k, int threads) {
+    (void)k;
+    orc_lagrange_to_coeff(ext, ext_k, threads);
+    distribute_powers_zeta((fe *)ext, (size_t)1 << ext_k, 0);
+}
+
+/* ---------------------------------------------------------------- helpers for tests */
+void orc_fr_mul(const uint8_t a[32], const uint8_t b[32], uint8_t o[32]) { fe r; fe_mul(&FR, &r, (const fe *)a, (const fe *)b); memcpy(o, &r, 32); }
+void orc_fq_mul(const uint8_t a[32], const uint8_t b[32], uint8_t o[32]) { fe r; fe_mul(&FQ, &r, (const fe *)a, (const fe *)b); memcpy(o, &r, 32); }
+void orc_fr_add(const uint8_t a[32], const uint8_t b[32], uint8_t o[32]) { fe r; fe_add(&FR, &r, (const fe *)a, (const fe *)b); memcpy(o, &r, 32); }
+void orc_fr_sub(const uint8_t a[32], const uint8_t b[32], uint8_t o[32]) { fe r; fe_sub(&FR, &r, (const fe *)a, (const fe *)b); memcpy(o, &r, 32); }
+void orc_fr_inv(const uint8_t a[32], uint8_t o[32]) { fe r; fe_inv(&FR, &r, (const fe *)a); memcpy(o, &r, 32); }
+void orc_fr_to_mont(const uint8_t canon[32], uint8_t o[32]) { fe r; fe_to_mont(&FR, &r, (const fe *)canon); memcpy(o, &r, 32); }
+void orc_fr_from_mont(const uint8_t m[32], uint8_t o[32]) { fe r; fe_from_mont(&FR, &r, (const fe *)m); memcpy(o, &r, 32); }
+void orc_fr_to_mont_n(const uint8_t *canon, size_t n, uint8_t *o) { for (size_t i = 0; i < n; i++) orc_fr_to_mont(canon + 32 * i, o + 32 * i); }
+void orc_fr_from_mont_n(const uint8_t *m, size_t n, uint8_t *o) { for (size_t i = 0; i < n; i++) orc_fr_from_mont(m + 32 * i, o + 32 * i); }
+
+/* pointwise a[i]*b[i] and dot product (known-answer checks for MSM on s_i*G bases) */
+void orc_fr_dot(const uint8_t *a, const uint8_t *b, size_t n, uint8_t o[32]) {
+    fe acc = {{0, 0, 0, 0}}, t;
+    for (size_t i = 0; i < n; i++) {
+        fe_mul(&FR, &t, (const fe *)(a + 32 * i), (const fe *)(b + 32 * i));
+        fe_add(&FR, &acc, &acc, &t);
+    }
+    memcpy(o, &acc, 32);
+}
+/* out[i] = tau^i (Montgomery) */
+void orc_fr_powers(const uint8_t tau[32], size_t n, uint8_t *out) {
+    fe cur = FR.r1, t;
+    memcpy(&t, tau, 32);
+    for (size_t i = 0; i < n; i++) { memcpy(out + 32 * i, &cur, 32); fe_mul(&FR, &cur, &cur, &t); }
+}
+/* Horner evaluation of sum coeffs[i] x^i */
+void orc_fr_eval_poly(const uint8_t *coeffs, size_t n, const uint8_t x[32], uint8_t o[32]) {
+    fe acc = {{0, 0, 0, 0}}, xx;
+    memcpy(&xx, x, 32);
+    for (size_t i = n; i-- > 0;) {
+        fe_mul(&FR, &acc, &acc, &xx);
+        fe_add(&FR, &acc, &acc, (const fe *)(coeffs + 32 * i));
+    }
+    memcpy(o, &acc, 32);
+}
+
+int orc_g1_is_on_curve(const uint8_t p[64]) {
+    const g1a *a = (const g1a *)p;
+    if (g1a_is_id(a)) return 1;
+    fe y2, x3, three, t;
+    fe c3 = {{3, 0, 0, 0}};
+    fe_to_mont(&FQ, &three, &c3);
+    fe_sqr(&FQ, &y2, &a->y);
+    fe_sqr(&FQ, &t, &a->x);
+    fe_mul(&FQ, &x3, &t, &a->x);
+    fe_add(&FQ, &x3, &x3, &three);
+    return fe_eq(&y2, &x3);
+}
+/* out = scalar * p (scalar Fr Montgomery), double-and-add */
+static void g1_mul_canon(g1j *o, const g1a *p, const fe *canon) {
+    g1j acc;
+    g1j_set_id(&acc);
+    for (int i = 255; i >= 0; i--) {
+        g1j_double(&acc, &acc);
+        if ((canon->l[i >> 6] >> (i & 63)) & 1) g1j_add_affine(&acc, &acc, p);
+    }
+    *o = acc;
+}
+void orc_g1_mul(const uint8_t p[64], const uint8_t scalar[32], uint8_t out[64]) {
+    fe c;
+    fe_from_mont(&FR, &c, (const fe *)scalar);
+    g1j r;
+    g1_mul_canon(&r, (const g1a *)p, &c);
+    g1j_to_affine((g1a *)out, &r);
+}
+void orc_g1_add(const uint8_t p[64], const uint8_t q[64], uint8_t out[64]) {
+    g1j r;
+    const g1a *pa = (const g1a *)p;
+    g1j_set_id(&r);
+    g1j_add_affine(&r, &r, pa);
+    g1j_add_affine(&r, &r, (const g1a *)q);
+    g1j_to_affine((g1a *)out, &r);
+}
+void orc_g1_generator(uint8_t out[64]) {
+    fe one = {{1, 0, 0, 0}}, two = {{2, 0, 0, 0}};
+    g1a g;
+    fe_to_mont(&FQ, &g.x, &one);
+    fe_to_mont(&FQ, &g.y, &two);
+    memcpy(out, &g, 64);
+}
+/* out[i] = scalars[i] * G (affine), 8-bit fixed-base windows, threaded; what
+ * ParamsKZG::setup does for g[] */
+typedef struct { const uint8_t *sc; uint8_t *out; size_t s, e; const g1a *table; } fb_job;
+static void *fb_worker(void *arg) {
+    fb_job *j = (fb_job *)arg;
+    for (size_t i = j->s; i < j->e; i++) {
+        fe c;
+        fe_from_mont(&FR, &c, (const fe *)(j->sc + 32 * i));
+        g1j acc;
+        g1j_set_id(&acc);
+        for (int w = 0; w < 32; w++) {
+            unsigned d = (unsigned)((c.l[w >> 3] >> ((w & 7) * 8)) & 0xff);
+            if (d) g1j_add_affine(&acc, &acc, &j->table[w * 256 + d]);
+        }
+        g1j_to_affine((g1a *)(j->out + 64 * i), &acc);
+    }
+    return NULL;
+}
+void orc_fixed_base_mul(const uint8_t *scalars, size_t n, int threads, uint8_t *out) {
+    g1a *table = (g1a *)malloc(32 * 256 * sizeof(g1a));
+    g1a gen;
+    orc_g1_generator((uint8_t *)&gen);
+    g1j base;
+    base.x = gen.x; base.y = gen.y; base.z = FQ.r1;
+    for (int w = 0; w < 32; w++) {
+        g1a ba;
+        g1j_to_affine(&ba, &base);
+        g1j acc;
+        g1j_set_id(&acc);
+        memset(&table[w * 256], 0, sizeof(g1a));
+        for (int d = 1; d < 256; d++) {
+            g1j_add_affine(&acc, &acc, &ba);
+            g1j_to_affine(&table[w * 256 + d], &acc);
+        }
+        for (int b = 0; b < 8; b++) g1j_double(&base, &base);
+    }
+    if (threads < 1) threads = 1;
+    fb_job *jobs = (fb_job *)calloc((size_t)threads, sizeof(fb_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; t++) {
+        size_t s = (size_t)t * per, e = s + per > n ? n : s + per;
+        if (s > n) s = n;
+        jobs[t] = (fb_job){scalars, out, s, e, table};
+        pthread_create(&tid[t], NULL, fb_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(jobs); free(tid); free(table);
+}
+
+/* ---------------------------------------------------------------- seeded inputs */
+static inline u64 splitmix_next(u64 *s) {
+    u64 z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+/* same rule as oracle/pyref.py::random_fr; output canonical -> Montgomery */
+void orc_random_fr(uint64_t seed, size_t n, uint8_t *out) {
+    u64 s = seed;
+    for (size_t i = 0; i < n; i++) {
+        fe c;
+        for (int j = 0; j < 4; j++) c.l[j] = splitmix_next(&s);
+        c.l[3] &= (1ULL << 62) - 1;
+        u64 jj = 0;
+        while (geq_p(c.l, FR.p)) {
+            u64 s2 = (seed ^ (u64)(i + 1)) + (jj << 32);
+            for (int j = 0; j < 4; j++) c.l[j] = splitmix_next(&s2);
+            c.l[3] &= (1ULL << 62) - 1;
+            jj++;
+        }
+        fe m;
+        fe_to_mont(&FR, &m, &c);
+        memcpy(out + 32 * i, &m, 32);
+    }
+}

@@ -1,0 +1,209 @@
+"""ctypes loader for oracle/liboracle.so (C restatement; test infrastructure only).
+
+All buffers are numpy uint8 arrays in the halo2curves in-memory layout: Fr = 32 B
+(4 x u64 LE limbs, Montgomery), G1Affine = 64 B (x||y Montgomery Fq, identity = zeros).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "bn254_oracle.c")
+    if force or not os.path.exists(so) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_best_multiexp.restype = C.c_int
+        _LIB.orc_g1_is_on_curve.restype = C.c_int
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _buf(nbytes: int) -> np.ndarray:
+    return np.zeros(nbytes, dtype=np.uint8)
+
+
+def ncpu() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def best_multiexp(scalars: np.ndarray, bases: np.ndarray, threads: int = 1) -> np.ndarray:
+    n = scalars.size // 32
+    assert bases.size == 64 * n
+    out = _buf(64)
+    lib().orc_best_multiexp(_p(scalars), _p(bases), C.c_size_t(n), C.c_int(threads), _p(out))
+    return out
+
+
+def best_fft(a: np.ndarray, omega: np.ndarray, log_n: int, threads: int = 1) -> np.ndarray:
+    out = np.ascontiguousarray(a).copy()
+    assert out.size == 32 << log_n
+    lib().orc_best_fft(_p(out), _p(omega), C.c_uint32(log_n), C.c_int(threads))
+    return out
+
+
+def lagrange_to_coeff(a: np.ndarray, k: int, threads: int = 1) -> np.ndarray:
+    out = np.ascontiguousarray(a).copy()
+    assert out.size == 32 << k
+    lib().orc_lagrange_to_coeff(_p(out), C.c_uint32(k), C.c_int(threads))
+    return out
+
+
+def ifft(a, omega_inv, divisor, log_n, threads=1):
+    out = np.ascontiguousarray(a).copy()
+    lib().orc_ifft(_p(out), _p(omega_inv), _p(divisor), C.c_uint32(log_n), C.c_int(threads))
+    return out
+
+
+def coeff_to_extended(coeffs: np.ndarray, k: int, ext_k: int, threads: int = 1) -> np.ndarray:
+    assert coeffs.size == 32 << k
+    out = _buf(32 << ext_k)
+    lib().orc_coeff_to_extended(_p(coeffs), C.c_uint32(k), C.c_uint32(ext_k), _p(out), C.c_int(threads))
+    return out
+
+
+def extended_to_coeff(ext: np.ndarray, k: int, ext_k: int, threads: int = 1) -> np.ndarray:
+    out = np.ascontiguousarray(ext).copy()
+    assert out.size == 32 << ext_k
+    lib().orc_extended_to_coeff(_p(out), C.c_uint32(k), C.c_uint32(ext_k), C.c_int(threads))
+    return out
+
+
+def divide_by_vanishing_poly(ext: np.ndarray, k: int, ext_k: int) -> np.ndarray:
+    out = np.ascontiguousarray(ext).copy()
+    lib().orc_divide_by_vanishing_poly(_p(out), C.c_uint32(k), C.c_uint32(ext_k))
+    return out
+
+
+def _const(fn, *args) -> np.ndarray:
+    out = _buf(32)
+    fn(*args, _p(out))
+    return out
+
+
+def omega(k: int) -> np.ndarray:
+    return _const(lib().orc_omega, C.c_uint32(k))
+
+
+def omega_inv(k: int) -> np.ndarray:
+    return _const(lib().orc_omega_inv, C.c_uint32(k))
+
+
+def n_inv(k: int) -> np.ndarray:
+    return _const(lib().orc_n_inv, C.c_uint32(k))
+
+
+def zeta() -> np.ndarray:
+    return _const(lib().orc_zeta)
+
+
+def _bin(fn, a, b, n_out=32):
+    out = _buf(n_out)
+    fn(_p(a), _p(b), _p(out))
+    return out
+
+
+def fr_mul(a, b):
+    return _bin(lib().orc_fr_mul, a, b)
+
+
+def fq_mul(a, b):
+    return _bin(lib().orc_fq_mul, a, b)
+
+
+def fr_add(a, b):
+    return _bin(lib().orc_fr_add, a, b)
+
+
+def fr_sub(a, b):
+    return _bin(lib().orc_fr_sub, a, b)
+
+
+def fr_inv(a):
+    out = _buf(32)
+    lib().orc_fr_inv(_p(a), _p(out))
+    return out
+
+
+def fr_to_mont(canon: np.ndarray) -> np.ndarray:
+    out = _buf(canon.size)
+    lib().orc_fr_to_mont_n(_p(canon), C.c_size_t(canon.size // 32), _p(out))
+    return out
+
+
+def fr_from_mont(m: np.ndarray) -> np.ndarray:
+    out = _buf(m.size)
+    lib().orc_fr_from_mont_n(_p(m), C.c_size_t(m.size // 32), _p(out))
+    return out
+
+
+def fr_dot(a, b) -> np.ndarray:
+    out = _buf(32)
+    lib().orc_fr_dot(_p(a), _p(b), C.c_size_t(a.size // 32), _p(out))
+    return out
+
+
+def fr_powers(tau: np.ndarray, n: int) -> np.ndarray:
+    out = _buf(32 * n)
+    lib().orc_fr_powers(_p(tau), C.c_size_t(n), _p(out))
+    return out
+
+
+def fr_eval_poly(coeffs, x) -> np.ndarray:
+    out = _buf(32)
+    lib().orc_fr_eval_poly(_p(coeffs), C.c_size_t(coeffs.size // 32), _p(x), _p(out))
+    return out
+
+
+def g1_is_on_curve(p) -> bool:
+    return bool(lib().orc_g1_is_on_curve(_p(np.ascontiguousarray(p))))
+
+
+def g1_mul(p, scalar) -> np.ndarray:
+    return _bin(lib().orc_g1_mul, np.ascontiguousarray(p), np.ascontiguousarray(scalar), 64)
+
+
+def g1_add(p, q) -> np.ndarray:
+    return _bin(lib().orc_g1_add, np.ascontiguousarray(p), np.ascontiguousarray(q), 64)
+
+
+def g1_generator() -> np.ndarray:
+    out = _buf(64)
+    lib().orc_g1_generator(_p(out))
+    return out
+
+
+def fixed_base_mul(scalars: np.ndarray, threads: int = 1) -> np.ndarray:
+    n = scalars.size // 32
+    out = _buf(64 * n)
+    lib().orc_fixed_base_mul(_p(scalars), C.c_size_t(n), C.c_int(threads), _p(out))
+    return out
+
+
+def random_fr(seed: int, n: int) -> np.ndarray:
+    out = _buf(32 * n)
+    lib().orc_random_fr(C.c_uint64(seed), C.c_size_t(n), _p(out))
+    return out

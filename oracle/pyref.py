@@ -1,0 +1,348 @@
+"""Pure-Python big-integer twin of the BN254 MSM / NTT hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it, and only as the checker.
+
+The arithmetic of the path lives in third-party crates that are NOT present under
+/root/reference (halo2_proofs 0.2.0 @ summa-dev/halo2#8386d6e, halo2curves 0.1.0;
+zk_prover/Cargo.lock:2223-2276).  This file restates their *published* algorithms
+ with Python integers, slowly and obviously,
+so that the C restatement (bn254_oracle.c) and the HIP kernels have an independent
+second implementation to be compared with.  It is pinned against the reference's own
+artefacts: the SRS file backend/ptau/hermez-raw-11 (K1, K3), the verifier-contract
+constants contracts/src/InclusionVerifier.sol:217-271 (K2, K4).
+
+Reference call sites of the path: zk_prover/src/circuits/utils.rs:55,64,70,75,76,94-101.
+"""
+from __future__ import annotations
+
+import struct
+
+# --- field / curve constants (contracts/src/InclusionVerifier.sol:209-210) -------------
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583  # base field
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # scalar field
+MONT = 1 << 256            # Montgomery radix of halo2curves' 4x64-bit limb representation
+B_COEFF = 3                # y^2 = x^3 + 3
+G1_GEN = (1, 2)
+S_ADICITY = 28
+# 2^28-th primitive root of unity of Fr (halo2curves `Fr::ROOT_OF_UNITY`; SURVEY.md K4,
+# cross-checked against omega(k=11) in InclusionVerifier.sol:220)
+ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+# cube root of unity used by halo2's EvaluationDomain as the extended-coset shift (`Fr::ZETA`)
+ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+MULT_GEN = 7
+DELTA = pow(MULT_GEN, 1 << S_ADICITY, R)
+
+
+def omega_for(k: int) -> int:
+    """Generator of the 2^k domain: ROOT_OF_UNITY^(2^(28-k)) (EvaluationDomain::new)."""
+    assert 0 <= k <= S_ADICITY
+    return pow(ROOT_OF_UNITY, 1 << (S_ADICITY - k), R)
+
+
+# --- byte codecs (4 x u64 little-endian limbs, Montgomery form) ---------
+def fr_to_bytes(x: int) -> bytes:
+    return ((x * MONT) % R).to_bytes(32, "little")
+
+
+def fr_from_bytes(b: bytes) -> int:
+    return (int.from_bytes(b, "little") * pow(MONT, -1, R)) % R
+
+
+def fq_to_bytes(x: int) -> bytes:
+    return ((x * MONT) % Q).to_bytes(32, "little")
+
+
+def fq_from_bytes(b: bytes) -> int:
+    return (int.from_bytes(b, "little") * pow(MONT, -1, Q)) % Q
+
+
+def g1_to_bytes(p) -> bytes:
+    """Affine point -> 64 B (x||y Montgomery); identity (None) -> 64 zero bytes."""
+    if p is None:
+        return bytes(64)
+    return fq_to_bytes(p[0]) + fq_to_bytes(p[1])
+
+
+def g1_from_bytes(b: bytes):
+    if b == bytes(64):
+        return None
+    return (fq_from_bytes(b[:32]), fq_from_bytes(b[32:64]))
+
+
+def frs_to_bytes(xs) -> bytes:
+    return b"".join(fr_to_bytes(x) for x in xs)
+
+
+def frs_from_bytes(b: bytes):
+    return [fr_from_bytes(b[i:i + 32]) for i in range(0, len(b), 32)]
+
+
+# --- G1 arithmetic (affine, None = identity) --------------------------------------------
+def g1_is_on_curve(p) -> bool:
+    if p is None:
+        return True
+    x, y = p
+    return (y * y - x * x * x - B_COEFF) % Q == 0
+
+
+def g1_neg(p):
+    return None if p is None else (p[0], (-p[1]) % Q)
+
+
+def g1_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    x1, y1 = p
+    x2, y2 = q
+    if x1 == x2:
+        if (y1 + y2) % Q == 0:
+            return None
+        lam = (3 * x1 * x1) * pow(2 * y1, -1, Q) % Q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+    x3 = (lam * lam - x1 - x2) % Q
+    y3 = (lam * (x1 - x3) - y1) % Q
+    return (x3, y3)
+
+
+# Jacobian helpers keep the pure-Python scalar multiplication tolerable.
+def _jac_double(P):
+    X, Y, Z = P
+    if Z == 0:
+        return P
+    A = X * X % Q
+    Bv = Y * Y % Q
+    C = Bv * Bv % Q
+    D = 2 * ((X + Bv) * (X + Bv) - A - C) % Q
+    E = 3 * A % Q
+    F = E * E % Q
+    X3 = (F - 2 * D) % Q
+    Y3 = (E * (D - X3) - 8 * C) % Q
+    Z3 = 2 * Y * Z % Q
+    return (X3, Y3, Z3)
+
+
+def _jac_add_affine(P, q):
+    if q is None:
+        return P
+    X1, Y1, Z1 = P
+    x2, y2 = q
+    if Z1 == 0:
+        return (x2, y2, 1)
+    Z1Z1 = Z1 * Z1 % Q
+    U2 = x2 * Z1Z1 % Q
+    S2 = y2 * Z1 % Q * Z1Z1 % Q
+    if U2 == X1:
+        if S2 == Y1:
+            return _jac_double(P)
+        return (1, 1, 0)
+    H = (U2 - X1) % Q
+    HH = H * H % Q
+    HHH = H * HH % Q
+    r = (S2 - Y1) % Q
+    V = X1 * HH % Q
+    X3 = (r * r - HHH - 2 * V) % Q
+    Y3 = (r * (V - X3) - Y1 * HHH) % Q
+    Z3 = Z1 * H % Q
+    return (X3, Y3, Z3)
+
+
+def _jac_to_affine(P):
+    X, Y, Z = P
+    if Z == 0:
+        return None
+    zi = pow(Z, -1, Q)
+    zi2 = zi * zi % Q
+    return (X * zi2 % Q, Y * zi2 % Q * zi % Q)
+
+
+def g1_mul(p, k: int):
+    """k*p by left-to-right double-and-add; k is reduced mod r first."""
+    k %= R
+    if p is None or k == 0:
+        return None
+    acc = (1, 1, 0)
+    for bit in bin(k)[2:]:
+        acc = _jac_double(acc)
+        if bit == "1":
+            acc = _jac_add_affine(acc, p)
+    return _jac_to_affine(acc)
+
+
+def msm_naive(scalars, points):
+    """Definition of best_multiexp (M1): sum_i s_i * P_i."""
+    assert len(scalars) == len(points)
+    acc = None
+    for s, p in zip(scalars, points):
+        acc = g1_add(acc, g1_mul(p, s))
+    return acc
+
+
+def msm_pippenger(scalars, points, c: int | None = None):
+    """Bucket method in the shape of halo2's multiexp_serial:
+    unsigned c-bit digits of the canonical scalar, windows high->low, zero digits skipped,
+    running-sum bucket reduction."""
+    n = len(scalars)
+    assert n == len(points)
+    if c is None:
+        if n < 4:
+            c = 1
+        elif n < 32:
+            c = 3
+        else:
+            import math
+            c = int(math.ceil(math.log(n)))
+    segments = 256 // c + 1
+    acc = (1, 1, 0)
+    for seg in reversed(range(segments)):
+        for _ in range(c):
+            acc = _jac_double(acc)
+        buckets = [(1, 1, 0)] * ((1 << c) - 1)
+        for s, p in zip(scalars, points):
+            d = ((s % R) >> (seg * c)) & ((1 << c) - 1)
+            if d:
+                buckets[d - 1] = _jac_add_affine(buckets[d - 1], p)
+        running = None
+        for b in reversed(buckets):
+            running = g1_add(running, _jac_to_affine(b))
+            acc_aff = g1_add(_jac_to_affine(acc), running)
+            acc = (1, 1, 0) if acc_aff is None else (acc_aff[0], acc_aff[1], 1)
+    return _jac_to_affine(acc)
+
+
+# --- SRS container (ParamsKZG::read, RawBytes) -----------------------------
+def parse_srs(raw: bytes):
+    """k:u32 LE || g[2^k] || g_lagrange[2^k] || g2 || s_g2  (G1 64 B, G2 128 B)."""
+    (k,) = struct.unpack_from("<I", raw, 0)
+    n = 1 << k
+    assert len(raw) == 4 + 2 * n * 64 + 2 * 128, "unexpected SRS length"
+    g = raw[4:4 + 64 * n]
+    gl = raw[4 + 64 * n:4 + 128 * n]
+    g2 = raw[4 + 128 * n:4 + 128 * n + 128]
+    s_g2 = raw[4 + 128 * n + 128:]
+    return {"k": k, "n": n, "g": g, "g_lagrange": gl, "g2": g2, "s_g2": s_g2}
+
+
+# --- NTT (best_fft, N1) and EvaluationDomain ops (N2-N4) ---------------------------------
+def bitrev(x: int, bits: int) -> int:
+    return int(bin(x)[2:].zfill(bits)[::-1], 2) if bits else 0
+
+
+def ntt(a, omega: int, log_n: int):
+    """Natural-order in/out forward DFT A[j] = sum_i a[i] omega^(ij) over Fr:
+    bit-reverse permutation, then iterative radix-2 DIT (the serial shape of best_fft)."""
+    n = 1 << log_n
+    assert len(a) == n
+    a = [x % R for x in a]
+    for k in range(n):
+        rk = bitrev(k, log_n)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    tw = [1] * max(n // 2, 1)
+    for i in range(1, n // 2):
+        tw[i] = tw[i - 1] * omega % R
+    chunk, tchunk = 2, n // 2
+    for _ in range(log_n):
+        half = chunk // 2
+        for s in range(0, n, chunk):
+            for i in range(half):
+                t = a[s + half + i] * tw[i * tchunk] % R
+                u = a[s + i]
+                a[s + i] = (u + t) % R
+                a[s + half + i] = (u - t) % R
+        chunk *= 2
+        tchunk //= 2
+    return a
+
+
+def dft_naive(a, omega: int):
+    n = len(a)
+    return [sum(a[i] * pow(omega, i * j, R) for i in range(n)) % R for j in range(n)]
+
+
+def intt(a, log_n: int):
+    """EvaluationDomain::lagrange_to_coeff / ifft (N2): best_fft with omega^-1, then * n^-1."""
+    w = omega_for(log_n)
+    out = ntt(a, pow(w, -1, R), log_n)
+    ninv = pow(1 << log_n, -1, R)
+    return [x * ninv % R for x in out]
+
+
+def coeff_to_extended(coeffs, k: int, ext_k: int):
+    """EvaluationDomain::coeff_to_extended (N3): a[i] *= zeta^(i mod 3); zero-pad to
+    2^ext_k; best_fft with omega_ext."""
+    n = 1 << k
+    assert len(coeffs) == n
+    zp = [1, ZETA, ZETA * ZETA % R]
+    a = [coeffs[i] * zp[i % 3] % R for i in range(n)] + [0] * ((1 << ext_k) - n)
+    return ntt(a, omega_for(ext_k), ext_k)
+
+
+def t_evaluations(k: int, ext_k: int):
+    """1/(X^n - 1) on the coset zeta*<omega_ext>: period 2^(ext_k-k) table."""
+    n = 1 << k
+    w = omega_for(ext_k)
+    out = []
+    for i in range(1 << (ext_k - k)):
+        x = ZETA * pow(w, i, R) % R
+        out.append(pow(pow(x, n, R) - 1, -1, R))
+    return out
+
+
+def divide_by_vanishing_poly(ext, k: int, ext_k: int):
+    t = t_evaluations(k, ext_k)
+    return [v * t[i % len(t)] % R for i, v in enumerate(ext)]
+
+
+def extended_to_coeff(ext, k: int, ext_k: int, quotient_degree: int | None = None):
+    """EvaluationDomain::extended_to_coeff (N4): iNTT over the extended domain, undo the
+    zeta powers (a[i] *= zeta^-(i mod 3)), truncate to n*(2^(ext_k-k) - ... ) per halo2:
+    n * quotient_poly_degree (5n for this circuit); default keeps everything."""
+    a = intt(ext, ext_k)
+    zi = pow(ZETA, -1, R)
+    zp = [1, zi, zi * zi % R]
+    a = [a[i] * zp[i % 3] % R for i in range(len(a))]
+    if quotient_degree is not None:
+        a = a[: (1 << k) * quotient_degree]
+    return a
+
+
+# --- seeded inputs -----------------------------------------
+MASK64 = (1 << 64) - 1
+DEFAULT_SEED = 0x53554D4D41  # "SUMMA"
+
+
+def splitmix64_stream(seed: int, count: int):
+    """count successive outputs of SplitMix64 started at `seed`."""
+    out = []
+    s = seed & MASK64
+    for _ in range(count):
+        s = (s + 0x9E3779B97F4A7C15) & MASK64
+        z = s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        out.append(z ^ (z >> 31))
+    return out
+
+
+def random_fr(seed: int, n: int):
+    """n uniform Fr values: element i is built from SplitMix64 outputs 4i..4i+3 of the
+    stream (limb 3 masked to 62 bits => 254-bit candidate) and accepted if < r; rejected
+    candidates are replaced from a second stream seeded with seed ^ (i+1) -- a fixed,
+    order-independent rule so numpy / C / Python generate identical vectors."""
+    words = splitmix64_stream(seed, 4 * n)
+    out = []
+    for i in range(n):
+        l = words[4 * i:4 * i + 4]
+        v = l[0] | (l[1] << 64) | (l[2] << 128) | ((l[3] & ((1 << 62) - 1)) << 192)
+        j = 0
+        while v >= R:
+            w = splitmix64_stream((seed ^ (i + 1)) + (j << 32), 4)
+            v = w[0] | (w[1] << 64) | (w[2] << 128) | ((w[3] & ((1 << 62) - 1)) << 192)
+            j += 1
+        out.append(v)
+    return out

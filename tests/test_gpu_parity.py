@@ -1,0 +1,335 @@
+"""GPU parity tests: every case calls the HIP path through the C ABI (libsumma_gpu.so via the
+Python mirror of halo2's interface) and compares bit-for-bit with the CPU oracle, the
+committed golden vectors, or a size-independent property.  Run on the MI355X box with
+`pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import fr_np, golden_bin, point_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import circuits_halo2_amd as sg
+    assert sg.lib().sg_device_count() >= 1
+    return sg
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def P():
+    from oracle import pyref
+    return pyref
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ----------------------------------------------------------------------------- NTT (N1)
+def test_ntt_golden_vectors(gpu, O, kat):
+    a = fr_np([int(x, 16) for x in kat["ntt_k4"]["in"]])
+    want = fr_np([int(x, 16) for x in kat["ntt_k4"]["out"]])
+    assert (gpu.best_fft(a, O.omega(4), 4) == want).all()
+    x, y = golden_bin("ntt_k11_in.bin"), golden_bin("ntt_k11_out.bin")
+    assert (gpu.best_fft(x, O.omega(11), 11) == y).all()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 16, 17, 18, 20])
+def test_ntt_matches_oracle(gpu, O, log_n):
+    a = O.random_fr(1000 + log_n, 1 << log_n)
+    w = O.omega(log_n)
+    want = O.best_fft(a, w, log_n, O.ncpu())
+    assert (gpu.best_fft(a, w, log_n) == want).all()
+    # device-resident entry point (in place on a torch tensor)
+    d = dev(a)
+    gpu.best_fft(d, w, log_n)
+    assert (d.cpu().numpy() == want).all()
+
+
+def test_ntt_three_pass_plan(gpu, O):
+    log_n = 21  # > 2 * max_multi_log: exercises the three-pass (six-step) factorisation
+    a = O.random_fr(77, 1 << log_n)
+    w = O.omega(log_n)
+    assert (gpu.best_fft(a, w, log_n) == O.best_fft(a, w, log_n, O.ncpu())).all()
+
+
+def test_ntt_arbitrary_root(gpu, O, P):
+    """best_fft takes any omega of the right order, not only the domain generator"""
+    log_n = 9
+    w = fr_np([pow(P.omega_for(log_n), 5, P.R)])
+    a = O.random_fr(5, 1 << log_n)
+    assert (gpu.best_fft(a, w, log_n) == O.best_fft(a, w, log_n, 2)).all()
+
+
+def test_ntt_closed_forms(gpu, O, P):
+    k, n = 13, 1 << 13
+    c = P.random_fr(1, 1)[0]
+    assert (gpu.best_fft(fr_np([c] + [0] * (n - 1)), O.omega(k), k) == fr_np([c] * n)).all()
+    assert (gpu.best_fft(fr_np([c] * n), O.omega(k), k) == fr_np([c * n % P.R] + [0] * (n - 1))).all()
+
+
+@pytest.mark.parametrize("log_n", [17, 22])
+def test_ntt_roundtrip_full_size(gpu, O, log_n):
+    """BASELINE config 3: iNTT(NTT(a)) == a bit-exactly, device resident"""
+    dom = gpu.EvaluationDomain(2, log_n)
+    a = O.random_fr(0x53554D4D42, 1 << log_n)
+    d = dev(a)
+    gpu.best_fft(d, dom.get_omega(), log_n)
+    fwd = d.cpu().numpy().copy()
+    assert not (fwd == a).all()
+    dom.lagrange_to_coeff(d)
+    assert (d.cpu().numpy() == a).all()
+    # spot-check the forward transform against direct evaluation at three points
+    for j in (0, 1, (1 << log_n) - 1):
+        x = O.fr_powers(dom.get_omega(), j + 1)[32 * j:32 * j + 32].copy()
+        assert (O.fr_eval_poly(a, x) == fwd[32 * j:32 * j + 32]).all()
+
+
+def test_ntt_linearity(gpu, O):
+    log_n = 15
+    a, b = O.random_fr(1, 1 << log_n), O.random_fr(2, 1 << log_n)
+    w = O.omega(log_n)
+    s = np.concatenate([O.fr_add(a[i:i + 32].copy(), b[i:i + 32].copy()) for i in range(0, 32 * 64, 32)])
+    fa, fb = gpu.best_fft(a, w, log_n), gpu.best_fft(b, w, log_n)
+    ab = a.copy()
+    for i in range(0, a.size, 32):
+        pass
+    # NTT(a) + NTT(b) == NTT(a + b) on the first 64 outputs needs the full sum; use the oracle
+    # only for the element-wise additions
+    import ctypes as C
+    tot = np.zeros_like(a)
+    lib = O.lib()
+    for i in range(0, a.size, 32):
+        lib.orc_fr_add(C.c_void_p(a.ctypes.data + i), C.c_void_p(b.ctypes.data + i), C.c_void_p(tot.ctypes.data + i))
+    fs = gpu.best_fft(tot, w, log_n)
+    chk = np.zeros(32 * 64, dtype=np.uint8)
+    for i in range(0, 32 * 64, 32):
+        lib.orc_fr_add(C.c_void_p(fa.ctypes.data + i), C.c_void_p(fb.ctypes.data + i), C.c_void_p(chk.ctypes.data + i))
+    assert (fs[:32 * 64] == chk).all()
+    del s, ab
+
+
+# ----------------------------------------------------------------------------- N2-N4
+@pytest.mark.parametrize("k", [1, 4, 9, 11, 12, 15])
+def test_lagrange_to_coeff(gpu, O, k):
+    a = O.random_fr(200 + k, 1 << k)
+    dom = gpu.EvaluationDomain(6, k)
+    want = O.lagrange_to_coeff(a, k, O.ncpu())
+    assert (dom.lagrange_to_coeff(a) == want).all()
+    assert (dom.get_omega() == O.omega(k)).all()
+    assert (dom.get_omega_inv() == O.omega_inv(k)).all()
+    assert (dom.ifft_divisor() == O.n_inv(k)).all()
+    # explicit-constant form: EvaluationDomain::ifft(a, omega_inv, log_n, divisor)
+    import ctypes as C
+    from circuits_halo2_amd import ffi
+    buf = a.copy()
+    ffi.check(ffi.lib().sg_intt_fr(ffi.ptr(buf), ffi.ptr(O.omega_inv(k)), ffi.ptr(O.n_inv(k)), C.c_uint32(k)))
+    assert (buf == want).all()
+
+
+def test_domain_golden_k11(gpu, kat, P):
+    dom = gpu.EvaluationDomain(6, 11)
+    assert dom.extended_k == 14 and dom.quotient_poly_degree == 5
+    assert P.fr_from_bytes(dom.get_omega().tobytes()) == int(kat["omega"], 16)
+    assert P.fr_from_bytes(dom.get_omega_inv().tobytes()) == int(kat["omega_inv"], 16)
+    assert P.fr_from_bytes(dom.ifft_divisor().tobytes()) == int(kat["n_inv"], 16)
+
+
+def test_extended_domain_golden(gpu, kat):
+    a = fr_np([int(x, 16) for x in kat["coeff_to_extended_k4_e7"]["in"]])
+    want = fr_np([int(x, 16) for x in kat["coeff_to_extended_k4_e7"]["out"]])
+    dom = gpu.EvaluationDomain(6, 4)
+    assert dom.extended_k == 7
+    assert (dom.coeff_to_extended(a) == want).all()
+    tev = [int(x, 16) for x in kat["t_evaluations_k4_e7"]]
+    ones = fr_np([1] * 128)
+    assert (dom.divide_by_vanishing_poly(ones) == fr_np([tev[i % 8] for i in range(128)])).all()
+
+
+@pytest.mark.parametrize("k", [3, 8, 11, 13, 17])
+def test_extended_domain_vs_oracle(gpu, O, k):
+    dom = gpu.EvaluationDomain(6, k)
+    ek = dom.extended_k
+    a = O.random_fr(300 + k, 1 << k)
+    want = O.coeff_to_extended(a, k, ek, O.ncpu())
+    got = dom.coeff_to_extended(a)
+    assert (got == want).all()
+    d = dom.coeff_to_extended(dev(a))
+    assert (d.cpu().numpy() == want).all()
+    assert (dom.divide_by_vanishing_poly(got) == O.divide_by_vanishing_poly(want, k, ek)).all()
+    back = dom.extended_to_coeff(got)
+    full = O.extended_to_coeff(want, k, ek, O.ncpu())
+    assert back.size == 32 * 5 * (1 << k)
+    assert (back == full[:back.size]).all()
+    assert (back[:a.size] == a).all() and not back[a.size:].any()
+    # a degree-5n polynomial survives the round trip through the extended domain
+    q = O.random_fr(400 + k, 5 << k)
+    qpad = np.concatenate([q, np.zeros((32 << ek) - q.size, dtype=np.uint8)])
+    ext = O.best_fft(_coset_scale(O, qpad), O.omega(ek), ek, O.ncpu())
+    assert (dom.extended_to_coeff(ext) == q).all()
+
+
+def _coset_scale(O, a):
+    import ctypes as C
+    out = a.copy()
+    z = O.zeta()
+    z2 = O.fr_mul(z, z)
+    lib = O.lib()
+    for i in range(0, a.size // 32):
+        m = i % 3
+        if m:
+            src = z if m == 1 else z2
+            lib.orc_fr_mul(C.c_void_p(out.ctypes.data + 32 * i), C.c_void_p(src.ctypes.data),
+                           C.c_void_p(out.ctypes.data + 32 * i))
+    return out
+
+
+# ----------------------------------------------------------------------------- MSM (M1)
+def test_msm_k2_fixed_comm4(gpu, srs11, kat):
+    want = point_np((int(kat["fixed_comms"][4][0], 16), int(kat["fixed_comms"][4][1], 16)))
+    assert (gpu.best_multiexp(fr_np(range(256)), srs11["gl_np"][:256 * 64]) == want).all()
+    params = gpu.ParamsKZG.read(open(__import__("os").path.join(__import__("conftest").GOLDEN, "hermez-raw-11"), "rb"))
+    assert params.k == 11
+    col = fr_np(list(range(256)) + [0] * (2048 - 256))
+    assert (params.commit_lagrange(col) == want).all()
+    assert (params.commit_lagrange(dev(col)) == want).all()
+    params.free()
+
+
+def test_msm_k3_srs_relations(gpu, O, P, srs11):
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    one = fr_np([1])
+    assert (params.commit_lagrange(O.fr_powers(one, 2048)) == srs11["g_np"][:64]).all()
+    for k in (1, 7):
+        wk = fr_np([pow(P.omega_for(11), k, P.R)])
+        assert (params.commit_lagrange(O.fr_powers(wk, 2048)) == srs11["g_np"][64 * k:64 * k + 64]).all()
+    dom = gpu.EvaluationDomain(6, 11)
+    for j in (0, 5, 2047):
+        e = [0] * 2048
+        e[j] = 1
+        assert (params.commit(dom.lagrange_to_coeff(fr_np(e))) == srs11["gl_np"][64 * j:64 * j + 64]).all()
+    params.free()
+
+
+def test_msm_tau_golden(gpu, kat):
+    sc, bases = golden_bin("msm_tau_k10_scalars.bin"), golden_bin("msm_tau_k10_bases.bin")
+    want = point_np(tuple(int(x, 16) for x in kat["msm_tau_k10"]["answer"]))
+    assert (gpu.best_multiexp(sc, bases) == want).all()
+    sp = fr_np([int(x, 16) for x in kat["msm_tau_k10_sparse"]["scalars"]])
+    want = point_np(tuple(int(x, 16) for x in kat["msm_tau_k10_sparse"]["answer"]))
+    assert (gpu.best_multiexp(sp, bases) == want).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 100, 1000, 1 << 12, 5000, 1 << 14, 1 << 16])
+def test_msm_matches_oracle(gpu, O, n):
+    sc = O.random_fr(500 + n, n)
+    bases = O.fixed_base_mul(O.random_fr(900 + n, n), O.ncpu())
+    want = O.best_multiexp(sc, bases, O.ncpu())
+    assert (gpu.best_multiexp(sc, bases) == want).all()
+    assert (gpu.best_multiexp(dev(sc), dev(bases)) == want).all()
+
+
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+def test_msm_window_sizes(gpu, O, c):
+    from circuits_halo2_amd import ffi
+    n = 3000
+    sc = O.random_fr(11, n)
+    bases = O.fixed_base_mul(O.random_fr(12, n), O.ncpu())
+    want = O.best_multiexp(sc, bases, O.ncpu())
+    ffi.check(ffi.lib().sg_set_param(b"msm.window_bits", c))
+    try:
+        assert (gpu.best_multiexp(sc, bases) == want).all()
+    finally:
+        ffi.check(ffi.lib().sg_set_param(b"msm.window_bits", 0))
+
+
+def test_msm_edge_cases(gpu, O, P, srs11):
+    gl = srs11["gl_np"]
+    ident = np.zeros(64, dtype=np.uint8)
+    assert (gpu.best_multiexp(np.zeros(0, np.uint8), np.zeros(0, np.uint8)) == ident).all()
+    assert (gpu.best_multiexp(fr_np([0] * 8), gl[:8 * 64]) == ident).all()
+    p = gl[:64]
+    pt = P.g1_from_bytes(p.tobytes())
+    negp = point_np(P.g1_neg(pt))
+    assert (gpu.best_multiexp(fr_np([1, 1]), np.concatenate([p, negp])) == ident).all()
+    assert (gpu.best_multiexp(fr_np([P.R - 1]), p) == negp).all()
+    assert (gpu.best_multiexp(fr_np([1, 1]), np.concatenate([p, p])) == point_np(P.g1_mul(pt, 2))).all()
+    assert (gpu.best_multiexp(fr_np([5, 1]), np.concatenate([ident, p])) == p).all()
+    # scalars at the top of the range and powers of two straddling window boundaries
+    vals = [P.R - 1, P.R - 2, (P.R - 1) // 2, 1 << 253, (1 << 128) - 1, 1 << 16, (1 << 16) - 1, 1 << 15, 65537, 2]
+    bases = gl[:64 * len(vals)]
+    assert (gpu.best_multiexp(fr_np(vals), bases) == O.best_multiexp(fr_np(vals), bases, 1)).all()
+    with pytest.raises(ValueError):
+        gpu.best_multiexp(fr_np([1, 2]), p)
+
+
+def test_msm_skewed_buckets(gpu, O, P, srs11):
+    """selector-like / sorted-lookup-like scalar vectors put most points in a few buckets:
+    heavy buckets are split into tasks and folded in merge rounds"""
+    from circuits_halo2_amd import ffi
+    p = srs11["gl_np"][:64]
+    pt = P.g1_from_bytes(p.tobytes())
+    n = 1 << 13
+    bases = O.fixed_base_mul(O.random_fr(21, n), O.ncpu())
+    ffi.check(ffi.lib().sg_set_param(b"msm.log_seg", 2))  # L = 4: forces several merge rounds
+    try:
+        assert (gpu.best_multiexp(fr_np([7] * 300), np.tile(p, 300)) == point_np(P.g1_mul(pt, 2100))).all()
+        ones = fr_np([1] * n)
+        assert (gpu.best_multiexp(ones, bases) == O.best_multiexp(ones, bases, O.ncpu())).all()
+        mixed = fr_np([(i % 3) + 1 if i % 5 else 0 for i in range(n)])
+        assert (gpu.best_multiexp(mixed, bases) == O.best_multiexp(mixed, bases, O.ncpu())).all()
+    finally:
+        ffi.check(ffi.lib().sg_set_param(b"msm.log_seg", 6))
+    ones = fr_np([1] * n)
+    assert (gpu.best_multiexp(ones, bases) == O.best_multiexp(ones, bases, O.ncpu())).all()
+    bytes_like = fr_np([(i * 37) % 256 for i in range(n)])  # range-check column shape
+    assert (gpu.best_multiexp(bytes_like, bases) == O.best_multiexp(bytes_like, bases, O.ncpu())).all()
+
+
+def test_fixed_base_mul(gpu, O):
+    from circuits_halo2_amd.arithmetic import g1_fixed_base_mul
+    sc = np.concatenate([O.random_fr(31, 200), fr_np([0, 1, 2])])
+    assert (g1_fixed_base_mul(sc) == O.fixed_base_mul(sc, 4)).all()
+
+
+@pytest.mark.parametrize("log_n", [17, 20])
+def test_msm_full_size_known_answer(gpu, O, log_n):
+    """BASELINE config 2: MSM over bases s_i*G must equal <k, s>*G (exact, independent of
+    the MSM algorithm); everything device resident."""
+    from circuits_halo2_amd.arithmetic import g1_fixed_base_mul, fr_to_montgomery
+    from circuits_halo2_amd.utils import random_fr_canonical
+    n = 1 << log_n
+    k = fr_to_montgomery(dev(random_fr_canonical(0x53554D4D41, n)))
+    s = fr_to_montgomery(dev(random_fr_canonical(0x7A55, n)))
+    bases = g1_fixed_base_mul(s)
+    got, tm = gpu.best_multiexp(k, bases, timings=True)
+    dot = O.fr_dot(k.cpu().numpy(), s.cpu().numpy())
+    assert (got == O.g1_mul(O.g1_generator(), dot)).all()
+    assert O.g1_is_on_curve(got)
+    print("msm timings", log_n, tm)
+    # witness-like scalars: 99 % zero, the rest below 2^64 (advice-column shape)
+    kk = k.cpu().numpy().reshape(n, 32).copy()
+    rng = np.random.default_rng(5)
+    keep = rng.random(n) < 0.01
+    kk[~keep] = 0
+    small = np.zeros((n, 32), dtype=np.uint8)
+    small[:, :8] = kk[:, :8]
+    small[~keep] = 0
+    from circuits_halo2_amd.utils import to_montgomery_host
+    idx = np.nonzero(keep)[0]
+    sm = np.zeros((n, 32), dtype=np.uint8)
+    sm[idx] = to_montgomery_host(small[idx].reshape(-1)).reshape(-1, 32)
+    got = gpu.best_multiexp(dev(sm.reshape(-1)), bases)
+    dot = O.fr_dot(sm[idx].reshape(-1).copy(), s.cpu().numpy().reshape(n, 32)[idx].reshape(-1).copy())
+    assert (got == O.g1_mul(O.g1_generator(), dot)).all()
