@@ -134,7 +134,9 @@ int get_consts(uint32_t k, const DomainConsts** out) {
   return SG_OK;
 }
 
-hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : g_ctx->stream; }
+// _dev entry points run on exactly the stream they are given (NULL = HIP's default stream,
+// which is what torch.cuda.current_stream() is unless the caller switched streams)
+hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // order the library's own stream work (plan/twiddle generation) before a caller stream
 int sync_own_stream_into(hipStream_t s) {
