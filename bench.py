@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): MSM-points/sec on the standalone BN254 G1 MSM of 2^20
+uniform scalars x synthetic-SRS points (configs[1]); one "step" = one such MSM per GPU with
+inputs resident in HBM.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
+the N shards form one N*2^20-point MSM: every rank reduces its shard, the 64-byte partial
+points are exchanged with one RCCL all_gather and summed (weak scaling, per-GPU work fixed).
+
+Also reported in the same JSON line: the NTT rates (configs[2]), the MSM+NTT kernel sum for
+the k=17 proof op list, `roofline` for the dominant kernel
+(msm_accumulate) and `cpu_baseline` (the oracle's restated halo2 best_multiexp on this box's
+host cores)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 20
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MSM_BYTES_PER_PAIR = 96        # 64 B point + 32 B scalar
+NTT_BYTES_PER_ELEM = 64        # 32 B read + 32 B write, one logical pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi
+    from circuits_halo2_amd.arithmetic import fr_to_montgomery, g1_fixed_base_mul
+    from circuits_halo2_amd.distributed import sharded_msm
+    from circuits_halo2_amd.utils import DEFAULT_SEED, random_fr_canonical
+    ffi.check(sg.lib().sg_init(local_rank))
+
+    n = 1 << args.log_n
+    # synthetic inputs, generated per rank from rank-dependent seeds, resident in HBM
+    scal = fr_to_montgomery(torch.from_numpy(random_fr_canonical(DEFAULT_SEED + rank, n)).cuda())
+    base_scal = fr_to_montgomery(torch.from_numpy(random_fr_canonical(0x7A55 + rank, n)).cuda())
+    bases = g1_fixed_base_mul(base_scal)  # s_i * G: valid, distinct curve points
+    torch.cuda.synchronize()
+
+    def step():
+        return sharded_msm(scal, bases)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    line = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * n * args.steps / dt
+        line = {
+            "metric": "msm_points_per_sec", "value": value, "unit": "points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
+            "data": "synthetic",
+            "config": {"workload": f"standalone BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x synthetic-SRS "
+                                   f"affine points per GPU (BASELINE configs[1])",
+                       "points_per_gpu": n, "sharding": "point-sharded, all_gather of 64-B partials" if world > 1 else "none"},
+        }
+        # ---- roofline of the dominant kernel (msm_accumulate), HIP events on its stream
+        _, tm = sg.best_multiexp(scal, bases, timings=True)
+        reps = [sg.best_multiexp(scal, bases, timings=True)[1] for _ in range(5)]
+        acc_ms = float(np.mean([r["accumulate_ms"] for r in reps]))
+        alg_bytes = MSM_BYTES_PER_PAIR * n
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
+        line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
+        line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
+                                 ("digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}
+        line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket")})
+        # integer-ALU view (MSM is VALU-bound): mixed adds * 10 products * ~560 VALU instr
+        adds = reps[0]["windows"] * n
+        line["alu"] = {"bucket_adds_per_launch": adds, "fq_mul_per_s": adds * 10 / (acc_ms * 1e-3),
+                       "note": "8M+2S XYZZ mixed add; see profiles/r01_microbench_instr_rates.txt for instruction peaks"}
+
+        if not args.no_extras:
+            line["ntt"] = {}
+            for lg in (17, 22):
+                a = fr_to_montgomery(torch.from_numpy(random_fr_canonical(DEFAULT_SEED + 100 + lg, 1 << lg)).cuda())
+                ms = C.c_float(0)
+                ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a), C.c_uint32(lg), 20, C.byref(ms)))
+                gbs = NTT_BYTES_PER_ELEM * (1 << lg) / (ms.value * 1e-3) / 1e9
+                line["ntt"][f"2^{lg}"] = {"ms": ms.value, "elements_per_s": (1 << lg) / (ms.value * 1e-3),
+                                          "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+                del a
+            # k = 17 proof op list: 16 MSM(2^17) + 9 iNTT(2^17) + 9 NTT(2^20) + 1 iNTT(2^20)
+            k = 17
+            s17, b17 = scal[: 32 << k], bases[: 64 << k]
+            sg.best_multiexp(s17, b17)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(16):
+                sg.best_multiexp(s17, b17)
+            torch.cuda.synchronize()
+            msm17 = (time.perf_counter() - t1) * 1e3
+            a20 = scal[: 32 << 20].clone()
+            ms20 = C.c_float(0)
+            ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a20), C.c_uint32(20), 10, C.byref(ms20)))
+            ntt_ms = 9 * line["ntt"]["2^17"]["ms"] + 10 * ms20.value
+            line["proof_oplist_k17"] = {"msm16x2^17_ms": msm17, "ntt_19_ms": ntt_ms, "sum_ms": msm17 + ntt_ms,
+                                        "rows_per_s": (1 << k) / ((msm17 + ntt_ms) * 1e-3),
+                                        "note": "MSM+NTT kernel sum only (evaluate_h etc. are §8f 'next' rows)"}
+
+        # ---- CPU baseline: the oracle's restated halo2 best_multiexp on this box's cores
+        if not args.no_cpu:
+            from oracle import oracle as O
+            cores = O.ncpu()
+            hs, hb = scal.cpu().numpy(), bases.cpu().numpy()
+            t1 = time.perf_counter()
+            ref = O.best_multiexp(hs, hb, cores)
+            cdt = time.perf_counter() - t1
+            ok = bool((ref == result).all()) if world == 1 else None
+            line["cpu_baseline"] = {"value": n / cdt, "unit": "points/s", "cores": cores, "kind": "port",
+                                    "sample": f"one full 2^{args.log_n} MSM on the same inputs ({cdt:.2f} s), "
+                                              f"halo2-shaped per-thread-chunked Pippenger (oracle/bn254_oracle.c)",
+                                    "matches_gpu_result": ok}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return line
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Multi-GPU sharding of the path: one process per GPU, torch.distributed.
+
+* op-level: independent MSMs/NTTs (the 16 + 19 of a proof, or whole proofs of a batch) are
+  dealt round-robin to ranks -- no data-path communication (`assign_ops`).
+* point-level: one large MSM is cut into contiguous shards; every rank reduces its shard and
+  the 64-byte affine partials are exchanged with ONE all_gather (EC addition is not an RCCL
+  reduction operator, so the "all-reduce" is all_gather + a local sum of world_size points,
+  done as an n = world_size MSM with unit scalars).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .arithmetic import best_multiexp
+
+# Montgomery form of 1 in Fr (R mod r), 32 bytes little-endian
+_ONE_FR = np.frombuffer((0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb).to_bytes(32, "little"),
+                        dtype=np.uint8)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def assign_ops(num_ops: int, rank: int | None = None, world: int | None = None):
+    """indices of the independent ops this rank owns (round-robin)"""
+    d = _dist()
+    if rank is None:
+        rank = d.get_rank() if d else 0
+    if world is None:
+        world = d.get_world_size() if d else 1
+    return list(range(rank, num_ops, world))
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """contiguous shard [lo, hi) of an n-point MSM for `rank`"""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def combine_partials(partials: np.ndarray, msm=best_multiexp) -> np.ndarray:
+    """sum of world_size affine points (64 B each) = MSM with unit scalars"""
+    m = partials.size // 64
+    return msm(np.tile(_ONE_FR, m), partials)
+
+
+def sharded_msm(local_scalars, local_bases, msm=best_multiexp) -> np.ndarray:
+    """sum over ALL ranks' shards of sum_i s_i P_i; every rank returns the same 64-byte point.
+    With no process group this is plain best_multiexp."""
+    part = msm(local_scalars, local_bases)
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return part
+    import torch
+    world = d.get_world_size()
+    dev = "cuda" if d.get_backend() == "nccl" else "cpu"
+    mine = torch.from_numpy(np.ascontiguousarray(part)).to(dev)
+    gathered = torch.empty(64 * world, dtype=torch.uint8, device=dev)
+    d.all_gather_into_tensor(gathered, mine)
+    return combine_partials(gathered.cpu().numpy(), msm)
