@@ -8,7 +8,7 @@ namespace sg {
 
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
-  uint32_t log_seg = 6;        // L = 64 entries per accumulation task
+  uint32_t log_seg = 8;        // L = 256 entries per accumulation task
   uint32_t log_red_chunk = 3;  // G = 8 buckets per thread in the bucket reduction
 };
 
@@ -51,7 +51,8 @@ class MsmEngine {
 
  private:
   MsmConfig cfg_;
-  DevBuf<uint32_t> keys_, sorted_, counts_, off_, ntask_[2], toff_[2], cursor_, meta_;
+  DevBuf<int16_t> dig_;
+  DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
   DevBuf<g1_xyzz> partial_[2], red_acc_[2], red_run_[2];
   uint32_t* h_meta_ = nullptr;
   g1_xyzz* h_win_ = nullptr;

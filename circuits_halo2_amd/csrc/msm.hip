@@ -5,20 +5,24 @@
 //   result = sum_i s_i * P_i,  s_i: 32-B Montgomery Fr, P_i: 64-B affine Montgomery points.
 //
 // Pipeline (all on one stream; one host read-back of three counters to size the launches):
-//   1 msm_digits     scalars -> canonical -> signed c-bit digits; one key per (window, scalar);
-//                    bucket histogram (zero digits are skipped, as in halo2)
-//   2 msm_scan       exclusive scans: bucket offsets and task offsets (a task = <= L
-//                    consecutive entries of one bucket, so heavy buckets are split)
-//   3 msm_scatter    counting sort of the point indices by (window, bucket)
-//   4 msm_accumulate one thread per task: XYZZ accumulator += affine points (8M+2S each)
-//     msm_merge      (only when a bucket had > L entries) same over partial sums
-//   5 msm_reduce     sum_b b*B_b per window: per-thread running sums over G buckets, then a
-//                    workgroup-wide suffix scan + tree reduction in LDS; repeated per level
-//   6 host           Horner over the W window sums (c doublings each) + affine normalisation
+//   1 msm_digits      scalars -> canonical -> W signed c-bit digits (int16 rows, one per window)
+//   2 msm_hist        LDS-staged window buckets: workgroup (chunk p, window j) histograms its
+//                     chunk's digits in LDS (2^(c-1) counters, up to 128 KiB); zero digits are
+//                     skipped, as in halo2
+//     msm_hist_prefix per-bucket prefix over chunks -> bucket counts
+//   3 msm_scan_*      exclusive scans: bucket offsets and task offsets (a task = <= L
+//                     consecutive entries of one bucket, so heavy buckets are split)
+//     msm_scatter     counting sort of the point indices by (window, bucket); slots are handed
+//                     out by LDS atomics on per-workgroup cursors (no global atomics anywhere)
+//   4 msm_accumulate  one thread per task: XYZZ accumulator += affine points (8M+2S each)
+//     msm_merge       (only when a bucket had > L entries) same over partial sums
+//   5 msm_reduce_*    sum_b b*B_b per window: per-thread running sums over G buckets, then a
+//                     workgroup-wide suffix scan + tree reduction in LDS; repeated per level
+//   6 host            Horner over the W window sums (c doublings each) + affine normalisation
 //
 // Signed digits halve the bucket count: digit d in [-2^(c-1), 2^(c-1)], bucket |d|, the point
 // is negated on the fly when d < 0.  The group law is commutative, so the order in which a
-// bucket's points are added (atomics make it non-deterministic) never changes the result bits.
+// bucket's points are added (LDS atomics make it non-deterministic) never changes the result bits.
 #include "msm.h"
 
 #include <algorithm>
@@ -29,93 +33,196 @@
 
 namespace sg {
 
-static constexpr uint32_t EMPTY_KEY = 0xffffffffu;
 
-// ------------------------------------------------------------------ 1: digits + histogram
+// ------------------------------------------------------------------ 1: signed digits
+// dig[j*n + i] = digit j of scalar i as int16: d in [-2^(c-1), 2^(c-1)) for j < W-1 and an
+// unsigned top digit.  Adding K = sum_{j<W-1} 2^(c-1) * 2^(jc) once makes every window's
+// digit independent of its neighbours: d_j = (((s + K) >> jc) & mask) - 2^(c-1).
 __global__ void msm_digits(const fp_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                           uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+                           int16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fp_t s = fp_from_mont<FrP>(fp_load(scalars + i));
   const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (uint32_t j = 0; j < W; j++) {
-    uint32_t v = (s.l[0] & mask) + carry;
-    // s >>= c
-#pragma unroll
-    for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
-    s.l[7] >>= c;
-    uint32_t key;
-    if (j + 1 < W && v > half) {
-      v = (1u << c) - v;  // |d| of the negative digit, in [0, half)
-      carry = 1;
-      key = v ? (0x80000000u | (j * half + v - 1)) : EMPTY_KEY;
-    } else {
-      carry = 0;
-      key = v ? (j * half + v - 1) : EMPTY_KEY;
+  // s += K (K < 2^255, s < 2^254: no overflow out of 256 bits)
+  {
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t j = 0; j + 1 < W; j++) {
+      uint32_t bit = j * c + c - 1;
+      k[bit >> 5] |= 1u << (bit & 31);
     }
-    keys[(size_t)j * n + i] = key;
-    if (key != EMPTY_KEY) atomicAdd(&counts[key & 0x7fffffffu], 1u);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      uint64_t t = (uint64_t)s.l[q] + k[q] + carry;
+      s.l[q] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+  }
+  for (uint32_t j = 0; j < W; j++) {
+    uint32_t v = s.l[0] & mask;
+#pragma unroll
+    for (int q = 0; q < 7; q++) s.l[q] = (s.l[q] >> c) | (s.l[q + 1] << (32 - c));
+    s.l[7] >>= c;
+    int32_t d = (j + 1 < W) ? (int32_t)v - (int32_t)half : (int32_t)v;
+    dig[(size_t)j * n + i] = (int16_t)d;
   }
 }
 
-// ------------------------------------------------------------------ 2: scans
-// One workgroup.  cnt[NB] -> off[NB+1] (exclusive scan, optional), ntask[b] = ceil(cnt/L),
-// toff[NB+1] (exclusive scan of ntask), meta = {sum cnt, sum ntask, max cnt}.
-__global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
-                                                 uint32_t* __restrict__ off, uint32_t* __restrict__ ntask,
-                                                 uint32_t* __restrict__ toff, uint32_t* __restrict__ meta) {
-  __shared__ uint32_t s_cnt[1024], s_tsk[1024], s_max[1024];
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-  const uint32_t per = (NB + nthr - 1) / nthr;
-  const uint32_t lo = min(tid * per, NB), hi = min(lo + per, NB);
-  const uint32_t Lm1 = (1u << log_L) - 1;
-  uint32_t a = 0, t = 0, m = 0;
-  for (uint32_t b = lo; b < hi; b++) {
-    uint32_t cval = cnt[b];
-    a += cval;
-    t += (cval + Lm1) >> log_L;
-    m = max(m, cval);
-  }
-  s_cnt[tid] = a; s_tsk[tid] = t; s_max[tid] = m;
+// ------------------------------------------------------------------ 2: LDS-staged histogram
+// grid (P, W): workgroup (p, j) counts the digits of scalar chunk p for window j in an LDS
+// histogram of 2^(c-1) buckets, then stores it to hist[(j*P + p)*nbw + b].
+__global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig, uint32_t n, uint32_t chunk,
+                                                 uint32_t nbw, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t s_cnt[];
+  const uint32_t p = blockIdx.x, j = blockIdx.y, P = gridDim.x;
+  for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cnt[b] = 0;
   __syncthreads();
-  // Hillis-Steele inclusive scan over the per-thread totals
-  for (uint32_t d = 1; d < nthr; d <<= 1) {
-    uint32_t va = 0, vt = 0, vm = 0;
-    if (tid >= d) { va = s_cnt[tid - d]; vt = s_tsk[tid - d]; vm = s_max[tid - d]; }
-    __syncthreads();
-    s_cnt[tid] += va; s_tsk[tid] += vt; s_max[tid] = max(s_max[tid], vm);
+  const uint32_t lo = p * chunk, hi = min(n, lo + chunk);
+  const int16_t* row = dig + (size_t)j * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int32_t d = row[i];
+    if (d) atomicAdd(&s_cnt[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = hist + ((size_t)j * P + p) * nbw;
+  for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) out[b] = s_cnt[b];
+}
+// per bucket: exclusive prefix over the P chunks (in place) and the bucket total
+__global__ void msm_hist_prefix(uint32_t* __restrict__ hist, uint32_t P, uint32_t nbw, uint32_t NB,
+                                uint32_t* __restrict__ counts) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // global bucket id = j*nbw + b
+  if (g >= NB) return;
+  uint32_t j = g / nbw, b = g - j * nbw;
+  uint32_t* col = hist + (size_t)j * P * nbw + b;
+  uint32_t run = 0;
+  for (uint32_t p = 0; p < P; p++) {
+    uint32_t v = col[(size_t)p * nbw];
+    col[(size_t)p * nbw] = run;
+    run += v;
+  }
+  counts[g] = run;
+}
+
+// ------------------------------------------------------------------ 3: scans (multi-block)
+// cnt[NB] -> off[NB+1] (exclusive scan, optional), ntask[b] = ceil(cnt[b]/L), toff[NB+1]
+// (exclusive scan of ntask), meta = {sum cnt, sum ntask, max cnt}.  2048 buckets per block.
+static constexpr uint32_t SCAN_ITEMS = 8, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+
+__global__ void __launch_bounds__(256) msm_scan_sums(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
+                                                     uint32_t* __restrict__ bsum, uint32_t* __restrict__ meta) {
+  __shared__ uint32_t s_a[SCAN_THREADS], s_t[SCAN_THREADS], s_m[SCAN_THREADS];
+  const uint32_t Lm1 = (1u << log_L) - 1;
+  uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+  uint32_t a = 0, t = 0, m = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    uint32_t v = (base + k < NB) ? cnt[base + k] : 0;
+    a += v;
+    t += (v + Lm1) >> log_L;
+    m = max(m, v);
+  }
+  s_a[threadIdx.x] = a; s_t[threadIdx.x] = t; s_m[threadIdx.x] = m;
+  __syncthreads();
+  for (uint32_t s = SCAN_THREADS / 2; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) {
+      s_a[threadIdx.x] += s_a[threadIdx.x + s];
+      s_t[threadIdx.x] += s_t[threadIdx.x + s];
+      s_m[threadIdx.x] = max(s_m[threadIdx.x], s_m[threadIdx.x + s]);
+    }
     __syncthreads();
   }
-  uint32_t base_a = s_cnt[tid] - a, base_t = s_tsk[tid] - t;
-  for (uint32_t b = lo; b < hi; b++) {
-    uint32_t cval = cnt[b];
-    uint32_t nt = (cval + Lm1) >> log_L;
-    if (off) off[b] = base_a;
-    ntask[b] = nt;
-    toff[b] = base_t;
-    base_a += cval;
-    base_t += nt;
+  if (threadIdx.x == 0) {
+    bsum[2 * blockIdx.x] = s_a[0];
+    bsum[2 * blockIdx.x + 1] = s_t[0];
+    atomicMax(&meta[2], s_m[0]);
   }
-  if (tid == nthr - 1) {
-    if (off) off[NB] = s_cnt[tid];
-    toff[NB] = s_tsk[tid];
-    meta[0] = s_cnt[tid];
-    meta[1] = s_tsk[tid];
-    meta[2] = s_max[tid];
+}
+// one workgroup: exclusive scan of the (<= 1024) block sums, totals into meta / the last slots
+__global__ void __launch_bounds__(1024) msm_scan_blocks(uint32_t* __restrict__ bsum, uint32_t nblk, uint32_t NB,
+                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
+                                                        uint32_t* __restrict__ meta) {
+  __shared__ uint32_t s_a[1024], s_t[1024];
+  const uint32_t tid = threadIdx.x;
+  uint32_t a = tid < nblk ? bsum[2 * tid] : 0, t = tid < nblk ? bsum[2 * tid + 1] : 0;
+  s_a[tid] = a; s_t[tid] = t;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t va = 0, vt = 0;
+    if (tid >= d) { va = s_a[tid - d]; vt = s_t[tid - d]; }
+    __syncthreads();
+    s_a[tid] += va; s_t[tid] += vt;
+    __syncthreads();
+  }
+  if (tid < nblk) {
+    bsum[2 * tid] = s_a[tid] - a;
+    bsum[2 * tid + 1] = s_t[tid] - t;
+  }
+  if (tid == 1023) {
+    if (off) off[NB] = s_a[tid];
+    toff[NB] = s_t[tid];
+    meta[0] = s_a[tid];
+    meta[1] = s_t[tid];
+  }
+}
+__global__ void __launch_bounds__(256) msm_scan_write(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
+                                                      const uint32_t* __restrict__ bsum, uint32_t* __restrict__ off,
+                                                      uint32_t* __restrict__ ntask, uint32_t* __restrict__ toff) {
+  __shared__ uint32_t s_a[SCAN_THREADS], s_t[SCAN_THREADS];
+  const uint32_t Lm1 = (1u << log_L) - 1, tid = threadIdx.x;
+  uint32_t base = blockIdx.x * SCAN_BLOCK + tid * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t a = 0, t = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    v[k] = (base + k < NB) ? cnt[base + k] : 0;
+    a += v[k];
+    t += (v[k] + Lm1) >> log_L;
+  }
+  s_a[tid] = a; s_t[tid] = t;
+  __syncthreads();
+  for (uint32_t d = 1; d < SCAN_THREADS; d <<= 1) {
+    uint32_t va = 0, vt = 0;
+    if (tid >= d) { va = s_a[tid - d]; vt = s_t[tid - d]; }
+    __syncthreads();
+    s_a[tid] += va; s_t[tid] += vt;
+    __syncthreads();
+  }
+  uint32_t ra = bsum[2 * blockIdx.x] + s_a[tid] - a, rt = bsum[2 * blockIdx.x + 1] + s_t[tid] - t;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
+    if (base + k < NB) {
+      uint32_t nt = (v[k] + Lm1) >> log_L;
+      if (off) off[base + k] = ra;
+      ntask[base + k] = nt;
+      toff[base + k] = rt;
+      ra += v[k];
+      rt += nt;
+    }
   }
 }
 
-// ------------------------------------------------------------------ 3: scatter
-__global__ void msm_scatter(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ off,
-                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t key = keys[(size_t)blockIdx.y * n + i];
-  if (key == EMPTY_KEY) return;
-  uint32_t b = key & 0x7fffffffu;
-  uint32_t pos = atomicAdd(&cursor[b], 1u);
-  sorted[off[b] + pos] = i | (key & 0x80000000u);
+// ------------------------------------------------------------------ 3b: LDS-cursor scatter
+// workgroup (p, j): cursors = bucket offset + this chunk's prefix, kept in LDS; every point
+// of the chunk takes the next slot of its bucket with an LDS atomic.
+__global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ dig, uint32_t n, uint32_t chunk,
+                                                    uint32_t nbw, const uint32_t* __restrict__ hist,
+                                                    const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t s_cur[];
+  const uint32_t p = blockIdx.x, j = blockIdx.y, P = gridDim.x;
+  const uint32_t* pre = hist + ((size_t)j * P + p) * nbw;
+  const uint32_t* ob = off + (size_t)j * nbw;
+  for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cur[b] = ob[b] + pre[b];
+  __syncthreads();
+  const uint32_t lo = p * chunk, hi = min(n, lo + chunk);
+  const int16_t* row = dig + (size_t)j * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int32_t d = row[i];
+    if (d) {
+      uint32_t pos = atomicAdd(&s_cur[(d < 0 ? -d : d) - 1], 1u);
+      sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ 4: accumulate / merge
@@ -306,7 +413,7 @@ __global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_t* __restrict_
 MsmEngine::~MsmEngine() { release(); }
 
 void MsmEngine::release() {
-  keys_.release(); sorted_.release(); counts_.release(); off_.release(); cursor_.release(); meta_.release();
+  dig_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_acc_[i].release(); red_run_[i].release();
   }
@@ -329,7 +436,23 @@ hipError_t MsmEngine::init() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             128 * 1024));
+  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             128 * 1024));
   return hipSuccess;
+}
+
+// exclusive scans over NB buckets (three small launches)
+static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, uint32_t* off, uint32_t* ntask,
+                              uint32_t* toff, uint32_t* bsum, uint32_t* meta, hipStream_t stream) {
+  const uint32_t nblk = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  if (nblk > 1024) return hipErrorInvalidValue;
+  SG_TRY(hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), stream));
+  msm_scan_sums<<<nblk, SCAN_THREADS, 0, stream>>>(cnt, NB, log_L, bsum, meta);
+  msm_scan_blocks<<<1, 1024, 0, stream>>>(bsum, nblk, NB, off, toff, meta);
+  msm_scan_write<<<nblk, SCAN_THREADS, 0, stream>>>(cnt, NB, log_L, bsum, off, ntask, toff);
+  return hipGetLastError();
 }
 
 hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_t n, hipStream_t stream,
@@ -347,12 +470,19 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   const uint32_t log_L = cfg_.log_seg;
   const size_t entries = (size_t)W * n;
 
+  // chunking of the scalars for the LDS-staged counting sort: W * P workgroups
+  const uint32_t target_wgs = (nbw * 4 > 64 * 1024) ? 256 : 512;
+  uint32_t P = std::max<uint32_t>(1, target_wgs / W);
+  uint32_t chunk = (uint32_t)std::max<size_t>(1024, (n + P - 1) / P);
+  P = (uint32_t)((n + chunk - 1) / chunk);
+
   // workspace (grown on demand, kept across calls)
-  SG_TRY(keys_.reserve(entries));
+  SG_TRY(dig_.reserve(entries));
   SG_TRY(sorted_.reserve(entries));
+  SG_TRY(hist_.reserve((size_t)W * P * nbw));
+  SG_TRY(bsum_.reserve(2 * 1024));
   SG_TRY(counts_.reserve((size_t)NB + 1));
   SG_TRY(off_.reserve((size_t)NB + 1));
-  SG_TRY(cursor_.reserve((size_t)NB + 1));
   for (int i = 0; i < 2; i++) {
     SG_TRY(ntask_[i].reserve((size_t)NB + 1));
     SG_TRY(toff_[i].reserve((size_t)NB + 1));
@@ -372,14 +502,14 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
     }
   };
 
-  SG_TRY(hipMemsetAsync(counts_.p, 0, sizeof(uint32_t) * (NB + 1), stream));
-  SG_TRY(hipMemsetAsync(cursor_.p, 0, sizeof(uint32_t) * (NB + 1), stream));
-  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, c, W, keys_.p, counts_.p);
+  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, c, W, dig_.p);
   if (tm) SG_TRY(hipEventRecord(ev[1], stream));
-  msm_scan<<<1, 1024, 0, stream>>>(counts_.p, NB, log_L, off_.p, ntask_[0].p, toff_[0].p, meta_.p);
+  msm_hist<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
+  msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
+  SG_TRY(launch_scan(counts_.p, NB, log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
   SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  msm_scatter<<<dim3((unsigned)((n + 255) / 256), W), 256, 0, stream>>>(keys_.p, (uint32_t)n, off_.p, cursor_.p,
-                                                                        sorted_.p);
+  msm_scatter<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
+                                                                    sorted_.p);
   if (tm) SG_TRY(hipEventRecord(ev[2], stream));
   SG_TRY(hipStreamSynchronize(stream));
   const uint32_t ntasks = h_meta_[1], max_cnt = h_meta_[2];
@@ -399,7 +529,7 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   for (uint32_t max_items = (max_cnt + (1u << log_L) - 1) >> log_L; max_items > 1;
        max_items = (max_items + (1u << log_L) - 1) >> log_L) {
     const int nxt = 1 - lvl;
-    msm_scan<<<1, 1024, 0, stream>>>(ntask_[lvl].p, NB, log_L, nullptr, ntask_[nxt].p, toff_[nxt].p, meta_.p);
+    SG_TRY(launch_scan(ntask_[lvl].p, NB, log_L, nullptr, ntask_[nxt].p, toff_[nxt].p, bsum_.p, meta_.p, stream));
     SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SG_TRY(hipStreamSynchronize(stream));
     const uint32_t nt2 = h_meta_[1];
