@@ -52,6 +52,8 @@ class MsmEngine {
  private:
   MsmConfig cfg_;
   DevBuf<int16_t> dig_;
+  DevBuf<uint2> order_;
+  DevBuf<uint32_t> thist_;
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
   DevBuf<g1_xyzz> partial_[2], red_acc_[2], red_run_[2];
   uint32_t* h_meta_ = nullptr;

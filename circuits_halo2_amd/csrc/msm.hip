@@ -235,16 +235,89 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff
   return lo;
 }
 
+// ---- task ordering: longest tasks first, equal lengths side by side, so the 64 lanes of a
+// wave run the same number of additions (bucket sizes are Poisson-distributed: without this
+// a wave waits for its largest bucket, ~30 % of the lanes' time idle).
+static constexpr uint32_t TASK_BINS = 257;        // task length clamped to 256
+static constexpr uint32_t TASK_BLOCK = 2048;      // buckets per workgroup in the ordering passes
+
+__device__ __forceinline__ uint32_t task_len(uint32_t cnt, uint32_t seg, uint32_t log_L) {
+  uint32_t rem = cnt - (seg << log_L);
+  return min(rem, 1u << log_L);
+}
+// thist[bin * nblk + blk] = number of tasks of (clamped) length `bin` in block blk
+__global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict__ cnt,
+                                                     const uint32_t* __restrict__ ntask, uint32_t NB,
+                                                     uint32_t log_L, uint32_t* __restrict__ thist) {
+  __shared__ uint32_t s_h[TASK_BINS];
+  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_h[k] = 0;
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < TASK_BLOCK; q += blockDim.x) {
+    uint32_t b = blockIdx.x * TASK_BLOCK + q;
+    if (b < NB) {
+      uint32_t nt = ntask[b], cv = cnt[b];
+      for (uint32_t seg = 0; seg < nt; seg++) atomicAdd(&s_h[min(task_len(cv, seg, log_L), TASK_BINS - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) thist[k * gridDim.x + blockIdx.x] = s_h[k];
+}
+// one workgroup: exclusive scan of thist in DESCENDING bin order (bin-major, block-minor)
+__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk) {
+  __shared__ uint32_t s_sum[1024];
+  const uint32_t total = TASK_BINS * nblk, tid = threadIdx.x;
+  const uint32_t per = (total + 1023) / 1024;
+  const uint32_t lo = min(tid * per, total), hi = min(lo + per, total);
+  // position q in scan order <-> entry (TASK_BINS-1 - q / nblk) * nblk + q % nblk
+  uint32_t a = 0;
+  for (uint32_t q = lo; q < hi; q++) a += thist[(TASK_BINS - 1 - q / nblk) * nblk + q % nblk];
+  s_sum[tid] = a;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = tid >= d ? s_sum[tid - d] : 0;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[tid] - a;
+  for (uint32_t q = lo; q < hi; q++) {
+    uint32_t idx = (TASK_BINS - 1 - q / nblk) * nblk + q % nblk;
+    uint32_t v = thist[idx];
+    thist[idx] = run;
+    run += v;
+  }
+}
+// order[pos] = (bucket, segment) of the task that runs as thread `pos`
+__global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ ntask, uint32_t NB,
+                                                        uint32_t log_L, const uint32_t* __restrict__ thist,
+                                                        uint2* __restrict__ order) {
+  __shared__ uint32_t s_c[TASK_BINS];
+  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = thist[k * gridDim.x + blockIdx.x];
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < TASK_BLOCK; q += blockDim.x) {
+    uint32_t b = blockIdx.x * TASK_BLOCK + q;
+    if (b < NB) {
+      uint32_t nt = ntask[b], cv = cnt[b];
+      for (uint32_t seg = 0; seg < nt; seg++) {
+        uint32_t pos = atomicAdd(&s_c[min(task_len(cv, seg, log_L), TASK_BINS - 1)], 1u);
+        order[pos] = make_uint2(b, seg);
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict__ sorted,
                                                       const g1_affine* __restrict__ bases,
                                                       const uint32_t* __restrict__ off,
                                                       const uint32_t* __restrict__ cnt,
-                                                      const uint32_t* __restrict__ toff, uint32_t NB, uint32_t log_L,
+                                                      const uint32_t* __restrict__ toff,
+                                                      const uint2* __restrict__ order, uint32_t log_L,
                                                       uint32_t ntasks, g1_xyzz* __restrict__ partial) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntasks) return;
-  uint32_t b = find_owner(toff, NB, t);
-  uint32_t seg = t - toff[b];
+  const uint2 o = order[t];
+  const uint32_t b = o.x, seg = o.y;
   uint32_t start = off[b] + (seg << log_L);
   uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
   g1_xyzz acc = xyzz_identity();
@@ -262,7 +335,7 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
     e = e_next;
     p = p_next;
   }
-  xyzz_store(partial + t, acc);
+  xyzz_store(partial + toff[b] + seg, acc);
 }
 
 __global__ void __launch_bounds__(256) msm_merge(const g1_xyzz* __restrict__ in, const uint32_t* __restrict__ off,
@@ -413,7 +486,7 @@ __global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_t* __restrict_
 MsmEngine::~MsmEngine() { release(); }
 
 void MsmEngine::release() {
-  dig_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
+  dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_acc_[i].release(); red_run_[i].release();
   }
@@ -521,8 +594,16 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
 
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
   SG_TRY(partial_[0].reserve(ntasks));
-  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, d_bases, off_.p, counts_.p, toff_[0].p, NB, log_L,
-                                                           ntasks, partial_[0].p);
+  {
+    const uint32_t tblk = (NB + TASK_BLOCK - 1) / TASK_BLOCK;
+    SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
+    SG_TRY(order_.reserve(ntasks));
+    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p);
+    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk);
+    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p, order_.p);
+  }
+  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, d_bases, off_.p, counts_.p, toff_[0].p, order_.p,
+                                                           log_L, ntasks, partial_[0].p);
   const g1_xyzz* cur = partial_[0].p;
   int lvl = 0, pbuf = 0;
   // heavy buckets: fold their partial sums until every bucket owns at most one
