@@ -54,6 +54,9 @@ def main():
     from circuits_halo2_amd.distributed import sharded_msm
     from circuits_halo2_amd.utils import DEFAULT_SEED, random_fr_canonical
     ffi.check(sg.lib().sg_init(local_rank))
+    for kv in filter(None, os.environ.get("SG_PARAMS", "").split(",")):  # e.g. SG_PARAMS=msm.log_seg=6
+        name, val = kv.split("=")
+        ffi.check(sg.lib().sg_set_param(name.encode(), int(val)))
 
     n = 1 << args.log_n
     # synthetic inputs, generated per rank from rank-dependent seeds, resident in HBM
