@@ -1,0 +1,262 @@
+// BN254 G1 (y^2 = x^3 + 3) point arithmetic on 9 x 29-bit limbs (see bn254_f29.cuh).
+//
+// Memory formats follow halo2curves: affine = 64 B (x || y as 8 x u32
+// Montgomery-2^256 words, identity = 64 zero bytes).  In registers coordinates live in the
+// Montgomery-2^261 domain: loading the stored words shifted left by 5 bits yields
+// x^ = 32 * x~ = x * 2^261 (mod p) with bound 32 at zero cost.  Buckets use extended Jacobian
+// "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity: all limbs of ZZ zero):
+// bucket += affine costs 8M + 2S, bucket + bucket 12M + 2S.
+//
+// Lazy-reduction invariants of a stored/accumulated XYZZ point (value < bound * p, limbs
+// normalised): X < 8, Y < 4, ZZ < 2, ZZZ < 2.  Every product below is annotated with the
+// bound product of its operands (must stay <= 170, see f29_mul).  All exceptional cases
+// (identity operands, P = Q, P = -Q) are decided exactly (f29_is_zero_mod_p).
+#pragma once
+#include "bn254_f29.cuh"
+
+namespace sg {
+
+struct affine29 {
+  f29 x, y;  // x^, y^ with bound 32 (33 after negation)
+  bool inf;
+};
+struct xyzz29 {
+  f29 x, y, zz, zzz;
+};
+
+SG_HD bool xyzz29_is_identity(const xyzz29& p) { return f29_all_zero(p.zz); }
+SG_HD xyzz29 xyzz29_identity() {
+  xyzz29 r;
+  r.x = f29_zero();
+  r.y = f29_zero();
+  r.zz = f29_zero();
+  r.zzz = f29_zero();
+  return r;
+}
+
+// 64-byte affine point (16 LE words) -> registers
+SG_HD affine29 affine29_from_words(const uint32_t w[16]) {
+  affine29 r;
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) o |= w[i];
+  r.inf = (o == 0);
+  r.x = f29_from_words<5>(w);
+  r.y = f29_from_words<5>(w + 8);
+  return r;
+}
+// y -> -y  (32p - y, bound 33)
+SG_HD void affine29_negate(affine29& q) { q.y = f29_sub<Fq29, 4>(f29_zero(), q.y); }
+
+// 2 * (affine point), a = 0  (mdbl-2008-s-1)
+SG_HD xyzz29 xyzz29_double_affine(const affine29& q) {
+  typedef Fq29 P;
+  if (q.inf) return xyzz29_identity();
+  xyzz29 r;
+  f29 x = f29_mul<P>(q.x, f29_one<P>());                       // 33*1 -> < 2
+  f29 y = f29_mul<P>(q.y, f29_one<P>());                       // < 2
+  f29 u = f29_dbl(y);                                          // < 4
+  f29 v = f29_sqr<P>(u);                                       // 16 -> < 2
+  f29 w = f29_mul<P>(u, v);                                    // 8
+  f29 s = f29_mul<P>(x, v);                                    // 4
+  f29 xx = f29_sqr<P>(x);                                      // 4
+  f29 m = f29_add(f29_dbl(xx), xx);                            // < 6
+  r.x = f29_sub<P, 1>(f29_sqr<P>(m), f29_dbl(s));              // 36 -> <2 ; - <4 + 4p  => < 6
+  f29 t = f29_sub<P, 2>(s, r.x);                               // < 2 + 8 = 10
+  r.y = f29_sub<P, 0>(f29_mul<P>(m, t), f29_mul<P>(w, y));     // 60, 4 ; <2 - <2 + 2p => < 4
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+// 2 * P  (dbl-2008-s-1)
+SG_HD xyzz29 xyzz29_double(const xyzz29& p) {
+  typedef Fq29 P;
+  if (xyzz29_is_identity(p)) return p;
+  xyzz29 r;
+  f29 u = f29_dbl(p.y);                                        // < 8
+  f29 v = f29_sqr<P>(u);                                       // 64
+  f29 w = f29_mul<P>(u, v);                                    // 16
+  f29 s = f29_mul<P>(p.x, v);                                  // 16
+  f29 xx = f29_sqr<P>(p.x);                                    // 64
+  f29 m = f29_add(f29_dbl(xx), xx);                            // < 6
+  r.x = f29_sub<P, 1>(f29_sqr<P>(m), f29_dbl(s));              // < 6
+  f29 t = f29_sub<P, 2>(s, r.x);                               // < 10
+  r.y = f29_sub<P, 0>(f29_mul<P>(m, t), f29_mul<P>(w, p.y));   // 60, 8 => < 4
+  r.zz = f29_mul<P>(v, p.zz);                                  // 4
+  r.zzz = f29_mul<P>(w, p.zzz);                                // 4
+  return r;
+}
+
+// acc += q   (q affine; madd-2008-s)
+SG_HD void xyzz29_madd(xyzz29& acc, const affine29& q) {
+  typedef Fq29 P;
+  if (q.inf) return;
+  if (xyzz29_is_identity(acc)) {
+    acc.x = f29_mul<P>(q.x, f29_one<P>());                     // 33 -> < 2
+    acc.y = f29_mul<P>(q.y, f29_one<P>());
+    acc.zz = f29_one<P>();
+    acc.zzz = f29_one<P>();
+    return;
+  }
+  f29 u2 = f29_mul<P>(q.x, acc.zz);                            // 33*2 = 66
+  f29 s2 = f29_mul<P>(q.y, acc.zzz);                           // 66
+  f29 p = f29_sub<P, 2>(u2, acc.x);                            // < 2 + 8 = 10
+  f29 r = f29_sub<P, 1>(s2, acc.y);                            // < 2 + 4 = 6
+  if (f29_is_zero_mod_p<P>(p)) {
+    if (f29_is_zero_mod_p<P>(r)) acc = xyzz29_double_affine(q);
+    else acc = xyzz29_identity();
+    return;
+  }
+  f29 pp = f29_sqr<P>(p);                                      // 100
+  f29 ppp = f29_mul<P>(p, pp);                                 // 20
+  f29 qq = f29_mul<P>(acc.x, pp);                              // 16
+  f29 rr = f29_sqr<P>(r);                                      // 36
+  f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // (<4) - (<4) + 4p => < 8
+  f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(acc.y, ppp));  // 60, 8 => < 4
+  acc.zz = f29_mul<P>(acc.zz, pp);                             // 4
+  acc.zzz = f29_mul<P>(acc.zzz, ppp);                          // 4
+  acc.x = x3;
+  acc.y = y3;
+}
+
+// acc += q   (both XYZZ; add-2008-s)
+SG_HD void xyzz29_add(xyzz29& acc, const xyzz29& q) {
+  typedef Fq29 P;
+  if (xyzz29_is_identity(q)) return;
+  if (xyzz29_is_identity(acc)) {
+    acc = q;
+    return;
+  }
+  f29 u1 = f29_mul<P>(acc.x, q.zz);                            // 16
+  f29 u2 = f29_mul<P>(q.x, acc.zz);                            // 16
+  f29 s1 = f29_mul<P>(acc.y, q.zzz);                           // 8
+  f29 s2 = f29_mul<P>(q.y, acc.zzz);                           // 8
+  f29 p = f29_sub<P, 0>(u2, u1);                               // < 4
+  f29 r = f29_sub<P, 0>(s2, s1);                               // < 4
+  if (f29_is_zero_mod_p<P>(p)) {
+    if (f29_is_zero_mod_p<P>(r)) acc = xyzz29_double(acc);
+    else acc = xyzz29_identity();
+    return;
+  }
+  f29 pp = f29_sqr<P>(p);                                      // 16
+  f29 ppp = f29_mul<P>(p, pp);                                 // 8
+  f29 qq = f29_mul<P>(u1, pp);                                 // 4
+  f29 rr = f29_sqr<P>(r);                                      // 16
+  f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // < 8
+  f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(s1, ppp));  // 40, 4 => < 4
+  acc.zz = f29_mul<P>(f29_mul<P>(acc.zz, q.zz), pp);           // 4, 4
+  acc.zzz = f29_mul<P>(f29_mul<P>(acc.zzz, q.zzz), ppp);       // 4, 4
+  acc.x = x3;
+  acc.y = y3;
+}
+
+// XYZZ in the 2^261 domain -> 32 canonical LE words (X, Y, ZZ, ZZZ as 8 x u32 Montgomery-2^256
+// each), the format the host tail (host_curve.h) consumes
+SG_HD void xyzz29_to_words(const xyzz29& p, uint32_t w[32]) {
+  typedef Fq29 P;
+  f29_to_words(f29_reduce_with<P>(p.x, P::r256), w);           // x^ * 2^256 * 2^-261 = x~
+  f29_to_words(f29_reduce_with<P>(p.y, P::r256), w + 8);
+  f29_to_words(f29_reduce_with<P>(p.zz, P::r256), w + 16);
+  f29_to_words(f29_reduce_with<P>(p.zzz, P::r256), w + 24);
+}
+
+}  // namespace sg
+
+#if defined(__HIPCC__)
+namespace sg {
+// ---- memory forms (device only) ----------------------------------------------------------
+struct alignas(16) g1_affine_mem {  // halo2curves G1Affine: x || y, 8 LE words each
+  uint4 q[4];
+};
+struct alignas(16) xyzz29_mem {  // 36 limbs: X[9] Y[9] ZZ[9] ZZZ[9]
+  uint4 q[9];
+};
+struct alignas(16) fp_words {  // one field element in the 8 x u32 memory format
+  uint4 q[2];
+};
+
+__device__ __forceinline__ affine29 affine29_load(const g1_affine_mem* p) {
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint4 v = p->q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  return affine29_from_words(w);
+}
+__device__ __forceinline__ xyzz29 xyzz29_load(const xyzz29_mem* p) {
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint4 v = p->q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  xyzz29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; r.zz.l[i] = w[18 + i]; r.zzz.l[i] = w[27 + i]; }
+  return r;
+}
+__device__ __forceinline__ void xyzz29_store(xyzz29_mem* p, const xyzz29& v) {
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { w[i] = v.x.l[i]; w[9 + i] = v.y.l[i]; w[18 + i] = v.zz.l[i]; w[27 + i] = v.zzz.l[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) p->q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void fp_words_load(const fp_words* p, uint32_t w[8]) {
+  uint4 a = p->q[0], b = p->q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void fp_words_store(fp_words* p, const uint32_t w[8]) {
+  p->q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p->q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// a^(p-2) in the 2^261 domain (off the hot path only)
+template <class P>
+__device__ inline f29 f29_inv(const f29& x) {
+  f29 acc = f29_one<P>();
+  for (int i = 253; i >= 0; i--) {
+    acc = f29_sqr<P>(acc);
+    // bit i of p - 2 (p[0] is odd and >= 3, so only limb 0 changes)
+    uint32_t limb = P::p[i / 29] - ((i / 29) == 0 ? 2u : 0u);
+    if ((limb >> (i % 29)) & 1) acc = f29_mul<P>(acc, x);
+  }
+  return acc;
+}
+template <class P>
+__device__ inline f29 f29_pow_u64(f29 x, uint64_t e) {
+  f29 acc = f29_one<P>();
+  while (e) {
+    if (e & 1) acc = f29_mul<P>(acc, x);
+    x = f29_sqr<P>(x);
+    e >>= 1;
+  }
+  return acc;
+}
+// memory word formats <-> register domains for one field element
+//   load_r256:  x~ words -> limbs, same domain, bound 1
+//   load_r261:  x~ words -> x^ canonical-ish (< 2p) via one product
+template <class P>
+__device__ __forceinline__ f29 f29_load_r256(const fp_words* p) {
+  uint32_t w[8];
+  fp_words_load(p, w);
+  return f29_from_words<0>(w);
+}
+template <class P>
+__device__ __forceinline__ f29 f29_words_to_r261(const uint32_t w[8]) {
+  f29 k;
+#pragma unroll
+  for (int i = 0; i < 9; i++) k.l[i] = P::r266[i];
+  return f29_mul<P>(f29_from_words<0>(w), k);  // x~ * 2^266 * 2^-261 = x * 2^261
+}
+// value (bound <= 170, any domain) -> canonical words of the same residue
+template <class P>
+__device__ __forceinline__ void f29_store_canonical(fp_words* p, const f29& a_lt2p_normalised) {
+  uint32_t w[8];
+  f29_to_words(f29_cond_sub_p<P>(a_lt2p_normalised), w);
+  fp_words_store(p, w);
+}
+}  // namespace sg
+#endif

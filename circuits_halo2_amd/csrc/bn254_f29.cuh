@@ -1,0 +1,258 @@
+// BN254 field arithmetic in 9 x 29-bit limbs for gfx950 (Montgomery radix R' = 2^261).
+//
+// Why 29-bit limbs: on gfx950 a 32x32+64 multiply-add (v_mad_u64_u32, 5.1 clk/wave) costs
+// about the same as ANY other integer instruction, and it has no carry-in.  With full 32-bit
+// limbs every product needs extra add-with-carry / move instructions (a compiler-scheduled
+// 8x32 CIOS product is 128 mads + ~420 other instructions).  With 29-bit limbs a column of
+// 9 + 9 products (a_i*b_j and m*p_j, each < 2^58) fits a 64-bit accumulator with room to
+// spare, so a Montgomery product is a pure chain of 162 mads into 64-bit accumulators plus
+// one shift/add per column -- and additions / subtractions become 9 independent 32-bit adds
+// with no carry chain ("lazy": values stay below a small multiple of p, limbs below
+// 2^29 + 4; the product tolerates both).
+//
+// Conventions
+//   f29           limbs l[0..8], value = sum l[k] * 2^(29k); "normalised" = every limb
+//                 < 2^29 + 4 (l[8] carries the excess of the value over 2^232).
+//   bound B       value < B * p.  f29_mul(a, b) requires Ba * Bb <= 170 and returns a value
+//                 < 2p with exactly normalised limbs (< 2^29).
+//   domains       memory holds x~ = x * 2^256 mod p (halo2curves).  f29_mul(a, b) = a*b*2^-261.
+//                 Curve code works on x^ = x * 2^261 mod p (loading x~ shifted left by 5 bits
+//                 gives x^ lazily, bound 32); NTT data stays x~ and only the twiddles are
+//                 stored as w^ (then x~ * w^ * 2^-261 = (xw)~).
+// The header also compiles as plain C++ (tools/test_f29.cpp checks it against big integers).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SG_HD __host__ __device__ __forceinline__
+#else
+#define SG_HD inline
+#endif
+
+namespace sg {
+
+struct f29 {
+  uint32_t l[9];
+};
+static constexpr uint32_t M29 = (1u << 29) - 1;
+
+struct Fq29 {
+  static constexpr uint32_t p[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                    0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t inv = 0x04866389u;      // -p^-1 mod 2^29
+  static constexpr uint32_t pinv = 0x1b799c77u;     //  p^-1 mod 2^29
+  static constexpr uint32_t one[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+  static constexpr uint32_t r256[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+                                       0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};  // 2^256 mod p
+  static constexpr uint32_t r266[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u,
+                                       0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};  // 2^266 mod p
+  static constexpr uint32_t r517[9] = {0x0f6b5c04u, 0x08ead878u, 0x1645525du, 0x1aefe9cdu, 0x09d605edu,
+                                       0x0483a115u, 0x0d08508bu, 0x0dba4804u, 0x001982b4u};  // 2^517 mod p
+  // k*p with limbs 0..7 raised by 2^30 (borrowed from the limb above): a - b + subc never
+  // goes negative limb-wise for normalised b < k*p.  Rows: k = 2, 4, 8, 16, 32, 64.
+  static constexpr uint32_t subc[6][9] = {
+      {0x50f9fa8eu, 0x4208c16bu, 0x58e5469cu, 0x45aa459fu, 0x4b0bb2eeu, 0x45b6817fu, 0x414dc280u, 0x5cb84c66u, 0x0060c89au},
+      {0x41f3f51cu, 0x441182d9u, 0x51ca8d3au, 0x4b548b41u, 0x561765deu, 0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u},
+      {0x43e7ea38u, 0x482305b4u, 0x43951a76u, 0x56a91685u, 0x4c2ecbbeu, 0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u},
+      {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u},
+      {0x4f9fa8e0u, 0x408c16d6u, 0x4e5469dfu, 0x5aa45a1au, 0x50bb2f00u, 0x5b681813u, 0x54dc2820u, 0x4b84c67eu, 0x060c89ccu},
+      {0x5f3f51c0u, 0x41182daeu, 0x5ca8d3c0u, 0x5548b436u, 0x41765e03u, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au}};
+};
+struct Fr29 {
+  static constexpr uint32_t p[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                    0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t inv = 0x0fffffffu;
+  static constexpr uint32_t pinv = 0x10000001u;
+  static constexpr uint32_t one[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+  static constexpr uint32_t r256[9] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu,
+                                       0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+  static constexpr uint32_t r266[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau,
+                                       0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+  static constexpr uint32_t r517[9] = {0x142db4dfu, 0x19d6990eu, 0x1472f48cu, 0x06dbe7e3u, 0x0b84d579u,
+                                       0x10f9faf7u, 0x121f4380u, 0x17a112deu, 0x001275c7u};
+  static constexpr uint32_t subc[6][9] = {
+      {0x40000002u, 0x5e1f593du, 0x5cb8489fu, 0x4fa121e4u, 0x4b0ba504u, 0x45b6817fu, 0x414dc280u, 0x5cb84c66u, 0x0060c89au},
+      {0x40000004u, 0x5c3eb27cu, 0x59709141u, 0x5f4243cbu, 0x56174a0au, 0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u},
+      {0x40000008u, 0x587d64fau, 0x52e12285u, 0x5e848799u, 0x4c2e9417u, 0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u},
+      {0x40000010u, 0x50fac9f6u, 0x45c2450du, 0x5d090f35u, 0x585d2831u, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u},
+      {0x40000020u, 0x41f593eeu, 0x4b848a1du, 0x5a121e6cu, 0x50ba5065u, 0x5b681813u, 0x54dc2820u, 0x4b84c67eu, 0x060c89ccu},
+      {0x40000040u, 0x43eb27deu, 0x5709143cu, 0x54243cdau, 0x4174a0cdu, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au}};
+};
+
+template <class P>
+SG_HD f29 f29_const(const uint32_t (&c)[9]) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c[i];
+  return r;
+}
+SG_HD f29 f29_zero() {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = 0;
+  return r;
+}
+template <class P>
+SG_HD f29 f29_one() {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = P::one[i];
+  return r;
+}
+SG_HD bool f29_all_zero(const f29& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o |= a.l[i];
+  return o == 0;
+}
+
+// one parallel carry step: limbs < 2^31 in -> limbs < 2^29 + 4 out (l[0] exactly < 2^29)
+SG_HD f29 f29_carry(const f29& a) {
+  f29 r;
+  r.l[0] = a.l[0] & M29;
+#pragma unroll
+  for (int i = 1; i < 8; i++) r.l[i] = (a.l[i] & M29) + (a.l[i - 1] >> 29);
+  r.l[8] = a.l[8] + (a.l[7] >> 29);
+  return r;
+}
+// exact sequential normalisation: every limb 0..7 < 2^29
+SG_HD f29 f29_normalize(const f29& a) {
+  f29 r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t t = a.l[i] + c;
+    r.l[i] = t & M29;
+    c = t >> 29;
+  }
+  r.l[8] = a.l[8] + c;
+  return r;
+}
+
+// lazy addition: bound Ba + Bb
+SG_HD f29 f29_add(const f29& a, const f29& b) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return f29_carry(r);
+}
+// lazy subtraction a - b + K*p, K = 2 << LOGK_MINUS1 must be >= bound(b); bound Ba + K
+template <class P, int KIDX>
+SG_HD f29 f29_sub(const f29& a, const f29& b) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P::subc[KIDX][i] - b.l[i];
+  return f29_carry(r);
+}
+SG_HD f29 f29_dbl(const f29& a) { return f29_add(a, a); }
+
+// Montgomery product a*b*2^-261 mod p.  Requires normalised limbs and Ba*Bb <= 170;
+// returns exactly normalised limbs, value < (Ba*Bb/170.7 + 1) p < 2p.
+template <class P>
+SG_HD f29 f29_mul(const f29& a, const f29& b) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+    uint32_t m = ((uint32_t)acc[i] * P::inv) & M29;
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * P::p[j];
+    acc[i + 1] += acc[i] >> 29;
+  }
+  f29 r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    r.l[k] = (uint32_t)acc[9 + k] & M29;
+    acc[10 + k] += acc[9 + k] >> 29;
+  }
+  r.l[8] = (uint32_t)acc[17];
+  return r;
+}
+template <class P>
+SG_HD f29 f29_sqr(const f29& a) {
+  return f29_mul<P>(a, a);
+}
+
+// value < 2p with exactly normalised limbs -> canonical [0, p)
+template <class P>
+SG_HD f29 f29_cond_sub_p(const f29& a) {
+  // d = a - p with borrow chain over 29-bit limbs
+  f29 d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t t = a.l[i] - P::p[i] - borrow;
+    borrow = t >> 31;  // limbs < 2^30: a negative difference sets bit 31
+    d.l[i] = (i < 8) ? (t & M29) : t;
+  }
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+  return r;
+}
+// any normalised value with bound <= 170 -> canonical representative of the same residue
+// TIMES 2^-261 * c ... helper: full reduction through one product with `c`
+template <class P>
+SG_HD f29 f29_reduce_with(const f29& a, const uint32_t (&c)[9]) {
+  f29 k;
+#pragma unroll
+  for (int i = 0; i < 9; i++) k.l[i] = c[i];
+  return f29_cond_sub_p<P>(f29_mul<P>(a, k));
+}
+// canonical representative of a (same Montgomery domain): a * (2^261 mod p) * 2^-261
+template <class P>
+SG_HD f29 f29_canonical(const f29& a) {
+  return f29_reduce_with<P>(a, P::one);
+}
+// is a == 0 (mod p)?  a normalised (l[0] < 2^29 exactly), bound <= 64.
+// If a = k*p then (a.l[0] * p^-1) mod 2^29 == k; anything else passes the filter with
+// probability 64 / 2^29 and is then decided exactly.
+template <class P>
+SG_HD bool f29_is_zero_mod_p(const f29& a) {
+  uint32_t t = (a.l[0] * P::pinv) & M29;
+  if (t > 64) return false;
+  return f29_all_zero(f29_canonical<P>(a));
+}
+
+// ---- conversions with the 8 x 32-bit memory format -------------------------------------
+// x (8 LE words, < 2^256) shifted left by SH bits (SH < 29) -> limbs (exactly normalised)
+template <int SH>
+SG_HD f29 f29_from_words(const uint32_t w[8]) {
+  f29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    // bits [29k - SH, 29k - SH + 29) of x
+    int lo = 29 * k - SH;
+    uint32_t v;
+    if (lo < 0) {
+      v = (w[0] << (-lo)) & M29;  // only k = 0 with SH > 0
+    } else {
+      int wi = lo >> 5, sh = lo & 31;
+      uint64_t two = (wi < 8 ? (uint64_t)w[wi] : 0) | (wi + 1 < 8 ? (uint64_t)w[wi + 1] << 32 : 0);
+      v = (uint32_t)(two >> sh);
+      if (k < 8) v &= M29;
+    }
+    r.l[k] = v;
+  }
+  return r;
+}
+// canonical limbs (value < 2^256) -> 8 LE words
+SG_HD void f29_to_words(const f29& a, uint32_t w[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    // bits [32i, 32i+32) of the value
+    int k = (32 * i) / 29, sh = (32 * i) % 29;
+    uint64_t two = (uint64_t)a.l[k] | ((uint64_t)a.l[k + 1] << 29);
+    uint32_t v = (uint32_t)(two >> sh);
+    if (sh + 32 > 58 && k + 2 < 9) v |= a.l[k + 2] << (58 - sh);
+    w[i] = v;
+  }
+}
+
+}  // namespace sg

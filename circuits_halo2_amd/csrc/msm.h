@@ -2,9 +2,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "bn254_curve.cuh"
+#include "bn254_curve29.cuh"
 
 namespace sg {
+
+#ifndef SG_WORDS8
+#define SG_WORDS8
+struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host side
+  uint32_t l[8];
+};
+#endif
 
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
@@ -46,7 +53,7 @@ class MsmEngine {
   MsmConfig& config() { return cfg_; }
   uint32_t window_bits_for(size_t n) const;
   // d_scalars: n x 32 B Montgomery Fr, d_bases: n x 64 B affine; result: 64 B affine on the host
-  hipError_t run(const fp_t* d_scalars, const g1_affine* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
+  hipError_t run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
                  MsmTimings* tm);
 
  private:
@@ -55,11 +62,12 @@ class MsmEngine {
   DevBuf<uint2> order_;
   DevBuf<uint32_t> thist_;
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
-  DevBuf<g1_xyzz> partial_[2], red_acc_[2], red_run_[2];
+  DevBuf<xyzz29_mem> partial_[2], red_acc_[2], red_run_[2];
+  DevBuf<uint32_t> win_words_;
   uint32_t* h_meta_ = nullptr;
-  g1_xyzz* h_win_ = nullptr;
+  uint32_t* h_win_ = nullptr;  // W x 32 words: canonical X, Y, ZZ, ZZZ per window
 };
 
-hipError_t fixed_base_mul(const fp_t* d_scalars, size_t n, g1_affine* d_out, hipStream_t stream);
+hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream);
 
 }  // namespace sg

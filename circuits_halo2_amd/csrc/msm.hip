@@ -38,11 +38,17 @@ namespace sg {
 // dig[j*n + i] = digit j of scalar i as int16: d in [-2^(c-1), 2^(c-1)) for j < W-1 and an
 // unsigned top digit.  Adding K = sum_{j<W-1} 2^(c-1) * 2^(jc) once makes every window's
 // digit independent of its neighbours: d_j = (((s + K) >> jc) & mask) - 2^(c-1).
-__global__ void msm_digits(const fp_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+__global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
                            int16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fp_t s = fp_from_mont<FrP>(fp_load(scalars + i));
+  words8 s;
+  {
+    // canonical scalar = s~ * 2^-256 = s~ * 2^5 * 2^-261
+    f29 k = f29_zero();
+    k.l[0] = 32;
+    f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(scalars + i), k)), s.l);
+  }
   const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
   // s += K (K < 2^255, s < 2^254: no overflow out of 256 bits)
   {
@@ -308,172 +314,194 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
 }
 
 __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict__ sorted,
-                                                      const g1_affine* __restrict__ bases,
+                                                      const g1_affine_mem* __restrict__ bases,
                                                       const uint32_t* __restrict__ off,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ toff,
                                                       const uint2* __restrict__ order, uint32_t log_L,
-                                                      uint32_t ntasks, g1_xyzz* __restrict__ partial) {
+                                                      uint32_t ntasks, xyzz29_mem* __restrict__ partial) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntasks) return;
   const uint2 o = order[t];
   const uint32_t b = o.x, seg = o.y;
   uint32_t start = off[b] + (seg << log_L);
   uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
-  g1_xyzz acc = xyzz_identity();
+  xyzz29 acc = xyzz29_identity();
   uint32_t e = sorted[start];
-  g1_affine p = affine_load(bases + (e & 0x7fffffffu));
+  g1_affine_mem raw = bases[e & 0x7fffffffu];
   for (uint32_t k = start; k < end; k++) {
     uint32_t e_next = 0;
-    g1_affine p_next;
+    g1_affine_mem raw_next = raw;
     if (k + 1 < end) {  // prefetch the next point while this one is being added
       e_next = sorted[k + 1];
-      p_next = affine_load(bases + (e_next & 0x7fffffffu));
+      raw_next = bases[e_next & 0x7fffffffu];
     }
-    if (e >> 31) p.y = fp_neg<FqP>(p.y);
-    xyzz_madd(acc, p);
+    affine29 p = affine29_load(&raw);
+    if (e >> 31) affine29_negate(p);
+    xyzz29_madd(acc, p);
     e = e_next;
-    p = p_next;
+    raw = raw_next;
   }
-  xyzz_store(partial + toff[b] + seg, acc);
+  xyzz29_store(partial + toff[b] + seg, acc);
 }
 
-__global__ void __launch_bounds__(256) msm_merge(const g1_xyzz* __restrict__ in, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ in, const uint32_t* __restrict__ off,
                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
                                                  uint32_t NB, uint32_t log_L, uint32_t ntasks,
-                                                 g1_xyzz* __restrict__ out) {
+                                                 xyzz29_mem* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntasks) return;
   uint32_t b = find_owner(toff, NB, t);
   uint32_t seg = t - toff[b];
   uint32_t start = off[b] + (seg << log_L);
   uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
-  g1_xyzz acc = xyzz_identity();
-  for (uint32_t k = start; k < end; k++) xyzz_add(acc, xyzz_load(in + k));
-  xyzz_store(out + t, acc);
+  xyzz29 acc = xyzz29_identity();
+  for (uint32_t k = start; k < end; k++) xyzz29_add(acc, xyzz29_load(in + k));
+  xyzz29_store(out + t, acc);
 }
 
 // ------------------------------------------------------------------ 5: bucket reduction
 // Items are (acc, run) pairs in bucket order; item t of a window stands for
 // acc_t + (t * M) * run_t.  A workgroup of N items produces one item of the next level:
 //   acc' = sum_t acc_t + M * sum_{t>=1} Suf_t,  run' = Suf_0,  Suf_t = sum_{u>=t} run_u.
-__device__ void block_combine(g1_xyzz acc, g1_xyzz run, uint32_t log_M, g1_xyzz* sA, g1_xyzz* sR,
-                              g1_xyzz* out_acc, g1_xyzz* out_run) {
+__device__ void block_combine(xyzz29 acc, xyzz29 run, uint32_t log_M, xyzz29_mem* sA, xyzz29_mem* sR,
+                              xyzz29_mem* out_acc, xyzz29_mem* out_run) {
   const uint32_t tid = threadIdx.x, N = blockDim.x;
-  xyzz_store(&sR[tid], run);
+  xyzz29_store(&sR[tid], run);
   __syncthreads();
   for (uint32_t d = 1; d < N; d <<= 1) {
-    g1_xyzz other = xyzz_identity();
-    if (tid + d < N) other = xyzz_load(&sR[tid + d]);
+    xyzz29 other = xyzz29_identity();
+    if (tid + d < N) other = xyzz29_load(&sR[tid + d]);
     __syncthreads();
-    xyzz_add(run, other);
-    xyzz_store(&sR[tid], run);
+    xyzz29_add(run, other);
+    xyzz29_store(&sR[tid], run);
     __syncthreads();
   }
-  g1_xyzz total = xyzz_load(&sR[0]);
+  xyzz29 total = xyzz29_load(&sR[0]);
   __syncthreads();
-  xyzz_store(&sA[tid], acc);
-  if (tid == 0) xyzz_store(&sR[0], xyzz_identity());
+  xyzz29_store(&sA[tid], acc);
+  if (tid == 0) xyzz29_store(&sR[0], xyzz29_identity());
   __syncthreads();
   // two tree reductions side by side: lower half of the threads folds sA, upper half sR
   const uint32_t halfN = N >> 1;
-  g1_xyzz* arr = (tid < halfN) ? sA : sR;
+  xyzz29_mem* arr = (tid < halfN) ? sA : sR;
   const uint32_t li = (tid < halfN) ? tid : tid - halfN;
   for (uint32_t s = halfN; s >= 1; s >>= 1) {
     if (li < s) {
-      g1_xyzz a = xyzz_load(&arr[li]);
-      xyzz_add(a, xyzz_load(&arr[li + s]));
-      xyzz_store(&arr[li], a);
+      xyzz29 a = xyzz29_load(&arr[li]);
+      xyzz29_add(a, xyzz29_load(&arr[li + s]));
+      xyzz29_store(&arr[li], a);
     }
     __syncthreads();
   }
   if (tid == 0) {
-    g1_xyzz sufsum = xyzz_load(&sR[0]);
-    for (uint32_t k = 0; k < log_M; k++) sufsum = xyzz_double(sufsum);
-    g1_xyzz a = xyzz_load(&sA[0]);
-    xyzz_add(a, sufsum);
-    xyzz_store(out_acc, a);
-    xyzz_store(out_run, total);
+    xyzz29 sufsum = xyzz29_load(&sR[0]);
+    for (uint32_t k = 0; k < log_M; k++) sufsum = xyzz29_double(sufsum);
+    xyzz29 a = xyzz29_load(&sA[0]);
+    xyzz29_add(a, sufsum);
+    xyzz29_store(out_acc, a);
+    xyzz29_store(out_run, total);
   }
 }
 
 // level 0: thread -> G = 2^log_G consecutive buckets of window blockIdx.y
-__global__ void __launch_bounds__(256) msm_reduce_buckets(const g1_xyzz* __restrict__ partial,
+__global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __restrict__ partial,
                                                           const uint32_t* __restrict__ toff,
                                                           const uint32_t* __restrict__ ntask, uint32_t nbw,
-                                                          uint32_t log_G, g1_xyzz* __restrict__ out_acc,
-                                                          g1_xyzz* __restrict__ out_run) {
+                                                          uint32_t log_G, xyzz29_mem* __restrict__ out_acc,
+                                                          xyzz29_mem* __restrict__ out_run) {
   extern __shared__ uint4 smem[];
-  g1_xyzz* sA = reinterpret_cast<g1_xyzz*>(smem);
-  g1_xyzz* sR = sA + blockDim.x;
+  xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
+  xyzz29_mem* sR = sA + blockDim.x;
   const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t G = 1u << log_G;
-  g1_xyzz acc = xyzz_identity(), run = xyzz_identity();
+  xyzz29 acc = xyzz29_identity(), run = xyzz29_identity();
   const uint32_t first = chunk << log_G;
   if (first < nbw) {
     const uint32_t wbase = blockIdx.y * nbw;
     for (uint32_t k = G; k-- > 0;) {
       uint32_t b = first + k;
-      if (b < nbw && ntask[wbase + b]) xyzz_add(run, xyzz_load(partial + toff[wbase + b]));
-      xyzz_add(acc, run);
+      if (b < nbw && ntask[wbase + b]) xyzz29_add(run, xyzz29_load(partial + toff[wbase + b]));
+      xyzz29_add(acc, run);
     }
   }
   const uint32_t o = blockIdx.y * gridDim.x + blockIdx.x;
   block_combine(acc, run, log_G, sA, sR, out_acc + o, out_run + o);
 }
 // level >= 1: items from the previous level, `count` per window
-__global__ void __launch_bounds__(256) msm_reduce_items(const g1_xyzz* __restrict__ in_acc,
-                                                        const g1_xyzz* __restrict__ in_run, uint32_t count,
-                                                        uint32_t log_M, g1_xyzz* __restrict__ out_acc,
-                                                        g1_xyzz* __restrict__ out_run) {
+__global__ void __launch_bounds__(256) msm_reduce_items(const xyzz29_mem* __restrict__ in_acc,
+                                                        const xyzz29_mem* __restrict__ in_run, uint32_t count,
+                                                        uint32_t log_M, xyzz29_mem* __restrict__ out_acc,
+                                                        xyzz29_mem* __restrict__ out_run) {
   extern __shared__ uint4 smem[];
-  g1_xyzz* sA = reinterpret_cast<g1_xyzz*>(smem);
-  g1_xyzz* sR = sA + blockDim.x;
+  xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
+  xyzz29_mem* sR = sA + blockDim.x;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  g1_xyzz acc = xyzz_identity(), run = xyzz_identity();
+  xyzz29 acc = xyzz29_identity(), run = xyzz29_identity();
   if (t < count) {
-    acc = xyzz_load(in_acc + blockIdx.y * count + t);
-    run = xyzz_load(in_run + blockIdx.y * count + t);
+    acc = xyzz29_load(in_acc + blockIdx.y * count + t);
+    run = xyzz29_load(in_run + blockIdx.y * count + t);
   }
   const uint32_t o = blockIdx.y * gridDim.x + blockIdx.x;
   block_combine(acc, run, log_M, sA, sR, out_acc + o, out_run + o);
 }
+// window sums -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ) for the host tail
+__global__ void msm_export_windows(const xyzz29_mem* __restrict__ in, uint32_t W, uint32_t* __restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W) return;
+  uint32_t w[32];
+  xyzz29_to_words(xyzz29_load(in + j), w);
+  for (int i = 0; i < 32; i++) out[32 * j + i] = w[i];
+}
 
 // out[i] = scalars[i] * G  (ParamsKZG::setup's fixed-base products; also used to build
-// synthetic bases for benchmarks).  One thread per scalar, double-and-add, Jacobian-free
-// XYZZ, result normalised on the device.
-__global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_t* __restrict__ scalars, uint32_t n,
-                                                         g1_affine* __restrict__ out) {
+// synthetic bases for benchmarks).  One thread per scalar, double-and-add in XYZZ, result
+// normalised on the device.
+__global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_words* __restrict__ scalars, uint32_t n,
+                                                         g1_affine_mem* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fp_t s = fp_from_mont<FrP>(fp_load(scalars + i));
-  g1_affine gen;
-  gen.x = fp_one<FqP>();
-  gen.y = fp_dbl<FqP>(gen.x);
-  g1_xyzz acc = xyzz_identity();
+  typedef Fq29 P;
+  words8 s;
+  {
+    f29 k = f29_zero();
+    k.l[0] = 32;
+    f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(scalars + i), k)), s.l);
+  }
+  affine29 gen;
+  {
+    // G = (1, 2): Montgomery-2^256 words of 1 and 2, then the usual shifted load
+    uint32_t w[16];
+    f29 one256 = f29_const<P>(P::r256);             // limbs of 2^256 mod q == words of 1~
+    f29_to_words(one256, w);
+    f29 two = f29_cond_sub_p<P>(f29_normalize(f29_add(one256, one256)));
+    f29_to_words(two, w + 8);
+    gen = affine29_from_words(w);
+  }
+  xyzz29 acc = xyzz29_identity();
   for (int limb = 7; limb >= 0; limb--) {
     uint32_t w = s.l[7];
 #pragma unroll
     for (int k = 7; k > 0; k--) s.l[k] = s.l[k - 1];
     s.l[0] = 0;
     for (int bit = 31; bit >= 0; bit--) {
-      acc = xyzz_double(acc);
-      if ((w >> bit) & 1) xyzz_madd(acc, gen);
+      acc = xyzz29_double(acc);
+      if ((w >> bit) & 1) xyzz29_madd(acc, gen);
     }
-    (void)limb;
   }
-  g1_affine r;
-  if (xyzz_is_identity(acc)) {
-    r.x = fp_zero<FqP>();
-    r.y = fp_zero<FqP>();
+  uint32_t ow[16];
+  if (xyzz29_is_identity(acc)) {
+    for (int k = 0; k < 16; k++) ow[k] = 0;
   } else {
-    fp_t iz = fp_inv<FqP>(acc.zzz);             // 1/ZZZ
-    fp_t t = fp_mul<FqP>(acc.zz, iz);           // ZZ/ZZZ = 1/Z
-    r.x = fp_mul<FqP>(acc.x, fp_sqr<FqP>(t));   // X/ZZ
-    r.y = fp_mul<FqP>(acc.y, iz);               // Y/ZZZ
+    f29 iz = f29_inv<P>(acc.zzz);                            // 1/ZZZ
+    f29 t = f29_mul<P>(acc.zz, iz);                          // ZZ/ZZZ = 1/Z
+    f29 ax = f29_mul<P>(acc.x, f29_sqr<P>(t));               // X/ZZ
+    f29 ay = f29_mul<P>(acc.y, iz);                          // Y/ZZZ
+    f29_to_words(f29_reduce_with<P>(ax, P::r256), ow);
+    f29_to_words(f29_reduce_with<P>(ay, P::r256), ow + 8);
   }
-  fp_store(&out[i].x, r.x);
-  fp_store(&out[i].y, r.y);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[i].q[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
 }
 
 // ------------------------------------------------------------------ host driver
@@ -486,7 +514,7 @@ __global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_t* __restrict_
 MsmEngine::~MsmEngine() { release(); }
 
 void MsmEngine::release() {
-  dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
+  win_words_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_acc_[i].release(); red_run_[i].release();
   }
@@ -506,9 +534,9 @@ uint32_t MsmEngine::window_bits_for(size_t n) const {
 
 hipError_t MsmEngine::init() {
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                              128 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -528,7 +556,7 @@ static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, 
   return hipGetLastError();
 }
 
-hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_t n, hipStream_t stream,
+hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream,
                           uint8_t out_affine[64], MsmTimings* tm) {
   if (tm) *tm = MsmTimings{};
   if (n == 0) {
@@ -562,7 +590,8 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   }
   SG_TRY(meta_.reserve(16));
   if (!h_meta_) SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t)));
-  if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * sizeof(g1_xyzz)));
+  if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * 32 * sizeof(uint32_t)));
+  SG_TRY(win_words_.reserve(64 * 32));
 
   hipEvent_t ev[5];
   if (tm) {
@@ -604,7 +633,7 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   }
   msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, d_bases, off_.p, counts_.p, toff_[0].p, order_.p,
                                                            log_L, ntasks, partial_[0].p);
-  const g1_xyzz* cur = partial_[0].p;
+  const xyzz29_mem* cur = partial_[0].p;
   int lvl = 0, pbuf = 0;
   // heavy buckets: fold their partial sums until every bucket owns at most one
   for (uint32_t max_items = (max_cnt + (1u << log_L) - 1) >> log_L; max_items > 1;
@@ -632,7 +661,7 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
     SG_TRY(red_acc_[i].reserve((size_t)W * blocks));
     SG_TRY(red_run_[i].reserve((size_t)W * blocks));
   }
-  size_t lds = (size_t)threads * 2 * sizeof(g1_xyzz);
+  size_t lds = (size_t)threads * 2 * sizeof(xyzz29_mem);
   msm_reduce_buckets<<<dim3(blocks, W), threads, lds, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, nbw, log_G,
                                                                  red_acc_[0].p, red_run_[0].p);
   uint32_t log_M = log_G;
@@ -646,13 +675,14 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
     threads = 64;
     while (threads < items && threads < 256) threads <<= 1;
     blocks = (items + threads - 1) / threads;
-    lds = (size_t)threads * 2 * sizeof(g1_xyzz);
+    lds = (size_t)threads * 2 * sizeof(xyzz29_mem);
     msm_reduce_items<<<dim3(blocks, W), threads, lds, stream>>>(red_acc_[src].p, red_run_[src].p, items, log_M,
                                                                  red_acc_[1 - src].p, red_run_[1 - src].p);
     src = 1 - src;
   }
   if (tm) SG_TRY(hipEventRecord(ev[4], stream));
-  SG_TRY(hipMemcpyAsync(h_win_, red_acc_[src].p, sizeof(g1_xyzz) * W, hipMemcpyDeviceToHost, stream));
+  msm_export_windows<<<1, 64, 0, stream>>>(red_acc_[src].p, W, win_words_.p);
+  SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 32 * W, hipMemcpyDeviceToHost, stream));
   SG_TRY(hipStreamSynchronize(stream));
 
   // Horner over the window sums, high to low
@@ -661,10 +691,10 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   for (int j = (int)W - 1; j >= 0; j--) {
     for (uint32_t k = 0; k < c; k++) total = jac_double(total);
     Fq x, y, zz, zzz;
-    std::memcpy(x.v, &h_win_[j].x, 32);
-    std::memcpy(y.v, &h_win_[j].y, 32);
-    std::memcpy(zz.v, &h_win_[j].zz, 32);
-    std::memcpy(zzz.v, &h_win_[j].zzz, 32);
+    std::memcpy(x.v, h_win_ + 32 * j, 32);
+    std::memcpy(y.v, h_win_ + 32 * j + 8, 32);
+    std::memcpy(zz.v, h_win_ + 32 * j + 16, 32);
+    std::memcpy(zzz.v, h_win_ + 32 * j + 24, 32);
     total = jac_add(total, jac_from_xyzz(x, y, zz, zzz));
   }
   jac_to_affine_bytes(total, out_affine);
@@ -685,7 +715,7 @@ hipError_t MsmEngine::run(const fp_t* d_scalars, const g1_affine* d_bases, size_
   return hipSuccess;
 }
 
-hipError_t fixed_base_mul(const fp_t* d_scalars, size_t n, g1_affine* d_out, hipStream_t stream) {
+hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream) {
   if (!n) return hipSuccess;
   g1_fixed_base_mul<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, d_out);
   return hipGetLastError();

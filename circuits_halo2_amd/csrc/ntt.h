@@ -5,7 +5,7 @@
 #include <deque>
 #include <vector>
 
-#include "bn254_field.cuh"
+#include "bn254_curve29.cuh"
 
 namespace sg {
 
@@ -16,15 +16,22 @@ struct NttConfig {
   uint32_t threads = 1024;       // one butterfly per thread per stage at tile_log = 11
 };
 
+#ifndef SG_WORDS8
+#define SG_WORDS8
+struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host side
+  uint32_t l[8];
+};
+#endif
+
 struct NttPlan {
   uint32_t log_n;
-  fp_t omega;
-  fp_t scale;
+  words8 omega;
+  words8 scale;
   bool has_scale;
   int npass;
   uint32_t l[3];      // log2 of the per-pass DFT lengths n1, n2, n3 (n = n1*n2*n3)
-  fp_t* tw_local[3];  // powers of omega_{n_i}
-  fp_t* tw_pass[3];   // inter-pass twiddles in output order
+  fp_words* tw_local[3];  // powers of omega_{n_i} (2^261 domain)
+  fp_words* tw_pass[3];   // inter-pass twiddles in output order (2^261 domain)
 };
 
 class NttEngine {
@@ -35,25 +42,26 @@ class NttEngine {
   NttConfig& config() { return cfg_; }
   // out = DFT_omega(pre3 .* zero-extend(in)) .* post3 (* scale); `in == out` allowed (then
   // `scratch` of 2^log_n elements is used for multi-pass plans).
-  hipError_t transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* scratch, uint32_t log_n, const fp_t& omega,
-                       const fp_t* scale, const fp_t* pre3, const fp_t* post3, hipStream_t stream);
+  hipError_t transform(const fp_words* in, size_t in_len, fp_words* out, fp_words* scratch, uint32_t log_n,
+                       const words8& omega, const words8* scale, const words8* pre3, const words8* post3,
+                       hipStream_t stream);
 
  private:
   struct LocalTw {
     uint32_t log_r;
-    fp_t omega_r;
-    fp_t* tw;
+    words8 omega_r;
+    fp_words* tw;
   };
-  hipError_t get_plan(uint32_t log_n, const fp_t& omega, const fp_t* scale, hipStream_t stream, const NttPlan** out);
-  hipError_t local_twiddles(const fp_t& omega_r, uint32_t log_r, hipStream_t stream, fp_t** out);
+  hipError_t get_plan(uint32_t log_n, const words8& omega, const words8* scale, hipStream_t stream, const NttPlan** out);
+  hipError_t local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out);
   NttConfig cfg_;
   std::deque<NttPlan> plans_;
   std::vector<LocalTw> local_tw_;
 };
 
-__global__ void pow_single(fp_t* out, fp_t w, uint64_t e);
-hipError_t ntt_scale(fp_t* a, const fp_t& s, size_t n, hipStream_t stream);
-hipError_t ntt_scale_periodic(fp_t* a, const fp_t* tab, uint32_t period, size_t n, hipStream_t stream);
-hipError_t fr_montgomery(const fp_t* in, fp_t* out, size_t n, int to_mont, hipStream_t stream);
+__global__ void pow_single(fp_words* out, words8 w, uint64_t e);
+hipError_t ntt_scale(fp_words* a, const words8& s, size_t n, hipStream_t stream);
+hipError_t ntt_scale_periodic(fp_words* a, const fp_words* tab, uint32_t period, size_t n, hipStream_t stream);
+hipError_t fr_montgomery(const fp_words* in, fp_words* out, size_t n, int to_mont, hipStream_t stream);
 
 }  // namespace sg

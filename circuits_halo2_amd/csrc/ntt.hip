@@ -22,46 +22,60 @@
 namespace sg {
 
 // ------------------------------------------------------------------ device kernels
+// Arithmetic: 9 x 29-bit limbs (bn254_f29.cuh).  Data stays in the Montgomery-2^256 domain it
+// is stored in; twiddle tables hold w^ = w * 2^261 mod r (as canonical 8 x u32 words), so
+// f29_mul(x~, w^) = (x w)~.  Inside a pass additions are lazy (bound grows by 2 per stage,
+// <= 25 after 10 stages); every pass ends with one product per element (inter-pass twiddle,
+// post-scale, or 1^) which brings the value below 2r, then a conditional subtraction makes it
+// canonical for the 32-byte store.
 struct PassArgs {
-  const fp_t* in;
-  fp_t* out;
-  const fp_t* tw_local;  // omega_R^k, k < R/2
-  const fp_t* tw_pass;   // per-element twiddle in output order (nullptr: none)
-  uint32_t log_r;        // log2 R  (DFT length of this pass)
-  uint32_t log_t;        // log2 T  (contiguous columns per tile)
-  uint32_t log_b;        // log2 B  (contiguous inner extent)
-  uint32_t kind;         // 0: in-place-like (Y), 1: transposing first pass (X)
-  uint32_t sig_lo;       // X only: b = lo + 2^sig_lo * hi  ->  b' = hi + 2^sig_hi * lo
+  const fp_words* in;
+  fp_words* out;
+  const fp_words* tw_local;  // w_R^k in the 2^261 domain, k < R/2
+  const fp_words* tw_pass;   // per-element twiddle in output order (nullptr: none)
+  uint32_t log_r;            // log2 R  (DFT length of this pass)
+  uint32_t log_t;            // log2 T  (contiguous columns per tile)
+  uint32_t log_b;            // log2 B  (contiguous inner extent)
+  uint32_t kind;             // 0: in-place-like (Y), 1: transposing first pass (X)
+  uint32_t sig_lo;           // X only: b = lo + 2^sig_lo * hi  ->  b' = hi + 2^sig_hi * lo
   uint32_t sig_hi;
-  uint32_t in_len;       // elements present in `in`; beyond that the input reads as zero
-  uint32_t pre3;         // multiply input i by pre[i % 3]   (coeff_to_extended)
-  uint32_t post3;        // multiply output j by post[j % 3] (extended_to_coeff / plain scale)
-  fp_t pre[3];
-  fp_t post[3];
+  uint32_t in_len;           // elements present in `in`; beyond that the input reads as zero
+  uint32_t pre3;             // multiply input i by pre[i % 3]   (coeff_to_extended)
+  uint32_t post3;            // multiply output j by post[j % 3] (extended_to_coeff / plain scale)
+  uint32_t pre[3][8];        // Montgomery-2^256 words, converted once per workgroup
+  uint32_t post[3][8];
 };
 
-__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, uint32_t i, const fp_t& v) {
-  lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-  hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+struct LdsTile {
+  uint4* lo;
+  uint4* hi;
+  uint32_t* top;
+};
+__device__ __forceinline__ void lds_put(const LdsTile& t, uint32_t i, const f29& v) {
+  t.lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  t.hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  t.top[i] = v.l[8];
 }
-__device__ __forceinline__ fp_t lds_get(const uint4* lo, const uint4* hi, uint32_t i) {
-  uint4 a = lo[i], b = hi[i];
-  fp_t r;
+__device__ __forceinline__ f29 lds_get(const LdsTile& t, uint32_t i) {
+  uint4 a = t.lo[i], b = t.hi[i];
+  f29 r;
   r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
   r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = t.top[i];
   return r;
 }
 
 // One pass.  grid.x = number of tiles = (2^log_b / T) * A  where A = n / (B*R).
-// Dynamic LDS: (T*R + R/2) * 32 bytes.
+// Dynamic LDS: (T*R + R/2 + 8) * 36 bytes.
 __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
   extern __shared__ uint4 lds[];
+  typedef Fr29 P;
   const uint32_t R = 1u << p.log_r, T = 1u << p.log_t;
-  const uint32_t E = R << p.log_t;
-  uint4* d_lo = lds;
-  uint4* d_hi = lds + E;
-  uint4* w_lo = lds + 2 * E;
-  uint4* w_hi = w_lo + (R >> 1);
+  const uint32_t E = R << p.log_t, H = (R >> 1) + 8;  // twiddles + 6 converted constants
+  LdsTile d{lds, lds + E, reinterpret_cast<uint32_t*>(lds + 2 * E)};
+  uint4* wbase = lds + 2 * E + ((E + 3) >> 2);
+  LdsTile w{wbase, wbase + H, reinterpret_cast<uint32_t*>(wbase + 2 * H)};
+  const uint32_t CONST0 = R >> 1;  // w-tile slots CONST0.. hold pre[0..2], post[0..2] in the 2^261 domain
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
 
   const uint32_t tiles_per_row = 1u << (p.log_b - p.log_t);
@@ -69,29 +83,34 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
   const uint32_t b0 = (blockIdx.x & (tiles_per_row - 1)) << p.log_t;
   const size_t base = ((size_t)a << (p.log_b + p.log_r)) + b0;
 
-  // stage the local twiddles
-  for (uint32_t k = tid; k < (R >> 1); k += nthr) {
-    fp_t w = fp_load(p.tw_local + k);
-    lds_put(w_lo, w_hi, k, w);
+  // stage the local twiddles (already 2^261-domain words) and convert the scale constants
+  for (uint32_t k = tid; k < (R >> 1); k += nthr) lds_put(w, k, f29_load_r256<P>(p.tw_local + k));
+  if (tid < 6 && ((tid < 3) ? p.pre3 : p.post3)) {
+    const uint32_t* src = tid < 3 ? p.pre[tid] : p.post[tid - 3];
+    uint32_t tmp[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) tmp[i] = src[i];
+    lds_put(w, CONST0 + tid, f29_words_to_r261<P>(tmp));
   }
+  if (p.pre3) __syncthreads();
   // load the tile: rows are bit-reversed on the way in so that the DIT stages below leave
   // natural order
   const uint32_t rshift = 32 - p.log_r;
   for (uint32_t e = tid; e < E; e += nthr) {
     uint32_t t = e & (T - 1), r = e >> p.log_t;
     size_t gi = base + t + ((size_t)r << p.log_b);
-    fp_t v;
+    f29 v;
     if (gi < p.in_len) {
-      v = fp_load(p.in + gi);
+      v = f29_load_r256<P>(p.in + gi);
       if (p.pre3) {
         uint32_t m = (uint32_t)(gi % 3);
-        if (m) v = fp_mul<FrP>(v, p.pre[m]);
+        if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
       }
     } else {
-      v = fp_zero<FrP>();
+      v = f29_zero();
     }
     uint32_t rr = p.log_r ? (__brev(r) >> rshift) : 0;
-    lds_put(d_lo, d_hi, (rr << p.log_t) + t, v);
+    lds_put(d, (rr << p.log_t) + t, v);
   }
   __syncthreads();
 
@@ -103,27 +122,36 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       uint32_t j = pr & (h - 1), blk = pr >> s;
       uint32_t row = (blk << (s + 1)) + j;
       uint32_t i0 = (row << p.log_t) + t, i1 = i0 + (h << p.log_t);
-      fp_t u = lds_get(d_lo, d_hi, i0);
-      fp_t v = lds_get(d_lo, d_hi, i1);
-      if (j) {  // omega^0 butterflies skip the product, as best_fft does
-        fp_t w = lds_get(w_lo, w_hi, j << (p.log_r - s - 1));
-        v = fp_mul<FrP>(v, w);
+      f29 u = lds_get(d, i0);
+      f29 v = lds_get(d, i1);
+      if (s < 2 && j == 0) {
+        // w^0 butterflies of the first two stages skip the product (as best_fft does):
+        // bounds 1 -> 3 (stage 0) and 3 -> 7 (stage 1)
+        lds_put(d, i0, f29_add(u, v));
+        lds_put(d, i1, s == 0 ? f29_sub<P, 0>(u, v) : f29_sub<P, 1>(u, v));
+      } else {
+        v = f29_mul<P>(v, lds_get(w, j << (p.log_r - s - 1)));  // bound(v) <= 25, twiddle canonical
+        lds_put(d, i0, f29_add(u, v));
+        lds_put(d, i1, f29_sub<P, 0>(u, v));
       }
-      lds_put(d_lo, d_hi, i0, fp_add<FrP>(u, v));
-      lds_put(d_lo, d_hi, i1, fp_sub<FrP>(u, v));
     }
     __syncthreads();
   }
 
-  // write back
+  // write back: one closing product per element, then canonical 32-byte store
+  const f29 one = f29_one<P>();
   if (p.kind == 0) {
     for (uint32_t e = tid; e < E; e += nthr) {
       uint32_t t = e & (T - 1), r = e >> p.log_t;
       size_t go = base + t + ((size_t)r << p.log_b);
-      fp_t v = lds_get(d_lo, d_hi, e);
-      if (p.tw_pass) v = fp_mul<FrP>(v, fp_load(p.tw_pass + go));
-      if (p.post3) v = fp_mul<FrP>(v, p.post[go % 3]);
-      fp_store(p.out + go, v);
+      f29 v = lds_get(d, e);
+      if (p.tw_pass) {
+        v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
+        if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
+      } else {
+        v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
+      }
+      f29_store_canonical<P>(p.out + go, v);
     }
   } else {
     for (uint32_t e = tid; e < E; e += nthr) {
@@ -131,26 +159,32 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       uint32_t b = b0 + t;
       uint32_t bp = (b >> p.sig_lo) + ((b & ((1u << p.sig_lo) - 1)) << p.sig_hi);
       size_t go = ((size_t)bp << p.log_r) + r;
-      fp_t v = lds_get(d_lo, d_hi, (r << p.log_t) + t);
-      if (p.tw_pass) v = fp_mul<FrP>(v, fp_load(p.tw_pass + go));
-      if (p.post3) v = fp_mul<FrP>(v, p.post[go % 3]);
-      fp_store(p.out + go, v);
+      f29 v = lds_get(d, (r << p.log_t) + t);
+      if (p.tw_pass) {
+        v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
+        if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
+      } else {
+        v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
+      }
+      f29_store_canonical<P>(p.out + go, v);
     }
   }
 }
 
-// tw[k] = w^k for k < count
-__global__ void fill_powers(fp_t* tw, fp_t w, uint32_t count) {
+// tw[k] = (w^k)^ for k < count; w given as Montgomery-2^256 words
+__global__ void fill_powers(fp_words* tw, words8 w, uint32_t count) {
+  typedef Fr29 P;
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < count) fp_store(tw + k, fp_pow_u64<FrP>(w, k));
+  if (k < count) f29_store_canonical<P>(tw + k, f29_pow_u64<P>(f29_words_to_r261<P>(w.l), k));
 }
 
 // inter-pass twiddle tables, in the output order of the pass they are applied in
 //  mode 0 (2-pass, pass X):   idx = j2 + n2*i1            -> w^(i1*j2) * scale
 //  mode 1 (3-pass, pass A):   idx = j3 + n3*(i2 + n2*i1)  -> w^(n1*i2*j3) * scale
 //  mode 2 (3-pass, pass B):   idx = j3 + n3*j2 + n2n3*i1  -> w^(i1*(j3 + n3*j2))
-__global__ void fill_pass_twiddles(fp_t* tw, fp_t w, fp_t scale, uint32_t has_scale, uint32_t mode,
+__global__ void fill_pass_twiddles(fp_words* tw, words8 w, words8 scale, uint32_t has_scale, uint32_t mode,
                                    uint32_t l1, uint32_t l2, uint32_t l3, uint32_t log_n) {
+  typedef Fr29 P;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >> log_n) return;
   uint64_t e;
@@ -165,30 +199,50 @@ __global__ void fill_pass_twiddles(fp_t* tw, fp_t w, fp_t scale, uint32_t has_sc
     e = i1 * jj;
   }
   e &= (1ull << log_n) - 1;
-  fp_t v = fp_pow_u64<FrP>(w, e);
-  if (has_scale) v = fp_mul<FrP>(v, scale);
-  fp_store(tw + idx, v);
+  f29 v = f29_pow_u64<P>(f29_words_to_r261<P>(w.l), e);
+  if (has_scale) v = f29_mul<P>(v, f29_words_to_r261<P>(scale.l));
+  f29_store_canonical<P>(tw + idx, v);
+}
+// out = w^e as Montgomery-2^256 words (host-visible domain constants)
+__global__ void pow_single(fp_words* out, words8 w, uint64_t e) {
+  typedef Fr29 P;
+  f29 v = f29_pow_u64<P>(f29_words_to_r261<P>(w.l), e);
+  uint32_t o[8];
+  f29_to_words(f29_reduce_with<P>(v, P::r256), o);
+  fp_words_store(out, o);
 }
 
-__global__ void scale_kernel(fp_t* a, fp_t s, size_t n) {
+__global__ void scale_kernel(fp_words* a, words8 s, size_t n) {
+  typedef Fr29 P;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) fp_store(a + i, fp_mul<FrP>(fp_load(a + i), s));
+  if (i < n) f29_store_canonical<P>(a + i, f29_mul<P>(f29_load_r256<P>(a + i), f29_words_to_r261<P>(s.l)));
 }
-// a[i] *= tab[i & (period-1)]   (divide_by_vanishing_poly; period = 2^(ext_k-k))
-__global__ void scale_periodic_kernel(fp_t* a, const fp_t* tab, uint32_t period, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) fp_store(a + i, fp_mul<FrP>(fp_load(a + i), fp_load(tab + (i & (period - 1)))));
-}
-__global__ void to_mont_kernel(const fp_t* in, fp_t* out, size_t n, int dir) {
+// a[i] *= tab[i & (period-1)]   (divide_by_vanishing_poly; period = 2^(ext_k-k)); tab in the
+// 2^256 domain like the data
+__global__ void scale_periodic_kernel(fp_words* a, const fp_words* tab, uint32_t period, size_t n) {
+  typedef Fr29 P;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    fp_t v = fp_load(in + i);
-    fp_store(out + i, dir ? fp_to_mont<FrP>(v) : fp_from_mont<FrP>(v));
+    uint32_t t[8];
+    fp_words_load(tab + (i & (period - 1)), t);
+    f29_store_canonical<P>(a + i, f29_mul<P>(f29_load_r256<P>(a + i), f29_words_to_r261<P>(t)));
+  }
+}
+// dir = 1: canonical integers -> Montgomery-2^256 (x * 2^517 * 2^-261); dir = 0: the inverse
+// (x~ * 2^5 * 2^-261)
+__global__ void to_mont_kernel(const fp_words* in, fp_words* out, size_t n, int dir) {
+  typedef Fr29 P;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    f29 k = f29_zero();
+    k.l[0] = 32;
+    if (dir) k = f29_const<P>(P::r517);
+    f29_store_canonical<P>(out + i, f29_mul<P>(f29_load_r256<P>(in + i), k));
   }
 }
 
 // ------------------------------------------------------------------ host side
-static bool fp_host_eq(const fp_t& a, const fp_t& b) { return std::memcmp(&a, &b, sizeof(fp_t)) == 0; }
+static bool fp_host_eq(const words8& a, const words8& b) { return std::memcmp(&a, &b, sizeof(words8)) == 0; }
 
 NttEngine::~NttEngine() { clear(); }
 
@@ -203,7 +257,7 @@ void NttEngine::clear() {
   local_tw_.clear();
 }
 
-hipError_t NttEngine::local_twiddles(const fp_t& omega_r, uint32_t log_r, hipStream_t stream, fp_t** out) {
+hipError_t NttEngine::local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out) {
   for (auto& e : local_tw_) {
     if (e.log_r == log_r && fp_host_eq(e.omega_r, omega_r)) {
       *out = e.tw;
@@ -211,8 +265,8 @@ hipError_t NttEngine::local_twiddles(const fp_t& omega_r, uint32_t log_r, hipStr
     }
   }
   uint32_t count = log_r ? (1u << (log_r - 1)) : 1;
-  fp_t* d = nullptr;
-  hipError_t err = hipMalloc(&d, sizeof(fp_t) * count);
+  fp_words* d = nullptr;
+  hipError_t err = hipMalloc(&d, sizeof(fp_words) * count);
   if (err != hipSuccess) return err;
   fill_powers<<<(count + 255) / 256, 256, 0, stream>>>(d, omega_r, count);
   local_tw_.push_back({log_r, omega_r, d});
@@ -238,7 +292,7 @@ static void factor(uint32_t log_n, uint32_t max_single, uint32_t max_multi, int*
   }
 }
 
-hipError_t NttEngine::get_plan(uint32_t log_n, const fp_t& omega, const fp_t* scale, hipStream_t stream,
+hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8* scale, hipStream_t stream,
                                const NttPlan** out) {
   for (auto& pl : plans_) {
     if (pl.log_n == log_n && fp_host_eq(pl.omega, omega) && pl.has_scale == (scale != nullptr) &&
@@ -257,34 +311,34 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const fp_t& omega, const fp_t* sc
   hipError_t err;
   // omega_R for a length-R sub-transform is omega^(n/R): square omega (log_n - log_r) times
   // on the device via fill_powers' pow (host has no field arithmetic on purpose)
-  auto omega_pow2 = [&](uint32_t times, fp_t* res) -> hipError_t {
-    fp_t* d = nullptr;
-    hipError_t e = hipMalloc(&d, sizeof(fp_t) * 2);
+  auto omega_pow2 = [&](uint32_t times, words8* res) -> hipError_t {
+    fp_words* d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(fp_words) * 2);
     if (e != hipSuccess) return e;
     // fill_powers computes w^k; k = 2^times fits 32 bits (times <= 28)
     pow_single<<<1, 1, 0, stream>>>(d, omega, 1ull << times);
-    e = hipMemcpyAsync(res, d, sizeof(fp_t), hipMemcpyDeviceToHost, stream);
+    e = hipMemcpyAsync(res, d, sizeof(fp_words), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     return e;
   };
   for (int i = 0; i < pl.npass; i++) {
-    fp_t wr;
+    words8 wr;
     err = omega_pow2(log_n - pl.l[i], &wr);
     if (err != hipSuccess) return err;
     err = local_twiddles(wr, pl.l[i], stream, &pl.tw_local[i]);
     if (err != hipSuccess) return err;
   }
-  fp_t one_or_scale = scale ? *scale : omega;  // placeholder when unused
+  words8 one_or_scale = scale ? *scale : omega;  // placeholder when unused
   if (pl.npass == 2) {
-    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_t) * n);
+    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
     fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
                                                                          scale ? 1 : 0, 0, pl.l[0], pl.l[1], 0, log_n);
   } else if (pl.npass == 3) {
-    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_t) * n);
+    err = hipMalloc(&pl.tw_pass[0], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
-    err = hipMalloc(&pl.tw_pass[1], sizeof(fp_t) * n);
+    err = hipMalloc(&pl.tw_pass[1], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
     fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
                                                                          scale ? 1 : 0, 1, pl.l[0], pl.l[1], pl.l[2], log_n);
@@ -301,7 +355,6 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const fp_t& omega, const fp_t* sc
   return hipSuccess;
 }
 
-__global__ void pow_single(fp_t* out, fp_t w, uint64_t e) { fp_store(out, fp_pow_u64<FrP>(w, e)); }
 
 static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n, hipStream_t stream) {
   // tile width: as many contiguous columns as the LDS budget allows
@@ -310,7 +363,7 @@ static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n,
   uint32_t log_t = std::min<uint32_t>(log_e - a.log_r, a.log_b);
   a.log_t = log_t;
   size_t E = (size_t)1 << (a.log_r + log_t);
-  size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 1) * 32;
+  size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 8) * 36 + 64;
   uint32_t threads = (uint32_t)std::min<size_t>(cfg.threads, std::max<size_t>(64, E / 2));
   uint32_t tiles = 1u << (log_n - a.log_r - log_t);
   hipLaunchKernelGGL(ntt_pass, dim3(tiles), dim3(threads), lds, stream, a);
@@ -323,8 +376,8 @@ hipError_t NttEngine::init() {
                              160 * 1024);
 }
 
-hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* scratch, uint32_t log_n,
-                                const fp_t& omega, const fp_t* scale, const fp_t* pre3, const fp_t* post3,
+hipError_t NttEngine::transform(const fp_words* in, size_t in_len, fp_words* out, fp_words* scratch, uint32_t log_n,
+                                const words8& omega, const words8* scale, const words8* pre3, const words8* post3,
                                 hipStream_t stream) {
   const NttPlan* pl;
   // a plain scale is folded into the first inter-pass twiddle table when there is one
@@ -332,7 +385,7 @@ hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* 
   hipError_t err = get_plan(log_n, omega, fold_scale ? scale : nullptr, stream, &pl);
   if (err != hipSuccess) return err;
   if (log_n == 0) {
-    if (in != out) err = hipMemcpyAsync(out, in, sizeof(fp_t), hipMemcpyDeviceToDevice, stream);
+    if (in != out) err = hipMemcpyAsync(out, in, sizeof(fp_words), hipMemcpyDeviceToDevice, stream);
     if (err == hipSuccess && scale && !post3) scale_kernel<<<1, 64, 0, stream>>>(out, *scale, 1);
     return err;
   }
@@ -342,14 +395,14 @@ hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* 
     a.post3 = 0;
     if (first && pre3) {
       a.pre3 = 1;
-      for (int i = 0; i < 3; i++) a.pre[i] = pre3[i];
+      for (int i = 0; i < 3; i++) std::memcpy(a.pre[i], pre3[i].l, 32);
     }
     if (last && post3) {
       a.post3 = 1;
-      for (int i = 0; i < 3; i++) a.post[i] = post3[i];
+      for (int i = 0; i < 3; i++) std::memcpy(a.post[i], post3[i].l, 32);
     } else if (last && scale && !fold_scale) {
       a.post3 = 1;
-      for (int i = 0; i < 3; i++) a.post[i] = *scale;
+      for (int i = 0; i < 3; i++) std::memcpy(a.post[i], scale->l, 32);
     }
   };
   const bool inplace = (in == out);
@@ -361,7 +414,7 @@ hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* 
   }
   if (pl->npass == 2) {
     const uint32_t l1 = pl->l[0], l2 = pl->l[1];
-    fp_t* mid = inplace ? scratch : out;
+    fp_words* mid = inplace ? scratch : out;
     // pass X: DFT over i2 (length n2, stride n1), columns i1 contiguous
     a.in = in; a.out = mid; a.tw_local = pl->tw_local[1]; a.tw_pass = pl->tw_pass[0];
     a.log_r = l2; a.log_b = l1; a.kind = 1; a.sig_lo = l1; a.sig_hi = 0;
@@ -376,7 +429,7 @@ hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* 
     return launch_pass(cfg_, a, log_n, stream);
   }
   const uint32_t l1 = pl->l[0], l2 = pl->l[1], l3 = pl->l[2];
-  fp_t* mid = inplace ? scratch : out;
+  fp_words* mid = inplace ? scratch : out;
   // pass A: DFT over i3 (length n3, stride n1 n2); writes j3 + n3*(i2 + n2*i1)
   a.in = in; a.out = mid; a.tw_local = pl->tw_local[2]; a.tw_pass = pl->tw_pass[0];
   a.log_r = l3; a.log_b = l1 + l2; a.kind = 1; a.sig_lo = l1; a.sig_hi = l2;
@@ -397,15 +450,15 @@ hipError_t NttEngine::transform(const fp_t* in, size_t in_len, fp_t* out, fp_t* 
   return launch_pass(cfg_, a, log_n, stream);
 }
 
-hipError_t ntt_scale(fp_t* a, const fp_t& s, size_t n, hipStream_t stream) {
+hipError_t ntt_scale(fp_words* a, const words8& s, size_t n, hipStream_t stream) {
   scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, s, n);
   return hipGetLastError();
 }
-hipError_t ntt_scale_periodic(fp_t* a, const fp_t* tab, uint32_t period, size_t n, hipStream_t stream) {
+hipError_t ntt_scale_periodic(fp_words* a, const fp_words* tab, uint32_t period, size_t n, hipStream_t stream) {
   scale_periodic_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, tab, period, n);
   return hipGetLastError();
 }
-hipError_t fr_montgomery(const fp_t* in, fp_t* out, size_t n, int to_mont, hipStream_t stream) {
+hipError_t fr_montgomery(const fp_words* in, fp_words* out, size_t n, int to_mont, hipStream_t stream) {
   if (!n) return hipSuccess;
   to_mont_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(in, out, n, to_mont);
   return hipGetLastError();

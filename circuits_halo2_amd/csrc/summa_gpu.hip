@@ -35,49 +35,58 @@ int hip_fail(const char* what, hipError_t e) {
     if (_e != hipSuccess) return hip_fail(what, _e); \
   } while (0)
 
-// BN254 Fr constants in Montgomery form (32-bit limbs)
+// BN254 Fr constants as Montgomery-2^256 words
 __device__ const uint32_t ROOT_OF_UNITY_M[8] = {0xb639feb8u, 0x9632c7c5u, 0x0d0ff299u, 0x985ce340u,
                                                 0x01b0ecd8u, 0xb2dd8800u, 0x6d98ce29u, 0x1d69070du};  // order 2^28
 __device__ const uint32_t ZETA_M[8] = {0x55fcd653u, 0x0363f299u, 0x5fc1e200u, 0x73e7950bu,
                                        0x576d9d24u, 0xc5fce83eu, 0xa1c3a4d4u, 0x059c805du};  // Fr::ZETA
 
-struct DomainConsts {
-  fp_t omega, omega_inv, n_inv, zeta, zeta2, ninv_zeta2, ninv_zeta, one;
+struct DomainConsts {  // all Montgomery-2^256 words
+  words8 omega, omega_inv, n_inv, zeta, zeta2, ninv_zeta2, ninv_zeta, one;
 };
-// EvaluationDomain::new constants for 2^k
+__device__ void put_words(words8* dst, const f29& v_r261) {
+  f29_to_words(f29_reduce_with<Fr29>(v_r261, Fr29::r256), dst->l);
+}
+// EvaluationDomain::new constants for 2^k (computed in the 2^261 domain, exported as words)
 __global__ void domain_kernel(uint32_t k, DomainConsts* out) {
-  fp_t w, z;
-  for (int i = 0; i < 8; i++) { w.l[i] = ROOT_OF_UNITY_M[i]; z.l[i] = ZETA_M[i]; }
-  for (uint32_t i = k; i < 28; i++) w = fp_sqr<FrP>(w);
-  fp_t n = fp_zero<FrP>();
-  n.l[k >> 5] = 1u << (k & 31);
-  fp_t ninv = fp_inv<FrP>(fp_to_mont<FrP>(n));
-  fp_t z2 = fp_sqr<FrP>(z);
-  out->omega = w;
-  out->omega_inv = fp_inv<FrP>(w);
-  out->n_inv = ninv;
-  out->zeta = z;
-  out->zeta2 = z2;
-  out->ninv_zeta2 = fp_mul<FrP>(ninv, z2);
-  out->ninv_zeta = fp_mul<FrP>(ninv, z);
-  out->one = fp_one<FrP>();
+  typedef Fr29 P;
+  uint32_t rw[8], zw[8];
+  for (int i = 0; i < 8; i++) { rw[i] = ROOT_OF_UNITY_M[i]; zw[i] = ZETA_M[i]; }
+  f29 w = f29_words_to_r261<P>(rw), z = f29_words_to_r261<P>(zw);
+  for (uint32_t i = k; i < 28; i++) w = f29_sqr<P>(w);
+  // 2^k in the 2^261 domain: canonical integer times 2^522 * 2^-261; build it by doubling 1^
+  f29 n = f29_one<P>();
+  for (uint32_t i = 0; i < k; i++) n = f29_cond_sub_p<P>(f29_normalize(f29_dbl(n)));
+  f29 ninv = f29_inv<P>(n);
+  f29 z2 = f29_sqr<P>(z);
+  put_words(&out->omega, w);
+  put_words(&out->omega_inv, f29_inv<P>(w));
+  put_words(&out->n_inv, ninv);
+  put_words(&out->zeta, z);
+  put_words(&out->zeta2, z2);
+  put_words(&out->ninv_zeta2, f29_mul<P>(ninv, z2));
+  put_words(&out->ninv_zeta, f29_mul<P>(ninv, z));
+  put_words(&out->one, f29_one<P>());
 }
 // t_evaluations[i] = 1 / ((zeta * omega_ext^i)^(2^k) - 1), i < 2^(ext_k - k)
-__global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, fp_t omega_ext, fp_t* out) {
+__global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, words8 omega_ext, fp_words* out) {
+  typedef Fr29 P;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> (ext_k - k)) return;
-  fp_t z;
-  for (int j = 0; j < 8; j++) z.l[j] = ZETA_M[j];
-  fp_t x = fp_mul<FrP>(z, fp_pow_u64<FrP>(omega_ext, i));
-  for (uint32_t s = 0; s < k; s++) x = fp_sqr<FrP>(x);
-  x = fp_sub<FrP>(x, fp_one<FrP>());
-  fp_store(out + i, fp_inv<FrP>(x));
+  uint32_t zw[8];
+  for (int j = 0; j < 8; j++) zw[j] = ZETA_M[j];
+  f29 x = f29_mul<P>(f29_words_to_r261<P>(zw), f29_pow_u64<P>(f29_words_to_r261<P>(omega_ext.l), i));
+  for (uint32_t s = 0; s < k; s++) x = f29_sqr<P>(x);
+  x = f29_sub<P, 0>(x, f29_one<P>());
+  uint32_t o[8];
+  f29_to_words(f29_reduce_with<P>(f29_inv<P>(f29_mul<P>(x, f29_one<P>())), P::r256), o);
+  fp_words_store(out + i, o);
 }
 
 struct Srs {
   uint32_t k;
-  g1_affine* g;
-  g1_affine* g_lagrange;
+  g1_affine_mem* g;
+  g1_affine_mem* g_lagrange;
 };
 
 struct Context {
@@ -88,7 +97,7 @@ struct Context {
   DevBuf<uint8_t> stage_a, stage_b, scratch;
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
-  std::map<uint64_t, fp_t*> t_evals;  // key = k << 32 | ext_k
+  std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
   std::map<uint64_t, Srs> srs;
   uint64_t next_handle = 1;
 };
@@ -145,15 +154,15 @@ int sync_own_stream_into(hipStream_t s) {
   return SG_OK;
 }
 
-int ntt_dev(const fp_t* in, size_t in_len, fp_t* out, uint32_t log_n, const fp_t& omega, const fp_t* scale,
-            const fp_t* pre3, const fp_t* post3, hipStream_t s) {
+int ntt_dev(const fp_words* in, size_t in_len, fp_words* out, uint32_t log_n, const words8& omega,
+            const words8* scale, const words8* pre3, const words8* post3, hipStream_t s) {
   Context& c = *g_ctx;
   if (log_n > 28) return fail(SG_ERR_INVALID, "log_n exceeds the 2-adicity (28) of BN254 Fr");
-  fp_t* scratch = nullptr;
+  fp_words* scratch = nullptr;
   if (in == out && log_n > c.ntt.config().max_single_log) {
     hipError_t e = c.scratch.reserve((size_t)32 << log_n);
     if (e != hipSuccess) return hip_fail("ntt scratch", e);
-    scratch = reinterpret_cast<fp_t*>(c.scratch.p);
+    scratch = reinterpret_cast<fp_words*>(c.scratch.p);
   }
   // plans are generated on the same stream the transform runs on
   hipError_t e = c.ntt.transform(in, in_len, out, scratch, log_n, omega, scale, pre3, post3, s);
@@ -246,7 +255,7 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
   if (!out_affine || (n && (!d_scalars || !d_bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
   LOCKED_CTX();
   MsmTimings tm;
-  hipError_t e = g_ctx->msm.run(static_cast<const fp_t*>(d_scalars), static_cast<const g1_affine*>(d_bases), n,
+  hipError_t e = g_ctx->msm.run(static_cast<const fp_words*>(d_scalars), static_cast<const g1_affine_mem*>(d_bases), n,
                                 pick_stream(stream), out_affine, timings ? &tm : nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
   if (timings) {
@@ -265,8 +274,8 @@ int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t ou
     LOCKED_CTX();
     TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
     TRY(upload(g_ctx->stage_b, bases, n * 64, g_ctx->stream));
-    hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p),
-                                  reinterpret_cast<const g1_affine*>(g_ctx->stage_b.p), n, g_ctx->stream, out_affine,
+    hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p),
+                                  reinterpret_cast<const g1_affine_mem*>(g_ctx->stage_b.p), n, g_ctx->stream, out_affine,
                                   nullptr);
     if (e != hipSuccess) return hip_fail("msm", e);
   }
@@ -317,7 +326,7 @@ int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t 
   auto it = g_ctx->srs.find(srs_handle);
   if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
   if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
-  hipError_t e = g_ctx->msm.run(static_cast<const fp_t*>(d_scalars), basis ? it->second.g_lagrange : it->second.g, n,
+  hipError_t e = g_ctx->msm.run(static_cast<const fp_words*>(d_scalars), basis ? it->second.g_lagrange : it->second.g, n,
                                 pick_stream(stream), out_affine, nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
   return SG_OK;
@@ -329,7 +338,7 @@ int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, 
   if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
   if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
-  hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p),
+  hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p),
                                 basis ? it->second.g_lagrange : it->second.g, n, g_ctx->stream, out_affine, nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
   return SG_OK;
@@ -339,9 +348,9 @@ int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, 
 int sg_ntt_fr_dev(void* d_a, const uint8_t omega[32], uint32_t log_n, void* stream) {
   if (!d_a || !omega) return fail(SG_ERR_INVALID, "sg_ntt_fr: null argument");
   LOCKED_CTX();
-  fp_t w;
+  words8 w;
   std::memcpy(&w, omega, 32);
-  fp_t* a = static_cast<fp_t*>(d_a);
+  fp_words* a = static_cast<fp_words*>(d_a);
   return ntt_dev(a, (size_t)1 << log_n, a, log_n, w, nullptr, nullptr, nullptr, pick_stream(stream));
 }
 int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n) {
@@ -349,19 +358,19 @@ int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n) {
   LOCKED_CTX();
   const size_t bytes = (size_t)32 << log_n;
   TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
-  fp_t w;
+  words8 w;
   std::memcpy(&w, omega, 32);
-  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  fp_words* d = reinterpret_cast<fp_words*>(g_ctx->stage_a.p);
   TRY(ntt_dev(d, (size_t)1 << log_n, d, log_n, w, nullptr, nullptr, nullptr, g_ctx->stream));
   return download(a, d, bytes, g_ctx->stream);
 }
 int sg_intt_fr_dev(void* d_a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n, void* stream) {
   if (!d_a || !omega_inv || !divisor) return fail(SG_ERR_INVALID, "sg_intt_fr: null argument");
   LOCKED_CTX();
-  fp_t w, d;
+  words8 w, d;
   std::memcpy(&w, omega_inv, 32);
   std::memcpy(&d, divisor, 32);
-  fp_t* a = static_cast<fp_t*>(d_a);
+  fp_words* a = static_cast<fp_words*>(d_a);
   return ntt_dev(a, (size_t)1 << log_n, a, log_n, w, &d, nullptr, nullptr, pick_stream(stream));
 }
 int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n) {
@@ -369,10 +378,10 @@ int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32
   LOCKED_CTX();
   const size_t bytes = (size_t)32 << log_n;
   TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
-  fp_t w, dv;
+  words8 w, dv;
   std::memcpy(&w, omega_inv, 32);
   std::memcpy(&dv, divisor, 32);
-  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  fp_words* d = reinterpret_cast<fp_words*>(g_ctx->stage_a.p);
   TRY(ntt_dev(d, (size_t)1 << log_n, d, log_n, w, &dv, nullptr, nullptr, g_ctx->stream));
   return download(a, d, bytes, g_ctx->stream);
 }
@@ -382,7 +391,7 @@ int sg_lagrange_to_coeff_dev(void* d_a, uint32_t k, void* stream) {
   const DomainConsts* dc;
   TRY(get_consts(k, &dc));
   TRY(sync_own_stream_into(pick_stream(stream)));
-  fp_t* a = static_cast<fp_t*>(d_a);
+  fp_words* a = static_cast<fp_words*>(d_a);
   return ntt_dev(a, (size_t)1 << k, a, k, dc->omega_inv, &dc->n_inv, nullptr, nullptr, pick_stream(stream));
 }
 int sg_lagrange_to_coeff(uint8_t* a, uint32_t k) {
@@ -392,7 +401,7 @@ int sg_lagrange_to_coeff(uint8_t* a, uint32_t k) {
   TRY(get_consts(k, &dc));
   const size_t bytes = (size_t)32 << k;
   TRY(upload(g_ctx->stage_a, a, bytes, g_ctx->stream));
-  fp_t* d = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  fp_words* d = reinterpret_cast<fp_words*>(g_ctx->stage_a.p);
   TRY(ntt_dev(d, (size_t)1 << k, d, k, dc->omega_inv, &dc->n_inv, nullptr, nullptr, g_ctx->stream));
   return download(a, d, bytes, g_ctx->stream);
 }
@@ -404,8 +413,8 @@ int sg_coeff_to_extended_dev(const void* d_coeffs, uint32_t k, uint32_t ext_k, v
   const DomainConsts* dc;
   TRY(get_consts(ext_k, &dc));
   TRY(sync_own_stream_into(pick_stream(stream)));
-  fp_t pre[3] = {dc->one, dc->zeta, dc->zeta2};
-  return ntt_dev(static_cast<const fp_t*>(d_coeffs), (size_t)1 << k, static_cast<fp_t*>(d_out), ext_k, dc->omega,
+  words8 pre[3] = {dc->one, dc->zeta, dc->zeta2};
+  return ntt_dev(static_cast<const fp_words*>(d_coeffs), (size_t)1 << k, static_cast<fp_words*>(d_out), ext_k, dc->omega,
                  nullptr, pre, nullptr, pick_stream(stream));
 }
 int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint8_t* out) {
@@ -416,8 +425,8 @@ int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint
   TRY(upload(g_ctx->stage_a, coeffs, (size_t)32 << k, g_ctx->stream));
   hipError_t e = g_ctx->stage_b.reserve((size_t)32 << ext_k);
   if (e != hipSuccess) return hip_fail("staging buffer", e);
-  fp_t pre[3] = {dc->one, dc->zeta, dc->zeta2};
-  TRY(ntt_dev(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p), (size_t)1 << k, reinterpret_cast<fp_t*>(g_ctx->stage_b.p),
+  words8 pre[3] = {dc->one, dc->zeta, dc->zeta2};
+  TRY(ntt_dev(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), (size_t)1 << k, reinterpret_cast<fp_words*>(g_ctx->stage_b.p),
               ext_k, dc->omega, nullptr, pre, nullptr, g_ctx->stream));
   return download(out, g_ctx->stage_b.p, (size_t)32 << ext_k, g_ctx->stream);
 }
@@ -428,8 +437,8 @@ int sg_extended_to_coeff_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stre
   TRY(get_consts(ext_k, &dc));
   TRY(sync_own_stream_into(pick_stream(stream)));
   // undo the coset: a[i] *= zeta^-(i mod 3) = {1, zeta^2, zeta}; the 2^-ext_k divisor rides along
-  fp_t post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
-  fp_t* a = static_cast<fp_t*>(d_ext);
+  words8 post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
+  fp_words* a = static_cast<fp_words*>(d_ext);
   return ntt_dev(a, (size_t)1 << ext_k, a, ext_k, dc->omega_inv, nullptr, nullptr, post, pick_stream(stream));
 }
 int sg_extended_to_coeff(uint8_t* ext, uint32_t k, uint32_t ext_k) {
@@ -439,13 +448,13 @@ int sg_extended_to_coeff(uint8_t* ext, uint32_t k, uint32_t ext_k) {
   TRY(get_consts(ext_k, &dc));
   const size_t bytes = (size_t)32 << ext_k;
   TRY(upload(g_ctx->stage_a, ext, bytes, g_ctx->stream));
-  fp_t post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
-  fp_t* a = reinterpret_cast<fp_t*>(g_ctx->stage_a.p);
+  words8 post[3] = {dc->n_inv, dc->ninv_zeta2, dc->ninv_zeta};
+  fp_words* a = reinterpret_cast<fp_words*>(g_ctx->stage_a.p);
   TRY(ntt_dev(a, (size_t)1 << ext_k, a, ext_k, dc->omega_inv, nullptr, nullptr, post, g_ctx->stream));
   return download(ext, a, bytes, g_ctx->stream);
 }
 
-static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_t** out) {
+static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_words** out) {
   Context& c = *g_ctx;
   uint64_t key = ((uint64_t)k << 32) | ext_k;
   auto it = c.t_evals.find(key);
@@ -453,8 +462,8 @@ static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_t** out) {
     const DomainConsts* dc;
     TRY(get_consts(ext_k, &dc));
     uint32_t cnt = 1u << (ext_k - k);
-    fp_t* d = nullptr;
-    CHECK_HIP(hipMalloc(&d, sizeof(fp_t) * cnt), "t_evaluations");
+    fp_words* d = nullptr;
+    CHECK_HIP(hipMalloc(&d, sizeof(fp_words) * cnt), "t_evaluations");
     t_eval_kernel<<<(cnt + 63) / 64, 64, 0, c.stream>>>(k, ext_k, dc->omega, d);
     CHECK_HIP(hipStreamSynchronize(c.stream), "t_evaluations");
     it = c.t_evals.emplace(key, d).first;
@@ -465,9 +474,9 @@ static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_t** out) {
 int sg_divide_by_vanishing_poly_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream) {
   if (!d_ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_divide_by_vanishing_poly: bad argument");
   LOCKED_CTX();
-  const fp_t* tab;
+  const fp_words* tab;
   TRY(t_eval_table(k, ext_k, &tab));
-  hipError_t e = ntt_scale_periodic(static_cast<fp_t*>(d_ext), tab, 1u << (ext_k - k), (size_t)1 << ext_k,
+  hipError_t e = ntt_scale_periodic(static_cast<fp_words*>(d_ext), tab, 1u << (ext_k - k), (size_t)1 << ext_k,
                                     pick_stream(stream));
   if (e != hipSuccess) return hip_fail("divide_by_vanishing_poly", e);
   return SG_OK;
@@ -475,11 +484,11 @@ int sg_divide_by_vanishing_poly_dev(void* d_ext, uint32_t k, uint32_t ext_k, voi
 int sg_divide_by_vanishing_poly(uint8_t* ext, uint32_t k, uint32_t ext_k) {
   if (!ext || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_divide_by_vanishing_poly: bad argument");
   LOCKED_CTX();
-  const fp_t* tab;
+  const fp_words* tab;
   TRY(t_eval_table(k, ext_k, &tab));
   const size_t bytes = (size_t)32 << ext_k;
   TRY(upload(g_ctx->stage_a, ext, bytes, g_ctx->stream));
-  hipError_t e = ntt_scale_periodic(reinterpret_cast<fp_t*>(g_ctx->stage_a.p), tab, 1u << (ext_k - k),
+  hipError_t e = ntt_scale_periodic(reinterpret_cast<fp_words*>(g_ctx->stage_a.p), tab, 1u << (ext_k - k),
                                     (size_t)1 << ext_k, g_ctx->stream);
   if (e != hipSuccess) return hip_fail("divide_by_vanishing_poly", e);
   return download(ext, g_ctx->stage_a.p, bytes, g_ctx->stream);
@@ -490,7 +499,7 @@ int sg_domain_constant(uint32_t k, int which, uint8_t out[32]) {
   LOCKED_CTX();
   const DomainConsts* dc;
   TRY(get_consts(k, &dc));
-  const fp_t* src = which == 0 ? &dc->omega : which == 1 ? &dc->omega_inv : which == 2 ? &dc->n_inv : &dc->zeta;
+  const words8* src = which == 0 ? &dc->omega : which == 1 ? &dc->omega_inv : which == 2 ? &dc->n_inv : &dc->zeta;
   std::memcpy(out, src, 32);
   return SG_OK;
 }
@@ -499,7 +508,7 @@ int sg_domain_constant(uint32_t k, int which, uint8_t out[32]) {
 int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, void* stream) {
   if (n && (!d_scalars || !d_out_affine)) return fail(SG_ERR_INVALID, "sg_g1_fixed_base_mul: null argument");
   LOCKED_CTX();
-  hipError_t e = fixed_base_mul(static_cast<const fp_t*>(d_scalars), n, static_cast<g1_affine*>(d_out_affine),
+  hipError_t e = fixed_base_mul(static_cast<const fp_words*>(d_scalars), n, static_cast<g1_affine_mem*>(d_out_affine),
                                 pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fixed_base_mul", e);
   return SG_OK;
@@ -510,7 +519,7 @@ int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) 
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
   hipError_t e = g_ctx->stage_b.reserve(n * 64 + 64);
   if (e != hipSuccess) return hip_fail("staging buffer", e);
-  e = fixed_base_mul(reinterpret_cast<const fp_t*>(g_ctx->stage_a.p), n, reinterpret_cast<g1_affine*>(g_ctx->stage_b.p),
+  e = fixed_base_mul(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, reinterpret_cast<g1_affine_mem*>(g_ctx->stage_b.p),
                      g_ctx->stream);
   if (e != hipSuccess) return hip_fail("fixed_base_mul", e);
   if (!n) return SG_OK;
@@ -519,14 +528,14 @@ int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) 
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
   if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
   LOCKED_CTX();
-  hipError_t e = fr_montgomery(static_cast<const fp_t*>(d_in), static_cast<fp_t*>(d_out), n, 1, pick_stream(stream));
+  hipError_t e = fr_montgomery(static_cast<const fp_words*>(d_in), static_cast<fp_words*>(d_out), n, 1, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_to_montgomery", e);
   return SG_OK;
 }
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
   if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
   LOCKED_CTX();
-  hipError_t e = fr_montgomery(static_cast<const fp_t*>(d_in), static_cast<fp_t*>(d_out), n, 0, pick_stream(stream));
+  hipError_t e = fr_montgomery(static_cast<const fp_words*>(d_in), static_cast<fp_words*>(d_out), n, 0, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_from_montgomery", e);
   return SG_OK;
 }
@@ -551,7 +560,7 @@ int sg_time_ntt_dev(void* d_a, uint32_t log_n, int reps, float* ms_out) {
   LOCKED_CTX();
   const DomainConsts* dc;
   TRY(get_consts(log_n, &dc));
-  fp_t* a = static_cast<fp_t*>(d_a);
+  fp_words* a = static_cast<fp_words*>(d_a);
   hipStream_t s = g_ctx->stream;
   TRY(ntt_dev(a, (size_t)1 << log_n, a, log_n, dc->omega, nullptr, nullptr, nullptr, s));  // warm plan + caches
   hipEvent_t e0, e1;

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Checks bn254_f29.cuh (compiled for the host) against Python integers."""
+import os, random, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyref as P
+M = (1 << 29) - 1
+exe = "/tmp/test_f29"
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools/test_f29.cpp")])
+def limbs(x): return [(x >> (29 * i)) & M if i < 8 else x >> (29 * i) for i in range(9)]
+def val(l): return sum(v << (29 * i) for i, v in enumerate(l))
+def lazy(x, rnd):
+    """a non-canonical limb vector with the same value: limbs < 2^29 + 4"""
+    l = limbs(x)
+    for i in range(8):
+        d = rnd.randrange(0, 4)
+        if l[i + 1] >= 1 and l[i] + (1 << 29) * 0 + d * 0 >= 0:
+            pass
+    return l
+rnd = random.Random(1)
+cases = []
+for fld, p in (("q", P.Q), ("r", P.R)):
+    R = 1 << 261
+    for _ in range(300):
+        ba, bb = rnd.choice([(1, 1), (2, 8), (13, 13), (32, 2), (10, 10), (170, 1)])
+        a, b = rnd.randrange(ba * p), rnd.randrange(bb * p)
+        if rnd.random() < 0.1: a = rnd.choice([0, p, 2 * p, p - 1, ba * p - 1])
+        cases.append(("mul", fld, limbs(a), limbs(b), ("mul", p, a, b)))
+        cases.append(("add", fld, limbs(a), limbs(b), ("add", p, a, b)))
+        a8, b8 = rnd.randrange(8 * p), rnd.randrange(8 * p)
+        cases.append(("sub8", fld, limbs(a8), limbs(b8), ("sub", p, a8, b8, 8)))
+        b2 = rnd.randrange(2 * p)
+        cases.append(("sub2", fld, limbs(a8), limbs(b2), ("sub", p, a8, b2, 2)))
+        b64 = rnd.randrange(64 * p)
+        cases.append(("sub64", fld, limbs(a8), limbs(b64), ("sub", p, a8, b64, 64)))
+        cases.append(("canon", fld, limbs(a), limbs(0), ("canon", p, a)))
+        z = rnd.choice([k * p for k in range(0, 65)] + [rnd.randrange(64 * p) for _ in range(8)] + [k * p + 1 for k in range(3)])
+        cases.append(("iszero", fld, limbs(z), limbs(0), ("iszero", p, z)))
+        x = rnd.randrange(p)
+        w = [(x >> (32 * i)) & 0xffffffff for i in range(8)] + [0]
+        cases.append(("from0", fld, w, limbs(0), ("from", x, 0)))
+        cases.append(("from5", fld, w, limbs(0), ("from", x, 5)))
+        cases.append(("towords", fld, limbs(x), limbs(0), ("towords", x)))
+inp = "\n".join(f"{op} {f} " + " ".join("%x" % v for v in a + b) for op, f, a, b, _ in cases) + "\n"
+out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+assert len(out) == len(cases)
+bad = 0
+for (op, f, a, b, exp), line in zip(cases, out):
+    l = [int(v, 16) for v in line.split()]
+    ok = True
+    if exp[0] == "mul":
+        _, p, x, y = exp
+        v = val(l)
+        ok = v % p == (x * y * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "add":
+        _, p, x, y = exp
+        ok = val(l) == x + y and all(t < (1 << 29) + 4 for t in l[:8])
+    elif exp[0] == "sub":
+        _, p, x, y, k = exp
+        ok = val(l) == x - y + k * p and all(t < (1 << 29) + 4 for t in l[:8])
+    elif exp[0] == "canon":
+        _, p, x = exp
+        ok = val(l) == x % p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "iszero":
+        _, p, z = exp
+        ok = l[0] == (1 if z % p == 0 else 0)
+    elif exp[0] == "from":
+        _, x, sh = exp
+        ok = val(l) == x << sh and all(t < (1 << 29) for t in l)
+    elif exp[0] == "towords":
+        ok = sum(v << (32 * i) for i, v in enumerate(l[:8])) == exp[1]
+    if not ok:
+        bad += 1
+        if bad < 10: print("FAIL", op, f, exp[:1], line)
+print("cases", len(cases), "bad", bad)
+sys.exit(1 if bad else 0)
