@@ -146,7 +146,7 @@ def main():
         # ---- CPU baseline: the oracle's restated halo2 best_multiexp on this box's cores
         if not args.no_cpu:
             from oracle import oracle as O
-            cores = O.ncpu()
+            cores = min(O.ncpu(), 16)  # the GPU box gives a 16-core share per GPU
             hs, hb = scal.cpu().numpy(), bases.cpu().numpy()
             t1 = time.perf_counter()
             ref = O.best_multiexp(hs, hb, cores)

@@ -15,8 +15,8 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
-  uint32_t log_seg = 8;        // L = 256 entries per accumulation task
-  uint32_t log_red_chunk = 3;  // G = 8 buckets per thread in the bucket reduction
+  uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
+  uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
 };
 
 struct MsmTimings {
@@ -62,10 +62,10 @@ class MsmEngine {
   DevBuf<uint2> order_;
   DevBuf<uint32_t> thist_;
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
-  DevBuf<xyzz29_mem> partial_[2], red_acc_[2], red_run_[2];
+  DevBuf<xyzz29_mem> partial_[2], red_a_[2], red_s_[2], red_r_[2];
   DevBuf<uint32_t> win_words_;
   uint32_t* h_meta_ = nullptr;
-  uint32_t* h_win_ = nullptr;  // W x 32 words: canonical X, Y, ZZ, ZZZ per window
+  uint32_t* h_win_ = nullptr;  // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window
 };
 
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream);

@@ -35,10 +35,18 @@ namespace sg {
 
 
 // ------------------------------------------------------------------ 1: signed digits
-// dig[j*n + i] = digit j of scalar i as int16: d in [-2^(c-1), 2^(c-1)) for j < W-1 and an
-// unsigned top digit.  Adding K = sum_{j<W-1} 2^(c-1) * 2^(jc) once makes every window's
-// digit independent of its neighbours: d_j = (((s + K) >> jc) & mask) - 2^(c-1).
-__global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+// Windows have individual widths (WindowPlan): W-1 signed windows of c or c-1 bits and an
+// unsigned top window of at most c-1 bits, widths summing to exactly 254, so every window
+// spreads its points over (almost) the same number of buckets -- a leftover-bits top window
+// would put n / 2^t points in each of its 2^t buckets.
+// dig[j*n + i] = digit j of scalar i as int16.  Adding K = sum_{j<W-1} 2^(o_j + w_j - 1)
+// once makes every window's digit independent of its neighbours:
+//   d_j = (((s + K) >> o_j) & (2^w_j - 1)) - 2^(w_j - 1)   in [-2^(w_j-1), 2^(w_j-1)).
+struct WindowPlan {
+  uint32_t W;
+  uint8_t width[64];
+};
+__global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, WindowPlan wp,
                            int16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -49,13 +57,18 @@ __global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, uin
     k.l[0] = 32;
     f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(scalars + i), k)), s.l);
   }
-  const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-  // s += K (K < 2^255, s < 2^254: no overflow out of 256 bits)
+  const uint32_t W = wp.W;
+  // s += K (K < 2^254, s < 2^254: no overflow out of 256 bits)
   {
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t o = 0;
     for (uint32_t j = 0; j + 1 < W; j++) {
-      uint32_t bit = j * c + c - 1;
-      k[bit >> 5] |= 1u << (bit & 31);
+      uint32_t bit = o + wp.width[j] - 1;
+      uint32_t m = 1u << (bit & 31);
+      uint32_t q = bit >> 5;
+#pragma unroll
+      for (int t = 0; t < 8; t++) k[t] |= (q == (uint32_t)t) ? m : 0u;
+      o += wp.width[j];
     }
     uint32_t carry = 0;
 #pragma unroll
@@ -66,11 +79,12 @@ __global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, uin
     }
   }
   for (uint32_t j = 0; j < W; j++) {
-    uint32_t v = s.l[0] & mask;
+    const uint32_t w = wp.width[j];
+    uint32_t v = s.l[0] & ((1u << w) - 1);
 #pragma unroll
-    for (int q = 0; q < 7; q++) s.l[q] = (s.l[q] >> c) | (s.l[q + 1] << (32 - c));
-    s.l[7] >>= c;
-    int32_t d = (j + 1 < W) ? (int32_t)v - (int32_t)half : (int32_t)v;
+    for (int q = 0; q < 7; q++) s.l[q] = (s.l[q] >> w) | (s.l[q + 1] << (32 - w));
+    s.l[7] >>= w;
+    int32_t d = (j + 1 < W) ? (int32_t)v - (int32_t)(1u << (w - 1)) : (int32_t)v;
     dig[(size_t)j * n + i] = (int16_t)d;
   }
 }
@@ -361,59 +375,58 @@ __global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ 
 }
 
 // ------------------------------------------------------------------ 5: bucket reduction
-// Items are (acc, run) pairs in bucket order; item t of a window stands for
-// acc_t + (t * M) * run_t.  A workgroup of N items produces one item of the next level:
-//   acc' = sum_t acc_t + M * sum_{t>=1} Suf_t,  run' = Suf_0,  Suf_t = sum_{u>=t} run_u.
-__device__ void block_combine(xyzz29 acc, xyzz29 run, uint32_t log_M, xyzz29_mem* sA, xyzz29_mem* sR,
-                              xyzz29_mem* out_acc, xyzz29_mem* out_run) {
-  const uint32_t tid = threadIdx.x, N = blockDim.x;
-  xyzz29_store(&sR[tid], run);
-  __syncthreads();
-  for (uint32_t d = 1; d < N; d <<= 1) {
-    xyzz29 other = xyzz29_identity();
-    if (tid + d < N) other = xyzz29_load(&sR[tid + d]);
-    __syncthreads();
-    xyzz29_add(run, other);
-    xyzz29_store(&sR[tid], run);
-    __syncthreads();
-  }
-  xyzz29 total = xyzz29_load(&sR[0]);
-  __syncthreads();
-  xyzz29_store(&sA[tid], acc);
-  if (tid == 0) xyzz29_store(&sR[0], xyzz29_identity());
-  __syncthreads();
-  // two tree reductions side by side: lower half of the threads folds sA, upper half sR
-  const uint32_t halfN = N >> 1;
-  xyzz29_mem* arr = (tid < halfN) ? sA : sR;
-  const uint32_t li = (tid < halfN) ? tid : tid - halfN;
-  for (uint32_t s = halfN; s >= 1; s >>= 1) {
-    if (li < s) {
+// Window sum = sum_b (b+1) * B_b.  No doublings run on the GPU: every level only adds, and
+// the power-of-two weights are applied by the host tail, where a dependent chain of point
+// doublings costs a fraction of a microsecond per step instead of several on one GPU lane.
+//
+// level 0: thread t of window j owns G = 2^log_G consecutive buckets: run_t = sum B,
+//          acc_t = sum (k+1) B_{first+k} (running sums).  A workgroup w of N threads emits
+//             A_w = sum_t acc_t,  S_w = sum_t t * run_t (= sum_{t>=1} Suf_t),  R_w = sum_t run_t
+//          so that  window = sum_w [ A_w + G * S_w + G * N * w * R_w ].
+// level 1: one workgroup per window:  A = sum A_w,  S = sum S_w,  T = sum_w w * R_w.
+// host:    window = A + 2^log_G * (S + 2^log_N * T).
+struct ReduceOut {
+  xyzz29_mem* a;
+  xyzz29_mem* s;
+  xyzz29_mem* r;
+};
+// tree-sum of arr[0..len) (len a power of two) by threads li = 0..len/2-1 of a group;
+// every thread of the workgroup must call it (barriers inside)
+__device__ __forceinline__ void tree_sum(xyzz29_mem* arr, uint32_t len, uint32_t li, bool member) {
+  for (uint32_t s = len >> 1; s >= 1; s >>= 1) {
+    if (member && li < s) {
       xyzz29 a = xyzz29_load(&arr[li]);
       xyzz29_add(a, xyzz29_load(&arr[li + s]));
       xyzz29_store(&arr[li], a);
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    xyzz29 sufsum = xyzz29_load(&sR[0]);
-    for (uint32_t k = 0; k < log_M; k++) sufsum = xyzz29_double(sufsum);
-    xyzz29 a = xyzz29_load(&sA[0]);
-    xyzz29_add(a, sufsum);
-    xyzz29_store(out_acc, a);
-    xyzz29_store(out_run, total);
+}
+// in-place suffix scan of arr[0..N) by N threads (Hillis-Steele)
+__device__ __forceinline__ xyzz29 suffix_scan(xyzz29_mem* arr, xyzz29 mine, uint32_t N, uint32_t tid) {
+  xyzz29_store(&arr[tid], mine);
+  __syncthreads();
+  for (uint32_t d = 1; d < N; d <<= 1) {
+    xyzz29 other = xyzz29_identity();
+    if (tid + d < N) other = xyzz29_load(&arr[tid + d]);
+    __syncthreads();
+    xyzz29_add(mine, other);
+    xyzz29_store(&arr[tid], mine);
+    __syncthreads();
   }
+  return mine;
 }
 
-// level 0: thread -> G = 2^log_G consecutive buckets of window blockIdx.y
+// level 0: grid (blocks, W), N = blockDim.x threads (power of two >= 64)
 __global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __restrict__ partial,
                                                           const uint32_t* __restrict__ toff,
                                                           const uint32_t* __restrict__ ntask, uint32_t nbw,
-                                                          uint32_t log_G, xyzz29_mem* __restrict__ out_acc,
-                                                          xyzz29_mem* __restrict__ out_run) {
+                                                          uint32_t log_G, ReduceOut out) {
   extern __shared__ uint4 smem[];
   xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
   xyzz29_mem* sR = sA + blockDim.x;
-  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = threadIdx.x, N = blockDim.x;
+  const uint32_t chunk = blockIdx.x * N + tid;
   const uint32_t G = 1u << log_G;
   xyzz29 acc = xyzz29_identity(), run = xyzz29_identity();
   const uint32_t first = chunk << log_G;
@@ -426,32 +439,65 @@ __global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __re
     }
   }
   const uint32_t o = blockIdx.y * gridDim.x + blockIdx.x;
-  block_combine(acc, run, log_G, sA, sR, out_acc + o, out_run + o);
-}
-// level >= 1: items from the previous level, `count` per window
-__global__ void __launch_bounds__(256) msm_reduce_items(const xyzz29_mem* __restrict__ in_acc,
-                                                        const xyzz29_mem* __restrict__ in_run, uint32_t count,
-                                                        uint32_t log_M, xyzz29_mem* __restrict__ out_acc,
-                                                        xyzz29_mem* __restrict__ out_run) {
-  extern __shared__ uint4 smem[];
-  xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
-  xyzz29_mem* sR = sA + blockDim.x;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  xyzz29 acc = xyzz29_identity(), run = xyzz29_identity();
-  if (t < count) {
-    acc = xyzz29_load(in_acc + blockIdx.y * count + t);
-    run = xyzz29_load(in_run + blockIdx.y * count + t);
+  xyzz29_store(&sA[tid], acc);
+  suffix_scan(sR, run, N, tid);            // sR[t] = Suf_t
+  if (tid == 0) {
+    xyzz29_store(out.r + o, xyzz29_load(&sR[0]));
+    xyzz29_store(&sR[0], xyzz29_identity());  // S sums t >= 1 only
   }
-  const uint32_t o = blockIdx.y * gridDim.x + blockIdx.x;
-  block_combine(acc, run, log_M, sA, sR, out_acc + o, out_run + o);
+  __syncthreads();
+  // two tree sums side by side: lower half of the threads folds sA, upper half sR
+  const uint32_t halfN = N >> 1;
+  xyzz29_mem* arr = (tid < halfN) ? sA : sR;
+  tree_sum(arr, N, (tid < halfN) ? tid : tid - halfN, true);
+  if (tid == 0) xyzz29_store(out.a + o, xyzz29_load(&sA[0]));
+  if (tid == halfN) xyzz29_store(out.s + o, xyzz29_load(&sR[0]));
 }
-// window sums -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ) for the host tail
-__global__ void msm_export_windows(const xyzz29_mem* __restrict__ in, uint32_t W, uint32_t* __restrict__ out) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= W) return;
+// level 1: grid (1, W), blockDim = 3 * T1 (T1 a power of two >= count): group 0 scans/folds
+// the R items, group 1 folds A, group 2 folds S
+__global__ void __launch_bounds__(768) msm_reduce_items(ReduceOut in, uint32_t count, uint32_t T1, ReduceOut out) {
+  extern __shared__ uint4 smem[];
+  xyzz29_mem* sR = reinterpret_cast<xyzz29_mem*>(smem);
+  xyzz29_mem* sA = sR + T1;
+  xyzz29_mem* sS = sA + T1;
+  const uint32_t g = threadIdx.x / T1, li = threadIdx.x - g * T1;
+  const uint32_t base = blockIdx.y * count;
+  xyzz29 v = xyzz29_identity();
+  if (li < count) v = xyzz29_load((g == 0 ? in.r : g == 1 ? in.a : in.s) + base + li);
+  if (g == 1) xyzz29_store(&sA[li], v);
+  if (g == 2) xyzz29_store(&sS[li], v);
+  // suffix scan of R (group 0 works, everyone keeps the barriers)
+  if (g == 0) xyzz29_store(&sR[li], v);
+  __syncthreads();
+  for (uint32_t d = 1; d < T1; d <<= 1) {
+    xyzz29 other = xyzz29_identity();
+    if (g == 0 && li + d < T1) other = xyzz29_load(&sR[li + d]);
+    __syncthreads();
+    if (g == 0) {
+      xyzz29_add(v, other);
+      xyzz29_store(&sR[li], v);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) xyzz29_store(&sR[0], xyzz29_identity());  // T sums w >= 1 only
+  __syncthreads();
+  xyzz29_mem* arr = g == 0 ? sR : g == 1 ? sA : sS;
+  tree_sum(arr, T1, li, true);
+  if (li == 0) xyzz29_store((g == 0 ? out.r : g == 1 ? out.a : out.s) + blockIdx.y, xyzz29_load(&arr[0]));
+}
+// per-window (A, S, T) -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ each) for the
+// host tail; out[(3*j + which)*32 ..]
+__global__ void msm_export_windows(ReduceOut in, uint32_t W, uint32_t has_t, uint32_t* __restrict__ out) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 3 * W) return;
+  uint32_t j = q / 3, which = q - 3 * j;
   uint32_t w[32];
-  xyzz29_to_words(xyzz29_load(in + j), w);
-  for (int i = 0; i < 32; i++) out[32 * j + i] = w[i];
+  if (which == 2 && !has_t) {
+    for (int i = 0; i < 32; i++) w[i] = 0;
+  } else {
+    xyzz29_to_words(xyzz29_load((which == 0 ? in.a : which == 1 ? in.s : in.r) + j), w);
+  }
+  for (int i = 0; i < 32; i++) out[32 * q + i] = w[i];
 }
 
 // out[i] = scalars[i] * G  (ParamsKZG::setup's fixed-base products; also used to build
@@ -516,7 +562,7 @@ MsmEngine::~MsmEngine() { release(); }
 void MsmEngine::release() {
   win_words_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
-    ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_acc_[i].release(); red_run_[i].release();
+    ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_a_[i].release(); red_s_[i].release(); red_r_[i].release();
   }
   if (h_meta_) (void)hipHostFree(h_meta_);
   if (h_win_) (void)hipHostFree(h_win_);
@@ -525,7 +571,7 @@ void MsmEngine::release() {
 }
 
 uint32_t MsmEngine::window_bits_for(size_t n) const {
-  if (cfg_.window_bits) return std::min<uint32_t>(16, std::max<uint32_t>(2, cfg_.window_bits));
+  if (cfg_.window_bits) return std::min<uint32_t>(16, std::max<uint32_t>(4, cfg_.window_bits));
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = (int)lg - 4;
@@ -536,7 +582,7 @@ hipError_t MsmEngine::init() {
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                              128 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -568,8 +614,21 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   const uint32_t W = (255 + c - 1) / c;  // W*c >= 255: the top window never needs a carry out
   const uint32_t nbw = 1u << (c - 1);
   const uint32_t NB = W * nbw;
-  const uint32_t log_L = cfg_.log_seg;
   const size_t entries = (size_t)W * n;
+  // window widths: W-1 signed windows + an unsigned top window, 254 bits in total
+  WindowPlan wp{};
+  wp.W = W;
+  for (uint32_t j = 0; j + 1 < W; j++) wp.width[j] = (uint8_t)c;
+  wp.width[W - 1] = (uint8_t)(c - 1);
+  for (uint32_t k = 0, slack = W * c - 255; k < slack; k++) wp.width[W - 2 - k] -= 1;
+  // task length: deep enough to amortise, shallow enough that the longest dependent chain of
+  // additions stays a small multiple of the per-lane share of the work
+  uint32_t log_L = cfg_.log_seg;
+  if (!log_L) {
+    const size_t share = 2 * entries / (256 * 4 * 64 * 4);  // entries per resident lane, x2
+    log_L = 4;
+    while (log_L < 8 && ((size_t)1 << log_L) < share) log_L++;
+  }
 
   // chunking of the scalars for the LDS-staged counting sort: W * P workgroups
   const uint32_t target_wgs = (nbw * 4 > 64 * 1024) ? 256 : 512;
@@ -590,8 +649,8 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   }
   SG_TRY(meta_.reserve(16));
   if (!h_meta_) SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t)));
-  if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * 32 * sizeof(uint32_t)));
-  SG_TRY(win_words_.reserve(64 * 32));
+  if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * 96 * sizeof(uint32_t)));
+  SG_TRY(win_words_.reserve(64 * 96));
 
   hipEvent_t ev[5];
   if (tm) {
@@ -604,7 +663,7 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
     }
   };
 
-  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, c, W, dig_.p);
+  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, wp, dig_.p);
   if (tm) SG_TRY(hipEventRecord(ev[1], stream));
   msm_hist<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
   msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
@@ -652,50 +711,54 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   }
   if (tm) SG_TRY(hipEventRecord(ev[3], stream));
 
-  // bucket reduction levels
-  const uint32_t log_G = std::min<uint32_t>(cfg_.log_red_chunk, c - 1);
-  uint32_t items = nbw >> log_G;  // chunks per window at level 0 (a power of two)
-  uint32_t threads = std::min<uint32_t>(256, std::max<uint32_t>(64, items));
-  uint32_t blocks = (items + threads - 1) / threads;
+  // bucket reduction: level 0 over the buckets, level 1 over the workgroup items
+  // G buckets per thread: 8 for the largest windows, 4 below (depth vs. work, measured)
+  const uint32_t log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 15) ? 3 : 2), c - 1);
+  const uint32_t items = nbw >> log_G;  // chunks per window at level 0 (a power of two)
+  const uint32_t threads = std::min<uint32_t>(256, std::max<uint32_t>(64, items));
+  const uint32_t blocks = (items + threads - 1) / threads;  // <= 256 for nbw <= 2^15, log_G >= 0... checked below
+  if (blocks > 256) return hipErrorInvalidValue;
+  uint32_t log_N = 0;
+  while ((1u << log_N) < threads) log_N++;
   for (int i = 0; i < 2; i++) {
-    SG_TRY(red_acc_[i].reserve((size_t)W * blocks));
-    SG_TRY(red_run_[i].reserve((size_t)W * blocks));
+    SG_TRY(red_a_[i].reserve((size_t)W * blocks));
+    SG_TRY(red_s_[i].reserve((size_t)W * blocks));
+    SG_TRY(red_r_[i].reserve((size_t)W * blocks));
   }
-  size_t lds = (size_t)threads * 2 * sizeof(xyzz29_mem);
-  msm_reduce_buckets<<<dim3(blocks, W), threads, lds, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, nbw, log_G,
-                                                                 red_acc_[0].p, red_run_[0].p);
-  uint32_t log_M = log_G;
-  int src = 0;
-  while (blocks > 1) {
-    // one item of this level spans `threads` items of the previous one
-    uint32_t lt = 0;
-    while ((1u << lt) < threads) lt++;
-    log_M += lt;
-    items = blocks;
-    threads = 64;
-    while (threads < items && threads < 256) threads <<= 1;
-    blocks = (items + threads - 1) / threads;
-    lds = (size_t)threads * 2 * sizeof(xyzz29_mem);
-    msm_reduce_items<<<dim3(blocks, W), threads, lds, stream>>>(red_acc_[src].p, red_run_[src].p, items, log_M,
-                                                                 red_acc_[1 - src].p, red_run_[1 - src].p);
-    src = 1 - src;
+  ReduceOut lvl0{red_a_[0].p, red_s_[0].p, red_r_[0].p}, lvl1{red_a_[1].p, red_s_[1].p, red_r_[1].p};
+  msm_reduce_buckets<<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
+      cur, toff_[lvl].p, ntask_[lvl].p, nbw, log_G, lvl0);
+  ReduceOut fin = lvl0;
+  if (blocks > 1) {
+    uint32_t T1 = 16;
+    while (T1 < blocks) T1 <<= 1;
+    msm_reduce_items<<<dim3(1, W), 3 * T1, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
+    fin = lvl1;
   }
   if (tm) SG_TRY(hipEventRecord(ev[4], stream));
-  msm_export_windows<<<1, 64, 0, stream>>>(red_acc_[src].p, W, win_words_.p);
-  SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 32 * W, hipMemcpyDeviceToHost, stream));
+  msm_export_windows<<<(3 * W + 63) / 64, 64, 0, stream>>>(fin, W, blocks > 1 ? 1u : 0u, win_words_.p);
+  SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 96 * W, hipMemcpyDeviceToHost, stream));
   SG_TRY(hipStreamSynchronize(stream));
 
-  // Horner over the window sums, high to low
+  // host tail: window_j = A + 2^log_G (S + 2^log_N T); then Horner over the windows, high to low
   using namespace host;
+  auto point_at = [&](uint32_t q) {
+    Fq x, y, zz, zzz;
+    std::memcpy(x.v, h_win_ + 32 * q, 32);
+    std::memcpy(y.v, h_win_ + 32 * q + 8, 32);
+    std::memcpy(zz.v, h_win_ + 32 * q + 16, 32);
+    std::memcpy(zzz.v, h_win_ + 32 * q + 24, 32);
+    return jac_from_xyzz(x, y, zz, zzz);
+  };
   Jac total = Jac::identity();
   for (int j = (int)W - 1; j >= 0; j--) {
-    for (uint32_t k = 0; k < c; k++) total = jac_double(total);
-    Fq x, y, zz, zzz;
-    std::memcpy(x.v, h_win_ + 32 * j, 32);
-    std::memcpy(y.v, h_win_ + 32 * j + 8, 32);
-    std::memcpy(zz.v, h_win_ + 32 * j + 16, 32);
-    std::memcpy(zzz.v, h_win_ + 32 * j + 24, 32);
-    total = jac_add(total, jac_from_xyzz(x, y, zz, zzz));
+    for (uint32_t k = 0; k < wp.width[j]; k++) total = jac_double(total);
+    Jac t = point_at(3 * j + 2);
+    for (uint32_t k = 0; k < log_N; k++) t = jac_double(t);
+    t = jac_add(t, point_at(3 * j + 1));
+    for (uint32_t k = 0; k < log_G; k++) t = jac_double(t);
+    t = jac_add(t, point_at(3 * j));
+    total = jac_add(total, t);
   }
   jac_to_affine_bytes(total, out_affine);
 

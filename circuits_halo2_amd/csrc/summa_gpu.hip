@@ -545,7 +545,7 @@ int sg_set_param(const char* name, int value) {
   LOCKED_CTX();
   std::string s(name);
   if (s == "msm.window_bits") g_ctx->msm.config().window_bits = (uint32_t)value;
-  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = (uint32_t)std::max(1, std::min(12, value));
+  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = (uint32_t)std::min(12, value);
   else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = (uint32_t)std::min(8, value);
   else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
   else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));

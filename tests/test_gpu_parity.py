@@ -240,7 +240,7 @@ def test_msm_matches_oracle(gpu, O, n):
     assert (gpu.best_multiexp(dev(sc), dev(bases)) == want).all()
 
 
-@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+@pytest.mark.parametrize("c", [4, 5, 7, 9, 11, 12, 13, 14, 15, 16])
 def test_msm_window_sizes(gpu, O, c):
     from circuits_halo2_amd import ffi
     n = 3000
@@ -290,7 +290,7 @@ def test_msm_skewed_buckets(gpu, O, P, srs11):
         mixed = fr_np([(i % 3) + 1 if i % 5 else 0 for i in range(n)])
         assert (gpu.best_multiexp(mixed, bases) == O.best_multiexp(mixed, bases, O.ncpu())).all()
     finally:
-        ffi.check(ffi.lib().sg_set_param(b"msm.log_seg", 6))
+        ffi.check(ffi.lib().sg_set_param(b"msm.log_seg", 0))
     ones = fr_np([1] * n)
     assert (gpu.best_multiexp(ones, bases) == O.best_multiexp(ones, bases, O.ncpu())).all()
     bytes_like = fr_np([(i * 37) % 256 for i in range(n)])  # range-check column shape
