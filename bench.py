@@ -27,6 +27,27 @@ MSM_BYTES_PER_PAIR = 96        # 64 B point + 32 B scalar
 NTT_BYTES_PER_ELEM = 64        # 32 B read + 32 B write, one logical pass
 
 
+def pmc_traffic(kernel, log_n):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/*_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command at the default 2^20 workload); null when no matching profile exists."""
+    import glob
+    if log_n != LOG_N:
+        return {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+        pm = json.load(open(path)).get("pmc", {})
+        cands = [(int(k.split("@grid")[1]), v) for k, v in pm.items()
+                 if k.startswith(kernel + "@") and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v]
+        if cands:
+            _, v = max(cands)
+            raw = (v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024
+            return {"traffic": raw, "traffic_source": os.path.basename(path),
+                    "traffic_note": "FETCH_SIZE + WRITE_SIZE, uncorrected (64-B gathers are uncalibrated on gfx950; "
+                                    "the x2 streaming-read correction would give %.3g B)" %
+                                    ((2 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)}
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +128,7 @@ def main():
         line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
+        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n))
         line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
                                  ("digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}
         line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket")})

@@ -259,7 +259,7 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff
 // wave run the same number of additions (bucket sizes are Poisson-distributed: without this
 // a wave waits for its largest bucket, ~30 % of the lanes' time idle).
 static constexpr uint32_t TASK_BINS = 257;        // task length clamped to 256
-static constexpr uint32_t TASK_BLOCK = 2048;      // buckets per workgroup in the ordering passes
+static constexpr uint32_t TASK_BLOCK = 8192;      // buckets per workgroup in the ordering passes
 
 __device__ __forceinline__ uint32_t task_len(uint32_t cnt, uint32_t seg, uint32_t log_L) {
   uint32_t rem = cnt - (seg << log_L);
