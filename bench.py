@@ -137,6 +137,16 @@ def main():
         line["alu"] = {"bucket_adds_per_launch": adds, "fq_mul_per_s": adds * 10 / (acc_ms * 1e-3),
                        "note": "8M+2S XYZZ mixed add; see profiles/r01_microbench_instr_rates.txt for instruction peaks"}
 
+        # throughput mode: the same MSM issued as a batch of 8 (pipelined over two streams)
+        sg.best_multiexp_batch([(scal, bases)] * 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = sg.best_multiexp_batch([(scal, bases)] * 8)
+        torch.cuda.synchronize()
+        bdt = time.perf_counter() - t1
+        assert all((o == result).all() for o in outs) or world > 1
+        line["batched"] = {"msms": 8, "ms_per_msm": bdt / 8 * 1e3, "points_per_s": 8 * n / bdt}
+
         if not args.no_extras:
             line["ntt"] = {}
             for lg in (17, 22):
@@ -153,8 +163,7 @@ def main():
             sg.best_multiexp(s17, b17)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(16):
-                sg.best_multiexp(s17, b17)
+            sg.best_multiexp_batch([(s17, b17)] * 16)
             torch.cuda.synchronize()
             msm17 = (time.perf_counter() - t1) * 1e3
             a20 = scal[: 32 << 20].clone()

@@ -8,8 +8,8 @@ implementation of the path in this package: without the HIP library or a GPU eve
 raises.
 """
 from .ffi import SummaGpuError, lib, library_path  # noqa: F401
-from .arithmetic import best_fft, best_multiexp  # noqa: F401
+from .arithmetic import best_fft, best_multiexp, best_multiexp_batch  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401
 from .params import ParamsKZG  # noqa: F401
 
-__all__ = ["best_multiexp", "best_fft", "EvaluationDomain", "ParamsKZG", "SummaGpuError", "lib", "library_path"]
+__all__ = ["best_multiexp", "best_multiexp_batch", "best_fft", "EvaluationDomain", "ParamsKZG", "SummaGpuError", "lib", "library_path"]

@@ -45,6 +45,41 @@ def best_multiexp(coeffs, bases, timings: bool = False):
     return out
 
 
+def best_multiexp_batch(pairs):
+    """[(coeffs, bases), ...] -> list of 64-byte affine points.  The independent MSMs of one
+    prover phase in one call; they are pipelined on the device (C ABI: sg_msm_g1_batch).
+    All pairs must be of one kind: host buffers or device tensors."""
+    L = ffi.lib()
+    count = len(pairs)
+    out = np.zeros(64 * count, dtype=np.uint8)
+    if count == 0:
+        return []
+    ns = (C.c_size_t * count)()
+    ps = (C.c_void_p * count)()
+    pb = (C.c_void_p * count)()
+    keep = []
+    dev = _is_torch_cuda(pairs[0][0])
+    for i, (s, b) in enumerate(pairs):
+        if dev:
+            n = s.numel() // 32
+            if b.numel() != 64 * n:
+                raise ValueError("best_multiexp: coeffs.len() != bases.len()")
+            ps[i], pb[i] = s.data_ptr(), b.data_ptr()
+        else:
+            s, b = ffi.u8(s), ffi.u8(b)
+            n = s.size // 32
+            if s.size % 32 or b.size != 64 * n:
+                raise ValueError("best_multiexp: coeffs.len() != bases.len()")
+            keep.append((s, b))
+            ps[i], pb[i] = s.ctypes.data, b.ctypes.data
+        ns[i] = n
+    if dev:
+        ffi.check(L.sg_msm_g1_batch_dev(ps, pb, ns, C.c_size_t(count), ffi.current_stream_ptr(), ffi.ptr(out)))
+    else:
+        ffi.check(L.sg_msm_g1_batch(ps, pb, ns, C.c_size_t(count), ffi.ptr(out)))
+    return [out[64 * i:64 * i + 64].copy() for i in range(count)]
+
+
 def best_fft(a, omega, log_n: int):
     """Forward DFT of 2^log_n Fr values with generator `omega`, natural order in and out.
     Host input: returns a new numpy buffer.  Device tensor: transformed in place (like the

@@ -45,18 +45,48 @@ struct DevBuf {
   }
 };
 
+struct WindowPlan {  // per-window digit widths (see msm_digits)
+  uint32_t W;
+  uint8_t width[64];
+};
+
 class MsmEngine {
  public:
   ~MsmEngine();
   hipError_t init();
   void release();
   MsmConfig& config() { return cfg_; }
+  void set_tail_stream(hipStream_t s) { tail_stream_ = s; }
   uint32_t window_bits_for(size_t n) const;
   // d_scalars: n x 32 B Montgomery Fr, d_bases: n x 64 B affine; result: 64 B affine on the host
   hipError_t run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
                  MsmTimings* tm);
+  // the same in three phases, so that two engines on two streams can overlap one MSM's
+  // latency-bound tail with the next MSM's sort/accumulate (sg_msm_g1_batch):
+  //   enqueue_front: digits .. counting sort (+ async copy of the task counters)
+  //   enqueue_back:  waits for the counters, enqueues accumulate .. reduction + result copy
+  //   finish:        waits for the result copy, host tail (Horner + normalisation)
+  hipError_t enqueue_front(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream,
+                           uint8_t* out_affine, MsmTimings* tm);
+  hipError_t enqueue_back();
+  hipError_t finish();
 
  private:
+  struct Job {
+    const fp_words* scalars = nullptr;
+    const g1_affine_mem* bases = nullptr;
+    size_t n = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* out = nullptr;
+    MsmTimings* tm = nullptr;
+    bool trivial = false, all_zero = false;
+    uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0;
+    WindowPlan wp{};
+    hipEvent_t ev[5];
+  };
+  Job job_;
+  hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
+  hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;
   DevBuf<int16_t> dig_;
   DevBuf<uint2> order_;

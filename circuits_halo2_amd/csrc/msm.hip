@@ -42,10 +42,6 @@ namespace sg {
 // dig[j*n + i] = digit j of scalar i as int16.  Adding K = sum_{j<W-1} 2^(o_j + w_j - 1)
 // once makes every window's digit independent of its neighbours:
 //   d_j = (((s + K) >> o_j) & (2^w_j - 1)) - 2^(w_j - 1)   in [-2^(w_j-1), 2^(w_j-1)).
-struct WindowPlan {
-  uint32_t W;
-  uint8_t width[64];
-};
 __global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, WindowPlan wp,
                            int16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -564,6 +560,11 @@ void MsmEngine::release() {
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_a_[i].release(); red_s_[i].release(); red_r_[i].release();
   }
+  if (ev_acc_) (void)hipEventDestroy(ev_acc_);
+  ev_acc_ = nullptr;
+  if (ev_meta_) (void)hipEventDestroy(ev_meta_);
+  if (ev_done_) (void)hipEventDestroy(ev_done_);
+  ev_meta_ = ev_done_ = nullptr;
   if (h_meta_) (void)hipHostFree(h_meta_);
   if (h_win_) (void)hipHostFree(h_win_);
   h_meta_ = nullptr;
@@ -602,38 +603,39 @@ static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, 
   return hipGetLastError();
 }
 
-hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream,
-                          uint8_t out_affine[64], MsmTimings* tm) {
+// ---- phase 1: everything up to the counting sort; ends with an async copy of the counters
+hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n,
+                                    hipStream_t stream, uint8_t* out_affine, MsmTimings* tm) {
+  Job& j = job_;
+  j = Job{};
+  j.scalars = d_scalars; j.bases = d_bases; j.n = n; j.stream = stream; j.out = out_affine; j.tm = tm;
   if (tm) *tm = MsmTimings{};
   if (n == 0) {
-    std::memset(out_affine, 0, 64);
+    j.trivial = true;
     return hipSuccess;
   }
   if (n >= (1ull << 31)) return hipErrorInvalidValue;
-  const uint32_t c = window_bits_for(n);
-  const uint32_t W = (255 + c - 1) / c;  // W*c >= 255: the top window never needs a carry out
-  const uint32_t nbw = 1u << (c - 1);
-  const uint32_t NB = W * nbw;
+  const uint32_t c = j.c = window_bits_for(n);
+  const uint32_t W = j.wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
+  const uint32_t nbw = j.nbw = 1u << (c - 1);
+  const uint32_t NB = j.NB = W * nbw;
   const size_t entries = (size_t)W * n;
   // window widths: W-1 signed windows + an unsigned top window, 254 bits in total
-  WindowPlan wp{};
-  wp.W = W;
-  for (uint32_t j = 0; j + 1 < W; j++) wp.width[j] = (uint8_t)c;
-  wp.width[W - 1] = (uint8_t)(c - 1);
-  for (uint32_t k = 0, slack = W * c - 255; k < slack; k++) wp.width[W - 2 - k] -= 1;
+  for (uint32_t q = 0; q + 1 < W; q++) j.wp.width[q] = (uint8_t)c;
+  j.wp.width[W - 1] = (uint8_t)(c - 1);
+  for (uint32_t k = 0, slack = W * c - 255; k < slack; k++) j.wp.width[W - 2 - k] -= 1;
   // task length: deep enough to amortise, shallow enough that the longest dependent chain of
   // additions stays a small multiple of the per-lane share of the work
-  uint32_t log_L = cfg_.log_seg;
-  if (!log_L) {
+  j.log_L = cfg_.log_seg;
+  if (!j.log_L) {
     const size_t share = 2 * entries / (256 * 4 * 64 * 4);  // entries per resident lane, x2
-    log_L = 4;
-    while (log_L < 8 && ((size_t)1 << log_L) < share) log_L++;
+    j.log_L = 4;
+    while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
   }
-
   // chunking of the scalars for the LDS-staged counting sort: W * P workgroups
   const uint32_t target_wgs = (nbw * 4 > 64 * 1024) ? 256 : 512;
   uint32_t P = std::max<uint32_t>(1, target_wgs / W);
-  uint32_t chunk = (uint32_t)std::max<size_t>(1024, (n + P - 1) / P);
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1024, (n + P - 1) / P);
   P = (uint32_t)((n + chunk - 1) / chunk);
 
   // workspace (grown on demand, kept across calls)
@@ -651,35 +653,38 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   if (!h_meta_) SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t)));
   if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * 96 * sizeof(uint32_t)));
   SG_TRY(win_words_.reserve(64 * 96));
-
-  hipEvent_t ev[5];
+  if (!ev_meta_) SG_TRY(hipEventCreateWithFlags(&ev_meta_, hipEventDisableTiming));
+  if (!ev_done_) SG_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
   if (tm) {
-    for (auto& e : ev) SG_TRY(hipEventCreate(&e));
-    SG_TRY(hipEventRecord(ev[0], stream));
+    for (auto& e : j.ev) SG_TRY(hipEventCreate(&e));
+    SG_TRY(hipEventRecord(j.ev[0], stream));
   }
-  auto drop_events = [&]() {
-    if (tm) {
-      for (auto& e : ev) (void)hipEventDestroy(e);
-    }
-  };
 
-  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, wp, dig_.p);
-  if (tm) SG_TRY(hipEventRecord(ev[1], stream));
+  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, j.wp, dig_.p);
+  if (tm) SG_TRY(hipEventRecord(j.ev[1], stream));
   msm_hist<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
   msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
-  SG_TRY(launch_scan(counts_.p, NB, log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
+  SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
   SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  SG_TRY(hipEventRecord(ev_meta_, stream));
   msm_scatter<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
                                                                     sorted_.p);
-  if (tm) SG_TRY(hipEventRecord(ev[2], stream));
-  SG_TRY(hipStreamSynchronize(stream));
-  const uint32_t ntasks = h_meta_[1], max_cnt = h_meta_[2];
+  if (tm) SG_TRY(hipEventRecord(j.ev[2], stream));
+  return hipGetLastError();
+}
+
+// ---- phase 2: needs the task count on the host; enqueues accumulate .. export + result copy
+hipError_t MsmEngine::enqueue_back() {
+  Job& j = job_;
+  if (j.trivial) return hipSuccess;
+  hipStream_t stream = j.stream;
+  SG_TRY(hipEventSynchronize(ev_meta_));
+  const uint32_t ntasks = j.ntasks = h_meta_[1], max_cnt = j.max_cnt = h_meta_[2];
   if (!ntasks) {  // every digit was zero
-    std::memset(out_affine, 0, 64);
-    drop_events();
+    j.all_zero = true;
     return hipSuccess;
   }
-
+  const uint32_t NB = j.NB, W = j.wp.W, nbw = j.nbw, log_L = j.log_L;
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
   SG_TRY(partial_[0].reserve(ntasks));
   {
@@ -690,7 +695,7 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
     msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk);
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p, order_.p);
   }
-  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, d_bases, off_.p, counts_.p, toff_[0].p, order_.p,
+  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bases, off_.p, counts_.p, toff_[0].p, order_.p,
                                                            log_L, ntasks, partial_[0].p);
   const xyzz29_mem* cur = partial_[0].p;
   int lvl = 0, pbuf = 0;
@@ -709,17 +714,25 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
     cur = partial_[pbuf].p;
     lvl = nxt;
   }
-  if (tm) SG_TRY(hipEventRecord(ev[3], stream));
+  if (j.tm) SG_TRY(hipEventRecord(j.ev[3], stream));
+  if (tail_stream_) {
+    // the latency-bound tail runs on a high-priority stream so that its few workgroups are
+    // dispatched ahead of the next MSM's accumulation (batches ping-pong between two engines)
+    if (!ev_acc_) SG_TRY(hipEventCreateWithFlags(&ev_acc_, hipEventDisableTiming));
+    SG_TRY(hipEventRecord(ev_acc_, stream));
+    SG_TRY(hipStreamWaitEvent(tail_stream_, ev_acc_, 0));
+    stream = tail_stream_;
+  }
 
   // bucket reduction: level 0 over the buckets, level 1 over the workgroup items
   // G buckets per thread: 8 for the largest windows, 4 below (depth vs. work, measured)
-  const uint32_t log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 15) ? 3 : 2), c - 1);
-  const uint32_t items = nbw >> log_G;  // chunks per window at level 0 (a power of two)
+  j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 15) ? 3 : 2), j.c - 1);
+  const uint32_t items = nbw >> j.log_G;  // chunks per window at level 0 (a power of two)
   const uint32_t threads = std::min<uint32_t>(256, std::max<uint32_t>(64, items));
-  const uint32_t blocks = (items + threads - 1) / threads;  // <= 256 for nbw <= 2^15, log_G >= 0... checked below
+  const uint32_t blocks = j.blocks = (items + threads - 1) / threads;
   if (blocks > 256) return hipErrorInvalidValue;
-  uint32_t log_N = 0;
-  while ((1u << log_N) < threads) log_N++;
+  j.log_N = 0;
+  while ((1u << j.log_N) < threads) j.log_N++;
   for (int i = 0; i < 2; i++) {
     SG_TRY(red_a_[i].reserve((size_t)W * blocks));
     SG_TRY(red_s_[i].reserve((size_t)W * blocks));
@@ -727,7 +740,7 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   }
   ReduceOut lvl0{red_a_[0].p, red_s_[0].p, red_r_[0].p}, lvl1{red_a_[1].p, red_s_[1].p, red_r_[1].p};
   msm_reduce_buckets<<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
-      cur, toff_[lvl].p, ntask_[lvl].p, nbw, log_G, lvl0);
+      cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
   ReduceOut fin = lvl0;
   if (blocks > 1) {
     uint32_t T1 = 16;
@@ -735,12 +748,32 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
     msm_reduce_items<<<dim3(1, W), 3 * T1, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
     fin = lvl1;
   }
-  if (tm) SG_TRY(hipEventRecord(ev[4], stream));
+  if (j.tm) SG_TRY(hipEventRecord(j.ev[4], stream));
   msm_export_windows<<<(3 * W + 63) / 64, 64, 0, stream>>>(fin, W, blocks > 1 ? 1u : 0u, win_words_.p);
   SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 96 * W, hipMemcpyDeviceToHost, stream));
-  SG_TRY(hipStreamSynchronize(stream));
+  SG_TRY(hipEventRecord(ev_done_, stream));
+  return hipGetLastError();
+}
 
-  // host tail: window_j = A + 2^log_G (S + 2^log_N T); then Horner over the windows, high to low
+// ---- phase 3: wait for the window sums; host tail
+hipError_t MsmEngine::finish() {
+  Job& j = job_;
+  auto drop_events = [&]() {
+    if (j.tm) {
+      for (auto& e : j.ev) (void)hipEventDestroy(e);
+    }
+  };
+  if (j.trivial) {
+    std::memset(j.out, 0, 64);
+    return hipSuccess;
+  }
+  if (j.all_zero) {
+    std::memset(j.out, 0, 64);
+    drop_events();
+    return hipSuccess;
+  }
+  SG_TRY(hipEventSynchronize(ev_done_));
+  // window_j = A + 2^log_G (S + 2^log_N T); then Horner over the windows, high to low
   using namespace host;
   auto point_at = [&](uint32_t q) {
     Fq x, y, zz, zzz;
@@ -751,31 +784,39 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
     return jac_from_xyzz(x, y, zz, zzz);
   };
   Jac total = Jac::identity();
-  for (int j = (int)W - 1; j >= 0; j--) {
-    for (uint32_t k = 0; k < wp.width[j]; k++) total = jac_double(total);
-    Jac t = point_at(3 * j + 2);
-    for (uint32_t k = 0; k < log_N; k++) t = jac_double(t);
-    t = jac_add(t, point_at(3 * j + 1));
-    for (uint32_t k = 0; k < log_G; k++) t = jac_double(t);
-    t = jac_add(t, point_at(3 * j));
+  for (int w = (int)j.wp.W - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < j.wp.width[w]; k++) total = jac_double(total);
+    Jac t = point_at(3 * w + 2);
+    for (uint32_t k = 0; k < j.log_N; k++) t = jac_double(t);
+    t = jac_add(t, point_at(3 * w + 1));
+    for (uint32_t k = 0; k < j.log_G; k++) t = jac_double(t);
+    t = jac_add(t, point_at(3 * w));
     total = jac_add(total, t);
   }
-  jac_to_affine_bytes(total, out_affine);
+  jac_to_affine_bytes(total, j.out);
 
-  if (tm) {
+  if (j.tm) {
+    MsmTimings* tm = j.tm;
     float ms;
-    (void)hipEventElapsedTime(&ms, ev[0], ev[1]); tm->digits_ms = ms;
-    (void)hipEventElapsedTime(&ms, ev[1], ev[2]); tm->sort_ms = ms;
-    (void)hipEventElapsedTime(&ms, ev[2], ev[3]); tm->accumulate_ms = ms;
-    (void)hipEventElapsedTime(&ms, ev[3], ev[4]); tm->reduce_ms = ms;
-    (void)hipEventElapsedTime(&ms, ev[0], ev[4]); tm->total_ms = ms;
-    tm->window_bits = c;
-    tm->windows = W;
-    tm->tasks = ntasks;
-    tm->max_bucket = max_cnt;
+    (void)hipEventElapsedTime(&ms, j.ev[0], j.ev[1]); tm->digits_ms = ms;
+    (void)hipEventElapsedTime(&ms, j.ev[1], j.ev[2]); tm->sort_ms = ms;
+    (void)hipEventElapsedTime(&ms, j.ev[2], j.ev[3]); tm->accumulate_ms = ms;
+    (void)hipEventElapsedTime(&ms, j.ev[3], j.ev[4]); tm->reduce_ms = ms;
+    (void)hipEventElapsedTime(&ms, j.ev[0], j.ev[4]); tm->total_ms = ms;
+    tm->window_bits = j.c;
+    tm->windows = j.wp.W;
+    tm->tasks = j.ntasks;
+    tm->max_bucket = j.max_cnt;
     drop_events();
   }
   return hipSuccess;
+}
+
+hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream,
+                          uint8_t out_affine[64], MsmTimings* tm) {
+  SG_TRY(enqueue_front(d_scalars, d_bases, n, stream, out_affine, tm));
+  SG_TRY(enqueue_back());
+  return finish();
 }
 
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream) {

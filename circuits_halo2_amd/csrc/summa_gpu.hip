@@ -11,7 +11,9 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
+#include "host_curve.h"
 #include "msm.h"
 #include "ntt.h"
 
@@ -93,7 +95,10 @@ struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
   NttEngine ntt;
-  MsmEngine msm;
+  MsmEngine msm, msm_b;          // two engines: batches ping-pong between them
+  hipStream_t bstream[2] = {nullptr, nullptr};
+  hipStream_t tstream[2] = {nullptr, nullptr};  // high-priority tails
+  hipEvent_t ev_in = nullptr;
   DevBuf<uint8_t> stage_a, stage_b, scratch;
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
@@ -116,6 +121,9 @@ int need_ctx() {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = c->ntt.init();
     if (e == hipSuccess) e = c->msm.init();
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[1], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
     if (e != hipSuccess) {
       delete c;
@@ -218,6 +226,9 @@ int sg_init(int device) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = c->ntt.init();
   if (e == hipSuccess) e = c->msm.init();
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[1], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
   if (e != hipSuccess) {
     delete c;
@@ -240,6 +251,14 @@ void sg_shutdown(void) {
   for (auto& kv : g_ctx->t_evals) (void)hipFree(kv.second);
   g_ctx->ntt.clear();
   g_ctx->msm.release();
+  g_ctx->msm_b.release();
+  for (auto& bs : g_ctx->bstream) {
+    if (bs) (void)hipStreamDestroy(bs);
+  }
+  for (auto& ts : g_ctx->tstream) {
+    if (ts) (void)hipStreamDestroy(ts);
+  }
+  if (g_ctx->ev_in) (void)hipEventDestroy(g_ctx->ev_in);
   g_ctx->stage_a.release();
   g_ctx->stage_b.release();
   g_ctx->scratch.release();
@@ -279,6 +298,98 @@ int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t ou
                                   nullptr);
     if (e != hipSuccess) return hip_fail("msm", e);
   }
+  return SG_OK;
+}
+
+// A batch of independent MSMs (the commitments of one prover phase): two engines on two
+// streams, so that MSM i's latency-bound bucket reduction overlaps MSM i+1's sort/accumulate.
+int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases, const size_t* n, size_t count,
+                        void* stream, uint8_t* out_affine) {
+  if (count && (!d_scalars || !d_bases || !n || !out_affine)) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+  for (size_t i = 0; i < count; i++) {
+    if (n[i] && (!d_scalars[i] || !d_bases[i])) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+  }
+  LOCKED_CTX();
+  Context& c = *g_ctx;
+  MsmEngine* eng[2] = {&c.msm, &c.msm_b};
+  for (int k = 0; k < 2; k++) {
+    if (!c.tstream[k]) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+      CHECK_HIP(hipStreamCreateWithPriority(&c.tstream[k], hipStreamNonBlocking, hi), "priority stream");
+    }
+    eng[k]->set_tail_stream(c.tstream[k]);
+  }
+  struct Restore {
+    MsmEngine** e;
+    ~Restore() { e[0]->set_tail_stream(nullptr); e[1]->set_tail_stream(nullptr); }
+  } restore{eng};
+  // inputs are ordered on the caller's stream
+  CHECK_HIP(hipEventRecord(c.ev_in, pick_stream(stream)), "event");
+  for (auto& bs : c.bstream) CHECK_HIP(hipStreamWaitEvent(bs, c.ev_in, 0), "stream wait");
+  hipError_t e = hipSuccess;
+  size_t finished = 0;
+  for (size_t i = 0; i < count && e == hipSuccess; i++) {
+    const int k = (int)(i & 1);
+    if (i >= 2) {
+      e = eng[k]->finish();
+      finished = i - 1;
+      if (e != hipSuccess) break;
+    }
+    e = eng[k]->enqueue_front(static_cast<const fp_words*>(d_scalars[i]), static_cast<const g1_affine_mem*>(d_bases[i]),
+                              n[i], c.bstream[k], out_affine + 64 * i, nullptr);
+    if (e == hipSuccess) e = eng[k]->enqueue_back();
+  }
+  for (size_t i = (count >= 2 ? count - 2 : 0); i < count && e == hipSuccess; i++) e = eng[i & 1]->finish();
+  (void)finished;
+  if (e != hipSuccess) {
+    (void)hipDeviceSynchronize();
+    return hip_fail("msm batch", e);
+  }
+  return SG_OK;
+}
+int sg_msm_g1_batch(const uint8_t* const* scalars, const uint8_t* const* bases, const size_t* n, size_t count,
+                    uint8_t* out_affine) {
+  if (count && (!scalars || !bases || !n || !out_affine)) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+  std::vector<const void*> ds(count), db(count);
+  {
+    LOCKED_CTX();
+    size_t tot_s = 0, tot_b = 0;
+    for (size_t i = 0; i < count; i++) { tot_s += n[i] * 32; tot_b += n[i] * 64; }
+    hipError_t e = g_ctx->stage_a.reserve(tot_s + 64);
+    if (e == hipSuccess) e = g_ctx->stage_b.reserve(tot_b + 64);
+    if (e != hipSuccess) return hip_fail("staging buffer", e);
+    size_t os = 0, ob = 0;
+    for (size_t i = 0; i < count; i++) {
+      if (n[i] && (!scalars[i] || !bases[i])) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+      if (n[i]) {
+        CHECK_HIP(hipMemcpyAsync(g_ctx->stage_a.p + os, scalars[i], n[i] * 32, hipMemcpyHostToDevice, g_ctx->stream), "H2D copy");
+        CHECK_HIP(hipMemcpyAsync(g_ctx->stage_b.p + ob, bases[i], n[i] * 64, hipMemcpyHostToDevice, g_ctx->stream), "H2D copy");
+      }
+      ds[i] = g_ctx->stage_a.p + os;
+      db[i] = g_ctx->stage_b.p + ob;
+      os += n[i] * 32;
+      ob += n[i] * 64;
+    }
+  }
+  return sg_msm_g1_batch_dev(ds.data(), db.data(), n, count, g_ctx->stream, out_affine);
+}
+
+// Sum of a handful of affine points on the host (combining the per-GPU partial results of a
+// point-sharded MSM after the all_gather): a few Jacobian additions + one normalisation.
+int sg_g1_sum_affine(const uint8_t* points, size_t n, uint8_t out_affine[64]) {
+  if (!out_affine || (n && !points)) return fail(SG_ERR_INVALID, "sg_g1_sum_affine: null argument");
+  if (n > 4096) return fail(SG_ERR_INVALID, "sg_g1_sum_affine: meant for a handful of points; use sg_msm_g1");
+  using namespace sg::host;
+  Jac acc = Jac::identity();
+  for (size_t i = 0; i < n; i++) {
+    Fq x, y;
+    std::memcpy(x.v, points + 64 * i, 32);
+    std::memcpy(y.v, points + 64 * i + 32, 32);
+    if (x.is_zero() && y.is_zero()) continue;
+    acc = jac_add(acc, Jac{x, y, Fq::one()});
+  }
+  jac_to_affine_bytes(acc, out_affine);
   return SG_OK;
 }
 

@@ -63,6 +63,19 @@ const char* sg_version(void);
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]);
 int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]);
 
+/* A batch of independent MSMs -- e.g. the advice / permuted-lookup / quotient-piece commitments
+ * that halo2's create_proof computes in a loop within one Fiat-Shamir phase (SURVEY.md §3.1
+ * steps 3-10; proposed in §8b).  out_affine receives count x 64 bytes.  The MSMs are pipelined
+ * over two streams (one MSM's bucket reduction overlaps the next one's accumulation). */
+int sg_msm_g1_batch(const uint8_t* const* scalars, const uint8_t* const* bases, const size_t* n, size_t count,
+                    uint8_t* out_affine);
+int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases, const size_t* n, size_t count,
+                        void* stream, uint8_t* out_affine);
+
+/* Sum of a few affine points, on the host (the local "reduce" after the all_gather of the
+ * per-GPU partial results of a point-sharded MSM; EC addition is not an RCCL reduction op). */
+int sg_g1_sum_affine(const uint8_t* points, size_t n, uint8_t out_affine[64]);
+
 /* SRS cache: keeps ParamsKZG's g[] / g_lagrange[] resident in HBM across proofs
  * (the reference re-reads the file per Snapshot: backend/src/apis/round.rs:136-145). */
 int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint64_t* handle_out);

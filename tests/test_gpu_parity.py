@@ -297,6 +297,25 @@ def test_msm_skewed_buckets(gpu, O, P, srs11):
     assert (gpu.best_multiexp(bytes_like, bases) == O.best_multiexp(bytes_like, bases, O.ncpu())).all()
 
 
+def test_msm_batch_pipeline(gpu, O):
+    """sg_msm_g1_batch: independent MSMs of different sizes pipelined over two engines"""
+    sizes = [1 << 12, 0, 3000, 1 << 14, 1, 5000, 1 << 13]
+    pairs, want = [], []
+    for i, n in enumerate(sizes):
+        sc = O.random_fr(40 + i, n) if n else np.zeros(0, np.uint8)
+        bs = O.fixed_base_mul(O.random_fr(60 + i, n), O.ncpu()) if n else np.zeros(0, np.uint8)
+        pairs.append((sc, bs))
+        want.append(O.best_multiexp(sc, bs, O.ncpu()))
+    got = gpu.best_multiexp_batch(pairs)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+    dpairs = [(dev(s), dev(b)) for s, b in pairs if s.size]
+    got = gpu.best_multiexp_batch(dpairs)
+    for g, w in zip(got, [w for w, (s, _) in zip(want, pairs) if s.size]):
+        assert (g == w).all()
+    assert gpu.best_multiexp_batch([]) == []
+
+
 def test_fixed_base_mul(gpu, O):
     from circuits_halo2_amd.arithmetic import g1_fixed_base_mul
     sc = np.concatenate([O.random_fr(31, 200), fr_np([0, 1, 2])])

@@ -98,3 +98,27 @@ def test_seeded_inputs_are_in_range():
     vals = [int.from_bytes(c[32 * i:32 * i + 32].tobytes(), "little") for i in range(4096)]
     assert max(vals) < R_MODULUS and len(set(vals)) == 4096
     assert (random_fr_canonical(123, 4096) == c).all() and not (random_fr_canonical(124, 4096) == c).all()
+
+
+def test_host_point_sum_matches_bigint(srs11):
+    """sg_g1_sum_affine runs on the host (no GPU needed): compare with the big-integer twin"""
+    import ctypes as C
+    from circuits_halo2_amd import ffi
+    from oracle import pyref as P
+    pts = srs11["gl_np"][:64 * 9].copy()
+    pts[64 * 4:64 * 5] = 0  # an identity in the middle is skipped
+    want = None
+    for i in range(9):
+        want = P.g1_add(want, P.g1_from_bytes(pts[64 * i:64 * i + 64].tobytes()))
+    out = np.zeros(64, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_g1_sum_affine(ffi.ptr(pts), C.c_size_t(9), ffi.ptr(out)))
+    assert P.g1_from_bytes(out.tobytes()) == want
+    p = pts[:64]
+    neg = np.frombuffer(P.g1_to_bytes(P.g1_neg(P.g1_from_bytes(p.tobytes()))), dtype=np.uint8)
+    both = np.concatenate([p, neg, p, p])
+    ffi.check(ffi.lib().sg_g1_sum_affine(ffi.ptr(both), C.c_size_t(2), ffi.ptr(out)))
+    assert not out.any()
+    ffi.check(ffi.lib().sg_g1_sum_affine(ffi.ptr(both[128:]), C.c_size_t(2), ffi.ptr(out)))
+    assert P.g1_from_bytes(out.tobytes()) == P.g1_mul(P.g1_from_bytes(p.tobytes()), 2)
+    from circuits_halo2_amd.distributed import combine_partials
+    assert P.g1_from_bytes(combine_partials(pts).tobytes()) == want
