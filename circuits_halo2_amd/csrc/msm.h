@@ -16,6 +16,7 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
   uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
+  uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
 };
 
@@ -50,6 +51,12 @@ struct WindowPlan {  // per-window digit widths (see msm_digits)
   uint8_t width[64];
 };
 
+static constexpr size_t MAX_FUSED = 32;
+struct BatchPtrs {  // inputs of a fused batch (kernel argument)
+  const fp_words* scalars[MAX_FUSED];
+  const g1_affine_mem* bases[MAX_FUSED];
+};
+
 class MsmEngine {
  public:
   ~MsmEngine();
@@ -68,13 +75,17 @@ class MsmEngine {
   //   finish:        waits for the result copy, host tail (Horner + normalisation)
   hipError_t enqueue_front(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream,
                            uint8_t* out_affine, MsmTimings* tm);
+  // M same-length MSMs fused into one job (out_affine: M x 64 bytes); M <= max_fused(n)
+  hipError_t enqueue_front_fused(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases, size_t M,
+                                 size_t n, hipStream_t stream, uint8_t* out_affine, MsmTimings* tm);
+  size_t max_fused(size_t n) const;
   hipError_t enqueue_back();
   hipError_t finish();
 
  private:
   struct Job {
-    const fp_words* scalars = nullptr;
-    const g1_affine_mem* bases = nullptr;
+    BatchPtrs bp{};
+    uint32_t M = 1;
     size_t n = 0;
     hipStream_t stream = nullptr;
     uint8_t* out = nullptr;
@@ -95,6 +106,7 @@ class MsmEngine {
   DevBuf<xyzz29_mem> partial_[2], red_a_[2], red_s_[2], red_r_[2];
   DevBuf<uint32_t> win_words_;
   uint32_t* h_meta_ = nullptr;
+  size_t h_win_cap_ = 0;
   uint32_t* h_win_ = nullptr;  // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window
 };
 

@@ -42,10 +42,13 @@ namespace sg {
 // dig[j*n + i] = digit j of scalar i as int16.  Adding K = sum_{j<W-1} 2^(o_j + w_j - 1)
 // once makes every window's digit independent of its neighbours:
 //   d_j = (((s + K) >> o_j) & (2^w_j - 1)) - 2^(w_j - 1)   in [-2^(w_j-1), 2^(w_j-1)).
-__global__ void msm_digits(const fp_words* __restrict__ scalars, uint32_t n, WindowPlan wp,
-                           int16_t* __restrict__ dig) {
+// blockIdx.y = m selects the scalar vector of a fused batch (BatchPtrs); its digit rows are
+// dig[(m*W + j)*n + i].
+__global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __restrict__ dig) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const fp_words* __restrict__ scalars = bp.scalars[blockIdx.y];
+  dig += (size_t)blockIdx.y * wp.W * n;
   words8 s;
   {
     // canonical scalar = s~ * 2^-256 = s~ * 2^5 * 2^-261
@@ -323,8 +326,8 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict__ sorted,
-                                                      const g1_affine_mem* __restrict__ bases,
+__global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict__ sorted, BatchPtrs bp,
+                                                      uint32_t buckets_per_msm,
                                                       const uint32_t* __restrict__ off,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ toff,
@@ -334,6 +337,7 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
   if (t >= ntasks) return;
   const uint2 o = order[t];
   const uint32_t b = o.x, seg = o.y;
+  const g1_affine_mem* __restrict__ bases = bp.bases[b / buckets_per_msm];
   uint32_t start = off[b] + (seg << log_L);
   uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
   xyzz29 acc = xyzz29_identity();
@@ -604,26 +608,53 @@ static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, 
 }
 
 // ---- phase 1: everything up to the counting sort; ends with an async copy of the counters
+size_t MsmEngine::max_fused(size_t n) const {
+  if (n == 0) return MAX_FUSED;
+  const uint32_t c = window_bits_for(n);
+  const uint32_t W = (255 + c - 1) / c;
+  const size_t nb = (size_t)W << (c - 1);
+  // the scans handle 2^21 buckets (1024 blocks x 2048); cap the fused work space (cfg: log_fuse_entries)
+  const size_t by_buckets = ((size_t)1 << 21) / nb;
+  const size_t by_entries = ((size_t)1 << cfg_.log_fuse_entries) / std::max<size_t>(1, (size_t)W * n);
+  return std::max<size_t>(1, std::min<size_t>(std::min(by_buckets, by_entries), MAX_FUSED));
+}
+
 hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n,
                                     hipStream_t stream, uint8_t* out_affine, MsmTimings* tm) {
+  const fp_words* sc[1] = {d_scalars};
+  const g1_affine_mem* bs[1] = {d_bases};
+  return enqueue_front_fused(sc, bs, 1, n, stream, out_affine, tm);
+}
+
+// M independent MSMs of the same length n as ONE job: every kernel covers M*W windows, so the
+// latency-bound phases (scans, bucket reduction, host round trips) are paid once per batch
+hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases,
+                                          size_t M, size_t n, hipStream_t stream, uint8_t* out_affine,
+                                          MsmTimings* tm) {
   Job& j = job_;
   j = Job{};
-  j.scalars = d_scalars; j.bases = d_bases; j.n = n; j.stream = stream; j.out = out_affine; j.tm = tm;
+  j.M = (uint32_t)M; j.n = n; j.stream = stream; j.out = out_affine; j.tm = tm;
   if (tm) *tm = MsmTimings{};
-  if (n == 0) {
+  if (n == 0 || M == 0) {
     j.trivial = true;
     return hipSuccess;
   }
-  if (n >= (1ull << 31)) return hipErrorInvalidValue;
+  if (n >= (1ull << 31) || M > MAX_FUSED) return hipErrorInvalidValue;
+  for (size_t m = 0; m < M; m++) {
+    j.bp.scalars[m] = d_scalars[m];
+    j.bp.bases[m] = d_bases[m];
+  }
   const uint32_t c = j.c = window_bits_for(n);
-  const uint32_t W = j.wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
+  const uint32_t W1 = j.wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
+  const uint32_t W = W1 * (uint32_t)M;             // windows of the whole fused job
   const uint32_t nbw = j.nbw = 1u << (c - 1);
   const uint32_t NB = j.NB = W * nbw;
+  if (NB > (1u << 21)) return hipErrorInvalidValue;
   const size_t entries = (size_t)W * n;
   // window widths: W-1 signed windows + an unsigned top window, 254 bits in total
-  for (uint32_t q = 0; q + 1 < W; q++) j.wp.width[q] = (uint8_t)c;
-  j.wp.width[W - 1] = (uint8_t)(c - 1);
-  for (uint32_t k = 0, slack = W * c - 255; k < slack; k++) j.wp.width[W - 2 - k] -= 1;
+  for (uint32_t q = 0; q + 1 < W1; q++) j.wp.width[q] = (uint8_t)c;
+  j.wp.width[W1 - 1] = (uint8_t)(c - 1);
+  for (uint32_t k = 0, slack = W1 * c - 255; k < slack; k++) j.wp.width[W1 - 2 - k] -= 1;
   // task length: deep enough to amortise, shallow enough that the longest dependent chain of
   // additions stays a small multiple of the per-lane share of the work
   j.log_L = cfg_.log_seg;
@@ -651,8 +682,13 @@ hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_m
   }
   SG_TRY(meta_.reserve(16));
   if (!h_meta_) SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t)));
-  if (!h_win_) SG_TRY(hipHostMalloc(&h_win_, 64 * 96 * sizeof(uint32_t)));
-  SG_TRY(win_words_.reserve(64 * 96));
+  if (h_win_cap_ < (size_t)W * 96) {
+    if (h_win_) (void)hipHostFree(h_win_);
+    h_win_ = nullptr;
+    SG_TRY(hipHostMalloc(&h_win_, (size_t)W * 96 * sizeof(uint32_t)));
+    h_win_cap_ = (size_t)W * 96;
+  }
+  SG_TRY(win_words_.reserve((size_t)W * 96));
   if (!ev_meta_) SG_TRY(hipEventCreateWithFlags(&ev_meta_, hipEventDisableTiming));
   if (!ev_done_) SG_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
   if (tm) {
@@ -660,7 +696,7 @@ hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_m
     SG_TRY(hipEventRecord(j.ev[0], stream));
   }
 
-  msm_digits<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, j.wp, dig_.p);
+  msm_digits<<<dim3((unsigned)((n + 255) / 256), (unsigned)M), 256, 0, stream>>>(j.bp, (uint32_t)n, j.wp, dig_.p);
   if (tm) SG_TRY(hipEventRecord(j.ev[1], stream));
   msm_hist<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
   msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
@@ -684,7 +720,7 @@ hipError_t MsmEngine::enqueue_back() {
     j.all_zero = true;
     return hipSuccess;
   }
-  const uint32_t NB = j.NB, W = j.wp.W, nbw = j.nbw, log_L = j.log_L;
+  const uint32_t NB = j.NB, W = j.wp.W * j.M, nbw = j.nbw, log_L = j.log_L;
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
   SG_TRY(partial_[0].reserve(ntasks));
   {
@@ -695,8 +731,8 @@ hipError_t MsmEngine::enqueue_back() {
     msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk);
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p, order_.p);
   }
-  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bases, off_.p, counts_.p, toff_[0].p, order_.p,
-                                                           log_L, ntasks, partial_[0].p);
+  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bp, j.wp.W * nbw, off_.p, counts_.p,
+                                                           toff_[0].p, order_.p, log_L, ntasks, partial_[0].p);
   const xyzz29_mem* cur = partial_[0].p;
   int lvl = 0, pbuf = 0;
   // heavy buckets: fold their partial sums until every bucket owns at most one
@@ -764,11 +800,11 @@ hipError_t MsmEngine::finish() {
     }
   };
   if (j.trivial) {
-    std::memset(j.out, 0, 64);
+    std::memset(j.out, 0, 64 * std::max<size_t>(1, j.M));
     return hipSuccess;
   }
   if (j.all_zero) {
-    std::memset(j.out, 0, 64);
+    std::memset(j.out, 0, 64 * (size_t)j.M);
     drop_events();
     return hipSuccess;
   }
@@ -783,17 +819,20 @@ hipError_t MsmEngine::finish() {
     std::memcpy(zzz.v, h_win_ + 32 * q + 24, 32);
     return jac_from_xyzz(x, y, zz, zzz);
   };
-  Jac total = Jac::identity();
-  for (int w = (int)j.wp.W - 1; w >= 0; w--) {
-    for (uint32_t k = 0; k < j.wp.width[w]; k++) total = jac_double(total);
-    Jac t = point_at(3 * w + 2);
-    for (uint32_t k = 0; k < j.log_N; k++) t = jac_double(t);
-    t = jac_add(t, point_at(3 * w + 1));
-    for (uint32_t k = 0; k < j.log_G; k++) t = jac_double(t);
-    t = jac_add(t, point_at(3 * w));
-    total = jac_add(total, t);
+  for (uint32_t m = 0; m < j.M; m++) {
+    Jac total = Jac::identity();
+    for (int w = (int)j.wp.W - 1; w >= 0; w--) {
+      const uint32_t q = 3 * (m * j.wp.W + (uint32_t)w);
+      for (uint32_t k = 0; k < j.wp.width[w]; k++) total = jac_double(total);
+      Jac t = point_at(q + 2);
+      for (uint32_t k = 0; k < j.log_N; k++) t = jac_double(t);
+      t = jac_add(t, point_at(q + 1));
+      for (uint32_t k = 0; k < j.log_G; k++) t = jac_double(t);
+      t = jac_add(t, point_at(q));
+      total = jac_add(total, t);
+    }
+    jac_to_affine_bytes(total, j.out + 64 * m);
   }
-  jac_to_affine_bytes(total, j.out);
 
   if (j.tm) {
     MsmTimings* tm = j.tm;

@@ -10,10 +10,12 @@
 namespace sg {
 
 struct NttConfig {
+  // measured on MI355X (gpurun_out/ntt_sweep*.txt): small tiles (several workgroups per CU
+  // hide the barrier and load latency) beat fewer, longer passes: the kernel is product-bound
   uint32_t max_single_log = 11;  // largest transform done in one LDS-resident pass
-  uint32_t max_multi_log = 10;   // largest per-pass DFT length in multi-pass plans
-  uint32_t tile_log = 11;        // log2(elements per workgroup tile)  (2^11 * 32 B = 64 KiB LDS)
-  uint32_t threads = 1024;       // one butterfly per thread per stage at tile_log = 11
+  uint32_t max_multi_log = 8;    // largest per-pass DFT length in multi-pass plans
+  uint32_t tile_log = 9;         // log2(elements per workgroup tile)  (2^9 * 36 B = 18 KiB LDS)
+  uint32_t threads = 256;        // one butterfly per thread per stage at tile_log = 9
 };
 
 #ifndef SG_WORDS8

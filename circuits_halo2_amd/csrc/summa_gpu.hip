@@ -327,21 +327,31 @@ int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases
   // inputs are ordered on the caller's stream
   CHECK_HIP(hipEventRecord(c.ev_in, pick_stream(stream)), "event");
   for (auto& bs : c.bstream) CHECK_HIP(hipStreamWaitEvent(bs, c.ev_in, 0), "stream wait");
+  // consecutive MSMs of equal length are fused into one job (all kernels span the whole
+  // group); groups alternate between the two engines
+  struct Group { size_t first, count; };
+  std::vector<Group> groups;
+  for (size_t i = 0; i < count;) {
+    size_t lim = eng[0]->max_fused(n[i]), g = 1;
+    while (i + g < count && n[i + g] == n[i] && g < lim) g++;
+    groups.push_back({i, g});
+    i += g;
+  }
   hipError_t e = hipSuccess;
-  size_t finished = 0;
-  for (size_t i = 0; i < count && e == hipSuccess; i++) {
-    const int k = (int)(i & 1);
-    if (i >= 2) {
+  for (size_t gi = 0; gi < groups.size() && e == hipSuccess; gi++) {
+    const int k = (int)(gi & 1);
+    if (gi >= 2) {
       e = eng[k]->finish();
-      finished = i - 1;
       if (e != hipSuccess) break;
     }
-    e = eng[k]->enqueue_front(static_cast<const fp_words*>(d_scalars[i]), static_cast<const g1_affine_mem*>(d_bases[i]),
-                              n[i], c.bstream[k], out_affine + 64 * i, nullptr);
+    const Group& g = groups[gi];
+    e = eng[k]->enqueue_front_fused(reinterpret_cast<const fp_words* const*>(d_scalars + g.first),
+                                    reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), g.count,
+                                    n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr);
     if (e == hipSuccess) e = eng[k]->enqueue_back();
   }
-  for (size_t i = (count >= 2 ? count - 2 : 0); i < count && e == hipSuccess; i++) e = eng[i & 1]->finish();
-  (void)finished;
+  for (size_t gi = (groups.size() >= 2 ? groups.size() - 2 : 0); gi < groups.size() && e == hipSuccess; gi++)
+    e = eng[gi & 1]->finish();
   if (e != hipSuccess) {
     (void)hipDeviceSynchronize();
     return hip_fail("msm batch", e);
@@ -657,6 +667,7 @@ int sg_set_param(const char* name, int value) {
   std::string s(name);
   if (s == "msm.window_bits") g_ctx->msm.config().window_bits = (uint32_t)value;
   else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = (uint32_t)std::min(12, value);
+  else if (s == "msm.log_fuse_entries") { g_ctx->msm.config().log_fuse_entries = g_ctx->msm_b.config().log_fuse_entries = (uint32_t)std::max(16, std::min(30, value)); }
   else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = (uint32_t)std::min(8, value);
   else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
   else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));

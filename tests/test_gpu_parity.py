@@ -314,6 +314,17 @@ def test_msm_batch_pipeline(gpu, O):
     for g, w in zip(got, [w for w, (s, _) in zip(want, pairs) if s.size]):
         assert (g == w).all()
     assert gpu.best_multiexp_batch([]) == []
+    # equal-length MSMs are fused into one job: same bases / different scalars (advice columns),
+    # different bases too, all-zero members, more members than one fused job holds
+    n = 1 << 12
+    bases = [O.fixed_base_mul(O.random_fr(70 + i, n), O.ncpu()) for i in range(2)]
+    pairs = []
+    for i in range(40):
+        sc = O.random_fr(100 + i, n) if i % 7 != 3 else np.zeros(32 * n, np.uint8)
+        pairs.append((sc, bases[i % 2]))
+    got = gpu.best_multiexp_batch(pairs)
+    for g, (sc, bs) in zip(got, pairs):
+        assert (g == O.best_multiexp(sc, bs, O.ncpu())).all()
 
 
 def test_fixed_base_mul(gpu, O):
