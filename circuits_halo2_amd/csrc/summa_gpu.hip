@@ -85,6 +85,32 @@ __global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, words8 omega_ext, fp_w
   fp_words_store(out + i, o);
 }
 
+// ParamsKZG::setup scalars: pw[i] = tau^i, lg[i] = L_i(tau) = omega^i (tau^n - 1) / (n (tau - omega^i))
+// (Montgomery-2^256 words); the group part is g1_fixed_base_mul over them.
+__global__ void kzg_setup_scalars(uint32_t k, words8 tau_w, fp_words* pw, fp_words* lg) {
+  typedef Fr29 P;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> k) return;
+  uint32_t rw[8];
+  for (int q = 0; q < 8; q++) rw[q] = ROOT_OF_UNITY_M[q];
+  f29 omega = f29_words_to_r261<P>(rw);
+  for (uint32_t q = k; q < 28; q++) omega = f29_sqr<P>(omega);
+  const f29 tau = f29_words_to_r261<P>(tau_w.l);
+  uint32_t o[8];
+  f29_to_words(f29_reduce_with<P>(f29_pow_u64<P>(tau, i), P::r256), o);
+  fp_words_store(pw + i, o);
+  f29 tn = tau;
+  for (uint32_t q = 0; q < k; q++) tn = f29_sqr<P>(tn);
+  f29 num = f29_sub<P, 0>(tn, f29_one<P>());                   // tau^n - 1
+  f29 n = f29_one<P>();
+  for (uint32_t q = 0; q < k; q++) n = f29_cond_sub_p<P>(f29_normalize(f29_dbl(n)));
+  const f29 wi = f29_pow_u64<P>(omega, i);
+  f29 den = f29_mul<P>(n, f29_sub<P, 0>(tau, wi));             // n (tau - omega^i)
+  f29 l = f29_mul<P>(f29_mul<P>(wi, num), f29_inv<P>(den));
+  f29_to_words(f29_reduce_with<P>(l, P::r256), o);
+  fp_words_store(lg + i, o);
+}
+
 struct Srs {
   uint32_t k;
   g1_affine_mem* g;
@@ -646,6 +672,50 @@ int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) 
   if (!n) return SG_OK;
   return download(out_affine, g_ctx->stage_b.p, n * 64, g_ctx->stream);
 }
+// ParamsKZG::<Bn256>::setup(k, rng) with tau supplied by the caller's RNG (zk_prover/src/circuits/
+// utils.rs:70): g[i] = tau^i G, g_lagrange[i] = L_i(tau) G.  (g2 / s_g2 are verifier-side, not built.)
+int sg_kzg_setup_dev(uint32_t k, const uint8_t tau[32], void* d_g, void* d_g_lagrange, void* stream) {
+  if (!tau || !d_g || !d_g_lagrange || k > 28) return fail(SG_ERR_INVALID, "sg_kzg_setup: bad argument");
+  LOCKED_CTX();
+  const size_t n = (size_t)1 << k;
+  hipError_t e = g_ctx->stage_a.reserve(n * 32);
+  if (e == hipSuccess) e = g_ctx->stage_b.reserve(n * 32);
+  if (e != hipSuccess) return hip_fail("staging buffer", e);
+  hipStream_t s = pick_stream(stream);
+  words8 t;
+  std::memcpy(&t, tau, 32);
+  fp_words* pw = reinterpret_cast<fp_words*>(g_ctx->stage_a.p);
+  fp_words* lg = reinterpret_cast<fp_words*>(g_ctx->stage_b.p);
+  kzg_setup_scalars<<<(unsigned)((n + 127) / 128), 128, 0, s>>>(k, t, pw, lg);
+  e = fixed_base_mul(pw, n, static_cast<g1_affine_mem*>(d_g), s);
+  if (e == hipSuccess) e = fixed_base_mul(lg, n, static_cast<g1_affine_mem*>(d_g_lagrange), s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // staging buffers are reused by later calls
+  if (e != hipSuccess) return hip_fail("kzg_setup", e);
+  return SG_OK;
+}
+int sg_kzg_setup(uint32_t k, const uint8_t tau[32], uint8_t* g, uint8_t* g_lagrange) {
+  if (!tau || !g || !g_lagrange || k > 28) return fail(SG_ERR_INVALID, "sg_kzg_setup: bad argument");
+  const size_t bytes = (size_t)64 << k;
+  void *dg = nullptr, *dl = nullptr;
+  {
+    LOCKED_CTX();
+    CHECK_HIP(hipMalloc(&dg, bytes), "sg_kzg_setup");
+    if (hipMalloc(&dl, bytes) != hipSuccess) {
+      (void)hipFree(dg);
+      return fail(SG_ERR_NOMEM, "sg_kzg_setup: out of device memory");
+    }
+  }
+  int rc = sg_kzg_setup_dev(k, tau, dg, dl, nullptr);
+  if (rc == SG_OK) {
+    hipError_t e = hipMemcpy(g, dg, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(g_lagrange, dl, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail("sg_kzg_setup", e);
+  }
+  (void)hipFree(dg);
+  (void)hipFree(dl);
+  return rc;
+}
+
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
   if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
   LOCKED_CTX();

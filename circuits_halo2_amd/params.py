@@ -44,6 +44,19 @@ class ParamsKZG:
                    bytes(raw[4 + 128 * n:4 + 128 * n + 128]), bytes(raw[4 + 128 * n + 128:]))
 
     @classmethod
+    def setup(cls, k: int, tau) -> "ParamsKZG":
+        """ParamsKZG::setup(k, rng): the "unsafe" setup of generate_setup_artifacts(k, None, ..)
+        (utils.rs:68-71).  `tau`: the secret scalar as 32 B Montgomery Fr (upstream draws it
+        from OsRng).  Scalars tau^i / L_i(tau) and the 2 * 2^k fixed-base products run on the GPU."""
+        t = ffi.u8(tau)
+        if t.size != 32:
+            raise ValueError("tau must be one 32-byte Fr")
+        g = np.zeros(64 << k, dtype=np.uint8)
+        gl = np.zeros(64 << k, dtype=np.uint8)
+        ffi.check(ffi.lib().sg_kzg_setup(C.c_uint32(k), ffi.ptr(t), ffi.ptr(g), ffi.ptr(gl)))
+        return cls(k, g, gl)
+
+    @classmethod
     def setup_from_tau_powers(cls, k: int, tau_powers_mont: np.ndarray, lagrange_evals_mont: np.ndarray):
         """ParamsKZG::setup's group part: g[i] = tau^i * G, g_lagrange[i] = L_i(tau) * G, both
         as fixed-base products on the GPU (the scalar side -- powers of tau and L_i(tau) -- is

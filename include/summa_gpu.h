@@ -123,6 +123,13 @@ int sg_domain_constant(uint32_t k, int which, uint8_t out[32]);
 int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine);
 int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, void* stream);
 
+/* ParamsKZG::<Bn256>::setup(k, rng) (zk_prover/src/circuits/utils.rs:70) with tau = the field
+ * element the caller drew from its RNG (32 B Montgomery Fr): g[i] = tau^i * G,
+ * g_lagrange[i] = L_i(tau) * G, 2^k points of 64 B each.  The G2 elements of the SRS are only
+ * used by the verifier's pairing check and are not produced here. */
+int sg_kzg_setup(uint32_t k, const uint8_t tau[32], uint8_t* g, uint8_t* g_lagrange);
+int sg_kzg_setup_dev(uint32_t k, const uint8_t tau[32], void* d_g, void* d_g_lagrange, void* stream);
+
 /* ---- helpers: Fr canonical <-> Montgomery (PrimeField::from_repr / to_repr in bulk) */
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);

@@ -363,3 +363,55 @@ def test_msm_full_size_known_answer(gpu, O, log_n):
     got = gpu.best_multiexp(dev(sm.reshape(-1)), bases)
     dot = O.fr_dot(sm[idx].reshape(-1).copy(), s.cpu().numpy().reshape(n, 32)[idx].reshape(-1).copy())
     assert (got == O.g1_mul(O.g1_generator(), dot)).all()
+
+
+def test_params_setup_matches_bigint(gpu, O, P):
+    """ParamsKZG::setup on the GPU vs the definition: g[i] = tau^i G, g_lagrange[i] = L_i(tau) G"""
+    k, n = 6, 64
+    tau = P.random_fr(0xBEEF, 1)[0]
+    params = gpu.ParamsKZG.setup(k, fr_np([tau]))
+    assert (params.g == O.fixed_base_mul(O.fr_powers(fr_np([tau]), n), 2)).all()
+    w = P.omega_for(k)
+    num = (pow(tau, n, P.R) - 1) * pow(n, -1, P.R) % P.R
+    lag = [pow(w, i, P.R) * num * pow(tau - pow(w, i, P.R), -1, P.R) % P.R for i in range(n)]
+    assert sum(lag) % P.R == 1
+    assert (params.g_lagrange == O.fixed_base_mul(fr_np(lag), 2)).all()
+    # the two bases commit to the same polynomial
+    evals = O.random_fr(9, n)
+    coeffs = gpu.EvaluationDomain(3, k).lagrange_to_coeff(evals)
+    assert (params.commit_lagrange(evals) == params.commit(coeffs)).all()
+    params.free()
+
+
+def test_k11_proof_op_shapes_on_reference_srs(gpu, O, srs11):
+    """BASELINE configs[0] shape (k = 11, SRS hermez-raw-11): the MSM / NTT call shapes of one
+    MstInclusion proof -- commit_lagrange of witness-like and dense columns,
+    commit of coefficient-form polynomials, lagrange_to_coeff (2^11), coeff_to_extended /
+    extended_to_coeff (2^14) -- each compared with the oracle."""
+    k = 11
+    n = 1 << k
+    params = gpu.ParamsKZG(k, srs11["g_np"], srs11["gl_np"])
+    dom = gpu.EvaluationDomain(6, k)
+    rng = np.random.default_rng(11)
+    dense = O.random_fr(0x11, n)
+    bytes_col = fr_np([int(v) for v in rng.integers(0, 256, n)])          # range-check column
+    sparse = fr_np([int(v) if i % 37 == 0 else 0 for i, v in enumerate(rng.integers(0, 1 << 62, n))])
+    cols = [dense, bytes_col, sparse]
+    got = gpu.best_multiexp_batch([(c, srs11["gl_np"]) for c in cols])          # phase-1 advice commitments
+    for g, c in zip(got, cols):
+        assert (g == O.best_multiexp(c, srs11["gl_np"], O.ncpu())).all()
+        assert (params.commit_lagrange(c) == g).all()
+    coeffs = dom.lagrange_to_coeff(dense)
+    assert (coeffs == O.lagrange_to_coeff(dense, k, O.ncpu())).all()
+    assert (params.commit(coeffs) == O.best_multiexp(coeffs, srs11["g_np"], O.ncpu())).all()
+    assert (params.commit(coeffs) == params.commit_lagrange(dense)).all()      # same polynomial, two bases
+    ext = dom.coeff_to_extended(coeffs)
+    assert (ext == O.coeff_to_extended(coeffs, k, dom.extended_k, O.ncpu())).all()
+    h = dom.extended_to_coeff(dom.divide_by_vanishing_poly(ext))
+    want = O.extended_to_coeff(O.divide_by_vanishing_poly(ext, k, dom.extended_k), k, dom.extended_k, O.ncpu())
+    assert (h == want[:h.size]).all()
+    pieces = [h[32 * n * i:32 * n * (i + 1)] for i in range(5)]                # 5 quotient pieces
+    got = gpu.best_multiexp_batch([(p, srs11["g_np"]) for p in pieces])
+    for g, p in zip(got, pieces):
+        assert (g == O.best_multiexp(np.ascontiguousarray(p), srs11["g_np"], O.ncpu())).all()
+    params.free()
