@@ -110,6 +110,9 @@ class MsmEngine {
   uint32_t* h_win_ = nullptr;  // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window
 };
 
+// FFT over G1 (N5): out = DFT_omega(in) [* scale], natural order; d_work: 2^log_n xyzz29_mem
+hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_n, const words8& omega,
+                  const words8* scale, xyzz29_mem* d_work, hipStream_t stream);
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream);
 
 }  // namespace sg

@@ -550,6 +550,92 @@ __global__ void __launch_bounds__(256) g1_fixed_base_mul(const fp_words* __restr
   for (int k = 0; k < 4; k++) out[i].q[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
 }
 
+// ------------------------------------------------------------------ N5: FFT over G1
+// ParamsKZG::downsize / g_to_lagrange: the same radix-2 butterfly as
+// best_fft with group elements: a' = a + w*b, b' = a - w*b, w*b a 254-bit scalar
+// multiplication.  Set-up time only (once per SRS), so: one thread per butterfly per stage,
+// points in XYZZ limb form in global memory, twiddles computed on the fly.
+__device__ inline xyzz29 xyzz29_scalar_mul(const xyzz29& p, const uint32_t k[8]) {
+  xyzz29 acc = xyzz29_identity();
+  for (int limb = 7; limb >= 0; limb--) {
+    const uint32_t w = k[limb];
+    for (int bit = 31; bit >= 0; bit--) {
+      acc = xyzz29_double(acc);
+      if ((w >> bit) & 1) xyzz29_add(acc, p);
+    }
+  }
+  return acc;
+}
+// canonical integer words of x^ (2^261-domain Fr)
+__device__ __forceinline__ void fr29_to_integer_words(const f29& x, uint32_t w[8]) {
+  f29 one = f29_zero();
+  one.l[0] = 1;
+  f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(x, one)), w);
+}
+__global__ void g1fft_load(const g1_affine_mem* __restrict__ in, uint32_t log_n, xyzz29_mem* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> log_n) return;
+  g1_affine_mem raw = in[i];
+  affine29 q = affine29_load(&raw);
+  xyzz29 p = xyzz29_identity();
+  xyzz29_madd(p, q);  // identity + q: reduces the lazy coordinates, sets ZZ = ZZZ = 1
+  uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0;
+  xyzz29_store(out + r, p);
+}
+__global__ void __launch_bounds__(128) g1fft_stage(xyzz29_mem* __restrict__ a, uint32_t log_n, uint32_t s, words8 omega) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >> (log_n - 1)) return;
+  const uint32_t h = 1u << s, j = q & (h - 1), blk = q >> s;
+  const uint32_t i0 = (blk << (s + 1)) + j, i1 = i0 + h;
+  xyzz29 u = xyzz29_load(a + i0), v = xyzz29_load(a + i1);
+  if (j) {
+    uint32_t k[8];
+    fr29_to_integer_words(f29_pow_u64<Fr29>(f29_words_to_r261<Fr29>(omega.l), (uint64_t)j << (log_n - s - 1)), k);
+    v = xyzz29_scalar_mul(v, k);
+  }
+  xyzz29 sum = u;
+  xyzz29_add(sum, v);
+  if (!xyzz29_is_identity(v)) v.y = f29_sub<Fq29, 1>(f29_zero(), v.y);  // -v: Y < 4 -> 4p - Y
+  xyzz29_add(u, v);
+  xyzz29_store(a + i0, sum);
+  xyzz29_store(a + i1, u);
+}
+// out[i] = scale * a[i], affine
+__global__ void __launch_bounds__(128) g1fft_store(const xyzz29_mem* __restrict__ a, uint32_t log_n, words8 scale,
+                                                   uint32_t has_scale, g1_affine_mem* __restrict__ out) {
+  typedef Fq29 P;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> log_n) return;
+  xyzz29 p = xyzz29_load(a + i);
+  if (has_scale) {
+    uint32_t k[8];
+    fr29_to_integer_words(f29_words_to_r261<Fr29>(scale.l), k);
+    p = xyzz29_scalar_mul(p, k);
+  }
+  uint32_t ow[16];
+  if (xyzz29_is_identity(p)) {
+    for (int k = 0; k < 16; k++) ow[k] = 0;
+  } else {
+    f29 iz = f29_inv<P>(p.zzz);
+    f29 t = f29_mul<P>(p.zz, iz);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(p.x, f29_sqr<P>(t)), P::r256), ow);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(p.y, iz), P::r256), ow + 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[i].q[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
+}
+
+hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_n, const words8& omega,
+                  const words8* scale, xyzz29_mem* d_work, hipStream_t stream) {
+  const uint32_t n = 1u << log_n;
+  g1fft_load<<<(n + 127) / 128, 128, 0, stream>>>(d_in, log_n, d_work);
+  for (uint32_t s = 0; s < log_n; s++)
+    g1fft_stage<<<(n / 2 + 127) / 128, 128, 0, stream>>>(d_work, log_n, s, omega);
+  words8 sc = scale ? *scale : omega;
+  g1fft_store<<<(n + 127) / 128, 128, 0, stream>>>(d_work, log_n, sc, scale ? 1u : 0u, d_out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ host driver
 #define SG_TRY(x)                      \
   do {                                 \

@@ -716,6 +716,46 @@ int sg_kzg_setup(uint32_t k, const uint8_t tau[32], uint8_t* g, uint8_t* g_lagra
   return rc;
 }
 
+// N5: best_fft over G1 (FftGroup = G1) as used by ParamsKZG::downsize / g_to_lagrange:
+// out[j] = sum_i omega^(ij) * in[i], optionally times `scale`; affine in, affine out.
+int sg_g1_fft_dev(const void* d_in, void* d_out, const uint8_t omega[32], const uint8_t* scale, uint32_t log_n,
+                  void* stream) {
+  if (!d_in || !d_out || !omega || log_n > 28) return fail(SG_ERR_INVALID, "sg_g1_fft: bad argument");
+  LOCKED_CTX();
+  hipError_t e = g_ctx->scratch.reserve((size_t)144 << log_n);
+  if (e != hipSuccess) return hip_fail("g1 fft work space", e);
+  words8 w, sc;
+  std::memcpy(&w, omega, 32);
+  if (scale) std::memcpy(&sc, scale, 32);
+  e = g1_fft(static_cast<const g1_affine_mem*>(d_in), static_cast<g1_affine_mem*>(d_out), log_n, w,
+             scale ? &sc : nullptr, reinterpret_cast<xyzz29_mem*>(g_ctx->scratch.p), pick_stream(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(pick_stream(stream));  // scratch is shared with the NTT engine
+  if (e != hipSuccess) return hip_fail("g1 fft", e);
+  return SG_OK;
+}
+// ParamsKZG::downsize's recomputation of g_lagrange from g[0..2^k): iFFT over G1 (omega^-1, n^-1)
+int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange) {
+  if (!g || !g_lagrange || k > 28) return fail(SG_ERR_INVALID, "sg_g1_to_lagrange: bad argument");
+  const size_t bytes = (size_t)64 << k;
+  words8 wi, ni;
+  {
+    LOCKED_CTX();
+    const DomainConsts* dc;
+    TRY(get_consts(k, &dc));
+    wi = dc->omega_inv;
+    ni = dc->n_inv;
+    TRY(upload(g_ctx->stage_a, g, bytes, g_ctx->stream));
+    hipError_t e = g_ctx->stage_b.reserve(bytes);
+    if (e != hipSuccess) return hip_fail("staging buffer", e);
+    CHECK_HIP(hipStreamSynchronize(g_ctx->stream), "stream sync");
+  }
+  int rc = sg_g1_fft_dev(g_ctx->stage_a.p, g_ctx->stage_b.p, reinterpret_cast<const uint8_t*>(&wi),
+                         reinterpret_cast<const uint8_t*>(&ni), k, g_ctx->stream);
+  if (rc != SG_OK) return rc;
+  LOCKED_CTX();
+  return download(g_lagrange, g_ctx->stage_b.p, bytes, g_ctx->stream);
+}
+
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
   if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
   LOCKED_CTX();

@@ -63,6 +63,20 @@ class ParamsKZG:
         supplied by the caller)."""
         return cls(k, g1_fixed_base_mul(tau_powers_mont), g1_fixed_base_mul(lagrange_evals_mont))
 
+    def downsize(self, k: int) -> None:
+        """ParamsKZG::downsize(k) (utils.rs:62-65): keep g[0..2^k) and recompute g_lagrange for
+        the smaller domain with an inverse FFT over G1 (sg_g1_to_lagrange)."""
+        if k > self.k:
+            raise ValueError("k is too large for the given params")  # utils.rs:58-60
+        if k == self.k:
+            return
+        self.free()
+        n = 1 << k
+        g = np.ascontiguousarray(self.g[:64 * n])
+        gl = np.zeros(64 * n, dtype=np.uint8)
+        ffi.check(ffi.lib().sg_g1_to_lagrange(ffi.ptr(g), C.c_uint32(k), ffi.ptr(gl)))
+        self.k, self.n, self.g, self.g_lagrange = k, n, g, gl
+
     # --- device cache -------------------------------------------------------------------
     def handle(self) -> int:
         if self._handle is None:

@@ -130,6 +130,14 @@ int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine
 int sg_kzg_setup(uint32_t k, const uint8_t tau[32], uint8_t* g, uint8_t* g_lagrange);
 int sg_kzg_setup_dev(uint32_t k, const uint8_t tau[32], void* d_g, void* d_g_lagrange, void* stream);
 
+/* ---- N5: best_fft over G1 (halo2's FftGroup for curve points), used by ParamsKZG::downsize
+ * (zk_prover/src/circuits/utils.rs:64) to recompute g_lagrange for the truncated g[]:
+ * out[j] = sum_i omega^(ij) * in[i], optionally times `scale` (NULL: none).  Set-up time only. */
+int sg_g1_fft_dev(const void* d_in, void* d_out, const uint8_t omega[32], const uint8_t* scale, uint32_t log_n,
+                  void* stream);
+/* g_lagrange[0..2^k) from g[0..2^k): inverse G1 FFT with the domain's omega^-1 and n^-1 */
+int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange);
+
 /* ---- helpers: Fr canonical <-> Montgomery (PrimeField::from_repr / to_repr in bulk) */
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);

@@ -415,3 +415,29 @@ def test_k11_proof_op_shapes_on_reference_srs(gpu, O, srs11):
     for g, p in zip(got, pieces):
         assert (g == O.best_multiexp(np.ascontiguousarray(p), srs11["g_np"], O.ncpu())).all()
     params.free()
+
+
+def test_g1_fft_reproduces_the_reference_srs_lagrange_basis(gpu, O, srs11):
+    """N5 golden: the reference's own SRS file holds both bases; the inverse G1 FFT of g[]
+    (what ParamsKZG::downsize / g_to_lagrange compute) must give the file's g_lagrange."""
+    import ctypes as C
+    from circuits_halo2_amd import ffi
+    gl = np.zeros_like(srs11["gl_np"])
+    ffi.check(ffi.lib().sg_g1_to_lagrange(ffi.ptr(srs11["g_np"]), C.c_uint32(11), ffi.ptr(gl)))
+    assert (gl == srs11["gl_np"]).all()
+
+
+def test_params_downsize(gpu, O, srs11):
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    with pytest.raises(ValueError):
+        params.downsize(12)
+    params.downsize(8)
+    assert params.k == 8 and (params.g == srs11["g_np"][:64 * 256]).all()
+    dom = gpu.EvaluationDomain(3, 8)
+    for j in (0, 1, 77, 255):  # g_lagrange[j] = commit(L_j) over the truncated monomial basis
+        e = [0] * 256
+        e[j] = 1
+        assert (params.commit(dom.lagrange_to_coeff(fr_np(e))) == params.g_lagrange[64 * j:64 * j + 64]).all()
+    evals = O.random_fr(3, 256)
+    assert (params.commit_lagrange(evals) == params.commit(dom.lagrange_to_coeff(evals))).all()
+    params.free()
