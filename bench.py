@@ -137,7 +137,7 @@ def main():
         line["alu"] = {"bucket_adds_per_launch": adds, "fq_mul_per_s": adds * 10 / (acc_ms * 1e-3),
                        "note": "8M+2S XYZZ mixed add; see profiles/r01_microbench_instr_rates.txt for instruction peaks"}
 
-        # throughput mode: the same MSM issued as a batch of 8 (pipelined over two streams)
+        # throughput mode: the same MSM issued as a batch of 8 (fused / pipelined jobs)
         sg.best_multiexp_batch([(scal, bases)] * 2)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -147,7 +147,7 @@ def main():
         assert all((o == result).all() for o in outs) or world > 1
         line["batched"] = {"msms": 8, "ms_per_msm": bdt / 8 * 1e3, "points_per_s": 8 * n / bdt}
 
-        if not args.no_extras:
+        if not args.no_extras and world == 1:
             line["ntt"] = {}
             for lg in (17, 22):
                 a = fr_to_montgomery(torch.from_numpy(random_fr_canonical(DEFAULT_SEED + 100 + lg, 1 << lg)).cuda())
@@ -175,7 +175,7 @@ def main():
                                         "note": "MSM+NTT kernel sum only (evaluate_h etc. are §8f 'next' rows)"}
 
         # ---- CPU baseline: the oracle's restated halo2 best_multiexp on this box's cores
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             from oracle import oracle as O
             cores = min(O.ncpu(), 16)  # the GPU box gives a 16-core share per GPU
             hs, hb = scal.cpu().numpy(), bases.cpu().numpy()
