@@ -133,3 +133,42 @@ def fr_from_montgomery(mont):
     ffi.check(L.sg_fr_from_montgomery_dev(ffi.dev_ptr(mont), ffi.dev_ptr(out), C.c_size_t(mont.numel() // 32),
                                           ffi.current_stream_ptr()))
     return out
+
+
+# ---- helpers that keep vectors on the device between NTTs and MSMs ---------
+def eval_polynomial(poly, point):
+    """halo2_proofs::arithmetic::eval_polynomial: sum_i poly[i] * point^i -> 32-byte Fr"""
+    L = ffi.lib()
+    x = ffi.u8(point)
+    out = np.zeros(32, dtype=np.uint8)
+    if _is_torch_cuda(poly):
+        ffi.check(L.sg_fr_eval_poly_dev(ffi.dev_ptr(poly), C.c_size_t(poly.numel() // 32), ffi.ptr(x),
+                                        ffi.current_stream_ptr(), ffi.ptr(out)))
+    else:
+        c = ffi.u8(poly)
+        ffi.check(L.sg_fr_eval_poly(ffi.ptr(c), C.c_size_t(c.size // 32), ffi.ptr(x), ffi.ptr(out)))
+    return out
+
+
+def batch_invert(a):
+    """ff::BatchInvert on a device tensor, in place (zeros stay zero)"""
+    ffi.check(ffi.lib().sg_fr_batch_invert_dev(ffi.dev_ptr(a), C.c_size_t(a.numel() // 32), ffi.current_stream_ptr()))
+    return a
+
+
+def prefix_product(a):
+    """out[0] = 1, out[i] = a[0] * ... * a[i-1]; returns a device tensor of n + 1 elements"""
+    import torch
+    n = a.numel() // 32
+    out = torch.empty(32 * (n + 1), dtype=torch.uint8, device=a.device)
+    ffi.check(ffi.lib().sg_fr_prefix_product_dev(ffi.dev_ptr(a), C.c_size_t(n), ffi.dev_ptr(out),
+                                                 ffi.current_stream_ptr()))
+    return out
+
+
+def fr_mul(a, b):
+    import torch
+    out = torch.empty_like(a)
+    ffi.check(ffi.lib().sg_fr_mul_dev(ffi.dev_ptr(a), ffi.dev_ptr(b), C.c_size_t(a.numel() // 32), ffi.dev_ptr(out),
+                                      ffi.current_stream_ptr()))
+    return out

@@ -16,6 +16,7 @@
 #include "host_curve.h"
 #include "msm.h"
 #include "ntt.h"
+#include "poly.h"
 
 using namespace sg;
 
@@ -768,6 +769,67 @@ int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* str
   LOCKED_CTX();
   hipError_t e = fr_montgomery(static_cast<const fp_words*>(d_in), static_cast<fp_words*>(d_out), n, 0, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_from_montgomery", e);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ polynomial helpers
+int sg_fr_eval_poly_dev(const void* d_coeffs, size_t n, const uint8_t x[32], void* stream, uint8_t out[32]) {
+  if (!x || !out || (n && !d_coeffs)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly: null argument");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly: polynomial too long");
+  if (n == 0) {
+    std::memset(out, 0, 32);
+    return SG_OK;
+  }
+  LOCKED_CTX();
+  const size_t t = poly_eval_tmp_elems(n);
+  hipError_t e = g_ctx->scratch.reserve((2 * t + 1) * 32);
+  if (e != hipSuccess) return hip_fail("eval_poly work space", e);
+  fp_words* tmp = reinterpret_cast<fp_words*>(g_ctx->scratch.p);
+  words8 xw;
+  std::memcpy(&xw, x, 32);
+  hipStream_t s = pick_stream(stream);
+  e = poly_eval(static_cast<const fp_words*>(d_coeffs), n, xw, tmp, tmp + t, tmp + 2 * t, s);
+  if (e != hipSuccess) return hip_fail("eval_poly", e);
+  return download(out, tmp + 2 * t, 32, s);
+}
+int sg_fr_eval_poly(const uint8_t* coeffs, size_t n, const uint8_t x[32], uint8_t out[32]) {
+  if (!x || !out || (n && !coeffs)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly: null argument");
+  const void* d = nullptr;
+  {
+    LOCKED_CTX();
+    TRY(upload(g_ctx->stage_a, coeffs, n * 32, g_ctx->stream));
+    d = g_ctx->stage_a.p;
+  }
+  return sg_fr_eval_poly_dev(d, n, x, g_ctx->stream, out);
+}
+int sg_fr_batch_invert_dev(void* d_a, size_t n, void* stream) {
+  if (n && !d_a) return fail(SG_ERR_INVALID, "sg_fr_batch_invert: null argument");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_batch_invert: vector too long");
+  LOCKED_CTX();
+  hipError_t e = poly_batch_invert(static_cast<fp_words*>(d_a), n, pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("batch_invert", e);
+  return SG_OK;
+}
+int sg_fr_prefix_product_dev(const void* d_a, size_t n, void* d_out, void* stream) {
+  if (!d_out || (n && !d_a)) return fail(SG_ERR_INVALID, "sg_fr_prefix_product: null argument");
+  if (n > (1ull << 21) - 1) return fail(SG_ERR_INVALID, "sg_fr_prefix_product: at most 2^21 - 1 elements");
+  LOCKED_CTX();
+  hipError_t e = g_ctx->scratch.reserve(prefix_product_tmp_elems(n + 1) * 32 + 64);
+  if (e != hipSuccess) return hip_fail("prefix_product work space", e);
+  hipStream_t s = pick_stream(stream);
+  e = poly_prefix_product(static_cast<const fp_words*>(d_a), n, reinterpret_cast<fp_words*>(g_ctx->scratch.p),
+                          static_cast<fp_words*>(d_out), s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the scratch buffer is shared
+  if (e != hipSuccess) return hip_fail("prefix_product", e);
+  return SG_OK;
+}
+int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream) {
+  if (n && (!d_a || !d_b || !d_out)) return fail(SG_ERR_INVALID, "sg_fr_mul: null argument");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_mul: vector too long");
+  LOCKED_CTX();
+  hipError_t e = poly_mul_elementwise(static_cast<const fp_words*>(d_a), static_cast<const fp_words*>(d_b), n,
+                                      static_cast<fp_words*>(d_out), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fr_mul", e);
   return SG_OK;
 }
 

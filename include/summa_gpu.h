@@ -142,6 +142,19 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange);
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 
+/* ---- first "next" row: device-resident helpers between NTTs and MSMs.
+ * halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i
+ * (the 35 evaluations of create_proof) */
+int sg_fr_eval_poly(const uint8_t* coeffs, size_t n, const uint8_t x[32], uint8_t out[32]);
+int sg_fr_eval_poly_dev(const void* d_coeffs, size_t n, const uint8_t x[32], void* stream, uint8_t out[32]);
+/* ff::BatchInvert::batch_invert: in place, zeros stay zero */
+int sg_fr_batch_invert_dev(void* d_a, size_t n, void* stream);
+/* exclusive prefix product, the core of the permutation / lookup grand products (steps 5-6):
+ * out[0] = 1, out[i] = a[0] * ... * a[i-1] for i <= n  (n + 1 outputs, n < 2^21) */
+int sg_fr_prefix_product_dev(const void* d_a, size_t n, void* d_out, void* stream);
+/* out[i] = a[i] * b[i] */
+int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
+
 /* ---- tuning / introspection (not part of the reference seam) */
 typedef struct {
   float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream */

@@ -542,6 +542,37 @@ void orc_fr_eval_poly(const uint8_t *coeffs, size_t n, const uint8_t x[32], uint
     memcpy(o, &acc, 32);
 }
 
+/* ff::BatchInvert::batch_invert: in place, zeros stay zero */
+void orc_fr_batch_invert(uint8_t *a, size_t n) {
+    fe *v = (fe *)a;
+    fe *pre = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    fe acc = FR.r1;
+    for (size_t i = 0; i < n; i++) {
+        pre[i] = acc;
+        if (!fe_is_zero(&v[i])) fe_mul(&FR, &acc, &acc, &v[i]);
+    }
+    fe_inv(&FR, &acc, &acc);
+    for (size_t i = n; i-- > 0;) {
+        if (fe_is_zero(&v[i])) continue;
+        fe t;
+        fe_mul(&FR, &t, &acc, &pre[i]);
+        fe_mul(&FR, &acc, &acc, &v[i]);
+        v[i] = t;
+    }
+    free(pre);
+}
+/* out[0] = 1, out[i] = a[0] * ... * a[i-1], i <= n (the z of a grand product) */
+void orc_fr_prefix_product(const uint8_t *a, size_t n, uint8_t *out) {
+    fe acc = FR.r1;
+    for (size_t i = 0; i <= n; i++) {
+        memcpy(out + 32 * i, &acc, 32);
+        if (i < n) fe_mul(&FR, &acc, &acc, (const fe *)(a + 32 * i));
+    }
+}
+void orc_fr_mul_n(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) fe_mul(&FR, (fe *)(out + 32 * i), (const fe *)(a + 32 * i), (const fe *)(b + 32 * i));
+}
+
 int orc_g1_is_on_curve(const uint8_t p[64]) {
     const g1a *a = (const g1a *)p;
     if (g1a_is_id(a)) return 1;

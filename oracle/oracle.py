@@ -178,6 +178,25 @@ def fr_eval_poly(coeffs, x) -> np.ndarray:
     return out
 
 
+def fr_batch_invert(a) -> np.ndarray:
+    out = np.ascontiguousarray(a).copy()
+    lib().orc_fr_batch_invert(_p(out), C.c_size_t(out.size // 32))
+    return out
+
+
+def fr_prefix_product(a) -> np.ndarray:
+    n = a.size // 32
+    out = _buf(32 * (n + 1))
+    lib().orc_fr_prefix_product(_p(np.ascontiguousarray(a)), C.c_size_t(n), _p(out))
+    return out
+
+
+def fr_mul_n(a, b) -> np.ndarray:
+    out = _buf(a.size)
+    lib().orc_fr_mul_n(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), C.c_size_t(a.size // 32), _p(out))
+    return out
+
+
 def g1_is_on_curve(p) -> bool:
     return bool(lib().orc_g1_is_on_curve(_p(np.ascontiguousarray(p))))
 

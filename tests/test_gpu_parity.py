@@ -441,3 +441,39 @@ def test_params_downsize(gpu, O, srs11):
     evals = O.random_fr(3, 256)
     assert (params.commit_lagrange(evals) == params.commit(dom.lagrange_to_coeff(evals))).all()
     params.free()
+
+
+# ----------------------------------------------------------------------------- §8f-2 helpers
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 8191, 8192, 8193, 100000, 1 << 17, (1 << 20) + 5])
+def test_eval_polynomial(gpu, O, n):
+    from circuits_halo2_amd.arithmetic import eval_polynomial
+    c = O.random_fr(700 + n % 97, n)
+    x = O.random_fr(701, 1)
+    want = O.fr_eval_poly(c, x)
+    assert (eval_polynomial(c, x) == want).all()
+    assert (eval_polynomial(dev(c), x) == want).all()
+    one = fr_np([1])
+    assert (eval_polynomial(c, fr_np([0])) == c[:32]).all()
+    if n <= 8193:
+        tot = fr_np([sum(__import__("oracle.pyref", fromlist=["x"]).frs_from_bytes(c.tobytes())) %
+                     21888242871839275222246405745257275088548364400416034343698204186575808495617])
+        assert (eval_polynomial(c, one) == tot).all()
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 1000, 1 << 17])
+def test_batch_invert_and_prefix_product(gpu, O, n):
+    from circuits_halo2_amd.arithmetic import batch_invert, prefix_product, fr_mul
+    a = O.random_fr(800 + n % 89, n)
+    a[32 * (n // 3):32 * (n // 3) + 32] = 0          # zeros stay zero
+    if n > 20:
+        a[32 * 17:32 * 18] = 0
+    inv = batch_invert(dev(a)).cpu().numpy()
+    assert (inv == O.fr_batch_invert(a)).all()
+    b = O.random_fr(801, n)
+    assert (prefix_product(dev(b)).cpu().numpy() == O.fr_prefix_product(b)).all()
+    assert (fr_mul(dev(a), dev(b)).cpu().numpy() == O.fr_mul_n(a, b)).all()
+    # a grand product the way the permutation argument builds it: z[i+1] = z[i] * num[i] / den[i]
+    num, den = O.random_fr(802, n), O.random_fr(803, n)
+    ratio = fr_mul(dev(num), batch_invert(dev(den)))
+    z = prefix_product(ratio).cpu().numpy()
+    assert (z == O.fr_prefix_product(O.fr_mul_n(num, O.fr_batch_invert(den)))).all()
