@@ -14,6 +14,11 @@
 #pragma once
 #include "bn254_f29.cuh"
 
+// y3 = a*b - c*d: one fused reduction (f29_mul2) or two products; measured per kernel
+#ifndef SG_FUSED_Y3
+#define SG_FUSED_Y3 1
+#endif
+
 namespace sg {
 
 struct affine29 {
@@ -63,7 +68,11 @@ SG_HD xyzz29 xyzz29_double_affine(const affine29& q) {
   f29 m = f29_add(f29_dbl(xx), xx);                            // < 6
   r.x = f29_sub<P, 1>(f29_sqr<P>(m), f29_dbl(s));              // 36 -> <2 ; - <4 + 4p  => < 6
   f29 t = f29_sub<P, 2>(s, r.x);                               // < 2 + 8 = 10
+#if SG_FUSED_Y3
+  r.y = f29_mul2<P>(m, t, w, f29_sub<P, 0>(f29_zero(), y));    // m t + w (2p - y): 60 + 4 -> < 2
+#else
   r.y = f29_sub<P, 0>(f29_mul<P>(m, t), f29_mul<P>(w, y));     // 60, 4 ; <2 - <2 + 2p => < 4
+#endif
   r.zz = v;
   r.zzz = w;
   return r;
@@ -81,7 +90,11 @@ SG_HD xyzz29 xyzz29_double(const xyzz29& p) {
   f29 m = f29_add(f29_dbl(xx), xx);                            // < 6
   r.x = f29_sub<P, 1>(f29_sqr<P>(m), f29_dbl(s));              // < 6
   f29 t = f29_sub<P, 2>(s, r.x);                               // < 10
+#if SG_FUSED_Y3
+  r.y = f29_mul2<P>(m, t, w, f29_sub<P, 1>(f29_zero(), p.y));  // m t + w (4p - Y): 60 + 8 -> < 2
+#else
   r.y = f29_sub<P, 0>(f29_mul<P>(m, t), f29_mul<P>(w, p.y));   // 60, 8 => < 4
+#endif
   r.zz = f29_mul<P>(v, p.zz);                                  // 4
   r.zzz = f29_mul<P>(w, p.zzz);                                // 4
   return r;
@@ -113,7 +126,11 @@ SG_HD void xyzz29_madd(xyzz29& acc, const affine29& q) {
   f29 rr = f29_sqr<P>(r);                                      // 36
   f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // (<4) - (<4) + 4p => < 8
   f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
-  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(acc.y, ppp));  // 60, 8 => < 4
+#if SG_FUSED_Y3
+  f29 y3 = f29_mul2<P>(r, t, f29_sub<P, 1>(f29_zero(), acc.y), ppp);  // r t + (4p - Y1) ppp: 60 + 8 -> < 2
+#else
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(acc.y, ppp));   // 60, 8 => < 4
+#endif
   acc.zz = f29_mul<P>(acc.zz, pp);                             // 4
   acc.zzz = f29_mul<P>(acc.zzz, ppp);                          // 4
   acc.x = x3;
@@ -145,7 +162,11 @@ SG_HD void xyzz29_add(xyzz29& acc, const xyzz29& q) {
   f29 rr = f29_sqr<P>(r);                                      // 16
   f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // < 8
   f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
-  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(s1, ppp));  // 40, 4 => < 4
+#if SG_FUSED_Y3
+  f29 y3 = f29_mul2<P>(r, t, f29_sub<P, 0>(f29_zero(), s1), ppp);  // r t + (2p - S1) ppp: 40 + 4 -> < 2
+#else
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(s1, ppp));   // 40, 4 => < 4
+#endif
   acc.zz = f29_mul<P>(f29_mul<P>(acc.zz, q.zz), pp);           // 4, 4
   acc.zzz = f29_mul<P>(f29_mul<P>(acc.zzz, q.zzz), ppp);       // 4, 4
   acc.x = x3;

@@ -29,20 +29,31 @@ def _lt_r(limbs: np.ndarray) -> np.ndarray:
     return lt
 
 
+def _mix(s: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (s ^ (s >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
 def random_fr_canonical(seed: int, n: int) -> np.ndarray:
     """n uniform values in [0, r) as canonical 32-B little-endian integers (numpy uint8,
-    length 32 n).  Same stream rule as the oracle's generators (oracle/pyref.py::random_fr)."""
+    length 32 n).  Same stream rule as the oracle's generators (oracle/pyref.py::random_fr):
+    element i = SplitMix64 outputs 4i+1..4i+4 (limb 3 masked to 62 bits), a rejected candidate
+    (~24 %) is redrawn from the stream seeded (seed ^ (i+1)) + (j << 32), j = 0, 1, ...
+    Fully vectorised."""
     limbs = _splitmix_block(seed, 4 * n).reshape(n, 4).copy()
     limbs[:, 3] &= np.uint64((1 << 62) - 1)
     bad = np.nonzero(~_lt_r(limbs))[0]
-    for i in bad:  # ~24 % of candidates; each retried from its own stream
-        j = 0
-        while True:
-            w = _splitmix_block(((seed ^ (int(i) + 1)) + (j << 32)) & 0xFFFFFFFFFFFFFFFF, 4)
-            w[3] &= np.uint64((1 << 62) - 1)
-            if _lt_r(w.reshape(1, 4))[0]:
-                limbs[i] = w
-                break
+    j = 0
+    with np.errstate(over="ignore"):
+        while bad.size:
+            base = (np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (bad.astype(np.uint64) + np.uint64(1))) + np.uint64((j << 32) & 0xFFFFFFFFFFFFFFFF)
+            w = _mix(base[:, None] + _GOLD * np.arange(1, 5, dtype=np.uint64)[None, :])
+            w[:, 3] &= np.uint64((1 << 62) - 1)
+            ok = _lt_r(w)
+            limbs[bad[ok]] = w[ok]
+            bad = bad[~ok]
             j += 1
     return limbs.view(np.uint8).reshape(-1)
 

@@ -477,3 +477,27 @@ def test_batch_invert_and_prefix_product(gpu, O, n):
     ratio = fr_mul(dev(num), batch_invert(dev(den)))
     z = prefix_product(ratio).cpu().numpy()
     assert (z == O.fr_prefix_product(O.fr_mul_n(num, O.fr_batch_invert(den)))).all()
+
+
+def test_sizes_beyond_the_baseline_configs(gpu, O):
+    """maximum-size cases: MSM 2^22 (known answer <k,s> G) and NTT 2^24 (round trip + spot value)"""
+    from circuits_halo2_amd.arithmetic import g1_fixed_base_mul, fr_to_montgomery
+    from circuits_halo2_amd.utils import random_fr_canonical
+    n = 1 << 22
+    k = fr_to_montgomery(dev(random_fr_canonical(0xA1, n)))
+    s = fr_to_montgomery(dev(random_fr_canonical(0xA2, n)))
+    bases = g1_fixed_base_mul(s)
+    got = gpu.best_multiexp(k, bases)
+    assert (got == O.g1_mul(O.g1_generator(), O.fr_dot(k.cpu().numpy(), s.cpu().numpy()))).all()
+    del bases, s
+    log_n = 24
+    a = fr_to_montgomery(dev(random_fr_canonical(0xA3, 1 << log_n)))
+    orig = a.clone()
+    dom = gpu.EvaluationDomain(2, log_n)
+    gpu.best_fft(a, dom.get_omega(), log_n)
+    j = 12345
+    x = O.fr_powers(dom.get_omega(), j + 1)[32 * j:32 * j + 32].copy()
+    from circuits_halo2_amd.arithmetic import eval_polynomial
+    assert (eval_polynomial(orig, x) == a[32 * j:32 * j + 32].cpu().numpy()).all()
+    dom.lagrange_to_coeff(a)
+    assert bool((a == orig).all())

@@ -10,6 +10,8 @@ using namespace sg;
 template <class P> void run(const std::string& op, const f29& a, const f29& b) {
   f29 r = f29_zero();
   if (op == "mul") r = f29_mul<P>(a, b);
+  else if (op == "sqr") r = f29_sqr<P>(a);
+  else if (op == "mul2") r = f29_mul2<P>(a, b, b, a);
   else if (op == "add") r = f29_add(a, b);
   else if (op == "sub2") r = f29_sub<P, 0>(a, b);
   else if (op == "sub8") r = f29_sub<P, 2>(a, b);

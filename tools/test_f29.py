@@ -27,6 +27,10 @@ for fld, p in (("q", P.Q), ("r", P.R)):
         if rnd.random() < 0.1: a = rnd.choice([0, p, 2 * p, p - 1, ba * p - 1])
         cases.append(("mul", fld, limbs(a), limbs(b), ("mul", p, a, b)))
         cases.append(("add", fld, limbs(a), limbs(b), ("add", p, a, b)))
+        if ba * ba <= 170:
+            cases.append(("sqr", fld, limbs(a), limbs(0), ("mul", p, a, a)))
+        if 2 * ba * bb <= 170:
+            cases.append(("mul2", fld, limbs(a), limbs(b), ("mul2", p, a, b)))
         a8, b8 = rnd.randrange(8 * p), rnd.randrange(8 * p)
         cases.append(("sub8", fld, limbs(a8), limbs(b8), ("sub", p, a8, b8, 8)))
         b2 = rnd.randrange(2 * p)
@@ -52,6 +56,10 @@ for (op, f, a, b, exp), line in zip(cases, out):
         _, p, x, y = exp
         v = val(l)
         ok = v % p == (x * y * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "mul2":
+        _, p, x, y = exp
+        v = val(l)
+        ok = v % p == (2 * x * y * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
     elif exp[0] == "add":
         _, p, x, y = exp
         ok = val(l) == x + y and all(t < (1 << 29) + 4 for t in l[:8])
