@@ -905,17 +905,36 @@ hipError_t MsmEngine::finish() {
     std::memcpy(zzz.v, h_win_ + 32 * q + 24, 32);
     return jac_from_xyzz(x, y, zz, zzz);
   };
+  // window_w = A + 2^log_G (S + 2^log_N T) and result = sum_w 2^(offset_w) window_w: all 3W terms
+  // are placed at their bit offsets and folded by ONE double-and-add sweep from the top bit
+  // (254 + log_G + log_N doublings instead of W * (width + log_G + log_N))
+  uint32_t offs[64];
+  {
+    uint32_t o = 0;
+    for (uint32_t w = 0; w < j.wp.W; w++) {
+      offs[w] = o;
+      o += j.wp.width[w];
+    }
+  }
+  constexpr uint32_t MAXBIT = 254 + 16 + 16;
   for (uint32_t m = 0; m < j.M; m++) {
+    int head[MAXBIT + 1];
+    int next[3 * 64];
+    for (auto& h : head) h = -1;
+    uint32_t top = 0;
+    for (uint32_t w = 0; w < j.wp.W; w++) {
+      for (uint32_t which = 0; which < 3; which++) {
+        const uint32_t bit = offs[w] + (which >= 1 ? j.log_G : 0) + (which == 2 ? j.log_N : 0);
+        const int id = (int)(3 * w + which);
+        next[id] = head[bit];
+        head[bit] = id;
+        top = std::max(top, bit);
+      }
+    }
     Jac total = Jac::identity();
-    for (int w = (int)j.wp.W - 1; w >= 0; w--) {
-      const uint32_t q = 3 * (m * j.wp.W + (uint32_t)w);
-      for (uint32_t k = 0; k < j.wp.width[w]; k++) total = jac_double(total);
-      Jac t = point_at(q + 2);
-      for (uint32_t k = 0; k < j.log_N; k++) t = jac_double(t);
-      t = jac_add(t, point_at(q + 1));
-      for (uint32_t k = 0; k < j.log_G; k++) t = jac_double(t);
-      t = jac_add(t, point_at(q));
-      total = jac_add(total, t);
+    for (int bit = (int)top; bit >= 0; bit--) {
+      total = jac_double(total);
+      for (int id = head[bit]; id >= 0; id = next[id]) total = jac_add(total, point_at(3 * m * j.wp.W + (uint32_t)id));
     }
     jac_to_affine_bytes(total, j.out + 64 * m);
   }
