@@ -1,0 +1,131 @@
+//! Rust side of the drop-in boundary: the FFI declarations of `include/summa_gpu.h` and safe
+//! wrappers with the exact signatures of the two `halo2_proofs::arithmetic` functions the
+//! prover's hot path goes through (`best_multiexp`, `best_fft`), plus the `EvaluationDomain` /
+//! `ParamsKZG` conveniences.  UNBUILT in this repository (no cargo/rustc in the image); the same
+//! ABI is exercised through `circuits_halo2_amd/ffi.py`.
+//!
+//! Layout contract: `halo2curves::bn256::Fr` is 4 x u64 little-endian limbs in Montgomery form
+//! (32 bytes), `G1Affine` is `x || y` of two such `Fq` (64 bytes, identity = all zero); the
+//! assertions below make a layout change a compile error instead of a wrong proof.
+use halo2curves::bn256::{Fr, G1Affine, G1};
+use std::os::raw::{c_char, c_int, c_void};
+
+#[allow(non_camel_case_types)]
+type size_t = usize;
+
+extern "C" {
+    pub fn sg_init(device: c_int) -> c_int;
+    pub fn sg_shutdown();
+    pub fn sg_last_error() -> *const c_char;
+    pub fn sg_device_count() -> c_int;
+    pub fn sg_msm_g1(scalars: *const u8, bases: *const u8, n: size_t, out_affine: *mut u8) -> c_int;
+    pub fn sg_msm_g1_batch(
+        scalars: *const *const u8,
+        bases: *const *const u8,
+        n: *const size_t,
+        count: size_t,
+        out_affine: *mut u8,
+    ) -> c_int;
+    pub fn sg_srs_upload(k: u32, g: *const u8, g_lagrange: *const u8, handle_out: *mut u64) -> c_int;
+    pub fn sg_srs_free(handle: u64) -> c_int;
+    pub fn sg_commit(handle: u64, basis: c_int, scalars: *const u8, n: size_t, out_affine: *mut u8) -> c_int;
+    pub fn sg_ntt_fr(a: *mut u8, omega: *const u8, log_n: u32) -> c_int;
+    pub fn sg_intt_fr(a: *mut u8, omega_inv: *const u8, divisor: *const u8, log_n: u32) -> c_int;
+    pub fn sg_coeff_to_extended(coeffs: *const u8, k: u32, ext_k: u32, out: *mut u8) -> c_int;
+    pub fn sg_extended_to_coeff(ext: *mut u8, k: u32, ext_k: u32) -> c_int;
+    pub fn sg_divide_by_vanishing_poly(ext: *mut u8, k: u32, ext_k: u32) -> c_int;
+    pub fn sg_fr_eval_poly(coeffs: *const u8, n: size_t, x: *const u8, out: *mut u8) -> c_int;
+    pub fn sg_kzg_setup(k: u32, tau: *const u8, g: *mut u8, g_lagrange: *mut u8) -> c_int;
+    pub fn sg_g1_to_lagrange(g: *const u8, k: u32, g_lagrange: *mut u8) -> c_int;
+    // device-resident variants (`*_dev`) take HIP pointers; a Rust prover that keeps its
+    // polynomials in HBM binds them the same way (see include/summa_gpu.h)
+    pub fn sg_msm_g1_dev(s: *const c_void, b: *const c_void, n: size_t, stream: *mut c_void, out: *mut u8) -> c_int;
+}
+
+const _: () = assert!(std::mem::size_of::<Fr>() == 32);
+const _: () = assert!(std::mem::size_of::<G1Affine>() == 64);
+
+#[derive(Debug)]
+pub struct GpuError(pub c_int, pub String);
+
+fn check(rc: c_int) -> Result<(), GpuError> {
+    if rc == 0 {
+        return Ok(());
+    }
+    let msg = unsafe { std::ffi::CStr::from_ptr(sg_last_error()) }.to_string_lossy().into_owned();
+    Err(GpuError(rc, msg))
+}
+
+fn affine_from_bytes(b: [u8; 64]) -> G1Affine {
+    // 64 zero bytes = identity (halo2curves' own encoding of the point at infinity);
+    // otherwise (x, y) Montgomery limbs, which is G1Affine's in-memory representation
+    unsafe { std::mem::transmute::<[u8; 64], G1Affine>(b) }
+}
+
+/// `halo2_proofs::arithmetic::best_multiexp` for `C = bn256::G1Affine`.
+pub fn best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> Result<G1, GpuError> {
+    assert_eq!(coeffs.len(), bases.len()); // upstream's own assertion
+    let mut out = [0u8; 64];
+    check(unsafe { sg_msm_g1(coeffs.as_ptr() as *const u8, bases.as_ptr() as *const u8, coeffs.len(), out.as_mut_ptr()) })?;
+    Ok(G1::from(affine_from_bytes(out)))
+}
+
+/// The commitments of one prover phase in one call (advice columns, quotient pieces, ...).
+pub fn best_multiexp_batch(pairs: &[(&[Fr], &[G1Affine])]) -> Result<Vec<G1>, GpuError> {
+    let s: Vec<*const u8> = pairs.iter().map(|(c, _)| c.as_ptr() as *const u8).collect();
+    let b: Vec<*const u8> = pairs.iter().map(|(_, g)| g.as_ptr() as *const u8).collect();
+    let n: Vec<usize> = pairs.iter().map(|(c, g)| { assert_eq!(c.len(), g.len()); c.len() }).collect();
+    let mut out = vec![0u8; 64 * pairs.len()];
+    check(unsafe { sg_msm_g1_batch(s.as_ptr(), b.as_ptr(), n.as_ptr(), pairs.len(), out.as_mut_ptr()) })?;
+    Ok(out.chunks_exact(64).map(|c| G1::from(affine_from_bytes(c.try_into().unwrap()))).collect())
+}
+
+/// `halo2_proofs::arithmetic::best_fft` for `Scalar = G = bn256::Fr` (in place, natural order).
+pub fn best_fft(a: &mut [Fr], omega: Fr, log_n: u32) -> Result<(), GpuError> {
+    assert_eq!(a.len(), 1usize << log_n);
+    check(unsafe { sg_ntt_fr(a.as_mut_ptr() as *mut u8, &omega as *const Fr as *const u8, log_n) })
+}
+
+/// `EvaluationDomain::ifft(a, omega_inv, log_n, divisor)`.
+pub fn ifft(a: &mut [Fr], omega_inv: Fr, log_n: u32, divisor: Fr) -> Result<(), GpuError> {
+    assert_eq!(a.len(), 1usize << log_n);
+    check(unsafe {
+        sg_intt_fr(a.as_mut_ptr() as *mut u8, &omega_inv as *const Fr as *const u8, &divisor as *const Fr as *const u8, log_n)
+    })
+}
+
+/// `EvaluationDomain::coeff_to_extended` (zeta-coset, zero padding and the NTT fused).
+pub fn coeff_to_extended(coeffs: &[Fr], k: u32, extended_k: u32) -> Result<Vec<Fr>, GpuError> {
+    assert_eq!(coeffs.len(), 1usize << k);
+    let mut out = vec![Fr::zero(); 1usize << extended_k];
+    check(unsafe { sg_coeff_to_extended(coeffs.as_ptr() as *const u8, k, extended_k, out.as_mut_ptr() as *mut u8) })?;
+    Ok(out)
+}
+
+/// `EvaluationDomain::extended_to_coeff`; the caller truncates to `n * quotient_poly_degree`.
+pub fn extended_to_coeff(ext: &mut [Fr], k: u32, extended_k: u32) -> Result<(), GpuError> {
+    assert_eq!(ext.len(), 1usize << extended_k);
+    check(unsafe { sg_extended_to_coeff(ext.as_mut_ptr() as *mut u8, k, extended_k) })
+}
+
+/// SRS kept resident in HBM: upload once in `ParamsKZG::read/setup`, then `commit`/`commit_lagrange`.
+pub struct SrsHandle(u64);
+impl SrsHandle {
+    pub fn upload(k: u32, g: &[G1Affine], g_lagrange: &[G1Affine]) -> Result<Self, GpuError> {
+        assert!(g.len() == 1usize << k && g_lagrange.len() == g.len());
+        let mut h = 0u64;
+        check(unsafe { sg_srs_upload(k, g.as_ptr() as *const u8, g_lagrange.as_ptr() as *const u8, &mut h) })?;
+        Ok(SrsHandle(h))
+    }
+    /// basis: false = `ParamsKZG::commit` (monomial g), true = `commit_lagrange`
+    pub fn commit(&self, lagrange: bool, poly: &[Fr]) -> Result<G1, GpuError> {
+        let mut out = [0u8; 64];
+        check(unsafe { sg_commit(self.0, lagrange as c_int, poly.as_ptr() as *const u8, poly.len(), out.as_mut_ptr()) })?;
+        Ok(G1::from(affine_from_bytes(out)))
+    }
+}
+impl Drop for SrsHandle {
+    fn drop(&mut self) {
+        unsafe { sg_srs_free(self.0) };
+    }
+}
