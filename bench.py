@@ -25,6 +25,8 @@ LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MSM_BYTES_PER_PAIR = 96        # 64 B point + 32 B scalar
 NTT_BYTES_PER_ELEM = 64        # 32 B read + 32 B write, one logical pass
+MADS_PER_MIXED_ADD = 6 * 162 + 2 * 126 + 243   # v_mad_u64_u32 per XYZZ += affine
+MAD_PEAK = 30.1e12             # measured v_mad_u64_u32 lane-ops/s, full occupancy (microbench2)
 
 
 def pmc_traffic(kernel, log_n):
@@ -134,8 +136,13 @@ def main():
         line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket")})
         # integer-ALU view (MSM is VALU-bound): mixed adds * 10 products * ~560 VALU instr
         adds = reps[0]["windows"] * n
-        line["alu"] = {"bucket_adds_per_launch": adds, "fq_mul_per_s": adds * 10 / (acc_ms * 1e-3),
-                       "note": "8M+2S XYZZ mixed add; see profiles/r01_microbench_instr_rates.txt for instruction peaks"}
+        mads = adds * MADS_PER_MIXED_ADD
+        line["alu"] = {"bucket_adds_per_launch": adds, "mixed_adds_per_s": adds / (acc_ms * 1e-3),
+                       "mad_u64_u32_lane_ops_per_s": mads / (acc_ms * 1e-3), "mad_peak_lane_ops_per_s": MAD_PEAK,
+                       "frac_of_mad_peak": mads / (acc_ms * 1e-3) / MAD_PEAK,
+                       "note": "integer-VALU view: a mixed add is 6 products + 2 squarings + 1 fused two-product "
+                               "reduction on 9x29-bit limbs = 1467 v_mad_u64_u32 (70 % of its instructions); peak = "
+                               "measured v_mad_u64_u32 issue rate (profiles/r01_microbench_instr_rates.txt)"}
 
         # throughput mode: the same MSM issued as a batch of 8 (fused / pipelined jobs)
         sg.best_multiexp_batch([(scal, bases)] * 2)

@@ -501,3 +501,32 @@ def test_sizes_beyond_the_baseline_configs(gpu, O):
     assert (eval_polynomial(orig, x) == a[32 * j:32 * j + 32].cpu().numpy()).all()
     dom.lagrange_to_coeff(a)
     assert bool((a == orig).all())
+
+
+def test_abi_is_thread_safe(gpu, O):
+    """halo2 calls best_multiexp / best_fft from inside rayon iterators: concurrent callers
+    must get correct results (calls are serialised per device context)"""
+    import threading
+    n = 1 << 12
+    bases = O.fixed_base_mul(O.random_fr(950, n), O.ncpu())
+    jobs = []
+    for i in range(6):
+        sc = O.random_fr(960 + i, n)
+        a = O.random_fr(970 + i, 1 << 11)
+        jobs.append((sc, O.best_multiexp(sc, bases, O.ncpu()), a, O.best_fft(a, O.omega(11), 11, 2)))
+    errors = []
+
+    def worker(sc, want_p, a, want_a):
+        try:
+            for _ in range(3):
+                assert (gpu.best_multiexp(sc, bases) == want_p).all()
+                assert (gpu.best_fft(a, O.omega(11), 11) == want_a).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
