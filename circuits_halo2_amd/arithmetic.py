@@ -172,3 +172,28 @@ def fr_mul(a, b):
     ffi.check(ffi.lib().sg_fr_mul_dev(ffi.dev_ptr(a), ffi.dev_ptr(b), C.c_size_t(a.numel() // 32), ffi.dev_ptr(out),
                                       ffi.current_stream_ptr()))
     return out
+
+
+def permutation_product(values, sigmas, beta, gamma, delta_start, k: int, z0=None):
+    """one chunk of halo2's permutation grand product on device tensors; returns z (2^k rows)"""
+    import torch
+    m = len(values)
+    pv = (C.c_void_p * m)(*[v.data_ptr() for v in values])
+    ps = (C.c_void_p * m)(*[s.data_ptr() for s in sigmas])
+    z = torch.empty(32 << k, dtype=torch.uint8, device=values[0].device)
+    z0p = ffi.ptr(ffi.u8(z0)) if z0 is not None else None
+    ffi.check(ffi.lib().sg_permutation_product_dev(pv, ps, C.c_uint32(m), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)),
+                                                   ffi.ptr(ffi.u8(delta_start)), C.c_uint32(k), z0p, ffi.dev_ptr(z),
+                                                   ffi.current_stream_ptr()))
+    return z
+
+
+def lookup_product(inp, table, permuted_input, permuted_table, beta, gamma):
+    """halo2's lookup grand product on device tensors; returns z (n rows)"""
+    import torch
+    n = inp.numel() // 32
+    z = torch.empty(32 * n, dtype=torch.uint8, device=inp.device)
+    ffi.check(ffi.lib().sg_lookup_product_dev(ffi.dev_ptr(inp), ffi.dev_ptr(table), ffi.dev_ptr(permuted_input),
+                                              ffi.dev_ptr(permuted_table), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)),
+                                              C.c_size_t(n), ffi.dev_ptr(z), ffi.current_stream_ptr()))
+    return z

@@ -12,7 +12,22 @@ size_t poly_eval_tmp_elems(size_t n);
 // in place; zeros stay zero
 hipError_t poly_batch_invert(fp_words* d_a, size_t n, hipStream_t stream);
 // out[0] = 1, out[i] = a[0] * ... * a[i-1], i <= n (n + 1 outputs); n <= 2^21
-hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, fp_words* d_out, hipStream_t stream);
+// count_out <= n + 1 values are written; *init (optional) multiplies every output (z[0] = init)
+hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, fp_words* d_out, size_t count_out,
+                               const words8* init, hipStream_t stream);
+static constexpr uint32_t PERM_MAX_COLS = 8;
+struct PermCols {  // one chunk of the permutation argument (kernel argument)
+  const fp_words* values[PERM_MAX_COLS];
+  const fp_words* sigma[PERM_MAX_COLS];
+};
+// numer = 0: io[i] = prod_c (beta sigma_c[i] + gamma + v_c[i]);  numer = 1: io[i] *= prod_c (delta_start
+// delta^c omega^i beta + gamma + v_c[i])
+hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8& beta, const words8& gamma,
+                              const words8& delta_start, const words8& delta, const words8& omega, size_t n,
+                              int numer, fp_words* d_io, hipStream_t stream);
+// numer = 0: io[i] = (x[i] + beta)(y[i] + gamma);  numer = 1: io[i] *= (x[i] + beta)(y[i] + gamma)
+hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,
+                                size_t n, int numer, fp_words* d_io, hipStream_t stream);
 size_t prefix_product_tmp_elems(size_t n);
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,
                                 hipStream_t stream);

@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(1024) prefix_product_scan_blocks(fp_words* __r
   if (tid < nblk) store_hat(bprod + tid, ex);
 }
 __global__ void __launch_bounds__(256) prefix_product_write(const fp_words* __restrict__ a, uint32_t n,
-                                                            const fp_words* __restrict__ bprod,
+                                                            const fp_words* __restrict__ bprod, words8 init,
+                                                            uint32_t has_init, uint32_t count_out,
                                                             fp_words* __restrict__ out) {
   __shared__ uint32_t sh[PP_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * PP_THREADS + tid) * PP_CH;
@@ -164,9 +165,10 @@ __global__ void __launch_bounds__(256) prefix_product_write(const fp_words* __re
     acc = f29_mul<P>(acc, v[i]);
   }
   f29 run = f29_mul<P>(block_exclusive_scan_mul(acc, sh, tid, PP_THREADS, nullptr), load_hat(bprod + blockIdx.x));
+  if (has_init) run = f29_mul<P>(run, f29_words_to_r261<P>(init.l));
 #pragma unroll
   for (uint32_t i = 0; i < PP_CH; i++) {
-    if (first + i <= n) store_hat(out + first + i, run);   // out has n + 1 entries
+    if (first + i < count_out) store_hat(out + first + i, run);
     run = f29_mul<P>(run, v[i]);
   }
 }
@@ -210,12 +212,61 @@ hipError_t poly_batch_invert(fp_words* d_a, size_t n, hipStream_t stream) {
   return hipGetLastError();
 }
 size_t prefix_product_tmp_elems(size_t n) { return (n + PP_BLOCK - 1) / PP_BLOCK + 1; }
-hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, fp_words* d_out, hipStream_t stream) {
+hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, fp_words* d_out, size_t count_out,
+                               const words8* init, hipStream_t stream) {
   const uint32_t nblk = (uint32_t)((n + 1 + PP_BLOCK - 1) / PP_BLOCK);  // covers out[0..n]
-  if (nblk > 1024) return hipErrorInvalidValue;                         // n <= 2^21
+  if (nblk > 1024 || count_out > n + 1) return hipErrorInvalidValue;    // n <= 2^21
   prefix_product_blocks<<<nblk, PP_THREADS, 0, stream>>>(d_a, (uint32_t)n, d_tmp);
   prefix_product_scan_blocks<<<1, 1024, 0, stream>>>(d_tmp, nblk);
-  prefix_product_write<<<nblk, PP_THREADS, 0, stream>>>(d_a, (uint32_t)n, d_tmp, d_out);
+  words8 one{};
+  prefix_product_write<<<nblk, PP_THREADS, 0, stream>>>(d_a, (uint32_t)n, d_tmp, init ? *init : one, init ? 1u : 0u,
+                                                        (uint32_t)count_out, d_out);
+  return hipGetLastError();
+}
+
+// ---- grand-product fractions (halo2 permutation::prover::commit / lookup::prover::commit_product)
+// permutation chunk: den[i] = prod_c (beta * sigma_c[i] + gamma + v_c[i])
+//                    num[i] = prod_c (delta^(j0+c) * omega^i * beta + gamma + v_c[i])
+__global__ void perm_fraction_kernel(PermCols cols, uint32_t ncols, words8 beta_w, words8 gamma_w, words8 dstart_w,
+                                     words8 delta_w, words8 omega_w, uint32_t n, uint32_t numer,
+                                     fp_words* __restrict__ io) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
+  f29 acc = numer ? load_hat(io + i) : f29_one<P>();          // numerators multiply the inverted denominators
+  f29 dw = f29_one<P>();
+  if (numer) dw = f29_mul<P>(f29_words_to_r261<P>(dstart_w.l), f29_pow_u64<P>(f29_words_to_r261<P>(omega_w.l), i));
+  const f29 delta = f29_words_to_r261<P>(delta_w.l);
+  for (uint32_t c = 0; c < ncols; c++) {
+    f29 v = load_hat(cols.values[c] + i);                      // < 2
+    f29 t = numer ? f29_mul<P>(dw, beta) : f29_mul<P>(load_hat(cols.sigma[c] + i), beta);
+    t = f29_add(f29_add(t, gamma), v);                         // < 6
+    acc = f29_mul<P>(acc, t);                                  // 12
+    if (numer) dw = f29_mul<P>(dw, delta);
+  }
+  store_hat(io + i, acc);
+}
+// lookup: den[i] = (a'[i] + beta)(s'[i] + gamma);  num[i] = (a[i] + beta)(s[i] + gamma)
+__global__ void lookup_fraction_kernel(const fp_words* __restrict__ x, const fp_words* __restrict__ y, words8 beta_w,
+                                       words8 gamma_w, uint32_t n, uint32_t numer, fp_words* __restrict__ io) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
+  f29 t = f29_mul<P>(f29_add(load_hat(x + i), beta), f29_add(load_hat(y + i), gamma));   // 4 * 4
+  if (numer) t = f29_mul<P>(t, load_hat(io + i));
+  store_hat(io + i, t);
+}
+hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8& beta, const words8& gamma,
+                              const words8& delta_start, const words8& delta, const words8& omega, size_t n,
+                              int numer, fp_words* d_io, hipStream_t stream) {
+  perm_fraction_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(cols, ncols, beta, gamma, delta_start, delta,
+                                                                        omega, (uint32_t)n, (uint32_t)numer, d_io);
+  return hipGetLastError();
+}
+hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,
+                                size_t n, int numer, fp_words* d_io, hipStream_t stream) {
+  lookup_fraction_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_x, d_y, beta, gamma, (uint32_t)n,
+                                                                          (uint32_t)numer, d_io);
   return hipGetLastError();
 }
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,

@@ -818,11 +818,78 @@ int sg_fr_prefix_product_dev(const void* d_a, size_t n, void* d_out, void* strea
   if (e != hipSuccess) return hip_fail("prefix_product work space", e);
   hipStream_t s = pick_stream(stream);
   e = poly_prefix_product(static_cast<const fp_words*>(d_a), n, reinterpret_cast<fp_words*>(g_ctx->scratch.p),
-                          static_cast<fp_words*>(d_out), s);
+                          static_cast<fp_words*>(d_out), n + 1, nullptr, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // the scratch buffer is shared
   if (e != hipSuccess) return hip_fail("prefix_product", e);
   return SG_OK;
 }
+// delta = 7^(2^28): generator of the 2^28-torsion-free part used to separate permutation columns
+static const uint32_t DELTA_M[8] = {0xefd78855u, 0x9a0c322bu, 0x249b563cu, 0x46e82d14u,
+                                    0xe0b0b7a7u, 0x5983a663u, 0xaaa111adu, 0x22ab452bu};  // Montgomery-2^256 words
+static int grand_product_tail(fp_words* d_mod, size_t n, const uint8_t* z0, void* d_z, hipStream_t s) {
+  // z[0] = z0 (or 1), z[i] = z[i-1] * mod[i-1], n values
+  hipError_t e = g_ctx->scratch.reserve(prefix_product_tmp_elems(n + 1) * 32 + 64);
+  if (e != hipSuccess) return hip_fail("grand product work space", e);
+  words8 init;
+  if (z0) std::memcpy(&init, z0, 32);
+  e = poly_prefix_product(d_mod, n, reinterpret_cast<fp_words*>(g_ctx->scratch.p), static_cast<fp_words*>(d_z), n,
+                          z0 ? &init : nullptr, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail("grand product", e);
+  return SG_OK;
+}
+int sg_permutation_product_dev(const void* const* d_values, const void* const* d_sigma, uint32_t ncols,
+                               const uint8_t beta[32], const uint8_t gamma[32], const uint8_t delta_start[32],
+                               uint32_t k, const uint8_t* z0, void* d_z, void* stream) {
+  if (!d_values || !d_sigma || !beta || !gamma || !delta_start || !d_z || ncols == 0 || ncols > PERM_MAX_COLS ||
+      k > 21)
+    return fail(SG_ERR_INVALID, "sg_permutation_product: bad argument");
+  LOCKED_CTX();
+  const size_t n = (size_t)1 << k;
+  const DomainConsts* dc;
+  TRY(get_consts(k, &dc));
+  PermCols cols{};
+  for (uint32_t c = 0; c < ncols; c++) {
+    if (!d_values[c] || !d_sigma[c]) return fail(SG_ERR_INVALID, "sg_permutation_product: null column");
+    cols.values[c] = static_cast<const fp_words*>(d_values[c]);
+    cols.sigma[c] = static_cast<const fp_words*>(d_sigma[c]);
+  }
+  hipError_t e = g_ctx->stage_b.reserve(n * 32 + 64);
+  if (e != hipSuccess) return hip_fail("grand product work space", e);
+  fp_words* mod = reinterpret_cast<fp_words*>(g_ctx->stage_b.p);
+  words8 b, g, ds, dl;
+  std::memcpy(&b, beta, 32); std::memcpy(&g, gamma, 32); std::memcpy(&ds, delta_start, 32);
+  std::memcpy(&dl, DELTA_M, 32);
+  hipStream_t s = pick_stream(stream);
+  e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 0, mod, s);
+  if (e == hipSuccess) e = poly_batch_invert(mod, n, s);
+  if (e == hipSuccess) e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 1, mod, s);
+  if (e != hipSuccess) return hip_fail("permutation product", e);
+  return grand_product_tail(mod, n, z0, d_z, s);
+}
+int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input,
+                          const void* d_permuted_table, const uint8_t beta[32], const uint8_t gamma[32], size_t n,
+                          void* d_z, void* stream) {
+  if (!d_input || !d_table || !d_permuted_input || !d_permuted_table || !beta || !gamma || !d_z || n == 0 ||
+      n > (1u << 21) - 1)
+    return fail(SG_ERR_INVALID, "sg_lookup_product: bad argument");
+  LOCKED_CTX();
+  hipError_t e = g_ctx->stage_b.reserve(n * 32 + 64);
+  if (e != hipSuccess) return hip_fail("grand product work space", e);
+  fp_words* mod = reinterpret_cast<fp_words*>(g_ctx->stage_b.p);
+  words8 b, g;
+  std::memcpy(&b, beta, 32); std::memcpy(&g, gamma, 32);
+  hipStream_t s = pick_stream(stream);
+  e = poly_lookup_fraction(static_cast<const fp_words*>(d_permuted_input), static_cast<const fp_words*>(d_permuted_table),
+                           b, g, n, 0, mod, s);
+  if (e == hipSuccess) e = poly_batch_invert(mod, n, s);
+  if (e == hipSuccess)
+    e = poly_lookup_fraction(static_cast<const fp_words*>(d_input), static_cast<const fp_words*>(d_table), b, g, n, 1,
+                             mod, s);
+  if (e != hipSuccess) return hip_fail("lookup product", e);
+  return grand_product_tail(mod, n, nullptr, d_z, s);
+}
+
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream) {
   if (n && (!d_a || !d_b || !d_out)) return fail(SG_ERR_INVALID, "sg_fr_mul: null argument");
   if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_mul: vector too long");

@@ -152,6 +152,21 @@ int sg_fr_batch_invert_dev(void* d_a, size_t n, void* stream);
 /* exclusive prefix product, the core of the permutation / lookup grand products (steps 5-6):
  * out[0] = 1, out[i] = a[0] * ... * a[i-1] for i <= n  (n + 1 outputs, n < 2^21) */
 int sg_fr_prefix_product_dev(const void* d_a, size_t n, void* d_out, void* stream);
+/* One chunk of halo2's permutation grand product (permutation::prover::commit; SURVEY.md §3.1
+ * step 5): for the `ncols` columns of the chunk (values / permuted sigma columns in Lagrange
+ * basis, 2^k rows, k <= 21)
+ *   z[0] = z0 (NULL: 1),  z[i+1] = z[i] * prod_c (v_c[i] + delta_start delta^c omega^i beta + gamma)
+ *                                        / prod_c (v_c[i] + beta sigma_c[i] + gamma)
+ * n values are written; the caller chains chunks through z0 and overwrites the blinding rows. */
+int sg_permutation_product_dev(const void* const* d_values, const void* const* d_sigma, uint32_t ncols,
+                               const uint8_t beta[32], const uint8_t gamma[32], const uint8_t delta_start[32],
+                               uint32_t k, const uint8_t* z0, void* d_z, void* stream);
+/* halo2's lookup grand product (lookup::prover::commit_product; step 6), inputs already
+ * theta-compressed / permuted by the caller:
+ *   z[0] = 1,  z[i+1] = z[i] (a[i] + beta)(s[i] + gamma) / ((a'[i] + beta)(s'[i] + gamma)) */
+int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input,
+                          const void* d_permuted_table, const uint8_t beta[32], const uint8_t gamma[32], size_t n,
+                          void* d_z, void* stream);
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 

@@ -573,6 +573,79 @@ void orc_fr_mul_n(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) fe_mul(&FR, (fe *)(out + 32 * i), (const fe *)(a + 32 * i), (const fe *)(b + 32 * i));
 }
 
+/* halo2 permutation::prover::commit, one chunk:
+ * z[0] = z0, z[i+1] = z[i] * prod_c (v_c[i] + delta_start*delta^c*omega^i*beta + gamma)
+ *                           / prod_c (v_c[i] + beta*sigma_c[i] + gamma); n = 2^k values */
+static const u64 DELTA_CANON[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL,
+                                   0x09226b6e22c6f0caULL};
+void orc_permutation_product(const uint8_t *const *values, const uint8_t *const *sigma, uint32_t ncols,
+                             const uint8_t beta[32], const uint8_t gamma[32], const uint8_t delta_start[32],
+                             uint32_t k, const uint8_t *z0, uint8_t *z_out) {
+    size_t n = (size_t)1 << k;
+    fe b, g, ds, delta, dc, omega;
+    memcpy(&b, beta, 32); memcpy(&g, gamma, 32); memcpy(&ds, delta_start, 32);
+    memcpy(dc.l, DELTA_CANON, 32);
+    fe_to_mont(&FR, &delta, &dc);
+    fr_omega(k, &omega);
+    fe *mod = (fe *)malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; i++) {
+        fe acc = FR.r1, t;
+        for (uint32_t c = 0; c < ncols; c++) {
+            fe_mul(&FR, &t, &b, (const fe *)(sigma[c] + 32 * i));
+            fe_add(&FR, &t, &t, &g);
+            fe_add(&FR, &t, &t, (const fe *)(values[c] + 32 * i));
+            fe_mul(&FR, &acc, &acc, &t);
+        }
+        mod[i] = acc;
+    }
+    orc_fr_batch_invert((uint8_t *)mod, n);
+    fe wi = FR.r1;
+    for (size_t i = 0; i < n; i++) {
+        fe dw, t;
+        fe_mul(&FR, &dw, &ds, &wi);
+        for (uint32_t c = 0; c < ncols; c++) {
+            fe_mul(&FR, &t, &dw, &b);
+            fe_add(&FR, &t, &t, &g);
+            fe_add(&FR, &t, &t, (const fe *)(values[c] + 32 * i));
+            fe_mul(&FR, &mod[i], &mod[i], &t);
+            fe_mul(&FR, &dw, &dw, &delta);
+        }
+        fe_mul(&FR, &wi, &wi, &omega);
+    }
+    fe z = FR.r1;
+    if (z0) memcpy(&z, z0, 32);
+    for (size_t i = 0; i < n; i++) {
+        memcpy(z_out + 32 * i, &z, 32);
+        fe_mul(&FR, &z, &z, &mod[i]);
+    }
+    free(mod);
+}
+/* halo2 lookup::prover::commit_product (step 6) on compressed / permuted columns */
+void orc_lookup_product(const uint8_t *a, const uint8_t *s, const uint8_t *ap, const uint8_t *sp,
+                        const uint8_t beta[32], const uint8_t gamma[32], size_t n, uint8_t *z_out) {
+    fe b, g;
+    memcpy(&b, beta, 32); memcpy(&g, gamma, 32);
+    fe *mod = (fe *)malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; i++) {
+        fe x, y;
+        fe_add(&FR, &x, (const fe *)(ap + 32 * i), &b);
+        fe_add(&FR, &y, (const fe *)(sp + 32 * i), &g);
+        fe_mul(&FR, &mod[i], &x, &y);
+    }
+    orc_fr_batch_invert((uint8_t *)mod, n);
+    fe z = FR.r1;
+    for (size_t i = 0; i < n; i++) {
+        fe x, y;
+        fe_add(&FR, &x, (const fe *)(a + 32 * i), &b);
+        fe_add(&FR, &y, (const fe *)(s + 32 * i), &g);
+        fe_mul(&FR, &x, &x, &y);
+        fe_mul(&FR, &mod[i], &mod[i], &x);
+        memcpy(z_out + 32 * i, &z, 32);
+        fe_mul(&FR, &z, &z, &mod[i]);
+    }
+    free(mod);
+}
+
 int orc_g1_is_on_curve(const uint8_t p[64]) {
     const g1a *a = (const g1a *)p;
     if (g1a_is_id(a)) return 1;

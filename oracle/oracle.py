@@ -197,6 +197,26 @@ def fr_mul_n(a, b) -> np.ndarray:
     return out
 
 
+def permutation_product(values, sigmas, beta, gamma, delta_start, k, z0=None) -> np.ndarray:
+    m = len(values)
+    vs = [np.ascontiguousarray(v) for v in values]
+    ss = [np.ascontiguousarray(s) for s in sigmas]
+    pv = (C.c_void_p * m)(*[v.ctypes.data for v in vs])
+    ps = (C.c_void_p * m)(*[s.ctypes.data for s in ss])
+    out = _buf(32 << k)
+    lib().orc_permutation_product(pv, ps, C.c_uint32(m), _p(beta), _p(gamma), _p(delta_start), C.c_uint32(k),
+                                  _p(z0) if z0 is not None else None, _p(out))
+    return out
+
+
+def lookup_product(a, s, ap, sp, beta, gamma) -> np.ndarray:
+    n = a.size // 32
+    out = _buf(32 * n)
+    lib().orc_lookup_product(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(s)), _p(np.ascontiguousarray(ap)),
+                             _p(np.ascontiguousarray(sp)), _p(beta), _p(gamma), C.c_size_t(n), _p(out))
+    return out
+
+
 def g1_is_on_curve(p) -> bool:
     return bool(lib().orc_g1_is_on_curve(_p(np.ascontiguousarray(p))))
 

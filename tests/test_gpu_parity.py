@@ -530,3 +530,46 @@ def test_abi_is_thread_safe(gpu, O):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("k,ncols", [(4, 1), (9, 4), (11, 2), (13, 4)])
+def test_permutation_grand_product(gpu, O, P, k, ncols):
+    """halo2 permutation::prover::commit, one chunk (for MstInclusion: 6 columns in chunks of 4 + 2)"""
+    from circuits_halo2_amd.arithmetic import permutation_product
+    n = 1 << k
+    vals = [O.random_fr(1100 + 10 * k + c, n) for c in range(ncols)]
+    sig = [O.random_fr(1200 + 10 * k + c, n) for c in range(ncols)]
+    beta, gamma = O.random_fr(1301, 1), O.random_fr(1302, 1)
+    dstart = fr_np([pow(P.DELTA, 4, P.R)])          # second chunk of a chunk_len = 4 argument
+    z0 = O.random_fr(1303, 1)
+    want = O.permutation_product(vals, sig, beta, gamma, dstart, k, z0)
+    got = permutation_product([dev(v) for v in vals], [dev(s) for s in sig], beta, gamma, dstart, k, z0)
+    assert (got.cpu().numpy() == want).all()
+    one = fr_np([1])
+    want = O.permutation_product(vals, sig, beta, gamma, one, k)
+    got = permutation_product([dev(v) for v in vals], [dev(s) for s in sig], beta, gamma, one, k)
+    assert (got.cpu().numpy() == want).all()
+    # a real permutation: sigma = identity labels delta^c * omega^i  =>  every fraction is 1, z == 1
+    w = P.omega_for(k)
+    labels = [fr_np([pow(P.DELTA, c, P.R) * pow(w, i, P.R) % P.R for i in range(n)]) for c in range(ncols)] if k <= 9 else None
+    if labels:
+        got = permutation_product([dev(v) for v in vals], [dev(s) for s in labels], beta, gamma, one, k)
+        assert (got.cpu().numpy() == np.tile(one, n)).all()
+
+
+@pytest.mark.parametrize("n", [16, 2048, 1 << 13, 5000])
+def test_lookup_grand_product(gpu, O, n):
+    from circuits_halo2_amd.arithmetic import lookup_product
+    a, s, ap, sp = (O.random_fr(1400 + i, n) for i in range(4))
+    beta, gamma = O.random_fr(1411, 1), O.random_fr(1412, 1)
+    want = O.lookup_product(a, s, ap, sp, beta, gamma)
+    got = lookup_product(dev(a), dev(s), dev(ap), dev(sp), beta, gamma)
+    assert (got.cpu().numpy() == want).all()
+    # permuted columns that are permutations of the inputs => the product telescopes back to 1
+    perm = np.random.default_rng(3).permutation(n)
+    ap2 = a.reshape(n, 32)[perm].reshape(-1).copy()
+    sp2 = s.reshape(n, 32)[perm].reshape(-1).copy()
+    z = lookup_product(dev(a), dev(s), dev(ap2), dev(sp2), beta, gamma).cpu().numpy()
+    last = O.fr_mul(z[-32:].copy(), O.fr_mul(O.fr_mul(O.fr_add(a[-32:].copy(), beta), O.fr_add(s[-32:].copy(), gamma)),
+                                             O.fr_inv(O.fr_mul(O.fr_add(ap2[-32:].copy(), beta), O.fr_add(sp2[-32:].copy(), gamma)))))
+    assert (last == fr_np([1])).all()
