@@ -89,12 +89,15 @@ __global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __r
 }
 
 // ------------------------------------------------------------------ 2: LDS-staged histogram
-// grid (P, W): workgroup (p, j) counts the digits of scalar chunk p for window j in an LDS
-// histogram of 2^(c-1) buckets, then stores it to hist[(j*P + p)*nbw + b].
+// grid (W, P): workgroup (j, p) counts the digits of scalar chunk p for window j in an LDS
+// histogram of 2^(c-1) buckets, then stores it to hist[(j*P + p)*nbw + b].  The window is the
+// fast grid index so that (workgroups being dealt round-robin to the 8 XCDs) the chunks of a
+// window share an XCD's L2; measured neutral for msm_scatter's 4-byte scattered stores
+// (WRITE_SIZE stays ~8x the useful bytes), kept because it costs nothing.
 __global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig, uint32_t n, uint32_t chunk,
                                                  uint32_t nbw, uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t s_cnt[];
-  const uint32_t p = blockIdx.x, j = blockIdx.y, P = gridDim.x;
+  const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
   for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cnt[b] = 0;
   __syncthreads();
   const uint32_t lo = p * chunk, hi = min(n, lo + chunk);
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
                                                     uint32_t nbw, const uint32_t* __restrict__ hist,
                                                     const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t s_cur[];
-  const uint32_t p = blockIdx.x, j = blockIdx.y, P = gridDim.x;
+  const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
   const uint32_t* pre = hist + ((size_t)j * P + p) * nbw;
   const uint32_t* ob = off + (size_t)j * nbw;
   for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cur[b] = ob[b] + pre[b];
@@ -784,12 +787,12 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
 
   msm_digits<<<dim3((unsigned)((n + 255) / 256), (unsigned)M), 256, 0, stream>>>(j.bp, (uint32_t)n, j.wp, dig_.p);
   if (tm) SG_TRY(hipEventRecord(j.ev[1], stream));
-  msm_hist<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
+  msm_hist<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
   msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
   SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
   SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   SG_TRY(hipEventRecord(ev_meta_, stream));
-  msm_scatter<<<dim3(P, W), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
+  msm_scatter<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
                                                                     sorted_.p);
   if (tm) SG_TRY(hipEventRecord(j.ev[2], stream));
   return hipGetLastError();
