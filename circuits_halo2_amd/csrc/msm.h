@@ -17,6 +17,7 @@ struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
   uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
   uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
+  uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
 };
 

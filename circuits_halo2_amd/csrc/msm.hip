@@ -853,7 +853,7 @@ hipError_t MsmEngine::enqueue_back() {
   // G buckets per thread: 8 for the largest windows, 4 below (depth vs. work, measured)
   j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 15) ? 3 : 2), j.c - 1);
   const uint32_t items = nbw >> j.log_G;  // chunks per window at level 0 (a power of two)
-  const uint32_t threads = std::min<uint32_t>(256, std::max<uint32_t>(64, items));
+  const uint32_t threads = std::min<uint32_t>(cfg_.red_threads, std::max<uint32_t>(64, items));
   const uint32_t blocks = j.blocks = (items + threads - 1) / threads;
   if (blocks > 256) return hipErrorInvalidValue;
   j.log_N = 0;
