@@ -10,7 +10,7 @@
 namespace sg {
 
 struct NttConfig {
-  // measured on MI355X (gpurun_out/ntt_sweep*.txt): small tiles (several workgroups per CU
+  // measured on MI355X (profiles/r01_sweeps/ntt_sweep*.txt): small tiles (several workgroups per CU
   // hide the barrier and load latency) beat fewer, longer passes: the kernel is product-bound
   uint32_t max_single_log = 11;  // largest transform done in one LDS-resident pass
   uint32_t max_multi_log = 8;    // largest per-pass DFT length in multi-pass plans
