@@ -14,7 +14,7 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 #endif
 
 struct MsmConfig {
-  uint32_t window_bits = 0;    // 0: choose from n (log2 n - 4, clamped to [4, 16])
+  uint32_t window_bits = 0;    // 0: choose from n (log2 n - 2 single / - 4 fused, clamped to [4, 16])
   uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
   uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
   uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
@@ -65,7 +65,7 @@ class MsmEngine {
   void release();
   MsmConfig& config() { return cfg_; }
   void set_tail_stream(hipStream_t s) { tail_stream_ = s; }
-  uint32_t window_bits_for(size_t n) const;
+  uint32_t window_bits_for(size_t n, bool fused = false) const;
   // d_scalars: n x 32 B Montgomery Fr, d_bases: n x 64 B affine; result: 64 B affine on the host
   hipError_t run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
                  MsmTimings* tm);

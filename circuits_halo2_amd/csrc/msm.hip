@@ -664,11 +664,14 @@ void MsmEngine::release() {
   h_win_ = nullptr;
 }
 
-uint32_t MsmEngine::window_bits_for(size_t n) const {
+// Window size, from the measured sweeps (profiles/r01_sweeps/sweep_c2.txt): a single MSM is
+// partly latency-bound (few, deep tasks) and prefers larger windows (log2 n - 2); a fused batch
+// is throughput-bound and prefers the work-optimal log2 n - 4.
+uint32_t MsmEngine::window_bits_for(size_t n, bool fused) const {
   if (cfg_.window_bits) return std::min<uint32_t>(16, std::max<uint32_t>(4, cfg_.window_bits));
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 4;
+  int c = (int)lg - (fused ? 4 : 2);
   return (uint32_t)std::min(16, std::max(4, c));
 }
 
@@ -699,7 +702,7 @@ static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, 
 // ---- phase 1: everything up to the counting sort; ends with an async copy of the counters
 size_t MsmEngine::max_fused(size_t n) const {
   if (n == 0) return MAX_FUSED;
-  const uint32_t c = window_bits_for(n);
+  const uint32_t c = window_bits_for(n, true);
   const uint32_t W = (255 + c - 1) / c;
   const size_t nb = (size_t)W << (c - 1);
   // the scans handle 2^21 buckets (1024 blocks x 2048); cap the fused work space (cfg: log_fuse_entries)
@@ -733,7 +736,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     j.bp.scalars[m] = d_scalars[m];
     j.bp.bases[m] = d_bases[m];
   }
-  const uint32_t c = j.c = window_bits_for(n);
+  const uint32_t c = j.c = window_bits_for(n, M > 1);
   const uint32_t W1 = j.wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
   const uint32_t W = W1 * (uint32_t)M;             // windows of the whole fused job
   const uint32_t nbw = j.nbw = 1u << (c - 1);
@@ -851,7 +854,7 @@ hipError_t MsmEngine::enqueue_back() {
 
   // bucket reduction: level 0 over the buckets, level 1 over the workgroup items
   // G buckets per thread: 8 for the largest windows, 4 below (depth vs. work, measured)
-  j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 15) ? 3 : 2), j.c - 1);
+  j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 14) ? 3 : 2), j.c - 1);
   const uint32_t items = nbw >> j.log_G;  // chunks per window at level 0 (a power of two)
   const uint32_t threads = std::min<uint32_t>(cfg_.red_threads, std::max<uint32_t>(64, items));
   const uint32_t blocks = j.blocks = (items + threads - 1) / threads;

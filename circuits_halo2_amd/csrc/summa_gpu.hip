@@ -904,11 +904,11 @@ int sg_set_param(const char* name, int value) {
   if (!name || value < 0) return fail(SG_ERR_INVALID, "sg_set_param: bad argument");
   LOCKED_CTX();
   std::string s(name);
-  if (s == "msm.window_bits") g_ctx->msm.config().window_bits = (uint32_t)value;
-  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = (uint32_t)std::min(12, value);
+  if (s == "msm.window_bits") g_ctx->msm.config().window_bits = g_ctx->msm_b.config().window_bits = (uint32_t)value;
+  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = g_ctx->msm_b.config().log_seg = (uint32_t)std::min(12, value);
   else if (s == "msm.log_fuse_entries") { g_ctx->msm.config().log_fuse_entries = g_ctx->msm_b.config().log_fuse_entries = (uint32_t)std::max(16, std::min(30, value)); }
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; g_ctx->msm.config().red_threads = g_ctx->msm_b.config().red_threads = v; }
-  else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = (uint32_t)std::min(8, value);
+  else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = g_ctx->msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
   else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
   else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));
   else if (s == "ntt.max_single_log") { g_ctx->ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); g_ctx->ntt.clear(); }
