@@ -197,3 +197,16 @@ def lookup_product(inp, table, permuted_input, permuted_table, beta, gamma):
                                               ffi.dev_ptr(permuted_table), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)),
                                               C.c_size_t(n), ffi.dev_ptr(z), ffi.current_stream_ptr()))
     return z
+
+
+def best_fft_batch(vectors, omega, log_n: int, divisor=None):
+    """in-place best_fft (or ifft when `divisor` is given) of several device tensors of one size"""
+    m = len(vectors)
+    ptrs = (C.c_void_p * m)(*[v.data_ptr() for v in vectors])
+    for v in vectors:
+        if v.numel() != 32 << log_n:
+            raise ValueError("best_fft: a.len() != 1 << log_n")
+    dv = ffi.ptr(ffi.u8(divisor)) if divisor is not None else None
+    ffi.check(ffi.lib().sg_ntt_fr_batch_dev(ptrs, C.c_size_t(m), ffi.ptr(ffi.u8(omega)), dv, C.c_uint32(log_n),
+                                            ffi.current_stream_ptr()))
+    return vectors

@@ -512,6 +512,38 @@ int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n) {
   TRY(ntt_dev(d, (size_t)1 << log_n, d, log_n, w, nullptr, nullptr, nullptr, g_ctx->stream));
   return download(a, d, bytes, g_ctx->stream);
 }
+// A batch of independent in-place transforms of one size (the 9 lagrange_to_coeff / 9
+// coeff_to_extended calls of a proof): round-robin over the two batch streams so that one
+// transform's tail overlaps the next one's head.  divisor == NULL: plain best_fft.
+int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32], const uint8_t* divisor,
+                        uint32_t log_n, void* stream) {
+  if ((count && !d_a) || !omega || log_n > 28) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch: bad argument");
+  LOCKED_CTX();
+  Context& c = *g_ctx;
+  words8 w, dv;
+  std::memcpy(&w, omega, 32);
+  if (divisor) std::memcpy(&dv, divisor, 32);
+  const size_t n = (size_t)1 << log_n;
+  const bool need_scratch = log_n > c.ntt.config().max_single_log;
+  // one scratch area per stream
+  if (need_scratch) {
+    hipError_t e = c.scratch.reserve(2 * n * 32);
+    if (e != hipSuccess) return hip_fail("ntt scratch", e);
+  }
+  CHECK_HIP(hipEventRecord(c.ev_in, pick_stream(stream)), "event");
+  for (auto& bs : c.bstream) CHECK_HIP(hipStreamWaitEvent(bs, c.ev_in, 0), "stream wait");
+  for (size_t i = 0; i < count; i++) {
+    if (!d_a[i]) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch: null vector");
+    const int k = (int)(i & 1);
+    fp_words* a = static_cast<fp_words*>(d_a[i]);
+    fp_words* scratch = need_scratch ? reinterpret_cast<fp_words*>(c.scratch.p) + (size_t)k * n : nullptr;
+    hipError_t e = c.ntt.transform(a, n, a, scratch, log_n, w, divisor ? &dv : nullptr, nullptr, nullptr, c.bstream[k]);
+    if (e != hipSuccess) return hip_fail("ntt batch", e);
+  }
+  for (auto& bs : c.bstream) CHECK_HIP(hipStreamSynchronize(bs), "stream sync");
+  return SG_OK;
+}
+
 int sg_intt_fr_dev(void* d_a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n, void* stream) {
   if (!d_a || !omega_inv || !divisor) return fail(SG_ERR_INVALID, "sg_intt_fr: null argument");
   LOCKED_CTX();

@@ -92,6 +92,12 @@ int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagra
 int sg_ntt_fr(uint8_t* a, const uint8_t omega[32], uint32_t log_n);
 int sg_ntt_fr_dev(void* d_a, const uint8_t omega[32], uint32_t log_n, void* stream);
 
+/* A batch of independent in-place transforms of one size with one omega (the per-column loops
+ * of create_proof: 9 x lagrange_to_coeff, ...; SURVEY.md §8b `sg_ntt_fr_batch`).
+ * divisor == NULL: best_fft; otherwise EvaluationDomain::ifft semantics. */
+int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32], const uint8_t* divisor,
+                        uint32_t log_n, void* stream);
+
 /* ---- N2: EvaluationDomain::ifft(a, omega_inv, log_n, divisor): best_fft with omega_inv,
  * then every element times `divisor` (n^-1 for lagrange_to_coeff). */
 int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n);

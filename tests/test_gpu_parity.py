@@ -573,3 +573,16 @@ def test_lookup_grand_product(gpu, O, n):
     last = O.fr_mul(z[-32:].copy(), O.fr_mul(O.fr_mul(O.fr_add(a[-32:].copy(), beta), O.fr_add(s[-32:].copy(), gamma)),
                                              O.fr_inv(O.fr_mul(O.fr_add(ap2[-32:].copy(), beta), O.fr_add(sp2[-32:].copy(), gamma)))))
     assert (last == fr_np([1])).all()
+
+
+@pytest.mark.parametrize("log_n", [9, 13, 17])
+def test_ntt_batch(gpu, O, log_n):
+    from circuits_halo2_amd.arithmetic import best_fft_batch
+    vecs = [O.random_fr(1500 + i, 1 << log_n) for i in range(5)]
+    d = [dev(v) for v in vecs]
+    best_fft_batch(d, O.omega(log_n), log_n)
+    for got, v in zip(d, vecs):
+        assert (got.cpu().numpy() == O.best_fft(v, O.omega(log_n), log_n, O.ncpu())).all()
+    best_fft_batch(d, O.omega_inv(log_n), log_n, divisor=O.n_inv(log_n))
+    for got, v in zip(d, vecs):
+        assert (got.cpu().numpy() == v).all()
