@@ -181,6 +181,16 @@ def main():
                                         "rows_per_s": (1 << k) / ((msm17 + ntt_ms) * 1e-3),
                                         "note": "MSM+NTT kernel sum only (evaluate_h etc. are §8f 'next' rows)"}
 
+        # ---- CPU baseline for the NTT numbers above (same oracle, same box)
+        if not args.no_cpu and world == 1 and "ntt" in line:
+            from oracle import oracle as O
+            cores = min(O.ncpu(), 16)
+            a = O.random_fr(7, 1 << 22)
+            t1 = time.perf_counter()
+            O.best_fft(a, O.omega(22), 22, cores)
+            cdt = time.perf_counter() - t1
+            line["ntt"]["cpu_baseline_2^22"] = {"ms": cdt * 1e3, "elements_per_s": (1 << 22) / cdt, "cores": cores,
+                                                "kind": "port"}
         # ---- CPU baseline: the oracle's restated halo2 best_multiexp on this box's cores
         if not args.no_cpu and world == 1:
             from oracle import oracle as O
