@@ -290,9 +290,16 @@ __global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thi
   const uint32_t total = TASK_BINS * nblk, tid = threadIdx.x;
   const uint32_t per = (total + 1023) / 1024;
   const uint32_t lo = min(tid * per, total), hi = min(lo + per, total);
-  // position q in scan order <-> entry (TASK_BINS-1 - q / nblk) * nblk + q % nblk
+  // position q in scan order <-> entry (TASK_BINS-1 - q / nblk) * nblk + q % nblk; each thread
+  // walks its run incrementally (one division, then wrap-around counters)
   uint32_t a = 0;
-  for (uint32_t q = lo; q < hi; q++) a += thist[(TASK_BINS - 1 - q / nblk) * nblk + q % nblk];
+  {
+    uint32_t row = lo / nblk, col = lo - row * nblk;
+    for (uint32_t q = lo; q < hi; q++) {
+      a += thist[(TASK_BINS - 1 - row) * nblk + col];
+      if (++col == nblk) { col = 0; row++; }
+    }
+  }
   s_sum[tid] = a;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -302,11 +309,15 @@ __global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thi
     __syncthreads();
   }
   uint32_t run = s_sum[tid] - a;
-  for (uint32_t q = lo; q < hi; q++) {
-    uint32_t idx = (TASK_BINS - 1 - q / nblk) * nblk + q % nblk;
-    uint32_t v = thist[idx];
-    thist[idx] = run;
-    run += v;
+  {
+    uint32_t row = lo / nblk, col = lo - row * nblk;
+    for (uint32_t q = lo; q < hi; q++) {
+      uint32_t idx = (TASK_BINS - 1 - row) * nblk + col;
+      uint32_t v = thist[idx];
+      thist[idx] = run;
+      run += v;
+      if (++col == nblk) { col = 0; row++; }
+    }
   }
 }
 // order[pos] = (bucket, segment) of the task that runs as thread `pos`
