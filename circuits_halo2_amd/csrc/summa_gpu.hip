@@ -17,6 +17,7 @@
 #include "msm.h"
 #include "ntt.h"
 #include "poly.h"
+#include "witness.h"
 
 using namespace sg;
 
@@ -123,6 +124,7 @@ struct Context {
   hipStream_t stream = nullptr;
   NttEngine ntt;
   MsmEngine msm, msm_b;          // two engines: batches ping-pong between them
+  WitnessEngine witness;
   hipStream_t bstream[2] = {nullptr, nullptr};
   hipStream_t tstream[2] = {nullptr, nullptr};  // high-priority tails
   hipEvent_t ev_in = nullptr;
@@ -279,6 +281,7 @@ void sg_shutdown(void) {
   g_ctx->ntt.clear();
   g_ctx->msm.release();
   g_ctx->msm_b.release();
+  g_ctx->witness.release();
   for (auto& bs : g_ctx->bstream) {
     if (bs) (void)hipStreamDestroy(bs);
   }
@@ -929,6 +932,60 @@ int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void*
   hipError_t e = poly_mul_elementwise(static_cast<const fp_words*>(d_a), static_cast<const fp_words*>(d_b), n,
                                       static_cast<fp_words*>(d_out), pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_mul", e);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ witness side (Merkle sum tree)
+int sg_mst_leaves_dev(const void* d_usernames, const void* d_balances, size_t n, uint32_t n_currencies,
+                      void* d_hashes, void* stream) {
+  if (n && (!d_usernames || !d_balances || !d_hashes)) return fail(SG_ERR_INVALID, "sg_mst_leaves: null argument");
+  if (n_currencies == 0 || n_currencies > 64 || n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_mst_leaves: bad size");
+  LOCKED_CTX();
+  hipStream_t s = pick_stream(stream);
+  hipError_t e = g_ctx->witness.init(g_ctx->stream);
+  if (e == hipSuccess)
+    e = g_ctx->witness.leaves(static_cast<const fp_words*>(d_usernames), static_cast<const fp_words*>(d_balances), n,
+                              n_currencies, static_cast<fp_words*>(d_hashes), s);
+  if (e != hipSuccess) return hip_fail("mst leaves", e);
+  return SG_OK;
+}
+int sg_mst_level_dev(const void* d_child_hashes, const void* d_child_balances, size_t n_parents, uint32_t n_currencies,
+                     void* d_hashes, void* d_balances, void* stream) {
+  if (n_parents && (!d_child_hashes || !d_child_balances || !d_hashes || !d_balances))
+    return fail(SG_ERR_INVALID, "sg_mst_level: null argument");
+  if (n_currencies == 0 || n_currencies > 64 || n_parents >= (1ull << 31)) return fail(SG_ERR_INVALID, "sg_mst_level: bad size");
+  LOCKED_CTX();
+  hipError_t e = g_ctx->witness.init(g_ctx->stream);
+  if (e == hipSuccess)
+    e = g_ctx->witness.level(static_cast<const fp_words*>(d_child_hashes), static_cast<const fp_words*>(d_child_balances),
+                             n_parents, n_currencies, static_cast<fp_words*>(d_hashes),
+                             static_cast<fp_words*>(d_balances), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("mst level", e);
+  return SG_OK;
+}
+// whole tree: node arrays are level-major (2^depth leaves, then 2^(depth-1) parents, ..., the root)
+int sg_mst_build_dev(const void* d_usernames, const void* d_leaf_balances, uint32_t depth, uint32_t n_currencies,
+                     void* d_node_hashes, void* d_node_balances, void* stream) {
+  if (!d_usernames || !d_leaf_balances || !d_node_hashes || !d_node_balances || depth > 30)
+    return fail(SG_ERR_INVALID, "sg_mst_build: bad argument");
+  const size_t n = (size_t)1 << depth;
+  uint8_t* h = static_cast<uint8_t*>(d_node_hashes);
+  uint8_t* b = static_cast<uint8_t*>(d_node_balances);
+  int rc = sg_mst_leaves_dev(d_usernames, d_leaf_balances, n, n_currencies, h, stream);
+  if (rc != SG_OK) return rc;
+  {
+    LOCKED_CTX();
+    CHECK_HIP(hipMemcpyAsync(b, d_leaf_balances, n * n_currencies * 32, hipMemcpyDeviceToDevice, pick_stream(stream)),
+              "mst balances");
+  }
+  size_t off = 0;
+  for (size_t m = n >> 1; m >= 1; m >>= 1) {
+    const size_t child = off, parent = off + 2 * m;
+    rc = sg_mst_level_dev(h + 32 * child, b + 32 * child * n_currencies, m, n_currencies, h + 32 * parent,
+                          b + 32 * parent * n_currencies, stream);
+    if (rc != SG_OK) return rc;
+    off = parent;
+  }
   return SG_OK;
 }
 

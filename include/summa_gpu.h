@@ -176,6 +176,21 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 
+/* ---- witness side: the Merkle sum tree of
+ * zk_prover/src/merkle_sum_tree (node.rs:16-84, utils/build_tree.rs:5-78) over Poseidon(t = 2,
+ * rate 1, R_F = 8, R_P = 56, x^5; chips/poseidon/poseidon_spec.rs:14-37).  All values 32-B Fr
+ * (Montgomery); usernames are keccak256(username) reduced mod r by the caller (entry.rs:21).
+ *   leaf hash   = H(username, balance_0 .. balance_{NC-1})
+ *   middle node = H(bal_l + bal_r (per currency) .., hash_l, hash_r), balances = the sums */
+int sg_mst_leaves_dev(const void* d_usernames, const void* d_balances, size_t n, uint32_t n_currencies,
+                      void* d_hashes, void* stream);
+int sg_mst_level_dev(const void* d_child_hashes, const void* d_child_balances, size_t n_parents, uint32_t n_currencies,
+                     void* d_hashes, void* d_balances, void* stream);
+/* whole tree of 2^depth (already padded) entries; node arrays are level-major: 2^depth leaves,
+ * 2^(depth-1) parents, ..., the root last (2^(depth+1) - 1 nodes; balances NC per node) */
+int sg_mst_build_dev(const void* d_usernames, const void* d_leaf_balances, uint32_t depth, uint32_t n_currencies,
+                     void* d_node_hashes, void* d_node_balances, void* stream);
+
 /* ---- tuning / introspection (not part of the reference seam) */
 typedef struct {
   float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream */

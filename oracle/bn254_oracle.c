@@ -646,6 +646,82 @@ void orc_lookup_product(const uint8_t *a, const uint8_t *s, const uint8_t *ap, c
     free(mod);
 }
 
+/* ---------------------------------------------------------------- witness side (row W)
+ * Poseidon(t = 2, rate 1, R_F = 8, R_P = 56, x^5) sponge of halo2_gadgets as used by
+ * zk_prover/src/merkle_sum_tree/node.rs:57-84; parameters are supplied by the caller
+ * (oracle/poseidon_params.py regenerates them from the published Grain-LFSR procedure). */
+static fe PSD_RC[64][2], PSD_MDS[2][2];
+void orc_poseidon_set_params(const uint8_t *rc_mont /*128 x 32 B*/, const uint8_t *mds_mont /*4 x 32 B*/) {
+    memcpy(PSD_RC, rc_mont, sizeof PSD_RC);
+    memcpy(PSD_MDS, mds_mont, sizeof PSD_MDS);
+}
+static void psd_pow5(fe *x) {
+    fe x2, x4;
+    fe_sqr(&FR, &x2, x);
+    fe_sqr(&FR, &x4, &x2);
+    fe_mul(&FR, x, &x4, x);
+}
+static void psd_mix(fe s[2]) {
+    fe a, b, t;
+    fe_mul(&FR, &a, &PSD_MDS[0][0], &s[0]); fe_mul(&FR, &t, &PSD_MDS[0][1], &s[1]); fe_add(&FR, &a, &a, &t);
+    fe_mul(&FR, &b, &PSD_MDS[1][0], &s[0]); fe_mul(&FR, &t, &PSD_MDS[1][1], &s[1]); fe_add(&FR, &b, &b, &t);
+    s[0] = a; s[1] = b;
+}
+static void psd_permute(fe s[2]) {
+    int r = 0;
+    for (int k = 0; k < 4; k++, r++) {
+        for (int i = 0; i < 2; i++) { fe_add(&FR, &s[i], &s[i], &PSD_RC[r][i]); psd_pow5(&s[i]); }
+        psd_mix(s);
+    }
+    for (int k = 0; k < 56; k++, r++) {
+        for (int i = 0; i < 2; i++) fe_add(&FR, &s[i], &s[i], &PSD_RC[r][i]);
+        psd_pow5(&s[0]);
+        psd_mix(s);
+    }
+    for (int k = 0; k < 4; k++, r++) {
+        for (int i = 0; i < 2; i++) { fe_add(&FR, &s[i], &s[i], &PSD_RC[r][i]); psd_pow5(&s[i]); }
+        psd_mix(s);
+    }
+}
+/* Hash<_, _, ConstantLength<L>, 2, 1>: state = [0, L * 2^64]; absorb one input per permutation */
+void orc_poseidon_hash(const uint8_t *inputs, size_t L, uint8_t out[32]) {
+    fe s[2], cap = {{0, (u64)L, 0, 0}};
+    memset(&s[0], 0, sizeof(fe));
+    fe_to_mont(&FR, &s[1], &cap);
+    for (size_t i = 0; i < L; i++) {
+        fe_add(&FR, &s[0], &s[0], (const fe *)(inputs + 32 * i));
+        psd_permute(s);
+    }
+    memcpy(out, &s[0], 32);
+}
+/* leaves: hash_i = H(user_i, bal_i0 .. bal_i,nc-1) */
+void orc_mst_leaves(const uint8_t *users, const uint8_t *balances, size_t n, uint32_t nc, uint8_t *hashes) {
+    uint8_t *pre = (uint8_t *)malloc(32 * (nc + 1));
+    for (size_t i = 0; i < n; i++) {
+        memcpy(pre, users + 32 * i, 32);
+        memcpy(pre + 32, balances + 32 * (size_t)nc * i, 32 * (size_t)nc);
+        orc_poseidon_hash(pre, nc + 1, hashes + 32 * i);
+    }
+    free(pre);
+}
+/* one level: parent p of children 2p, 2p+1 (build_tree.rs:54-78) */
+void orc_mst_level(const uint8_t *child_hash, const uint8_t *child_bal, size_t m, uint32_t nc, uint8_t *hashes,
+                   uint8_t *bal) {
+    uint8_t *pre = (uint8_t *)malloc(32 * (nc + 2));
+    for (size_t p = 0; p < m; p++) {
+        for (uint32_t c = 0; c < nc; c++) {
+            fe s;
+            fe_add(&FR, &s, (const fe *)(child_bal + 32 * ((2 * p) * nc + c)), (const fe *)(child_bal + 32 * ((2 * p + 1) * nc + c)));
+            memcpy(bal + 32 * (p * nc + c), &s, 32);
+            memcpy(pre + 32 * c, &s, 32);
+        }
+        memcpy(pre + 32 * nc, child_hash + 32 * (2 * p), 32);
+        memcpy(pre + 32 * (nc + 1), child_hash + 32 * (2 * p + 1), 32);
+        orc_poseidon_hash(pre, nc + 2, hashes + 32 * p);
+    }
+    free(pre);
+}
+
 int orc_g1_is_on_curve(const uint8_t p[64]) {
     const g1a *a = (const g1a *)p;
     if (g1a_is_id(a)) return 1;

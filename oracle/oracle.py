@@ -217,6 +217,44 @@ def lookup_product(a, s, ap, sp, beta, gamma) -> np.ndarray:
     return out
 
 
+_PSD_READY = False
+
+
+def _poseidon_ready():
+    global _PSD_READY
+    if not _PSD_READY:
+        from . import poseidon_params, pyref
+        rcs, mds, _ = poseidon_params.generate()
+        rc = np.frombuffer(pyref.frs_to_bytes([x for r in rcs for x in r]), dtype=np.uint8).copy()
+        md = np.frombuffer(pyref.frs_to_bytes([x for r in mds for x in r]), dtype=np.uint8).copy()
+        lib().orc_poseidon_set_params(_p(rc), _p(md))
+        _PSD_READY = True
+
+
+def poseidon_hash(inputs: np.ndarray) -> np.ndarray:
+    _poseidon_ready()
+    out = _buf(32)
+    lib().orc_poseidon_hash(_p(np.ascontiguousarray(inputs)), C.c_size_t(inputs.size // 32), _p(out))
+    return out
+
+
+def mst_leaves(users: np.ndarray, balances: np.ndarray, nc: int) -> np.ndarray:
+    _poseidon_ready()
+    n = users.size // 32
+    out = _buf(32 * n)
+    lib().orc_mst_leaves(_p(np.ascontiguousarray(users)), _p(np.ascontiguousarray(balances)), C.c_size_t(n), C.c_uint32(nc), _p(out))
+    return out
+
+
+def mst_level(child_hash: np.ndarray, child_bal: np.ndarray, nc: int):
+    _poseidon_ready()
+    m = child_hash.size // 64
+    h, b = _buf(32 * m), _buf(32 * m * nc)
+    lib().orc_mst_level(_p(np.ascontiguousarray(child_hash)), _p(np.ascontiguousarray(child_bal)), C.c_size_t(m),
+                        C.c_uint32(nc), _p(h), _p(b))
+    return h, b
+
+
 def g1_is_on_curve(p) -> bool:
     return bool(lib().orc_g1_is_on_curve(_p(np.ascontiguousarray(p))))
 

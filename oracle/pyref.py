@@ -346,3 +346,112 @@ def random_fr(seed: int, n: int):
             j += 1
         out.append(v)
     return out
+
+
+# --- witness side: Poseidon Merkle sum tree ---------------------
+# zk_prover/src/merkle_sum_tree/{entry.rs:15-27, node.rs:16-84, utils/build_tree.rs:5-78,
+# utils/operation_helpers.rs:10-12, mst.rs:74-134}; Poseidon = halo2_gadgets' Pow5 sponge with
+# the parameters of chips/poseidon/poseidon_spec.rs:14-37 (t = 2, rate 1, R_F = 8, R_P = 56).
+def keccak256(data: bytes) -> bytes:
+    """Keccak-256 (the pre-NIST padding 0x01 .. 0x80 that Ethereum uses), rate 136"""
+    RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
+          0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
+          0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
+          0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+          0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+    ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+    M = (1 << 64) - 1
+    rol = lambda v, r: ((v << r) | (v >> (64 - r))) & M if r else v
+    rate = 136
+    msg = bytearray(data)
+    msg.append(0x01)
+    while len(msg) % rate:
+        msg.append(0)
+    msg[-1] |= 0x80
+    A = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(msg), rate):
+        for i in range(rate // 8):
+            A[i % 5][i // 5] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], "little")
+        for rnd in range(24):
+            Cc = [A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4] for x in range(5)]
+            D = [Cc[(x - 1) % 5] ^ rol(Cc[(x + 1) % 5], 1) for x in range(5)]
+            A = [[A[x][y] ^ D[x] for y in range(5)] for x in range(5)]
+            B = [[0] * 5 for _ in range(5)]
+            for x in range(5):
+                for y in range(5):
+                    B[y][(2 * x + 3 * y) % 5] = rol(A[x][y], ROT[x][y])
+            A = [[B[x][y] ^ ((~B[(x + 1) % 5][y]) & B[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+            A[0][0] ^= RC[rnd]
+    out = b"".join(A[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+    return out
+
+
+_POSEIDON = None
+
+
+def _poseidon_params():
+    global _POSEIDON
+    if _POSEIDON is None:
+        from . import poseidon_params
+        _POSEIDON = poseidon_params.generate()
+    return _POSEIDON
+
+
+def poseidon_permute(state):
+    rcs, mds, _ = _poseidon_params()
+    s = list(state)
+    def mix(s):
+        return [(mds[0][0] * s[0] + mds[0][1] * s[1]) % R, (mds[1][0] * s[0] + mds[1][1] * s[1]) % R]
+    rnd = 0
+    for _ in range(4):
+        s = mix([pow((s[i] + rcs[rnd][i]) % R, 5, R) for i in range(2)])
+        rnd += 1
+    for _ in range(56):
+        s = [(s[i] + rcs[rnd][i]) % R for i in range(2)]
+        s[0] = pow(s[0], 5, R)
+        s = mix(s)
+        rnd += 1
+    for _ in range(4):
+        s = mix([pow((s[i] + rcs[rnd][i]) % R, 5, R) for i in range(2)])
+        rnd += 1
+    return s
+
+
+def poseidon_hash(inputs):
+    """halo2_gadgets poseidon::Hash<Fr, Spec, ConstantLength<L>, 2, 1>: capacity element L * 2^64,
+    one input absorbed per permutation (rate 1), output = state[0]"""
+    state = [0, (len(inputs) << 64) % R]
+    for m in inputs:
+        state[0] = (state[0] + m) % R
+        state = poseidon_permute(state)
+    return state[0]
+
+
+def mst_entry(username: str, balances):
+    """Entry::new (entry.rs:15-27) + big_uint_to_fp: (keccak256(username) as BE integer mod r, balances mod r)"""
+    return int.from_bytes(keccak256(username.encode()), "big") % R, [b % R for b in balances]
+
+
+def mst_leaf(user_fr: int, balances):
+    return poseidon_hash([user_fr] + list(balances))
+
+
+def mst_middle(left, right):
+    """nodes are (hash, balances)"""
+    bal = [(a + b) % R for a, b in zip(left[1], right[1])]
+    return poseidon_hash(bal + [left[0], right[0]]), bal
+
+
+def mst_build(entries):
+    """entries: [(user_fr, [balances])] already ordered; pads with zero entries to 2^depth
+    (mst.rs:103-134); returns (root, levels) with nodes as (hash, balances)"""
+    n = len(entries)
+    depth = max(0, (n - 1).bit_length())
+    nc = len(entries[0][1])
+    entries = list(entries) + [(0, [0] * nc)] * ((1 << depth) - n)
+    level = [(mst_leaf(u, b), list(b)) for u, b in entries]
+    levels = [level]
+    for _ in range(depth):
+        level = [mst_middle(level[i], level[i + 1]) for i in range(0, len(level), 2)]
+        levels.append(level)
+    return levels[-1][0], levels

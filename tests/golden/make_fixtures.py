@@ -75,6 +75,29 @@ def main():
     f_tau = sum(s * pow(tau, i, P.R) for i, s in enumerate(sp)) % P.R
     ans = P.g1_mul(P.G1_GEN, f_tau)
     kat["msm_tau_k10_sparse"] = {"scalars": [hex(x) for x in sp], "answer": [hex(ans[0]), hex(ans[1])] if ans else None}
+    # --- witness side (K5): the reference's own data file and the constants its tests pin
+    shutil.copyfile(os.path.join(REF, "csv/entry_16.csv"), os.path.join(HERE, "entry_16.csv"))
+    os.chmod(os.path.join(HERE, "entry_16.csv"), 0o644)
+    tests_rs = open(os.path.join(REF, "zk_prover/src/circuits/tests.rs")).read()
+    backend_rs = open(os.path.join(REF, "backend/src/tests.rs")).read()
+    leafs = re.findall(r'"(0x[0-9a-f]{64})"', tests_rs)
+    kat["k5"] = {"source": "zk_prover/src/circuits/tests.rs:341,346; backend/src/tests.rs:265,268; "
+                           "zk_prover/src/merkle_sum_tree/tests.rs:24",
+                 "leaf0": leafs[0], "leaf1": leafs[1],
+                 "root": re.search(r'mst_root: "(0x[0-9a-f]{64})"', backend_rs).group(1),
+                 "root_balances": [556862, 556862]}
+    # the regenerated Poseidon parameters must equal the 136 constants of the reference's
+    # chips/poseidon/poseidon_params.rs (values only are compared; nothing is copied)
+    from oracle import poseidon_params
+    rcs, mds, inv = poseidon_params.generate()
+    src = open(os.path.join(REF, "zk_prover/src/chips/poseidon/poseidon_params.rs")).read()
+    vals = []
+    for m in re.finditer(r"Fp::from_raw\(\[\s*(0x[0-9a-f_]+),\s*(0x[0-9a-f_]+),\s*(0x[0-9a-f_]+),\s*(0x[0-9a-f_]+),?\s*\]\)", src):
+        l = [int(x.replace("_", ""), 16) for x in m.groups()]
+        vals.append(l[0] | l[1] << 64 | l[2] << 128 | l[3] << 192)
+    assert vals == [x for r in rcs for x in r] + [x for r in mds for x in r] + [x for r in inv for x in r]
+    import hashlib
+    kat["poseidon_t2_sha256"] = hashlib.sha256(repr((rcs, mds)).encode()).hexdigest()
     json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
     print("fixtures written to", HERE)
 

@@ -586,3 +586,49 @@ def test_ntt_batch(gpu, O, log_n):
     best_fft_batch(d, O.omega_inv(log_n), log_n, divisor=O.n_inv(log_n))
     for got, v in zip(d, vecs):
         assert (got.cpu().numpy() == v).all()
+
+
+# ----------------------------------------------------------------------------- witness side (row W)
+def test_k5_merkle_sum_tree_on_gpu(gpu, kat, P):
+    """the reference's own constants: entry_16.csv -> leaf 0, leaf 1, root hash and root balances
+    (zk_prover/src/circuits/tests.rs:341,346; backend/src/tests.rs:265,268)"""
+    import os
+    from conftest import GOLDEN
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    tree = MerkleSumTree.from_csv(os.path.join(GOLDEN, "entry_16.csv"), 2)
+    assert tree.depth == 4
+    assert P.fr_from_bytes(tree.node(0, 0)[0].tobytes()) == int(kat["k5"]["leaf0"], 16)
+    assert P.fr_from_bytes(tree.node(0, 1)[0].tobytes()) == int(kat["k5"]["leaf1"], 16)
+    rh, rb = tree.root()
+    assert P.fr_from_bytes(rh.tobytes()) == int(kat["k5"]["root"], 16)
+    assert P.frs_from_bytes(rb.tobytes()) == kat["k5"]["root_balances"]
+    # Merkle proof of user 0 recomputes the root with the oracle's middle-node hash
+    proof = tree.generate_proof(0)
+    node = (P.fr_from_bytes(proof["leaf"][0].tobytes()), P.frs_from_bytes(proof["leaf"][1].tobytes()))
+    for (sh, sb), bit in zip(proof["siblings"], proof["path_indices"]):
+        sib = (P.fr_from_bytes(sh.tobytes()), P.frs_from_bytes(sb.tobytes()))
+        node = P.mst_middle(sib, node) if bit else P.mst_middle(node, sib)
+    assert node[0] == int(kat["k5"]["root"], 16)
+
+
+@pytest.mark.parametrize("n,nc", [(1, 1), (13, 2), (17, 2), (1000, 3), (1 << 14, 2)])
+def test_merkle_sum_tree_vs_oracle(gpu, O, n, nc):
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree, keccak256
+    rng = np.random.default_rng(n)
+    entries = [("user%d" % i, [int(v) for v in rng.integers(0, 1 << 60, nc)]) for i in range(n)]
+    tree = MerkleSumTree.from_entries(entries, nc)
+    size = 1 << tree.depth
+    users = fr_np([int.from_bytes(keccak256(u.encode()), "big") for u, _ in entries] + [0] * (size - n))
+    bals = fr_np([v for _, b in entries for v in b] + [0] * (nc * (size - n)))
+    h, b = O.mst_leaves(users, bals, nc), bals
+    assert (tree._h[:32 * size] == h).all()
+    off = size
+    m = size >> 1
+    while m >= 1:
+        h, b = O.mst_level(h, b, nc)
+        assert (tree._h[32 * off:32 * (off + m)] == h).all()
+        assert (tree._b[32 * off * nc:32 * (off + m) * nc] == b).all()
+        off += m
+        m >>= 1
+    with pytest.raises(ValueError):
+        MerkleSumTree.from_entries([("x", [1 << 64] * nc)], nc, n_bytes=8)
