@@ -199,6 +199,40 @@ def lookup_product(inp, table, permuted_input, permuted_table, beta, gamma):
     return z
 
 
+def quotient_permutation(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l_active, beta, gamma, y, k: int,
+                         ext_k: int, last_rotation_abs: int):
+    """fold the permutation argument's constraints into the quotient numerator `values` (device
+    tensors over the extended coset, in place): values = values * y + term, in halo2's order"""
+    ns, m = len(zs), len(cols)
+    if len(sigmas) != m:
+        raise ValueError("quotient_permutation: one sigma per column")
+    for t in [values, l0, l_last, l_active, *zs, *cols, *sigmas]:
+        if t.numel() != 32 << ext_k:
+            raise ValueError("quotient_permutation: every array has 2^ext_k rows")
+    pz = (C.c_void_p * ns)(*[z.data_ptr() for z in zs])
+    pc = (C.c_void_p * m)(*[c.data_ptr() for c in cols])
+    ps = (C.c_void_p * m)(*[s.data_ptr() for s in sigmas])
+    ffi.check(ffi.lib().sg_quotient_permutation_dev(
+        ffi.dev_ptr(values), pz, C.c_uint32(ns), pc, ps, C.c_uint32(m), C.c_uint32(chunk_len), ffi.dev_ptr(l0),
+        ffi.dev_ptr(l_last), ffi.dev_ptr(l_active), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(y)),
+        C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(last_rotation_abs), ffi.current_stream_ptr()))
+    return values
+
+
+def quotient_lookup(values, z, permuted_input, permuted_table, inp, table, l0, l_last, l_active, beta, gamma, y,
+                    k: int, ext_k: int):
+    """fold one lookup argument's five constraints into the quotient numerator (in place)"""
+    for t in [values, z, permuted_input, permuted_table, inp, table, l0, l_last, l_active]:
+        if t.numel() != 32 << ext_k:
+            raise ValueError("quotient_lookup: every array has 2^ext_k rows")
+    ffi.check(ffi.lib().sg_quotient_lookup_dev(
+        ffi.dev_ptr(values), ffi.dev_ptr(z), ffi.dev_ptr(permuted_input), ffi.dev_ptr(permuted_table),
+        ffi.dev_ptr(inp), ffi.dev_ptr(table), ffi.dev_ptr(l0), ffi.dev_ptr(l_last), ffi.dev_ptr(l_active),
+        ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(y)), C.c_uint32(k), C.c_uint32(ext_k),
+        ffi.current_stream_ptr()))
+    return values
+
+
 def best_fft_batch(vectors, omega, log_n: int, divisor=None):
     """in-place best_fft (or ifft when `divisor` is given) of several device tensors of one size"""
     m = len(vectors)

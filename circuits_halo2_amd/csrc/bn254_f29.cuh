@@ -73,6 +73,21 @@ struct Fr29 {
                                        0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
   static constexpr uint32_t r517[9] = {0x142db4dfu, 0x19d6990eu, 0x1472f48cu, 0x06dbe7e3u, 0x0b84d579u,
                                        0x10f9faf7u, 0x121f4380u, 0x17a112deu, 0x001275c7u};
+  // 2^(261 + 5j) mod r, j = 0..12: undoes the 2^-5 drift of j products of memory-domain values
+  static constexpr uint32_t p2[13][9] = {
+      {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u},
+      {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u},
+      {0x0ffd5addu, 0x0d5998b1u, 0x1d5ce7cau, 0x1f285fe9u, 0x08ff23b9u, 0x09c89e51u, 0x177e12abu, 0x185f3518u, 0x001ed378u},
+      {0x1fab5b8cu, 0x1df999b9u, 0x0c6a22f9u, 0x08c0aa38u, 0x117004feu, 0x1ff2bb1bu, 0x02b8bc53u, 0x0cb3a707u, 0x001298f7u},
+      {0x156b7174u, 0x0a771fc5u, 0x00f2ab72u, 0x1a4e7ba3u, 0x0bbac1a1u, 0x1c105a69u, 0x0f44fb72u, 0x0a231672u, 0x000e6b3fu},
+      {0x1d6e2e77u, 0x1756e719u, 0x1d182771u, 0x037a5bd1u, 0x15a3cd9du, 0x08560665u, 0x02c18312u, 0x0325767bu, 0x0019e128u},
+      {0x1dc5cecfu, 0x1ad26ca5u, 0x0ee684d6u, 0x0a71da12u, 0x0696b8ecu, 0x1a317feau, 0x0d1b6cf5u, 0x109045eeu, 0x00057bcdu},
+      {0x08b9d9ddu, 0x1d1e8edfu, 0x11bc2de7u, 0x16c98f74u, 0x1245a600u, 0x1d9e3b04u, 0x0178faf6u, 0x06f44b31u, 0x001e4cc5u},
+      {0x173b3b8cu, 0x16985f72u, 0x1852e6a9u, 0x1ce69b8cu, 0x1a404dd5u, 0x1aa65184u, 0x0215c5c7u, 0x1f566a11u, 0x0001c285u},
+      {0x1767717fu, 0x13fc41b7u, 0x1c00b0e5u, 0x1502e0a4u, 0x1283e839u, 0x11eeefd9u, 0x0211d7b9u, 0x1c711beeu, 0x0007ec70u},
+      {0x1cee2fdbu, 0x0439d7d9u, 0x1849671fu, 0x19493fdau, 0x04dfeaa4u, 0x0f95b76fu, 0x1ef890ecu, 0x0656bebdu, 0x000b9894u},
+      {0x0dc5fb59u, 0x0dcd42e0u, 0x04a7e5adu, 0x127404b0u, 0x05549302u, 0x1eb828a0u, 0x1a81f4c7u, 0x0652cc52u, 0x00205461u},
+      {0x08bf6b0bu, 0x0d5f32f8u, 0x076dbb09u, 0x0a64b20cu, 0x06981b8eu, 0x1b08c437u, 0x028e1ea7u, 0x1cca6816u, 0x001251b6u}};
   static constexpr uint32_t subc[6][9] = {
       {0x40000002u, 0x5e1f593du, 0x5cb8489fu, 0x4fa121e4u, 0x4b0ba504u, 0x45b6817fu, 0x414dc280u, 0x5cb84c66u, 0x0060c89au},
       {0x40000004u, 0x5c3eb27cu, 0x59709141u, 0x5f4243cbu, 0x56174a0au, 0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u},

@@ -47,6 +47,8 @@ class NttEngine {
   hipError_t transform(const fp_words* in, size_t in_len, fp_words* out, fp_words* scratch, uint32_t log_n,
                        const words8& omega, const words8* scale, const words8* pre3, const words8* post3,
                        hipStream_t stream);
+  // cached table of omega_r^t, t < 2^(log_r - 1), as 2^261-domain words
+  hipError_t local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out);
 
  private:
   struct LocalTw {
@@ -55,7 +57,6 @@ class NttEngine {
     fp_words* tw;
   };
   hipError_t get_plan(uint32_t log_n, const words8& omega, const words8* scale, hipStream_t stream, const NttPlan** out);
-  hipError_t local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out);
   NttConfig cfg_;
   std::deque<NttPlan> plans_;
   std::vector<LocalTw> local_tw_;

@@ -16,6 +16,7 @@
 #include "host_curve.h"
 #include "msm.h"
 #include "ntt.h"
+#include "quotient.h"
 #include "poly.h"
 #include "witness.h"
 
@@ -932,6 +933,77 @@ int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void*
   hipError_t e = poly_mul_elementwise(static_cast<const fp_words*>(d_a), static_cast<const fp_words*>(d_b), n,
                                       static_cast<fp_words*>(d_out), pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_mul", e);
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
+int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                uint32_t last_rotation_abs, void* stream) {
+  if (!d_values || !d_z || !d_cols || !d_sigma || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !y)
+    return fail(SG_ERR_INVALID, "sg_quotient_permutation: null argument");
+  if (k == 0 || ext_k < k || ext_k > 28 || nsets == 0 || nsets > QUOT_MAX_SETS || ncols == 0 ||
+      ncols > QUOT_MAX_COLS || chunk_len == 0 || chunk_len > 11 ||
+      (size_t)nsets * chunk_len < ncols || (size_t)(nsets - 1) * chunk_len >= ncols ||
+      last_rotation_abs >= (1u << k))
+    return fail(SG_ERR_INVALID, "sg_quotient_permutation: bad shape");
+  LOCKED_CTX();
+  QuotPermArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.values = static_cast<fp_words*>(d_values);
+  for (uint32_t i = 0; i < nsets; i++) {
+    if (!d_z[i]) return fail(SG_ERR_INVALID, "sg_quotient_permutation: null z");
+    a.z[i] = static_cast<const fp_words*>(d_z[i]);
+  }
+  for (uint32_t i = 0; i < ncols; i++) {
+    if (!d_cols[i] || !d_sigma[i]) return fail(SG_ERR_INVALID, "sg_quotient_permutation: null column");
+    a.cols[i] = static_cast<const fp_words*>(d_cols[i]);
+    a.sigma[i] = static_cast<const fp_words*>(d_sigma[i]);
+  }
+  a.l0 = static_cast<const fp_words*>(d_l0);
+  a.l_last = static_cast<const fp_words*>(d_l_last);
+  a.l_active = static_cast<const fp_words*>(d_l_active);
+  a.nsets = nsets; a.ncols = ncols; a.chunk_len = chunk_len; a.k = k; a.ext_k = ext_k;
+  a.last_rot_abs = last_rotation_abs;
+  const DomainConsts *dk, *de;
+  TRY(get_consts(k, &dk));
+  TRY(get_consts(ext_k, &de));
+  std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
+  std::memcpy(a.delta, DELTA_M, 32); std::memcpy(a.zeta, &dk->zeta, 32); std::memcpy(a.omega_ext, &de->omega, 32);
+  hipStream_t s = pick_stream(stream);
+  fp_words* pw = nullptr;
+  hipError_t e = g_ctx->ntt.local_twiddles(de->omega, 9, s, &pw);   // omega_ext^t, t < 256
+  if (e != hipSuccess) return hip_fail("quotient twiddles", e);
+  a.pow_lo = pw;
+  e = quotient_permutation(a, s);
+  if (e != hipSuccess) return hip_fail("quotient_permutation", e);
+  return SG_OK;
+}
+int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                           const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                           const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                           uint32_t k, uint32_t ext_k, void* stream) {
+  if (!d_values || !d_z || !d_permuted_input || !d_permuted_table || !d_input || !d_table || !d_l0 || !d_l_last ||
+      !d_l_active || !beta || !gamma || !y)
+    return fail(SG_ERR_INVALID, "sg_quotient_lookup: null argument");
+  if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_lookup: bad shape");
+  LOCKED_CTX();
+  QuotLookupArgs a;
+  a.values = static_cast<fp_words*>(d_values);
+  a.z = static_cast<const fp_words*>(d_z);
+  a.permuted_input = static_cast<const fp_words*>(d_permuted_input);
+  a.permuted_table = static_cast<const fp_words*>(d_permuted_table);
+  a.input = static_cast<const fp_words*>(d_input);
+  a.table = static_cast<const fp_words*>(d_table);
+  a.l0 = static_cast<const fp_words*>(d_l0);
+  a.l_last = static_cast<const fp_words*>(d_l_last);
+  a.l_active = static_cast<const fp_words*>(d_l_active);
+  a.k = k; a.ext_k = ext_k;
+  std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
+  hipError_t e = quotient_lookup(a, pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("quotient_lookup", e);
   return SG_OK;
 }
 

@@ -176,6 +176,34 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 
+/* ---- the generic (circuit-independent) parts of halo2's `evaluate_h`
+ * (halo2_proofs plonk/evaluation.rs, Evaluator::evaluate_h; the same terms, in the same
+ * order, are folded by the generated verifier: contracts/src/InclusionVerifier.sol:903-997).
+ * All arrays are evaluations over the extended coset (2^ext_k rows, row i = zeta * omega_ext^i),
+ * `values` is the running numerator, updated in place as values = values * y + term for each
+ * term.  l0 / l_last / l_active are the extended-coset evaluations of the Lagrange selector
+ * polynomials the proving key holds.
+ *
+ * Permutation argument: nsets grand-product polynomials z_s over ncols columns in chunks of
+ * chunk_len (= degree - 2), sigma = the permutation polynomials of the proving key;
+ * last_rotation_abs = blinding_factors + 1 (z_{s-1} is read at omega^-last_rotation_abs):
+ *   l0 (1 - z_0);  l_last (z_last^2 - z_last);  l0 (z_s - z_{s-1}(omega^-last X)), s >= 1;
+ *   l_active (z_s(omega X) prod_j (v_j + beta sigma_j + gamma)
+ *             - z_s(X) prod_j (v_j + beta zeta delta^j' omega_ext^i + gamma))    per set          */
+int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                uint32_t last_rotation_abs, void* stream);
+/* Lookup argument (one lookup; inputs already theta-compressed by the caller):
+ *   l0 (1 - z);  l_last (z^2 - z);
+ *   l_active (z(omega X)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma));
+ *   l0 (a' - s');  l_active (a' - s')(a' - a'(omega^-1 X))                                         */
+int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                           const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                           const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                           uint32_t k, uint32_t ext_k, void* stream);
+
 /* ---- witness side: the Merkle sum tree of
  * zk_prover/src/merkle_sum_tree (node.rs:16-84, utils/build_tree.rs:5-78) over Poseidon(t = 2,
  * rate 1, R_F = 8, R_P = 56, x^5; chips/poseidon/poseidon_spec.rs:14-37).  All values 32-B Fr

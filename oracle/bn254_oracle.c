@@ -646,6 +646,109 @@ void orc_lookup_product(const uint8_t *a, const uint8_t *s, const uint8_t *ap, c
     free(mod);
 }
 
+/* ---------------------------------------------------------------- 8f-1: quotient numerator
+ * The permutation and lookup blocks of halo2's Evaluator::evaluate_h (halo2_proofs
+ * plonk/evaluation.rs in the summa-dev/halo2 fork pinned by zk_prover/Cargo.toml:13 -- a git
+ * dependency, not vendored under /root/reference).  Formulas and fold order are anchored on the
+ * reference's generated verifier, which evaluates the same expressions at the challenge point:
+ * contracts/src/InclusionVerifier.sol:903-997.  Row i of the extended domain is zeta*omega_ext^i;
+ * r_next / r_prev / r_last are index shifts by 2^(ext_k-k) * {+1, -1, -last_rotation_abs}. */
+static inline const fe *row(const uint8_t *a, size_t i) { return (const fe *)(a + 32 * i); }
+static void fold_term(fe *acc, const fe *y, const fe *term) {
+    fe_mul(&FR, acc, acc, y);
+    fe_add(&FR, acc, acc, term);
+}
+void orc_quotient_permutation(uint8_t *values, const uint8_t *const *z, uint32_t nsets, const uint8_t *const *cols,
+                              const uint8_t *const *sigma, uint32_t ncols, uint32_t chunk_len, const uint8_t *l0,
+                              const uint8_t *l_last, const uint8_t *l_active, const uint8_t beta[32],
+                              const uint8_t gamma[32], const uint8_t y_[32], uint32_t k, uint32_t ext_k,
+                              uint32_t last_rotation_abs) {
+    const size_t n_ext = (size_t)1 << ext_k, rot = (size_t)1 << (ext_k - k), mask = n_ext - 1;
+    fe b, g, y, delta, dc, zeta, zc, w_ext, beta_term;
+    memcpy(&b, beta, 32); memcpy(&g, gamma, 32); memcpy(&y, y_, 32);
+    memcpy(dc.l, DELTA_CANON, 32); fe_to_mont(&FR, &delta, &dc);
+    memcpy(zc.l, ZETA_CANON, 32); fe_to_mont(&FR, &zeta, &zc);
+    fr_omega(ext_k, &w_ext);
+    fe_mul(&FR, &beta_term, &b, &zeta);               /* beta * zeta * omega_ext^i, advanced per row */
+    for (size_t i = 0; i < n_ext; i++) {
+        const size_t i_next = (i + rot) & mask, i_last = (i + n_ext - last_rotation_abs * rot) & mask;
+        fe acc = *row(values, i), t, u;
+        /* l0 (1 - z_0) */
+        fe_sub(&FR, &t, &FR.r1, row(z[0], i));
+        fe_mul(&FR, &t, &t, row(l0, i));
+        fold_term(&acc, &y, &t);
+        /* l_last (z_l^2 - z_l) */
+        fe_sqr(&FR, &t, row(z[nsets - 1], i));
+        fe_sub(&FR, &t, &t, row(z[nsets - 1], i));
+        fe_mul(&FR, &t, &t, row(l_last, i));
+        fold_term(&acc, &y, &t);
+        /* l0 (z_s - z_{s-1}(omega^-last X)) */
+        for (uint32_t s = 1; s < nsets; s++) {
+            fe_sub(&FR, &t, row(z[s], i), row(z[s - 1], i_last));
+            fe_mul(&FR, &t, &t, row(l0, i));
+            fold_term(&acc, &y, &t);
+        }
+        fe cur = beta_term;
+        uint32_t c = 0;
+        for (uint32_t s = 0; s < nsets; s++) {
+            fe left = *row(z[s], i_next), right = *row(z[s], i);
+            for (uint32_t j = 0; j < chunk_len && c < ncols; j++, c++) {
+                fe_mul(&FR, &t, &b, row(sigma[c], i));
+                fe_add(&FR, &t, &t, row(cols[c], i));
+                fe_add(&FR, &t, &t, &g);
+                fe_mul(&FR, &left, &left, &t);
+                fe_add(&FR, &u, row(cols[c], i), &cur);
+                fe_add(&FR, &u, &u, &g);
+                fe_mul(&FR, &right, &right, &u);
+                fe_mul(&FR, &cur, &cur, &delta);
+            }
+            fe_sub(&FR, &t, &left, &right);
+            fe_mul(&FR, &t, &t, row(l_active, i));
+            fold_term(&acc, &y, &t);
+        }
+        memcpy(values + 32 * i, &acc, 32);
+        fe_mul(&FR, &beta_term, &beta_term, &w_ext);
+    }
+}
+void orc_quotient_lookup(uint8_t *values, const uint8_t *z, const uint8_t *ap, const uint8_t *sp, const uint8_t *a,
+                         const uint8_t *s, const uint8_t *l0, const uint8_t *l_last, const uint8_t *l_active,
+                         const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y_[32], uint32_t k,
+                         uint32_t ext_k) {
+    const size_t n_ext = (size_t)1 << ext_k, rot = (size_t)1 << (ext_k - k), mask = n_ext - 1;
+    fe b, g, y;
+    memcpy(&b, beta, 32); memcpy(&g, gamma, 32); memcpy(&y, y_, 32);
+    for (size_t i = 0; i < n_ext; i++) {
+        const size_t i_next = (i + rot) & mask, i_prev = (i + n_ext - rot) & mask;
+        fe acc = *row(values, i), t, u, v, d;
+        fe_sub(&FR, &t, &FR.r1, row(z, i));                       /* l0 (1 - z) */
+        fe_mul(&FR, &t, &t, row(l0, i));
+        fold_term(&acc, &y, &t);
+        fe_sqr(&FR, &t, row(z, i));                               /* l_last (z^2 - z) */
+        fe_sub(&FR, &t, &t, row(z, i));
+        fe_mul(&FR, &t, &t, row(l_last, i));
+        fold_term(&acc, &y, &t);
+        fe_add(&FR, &u, row(ap, i), &b);                          /* z(wX)(a'+beta)(s'+gamma) */
+        fe_add(&FR, &v, row(sp, i), &g);
+        fe_mul(&FR, &t, &u, &v);
+        fe_mul(&FR, &t, &t, row(z, i_next));
+        fe_add(&FR, &u, row(a, i), &b);                           /* z(X)(a+beta)(s+gamma) */
+        fe_add(&FR, &v, row(s, i), &g);
+        fe_mul(&FR, &u, &u, &v);
+        fe_mul(&FR, &u, &u, row(z, i));
+        fe_sub(&FR, &t, &t, &u);
+        fe_mul(&FR, &t, &t, row(l_active, i));
+        fold_term(&acc, &y, &t);
+        fe_sub(&FR, &d, row(ap, i), row(sp, i));                  /* l0 (a' - s') */
+        fe_mul(&FR, &t, &d, row(l0, i));
+        fold_term(&acc, &y, &t);
+        fe_sub(&FR, &u, row(ap, i), row(ap, i_prev));             /* l_active (a'-s')(a'-a'(w^-1 X)) */
+        fe_mul(&FR, &t, &d, &u);
+        fe_mul(&FR, &t, &t, row(l_active, i));
+        fold_term(&acc, &y, &t);
+        memcpy(values + 32 * i, &acc, 32);
+    }
+}
+
 /* ---------------------------------------------------------------- witness side (row W)
  * Poseidon(t = 2, rate 1, R_F = 8, R_P = 56, x^5) sponge of halo2_gadgets as used by
  * zk_prover/src/merkle_sum_tree/node.rs:57-84; parameters are supplied by the caller

@@ -217,6 +217,30 @@ def lookup_product(a, s, ap, sp, beta, gamma) -> np.ndarray:
     return out
 
 
+def quotient_permutation(values, zs, cols, sigmas, chunk_len, l0, l_last, l_active, beta, gamma, y, k, ext_k,
+                         last_rotation_abs) -> np.ndarray:
+    """returns the updated numerator (values is not modified)"""
+    out = np.ascontiguousarray(values).copy()
+    keep = [np.ascontiguousarray(t) for t in [*zs, *cols, *sigmas]]
+    ns, m = len(zs), len(cols)
+    pz = (C.c_void_p * ns)(*[t.ctypes.data for t in keep[:ns]])
+    pc = (C.c_void_p * m)(*[t.ctypes.data for t in keep[ns:ns + m]])
+    ps = (C.c_void_p * m)(*[t.ctypes.data for t in keep[ns + m:]])
+    lib().orc_quotient_permutation(_p(out), pz, C.c_uint32(ns), pc, ps, C.c_uint32(m), C.c_uint32(chunk_len),
+                                   _p(np.ascontiguousarray(l0)), _p(np.ascontiguousarray(l_last)),
+                                   _p(np.ascontiguousarray(l_active)), _p(beta), _p(gamma), _p(y), C.c_uint32(k),
+                                   C.c_uint32(ext_k), C.c_uint32(last_rotation_abs))
+    return out
+
+
+def quotient_lookup(values, z, ap, sp, a, s, l0, l_last, l_active, beta, gamma, y, k, ext_k) -> np.ndarray:
+    out = np.ascontiguousarray(values).copy()
+    c = np.ascontiguousarray
+    lib().orc_quotient_lookup(_p(out), _p(c(z)), _p(c(ap)), _p(c(sp)), _p(c(a)), _p(c(s)), _p(c(l0)), _p(c(l_last)),
+                              _p(c(l_active)), _p(beta), _p(gamma), _p(y), C.c_uint32(k), C.c_uint32(ext_k))
+    return out
+
+
 _PSD_READY = False
 
 

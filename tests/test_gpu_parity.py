@@ -588,6 +588,111 @@ def test_ntt_batch(gpu, O, log_n):
         assert (got.cpu().numpy() == v).all()
 
 
+# ----------------------------------------------------------------------------- §8f-1: quotient numerator
+def _to_extended_dev(cols, k, ext_k):
+    """Lagrange columns (numpy) -> extended-coset evaluations on the device, through the product path"""
+    from circuits_halo2_amd.domain import EvaluationDomain
+    dom = EvaluationDomain(1 + (1 << (ext_k - k)), k)
+    assert dom.extended_k == ext_k
+    return [dom.coeff_to_extended(dom.lagrange_to_coeff(dev(c))) for c in cols], dom
+
+
+@pytest.mark.parametrize("k,ext_k,ncols,chunk_len", [(4, 6, 3, 2), (9, 11, 6, 4), (10, 13, 6, 4), (12, 14, 16, 2),
+                                                     (11, 13, 11, 11)])
+def test_quotient_permutation_random_parity(gpu, O, k, ext_k, ncols, chunk_len):
+    """bit-exact against the oracle on arbitrary (non-satisfying) data, non-zero running value"""
+    from circuits_halo2_amd.arithmetic import quotient_permutation
+    ne = 1 << ext_k
+    nsets = -(-ncols // chunk_len)
+    r = lambda seed: O.random_fr(seed, ne)
+    zs = [r(1600 + i) for i in range(nsets)]
+    cols = [r(1620 + i) for i in range(ncols)]
+    sig = [r(1640 + i) for i in range(ncols)]
+    l0, ll, la, start = r(1660), r(1661), r(1662), r(1663)
+    beta, gamma, y = O.random_fr(1671, 1), O.random_fr(1672, 1), O.random_fr(1673, 1)
+    want = O.quotient_permutation(start, zs, cols, sig, chunk_len, l0, ll, la, beta, gamma, y, k, ext_k, 6)
+    got = quotient_permutation(dev(start), [dev(z) for z in zs], [dev(c) for c in cols], [dev(s) for s in sig],
+                               chunk_len, dev(l0), dev(ll), dev(la), beta, gamma, y, k, ext_k, 6)
+    assert (got.cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("k,ext_k", [(4, 6), (10, 13), (13, 15)])
+def test_quotient_lookup_random_parity(gpu, O, k, ext_k):
+    from circuits_halo2_amd.arithmetic import quotient_lookup
+    ne = 1 << ext_k
+    arrs = [O.random_fr(1700 + i, ne) for i in range(9)]
+    beta, gamma, y = O.random_fr(1711, 1), O.random_fr(1712, 1), O.random_fr(1713, 1)
+    want = O.quotient_lookup(arrs[0], *arrs[1:], beta, gamma, y, k, ext_k)
+    got = quotient_lookup(*[dev(a) for a in arrs], beta, gamma, y, k, ext_k)
+    assert (got.cpu().numpy() == want).all()
+
+
+def test_quotient_shape_errors(gpu, O):
+    from circuits_halo2_amd.arithmetic import quotient_permutation
+    from circuits_halo2_amd.ffi import SummaGpuError
+    k, ext_k = 4, 6
+    t = lambda: dev(O.random_fr(1, 1 << ext_k))
+    b = O.random_fr(2, 1)
+    with pytest.raises(SummaGpuError):           # 3 columns in chunks of 2 need exactly 2 sets
+        quotient_permutation(t(), [t()], [t(), t(), t()], [t(), t(), t()], 2, t(), t(), t(), b, b, b, k, ext_k, 6)
+    with pytest.raises(ValueError):
+        quotient_permutation(t(), [t()], [t()], [t(), t()], 2, t(), t(), t(), b, b, b, k, ext_k, 6)
+    with pytest.raises(ValueError):
+        quotient_permutation(t()[:64], [t()], [t()], [t()], 2, t(), t(), t(), b, b, b, k, ext_k, 6)
+
+
+@pytest.mark.parametrize("k,ncols,chunk_len", [(8, 6, 2), (12, 6, 4)])
+def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
+    """whole h(X) pipeline on the device with a witness that satisfies both arguments: grand products
+    -> iNTT -> coset NTT -> numerator -> / (X^n - 1) -> coset iNTT; the quotient is a polynomial of the
+    expected degree (top coefficients vanish), identical to the oracle's, and a tampered witness is caught"""
+    import torch
+    import quotient_witness as W
+    from circuits_halo2_amd.arithmetic import quotient_lookup, quotient_permutation
+    blinding, n = 5, 1 << k
+    ext_k = k + 3 if chunk_len == 4 else k + 2                 # degree 6 (MstInclusion's) / degree 4
+    ne = 1 << ext_k
+    beta, gamma, y = O.random_fr(1801, 1), O.random_fr(1802, 1), O.random_fr(1803, 1)
+    u, l0, l_last, l_active = W.selectors(k, blinding)
+    cols, sigmas, zs = W.permutation_witness(k, ncols, chunk_len, blinding, 1810 + k, beta, gamma)
+    a, s, ap, sp, z = W.lookup_witness(k, blinding, 1820 + k, beta, gamma)
+    lag = [l0, l_last, l_active, *zs, *cols, *sigmas, z, ap, sp, a, s]
+    ext, dom = _to_extended_dev(lag, k, ext_k)
+    e_l0, e_ll, e_la = ext[:3]
+    e_zs = ext[3:3 + len(zs)]
+    e_cols = ext[3 + len(zs):3 + len(zs) + ncols]
+    e_sig = ext[3 + len(zs) + ncols:3 + len(zs) + 2 * ncols]
+    e_z, e_ap, e_sp, e_a, e_s = ext[-5:]
+    values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    quotient_permutation(values, e_zs, e_cols, e_sig, chunk_len, e_l0, e_ll, e_la, beta, gamma, y, k, ext_k, blinding + 1)
+    quotient_lookup(values, e_z, e_ap, e_sp, e_a, e_s, e_l0, e_ll, e_la, beta, gamma, y, k, ext_k)
+    # same folds by the oracle on the same extended columns
+    h = lambda t: t.cpu().numpy()
+    want = O.quotient_permutation(np.zeros(32 * ne, dtype=np.uint8), [h(t) for t in e_zs], [h(t) for t in e_cols],
+                                  [h(t) for t in e_sig], chunk_len, h(e_l0), h(e_ll), h(e_la), beta, gamma, y, k, ext_k,
+                                  blinding + 1)
+    want = O.quotient_lookup(want, h(e_z), h(e_ap), h(e_sp), h(e_a), h(e_s), h(e_l0), h(e_ll), h(e_la), beta, gamma, y,
+                             k, ext_k)
+    assert (h(values) == want).all()
+    full = values.clone()
+    dom.divide_by_vanishing_poly(full)
+    ffi_check_full = dom.extended_to_coeff(full)                # truncated view; `full` now holds all coefficients
+    deg = max(chunk_len + 2, 4)
+    first_zero = (deg - 1) * n - deg + 1
+    assert W.top_coefficients_zero(h(full), first_zero)
+    assert h(ffi_check_full).any()
+    # tamper: one cell of one permutation column
+    bad = cols[1].copy()
+    bad[32 * 3:32 * 4] = O.fr_add(bad[32 * 3:32 * 4].copy(), W.fr_np([1]))
+    e_bad = dom.coeff_to_extended(dom.lagrange_to_coeff(dev(bad)))
+    values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    quotient_permutation(values, e_zs, [e_cols[0], e_bad, *e_cols[2:]], e_sig, chunk_len, e_l0, e_ll, e_la, beta, gamma,
+                         y, k, ext_k, blinding + 1)
+    dom.divide_by_vanishing_poly(values)
+    dom.extended_to_coeff(values)
+    assert not W.top_coefficients_zero(h(values), first_zero)
+
+
 # ----------------------------------------------------------------------------- witness side (row W)
 def test_k5_merkle_sum_tree_on_gpu(gpu, kat, P):
     """the reference's own constants: entry_16.csv -> leaf 0, leaf 1, root hash and root balances
