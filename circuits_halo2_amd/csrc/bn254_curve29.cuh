@@ -279,5 +279,68 @@ __device__ __forceinline__ void f29_store_canonical(fp_words* p, const f29& a_lt
   f29_to_words(f29_cond_sub_p<P>(a_lt2p_normalised), w);
   fp_words_store(p, w);
 }
+// ---- quad-cooperative XYZZ addition -----------------------------------------------------------
+// The latency-bound phases of an MSM (bucket reduction, merge rounds) run a few dependent point
+// additions per lane with most of the chip idle; one lane needs ~6.5 us per addition (14 dependent
+// field products).  Here the 4 lanes of a quad hold IDENTICAL copies of both operands and split the
+// products: 4 rounds of one product per lane instead of 14 products, results exchanged with DPP
+// quad broadcasts (full-rate VALU moves, no LDS).  Same formulas and bounds as xyzz29_add
+// (add-2008-s); the rare special cases (P = +-Q) fall back to the serial code in all 4 lanes.
+template <int SRC>
+__device__ __forceinline__ f29 quad_bcast(const f29& v) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int t = __builtin_amdgcn_mov_dpp((int)v.l[i], SRC * 0x55, 0xf, 0xf, true);   // every source lane is live
+    // keep the broadcast a plain v_mov_b32_dpp: the compiler's DPP combine folds it into the consuming
+    // VOP2 (v_subrev_u32_dpp ...), which on gfx950 returned the lane's own value (tools/test_quad.hip)
+    asm volatile("" : "+v"(t));
+    r.l[i] = (uint32_t)t;
+  }
+  return r;
+}
+__device__ __forceinline__ f29 quad_sel(uint32_t role, const f29& a0, const f29& a1, const f29& a2, const f29& a3) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t lo = (role & 1) ? a1.l[i] : a0.l[i];
+    uint32_t hi = (role & 1) ? a3.l[i] : a2.l[i];
+    r.l[i] = (role & 2) ? hi : lo;
+  }
+  return r;
+}
+// acc += q; every lane of the quad passes the same acc / q and receives the same result
+__device__ __forceinline__ void xyzz29_add_quad(xyzz29& acc, const xyzz29& q, uint32_t role) {
+  typedef Fq29 P;
+  if (xyzz29_is_identity(q)) return;
+  if (xyzz29_is_identity(acc)) {
+    acc = q;
+    return;
+  }
+  // round 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+  f29 m = f29_mul<P>(quad_sel(role, acc.x, q.x, acc.y, q.y), quad_sel(role, q.zz, acc.zz, q.zzz, acc.zzz));
+  const f29 u1 = quad_bcast<0>(m), u2 = quad_bcast<1>(m), s1 = quad_bcast<2>(m), s2 = quad_bcast<3>(m);
+  const f29 p = f29_sub<P, 0>(u2, u1);                         // < 4
+  const f29 r = f29_sub<P, 0>(s2, s1);                         // < 4
+  if (f29_is_zero_mod_p<P>(p)) {
+    if (f29_is_zero_mod_p<P>(r)) acc = xyzz29_double(acc);
+    else acc = xyzz29_identity();
+    return;
+  }
+  // round 2: PP = P^2 | RR = R^2 | ZZ12 = ZZ1 ZZ2 | ZZZ12 = ZZZ1 ZZZ2
+  m = f29_mul<P>(quad_sel(role, p, r, acc.zz, acc.zzz), quad_sel(role, p, r, q.zz, q.zzz));   // 16, 16, 4, 4
+  const f29 pp = quad_bcast<0>(m), rr = quad_bcast<1>(m);
+  // round 3: PPP = P PP | Q = U1 PP | ZZ3 = ZZ12 PP | V = ZZZ12 P      (lanes 2, 3 reuse their own m)
+  m = f29_mul<P>(quad_sel(role, p, u1, m, m), quad_sel(role, pp, pp, pp, p));                  // 8, 4, 4, 8
+  const f29 ppp = quad_bcast<0>(m), qq = quad_bcast<1>(m), zz3 = quad_bcast<2>(m);
+  const f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq));                           // < 8
+  const f29 t = f29_sub<P, 2>(qq, x3);                                                         // < 10
+  // round 4: R T | S1 PPP | (idle: repeats lane 1) | ZZZ3 = V PP
+  m = f29_mul<P>(quad_sel(role, r, s1, s1, m), quad_sel(role, t, ppp, ppp, pp));               // 40, 4, 4, 4
+  acc.y = f29_sub<P, 0>(quad_bcast<0>(m), quad_bcast<1>(m));                                   // < 4
+  acc.zzz = quad_bcast<3>(m);
+  acc.zz = zz3;
+  acc.x = x3;
+}
 }  // namespace sg
 #endif

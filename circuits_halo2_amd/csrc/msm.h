@@ -19,6 +19,7 @@ struct MsmConfig {
   uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
   uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
+  uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
 
 struct MsmTimings {
@@ -52,6 +53,20 @@ struct WindowPlan {  // per-window digit widths (see msm_digits)
   uint8_t width[64];
 };
 
+WindowPlan make_window_plan(uint32_t c);
+
+// Fixed-base mode (resident SRS): row w of `table` holds 2^(bit offset of window w) * P_i, so the W
+// digits of a scalar are W independent (digit, point) pairs of ONE bucket set: W - 1 of the W
+// bucket reductions disappear and the window can be as wide as the sort allows.
+struct FixedTable {
+  g1_affine_mem* table = nullptr;  // W x n affine points, row major
+  size_t n = 0;
+  uint32_t c = 0;
+  WindowPlan wp{};
+};
+uint32_t fixed_window_bits_for(size_t n);
+hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c, FixedTable* out, hipStream_t stream);
+
 static constexpr size_t MAX_FUSED = 32;
 struct BatchPtrs {  // inputs of a fused batch (kernel argument)
   const fp_words* scalars[MAX_FUSED];
@@ -80,6 +95,10 @@ class MsmEngine {
   hipError_t enqueue_front_fused(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases, size_t M,
                                  size_t n, hipStream_t stream, uint8_t* out_affine, MsmTimings* tm);
   size_t max_fused(size_t n) const;
+  // the same over a precomputed window table (n <= tab.n): all M MSMs use the table's bases
+  hipError_t enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
+                                 hipStream_t stream, uint8_t* out_affine, MsmTimings* tm);
+  size_t max_fused_fixed(const FixedTable& tab, size_t n) const;
   hipError_t enqueue_back();
   hipError_t finish();
 
@@ -91,12 +110,14 @@ class MsmEngine {
     hipStream_t stream = nullptr;
     uint8_t* out = nullptr;
     MsmTimings* tm = nullptr;
-    bool trivial = false, all_zero = false;
+    bool trivial = false, all_zero = false, fixed = false;
+    uint32_t n_tab = 0;
     uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0;
     WindowPlan wp{};
     hipEvent_t ev[5];
   };
   Job job_;
+  const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs
   hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
   hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;

@@ -110,20 +110,35 @@ __global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig
   uint32_t* out = hist + ((size_t)j * P + p) * nbw;
   for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) out[b] = s_cnt[b];
 }
-// per bucket: exclusive prefix over the P chunks (in place) and the bucket total
-__global__ void msm_hist_prefix(uint32_t* __restrict__ hist, uint32_t P, uint32_t nbw, uint32_t NB,
-                                uint32_t* __restrict__ counts) {
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // global bucket id = j*nbw + b
-  if (g >= NB) return;
-  uint32_t j = g / nbw, b = g - j * nbw;
+// per bucket: exclusive prefix over the P chunks (in place) and the bucket total.  Block of
+// 32 buckets x 8 chunk groups: every thread sums its group's share of the column, the group
+// bases come from LDS, then a second sweep writes the prefixes (a column is P strided loads;
+// one thread per bucket made this the slowest kernel of a small MSM).
+static constexpr uint32_t HP_BUCKETS = 32, HP_GROUPS = 8;
+__global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hist, uint32_t P, uint32_t nbw, uint32_t NB,
+                                                       uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_sum[HP_GROUPS][HP_BUCKETS];
+  const uint32_t bx = threadIdx.x % HP_BUCKETS, gy = threadIdx.x / HP_BUCKETS;
+  const uint32_t g = blockIdx.x * HP_BUCKETS + bx;  // global bucket id = j*nbw + b
+  const bool live = g < NB;
+  const uint32_t j = live ? g / nbw : 0, b = live ? g - j * nbw : 0;
   uint32_t* col = hist + (size_t)j * P * nbw + b;
+  const uint32_t per = (P + HP_GROUPS - 1) / HP_GROUPS;
+  const uint32_t lo = min(gy * per, P), hi = min(lo + per, P);
+  uint32_t sum = 0;
+  if (live)
+    for (uint32_t p = lo; p < hi; p++) sum += col[(size_t)p * nbw];
+  s_sum[gy][bx] = sum;
+  __syncthreads();
   uint32_t run = 0;
-  for (uint32_t p = 0; p < P; p++) {
+  for (uint32_t q = 0; q < gy; q++) run += s_sum[q][bx];
+  if (!live) return;
+  for (uint32_t p = lo; p < hi; p++) {
     uint32_t v = col[(size_t)p * nbw];
     col[(size_t)p * nbw] = run;
     run += v;
   }
-  counts[g] = run;
+  if (gy == HP_GROUPS - 1) counts[g] = run;
 }
 
 // ------------------------------------------------------------------ 3: scans (multi-block)
@@ -229,11 +244,15 @@ __global__ void __launch_bounds__(256) msm_scan_write(const uint32_t* __restrict
 // of the chunk takes the next slot of its bucket with an LDS atomic.
 __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ dig, uint32_t n, uint32_t chunk,
                                                     uint32_t nbw, const uint32_t* __restrict__ hist,
-                                                    const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+                                                    const uint32_t* __restrict__ off, uint32_t collapse_W,
+                                                    uint32_t n_tab, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t s_cur[];
   const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
   const uint32_t* pre = hist + ((size_t)j * P + p) * nbw;
-  const uint32_t* ob = off + (size_t)j * nbw;
+  // fixed-base mode (collapse_W = windows per MSM): the W windows of an MSM share ONE bucket set and an
+  // entry names row (window, i) of the precomputed table  2^offset_w * P_i
+  const uint32_t* ob = off + (size_t)(collapse_W ? j / collapse_W : j) * nbw;
+  const uint32_t base_idx = collapse_W ? (j % collapse_W) * n_tab : 0u;
   for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cur[b] = ob[b] + pre[b];
   __syncthreads();
   const uint32_t lo = p * chunk, hi = min(n, lo + chunk);
@@ -242,7 +261,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
     int32_t d = row[i];
     if (d) {
       uint32_t pos = atomicAdd(&s_cur[(d < 0 ? -d : d) - 1], 1u);
-      sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+      sorted[pos] = (base_idx + i) | (d < 0 ? 0x80000000u : 0u);
     }
   }
 }
@@ -261,7 +280,13 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff
 // wave run the same number of additions (bucket sizes are Poisson-distributed: without this
 // a wave waits for its largest bucket, ~30 % of the lanes' time idle).
 static constexpr uint32_t TASK_BINS = 257;        // task length clamped to 256
-static constexpr uint32_t TASK_BLOCK = 8192;      // buckets per workgroup in the ordering passes
+// buckets per workgroup in the ordering passes: ~128 workgroups, 256 .. 8192 buckets each
+static inline uint32_t task_block_for(uint32_t NB, uint32_t nbins) {
+  const uint32_t max_blk = std::min<uint32_t>(128, (32 * 1024) / nbins);  // msm_task_scan: nbins * nblk <= 32 Ki
+  uint32_t tb = 256;
+  while ((NB + tb - 1) / tb > max_blk) tb <<= 1;
+  return tb;
+}
 
 __device__ __forceinline__ uint32_t task_len(uint32_t cnt, uint32_t seg, uint32_t log_L) {
   uint32_t rem = cnt - (seg << log_L);
@@ -270,71 +295,85 @@ __device__ __forceinline__ uint32_t task_len(uint32_t cnt, uint32_t seg, uint32_
 // thist[bin * nblk + blk] = number of tasks of (clamped) length `bin` in block blk
 __global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict__ cnt,
                                                      const uint32_t* __restrict__ ntask, uint32_t NB,
-                                                     uint32_t log_L, uint32_t* __restrict__ thist) {
+                                                     uint32_t log_L, uint32_t task_block,
+                                                     uint32_t* __restrict__ thist) {
   __shared__ uint32_t s_h[TASK_BINS];
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_h[k] = 0;
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < TASK_BLOCK; q += blockDim.x) {
-    uint32_t b = blockIdx.x * TASK_BLOCK + q;
+  const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1);
+  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+    uint32_t b = blockIdx.x * task_block + q;
     if (b < NB) {
-      uint32_t nt = ntask[b], cv = cnt[b];
-      for (uint32_t seg = 0; seg < nt; seg++) atomicAdd(&s_h[min(task_len(cv, seg, log_L), TASK_BINS - 1)], 1u);
+      // a bucket is nfull tasks of exactly L entries plus at most one shorter task
+      uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
+      if (nfull) atomicAdd(&s_h[full_bin], nfull);
+      if (rem) atomicAdd(&s_h[min(rem, TASK_BINS - 1)], 1u);
     }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) thist[k * gridDim.x + blockIdx.x] = s_h[k];
 }
-// one workgroup: exclusive scan of thist in DESCENDING bin order (bin-major, block-minor)
-__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk) {
+// one workgroup: exclusive scan of thist in DESCENDING bin order (bin-major, block-minor) over the
+// nbins = L + 1 bins in use; total = nbins * nblk <= TASK_SCAN_MAX entries, a fixed number per
+// thread so that all loads of a thread are in flight together
+static constexpr uint32_t TASK_SCAN_PER = 32;  // x 1024 threads = 32 Ki entries at most
+__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk, uint32_t nbins) {
   __shared__ uint32_t s_sum[1024];
-  const uint32_t total = TASK_BINS * nblk, tid = threadIdx.x;
-  const uint32_t per = (total + 1023) / 1024;
-  const uint32_t lo = min(tid * per, total), hi = min(lo + per, total);
-  // position q in scan order <-> entry (TASK_BINS-1 - q / nblk) * nblk + q % nblk; each thread
-  // walks its run incrementally (one division, then wrap-around counters)
-  uint32_t a = 0;
+  const uint32_t total = nbins * nblk, tid = threadIdx.x;
+  const uint32_t per = (total + 1023) / 1024;  // <= TASK_SCAN_PER
+  const uint32_t lo = min(tid * per, total);
+  // position q in scan order <-> entry (nbins-1 - q / nblk) * nblk + q % nblk
+  uint32_t v[TASK_SCAN_PER], idx[TASK_SCAN_PER];
   {
     uint32_t row = lo / nblk, col = lo - row * nblk;
-    for (uint32_t q = lo; q < hi; q++) {
-      a += thist[(TASK_BINS - 1 - row) * nblk + col];
+#pragma unroll
+    for (uint32_t k = 0; k < TASK_SCAN_PER; k++) {
+      const bool live = k < per && lo + k < total;
+      idx[k] = live ? (nbins - 1 - row) * nblk + col : 0xffffffffu;
       if (++col == nblk) { col = 0; row++; }
     }
   }
+  uint32_t a = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) v[k] = idx[k] != 0xffffffffu ? thist[idx[k]] : 0u;
+#pragma unroll
+  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) a += v[k];
   s_sum[tid] = a;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t v = tid >= d ? s_sum[tid - d] : 0;
+    uint32_t u = tid >= d ? s_sum[tid - d] : 0;
     __syncthreads();
-    s_sum[tid] += v;
+    s_sum[tid] += u;
     __syncthreads();
   }
   uint32_t run = s_sum[tid] - a;
-  {
-    uint32_t row = lo / nblk, col = lo - row * nblk;
-    for (uint32_t q = lo; q < hi; q++) {
-      uint32_t idx = (TASK_BINS - 1 - row) * nblk + col;
-      uint32_t v = thist[idx];
-      thist[idx] = run;
-      run += v;
-      if (++col == nblk) { col = 0; row++; }
-    }
+#pragma unroll
+  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) {
+    if (idx[k] != 0xffffffffu) thist[idx[k]] = run;
+    run += v[k];
   }
 }
 // order[pos] = (bucket, segment) of the task that runs as thread `pos`
 __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restrict__ cnt,
                                                         const uint32_t* __restrict__ ntask, uint32_t NB,
-                                                        uint32_t log_L, const uint32_t* __restrict__ thist,
+                                                        uint32_t log_L, uint32_t task_block,
+                                                        const uint32_t* __restrict__ thist,
                                                         uint2* __restrict__ order) {
   __shared__ uint32_t s_c[TASK_BINS];
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = thist[k * gridDim.x + blockIdx.x];
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < TASK_BLOCK; q += blockDim.x) {
-    uint32_t b = blockIdx.x * TASK_BLOCK + q;
+  const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1);
+  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+    uint32_t b = blockIdx.x * task_block + q;
     if (b < NB) {
-      uint32_t nt = ntask[b], cv = cnt[b];
-      for (uint32_t seg = 0; seg < nt; seg++) {
-        uint32_t pos = atomicAdd(&s_c[min(task_len(cv, seg, log_L), TASK_BINS - 1)], 1u);
-        order[pos] = make_uint2(b, seg);
+      uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
+      if (nfull) {
+        uint32_t pos = atomicAdd(&s_c[full_bin], nfull);
+        for (uint32_t seg = 0; seg < nfull; seg++) order[pos + seg] = make_uint2(b, seg);
+      }
+      if (rem) {
+        uint32_t pos = atomicAdd(&s_c[min(rem, TASK_BINS - 1)], 1u);
+        order[pos] = make_uint2(b, nfull);
       }
     }
   }
@@ -373,19 +412,29 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
   xyzz29_store(partial + toff[b] + seg, acc);
 }
 
+// Every kernel below is written for LOGICAL threads of Q lanes: Q = 1 is one lane per point
+// operation, Q = 4 the quad-cooperative addition (xyzz29_add_quad; all 4 lanes hold the same
+// values).  lt = logical thread, role = lane within the quad.
+template <int Q>
+__device__ __forceinline__ void add_q(xyzz29& acc, const xyzz29& q, uint32_t role) {
+  if (Q == 4) xyzz29_add_quad(acc, q, role);
+  else xyzz29_add(acc, q);
+}
+template <int Q>
 __global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ in, const uint32_t* __restrict__ off,
                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
-                                                 uint32_t NB, uint32_t log_L, uint32_t ntasks,
+                                                 uint32_t NB, uint32_t log_L, const uint32_t* __restrict__ meta,
                                                  xyzz29_mem* __restrict__ out) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntasks) return;
+  // the grid covers a host-side upper bound; the exact task count of this level is meta[1]
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Q, role = threadIdx.x % Q;
+  if (t >= meta[1]) return;
   uint32_t b = find_owner(toff, NB, t);
   uint32_t seg = t - toff[b];
   uint32_t start = off[b] + (seg << log_L);
   uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
   xyzz29 acc = xyzz29_identity();
-  for (uint32_t k = start; k < end; k++) xyzz29_add(acc, xyzz29_load(in + k));
-  xyzz29_store(out + t, acc);
+  for (uint32_t k = start; k < end; k++) add_q<Q>(acc, xyzz29_load(in + k), role);
+  if (role == 0) xyzz29_store(out + t, acc);
 }
 
 // ------------------------------------------------------------------ 5: bucket reduction
@@ -404,100 +453,113 @@ struct ReduceOut {
   xyzz29_mem* s;
   xyzz29_mem* r;
 };
-// tree-sum of arr[0..len) (len a power of two) by threads li = 0..len/2-1 of a group;
+// tree-sum of arr[0..len) (len a power of two) by logical threads li = 0..len/2-1 of a group;
 // every thread of the workgroup must call it (barriers inside)
-__device__ __forceinline__ void tree_sum(xyzz29_mem* arr, uint32_t len, uint32_t li, bool member) {
+template <int Q>
+__device__ __forceinline__ void tree_sum(xyzz29_mem* arr, uint32_t len, uint32_t li, uint32_t role, bool member) {
   for (uint32_t s = len >> 1; s >= 1; s >>= 1) {
     if (member && li < s) {
       xyzz29 a = xyzz29_load(&arr[li]);
-      xyzz29_add(a, xyzz29_load(&arr[li + s]));
-      xyzz29_store(&arr[li], a);
+      add_q<Q>(a, xyzz29_load(&arr[li + s]), role);
+      if (role == 0) xyzz29_store(&arr[li], a);
     }
     __syncthreads();
   }
 }
-// in-place suffix scan of arr[0..N) by N threads (Hillis-Steele)
-__device__ __forceinline__ xyzz29 suffix_scan(xyzz29_mem* arr, xyzz29 mine, uint32_t N, uint32_t tid) {
-  xyzz29_store(&arr[tid], mine);
+// in-place suffix scan of arr[0..N) by N logical threads (Hillis-Steele)
+template <int Q>
+__device__ __forceinline__ xyzz29 suffix_scan(xyzz29_mem* arr, xyzz29 mine, uint32_t N, uint32_t lt, uint32_t role) {
+  if (role == 0) xyzz29_store(&arr[lt], mine);
   __syncthreads();
   for (uint32_t d = 1; d < N; d <<= 1) {
     xyzz29 other = xyzz29_identity();
-    if (tid + d < N) other = xyzz29_load(&arr[tid + d]);
+    if (lt + d < N) other = xyzz29_load(&arr[lt + d]);
     __syncthreads();
-    xyzz29_add(mine, other);
-    xyzz29_store(&arr[tid], mine);
+    add_q<Q>(mine, other, role);
+    if (role == 0) xyzz29_store(&arr[lt], mine);
     __syncthreads();
   }
   return mine;
 }
 
-// level 0: grid (blocks, W), N = blockDim.x threads (power of two >= 64)
+// level 0: grid (blocks, W), N = blockDim.x / Q logical threads (power of two >= 16)
+template <int Q>
 __global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __restrict__ partial,
                                                           const uint32_t* __restrict__ toff,
                                                           const uint32_t* __restrict__ ntask, uint32_t nbw,
                                                           uint32_t log_G, ReduceOut out) {
   extern __shared__ uint4 smem[];
+  const uint32_t N = blockDim.x / Q, lt = threadIdx.x / Q, role = threadIdx.x % Q;
   xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
-  xyzz29_mem* sR = sA + blockDim.x;
-  const uint32_t tid = threadIdx.x, N = blockDim.x;
-  const uint32_t chunk = blockIdx.x * N + tid;
+  xyzz29_mem* sR = sA + N;
+  const uint32_t chunk = blockIdx.x * N + lt;
   const uint32_t G = 1u << log_G;
   xyzz29 acc = xyzz29_identity(), run = xyzz29_identity();
   const uint32_t first = chunk << log_G;
   if (first < nbw) {
     const uint32_t wbase = blockIdx.y * nbw;
+    auto fetch = [&](uint32_t k) {
+      const uint32_t b = first + k;
+      return (b < nbw && ntask[wbase + b]) ? xyzz29_load(partial + toff[wbase + b]) : xyzz29_identity();
+    };
+    xyzz29 nxt = fetch(G - 1);
     for (uint32_t k = G; k-- > 0;) {
-      uint32_t b = first + k;
-      if (b < nbw && ntask[wbase + b]) xyzz29_add(run, xyzz29_load(partial + toff[wbase + b]));
-      xyzz29_add(acc, run);
+      const xyzz29 cur = nxt;
+      if (k) nxt = fetch(k - 1);  // in flight while the two additions below run
+      add_q<Q>(run, cur, role);
+      add_q<Q>(acc, run, role);
     }
   }
   const uint32_t o = blockIdx.y * gridDim.x + blockIdx.x;
-  xyzz29_store(&sA[tid], acc);
-  suffix_scan(sR, run, N, tid);            // sR[t] = Suf_t
-  if (tid == 0) {
+  if (role == 0) xyzz29_store(&sA[lt], acc);
+  suffix_scan<Q>(sR, run, N, lt, role);            // sR[t] = Suf_t
+  if (threadIdx.x == 0) {
     xyzz29_store(out.r + o, xyzz29_load(&sR[0]));
     xyzz29_store(&sR[0], xyzz29_identity());  // S sums t >= 1 only
   }
   __syncthreads();
-  // two tree sums side by side: lower half of the threads folds sA, upper half sR
+  // two tree sums side by side: lower half of the logical threads folds sA, upper half sR
   const uint32_t halfN = N >> 1;
-  xyzz29_mem* arr = (tid < halfN) ? sA : sR;
-  tree_sum(arr, N, (tid < halfN) ? tid : tid - halfN, true);
-  if (tid == 0) xyzz29_store(out.a + o, xyzz29_load(&sA[0]));
-  if (tid == halfN) xyzz29_store(out.s + o, xyzz29_load(&sR[0]));
+  xyzz29_mem* arr = (lt < halfN) ? sA : sR;
+  tree_sum<Q>(arr, N, (lt < halfN) ? lt : lt - halfN, role, true);
+  if (threadIdx.x == 0) xyzz29_store(out.a + o, xyzz29_load(&sA[0]));
+  if (lt == halfN && role == 0) xyzz29_store(out.s + o, xyzz29_load(&sR[0]));
 }
-// level 1: grid (1, W), blockDim = 3 * T1 (T1 a power of two >= count): group 0 scans/folds
+// level 1: grid (1, W), blockDim = 3 * T1 * Q (T1 a power of two >= count): group 0 scans/folds
 // the R items, group 1 folds A, group 2 folds S
+template <int Q>
 __global__ void __launch_bounds__(768) msm_reduce_items(ReduceOut in, uint32_t count, uint32_t T1, ReduceOut out) {
   extern __shared__ uint4 smem[];
   xyzz29_mem* sR = reinterpret_cast<xyzz29_mem*>(smem);
   xyzz29_mem* sA = sR + T1;
   xyzz29_mem* sS = sA + T1;
-  const uint32_t g = threadIdx.x / T1, li = threadIdx.x - g * T1;
+  const uint32_t lt = threadIdx.x / Q, role = threadIdx.x % Q;
+  const uint32_t g = lt / T1, li = lt - g * T1;
   const uint32_t base = blockIdx.y * count;
   xyzz29 v = xyzz29_identity();
   if (li < count) v = xyzz29_load((g == 0 ? in.r : g == 1 ? in.a : in.s) + base + li);
-  if (g == 1) xyzz29_store(&sA[li], v);
-  if (g == 2) xyzz29_store(&sS[li], v);
-  // suffix scan of R (group 0 works, everyone keeps the barriers)
-  if (g == 0) xyzz29_store(&sR[li], v);
+  if (role == 0) {
+    if (g == 1) xyzz29_store(&sA[li], v);
+    if (g == 2) xyzz29_store(&sS[li], v);
+    // suffix scan of R (group 0 works, everyone keeps the barriers)
+    if (g == 0) xyzz29_store(&sR[li], v);
+  }
   __syncthreads();
   for (uint32_t d = 1; d < T1; d <<= 1) {
     xyzz29 other = xyzz29_identity();
     if (g == 0 && li + d < T1) other = xyzz29_load(&sR[li + d]);
     __syncthreads();
     if (g == 0) {
-      xyzz29_add(v, other);
-      xyzz29_store(&sR[li], v);
+      add_q<Q>(v, other, role);
+      if (role == 0) xyzz29_store(&sR[li], v);
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) xyzz29_store(&sR[0], xyzz29_identity());  // T sums w >= 1 only
   __syncthreads();
   xyzz29_mem* arr = g == 0 ? sR : g == 1 ? sA : sS;
-  tree_sum(arr, T1, li, true);
-  if (li == 0) xyzz29_store((g == 0 ? out.r : g == 1 ? out.a : out.s) + blockIdx.y, xyzz29_load(&arr[0]));
+  tree_sum<Q>(arr, T1, li, role, true);
+  if (li == 0 && role == 0) xyzz29_store((g == 0 ? out.r : g == 1 ? out.a : out.s) + blockIdx.y, xyzz29_load(&arr[0]));
 }
 // per-window (A, S, T) -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ each) for the
 // host tail; out[(3*j + which)*32 ..]
@@ -650,6 +712,37 @@ hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ fixed-base window table
+// next[i] = 2^doublings * prev[i], affine (one inversion per point: this runs once per SRS)
+__global__ void __launch_bounds__(128) msm_table_step(const g1_affine_mem* __restrict__ prev, uint32_t n,
+                                                      uint32_t doublings, g1_affine_mem* __restrict__ next) {
+  typedef Fq29 P;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_affine_mem raw = prev[i];
+  uint32_t ow[16];
+  bool ident = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) ident = ident && !(raw.q[k].x | raw.q[k].y | raw.q[k].z | raw.q[k].w);
+  if (ident || doublings == 0) {
+    next[i] = raw;
+    return;
+  }
+  affine29 q = affine29_load(&raw);
+  xyzz29 acc = xyzz29_double_affine(q);
+  for (uint32_t d = 1; d < doublings; d++) acc = xyzz29_double(acc);
+  if (xyzz29_is_identity(acc)) {
+    for (int k = 0; k < 16; k++) ow[k] = 0;
+  } else {
+    f29 iz = f29_inv<P>(acc.zzz);
+    f29 t = f29_mul<P>(acc.zz, iz);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(acc.x, f29_sqr<P>(t)), P::r256), ow);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(acc.y, iz), P::r256), ow + 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) next[i].q[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
+}
+
 // ------------------------------------------------------------------ host driver
 #define SG_TRY(x)                      \
   do {                                 \
@@ -687,9 +780,9 @@ uint32_t MsmEngine::window_bits_for(size_t n, bool fused) const {
 }
 
 hipError_t MsmEngine::init() {
-  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets),
+  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets<1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items),
+  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items<1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                              128 * 1024));
@@ -722,6 +815,62 @@ size_t MsmEngine::max_fused(size_t n) const {
   return std::max<size_t>(1, std::min<size_t>(std::min(by_buckets, by_entries), MAX_FUSED));
 }
 
+// window widths: W-1 signed windows + an unsigned top window, 254 bits in total
+WindowPlan make_window_plan(uint32_t c) {
+  WindowPlan wp{};
+  const uint32_t W1 = wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
+  for (uint32_t q = 0; q + 1 < W1; q++) wp.width[q] = (uint8_t)c;
+  wp.width[W1 - 1] = (uint8_t)(c - 1);
+  for (uint32_t k = 0, slack = W1 * c - 255; k < slack; k++) wp.width[W1 - 2 - k] -= 1;
+  return wp;
+}
+
+uint32_t fixed_window_bits_for(size_t n) {
+  uint32_t lg = 0;
+  while (((size_t)1 << (lg + 1)) <= n) lg++;
+  return std::min<uint32_t>(16, std::max<uint32_t>(4, lg + 2));
+}
+
+// table rows: row w = 2^(offset of window w) * bases, W x n affine points
+hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c, FixedTable* out, hipStream_t stream) {
+  if (n == 0 || n >= (1ull << 31) || c < 4 || c > 16) return hipErrorInvalidValue;
+  FixedTable t;
+  t.c = c;
+  t.n = n;
+  t.wp = make_window_plan(c);
+  if ((size_t)t.wp.W * n >= (1ull << 31)) return hipErrorInvalidValue;
+  SG_TRY(hipMalloc(&t.table, sizeof(g1_affine_mem) * n * t.wp.W));
+  hipError_t e = hipMemcpyAsync(t.table, d_bases, sizeof(g1_affine_mem) * n, hipMemcpyDeviceToDevice, stream);
+  for (uint32_t w = 1; w < t.wp.W && e == hipSuccess; w++) {
+    msm_table_step<<<(unsigned)((n + 127) / 128), 128, 0, stream>>>(t.table + (size_t)(w - 1) * n, (uint32_t)n,
+                                                                    t.wp.width[w - 1], t.table + (size_t)w * n);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(t.table);
+    return e;
+  }
+  *out = t;
+  return hipSuccess;
+}
+
+hipError_t MsmEngine::enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
+                                          hipStream_t stream, uint8_t* out_affine, MsmTimings* tm) {
+  if (n > tab.n || !tab.table) return hipErrorInvalidValue;
+  const g1_affine_mem* bs[MAX_FUSED];
+  for (size_t m = 0; m < M && m < MAX_FUSED; m++) bs[m] = tab.table;
+  fixed_ = &tab;
+  hipError_t e = enqueue_front_fused(d_scalars, bs, M, n, stream, out_affine, tm);
+  fixed_ = nullptr;
+  return e;
+}
+size_t MsmEngine::max_fused_fixed(const FixedTable& tab, size_t n) const {
+  if (n == 0) return MAX_FUSED;
+  const size_t by_buckets = ((size_t)1 << 21) >> (tab.c - 1);
+  const size_t by_entries = ((size_t)1 << cfg_.log_fuse_entries) / std::max<size_t>(1, (size_t)tab.wp.W * n);
+  return std::max<size_t>(1, std::min<size_t>(std::min(by_buckets, by_entries), MAX_FUSED));
+}
+
 hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n,
                                     hipStream_t stream, uint8_t* out_affine, MsmTimings* tm) {
   const fp_words* sc[1] = {d_scalars};
@@ -747,17 +896,17 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     j.bp.scalars[m] = d_scalars[m];
     j.bp.bases[m] = d_bases[m];
   }
-  const uint32_t c = j.c = window_bits_for(n, M > 1);
-  const uint32_t W1 = j.wp.W = (255 + c - 1) / c;  // W*c >= 255: the top window never carries out
-  const uint32_t W = W1 * (uint32_t)M;             // windows of the whole fused job
+  // fixed-base mode: the job's windows all land in one bucket set per MSM (see msm_scatter)
+  j.fixed = fixed_ != nullptr;
+  j.n_tab = j.fixed ? (uint32_t)fixed_->n : 0;
+  const uint32_t c = j.c = j.fixed ? fixed_->c : window_bits_for(n, M > 1);
+  j.wp = j.fixed ? fixed_->wp : make_window_plan(c);
+  const uint32_t W1 = j.wp.W;
+  const uint32_t W = W1 * (uint32_t)M;             // digit rows of the whole fused job
   const uint32_t nbw = j.nbw = 1u << (c - 1);
-  const uint32_t NB = j.NB = W * nbw;
+  const uint32_t NB = j.NB = (j.fixed ? (uint32_t)M : W) * nbw;
   if (NB > (1u << 21)) return hipErrorInvalidValue;
   const size_t entries = (size_t)W * n;
-  // window widths: W-1 signed windows + an unsigned top window, 254 bits in total
-  for (uint32_t q = 0; q + 1 < W1; q++) j.wp.width[q] = (uint8_t)c;
-  j.wp.width[W1 - 1] = (uint8_t)(c - 1);
-  for (uint32_t k = 0, slack = W1 * c - 255; k < slack; k++) j.wp.width[W1 - 2 - k] -= 1;
   // task length: deep enough to amortise, shallow enough that the longest dependent chain of
   // additions stays a small multiple of the per-lane share of the work
   j.log_L = cfg_.log_seg;
@@ -802,12 +951,13 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   msm_digits<<<dim3((unsigned)((n + 255) / 256), (unsigned)M), 256, 0, stream>>>(j.bp, (uint32_t)n, j.wp, dig_.p);
   if (tm) SG_TRY(hipEventRecord(j.ev[1], stream));
   msm_hist<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p);
-  msm_hist_prefix<<<(NB + 255) / 256, 256, 0, stream>>>(hist_.p, P, nbw, NB, counts_.p);
+  msm_hist_prefix<<<(NB + HP_BUCKETS - 1) / HP_BUCKETS, HP_BUCKETS * HP_GROUPS, 0, stream>>>(
+      hist_.p, j.fixed ? W1 * P : P, nbw, NB, counts_.p);
   SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
   SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   SG_TRY(hipEventRecord(ev_meta_, stream));
   msm_scatter<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
-                                                                    sorted_.p);
+                                                                    j.fixed ? W1 : 0u, j.n_tab, sorted_.p);
   if (tm) SG_TRY(hipEventRecord(j.ev[2], stream));
   return hipGetLastError();
 }
@@ -823,32 +973,42 @@ hipError_t MsmEngine::enqueue_back() {
     j.all_zero = true;
     return hipSuccess;
   }
-  const uint32_t NB = j.NB, W = j.wp.W * j.M, nbw = j.nbw, log_L = j.log_L;
+  const uint32_t Wm = j.fixed ? 1u : j.wp.W;  // bucket sets ("windows") per MSM
+  const uint32_t NB = j.NB, W = Wm * j.M, nbw = j.nbw, log_L = j.log_L;
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
   SG_TRY(partial_[0].reserve(ntasks));
   {
-    const uint32_t tblk = (NB + TASK_BLOCK - 1) / TASK_BLOCK;
+    const uint32_t nbins = std::min<uint32_t>(1u << log_L, TASK_BINS - 1) + 1;  // task lengths 0 .. L
+    const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
     SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
     SG_TRY(order_.reserve(ntasks));
-    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p);
-    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk);
-    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, thist_.p, order_.p);
+    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, tb, thist_.p);
+    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins);
+    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, tb, thist_.p, order_.p);
   }
-  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bp, j.wp.W * nbw, off_.p, counts_.p,
+  msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
                                                            toff_[0].p, order_.p, log_L, ntasks, partial_[0].p);
   const xyzz29_mem* cur = partial_[0].p;
+  // quad-cooperative additions pay off while the reduction is a latency chain (few buckets in total);
+  // with many windows it is throughput-bound and one lane per addition is the efficient shape
+  const bool quad = cfg_.quad == 2 || (cfg_.quad == 1 && NB <= (1u << 17));
   int lvl = 0, pbuf = 0;
+  uint32_t items_ub = ntasks;  // upper bound of the number of partial sums alive at this level
   // heavy buckets: fold their partial sums until every bucket owns at most one
   for (uint32_t max_items = (max_cnt + (1u << log_L) - 1) >> log_L; max_items > 1;
        max_items = (max_items + (1u << log_L) - 1) >> log_L) {
     const int nxt = 1 - lvl;
     SG_TRY(launch_scan(ntask_[lvl].p, NB, log_L, nullptr, ntask_[nxt].p, toff_[nxt].p, bsum_.p, meta_.p, stream));
-    SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    SG_TRY(hipStreamSynchronize(stream));
-    const uint32_t nt2 = h_meta_[1];
+    // no host round trip: sum_b ceil(t_b / L) <= (#non-empty buckets) + items / L
+    const uint32_t nt2 = std::min(NB, items_ub) + (items_ub >> log_L);
+    items_ub = nt2;
     SG_TRY(partial_[1 - pbuf].reserve(nt2));
-    msm_merge<<<(nt2 + 255) / 256, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, toff_[nxt].p, NB, log_L, nt2,
-                                                     partial_[1 - pbuf].p);
+    if (quad)
+      msm_merge<4><<<(nt2 + 63) / 64, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, toff_[nxt].p, NB, log_L, meta_.p,
+                                                        partial_[1 - pbuf].p);
+    else
+      msm_merge<1><<<(nt2 + 255) / 256, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, toff_[nxt].p, NB, log_L, meta_.p,
+                                                          partial_[1 - pbuf].p);
     pbuf = 1 - pbuf;
     cur = partial_[pbuf].p;
     lvl = nxt;
@@ -863,13 +1023,18 @@ hipError_t MsmEngine::enqueue_back() {
     stream = tail_stream_;
   }
 
-  // bucket reduction: level 0 over the buckets, level 1 over the workgroup items
-  // G buckets per thread: 8 for the largest windows, 4 below (depth vs. work, measured)
+  // bucket reduction: level 0 over the buckets, level 1 over the workgroup items.  Both are chains of
+  // dependent point additions with most of the chip idle, so by default a point addition is spread
+  // over the 4 lanes of a quad (cfg.quad; see `quad` above): 64 logical threads per workgroup.
+  const uint32_t max_threads = quad ? 64u : cfg_.red_threads;       // logical threads per workgroup
+  const uint32_t max_blocks = quad ? 64u : 256u;                    // level 1 holds 3 * T1 * Q <= 768 lanes
+  // G buckets per logical thread: 8 for the largest windows, 4 below (depth vs. work, measured)
   j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 14) ? 3 : 2), j.c - 1);
+  while ((nbw >> j.log_G) > max_threads * max_blocks) j.log_G++;
   const uint32_t items = nbw >> j.log_G;  // chunks per window at level 0 (a power of two)
-  const uint32_t threads = std::min<uint32_t>(cfg_.red_threads, std::max<uint32_t>(64, items));
+  const uint32_t threads = std::min<uint32_t>(max_threads, std::max<uint32_t>(16, items));
   const uint32_t blocks = j.blocks = (items + threads - 1) / threads;
-  if (blocks > 256) return hipErrorInvalidValue;
+  if (blocks > max_blocks) return hipErrorInvalidValue;
   j.log_N = 0;
   while ((1u << j.log_N) < threads) j.log_N++;
   for (int i = 0; i < 2; i++) {
@@ -878,13 +1043,20 @@ hipError_t MsmEngine::enqueue_back() {
     SG_TRY(red_r_[i].reserve((size_t)W * blocks));
   }
   ReduceOut lvl0{red_a_[0].p, red_s_[0].p, red_r_[0].p}, lvl1{red_a_[1].p, red_s_[1].p, red_r_[1].p};
-  msm_reduce_buckets<<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
-      cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
+  if (quad)
+    msm_reduce_buckets<4><<<dim3(blocks, W), threads * 4, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
+        cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
+  else
+    msm_reduce_buckets<1><<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
+        cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
   ReduceOut fin = lvl0;
   if (blocks > 1) {
     uint32_t T1 = 16;
     while (T1 < blocks) T1 <<= 1;
-    msm_reduce_items<<<dim3(1, W), 3 * T1, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
+    if (quad)
+      msm_reduce_items<4><<<dim3(1, W), 3 * T1 * 4, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
+    else
+      msm_reduce_items<1><<<dim3(1, W), 3 * T1, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
     fin = lvl1;
   }
   if (j.tm) SG_TRY(hipEventRecord(j.ev[4], stream));
@@ -926,9 +1098,10 @@ hipError_t MsmEngine::finish() {
   // are placed at their bit offsets and folded by ONE double-and-add sweep from the top bit
   // (254 + log_G + log_N doublings instead of W * (width + log_G + log_N))
   uint32_t offs[64];
+  const uint32_t Wm = j.fixed ? 1u : j.wp.W;  // fixed-base: the table rows already carry the window offsets
   {
     uint32_t o = 0;
-    for (uint32_t w = 0; w < j.wp.W; w++) {
+    for (uint32_t w = 0; w < Wm; w++) {
       offs[w] = o;
       o += j.wp.width[w];
     }
@@ -939,7 +1112,7 @@ hipError_t MsmEngine::finish() {
     int next[3 * 64];
     for (auto& h : head) h = -1;
     uint32_t top = 0;
-    for (uint32_t w = 0; w < j.wp.W; w++) {
+    for (uint32_t w = 0; w < Wm; w++) {
       for (uint32_t which = 0; which < 3; which++) {
         const uint32_t bit = offs[w] + (which >= 1 ? j.log_G : 0) + (which == 2 ? j.log_N : 0);
         const int id = (int)(3 * w + which);
@@ -951,7 +1124,7 @@ hipError_t MsmEngine::finish() {
     Jac total = Jac::identity();
     for (int bit = (int)top; bit >= 0; bit--) {
       total = jac_double(total);
-      for (int id = head[bit]; id >= 0; id = next[id]) total = jac_add(total, point_at(3 * m * j.wp.W + (uint32_t)id));
+      for (int id = head[bit]; id >= 0; id = next[id]) total = jac_add(total, point_at(3 * m * Wm + (uint32_t)id));
     }
     jac_to_affine_bytes(total, j.out + 64 * m);
   }

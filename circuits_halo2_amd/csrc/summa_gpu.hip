@@ -118,6 +118,7 @@ struct Srs {
   uint32_t k;
   g1_affine_mem* g;
   g1_affine_mem* g_lagrange;
+  FixedTable tab[2];  // optional precomputed window tables (sg_srs_precompute): [0] g, [1] g_lagrange
 };
 
 struct Context {
@@ -334,13 +335,10 @@ int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t ou
 
 // A batch of independent MSMs (the commitments of one prover phase): two engines on two
 // streams, so that MSM i's latency-bound bucket reduction overlaps MSM i+1's sort/accumulate.
-int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases, const size_t* n, size_t count,
-                        void* stream, uint8_t* out_affine) {
-  if (count && (!d_scalars || !d_bases || !n || !out_affine)) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
-  for (size_t i = 0; i < count; i++) {
-    if (n[i] && (!d_scalars[i] || !d_bases[i])) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
-  }
-  LOCKED_CTX();
+// batch driver shared by sg_msm_g1_batch_dev (d_bases given) and sg_commit_batch_dev (tab given: every
+// MSM runs over the precomputed window table); caller holds the context lock
+static int msm_batch_locked(const void* const* d_scalars, const void* const* d_bases, const FixedTable* tab,
+                            const size_t* n, size_t count, void* stream, uint8_t* out_affine) {
   Context& c = *g_ctx;
   MsmEngine* eng[2] = {&c.msm, &c.msm_b};
   for (int k = 0; k < 2; k++) {
@@ -363,7 +361,7 @@ int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases
   struct Group { size_t first, count; };
   std::vector<Group> groups;
   for (size_t i = 0; i < count;) {
-    size_t lim = eng[0]->max_fused(n[i]), g = 1;
+    size_t lim = tab ? eng[0]->max_fused_fixed(*tab, n[i]) : eng[0]->max_fused(n[i]), g = 1;
     while (i + g < count && n[i + g] == n[i] && g < lim) g++;
     groups.push_back({i, g});
     i += g;
@@ -376,9 +374,13 @@ int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases
       if (e != hipSuccess) break;
     }
     const Group& g = groups[gi];
-    e = eng[k]->enqueue_front_fused(reinterpret_cast<const fp_words* const*>(d_scalars + g.first),
-                                    reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), g.count,
-                                    n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr);
+    if (tab)
+      e = eng[k]->enqueue_front_fixed(reinterpret_cast<const fp_words* const*>(d_scalars + g.first), *tab, g.count,
+                                      n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr);
+    else
+      e = eng[k]->enqueue_front_fused(reinterpret_cast<const fp_words* const*>(d_scalars + g.first),
+                                      reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), g.count,
+                                      n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr);
     if (e == hipSuccess) e = eng[k]->enqueue_back();
   }
   for (size_t gi = (groups.size() >= 2 ? groups.size() - 2 : 0); gi < groups.size() && e == hipSuccess; gi++)
@@ -388,6 +390,15 @@ int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases
     return hip_fail("msm batch", e);
   }
   return SG_OK;
+}
+int sg_msm_g1_batch_dev(const void* const* d_scalars, const void* const* d_bases, const size_t* n, size_t count,
+                        void* stream, uint8_t* out_affine) {
+  if (count && (!d_scalars || !d_bases || !n || !out_affine)) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+  for (size_t i = 0; i < count; i++) {
+    if (n[i] && (!d_scalars[i] || !d_bases[i])) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
+  }
+  LOCKED_CTX();
+  return msm_batch_locked(d_scalars, d_bases, nullptr, n, count, stream, out_affine);
 }
 int sg_msm_g1_batch(const uint8_t* const* scalars, const uint8_t* const* bases, const size_t* n, size_t count,
                     uint8_t* out_affine) {
@@ -438,7 +449,7 @@ int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint6
   if (!g || !g_lagrange || !handle_out || k > 28) return fail(SG_ERR_INVALID, "sg_srs_upload: bad argument");
   LOCKED_CTX();
   const size_t bytes = (size_t)64 << k;
-  Srs s{k, nullptr, nullptr};
+  Srs s{k, nullptr, nullptr, {}};
   hipError_t e = hipMalloc(&s.g, bytes);
   if (e == hipSuccess) e = hipMalloc(&s.g_lagrange, bytes);
   if (e == hipSuccess) e = hipMemcpy(s.g, g, bytes, hipMemcpyHostToDevice);
@@ -459,7 +470,28 @@ int sg_srs_free(uint64_t handle) {
   if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "sg_srs_free: unknown handle");
   (void)hipFree(it->second.g);
   (void)hipFree(it->second.g_lagrange);
+  for (auto& t : it->second.tab)
+    if (t.table) (void)hipFree(t.table);
   g_ctx->srs.erase(it);
+  return SG_OK;
+}
+// Precompute the fixed-base window table of one basis: W x 2^k points, row w = 2^(offset_w) * basis.
+// Later sg_commit* calls on this basis take the fixed-base path (same result bits).
+int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
+  if (basis != 0 && basis != 1) return fail(SG_ERR_INVALID, "sg_srs_precompute: bad basis");
+  if (window_bits && (window_bits < 4 || window_bits > 16)) return fail(SG_ERR_INVALID, "sg_srs_precompute: window_bits in [4, 16]");
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs& s = it->second;
+  const size_t n = (size_t)1 << s.k;
+  const uint32_t c = window_bits ? window_bits : fixed_window_bits_for(n);
+  FixedTable t;
+  hipError_t e = build_window_table(basis ? s.g_lagrange : s.g, n, c, &t, g_ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g_ctx->stream);
+  if (e != hipSuccess) return hip_fail("sg_srs_precompute", e);
+  if (s.tab[basis].table) (void)hipFree(s.tab[basis].table);
+  s.tab[basis] = t;
   return SG_OK;
 }
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k) {
@@ -471,17 +503,56 @@ int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagra
   if (k) *k = it->second.k;
   return SG_OK;
 }
-int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
-                  uint8_t out_affine[64]) {
+static hipError_t commit_run(const Srs& s, int basis, const fp_words* d_scalars, size_t n, hipStream_t stream,
+                             uint8_t out_affine[64], MsmTimings* tm = nullptr) {
+  MsmEngine& eng = g_ctx->msm;
+  if (s.tab[basis].table && n) {
+    const fp_words* sc[1] = {d_scalars};
+    hipError_t e = eng.enqueue_front_fixed(sc, s.tab[basis], 1, n, stream, out_affine, tm);
+    if (e == hipSuccess) e = eng.enqueue_back();
+    if (e == hipSuccess) e = eng.finish();
+    return e;
+  }
+  return eng.run(d_scalars, basis ? s.g_lagrange : s.g, n, stream, out_affine, tm);
+}
+int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
+                        uint8_t out_affine[64], sg_msm_timings* timings) {
   if (!out_affine || (n && !d_scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
   auto it = g_ctx->srs.find(srs_handle);
   if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
   if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
-  hipError_t e = g_ctx->msm.run(static_cast<const fp_words*>(d_scalars), basis ? it->second.g_lagrange : it->second.g, n,
-                                pick_stream(stream), out_affine, nullptr);
+  MsmTimings tm;
+  hipError_t e = commit_run(it->second, basis, static_cast<const fp_words*>(d_scalars), n, pick_stream(stream), out_affine,
+                            timings ? &tm : nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
+  if (timings) {
+    timings->digits_ms = tm.digits_ms; timings->sort_ms = tm.sort_ms; timings->accumulate_ms = tm.accumulate_ms;
+    timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
+    timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
+  }
   return SG_OK;
+}
+int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
+                  uint8_t out_affine[64]) {
+  return sg_commit_dev_timed(srs_handle, basis, d_scalars, n, stream, out_affine, nullptr);
+}
+// `count` commitments of equal length against one basis as fused jobs (the advice / quotient-piece
+// commitments of one proof phase); takes the fixed-base path when the table exists
+int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
+                        void* stream, uint8_t* out_affine) {
+  if ((count && (!d_scalars || !out_affine)) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit_batch: bad argument");
+  for (size_t i = 0; i < count; i++)
+    if (n && !d_scalars[i]) return fail(SG_ERR_INVALID, "sg_commit_batch: null argument");
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(srs_handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  const Srs& s = it->second;
+  std::vector<size_t> ns(count, n);
+  std::vector<const void*> bases(count, basis ? s.g_lagrange : s.g);
+  return msm_batch_locked(d_scalars, bases.data(), s.tab[basis].table ? &s.tab[basis] : nullptr, ns.data(), count, stream,
+                          out_affine);
 }
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && !scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
@@ -490,8 +561,8 @@ int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, 
   if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
   if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
-  hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p),
-                                basis ? it->second.g_lagrange : it->second.g, n, g_ctx->stream, out_affine, nullptr);
+  hipError_t e = commit_run(it->second, basis, reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, g_ctx->stream,
+                            out_affine);
   if (e != hipSuccess) return hip_fail("msm", e);
   return SG_OK;
 }
@@ -1069,6 +1140,7 @@ int sg_set_param(const char* name, int value) {
   else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = g_ctx->msm_b.config().log_seg = (uint32_t)std::min(12, value);
   else if (s == "msm.log_fuse_entries") { g_ctx->msm.config().log_fuse_entries = g_ctx->msm_b.config().log_fuse_entries = (uint32_t)std::max(16, std::min(30, value)); }
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; g_ctx->msm.config().red_threads = g_ctx->msm_b.config().red_threads = v; }
+  else if (s == "msm.quad") g_ctx->msm.config().quad = g_ctx->msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = g_ctx->msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
   else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
   else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));

@@ -86,6 +86,13 @@ class ParamsKZG:
             self._handle = h.value
         return self._handle
 
+    def precompute(self, basis: int | None = None, window_bits: int = 0) -> None:
+        """build the fixed-base window table(s) of the resident SRS (sg_srs_precompute): later
+        commit / commit_lagrange / commit_batch calls take the fixed-base path (same results).
+        basis: 0 = g, 1 = g_lagrange, None = both."""
+        for b in ([0, 1] if basis is None else [basis]):
+            ffi.check(ffi.lib().sg_srs_precompute(C.c_uint64(self.handle()), C.c_int(b), C.c_uint32(window_bits)))
+
     def free(self):
         if self._handle is not None:
             ffi.check(ffi.lib().sg_srs_free(C.c_uint64(self._handle)))
@@ -107,6 +114,23 @@ class ParamsKZG:
             raise ValueError("polynomial longer than the SRS")
         ffi.check(L.sg_commit(C.c_uint64(self.handle()), C.c_int(basis), ffi.ptr(s), C.c_size_t(s.size // 32),
                               ffi.ptr(out)))
+        return out
+
+    def commit_batch(self, polys, lagrange: bool = False) -> np.ndarray:
+        """commitments to several equal-length device polynomials as fused jobs -> (len, 64) uint8"""
+        m = len(polys)
+        out = np.zeros((m, 64), dtype=np.uint8)
+        if m == 0:
+            return out
+        n = polys[0].numel() // 32
+        for p in polys:
+            if not _is_torch_cuda(p) or p.numel() != 32 * n:
+                raise ValueError("commit_batch: equal-length device tensors expected")
+        if n > self.n:
+            raise ValueError("polynomial longer than the SRS")
+        ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+        ffi.check(ffi.lib().sg_commit_batch_dev(C.c_uint64(self.handle()), C.c_int(1 if lagrange else 0), ptrs,
+                                                C.c_size_t(m), C.c_size_t(n), ffi.current_stream_ptr(), ffi.ptr(out)))
         return out
 
     def commit(self, poly):

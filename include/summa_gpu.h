@@ -84,6 +84,16 @@ int sg_srs_free(uint64_t handle);
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]);
 int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                   uint8_t out_affine[64]);
+/* Fixed-base acceleration for a resident SRS (every MSM of create_proof is a ParamsKZG::commit /
+ * commit_lagrange against one of the two fixed bases): builds, once, the table
+ *   row w = 2^(bit offset of window w) * basis[i],   W x 2^k affine points (W = ceil(255 / window_bits)),
+ * after which sg_commit / sg_commit_dev / sg_commit_batch_dev on that basis run all W digits of a scalar
+ * into ONE bucket set (one bucket reduction instead of W; wider windows at small k).  Same result
+ * bits.  window_bits = 0 chooses min(16, k + 2).  Memory: W * 64 * 2^k bytes per basis. */
+int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits);
+/* `count` commitments of n scalars each against one basis, issued as fused jobs; out_affine: count x 64 B */
+int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
+                        void* stream, uint8_t* out_affine);
 /* Device pointers of a cached SRS (for callers that drive the *_dev entry points). */
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k);
 
@@ -227,7 +237,9 @@ typedef struct {
 /* as sg_msm_g1_dev, additionally fills per-phase HIP event timings */
 int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64],
                         sg_msm_timings* timings);
-/* name: "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "ntt.tile_log", "ntt.threads",
+int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
+                        uint8_t out_affine[64], sg_msm_timings* timings);
+/* name: "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
  * "ntt.max_single_log", "ntt.max_multi_log" */
 int sg_set_param(const char* name, int value);
 /* Time `reps` back-to-back launches of the operation with HIP events on the library's

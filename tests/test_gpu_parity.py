@@ -31,6 +31,11 @@ def P():
     return pyref
 
 
+def P_R():
+    from oracle import pyref
+    return pyref.R
+
+
 def dev(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -586,6 +591,87 @@ def test_ntt_batch(gpu, O, log_n):
     best_fft_batch(d, O.omega_inv(log_n), log_n, divisor=O.n_inv(log_n))
     for got, v in zip(d, vecs):
         assert (got.cpu().numpy() == v).all()
+
+
+# ----------------------------------------------------------------------------- fixed-base commits (precomputed SRS)
+def test_fixed_base_goldens(gpu, O, P, srs11, kat):
+    """the reference-derived known answers again, through the precomputed-window path"""
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    params.precompute()
+    want = point_np((int(kat["fixed_comms"][4][0], 16), int(kat["fixed_comms"][4][1], 16)))
+    col = fr_np(list(range(256)) + [0] * (2048 - 256))
+    assert (params.commit_lagrange(col) == want).all()
+    assert (params.commit_lagrange(dev(col)) == want).all()
+    assert (params.commit_lagrange(fr_np(range(256))) == want).all()          # shorter than the table
+    one = fr_np([1])
+    assert (params.commit_lagrange(O.fr_powers(one, 2048)) == srs11["g_np"][:64]).all()
+    wk = fr_np([pow(P.omega_for(11), 7, P.R)])
+    assert (params.commit_lagrange(O.fr_powers(wk, 2048)) == srs11["g_np"][64 * 7:64 * 8]).all()
+    dom = gpu.EvaluationDomain(6, 11)
+    for j in (0, 5, 2047):
+        e = [0] * 2048
+        e[j] = 1
+        assert (params.commit(dom.lagrange_to_coeff(fr_np(e))) == srs11["gl_np"][64 * j:64 * j + 64]).all()
+    params.free()
+
+
+@pytest.mark.parametrize("window_bits", [0, 4, 7, 11, 16])
+def test_fixed_base_vs_oracle_and_generic(gpu, O, srs11, window_bits):
+    """every window width: fixed-base == generic GPU path == oracle, full / ragged / edge-case scalars"""
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    params.precompute(window_bits=window_bits)
+    r = P_R()
+    cases = [O.random_fr(1900 + window_bits, 2048), O.random_fr(1901, 1), O.random_fr(1902, 1000),
+             fr_np([0] * 2048), fr_np([1] * 2048), fr_np([r - 1] * 2048), fr_np([r - 1, 0, 1, 2, (r - 1) // 2, (r + 1) // 2] * 300),
+             fr_np([(1 << 253) + 12345] * 64 + [0] * 64)]
+    for sc in cases:
+        n = sc.size // 32
+        for basis, name in ((0, "g_np"), (1, "gl_np")):
+            want = O.best_multiexp(sc, srs11[name][:64 * n], O.ncpu())
+            got = params.commit(sc) if basis == 0 else params.commit_lagrange(sc)
+            assert (got == want).all()
+            assert (gpu.best_multiexp(sc, srs11[name][:64 * n]) == want).all()
+    assert (params.commit(np.zeros(0, dtype=np.uint8)) == 0).all()
+    params.free()
+
+
+def test_fixed_base_batch(gpu, O, srs11):
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    cols = [O.random_fr(1950 + i, 2048) for i in range(7)] + [fr_np([0] * 2048), fr_np([5] * 2048)]
+    want = np.stack([O.best_multiexp(c, srs11["gl_np"], O.ncpu()) for c in cols])
+    d = [dev(c) for c in cols]
+    assert (params.commit_batch(d, lagrange=True) == want).all()              # no table yet: fused generic jobs
+    params.precompute(1)
+    assert (params.commit_batch(d, lagrange=True) == want).all()              # fixed-base fused jobs
+    assert (params.commit_batch(d[:1], lagrange=True) == want[:1]).all()
+    short = [t[:32 * 700] for t in d[:3]]
+    want_s = np.stack([O.best_multiexp(c[:32 * 700], srs11["g_np"][:64 * 700], O.ncpu()) for c in cols[:3]])
+    params.precompute(0, window_bits=9)
+    assert (params.commit_batch(short) == want_s).all()
+    assert params.commit_batch([]).shape == (0, 64)
+    params.free()
+
+
+def test_fixed_base_large_known_answer(gpu, O, P):
+    """2^17 points of a synthetic SRS g[i] = tau^i G: sum s_i tau^i is known in the exponent"""
+    k = 17
+    n = 1 << k
+    tau = O.random_fr(1970, 1)
+    params = gpu.ParamsKZG.setup(k, tau)
+    sc = O.random_fr(1971, n)
+    e = O.fr_eval_poly(sc, tau)
+    want = O.fixed_base_mul(e, 1)
+    assert (params.commit(sc) == want).all()
+    params.precompute(0)
+    assert (params.commit(sc) == want).all()
+    assert (params.commit(dev(sc)) == want).all()
+    got = params.commit_batch([dev(sc)] * 5 + [dev(O.random_fr(1972, n))])
+    assert (got[:5] == want).all()
+    assert (got[5] == O.fixed_base_mul(O.fr_eval_poly(O.random_fr(1972, n), tau), 1)).all()
+    # skewed scalars: one value everywhere -> every digit of a window lands in one bucket
+    same = np.tile(O.random_fr(1973, 1), n)
+    assert (params.commit(dev(same)) == O.fixed_base_mul(O.fr_eval_poly(same, tau), 1)).all()
+    params.free()
 
 
 # ----------------------------------------------------------------------------- §8f-1: quotient numerator

@@ -1,0 +1,80 @@
+// device self-test of xyzz29_add_quad against xyzz29_add (build: hipcc --offload-arch=gfx950 -O3 -I../circuits_halo2_amd/csrc)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "bn254_curve29.cuh"
+using namespace sg;
+
+__device__ xyzz29 mul_small(uint32_t k) {  // [k]G with G = (1, 2)
+  typedef Fq29 P;
+  uint32_t w[16];
+  f29 one256 = f29_const<P>(P::r256);
+  f29_to_words(one256, w);
+  f29 two = f29_cond_sub_p<P>(f29_normalize(f29_add(one256, one256)));
+  f29_to_words(two, w + 8);
+  affine29 g = affine29_from_words(w);
+  xyzz29 acc = xyzz29_identity();
+  for (int bit = 31; bit >= 0; bit--) {
+    acc = xyzz29_double(acc);
+    if ((k >> bit) & 1) xyzz29_madd(acc, g);
+  }
+  return acc;
+}
+__global__ void test(uint32_t* bad, uint32_t* out) {
+  uint32_t lt = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, role = threadIdx.x & 3;
+  uint32_t a = lt * 7 + 1, b = (lt % 5 == 0) ? a : (lt % 7 == 0 ? 0 : lt * 13 + 3);   // equal / identity / generic
+  xyzz29 A = mul_small(a), B = mul_small(b);
+  if (lt % 11 == 0) B.y = f29_sub<Fq29, 1>(f29_zero(), B.y), B = (lt % 5 == 0) ? B : B;  // sometimes -B (with a == b: P + (-P))
+  xyzz29 s = A, q = A;
+  xyzz29_add(s, B);
+  xyzz29_add_quad(q, B, role);
+  uint32_t ws[32], wq[32];
+  xyzz29_to_words(s, ws);
+  xyzz29_to_words(q, wq);
+  // compare as affine-equivalent: X1 ZZ2 == X2 ZZ1 is overkill -- formulas are identical, so words match
+  bool same = true;
+  for (int i = 0; i < 32; i++) same = same && (ws[i] == wq[i]);
+  if (xyzz29_is_identity(s) != xyzz29_is_identity(q)) same = false;
+  if (xyzz29_is_identity(s)) same = xyzz29_is_identity(q);
+  if (!same) {
+    uint32_t slot = atomicAdd(bad, 1u);
+    uint32_t mask = 0;
+    for (int i = 0; i < 32; i++) if (ws[i] != wq[i]) mask |= 1u << i;
+    if (slot < 8) { out[slot * 4] = lt; out[slot * 4 + 1] = role; out[slot * 4 + 2] = mask; out[slot * 4 + 3] = wq[8]; }
+  }
+}
+__global__ void chain(uint32_t* sink, int quad, int iters) {
+  uint32_t lt = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, role = threadIdx.x & 3;
+  xyzz29 A = mul_small(lt * 7 + 1), B = mul_small(lt * 13 + 3);
+  for (int i = 0; i < iters; i++) {
+    if (quad) xyzz29_add_quad(A, B, role); else xyzz29_add(A, B);
+  }
+  uint32_t w[32];
+  xyzz29_to_words(A, w);
+  if (w[0] == 0x12345678u) sink[0] = w[1];
+}
+static float time_chain(uint32_t* sink, int quad, int blocks, int iters) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  chain<<<blocks, 256>>>(sink, quad, iters);
+  hipEventRecord(a);
+  chain<<<blocks, 256>>>(sink, quad, iters);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms;
+}
+int main() {
+  { uint32_t* sink; hipMalloc(&sink, 4);
+    for (int blocks : {1, 256, 1024, 4096}) {
+      float s0 = time_chain(sink, 0, blocks, 0), s1 = time_chain(sink, 0, blocks, 200);
+      float q0 = time_chain(sink, 1, blocks, 0), q1 = time_chain(sink, 1, blocks, 200);
+      printf("blocks %4d: serial add %.2f us, quad add %.2f us per dependent addition\n", blocks, (s1 - s0) * 5.0f, (q1 - q0) * 5.0f);
+    } }
+  uint32_t *bad, *out;
+  hipMalloc(&bad, 4); hipMalloc(&out, 128);
+  hipMemset(bad, 0, 4); hipMemset(out, 0, 128);
+  test<<<16, 256>>>(bad, out);
+  uint32_t h = 0, ho[32];
+  hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+  hipMemcpy(ho, out, 128, hipMemcpyDeviceToHost);
+  printf("mismatching lanes: %u of %u\n", h, 16 * 256);
+  for (int i = 0; i < 8 && i < (int)h; i++) printf("  lt %u role %u mask %08x y0 %08x\n", ho[4 * i], ho[4 * i + 1], ho[4 * i + 2], ho[4 * i + 3]);
+  return h ? 1 : 0;
+}
