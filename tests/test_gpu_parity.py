@@ -593,6 +593,20 @@ def test_ntt_batch(gpu, O, log_n):
         assert (got.cpu().numpy() == v).all()
 
 
+def test_quad_cooperative_add_selftest(gpu):
+    """xyzz29_add_quad (4 lanes per point addition, DPP exchanges) against the one-lane formulas on
+    1024 operand pairs including P + P, P + (-P) and identity operands (tools/test_quad.hip, built by
+    __graft_entry__.build())"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "test_quad")
+    if not os.path.exists(exe):
+        pytest.skip("tools/test_quad not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatching lanes: 0 of" in out.stdout
+
+
 # ----------------------------------------------------------------------------- fixed-base commits (precomputed SRS)
 def test_fixed_base_goldens(gpu, O, P, srs11, kat):
     """the reference-derived known answers again, through the precomputed-window path"""

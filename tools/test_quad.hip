@@ -68,7 +68,7 @@ int main() {
       printf("blocks %4d: serial add %.2f us, quad add %.2f us per dependent addition\n", blocks, (s1 - s0) * 5.0f, (q1 - q0) * 5.0f);
     } }
   uint32_t *bad, *out;
-  hipMalloc(&bad, 4); hipMalloc(&out, 128);
+  (void)hipMalloc(&bad, 4); (void)hipMalloc(&out, 128);
   hipMemset(bad, 0, 4); hipMemset(out, 0, 128);
   test<<<16, 256>>>(bad, out);
   uint32_t h = 0, ho[32];
