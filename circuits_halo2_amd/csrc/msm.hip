@@ -248,19 +248,24 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
                                                     uint32_t n_tab, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t s_cur[];
   const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
-  const uint32_t* pre = hist + ((size_t)j * P + p) * nbw;
+  // blockIdx.z = round r of R: only the buckets [r, r+1) * nbw / R are placed.  Every round re-reads
+  // the (2-byte, coalesced) digits, but the 4-byte scattered stores of the workgroups in flight stay
+  // inside 1/R of the output, so sectors fill up in L2 before they are written back.
+  const uint32_t span = nbw / gridDim.z, b_lo = blockIdx.z * span;
+  const uint32_t* pre = hist + ((size_t)j * P + p) * nbw + b_lo;
   // fixed-base mode (collapse_W = windows per MSM): the W windows of an MSM share ONE bucket set and an
   // entry names row (window, i) of the precomputed table  2^offset_w * P_i
-  const uint32_t* ob = off + (size_t)(collapse_W ? j / collapse_W : j) * nbw;
+  const uint32_t* ob = off + (size_t)(collapse_W ? j / collapse_W : j) * nbw + b_lo;
   const uint32_t base_idx = collapse_W ? (j % collapse_W) * n_tab : 0u;
-  for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cur[b] = ob[b] + pre[b];
+  for (uint32_t b = threadIdx.x; b < span; b += blockDim.x) s_cur[b] = ob[b] + pre[b];
   __syncthreads();
   const uint32_t lo = p * chunk, hi = min(n, lo + chunk);
   const int16_t* row = dig + (size_t)j * n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int32_t d = row[i];
-    if (d) {
-      uint32_t pos = atomicAdd(&s_cur[(d < 0 ? -d : d) - 1], 1u);
+    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u - b_lo;   // d == 0 wraps to a huge value
+    if (b < span) {
+      uint32_t pos = atomicAdd(&s_cur[b], 1u);
       sorted[pos] = (base_idx + i) | (d < 0 ? 0x80000000u : 0u);
     }
   }
@@ -956,8 +961,11 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
   SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   SG_TRY(hipEventRecord(ev_meta_, stream));
-  msm_scatter<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p,
-                                                                    j.fixed ? W1 : 0u, j.n_tab, sorted_.p);
+  {
+    uint32_t log_R = std::min<uint32_t>(cfg_.log_scatter_rounds, c - 1);
+    msm_scatter<<<dim3(W, P, 1u << log_R), 1024, (nbw >> log_R) * sizeof(uint32_t), stream>>>(
+        dig_.p, (uint32_t)n, chunk, nbw, hist_.p, off_.p, j.fixed ? W1 : 0u, j.n_tab, sorted_.p);
+  }
   if (tm) SG_TRY(hipEventRecord(j.ev[2], stream));
   return hipGetLastError();
 }

@@ -28,6 +28,7 @@ extern "C" {
     ) -> c_int;
     pub fn sg_srs_upload(k: u32, g: *const u8, g_lagrange: *const u8, handle_out: *mut u64) -> c_int;
     pub fn sg_srs_free(handle: u64) -> c_int;
+    pub fn sg_srs_precompute(handle: u64, basis: c_int, window_bits: u32) -> c_int;
     pub fn sg_commit(handle: u64, basis: c_int, scalars: *const u8, n: size_t, out_affine: *mut u8) -> c_int;
     pub fn sg_ntt_fr(a: *mut u8, omega: *const u8, log_n: u32) -> c_int;
     pub fn sg_intt_fr(a: *mut u8, omega_inv: *const u8, divisor: *const u8, log_n: u32) -> c_int;
