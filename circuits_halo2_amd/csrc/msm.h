@@ -19,6 +19,7 @@ struct MsmConfig {
   uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
   uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
+  uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^17 entries), 2 always
   uint32_t log_scatter_rounds = 0;  // the counting sort's scatter runs in 2^x bucket-range rounds
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
@@ -128,6 +129,8 @@ class MsmEngine {
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
   DevBuf<xyzz29_mem> partial_[2], red_a_[2], red_s_[2], red_r_[2];
   DevBuf<uint32_t> win_words_;
+  DevBuf<uint32_t> part_entry_, ccnt_, coff_;  // two-pass sort: partitioned entries, coarse-bin counts / offsets
+  DevBuf<uint16_t> part_fine_;
   uint32_t* h_meta_ = nullptr;
   size_t h_win_cap_ = 0;
   uint32_t* h_win_ = nullptr;  // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window

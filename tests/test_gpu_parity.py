@@ -16,6 +16,13 @@ def gpu():
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     import circuits_halo2_amd as sg
     assert sg.lib().sg_device_count() >= 1
+    # SG_PARAMS=msm.two_pass=2,msm.quad=2 ... reruns the whole suite on a non-default code path
+    import os
+    from circuits_halo2_amd import ffi
+    for kv in filter(None, os.environ.get("SG_PARAMS", "").split(",")):
+        name, val = kv.split("=")
+        ffi.check(sg.lib().sg_init(0))
+        ffi.check(sg.lib().sg_set_param(name.encode(), int(val)))
     return sg
 
 
