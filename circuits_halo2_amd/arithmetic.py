@@ -233,6 +233,95 @@ def quotient_lookup(values, z, permuted_input, permuted_table, inp, table, l0, l
     return values
 
 
+class _VS(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("rotation", C.c_uint32)]
+
+
+class _Calc(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", _VS), ("b", _VS), ("parts_offset", C.c_uint32), ("parts_len", C.c_uint32)]
+
+
+class _Graph(C.Structure):
+    _fields_ = [("constants", C.c_void_p), ("n_constants", C.c_uint32), ("rotations", C.c_void_p),
+                ("n_rotations", C.c_uint32), ("calculations", C.c_void_p), ("n_calculations", C.c_uint32),
+                ("horner_parts", C.c_void_p), ("n_horner_parts", C.c_uint32)]
+
+
+# halo2's ValueSource / Calculation variants (plonk/evaluation.rs), numbered as in include/summa_gpu.h
+CONSTANT, INTERMEDIATE, FIXED, ADVICE, INSTANCE, CHALLENGE, BETA, GAMMA, THETA, Y, PREVIOUS_VALUE = range(11)
+ADD, SUB, MUL, SQUARE, DOUBLE, NEGATE, HORNER, STORE = range(8)
+
+
+class GraphEvaluator:
+    """host mirror of halo2's GraphEvaluator: constants, rotations and calculations are appended the way
+    upstream's add_constant / add_rotation / add_calculation do (deduplicated, returning a value source)"""
+
+    def __init__(self):
+        self.constants = []      # 32-byte Montgomery Fr each (bytes)
+        self.rotations = []
+        self.calculations = []   # (op, a, b[, parts]); a / b / parts: (kind, index, rotation_index)
+
+    def add_constant(self, fr32) -> tuple:
+        b = bytes(ffi.u8(fr32))
+        if b not in self.constants:
+            self.constants.append(b)
+        return (CONSTANT, self.constants.index(b), 0)
+
+    def add_rotation(self, rot: int) -> int:
+        if rot not in self.rotations:
+            self.rotations.append(rot)
+        return self.rotations.index(rot)
+
+    def query(self, kind: int, column: int, rot: int = 0) -> tuple:
+        return (kind, column, self.add_rotation(rot))
+
+    def add_calculation(self, op: int, a, b=None, parts=None) -> tuple:
+        cal = (op, tuple(a), tuple(b) if b is not None else (0, 0, 0)) + ((list(parts),) if parts is not None else ())
+        if cal in self.calculations:
+            return (INTERMEDIATE, self.calculations.index(cal), 0)
+        self.calculations.append(cal)
+        return (INTERMEDIATE, len(self.calculations) - 1, 0)
+
+    def as_dict(self):
+        consts = np.frombuffer(b"".join(self.constants), dtype=np.uint8) if self.constants else np.zeros(0, np.uint8)
+        return {"constants": consts, "rotations": list(self.rotations), "calculations": list(self.calculations)}
+
+    def _struct(self):
+        consts = np.frombuffer(b"".join(self.constants), dtype=np.uint8).copy() if self.constants else np.zeros(32, np.uint8)
+        rots = np.asarray(self.rotations if self.rotations else [0], dtype=np.int32)
+        parts = []
+        calcs = (_Calc * max(1, len(self.calculations)))()
+        for i, cal in enumerate(self.calculations):
+            calcs[i].op = cal[0]
+            calcs[i].a = _VS(*cal[1])
+            calcs[i].b = _VS(*cal[2])
+            if len(cal) > 3:
+                calcs[i].parts_offset = len(parts)
+                calcs[i].parts_len = len(cal[3])
+                parts.extend(cal[3])
+        parr = (_VS * max(1, len(parts)))(*[_VS(*p) for p in parts])
+        g = _Graph(consts.ctypes.data, len(self.constants), rots.ctypes.data, len(self.rotations), C.addressof(calcs),
+                   len(self.calculations), C.addressof(parr), len(parts))
+        return g, (consts, rots, calcs, parr)
+
+
+def quotient_gates(values, graph: GraphEvaluator, fixed, advice, instance, challenges, beta, gamma, theta, y, k: int,
+                   ext_k: int):
+    """run the custom-gate program over the extended coset: values[row] = program(row) (in place)"""
+    for t in [values, *fixed, *advice, *instance]:
+        if t.numel() != 32 << ext_k:
+            raise ValueError("quotient_gates: every array has 2^ext_k rows")
+    g, keep = graph._struct()
+    arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+    ch = np.ascontiguousarray(challenges, dtype=np.uint8) if len(challenges) else np.zeros(32, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_quotient_gates_dev(
+        ffi.dev_ptr(values), C.byref(g), arr(fixed), C.c_uint32(len(fixed)), arr(advice), C.c_uint32(len(advice)),
+        arr(instance), C.c_uint32(len(instance)), ffi.ptr(ch), C.c_uint32(len(challenges) // 32 if len(challenges) else 0),
+        ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(theta)), ffi.ptr(ffi.u8(y)), C.c_uint32(k),
+        C.c_uint32(ext_k), ffi.current_stream_ptr()))
+    return values
+
+
 def best_fft_batch(vectors, omega, log_n: int, divisor=None):
     """in-place best_fft (or ifft when `divisor` is given) of several device tensors of one size"""
     m = len(vectors)

@@ -1,0 +1,405 @@
+// Custom-gate block of the quotient numerator: values[row] <- program(row) for every
+// row of the extended coset, where the program is halo2's GraphEvaluator (plonk/evaluation.rs of the
+// pinned summa-dev/halo2 fork): a list of calculations over value sources (constants, earlier
+// intermediates, fixed / advice / instance columns at a rotation, challenges, beta / gamma / theta / y,
+// the previous value of the row).  halo2 runs it per row on the CPU with a Vec of intermediates; the
+// circuit-specific part is the program, which the Rust side already holds, not this code.
+//
+// Host side (compile_gates): the graph is lowered to a straight-line program over LDS slots --
+//   * every value lives in the 2^261 (hat) limb form; column words are converted on load with one
+//     product, constants once per workgroup;
+//   * additions / subtractions are lazy (bound tracking as in the curve code); a reduction (product
+//     with 1^) is inserted only where the next product would exceed bound_a * bound_b <= 170;
+//   * Store is an alias, Horner expands to product + sum per part, loads are emitted at first use;
+//   * slots are allocated by liveness (last use), so the LDS footprint is the maximum number of
+//     simultaneously live values, not the number of intermediates.
+// Device side (gates_kernel): one thread per row, T rows per workgroup, slots in LDS as [slot][limb][row]
+// (conflict-free), the instruction stream is uniform (scalar loads, no divergence).  Cost per
+// product-type instruction ~300 VALU instructions (229 of them the product): ALU-bound like the rest.
+#include "gates.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <map>
+
+namespace sg {
+
+typedef Fr29 P;
+
+// ------------------------------------------------------------------ device
+struct GateArgs {
+  fp_words* values;
+  const GateOp* ops;
+  const fp_words* const* cols;
+  const uint32_t* consts;  // 8 words each
+  uint32_t n_ops, n_consts, n_slots, result_kind, result_index, k, ext_k;
+};
+
+template <uint32_t T>
+__global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* s_const = lds;                       // [n_consts][9]
+  uint32_t* s_slot = lds + a.n_consts * 9;       // [n_slots][9][T]
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t c = tid; c < a.n_consts; c += T) {
+    f29 v = f29_words_to_r261<P>(a.consts + 8 * c);
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_const[c * 9 + q] = v.l[q];
+  }
+  __syncthreads();
+  const size_t n_ext = (size_t)1 << a.ext_k, mask = n_ext - 1;
+  const size_t row = (size_t)blockIdx.x * T + tid;
+  if (row >= n_ext) return;
+  const uint32_t rot_shift = a.ext_k - a.k;
+  auto get = [&](uint32_t kind, uint32_t idx) {
+    f29 r;
+    if (kind == GK_CONST) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) r.l[q] = s_const[idx * 9 + q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; q++) r.l[q] = s_slot[(idx * 9 + q) * T + tid];
+    }
+    return r;
+  };
+  auto sub_k = [&](uint32_t kidx, const f29& x, const f29& y) {
+    switch (kidx) {
+      case 0: return f29_sub<P, 0>(x, y);
+      case 1: return f29_sub<P, 1>(x, y);
+      case 2: return f29_sub<P, 2>(x, y);
+      case 3: return f29_sub<P, 3>(x, y);
+      case 4: return f29_sub<P, 4>(x, y);
+      default: return f29_sub<P, 5>(x, y);
+    }
+  };
+  for (uint32_t pc = 0; pc < a.n_ops; pc++) {
+    const GateOp op = a.ops[pc];
+    const uint32_t code = op.w0 & 0xff, kidx = (op.w0 >> 8) & 0xff, ak = (op.w0 >> 16) & 0xff, bk = op.w0 >> 24;
+    f29 r;
+    switch (code) {
+      case G_LOADCOL: {
+        const size_t i = (row + ((size_t)(int64_t)(int32_t)op.b << rot_shift)) & mask;
+        r = f29_mul<P>(f29_load_r256<P>(a.cols[op.a] + i), f29_const<P>(P::r266));
+        break;
+      }
+      case G_LOADPREV: r = f29_mul<P>(f29_load_r256<P>(a.values + row), f29_const<P>(P::r266)); break;
+      case G_ADD: r = f29_add(get(ak, op.a), get(bk, op.b)); break;
+      case G_SUB: r = sub_k(kidx, get(ak, op.a), get(bk, op.b)); break;
+      case G_MUL: r = f29_mul<P>(get(ak, op.a), get(bk, op.b)); break;
+      case G_SQR: r = f29_sqr<P>(get(ak, op.a)); break;
+      case G_DBL: { f29 x = get(ak, op.a); r = f29_add(x, x); break; }
+      case G_NEG: r = sub_k(kidx, f29_zero(), get(ak, op.a)); break;
+      default: r = f29_mul<P>(get(ak, op.a), f29_one<P>()); break;  // G_RED
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_slot[(op.dst * 9 + q) * T + tid] = r.l[q];
+  }
+  f29 res = get(a.result_kind, a.result_index);
+  // hat -> memory domain: x^ * 2^256 * 2^-261 = x~, then canonical
+  f29_store_canonical<P>(a.values + row, f29_mul<P>(res, f29_const<P>(P::r256)));
+}
+
+// ------------------------------------------------------------------ host: compiler
+namespace {
+struct Val {         // a virtual value of the lowered program
+  uint32_t kind;     // GK_SLOT (virtual id in `index`) or GK_CONST
+  uint32_t index;
+};
+struct IrOp {
+  uint32_t code, kidx;
+  uint32_t dst;      // virtual id
+  Val a, b;
+  uint32_t col = 0;
+  int32_t rot = 0;
+};
+struct Compiler {
+  std::vector<IrOp> ir;
+  std::vector<uint32_t> bound;     // per virtual id
+  std::vector<uint32_t> redirect;  // virtual id -> reduced replacement (or itself)
+  uint32_t new_value(uint32_t b) {
+    bound.push_back(b);
+    redirect.push_back((uint32_t)redirect.size());
+    return (uint32_t)bound.size() - 1;
+  }
+  Val resolve(Val v) {
+    if (v.kind == GK_SLOT)
+      while (redirect[v.index] != v.index) v.index = redirect[v.index];
+    return v;
+  }
+  uint32_t bnd(const Val& v) const { return v.kind == GK_CONST ? 2u : bound[v.index]; }
+  Val reduce(Val v) {  // product with 1^: bound 2
+    v = resolve(v);
+    if (v.kind == GK_CONST || bound[v.index] <= 2) return v;
+    uint32_t d = new_value(2);
+    ir.push_back({G_RED, 0, d, v, v});
+    redirect[v.index] = d;  // later uses see the reduced copy
+    return Val{GK_SLOT, d};
+  }
+  Val emit2(uint32_t code, uint32_t kidx, Val a, Val b, uint32_t out_bound) {
+    uint32_t d = new_value(out_bound);
+    ir.push_back({code, kidx, d, a, b});
+    return Val{GK_SLOT, d};
+  }
+  Val add(Val a, Val b) {
+    a = resolve(a); b = resolve(b);
+    while (bnd(a) + bnd(b) > 80) {
+      if (bnd(a) >= bnd(b)) a = reduce(a); else b = reduce(b);
+    }
+    return emit2(G_ADD, 0, a, b, bnd(a) + bnd(b));
+  }
+  static uint32_t kidx_for(uint32_t b) {  // smallest K = 2 << kidx >= b
+    uint32_t k = 0;
+    while ((2u << k) < b) k++;
+    return k;
+  }
+  Val sub(Val a, Val b) {
+    a = resolve(a); b = resolve(b);
+    if (bnd(b) > 64) b = reduce(b);
+    uint32_t k = kidx_for(bnd(b));
+    if (bnd(a) + (2u << k) > 120) a = reduce(a);
+    return emit2(G_SUB, k, a, b, bnd(a) + (2u << k));
+  }
+  Val neg(Val a) {
+    a = resolve(a);
+    if (bnd(a) > 64) a = reduce(a);
+    uint32_t k = kidx_for(bnd(a));
+    return emit2(G_NEG, k, a, a, 2u << k);
+  }
+  Val dbl(Val a) {
+    a = resolve(a);
+    if (bnd(a) > 40) a = reduce(a);
+    return emit2(G_DBL, 0, a, a, 2 * bnd(a));
+  }
+  Val mul(Val a, Val b) {
+    a = resolve(a); b = resolve(b);
+    while (bnd(a) * bnd(b) > 170) {
+      if (bnd(a) >= bnd(b)) a = reduce(a); else b = reduce(b);
+    }
+    return emit2(G_MUL, 0, a, b, 2);
+  }
+  Val sqr(Val a) {
+    a = resolve(a);
+    if (bnd(a) * bnd(a) > 170) a = reduce(a);
+    return emit2(G_SQR, 0, a, a, 2);
+  }
+};
+}  // namespace
+
+std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance,
+                          const uint8_t* challenges, uint32_t n_challenges, const uint8_t beta[32],
+                          const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32], GateProgram* out) {
+  if (g.n_calculations == 0) return "empty program";
+  if ((g.n_constants && !g.constants) || (g.n_rotations && !g.rotations) || !g.calculations ||
+      (g.n_horner_parts && !g.horner_parts))
+    return "null array in graph";
+  Compiler c;
+  GateProgram prog;
+  // constant table: constants ++ challenges ++ beta, gamma, theta, y
+  const uint32_t c_chal = g.n_constants, c_beta = c_chal + n_challenges;
+  auto push_const = [&](const uint8_t* p) {
+    uint32_t w[8];
+    std::memcpy(w, p, 32);
+    prog.const_words.insert(prog.const_words.end(), w, w + 8);
+  };
+  for (uint32_t i = 0; i < g.n_constants; i++) push_const(g.constants + 32 * (size_t)i);
+  for (uint32_t i = 0; i < n_challenges; i++) push_const(challenges + 32 * (size_t)i);
+  push_const(beta); push_const(gamma); push_const(theta); push_const(y);
+  // (column, rotation) -> (value, instruction index of its latest use): a loaded value is reused only
+  // while the previous use is at most RELOAD_DISTANCE instructions back; beyond that a fresh load
+  // (32-byte read + one product) is cheaper than pinning an LDS slot
+  constexpr size_t RELOAD_DISTANCE = 48;
+  std::map<std::pair<uint32_t, int32_t>, std::pair<Val, size_t>> loaded;
+  Val prev{GK_SLOT, 0xffffffffu};
+  std::vector<Val> inter(g.n_calculations);
+  std::string err;
+  auto source = [&](const sg_value_source& s, uint32_t upto) -> Val {
+    switch (s.kind) {
+      case SG_VS_CONSTANT:
+        if (s.index >= g.n_constants) { err = "constant index out of range"; return Val{GK_CONST, 0}; }
+        return Val{GK_CONST, s.index};
+      case SG_VS_INTERMEDIATE:
+        if (s.index >= upto) { err = "intermediate used before it is defined"; return Val{GK_CONST, 0}; }
+        return inter[s.index];
+      case SG_VS_FIXED: case SG_VS_ADVICE: case SG_VS_INSTANCE: {
+        const uint32_t lim = s.kind == SG_VS_FIXED ? n_fixed : s.kind == SG_VS_ADVICE ? n_advice : n_instance;
+        const uint32_t base = s.kind == SG_VS_FIXED ? 0 : s.kind == SG_VS_ADVICE ? n_fixed : n_fixed + n_advice;
+        if (s.index >= lim || s.rotation >= g.n_rotations) { err = "column query out of range"; return Val{GK_CONST, 0}; }
+        auto key = std::make_pair(base + s.index, g.rotations[s.rotation]);
+        auto it = loaded.find(key);
+        if (it != loaded.end() && c.ir.size() - it->second.second <= RELOAD_DISTANCE) {
+          it->second.second = c.ir.size();
+          return it->second.first;
+        }
+        uint32_t d = c.new_value(2);
+        IrOp op{G_LOADCOL, 0, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}};
+        op.col = key.first; op.rot = key.second;
+        c.ir.push_back(op);
+        loaded[key] = std::make_pair(Val{GK_SLOT, d}, c.ir.size());
+        return Val{GK_SLOT, d};
+      }
+      case SG_VS_CHALLENGE:
+        if (s.index >= n_challenges) { err = "challenge index out of range"; return Val{GK_CONST, 0}; }
+        return Val{GK_CONST, c_chal + s.index};
+      case SG_VS_BETA: return Val{GK_CONST, c_beta};
+      case SG_VS_GAMMA: return Val{GK_CONST, c_beta + 1};
+      case SG_VS_THETA: return Val{GK_CONST, c_beta + 2};
+      case SG_VS_Y: return Val{GK_CONST, c_beta + 3};
+      case SG_VS_PREVIOUS_VALUE:
+        if (prev.index == 0xffffffffu) {
+          uint32_t d = c.new_value(2);
+          c.ir.push_back({G_LOADPREV, 0, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}});
+          prev = Val{GK_SLOT, d};
+        }
+        return prev;
+      default: err = "unknown value source"; return Val{GK_CONST, 0};
+    }
+  };
+  // Demand-driven emission: an intermediate is lowered when it is first needed, starting from the last
+  // calculation.  halo2 ends a program with Horner(PreviousValue, [all gate polynomials], Y); emitted in
+  // program order every gate value would stay live until that final fold, emitted on demand each one
+  // is folded right after it is computed (and unused calculations disappear).
+  if (g.n_calculations > (1u << 16)) return "more than 65536 calculations";
+  for (uint32_t q = 0; q < g.n_calculations; q++) {  // validate references up front (the recursion trusts them)
+    const sg_calculation& cal = g.calculations[q];
+    auto bad = [&](const sg_value_source& s) { return s.kind == SG_VS_INTERMEDIATE && s.index >= q; };
+    if (bad(cal.a) || (cal.op <= SG_OP_MUL && bad(cal.b)) || (cal.op == SG_OP_HORNER && bad(cal.b)))
+      return "intermediate used before it is defined";
+    if (cal.op == SG_OP_HORNER) {
+      if ((uint64_t)cal.parts_offset + cal.parts_len > g.n_horner_parts) return "horner parts out of range";
+      for (uint32_t t = 0; t < cal.parts_len; t++)
+        if (bad(g.horner_parts[cal.parts_offset + t])) return "intermediate used before it is defined";
+    }
+  }
+  std::vector<uint8_t> done(g.n_calculations, 0);
+  std::function<Val(const sg_value_source&)> need;
+  std::function<void(uint32_t)> lower = [&](uint32_t q) {
+    if (done[q] || !err.empty()) return;
+    done[q] = 1;
+    const sg_calculation& cal = g.calculations[q];
+    Val a = need(cal.a);
+    switch (cal.op) {
+      case SG_OP_ADD: inter[q] = c.add(a, need(cal.b)); break;
+      case SG_OP_SUB: inter[q] = c.sub(a, need(cal.b)); break;
+      case SG_OP_MUL: inter[q] = c.mul(a, need(cal.b)); break;
+      case SG_OP_SQUARE: inter[q] = c.sqr(a); break;
+      case SG_OP_DOUBLE: inter[q] = c.dbl(a); break;
+      case SG_OP_NEGATE: inter[q] = c.neg(a); break;
+      case SG_OP_HORNER: {
+        Val f = need(cal.b), acc = a;
+        for (uint32_t t = 0; t < cal.parts_len && err.empty(); t++)
+          acc = c.add(c.mul(acc, f), need(g.horner_parts[cal.parts_offset + t]));
+        inter[q] = acc;
+        break;
+      }
+      case SG_OP_STORE: inter[q] = a; break;
+      default: err = "unknown calculation";
+    }
+  };
+  need = [&](const sg_value_source& s) -> Val {
+    if (s.kind == SG_VS_INTERMEDIATE) lower(s.index);
+    return source(s, g.n_calculations);
+  };
+  lower(g.n_calculations - 1);
+  if (!err.empty()) return err;
+  Val result = c.resolve(inter[g.n_calculations - 1]);
+  // liveness: last instruction that reads each virtual value (the result lives to the end)
+  const uint32_t nv = (uint32_t)c.bound.size(), END = 0xffffffffu;
+  std::vector<uint32_t> last(nv, 0);
+  for (uint32_t i = 0; i < c.ir.size(); i++) {
+    const IrOp& op = c.ir[i];
+    if (op.code == G_LOADCOL || op.code == G_LOADPREV) continue;
+    if (op.a.kind == GK_SLOT) last[op.a.index] = i;
+    if (op.b.kind == GK_SLOT) last[op.b.index] = i;
+  }
+  if (result.kind == GK_SLOT) last[result.index] = END;
+  std::vector<uint32_t> slot(nv, END), free_slots;
+  uint32_t n_slots = 0;
+  for (uint32_t i = 0; i < c.ir.size(); i++) {
+    const IrOp& op = c.ir[i];
+    GateOp o{};
+    uint32_t a_idx = 0, b_idx = 0;
+    const bool reads = !(op.code == G_LOADCOL || op.code == G_LOADPREV);
+    if (reads) {
+      a_idx = op.a.kind == GK_SLOT ? slot[op.a.index] : op.a.index;
+      b_idx = op.b.kind == GK_SLOT ? slot[op.b.index] : op.b.index;
+      // operands dying here free their slots before the destination is chosen (in-place update)
+      if (op.a.kind == GK_SLOT && last[op.a.index] == i) free_slots.push_back(slot[op.a.index]);
+      if (op.b.kind == GK_SLOT && last[op.b.index] == i && !(op.a.kind == GK_SLOT && op.a.index == op.b.index))
+        free_slots.push_back(slot[op.b.index]);
+    } else {
+      a_idx = op.col;
+      b_idx = (uint32_t)op.rot;
+    }
+    uint32_t d;
+    if (last[op.dst] == 0 && !(result.kind == GK_SLOT && result.index == op.dst)) {
+      // never read: still needs somewhere to land
+      if (free_slots.empty()) free_slots.push_back(n_slots++);
+      d = free_slots.back();  // not removed: immediately reusable
+    } else {
+      if (free_slots.empty()) free_slots.push_back(n_slots++);
+      d = free_slots.back();
+      free_slots.pop_back();
+    }
+    slot[op.dst] = d;
+    o.w0 = op.code | (op.kidx << 8) | (op.a.kind << 16) | (op.b.kind << 24);
+    o.dst = d; o.a = a_idx; o.b = b_idx;
+    prog.ops.push_back(o);
+  }
+  prog.n_slots = std::max<uint32_t>(1, n_slots);
+  prog.result_kind = result.kind;
+  prog.result_index = result.kind == GK_SLOT ? slot[result.index] : result.index;
+  prog.n_columns = n_fixed + n_advice + n_instance;
+  *out = std::move(prog);
+  return "";
+}
+
+size_t gates_blob(const GateProgram& p, const void* const* cols, std::vector<uint8_t>* blob) {
+  const size_t ops_b = p.ops.size() * sizeof(GateOp), cols_b = (size_t)p.n_columns * sizeof(void*),
+               const_b = p.const_words.size() * sizeof(uint32_t);
+  blob->resize(ops_b + cols_b + const_b + 16);
+  std::memcpy(blob->data(), p.ops.data(), ops_b);
+  if (cols_b) std::memcpy(blob->data() + ops_b, cols, cols_b);
+  std::memcpy(blob->data() + ops_b + cols_b, p.const_words.data(), const_b);
+  return blob->size();
+}
+
+hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_values, uint32_t k, uint32_t ext_k,
+                     hipStream_t stream) {
+  GateArgs a;
+  a.values = d_values;
+  a.ops = reinterpret_cast<const GateOp*>(d_blob);
+  a.cols = reinterpret_cast<const fp_words* const*>(d_blob + p.ops.size() * sizeof(GateOp));
+  a.consts = reinterpret_cast<const uint32_t*>(d_blob + p.ops.size() * sizeof(GateOp) + (size_t)p.n_columns * sizeof(void*));
+  a.n_ops = (uint32_t)p.ops.size();
+  a.n_consts = (uint32_t)(p.const_words.size() / 8);
+  a.n_slots = p.n_slots;
+  a.result_kind = p.result_kind;
+  a.result_index = p.result_index;
+  a.k = k; a.ext_k = ext_k;
+  const size_t n_ext = (size_t)1 << ext_k;
+  // rows per workgroup from the LDS budget: (constants + slots * T) * 36 B <= 144 KiB
+  const size_t budget = 144 * 1024, cbytes = (size_t)a.n_consts * 36;
+  uint32_t T = 256;
+  while (T > 64 && cbytes + (size_t)p.n_slots * T * 36 > budget) T >>= 1;
+  const size_t lds = cbytes + (size_t)p.n_slots * T * 36;
+  if (lds > budget) return hipErrorInvalidValue;
+  const unsigned blocks = (unsigned)((n_ext + T - 1) / T);
+  hipError_t e;
+  if (T == 256) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gates_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+    if (e != hipSuccess) return e;
+    gates_kernel<256><<<blocks, 256, lds, stream>>>(a);
+  } else if (T == 128) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gates_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+    if (e != hipSuccess) return e;
+    gates_kernel<128><<<blocks, 128, lds, stream>>>(a);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gates_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+    if (e != hipSuccess) return e;
+    gates_kernel<64><<<blocks, 64, lds, stream>>>(a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace sg

@@ -17,6 +17,7 @@
 #include "msm.h"
 #include "ntt.h"
 #include "quotient.h"
+#include "gates.h"
 #include "poly.h"
 #include "witness.h"
 
@@ -130,7 +131,8 @@ struct Context {
   hipStream_t bstream[2] = {nullptr, nullptr};
   hipStream_t tstream[2] = {nullptr, nullptr};  // high-priority tails
   hipEvent_t ev_in = nullptr;
-  DevBuf<uint8_t> stage_a, stage_b, scratch;
+  DevBuf<uint8_t> stage_a, stage_b, scratch, gate_blob;
+  std::vector<uint8_t> gate_blob_host;
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
@@ -294,6 +296,7 @@ void sg_shutdown(void) {
   g_ctx->stage_a.release();
   g_ctx->stage_b.release();
   g_ctx->scratch.release();
+  g_ctx->gate_blob.release();
   if (g_ctx->d_consts) (void)hipFree(g_ctx->d_consts);
   if (g_ctx->stream) (void)hipStreamDestroy(g_ctx->stream);
   delete g_ctx;
@@ -1075,6 +1078,38 @@ int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permut
   std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
   hipError_t e = quotient_lookup(a, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("quotient_lookup", e);
+  return SG_OK;
+}
+
+int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                          const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                          uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                          const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                          uint32_t k, uint32_t ext_k, void* stream) {
+  if (!d_values || !graph || !beta || !gamma || !theta || !y || (n_fixed && !d_fixed) || (n_advice && !d_advice) ||
+      (n_instance && !d_instance) || (n_challenges && !challenges))
+    return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
+  if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_gates: bad shape");
+  LOCKED_CTX();
+  GateProgram prog;
+  std::string err = compile_gates(*graph, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y,
+                                  &prog);
+  if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_quotient_gates: " + err).c_str());
+  if (prog.n_slots > 64) return fail(SG_ERR_INVALID, "sg_quotient_gates: more than 64 simultaneously live values");
+  std::vector<const void*> cols;
+  for (uint32_t i = 0; i < n_fixed; i++) cols.push_back(d_fixed[i]);
+  for (uint32_t i = 0; i < n_advice; i++) cols.push_back(d_advice[i]);
+  for (uint32_t i = 0; i < n_instance; i++) cols.push_back(d_instance[i]);
+  for (const void* c : cols)
+    if (!c) return fail(SG_ERR_INVALID, "sg_quotient_gates: null column");
+  hipStream_t s = pick_stream(stream);
+  // the staging vector lives in the context: it must outlive the asynchronous copy
+  const size_t bytes = gates_blob(prog, cols.data(), &g_ctx->gate_blob_host);
+  hipError_t e = g_ctx->gate_blob.reserve(bytes);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // a previous call's copy may still read the staging vector
+  if (e == hipSuccess) e = hipMemcpyAsync(g_ctx->gate_blob.p, g_ctx->gate_blob_host.data(), bytes, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = gates_run(prog, g_ctx->gate_blob.p, static_cast<fp_words*>(d_values), k, ext_k, s);
+  if (e != hipSuccess) return hip_fail("quotient_gates", e);
   return SG_OK;
 }
 

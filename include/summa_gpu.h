@@ -214,6 +214,35 @@ int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permut
                            const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
                            uint32_t k, uint32_t ext_k, void* stream);
 
+/* Custom-gate block: halo2's GraphEvaluator program (plonk/evaluation.rs: `calculations`, `constants`,
+ * `rotations`; value sources and calculations keep upstream's names).  calculations[i] defines
+ * intermediate i; for every extended row the value of the LAST calculation becomes values[row], the old
+ * values[row] being available as SG_VS_PREVIOUS_VALUE (upstream ends its program with
+ * Horner(PreviousValue, gate polynomials, Y)).  Column sources name (column index, index into
+ * rotations[]); a rotation r reads row + r * 2^(ext_k - k).  The program is compiled per call into a
+ * straight-line LDS-slot program (csrc/gates.hip); at most 64 simultaneously live values. */
+enum { SG_VS_CONSTANT = 0, SG_VS_INTERMEDIATE = 1, SG_VS_FIXED = 2, SG_VS_ADVICE = 3, SG_VS_INSTANCE = 4,
+       SG_VS_CHALLENGE = 5, SG_VS_BETA = 6, SG_VS_GAMMA = 7, SG_VS_THETA = 8, SG_VS_Y = 9, SG_VS_PREVIOUS_VALUE = 10 };
+enum { SG_OP_ADD = 0, SG_OP_SUB = 1, SG_OP_MUL = 2, SG_OP_SQUARE = 3, SG_OP_DOUBLE = 4, SG_OP_NEGATE = 5,
+       SG_OP_HORNER = 6, SG_OP_STORE = 7 };
+typedef struct { uint32_t kind, index, rotation; } sg_value_source;
+typedef struct {
+  uint32_t op;
+  sg_value_source a, b;              /* HORNER: a = start value, b = factor */
+  uint32_t parts_offset, parts_len;  /* HORNER: horner_parts[parts_offset .. +parts_len) */
+} sg_calculation;
+typedef struct {
+  const uint8_t* constants; uint32_t n_constants;      /* 32-B Montgomery Fr each */
+  const int32_t* rotations; uint32_t n_rotations;
+  const sg_calculation* calculations; uint32_t n_calculations;
+  const sg_value_source* horner_parts; uint32_t n_horner_parts;
+} sg_graph;
+int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                          const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                          uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                          const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                          uint32_t k, uint32_t ext_k, void* stream);
+
 /* ---- witness side: the Merkle sum tree of
  * zk_prover/src/merkle_sum_tree (node.rs:16-84, utils/build_tree.rs:5-78) over Poseidon(t = 2,
  * rate 1, R_F = 8, R_P = 56, x^5; chips/poseidon/poseidon_spec.rs:14-37).  All values 32-B Fr

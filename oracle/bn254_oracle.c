@@ -749,6 +749,91 @@ void orc_quotient_lookup(uint8_t *values, const uint8_t *z, const uint8_t *ap, c
     }
 }
 
+/* ---------------------------------------------------------------- 8f-1: custom gates
+ * Interpreter for halo2's GraphEvaluator program (plonk/evaluation.rs in the pinned summa-dev/halo2
+ * fork; not vendored): calculations[i] defines intermediate i from two value sources; the value of
+ * the LAST calculation is the new values[row] (the running numerator enters as PreviousValue).
+ * Same plain-struct ABI as include/summa_gpu.h (sg_graph). */
+typedef struct { uint32_t kind, index, rotation; } orc_value_source;
+typedef struct { uint32_t op; orc_value_source a, b; uint32_t parts_offset, parts_len; } orc_calculation;
+typedef struct {
+    const uint8_t *constants; uint32_t n_constants;
+    const int32_t *rotations; uint32_t n_rotations;
+    const orc_calculation *calculations; uint32_t n_calculations;
+    const orc_value_source *horner_parts; uint32_t n_horner_parts;
+} orc_graph;
+enum { VS_CONSTANT, VS_INTERMEDIATE, VS_FIXED, VS_ADVICE, VS_INSTANCE, VS_CHALLENGE, VS_BETA, VS_GAMMA, VS_THETA, VS_Y,
+       VS_PREVIOUS };
+enum { OP_ADD, OP_SUB, OP_MUL, OP_SQUARE, OP_DOUBLE, OP_NEGATE, OP_HORNER, OP_STORE };
+typedef struct {
+    const orc_graph *g;
+    const uint8_t *const *fixed, *const *advice, *const *instance;
+    const uint8_t *challenges;
+    fe beta, gamma, theta, y, prev;
+    const fe *inter;
+    size_t row, n_ext, rot_scale;
+} gate_ctx;
+static fe gate_value(const gate_ctx *c, const orc_value_source *v) {
+    fe r;
+    switch (v->kind) {
+    case VS_CONSTANT: memcpy(&r, c->g->constants + 32 * (size_t)v->index, 32); return r;
+    case VS_INTERMEDIATE: return c->inter[v->index];
+    case VS_FIXED: case VS_ADVICE: case VS_INSTANCE: {
+        const uint8_t *const *cols = v->kind == VS_FIXED ? c->fixed : v->kind == VS_ADVICE ? c->advice : c->instance;
+        long long rot = c->g->rotations[v->rotation];
+        size_t i = (size_t)(((long long)c->row + rot * (long long)c->rot_scale) & (long long)(c->n_ext - 1));
+        return *row(cols[v->index], i);
+    }
+    case VS_CHALLENGE: memcpy(&r, c->challenges + 32 * (size_t)v->index, 32); return r;
+    case VS_BETA: return c->beta;
+    case VS_GAMMA: return c->gamma;
+    case VS_THETA: return c->theta;
+    case VS_Y: return c->y;
+    default: return c->prev;
+    }
+}
+void orc_quotient_gates(uint8_t *values, const orc_graph *g, const uint8_t *const *fixed, const uint8_t *const *advice,
+                        const uint8_t *const *instance, const uint8_t *challenges, const uint8_t beta[32],
+                        const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32], uint32_t k,
+                        uint32_t ext_k) {
+    gate_ctx c;
+    c.g = g; c.fixed = fixed; c.advice = advice; c.instance = instance; c.challenges = challenges;
+    memcpy(&c.beta, beta, 32); memcpy(&c.gamma, gamma, 32); memcpy(&c.theta, theta, 32); memcpy(&c.y, y, 32);
+    c.n_ext = (size_t)1 << ext_k; c.rot_scale = (size_t)1 << (ext_k - k);
+    fe *inter = (fe *)malloc(sizeof(fe) * (g->n_calculations ? g->n_calculations : 1));
+    c.inter = inter;
+    for (size_t i = 0; i < c.n_ext; i++) {
+        c.row = i;
+        c.prev = *row(values, i);
+        for (uint32_t q = 0; q < g->n_calculations; q++) {
+            const orc_calculation *cal = &g->calculations[q];
+            fe a = gate_value(&c, &cal->a), b, r;
+            switch (cal->op) {
+            case OP_ADD: b = gate_value(&c, &cal->b); fe_add(&FR, &r, &a, &b); break;
+            case OP_SUB: b = gate_value(&c, &cal->b); fe_sub(&FR, &r, &a, &b); break;
+            case OP_MUL: b = gate_value(&c, &cal->b); fe_mul(&FR, &r, &a, &b); break;
+            case OP_SQUARE: fe_sqr(&FR, &r, &a); break;
+            case OP_DOUBLE: fe_dbl(&FR, &r, &a); break;
+            case OP_NEGATE: fe_neg(&FR, &r, &a); break;
+            case OP_HORNER: {   /* start * factor^len + parts[0] * factor^(len-1) + ... + parts[len-1] */
+                b = gate_value(&c, &cal->b);
+                r = a;
+                for (uint32_t t = 0; t < cal->parts_len; t++) {
+                    fe part = gate_value(&c, &g->horner_parts[cal->parts_offset + t]);
+                    fe_mul(&FR, &r, &r, &b);
+                    fe_add(&FR, &r, &r, &part);
+                }
+                break;
+            }
+            default: r = a; break;  /* OP_STORE */
+            }
+            inter[q] = r;
+        }
+        if (g->n_calculations) memcpy(values + 32 * i, &inter[g->n_calculations - 1], 32);
+    }
+    free(inter);
+}
+
 /* ---------------------------------------------------------------- witness side (row W)
  * Poseidon(t = 2, rate 1, R_F = 8, R_P = 56, x^5) sponge of halo2_gadgets as used by
  * zk_prover/src/merkle_sum_tree/node.rs:57-84; parameters are supplied by the caller

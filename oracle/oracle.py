@@ -241,6 +241,53 @@ def quotient_lookup(values, z, ap, sp, a, s, l0, l_last, l_active, beta, gamma, 
     return out
 
 
+class _VS(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("rotation", C.c_uint32)]
+
+
+class _Calc(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", _VS), ("b", _VS), ("parts_offset", C.c_uint32), ("parts_len", C.c_uint32)]
+
+
+class _Graph(C.Structure):
+    _fields_ = [("constants", C.c_void_p), ("n_constants", C.c_uint32), ("rotations", C.c_void_p),
+                ("n_rotations", C.c_uint32), ("calculations", C.c_void_p), ("n_calculations", C.c_uint32),
+                ("horner_parts", C.c_void_p), ("n_horner_parts", C.c_uint32)]
+
+
+def _graph_struct(graph):
+    """graph: {"constants": bytes-like n x 32, "rotations": [int], "calculations": [(op, a, b[, parts])]}
+    with a / b / parts entries = (kind, index, rotation_index); returns (struct, keepalive)"""
+    consts = np.ascontiguousarray(graph["constants"], dtype=np.uint8)
+    rots = np.asarray(graph["rotations"], dtype=np.int32)
+    parts = []
+    calcs = (_Calc * max(1, len(graph["calculations"])))()
+    for i, cal in enumerate(graph["calculations"]):
+        op, a, b = cal[0], cal[1], cal[2] if len(cal) > 2 and cal[2] is not None else (0, 0, 0)
+        calcs[i].op = op
+        calcs[i].a = _VS(*a)
+        calcs[i].b = _VS(*b)
+        if len(cal) > 3:
+            calcs[i].parts_offset = len(parts)
+            calcs[i].parts_len = len(cal[3])
+            parts.extend(cal[3])
+    parr = (_VS * max(1, len(parts)))(*[_VS(*p) for p in parts])
+    g = _Graph(consts.ctypes.data, consts.size // 32, rots.ctypes.data, rots.size, C.addressof(calcs),
+               len(graph["calculations"]), C.addressof(parr), len(parts))
+    return g, (consts, rots, calcs, parr)
+
+
+def quotient_gates(values, graph, fixed, advice, instance, challenges, beta, gamma, theta, y, k, ext_k) -> np.ndarray:
+    out = np.ascontiguousarray(values).copy()
+    g, keep = _graph_struct(graph)
+    cols = [[np.ascontiguousarray(c) for c in group] for group in (fixed, advice, instance)]
+    ptrs = [(C.c_void_p * max(1, len(group)))(*[c.ctypes.data for c in group]) for group in cols]
+    ch = np.ascontiguousarray(challenges, dtype=np.uint8) if len(challenges) else np.zeros(32, dtype=np.uint8)
+    lib().orc_quotient_gates(_p(out), C.byref(g), ptrs[0], ptrs[1], ptrs[2], _p(ch), _p(beta), _p(gamma), _p(theta), _p(y),
+                             C.c_uint32(k), C.c_uint32(ext_k))
+    return out
+
+
 _PSD_READY = False
 
 

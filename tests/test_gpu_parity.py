@@ -695,6 +695,129 @@ def test_fixed_base_large_known_answer(gpu, O, P):
     params.free()
 
 
+# ----------------------------------------------------------------------------- §8f-1: custom gates (GraphEvaluator)
+def _random_graph(rng, n_fixed, n_advice, n_instance, n_chal, n_calc, O):
+    """a random, valid GraphEvaluator program that exercises every calculation and value source"""
+    from circuits_halo2_amd import arithmetic as A
+    g = A.GraphEvaluator()
+    consts = [g.add_constant(O.random_fr(int(rng.integers(1 << 30)), 1)) for _ in range(3)]
+    consts.append(g.add_constant(fr_np([0])))
+    consts.append(g.add_constant(fr_np([1])))
+    rots = [0, 1, -1, 2, -5]
+
+    def src(upto):
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            return consts[int(rng.integers(len(consts)))]
+        if kind in (1, 2) and upto:
+            return (A.INTERMEDIATE, int(rng.integers(max(0, upto - 6), upto)), 0)   # mostly recent values
+        if kind == 3 and n_fixed:
+            return g.query(A.FIXED, int(rng.integers(n_fixed)), rots[int(rng.integers(len(rots)))])
+        if kind == 4 and n_instance:
+            return g.query(A.INSTANCE, int(rng.integers(n_instance)), rots[int(rng.integers(2))])
+        if kind == 5 and n_chal:
+            return (A.CHALLENGE, int(rng.integers(n_chal)), 0)
+        if kind == 6:
+            return (int(rng.choice([A.BETA, A.GAMMA, A.THETA, A.Y, A.PREVIOUS_VALUE])), 0, 0)
+        return g.query(A.ADVICE, int(rng.integers(n_advice)), rots[int(rng.integers(len(rots)))])
+
+    while len(g.calculations) < n_calc:
+        q = len(g.calculations)
+        op = int(rng.choice([A.ADD, A.ADD, A.SUB, A.SUB, A.MUL, A.MUL, A.SQUARE, A.DOUBLE, A.NEGATE, A.HORNER, A.STORE]))
+        if op == A.HORNER:
+            g.add_calculation(op, src(q), src(q), [src(q) for _ in range(int(rng.integers(0, 5)))])
+        elif op in (A.SQUARE, A.DOUBLE, A.NEGATE, A.STORE):
+            g.add_calculation(op, src(q))
+        else:
+            g.add_calculation(op, src(q), src(q))
+    return g
+
+
+@pytest.mark.parametrize("seed,k,ext_k,n_calc", [(1, 4, 6, 8), (2, 5, 7, 40), (3, 9, 12, 120), (4, 10, 13, 300),
+                                                  (5, 6, 6, 60), (6, 7, 10, 200)])
+def test_quotient_gates_random_programs(gpu, O, seed, k, ext_k, n_calc):
+    """bit-exact against the oracle's per-row interpreter on random programs: lazy-reduction bound tracking,
+    slot allocation, rotations, Horner, aliases"""
+    from circuits_halo2_amd.arithmetic import quotient_gates
+    rng = np.random.default_rng(seed)
+    ne = 1 << ext_k
+    nf, na, ni, nc = 3, 4, 1, 2
+    g = _random_graph(rng, nf, na, ni, nc, n_calc, O)
+    cols = [[O.random_fr(2000 + 100 * seed + 10 * j + i, ne) for i in range(n)] for j, n in enumerate((nf, na, ni))]
+    chal = O.random_fr(2090 + seed, nc)
+    beta, gamma, theta, y = (O.random_fr(2095 + i, 1) for i in range(4))
+    start = O.random_fr(2099, ne)
+    want = O.quotient_gates(start, g.as_dict(), *cols, chal, beta, gamma, theta, y, k, ext_k)
+    got = quotient_gates(dev(start), g, *[[dev(c) for c in grp] for grp in cols], chal, beta, gamma, theta, y, k, ext_k)
+    assert (got.cpu().numpy() == want).all()
+
+
+def test_quotient_gates_bounds_and_slots(gpu, O):
+    """long lazy chains (sums of 200 terms, alternating subtractions / negations / doublings) and many live
+    values (40 loads consumed in reverse order: the 64-rows-per-workgroup layout)"""
+    from circuits_halo2_amd import arithmetic as A
+    k, ext_k = 6, 8
+    ne = 1 << ext_k
+    adv = [O.random_fr(2200 + i, ne) for i in range(40)]
+    beta, gamma, theta, y = (O.random_fr(2295 + i, 1) for i in range(4))
+    g = A.GraphEvaluator()
+    acc = g.query(A.ADVICE, 0, 0)
+    for i in range(200):
+        term = g.query(A.ADVICE, i % 40, (i % 3) - 1)
+        op = [A.ADD, A.SUB, A.ADD, A.SUB][i % 4]
+        acc = g.add_calculation(op, acc, term)
+        if i % 17 == 0:
+            acc = g.add_calculation(A.DOUBLE, acc)
+        if i % 23 == 0:
+            acc = g.add_calculation(A.NEGATE, acc)
+    g.add_calculation(A.MUL, acc, acc)
+    args = ([], adv, [], np.zeros(0, dtype=np.uint8), beta, gamma, theta, y, k, ext_k)
+    start = O.random_fr(2299, ne)
+    want = O.quotient_gates(start, g.as_dict(), *args)
+    got = A.quotient_gates(dev(start), g, [], [dev(c) for c in adv], [], *args[3:])
+    assert (got.cpu().numpy() == want).all()
+    # 40 values loaded first, consumed last-in-first-out
+    g = A.GraphEvaluator()
+    loads = [g.add_calculation(A.SQUARE, g.query(A.ADVICE, i, 0)) for i in range(40)]
+    acc = loads[-1]
+    for v in reversed(loads[:-1]):
+        acc = g.add_calculation(A.MUL, acc, v)
+    want = O.quotient_gates(start, g.as_dict(), *args)
+    got = A.quotient_gates(dev(start), g, [], [dev(c) for c in adv], [], *args[3:])
+    assert (got.cpu().numpy() == want).all()
+
+
+def test_quotient_gates_errors(gpu, O):
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.ffi import SummaGpuError
+    k, ext_k = 4, 6
+    ne = 1 << ext_k
+    col = dev(O.random_fr(1, ne))
+    b = O.random_fr(2, 1)
+    run = lambda g, adv: A.quotient_gates(dev(O.random_fr(3, ne)), g, [], adv, [], np.zeros(0, dtype=np.uint8), b, b, b, b, k, ext_k)
+    g = A.GraphEvaluator()
+    g.add_calculation(A.ADD, g.query(A.ADVICE, 1, 0), g.query(A.ADVICE, 0, 0))       # column 1 of 1
+    with pytest.raises(SummaGpuError):
+        run(g, [col])
+    g = A.GraphEvaluator()
+    g.add_calculation(A.ADD, (A.INTERMEDIATE, 0, 0), g.query(A.ADVICE, 0, 0))        # use before definition
+    with pytest.raises(SummaGpuError):
+        run(g, [col])
+    with pytest.raises(SummaGpuError):
+        run(A.GraphEvaluator(), [col])                                               # empty program
+    g = A.GraphEvaluator()                                     # 70 computed values, each used twice, far apart
+    xs = [g.add_calculation(A.SQUARE, g.query(A.ADVICE, 0, i - 35)) for i in range(70)]
+    acc = xs[0]
+    for v in xs[1:]:
+        acc = g.add_calculation(A.MUL, acc, v)
+    for v in reversed(xs):
+        acc = g.add_calculation(A.ADD, g.add_calculation(A.MUL, acc, v), v)
+    with pytest.raises(SummaGpuError):
+        run(g, [col])
+    with pytest.raises(ValueError):
+        run(g, [col[:64]])
+
+
 # ----------------------------------------------------------------------------- §8f-1: quotient numerator
 def _to_extended_dev(cols, k, ext_k):
     """Lagrange columns (numpy) -> extended-coset evaluations on the device, through the product path"""
@@ -763,19 +886,38 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     u, l0, l_last, l_active = W.selectors(k, blinding)
     cols, sigmas, zs = W.permutation_witness(k, ncols, chunk_len, blinding, 1810 + k, beta, gamma)
     a, s, ap, sp, z = W.lookup_witness(k, blinding, 1820 + k, beta, gamma)
-    lag = [l0, l_last, l_active, *zs, *cols, *sigmas, z, ap, sp, a, s]
+    # a custom gate  q * (ga * gb(omega X) - gc) = 0  on the usable rows, degree 3
+    ga, gb = O.random_fr(1830 + k, n), O.random_fr(1831 + k, n)
+    gb_next = np.roll(gb.reshape(n, 32), -1, axis=0).reshape(-1)
+    gc = O.fr_mul_n(ga, gb_next)
+    gc[32 * u:] = O.random_fr(1832 + k, n - u)                       # blinding rows: anything
+    gq = l_active.copy()
+    lag = [l0, l_last, l_active, *zs, *cols, *sigmas, z, ap, sp, a, s, ga, gb, gc, gq]
     ext, dom = _to_extended_dev(lag, k, ext_k)
     e_l0, e_ll, e_la = ext[:3]
     e_zs = ext[3:3 + len(zs)]
     e_cols = ext[3 + len(zs):3 + len(zs) + ncols]
     e_sig = ext[3 + len(zs) + ncols:3 + len(zs) + 2 * ncols]
-    e_z, e_ap, e_sp, e_a, e_s = ext[-5:]
+    e_z, e_ap, e_sp, e_a, e_s = ext[-9:-4]
+    e_ga, e_gb, e_gc, e_gq = ext[-4:]
+    from circuits_halo2_amd import arithmetic as A
+    theta = O.random_fr(1804, 1)
+    graph = A.GraphEvaluator()
+    prod = graph.add_calculation(A.MUL, graph.query(A.ADVICE, 0, 0), graph.query(A.ADVICE, 1, 1))
+    gate = graph.add_calculation(A.MUL, graph.query(A.FIXED, 0, 0),
+                                 graph.add_calculation(A.SUB, prod, graph.query(A.ADVICE, 2, 0)))
+    graph.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), (A.Y, 0, 0), [gate])
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    gate_args = ([e_gq], [e_ga, e_gb, e_gc], [], np.zeros(0, dtype=np.uint8), beta, gamma, theta, y, k, ext_k)
+    A.quotient_gates(values, graph, *gate_args)                       # halo2's order: gates, permutation, lookups
+    assert values.any()
     quotient_permutation(values, e_zs, e_cols, e_sig, chunk_len, e_l0, e_ll, e_la, beta, gamma, y, k, ext_k, blinding + 1)
     quotient_lookup(values, e_z, e_ap, e_sp, e_a, e_s, e_l0, e_ll, e_la, beta, gamma, y, k, ext_k)
     # same folds by the oracle on the same extended columns
     h = lambda t: t.cpu().numpy()
-    want = O.quotient_permutation(np.zeros(32 * ne, dtype=np.uint8), [h(t) for t in e_zs], [h(t) for t in e_cols],
+    want = O.quotient_gates(np.zeros(32 * ne, dtype=np.uint8), graph.as_dict(), [h(e_gq)], [h(e_ga), h(e_gb), h(e_gc)], [],
+                            *gate_args[3:])
+    want = O.quotient_permutation(want, [h(t) for t in e_zs], [h(t) for t in e_cols],
                                   [h(t) for t in e_sig], chunk_len, h(e_l0), h(e_ll), h(e_la), beta, gamma, y, k, ext_k,
                                   blinding + 1)
     want = O.quotient_lookup(want, h(e_z), h(e_ap), h(e_sp), h(e_a), h(e_s), h(e_l0), h(e_ll), h(e_la), beta, gamma, y,
@@ -795,6 +937,15 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
     quotient_permutation(values, e_zs, [e_cols[0], e_bad, *e_cols[2:]], e_sig, chunk_len, e_l0, e_ll, e_la, beta, gamma,
                          y, k, ext_k, blinding + 1)
+    dom.divide_by_vanishing_poly(values)
+    dom.extended_to_coeff(values)
+    assert not W.top_coefficients_zero(h(values), first_zero)
+    # tamper: one cell of the gate's output column
+    bad = gc.copy()
+    bad[32 * 5:32 * 6] = O.fr_add(bad[32 * 5:32 * 6].copy(), W.fr_np([1]))
+    e_bad = dom.coeff_to_extended(dom.lagrange_to_coeff(dev(bad)))
+    values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(values, graph, [e_gq], [e_ga, e_gb, e_bad], [], *gate_args[3:])
     dom.divide_by_vanishing_poly(values)
     dom.extended_to_coeff(values)
     assert not W.top_coefficients_zero(h(values), first_zero)

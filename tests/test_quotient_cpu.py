@@ -67,3 +67,71 @@ def test_oracle_lookup_quotient_is_a_polynomial(k):
     cols[1] = E(bad)
     values = O.quotient_lookup(zero, *cols, E(l0), E(l_last), E(l_active), beta, gamma, y, k, ext_k)
     assert not W.top_coefficients_zero(_quotient_coeffs(values, k, ext_k), first_zero)
+
+
+def _py_eval_graph(graph, row, cols, chal, beta, gamma, theta, y, prev, n_ext, rot_scale):
+    """big-int evaluation of one row of a GraphEvaluator program (kinds / ops numbered as in the C ABI)"""
+    from oracle import pyref as P
+    toi = lambda arr, i: P.fr_from_bytes(arr[32 * i:32 * i + 32].tobytes())
+    inter = []
+
+    def val(v):
+        kind, index, rot = v
+        if kind == 0:
+            return toi(graph["constants"], index)
+        if kind == 1:
+            return inter[index]
+        if kind in (2, 3, 4):
+            return toi(cols[kind - 2][index], (row + graph["rotations"][rot] * rot_scale) % n_ext)
+        if kind == 5:
+            return toi(chal, index)
+        return {6: beta, 7: gamma, 8: theta, 9: y, 10: prev}[kind]
+
+    for cal in graph["calculations"]:
+        op, a = cal[0], val(cal[1])
+        if op == 0: r = a + val(cal[2])
+        elif op == 1: r = a - val(cal[2])
+        elif op == 2: r = a * val(cal[2])
+        elif op == 3: r = a * a
+        elif op == 4: r = 2 * a
+        elif op == 5: r = -a
+        elif op == 6:
+            f, r = val(cal[2]), a
+            for part in cal[3]:
+                r = r * f + val(part)
+        else: r = a
+        inter.append(r % P.R)
+    return inter[-1]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_oracle_gate_interpreter_vs_python_integers(seed):
+    """pins orc_quotient_gates (the checker of the GPU interpreter) against a big-int evaluation"""
+    from oracle import pyref as P
+    rng = np.random.default_rng(seed)
+    k, ext_k = 3, 5
+    ne, scale = 1 << ext_k, 1 << (ext_k - k)
+    cols = [[O.random_fr(50 * seed + 10 * j + i, ne) for i in range(2)] for j in range(3)]
+    chal = O.random_fr(77, 2)
+    consts = O.random_fr(78, 3)
+    chs = [O.random_fr(80 + i, 1) for i in range(4)]
+    calcs = []
+
+    def src():
+        kind = int(rng.integers(0, 11))
+        if kind == 0: return (0, int(rng.integers(3)), 0)
+        if kind == 1: return (1, int(rng.integers(len(calcs))), 0) if calcs else (9, 0, 0)
+        if kind in (2, 3, 4): return (kind, int(rng.integers(2)), int(rng.integers(3)))
+        if kind == 5: return (5, int(rng.integers(2)), 0)
+        return (kind, 0, 0)
+
+    for _ in range(40):
+        op = int(rng.integers(0, 8))
+        calcs.append((op, src(), src(), [src() for _ in range(int(rng.integers(0, 4)))]) if op == 6 else (op, src(), src()))
+    graph = {"constants": consts, "rotations": [0, 1, -2], "calculations": calcs}
+    start = O.random_fr(90, ne)
+    got = O.quotient_gates(start, graph, cols[0], cols[1], cols[2], chal, *chs, k, ext_k)
+    ints = [P.fr_from_bytes(c.tobytes()) for c in chs]
+    for rowi in range(ne):
+        want = _py_eval_graph(graph, rowi, cols, chal, *ints, P.fr_from_bytes(start[32 * rowi:32 * rowi + 32].tobytes()), ne, scale)
+        assert P.fr_from_bytes(got[32 * rowi:32 * rowi + 32].tobytes()) == want
