@@ -174,6 +174,36 @@ def fr_mul(a, b):
     return out
 
 
+def kate_division(a, b, with_remainder: bool = False):
+    """halo2 arithmetic::kate_division: quotient of a(X) by (X - b) on a device tensor; returns n - 1 coefficients
+    (and a(b) when asked)"""
+    import torch
+    n = a.numel() // 32
+    q = torch.empty(32 * n, dtype=torch.uint8, device=a.device)
+    rem = np.zeros(32, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_fr_kate_division_dev(ffi.dev_ptr(a), C.c_size_t(n), ffi.ptr(ffi.u8(b)), ffi.dev_ptr(q),
+                                                ffi.ptr(rem) if with_remainder else None, ffi.current_stream_ptr()))
+    q = q[:32 * max(0, n - 1)]
+    return (q, rem) if with_remainder else q
+
+
+def lincomb(polys, coeffs):
+    """sum_j coeffs[j] * polys[j] over equal-length device tensors; coeffs: m x 32 bytes"""
+    import torch
+    m = len(polys)
+    c = ffi.u8(coeffs)
+    if c.size != 32 * m:
+        raise ValueError("lincomb: one coefficient per polynomial")
+    for p in polys:
+        if p.numel() != polys[0].numel():
+            raise ValueError("lincomb: equal lengths expected")
+    out = torch.empty_like(polys[0])
+    ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+    ffi.check(ffi.lib().sg_fr_lincomb_dev(ptrs, ffi.ptr(c), C.c_uint32(m), C.c_size_t(polys[0].numel() // 32),
+                                          ffi.dev_ptr(out), ffi.current_stream_ptr()))
+    return out
+
+
 def permutation_product(values, sigmas, beta, gamma, delta_start, k: int, z0=None):
     """one chunk of halo2's permutation grand product on device tensors; returns z (2^k rows)"""
     import torch

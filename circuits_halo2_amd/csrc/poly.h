@@ -29,6 +29,14 @@ hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8
 hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,
                                 size_t n, int numer, fp_words* d_io, hipStream_t stream);
 size_t prefix_product_tmp_elems(size_t n);
+// Kate division a(X) = q(X)(X - b) + a(b): q_out gets n slots (q_0..q_{n-2}, then a zero) and must not alias a,
+// rem_out (optional) a(b); n <= 2^21; d_tmp: 1024 elements
+hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,
+                              fp_words* d_rem, hipStream_t stream);
+// out[i] = sum_j coeffs[j] * polys[j][i], m <= LINCOMB_MAX
+static constexpr uint32_t LINCOMB_MAX = 32;
+hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
+                        hipStream_t stream);
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,
                                 hipStream_t stream);
 }  // namespace sg

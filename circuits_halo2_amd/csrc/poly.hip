@@ -182,6 +182,142 @@ __global__ void mul_elementwise_kernel(const fp_words* __restrict__ a, const fp_
   f29_store_canonical<P>(out + i, f29_mul<P>(f29_load_r256<P>(a + i), load_hat(b + i)));
 }
 
+// ---- Kate division: a(X) = q(X) (X - b) + a(b) -------------------------------------------------
+// s_i = a_i + b s_{i+1} (s_n = 0), q_{i-1} = s_i, remainder s_0: a suffix scan whose combine step is
+// "multiply by a power of b and add".  Three launches like the prefix product: block values, scan of
+// the block values (one workgroup, <= 1024 blocks), final pass with the carries.
+static constexpr uint32_t KD_CH = 8, KD_THREADS = 256, KD_BLOCK = KD_CH * KD_THREADS;
+// S_t = sum_{u >= t} mine_u w^(u - t) over the nthr threads of a workgroup (w_pow[j] = w^(2^j), hat)
+__device__ __forceinline__ f29 block_suffix_geometric(f29 mine, const f29* w_pow, uint32_t (*sh)[9], uint32_t tid,
+                                                      uint32_t nthr) {
+#pragma unroll
+  for (int q = 0; q < 9; q++) sh[tid][q] = mine.l[q];
+  __syncthreads();
+  f29 v = mine;                                              // < 2p between steps
+  uint32_t j = 0;
+  for (uint32_t d = 1; d < nthr; d <<= 1, j++) {
+    f29 o = f29_zero();
+    if (tid + d < nthr) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) o.l[q] = sh[tid + d][q];
+    }
+    __syncthreads();
+    v = f29_mul2<P>(v, f29_one<P>(), o, w_pow[j]);           // v + w^d * o, one reduction
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[tid][q] = v.l[q];
+    __syncthreads();
+  }
+  return v;
+}
+__device__ __forceinline__ f29 kd_local(const fp_words* __restrict__ a, uint32_t n, uint32_t first, const f29& b_hat,
+                                        f29* vals) {
+  f29 acc = f29_zero();                                      // Horner from the top of the chunk down
+#pragma unroll
+  for (uint32_t k = KD_CH; k-- > 0;) {
+    vals[k] = (first + k < n) ? load_hat(a + first + k) : f29_zero();
+    acc = f29_mul2<P>(acc, b_hat, vals[k], f29_one<P>());    // acc * b + a_k
+  }
+  return acc;
+}
+// w[j] = b^(KD_CH * 2^j), j < count: the scan weights, by repeated squaring (every thread, 3 + count squarings)
+__device__ __forceinline__ void kd_powers(const f29& b_hat, f29* w, int count, int skip) {
+  f29 t = b_hat;
+  for (int i = 0; i < 3 + skip; i++) t = f29_sqr<P>(t);       // b^(8 * 2^skip)
+  for (int j = 0; j < count; j++) {
+    w[j] = t;
+    t = f29_sqr<P>(t);
+  }
+}
+__global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ a, uint32_t n, words8 b,
+                                                   fp_words* __restrict__ bval) {
+  __shared__ uint32_t sh[KD_THREADS][9];
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
+  f29 w[8], vals[KD_CH];
+  const f29 b_hat = f29_words_to_r261<P>(b.l);
+  kd_powers(b_hat, w, 8, 0);
+  f29 local = kd_local(a, n, first, b_hat, vals);
+  f29 s = block_suffix_geometric(local, w, sh, tid, KD_THREADS);
+  if (tid == 0) store_hat(bval + blockIdx.x, s);
+}
+// carry[k] = sum_{u > k} bval[u] * (b^KD_BLOCK)^(u - k - 1): the value of s just above block k
+__global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ bval, uint32_t nblk, words8 b) {
+  __shared__ uint32_t sh[1024][9];
+  const uint32_t tid = threadIdx.x;
+  f29 w[10];
+  kd_powers(f29_words_to_r261<P>(b.l), w, 10, 8);             // b^(KD_BLOCK * 2^j)
+  f29 mine = tid < nblk ? load_hat(bval + tid) : f29_zero();
+  block_suffix_geometric(mine, w, sh, tid, 1024);             // sh[t] = inclusive suffix value
+  f29 carry = f29_zero();
+  if (tid + 1 < 1024) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) carry.l[q] = sh[tid + 1][q];
+  }
+  __syncthreads();
+  if (tid < nblk) store_hat(bval + tid, carry);
+}
+__global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a, uint32_t n, words8 b,
+                                                  const fp_words* __restrict__ carry, fp_words* __restrict__ q_out,
+                                                  fp_words* __restrict__ rem_out) {
+  __shared__ uint32_t sh[KD_THREADS][9];
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
+  f29 w[8], vals[KD_CH];
+  const f29 b_hat = f29_words_to_r261<P>(b.l);
+  kd_powers(b_hat, w, 8, 0);
+  f29 local = kd_local(a, n, first, b_hat, vals);
+  // the top thread's chunk sees the block carry: s(lo) = local + b^KD_CH * carry
+  if (tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), w[0]);
+  block_suffix_geometric(local, w, sh, tid, KD_THREADS);      // sh[t] = s at the bottom of thread t's chunk
+  f29 run = f29_zero();                                        // s just above this thread's chunk
+  if (tid + 1 < KD_THREADS) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) run.l[q] = sh[tid + 1][q];
+  } else {
+    run = load_hat(carry + blockIdx.x);
+  }
+#pragma unroll
+  for (uint32_t k = KD_CH; k-- > 0;) {
+    const uint32_t i = first + k;
+    run = f29_mul2<P>(run, b_hat, vals[k], f29_one<P>());      // s_i
+    if (i < n) {
+      if (i >= 1) store_hat(q_out + i - 1, run);
+      else if (rem_out) store_hat(rem_out, run);
+    }
+  }
+  if (first <= n - 1 && n - 1 < first + KD_CH) store_hat(q_out + n - 1, f29_zero());   // padding slot
+}
+
+// ---- out[i] = sum_j c_j * p_j[i] ------------------------------------------------------------------
+struct LinCombArgs {
+  const fp_words* polys[LINCOMB_MAX];
+  words8 coeff[LINCOMB_MAX];
+};
+__global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgs a, uint32_t m, uint32_t n, fp_words* __restrict__ out) {
+  __shared__ uint32_t s_c[LINCOMB_MAX][9];
+  if (threadIdx.x < m) {
+    f29 c = f29_words_to_r261<P>(a.coeff[threadIdx.x].l);
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_c[threadIdx.x][q] = c.l[q];
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f29 acc = f29_zero();
+  for (uint32_t j = 0; j < m; j += 2) {                       // two terms per reduction
+    f29 c0, c1 = f29_zero(), p1 = f29_zero();
+#pragma unroll
+    for (int q = 0; q < 9; q++) c0.l[q] = s_c[j][q];
+    const f29 p0 = f29_load_r256<P>(a.polys[j] + i);           // p~ * c^ = (pc)~
+    if (j + 1 < m) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) c1.l[q] = s_c[j + 1][q];
+      p1 = f29_load_r256<P>(a.polys[j + 1] + i);
+    }
+    acc = f29_add(acc, f29_mul2<P>(p0, c0, p1, c1));          // bound grows by 2 per pair
+    if ((j & 31) == 30) acc = f29_mul<P>(acc, f29_one<P>());   // keep the lazy sum far below 170 p... (tilde stays tilde)
+  }
+  f29_store_canonical<P>(out + i, f29_mul<P>(acc, f29_one<P>()));
+}
+
 // ------------------------------------------------------------------ host side
 hipError_t poly_eval(const fp_words* d_coeffs, size_t n, const words8& x, fp_words* d_tmp_a, fp_words* d_tmp_b,
                      fp_words* d_out, hipStream_t stream) {
@@ -273,6 +409,29 @@ hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t
                                 hipStream_t stream) {
   if (!n) return hipSuccess;
   mul_elementwise_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_a, d_b, (uint32_t)n, d_out);
+  return hipGetLastError();
+}
+
+hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,
+                              fp_words* d_rem, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint32_t nblk = (uint32_t)((n + KD_BLOCK - 1) / KD_BLOCK);
+  if (nblk > 1024) return hipErrorInvalidValue;
+  kate_blocks<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp);
+  kate_scan_blocks<<<1, 1024, 0, stream>>>(d_tmp, nblk, b);
+  kate_write<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp, d_q, d_rem);
+  return hipGetLastError();
+}
+hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
+                        hipStream_t stream) {
+  if (m == 0 || m > LINCOMB_MAX) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  LinCombArgs a;
+  for (uint32_t j = 0; j < m; j++) {
+    a.polys[j] = d_polys[j];
+    a.coeff[j] = coeffs[j];
+  }
+  lincomb_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, m, (uint32_t)n, d_out);
   return hipGetLastError();
 }
 

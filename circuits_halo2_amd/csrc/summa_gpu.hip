@@ -1010,6 +1010,47 @@ int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void*
   return SG_OK;
 }
 
+// halo2's kate_division(a, b) (arithmetic.rs): the quotient of a(X) by (X - b), as SHPLONK's multi-open
+// applies it once per opening point; remainder = a(b) comes for free
+int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void* d_q, uint8_t* remainder_out,
+                            void* stream) {
+  if (!b || (n && (!d_a || !d_q))) return fail(SG_ERR_INVALID, "sg_fr_kate_division: null argument");
+  if (n > (1ull << 21)) return fail(SG_ERR_INVALID, "sg_fr_kate_division: at most 2^21 coefficients");
+  if (d_a == d_q && n) return fail(SG_ERR_INVALID, "sg_fr_kate_division: the quotient must not alias the input");
+  if (n == 0) {
+    if (remainder_out) std::memset(remainder_out, 0, 32);
+    return SG_OK;
+  }
+  LOCKED_CTX();
+  hipError_t e = g_ctx->scratch.reserve(1025 * 32 + 64);
+  if (e != hipSuccess) return hip_fail("kate_division work space", e);
+  words8 bw;
+  std::memcpy(&bw, b, 32);
+  hipStream_t s = pick_stream(stream);
+  fp_words* tmp = reinterpret_cast<fp_words*>(g_ctx->scratch.p);
+  e = poly_kate_division(static_cast<const fp_words*>(d_a), n, bw, tmp, static_cast<fp_words*>(d_q),
+                         remainder_out ? tmp + 1024 : nullptr, s);
+  if (e == hipSuccess && remainder_out) e = hipMemcpyAsync(remainder_out, tmp + 1024, 32, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the scratch buffer is shared
+  if (e != hipSuccess) return hip_fail("kate_division", e);
+  return SG_OK;
+}
+// out[i] = sum_j coeffs[j] * polys[j][i]: the random linear combinations of SHPLONK / multi-open
+int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream) {
+  if (!d_polys || !coeffs || (n && !d_out)) return fail(SG_ERR_INVALID, "sg_fr_lincomb: null argument");
+  if (m == 0 || m > LINCOMB_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb: between 1 and 32 polynomials");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_lincomb: vector too long");
+  for (uint32_t j = 0; j < m; j++)
+    if (n && !d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_lincomb: null polynomial");
+  LOCKED_CTX();
+  words8 cw[LINCOMB_MAX];
+  std::memcpy(cw, coeffs, 32 * (size_t)m);
+  hipError_t e = poly_lincomb(reinterpret_cast<const fp_words* const*>(d_polys), cw, m, n, static_cast<fp_words*>(d_out),
+                              pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("lincomb", e);
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
 int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
                                 const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,

@@ -186,6 +186,14 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 
+/* halo2 arithmetic::kate_division(a, b): quotient of a(X) by (X - b) -- applied once per opening point by the
+ * SHPLONK multi-open (§8f-3).  d_q receives n elements (q_0 .. q_{n-2}, then 0) and must not alias d_a;
+ * remainder_out (optional, host) receives a(b).  n <= 2^21. */
+int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void* d_q, uint8_t* remainder_out,
+                            void* stream);
+/* out[i] = sum_j coeffs[j] * polys[j][i], 1 <= m <= 32 (the random linear combinations of the multi-open) */
+int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
+
 /* ---- the generic (circuit-independent) parts of halo2's `evaluate_h`
  * (halo2_proofs plonk/evaluation.rs, Evaluator::evaluate_h; the same terms, in the same
  * order, are folded by the generated verifier: contracts/src/InclusionVerifier.sol:903-997).

@@ -569,6 +569,27 @@ void orc_fr_prefix_product(const uint8_t *a, size_t n, uint8_t *out) {
         if (i < n) fe_mul(&FR, &acc, &acc, (const fe *)(a + 32 * i));
     }
 }
+/* halo2 arithmetic::kate_division: q(X) = (a(X) - a(b)) / (X - b); q has n - 1 coefficients */
+void orc_fr_kate_division(const uint8_t *a, size_t n, const uint8_t b[32], uint8_t *q, uint8_t rem[32]) {
+    fe bb, s = {{0, 0, 0, 0}};
+    memcpy(&bb, b, 32);
+    for (size_t i = n; i-- > 0;) {          /* s_i = a_i + b s_{i+1};  q_{i-1} = s_i */
+        fe_mul(&FR, &s, &s, &bb);
+        fe_add(&FR, &s, &s, (const fe *)(a + 32 * i));
+        if (i >= 1) memcpy(q + 32 * (i - 1), &s, 32);
+        else if (rem) memcpy(rem, &s, 32);
+    }
+}
+void orc_fr_lincomb(const uint8_t *const *polys, const uint8_t *coeffs, uint32_t m, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        fe acc = {{0, 0, 0, 0}}, t;
+        for (uint32_t j = 0; j < m; j++) {
+            fe_mul(&FR, &t, (const fe *)(polys[j] + 32 * i), (const fe *)(coeffs + 32 * (size_t)j));
+            fe_add(&FR, &acc, &acc, &t);
+        }
+        memcpy(out + 32 * i, &acc, 32);
+    }
+}
 void orc_fr_mul_n(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) fe_mul(&FR, (fe *)(out + 32 * i), (const fe *)(a + 32 * i), (const fe *)(b + 32 * i));
 }

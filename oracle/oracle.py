@@ -197,6 +197,23 @@ def fr_mul_n(a, b) -> np.ndarray:
     return out
 
 
+def fr_kate_division(a, b):
+    """-> (q: n - 1 coefficients, remainder a(b))"""
+    a = np.ascontiguousarray(a)
+    n = a.size // 32
+    q, rem = _buf(32 * max(1, n - 1)), _buf(32)
+    lib().orc_fr_kate_division(_p(a), C.c_size_t(n), _p(b), _p(q), _p(rem))
+    return q[:32 * max(0, n - 1)], rem
+
+
+def fr_lincomb(polys, coeffs) -> np.ndarray:
+    ps = [np.ascontiguousarray(p) for p in polys]
+    ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+    out = _buf(ps[0].size)
+    lib().orc_fr_lincomb(ptrs, _p(np.ascontiguousarray(coeffs)), C.c_uint32(len(ps)), C.c_size_t(ps[0].size // 32), _p(out))
+    return out
+
+
 def permutation_product(values, sigmas, beta, gamma, delta_start, k, z0=None) -> np.ndarray:
     m = len(values)
     vs = [np.ascontiguousarray(v) for v in values]

@@ -695,6 +695,37 @@ def test_fixed_base_large_known_answer(gpu, O, P):
     params.free()
 
 
+# ----------------------------------------------------------------------------- §8f-3 pieces: multi-open helpers
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 5000, 1 << 17, (1 << 20) + 3])
+def test_kate_division(gpu, O, n):
+    """halo2 kate_division: bit-exact vs the oracle recurrence; a(z) == q(z) (z - b) + a(b) at a random z"""
+    from circuits_halo2_amd.arithmetic import kate_division, eval_polynomial
+    a, b, z = O.random_fr(2400 + n % 97, n), O.random_fr(2401, 1), O.random_fr(2402, 1)
+    want_q, want_rem = O.fr_kate_division(a, b)
+    q, rem = kate_division(dev(a), b, with_remainder=True)
+    assert (rem == want_rem).all() and (rem == O.fr_eval_poly(a, b)).all()
+    assert (q.cpu().numpy() == want_q).all()
+    if n > 1:
+        lhs = O.fr_eval_poly(a, z)
+        rhs = O.fr_add(O.fr_mul(eval_polynomial(q, z), O.fr_sub(z, b)), rem)
+        assert (lhs == rhs).all()
+    zero = fr_np([0])                                    # division by X: a shift
+    q0 = kate_division(dev(a), zero)
+    assert (q0.cpu().numpy() == a[32:]).all()
+
+
+def test_lincomb(gpu, O):
+    from circuits_halo2_amd.arithmetic import lincomb
+    for m, n in [(1, 5), (2, 1000), (5, 4096), (31, 3000), (32, 513)]:
+        polys = [O.random_fr(2500 + j, n) for j in range(m)]
+        coeffs = O.random_fr(2550 + m, m)
+        got = lincomb([dev(p) for p in polys], coeffs)
+        assert (got.cpu().numpy() == O.fr_lincomb(polys, coeffs)).all()
+    from circuits_halo2_amd.ffi import SummaGpuError
+    with pytest.raises(SummaGpuError):
+        lincomb([dev(O.random_fr(1, 4))] * 33, O.random_fr(2, 33))
+
+
 # ----------------------------------------------------------------------------- §8f-1: custom gates (GraphEvaluator)
 def _random_graph(rng, n_fixed, n_advice, n_instance, n_chal, n_calc, O):
     """a random, valid GraphEvaluator program that exercises every calculation and value source"""
