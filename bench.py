@@ -206,6 +206,23 @@ def main():
                                         "note": "MSM+NTT kernel sum only; sum_ms uses the resident-SRS commit path "
                                                 "(fixed-base window table), sum_generic_msm_ms arbitrary bases"}
 
+            # the whole create_proof op schedule at k = 17 with its Fiat-Shamir sync points (tools/proof_flow.py):
+            # 16 commitments in 6 groups, 9 + 9 + 1 transforms, evaluate_h (gates + permutation + lookup), 35
+            # evaluations, multi-open -- synthetic witness and a stand-in gate program, every op through the C ABI
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                from proof_flow import run_flow
+                del a20
+                torch.cuda.empty_cache()
+                flow = run_flow(17, n_gates=24, reps=3)
+                line["proof_flow_k17"] = {"ms": flow["total"], "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
+                                          "rows_per_s": (1 << 17) / (flow["total"] * 1e-3),
+                                          "note": "synthetic create_proof-shaped schedule (MstInclusion column/argument counts, "
+                                                  "24 stand-in Poseidon-round gates), host syncs at the 6 challenge points, "
+                                                  "Python/ctypes driver overhead included"}
+            except Exception as ex:  # the flow is an extra: never lose the headline line over it
+                line["proof_flow_k17"] = {"error": repr(ex)}
+
         # ---- CPU baseline for the NTT numbers above (same oracle, same box)
         if not args.no_cpu and world == 1 and "ntt" in line:
             from oracle import oracle as O

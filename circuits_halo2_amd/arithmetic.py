@@ -174,6 +174,25 @@ def fr_mul(a, b):
     return out
 
 
+def eval_polynomial_batch(polys, points) -> np.ndarray:
+    """polys[j](points[j]) for equal-length device polynomials; points: m x 32 bytes -> (m, 32) uint8"""
+    m = len(polys)
+    pts = ffi.u8(points)
+    if pts.size != 32 * m:
+        raise ValueError("eval_polynomial_batch: one point per polynomial")
+    out = np.zeros((m, 32), dtype=np.uint8)
+    if m == 0:
+        return out
+    n = polys[0].numel() // 32
+    for p in polys:
+        if p.numel() != 32 * n:
+            raise ValueError("eval_polynomial_batch: equal lengths expected")
+    ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+    ffi.check(ffi.lib().sg_fr_eval_poly_batch_dev(ptrs, C.c_size_t(n), ffi.ptr(pts), C.c_uint32(m),
+                                                  ffi.current_stream_ptr(), ffi.ptr(out)))
+    return out
+
+
 def kate_division(a, b, with_remainder: bool = False):
     """halo2 arithmetic::kate_division: quotient of a(X) by (X - b) on a device tensor; returns n - 1 coefficients
     (and a(b) when asked)"""

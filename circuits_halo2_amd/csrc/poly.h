@@ -9,6 +9,11 @@ namespace sg {
 hipError_t poly_eval(const fp_words* d_coeffs, size_t n, const words8& x, fp_words* d_tmp_a, fp_words* d_tmp_b,
                      fp_words* d_out, hipStream_t stream);
 size_t poly_eval_tmp_elems(size_t n);
+// out[j] = polys[j](xs[j]) for m <= EVAL_BATCH_MAX polynomials of n <= 2^26 coefficients each, two launches;
+// d_partial: m * ceil(n / 8192) elements
+static constexpr uint32_t EVAL_BATCH_MAX = 40;
+hipError_t poly_eval_batch(const fp_words* const* d_polys, const words8* xs, uint32_t m, size_t n, fp_words* d_partial,
+                           fp_words* d_out, hipStream_t stream);
 // in place; zeros stay zero
 hipError_t poly_batch_invert(fp_words* d_a, size_t n, hipStream_t stream);
 // out[0] = 1, out[i] = a[0] * ... * a[i-1], i <= n (n + 1 outputs); n <= 2^21

@@ -26,10 +26,10 @@ __device__ __forceinline__ void store_hat(fp_words* p, const f29& x_hat) {  // x
 // thread: Horner over CH consecutive coefficients; workgroup: pairwise fold with x^(CH*2^l);
 // one partial per workgroup, folded again by the same kernel until one value is left.
 static constexpr uint32_t EV_CH = 32, EV_THREADS = 256;
-__global__ void __launch_bounds__(256) eval_poly_kernel(const fp_words* __restrict__ c, uint32_t n, words8 xw,
-                                                        uint32_t log_stride, fp_words* __restrict__ out) {
+__device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, uint32_t n, const words8& xw,
+                                                uint32_t log_stride, fp_words* __restrict__ out,
+                                                uint32_t (*sh)[9]) {
   // element i of this level has weight x^(i << log_stride)
-  __shared__ uint32_t sh[EV_THREADS][9];
   const uint32_t tid = threadIdx.x;
   f29 x = f29_words_to_r261<P>(xw.l);
   for (uint32_t k = 0; k < log_stride; k++) x = f29_sqr<P>(x);   // x^(2^log_stride)
@@ -67,6 +67,25 @@ __global__ void __launch_bounds__(256) eval_poly_kernel(const fp_words* __restri
     for (int q = 0; q < 9; q++) r.l[q] = sh[0][q];
     store_hat(out + blockIdx.x, r);
   }
+}
+__global__ void __launch_bounds__(256) eval_poly_kernel(const fp_words* __restrict__ c, uint32_t n, words8 xw,
+                                                        uint32_t log_stride, fp_words* __restrict__ out) {
+  __shared__ uint32_t sh[EV_THREADS][9];
+  eval_poly_block(c, n, xw, log_stride, out, sh);
+}
+// m polynomials of one length, each at its own point: grid (blocks, m); level 0 reads the polynomials, level
+// 1 folds the per-block partials (partials[j * stride ..]) into out[j]
+struct EvalBatchArgs {
+  const fp_words* polys[EVAL_BATCH_MAX];
+  words8 x[EVAL_BATCH_MAX];
+};
+__global__ void __launch_bounds__(256) eval_poly_batch_kernel(EvalBatchArgs a, uint32_t n, uint32_t level,
+                                                              uint32_t stride, fp_words* __restrict__ partial,
+                                                              fp_words* __restrict__ out) {
+  __shared__ uint32_t sh[EV_THREADS][9];
+  const uint32_t j = blockIdx.y;
+  if (level == 0) eval_poly_block(a.polys[j], n, a.x[j], 0, partial + (size_t)j * stride, sh);
+  else eval_poly_block(partial + (size_t)j * stride, n, a.x[j], 13, out + j, sh);
 }
 
 // ---- batch inversion (zeros stay zero, like ff::BatchInvert) --------------------------------
@@ -412,6 +431,20 @@ hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t
   return hipGetLastError();
 }
 
+hipError_t poly_eval_batch(const fp_words* const* d_polys, const words8* xs, uint32_t m, size_t n, fp_words* d_partial,
+                           fp_words* d_out, hipStream_t stream) {
+  if (m == 0 || m > EVAL_BATCH_MAX) return hipErrorInvalidValue;
+  const uint32_t blocks = (uint32_t)((n + (size_t)EV_CH * EV_THREADS - 1) / ((size_t)EV_CH * EV_THREADS));
+  if (n == 0 || blocks > EV_CH * EV_THREADS) return hipErrorInvalidValue;
+  EvalBatchArgs a;
+  for (uint32_t j = 0; j < m; j++) {
+    a.polys[j] = d_polys[j];
+    a.x[j] = xs[j];
+  }
+  eval_poly_batch_kernel<<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
+  eval_poly_batch_kernel<<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
+  return hipGetLastError();
+}
 hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,
                               fp_words* d_rem, hipStream_t stream) {
   if (n == 0) return hipSuccess;

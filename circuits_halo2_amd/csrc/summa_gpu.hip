@@ -902,6 +902,37 @@ int sg_fr_eval_poly_dev(const void* d_coeffs, size_t n, const uint8_t x[32], voi
   if (e != hipSuccess) return hip_fail("eval_poly", e);
   return download(out, tmp + 2 * t, 32, s);
 }
+// The evaluation phase of a proof (35 eval_polynomial calls for MstInclusion) as batches: every polynomial
+// at its own point, two launches and one read-back per batch of 40
+int sg_fr_eval_poly_batch_dev(const void* const* d_polys, size_t n, const uint8_t* points, uint32_t m, void* stream,
+                              uint8_t* out) {
+  if (m && (!d_polys || !points || !out)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly_batch: null argument");
+  if (n > (1ull << 26)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly_batch: polynomial too long");
+  if (m == 0) return SG_OK;
+  if (n == 0) {
+    std::memset(out, 0, 32 * (size_t)m);
+    return SG_OK;
+  }
+  for (uint32_t j = 0; j < m; j++)
+    if (!d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_eval_poly_batch: null polynomial");
+  LOCKED_CTX();
+  const size_t blocks = (n + 8191) / 8192;
+  hipError_t e = g_ctx->scratch.reserve((EVAL_BATCH_MAX * (blocks + 1)) * 32);
+  if (e != hipSuccess) return hip_fail("eval_poly work space", e);
+  fp_words* partial = reinterpret_cast<fp_words*>(g_ctx->scratch.p);
+  fp_words* d_out = partial + EVAL_BATCH_MAX * blocks;
+  hipStream_t s = pick_stream(stream);
+  for (uint32_t first = 0; first < m; first += EVAL_BATCH_MAX) {
+    const uint32_t cnt = std::min<uint32_t>(EVAL_BATCH_MAX, m - first);
+    words8 xs[EVAL_BATCH_MAX];
+    std::memcpy(xs, points + 32 * (size_t)first, 32 * (size_t)cnt);
+    e = poly_eval_batch(reinterpret_cast<const fp_words* const*>(d_polys + first), xs, cnt, n, partial, d_out, s);
+    if (e != hipSuccess) return hip_fail("eval_poly_batch", e);
+    int rc = download(out + 32 * (size_t)first, d_out, 32 * (size_t)cnt, s);  // synchronises: scratch is reused
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
 int sg_fr_eval_poly(const uint8_t* coeffs, size_t n, const uint8_t x[32], uint8_t out[32]) {
   if (!x || !out || (n && !coeffs)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly: null argument");
   const void* d = nullptr;

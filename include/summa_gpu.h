@@ -163,6 +163,9 @@ int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* str
  * (the 35 evaluations of create_proof) */
 int sg_fr_eval_poly(const uint8_t* coeffs, size_t n, const uint8_t x[32], uint8_t out[32]);
 int sg_fr_eval_poly_dev(const void* d_coeffs, size_t n, const uint8_t x[32], void* stream, uint8_t out[32]);
+/* m evaluations in one go: out[j] = polys[j](points[j]); all polynomials have n coefficients (n <= 2^26) */
+int sg_fr_eval_poly_batch_dev(const void* const* d_polys, size_t n, const uint8_t* points, uint32_t m, void* stream,
+                              uint8_t* out);
 /* ff::BatchInvert::batch_invert: in place, zeros stay zero */
 int sg_fr_batch_invert_dev(void* d_a, size_t n, void* stream);
 /* exclusive prefix product, the core of the permutation / lookup grand products (steps 5-6):

@@ -714,6 +714,16 @@ def test_kate_division(gpu, O, n):
     assert (q0.cpu().numpy() == a[32:]).all()
 
 
+@pytest.mark.parametrize("n,m", [(1, 3), (100, 1), (8192, 5), (8193, 2), (1 << 17, 35), (300000, 41)])
+def test_eval_polynomial_batch(gpu, O, n, m):
+    from circuits_halo2_amd.arithmetic import eval_polynomial_batch
+    polys = [O.random_fr(2600 + j % 7, n) for j in range(m)]
+    pts = O.random_fr(2650 + m, m)
+    got = eval_polynomial_batch([dev(p) for p in polys], pts)
+    for j in range(m):
+        assert (got[j] == O.fr_eval_poly(polys[j], pts[32 * j:32 * j + 32].copy())).all()
+
+
 def test_lincomb(gpu, O):
     from circuits_halo2_amd.arithmetic import lincomb
     for m, n in [(1, 5), (2, 1000), (5, 4096), (31, 3000), (32, 513)]:

@@ -1,0 +1,2 @@
+#!/bin/bash
+for m in 1 2 3 5 8; do M=$m python tools/run_fixed_batch.py "$@" || exit 1; done
