@@ -29,7 +29,7 @@ MADS_PER_MIXED_ADD = 6 * 162 + 2 * 126 + 243   # v_mad_u64_u32 per XYZZ += affin
 MAD_PEAK = 30.1e12             # measured v_mad_u64_u32 lane-ops/s, full occupancy (microbench2)
 
 
-def pmc_traffic(kernel, log_n):
+def pmc_traffic(kernel, log_n, grid_threads=None):
     """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/*_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     same command at the default 2^20 workload); null when no matching profile exists."""
@@ -41,7 +41,8 @@ def pmc_traffic(kernel, log_n):
         cands = [(int(k.split("@grid")[1]), v) for k, v in pm.items()
                  if k.startswith(kernel + "@") and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v]
         if cands:
-            _, v = max(cands)
+            # the same kernel also runs at other sizes (fused batches): take the launch shape of the timed MSM
+            _, v = min(cands, key=lambda gv: abs(gv[0] - grid_threads)) if grid_threads else max(cands)
             raw = (v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024
             return {"traffic": raw, "traffic_source": os.path.basename(path),
                     "traffic_note": "FETCH_SIZE + WRITE_SIZE, uncorrected (64-B gathers are uncalibrated on gfx950; "
@@ -130,7 +131,7 @@ def main():
         line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
-        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n))
+        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, -(-reps[0]["tasks"] // 256) * 256))
         line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
                                  ("digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}
         line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket")})

@@ -261,13 +261,13 @@ __global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ 
 // carry[k] = sum_{u > k} bval[u] * (b^KD_BLOCK)^(u - k - 1): the value of s just above block k
 __global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ bval, uint32_t nblk, words8 b) {
   __shared__ uint32_t sh[1024][9];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;        // nthr = power of two >= nblk: log2(nthr) scan steps
   f29 w[10];
   kd_powers(f29_words_to_r261<P>(b.l), w, 10, 8);             // b^(KD_BLOCK * 2^j)
   f29 mine = tid < nblk ? load_hat(bval + tid) : f29_zero();
-  block_suffix_geometric(mine, w, sh, tid, 1024);             // sh[t] = inclusive suffix value
+  block_suffix_geometric(mine, w, sh, tid, nthr);             // sh[t] = inclusive suffix value
   f29 carry = f29_zero();
-  if (tid + 1 < 1024) {
+  if (tid + 1 < nthr) {
 #pragma unroll
     for (int q = 0; q < 9; q++) carry.l[q] = sh[tid + 1][q];
   }
@@ -451,7 +451,9 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
   const uint32_t nblk = (uint32_t)((n + KD_BLOCK - 1) / KD_BLOCK);
   if (nblk > 1024) return hipErrorInvalidValue;
   kate_blocks<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp);
-  kate_scan_blocks<<<1, 1024, 0, stream>>>(d_tmp, nblk, b);
+  uint32_t scan_threads = 64;
+  while (scan_threads < nblk) scan_threads <<= 1;
+  kate_scan_blocks<<<1, scan_threads, 0, stream>>>(d_tmp, nblk, b);
   kate_write<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp, d_q, d_rem);
   return hipGetLastError();
 }
