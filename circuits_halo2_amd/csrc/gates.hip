@@ -6,8 +6,8 @@
 // circuit-specific part is the program, which the Rust side already holds, not this code.
 //
 // Host side (compile_gates): the graph is lowered to a straight-line program over LDS slots --
-//   * every value lives in the 2^261 (hat) limb form; column words are converted on load with one
-//     product, constants once per workgroup;
+//   * every value lives in the 2^261 (hat) limb form; column words are shifted left by 5 bits on load
+//     (which is that form, with bound 32, at no cost), constants are converted once per workgroup;
 //   * additions / subtractions are lazy (bound tracking as in the curve code); a reduction (product
 //     with 1^) is inserted only where the next product would exceed bound_a * bound_b <= 170;
 //   * Store is an alias, Horner expands to product + sum per part, loads are emitted at first use;
@@ -80,10 +80,19 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
     switch (code) {
       case G_LOADCOL: {
         const size_t i = (row + ((size_t)(int64_t)(int32_t)op.b << rot_shift)) & mask;
-        r = f29_mul<P>(f29_load_r256<P>(a.cols[op.a] + i), f29_const<P>(P::r266));
+        uint32_t w[8];
+        fp_words_load(a.cols[op.a] + i, w);
+        // kidx 0: memory words shifted left by 5 bits ARE the 2^261 form (bound 32), no product;
+        // kidx 1: converted with one product (bound 2) -- for values with several consumers
+        r = kidx ? f29_mul<P>(f29_from_words<0>(w), f29_const<P>(P::r266)) : f29_from_words<5>(w);
         break;
       }
-      case G_LOADPREV: r = f29_mul<P>(f29_load_r256<P>(a.values + row), f29_const<P>(P::r266)); break;
+      case G_LOADPREV: {
+        uint32_t w[8];
+        fp_words_load(a.values + row, w);
+        r = f29_from_words<5>(w);
+        break;
+      }
       case G_ADD: r = f29_add(get(ak, op.a), get(bk, op.b)); break;
       case G_SUB: r = sub_k(kidx, get(ak, op.a), get(bk, op.b)); break;
       case G_MUL: r = f29_mul<P>(get(ak, op.a), get(bk, op.b)); break;
@@ -209,6 +218,26 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
   // while the previous use is at most RELOAD_DISTANCE instructions back; beyond that a fresh load
   // (32-byte read + one product) is cheaper than pinning an LDS slot
   constexpr size_t RELOAD_DISTANCE = 48;
+  // column words (canonical, < p) can enter as x~ << 5 = x^ with bound 32 for free; the bound tracker then
+  // inserts a reduction only if a consumer needs one (a product with a bound-2 value does not).  A query
+  // that is referenced more than once is converted at the load instead (one product, bound 2), so that the
+  // reduction is not repeated in every expression it feeds.
+  constexpr uint32_t LOAD_BOUND = 32;
+  std::map<std::pair<uint32_t, int32_t>, uint32_t> refs;
+  {
+    auto note = [&](const sg_value_source& v) {
+      if (v.kind < SG_VS_FIXED || v.kind > SG_VS_INSTANCE || v.rotation >= g.n_rotations) return;
+      const uint32_t base = v.kind == SG_VS_FIXED ? 0 : v.kind == SG_VS_ADVICE ? n_fixed : n_fixed + n_advice;
+      refs[std::make_pair(base + v.index, g.rotations[v.rotation])]++;
+    };
+    for (uint32_t q = 0; q < g.n_calculations; q++) {
+      const sg_calculation& cal = g.calculations[q];
+      note(cal.a);
+      if (cal.op <= SG_OP_MUL || cal.op == SG_OP_HORNER) note(cal.b);
+      if (cal.op == SG_OP_HORNER && (uint64_t)cal.parts_offset + cal.parts_len <= g.n_horner_parts)
+        for (uint32_t t = 0; t < cal.parts_len; t++) note(g.horner_parts[cal.parts_offset + t]);
+    }
+  }
   std::map<std::pair<uint32_t, int32_t>, std::pair<Val, size_t>> loaded;
   Val prev{GK_SLOT, 0xffffffffu};
   std::vector<Val> inter(g.n_calculations);
@@ -231,8 +260,9 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
           it->second.second = c.ir.size();
           return it->second.first;
         }
-        uint32_t d = c.new_value(2);
-        IrOp op{G_LOADCOL, 0, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}};
+        const bool convert = refs[key] > 1;
+        uint32_t d = c.new_value(convert ? 2 : LOAD_BOUND);
+        IrOp op{G_LOADCOL, convert ? 1u : 0u, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}};
         op.col = key.first; op.rot = key.second;
         c.ir.push_back(op);
         loaded[key] = std::make_pair(Val{GK_SLOT, d}, c.ir.size());
@@ -247,7 +277,7 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
       case SG_VS_Y: return Val{GK_CONST, c_beta + 3};
       case SG_VS_PREVIOUS_VALUE:
         if (prev.index == 0xffffffffu) {
-          uint32_t d = c.new_value(2);
+          uint32_t d = c.new_value(LOAD_BOUND);
           c.ir.push_back({G_LOADPREV, 0, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}});
           prev = Val{GK_SLOT, d};
         }

@@ -133,6 +133,9 @@ struct Context {
   hipEvent_t ev_in = nullptr;
   DevBuf<uint8_t> stage_a, stage_b, scratch, gate_blob;
   std::vector<uint8_t> gate_blob_host;
+  // in-place multi-pass transforms need a scratch vector; one per caller stream, so that transforms
+  // enqueued on a side stream never share it with work in flight on another stream
+  std::map<hipStream_t, DevBuf<uint8_t>> ntt_scratch;
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
@@ -201,9 +204,10 @@ int ntt_dev(const fp_words* in, size_t in_len, fp_words* out, uint32_t log_n, co
   if (log_n > 28) return fail(SG_ERR_INVALID, "log_n exceeds the 2-adicity (28) of BN254 Fr");
   fp_words* scratch = nullptr;
   if (in == out && log_n > c.ntt.config().max_single_log) {
-    hipError_t e = c.scratch.reserve((size_t)32 << log_n);
+    DevBuf<uint8_t>& buf = c.ntt_scratch[s];
+    hipError_t e = buf.reserve((size_t)32 << log_n);
     if (e != hipSuccess) return hip_fail("ntt scratch", e);
-    scratch = reinterpret_cast<fp_words*>(c.scratch.p);
+    scratch = reinterpret_cast<fp_words*>(buf.p);
   }
   // plans are generated on the same stream the transform runs on
   hipError_t e = c.ntt.transform(in, in_len, out, scratch, log_n, omega, scale, pre3, post3, s);
@@ -297,6 +301,8 @@ void sg_shutdown(void) {
   g_ctx->stage_b.release();
   g_ctx->scratch.release();
   g_ctx->gate_blob.release();
+  for (auto& kv : g_ctx->ntt_scratch) kv.second.release();
+  g_ctx->ntt_scratch.clear();
   if (g_ctx->d_consts) (void)hipFree(g_ctx->d_consts);
   if (g_ctx->stream) (void)hipStreamDestroy(g_ctx->stream);
   delete g_ctx;

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 
-def run_flow(k=17, n_gates=24, reps=3, verbose=False):
+def run_flow(k=17, n_gates=24, reps=3, overlap=True):
     import torch
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import arithmetic as A
@@ -48,17 +48,36 @@ def run_flow(k=17, n_gates=24, reps=3, verbose=False):
     one = to_montgomery_host(np.array([1, 0, 0, 0], dtype=np.uint64).view(np.uint8).reshape(1, 32)).reshape(-1) if False else fr1(999)
     delta4 = fr1(998)
 
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+
+    def to_extended(cols):
+        """Lagrange columns -> (coefficients, extended-coset evaluations).  With overlap on, the transforms are
+        enqueued on a side stream BEFORE the commitments of the same phase: they do not depend on the phase's
+        challenge and fill the latency-bound stretches (sort, merge, bucket reduction, host tail) of the MSMs."""
+        if overlap:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                co = [dom.lagrange_to_coeff(c.clone()) for c in cols]
+                return co, [dom.coeff_to_extended(c) for c in co]
+        co = [dom.lagrange_to_coeff(c.clone()) for c in cols]
+        return co, [dom.coeff_to_extended(c) for c in co]
+
     def flow():
         t = {}
         sync = torch.cuda.synchronize
         t0 = time.perf_counter()
         # 1: advice commitments
+        if overlap:
+            co1, ex1 = to_extended(advice + [instance])
         c_adv = params.commit_batch(advice, lagrange=True)
         t["1_advice_commit"] = time.perf_counter() - t0; t1 = time.perf_counter()
         theta = fr1(int(c_adv[0, 0]) + 500)
         # 2: lookup permuted columns (the sort itself is host work upstream)
         a_in, s_tab = advice[0], advice[1]
         a_perm, s_perm = advice[2], instance
+        if overlap:
+            co2, ex2 = to_extended([a_perm, s_perm])
         c_lk = params.commit_batch([a_perm, s_perm], lagrange=True)
         t["2_lookup_permuted_commit"] = time.perf_counter() - t1; t1 = time.perf_counter()
         beta, gamma = fr1(int(c_lk[0, 0]) + 501), fr1(int(c_lk[1, 0]) + 502)
@@ -66,15 +85,19 @@ def run_flow(k=17, n_gates=24, reps=3, verbose=False):
         z0 = A.permutation_product(perm_cols_lag[:4], sigma_lag[:4], beta, gamma, one, k)
         z1 = A.permutation_product(perm_cols_lag[4:], sigma_lag[4:], beta, gamma, delta4, k, z0=z0[32 * (n - 6):32 * (n - 5)].cpu().numpy())
         zl = A.lookup_product(a_in, s_tab, a_perm, s_perm, beta, gamma)
+        if overlap:
+            co3, ex3 = to_extended([z0, z1, zl])
         c_z = params.commit_batch([z0, z1, zl], lagrange=True)
         rand_poly = advice[0]
         c_r = params.commit(rand_poly)
         t["3_grand_products_commit"] = time.perf_counter() - t1; t1 = time.perf_counter()
         y = fr1(int(c_z[0, 0]) + 503)
         # 4: quotient
-        lag = advice + [instance, a_perm.clone(), s_perm.clone(), z0, z1, zl]
-        coeffs = [dom.lagrange_to_coeff(c.clone()) for c in lag]                      # 9 x iNTT(2^k)
-        ext = [dom.coeff_to_extended(c) for c in coeffs]                              # 9 x NTT(2^(k+3))
+        if overlap:
+            main.wait_stream(side)
+            coeffs, ext = co1 + co2 + co3, ex1 + ex2 + ex3
+        else:
+            coeffs, ext = to_extended(advice + [instance, a_perm, s_perm, z0, z1, zl])   # 9 x iNTT(2^k), 9 x NTT(2^(k+3))
         e_adv, e_inst, e_ap, e_sp, e_z0, e_z1, e_zl = ext[:3], ext[3], ext[4], ext[5], ext[6], ext[7], ext[8]
         sync(); t["4a_ntts"] = time.perf_counter() - t1; t2 = time.perf_counter()
         values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
@@ -129,4 +152,5 @@ if __name__ == "__main__":
     assert torch.cuda.is_available()
     ffi.check(ffi.lib().sg_init(0))
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
-    print(json.dumps(run_flow(k), indent=1))
+    for ov in (False, True):
+        print("overlap" if ov else "serial", json.dumps(run_flow(k, overlap=ov)))
