@@ -215,7 +215,7 @@ def main():
                 from proof_flow import run_flow
                 del a20
                 torch.cuda.empty_cache()
-                flow = run_flow(17, n_gates=24, reps=3)
+                flow = run_flow(17, n_gates=24, reps=3, overlap=False)
                 line["proof_flow_k17"] = {"ms": flow["total"], "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
                                           "rows_per_s": (1 << 17) / (flow["total"] * 1e-3),
                                           "note": "synthetic create_proof-shaped schedule (MstInclusion column/argument counts, "
