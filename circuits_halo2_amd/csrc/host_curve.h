@@ -171,5 +171,128 @@ inline void jac_to_affine_bytes(const Jac& p, uint8_t out[64]) {
   std::memcpy(out + 32, ay.v, 32);
 }
 
+// ---- G2 (verifier side of ParamsKZG: g2 and s_g2 = tau * g2).  Two scalar multiplications per SRS, on the
+// host: Fq2 = Fq[u] / (u^2 + 1), Jacobian coordinates, a = 0 formulas as above.
+struct Fq2 {
+  Fq c0, c1;
+  static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
+  static Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
+  bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  Fq2 operator+(const Fq2& o) const { return Fq2{c0 + o.c0, c1 + o.c1}; }
+  Fq2 operator-(const Fq2& o) const { return Fq2{c0 - o.c0, c1 - o.c1}; }
+  Fq2 operator*(const Fq2& o) const {  // Karatsuba, u^2 = -1
+    Fq a = c0 * o.c0, b = c1 * o.c1, m = (c0 + c1) * (o.c0 + o.c1);
+    return Fq2{a - b, m - a - b};
+  }
+  Fq2 sqr() const { return Fq2{(c0 + c1) * (c0 - c1), (c0 * c1).dbl()}; }
+  Fq2 dbl() const { return *this + *this; }
+  Fq2 inv() const {  // (c0 - c1 u) / (c0^2 + c1^2)
+    Fq n = (c0.sqr() + c1.sqr()).inv();
+    return Fq2{c0 * n, Fq::zero() - c1 * n};
+  }
+};
+struct G2Jac {
+  Fq2 x, y, z;
+  static G2Jac identity() { return G2Jac{Fq2::one(), Fq2::one(), Fq2::zero()}; }
+  bool is_identity() const { return z.is_zero(); }
+};
+inline G2Jac g2_double(const G2Jac& p) {
+  if (p.is_identity()) return p;
+  Fq2 a = p.x.sqr(), b = p.y.sqr(), c = b.sqr();
+  Fq2 d = ((p.x + b).sqr() - a - c).dbl();
+  Fq2 e = a.dbl() + a, f = e.sqr();
+  G2Jac r;
+  r.x = f - d.dbl();
+  r.y = e * (d - r.x) - c.dbl().dbl().dbl();
+  r.z = (p.y * p.z).dbl();
+  return r;
+}
+inline G2Jac g2_add(const G2Jac& p, const G2Jac& q) {
+  if (p.is_identity()) return q;
+  if (q.is_identity()) return p;
+  Fq2 z1z1 = p.z.sqr(), z2z2 = q.z.sqr();
+  Fq2 u1 = p.x * z2z2, u2 = q.x * z1z1;
+  Fq2 s1 = p.y * q.z * z2z2, s2 = q.y * p.z * z1z1;
+  if (u1 == u2) return s1 == s2 ? g2_double(p) : G2Jac::identity();
+  Fq2 h = u2 - u1, hh = h.sqr(), hhh = h * hh, r = s2 - s1, v = u1 * hh;
+  G2Jac o;
+  o.x = r.sqr() - hhh - v.dbl();
+  o.y = r * (v - o.x) - s1 * hhh;
+  o.z = p.z * q.z * h;
+  return o;
+}
+// the standard BN254 G2 generator (the g2 of every halo2 ParamsKZG, e.g. the reference's hermez-raw-11),
+// Montgomery form
+inline G2Jac g2_generator() {
+  static constexpr uint64_t X0[4] = {0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL};
+  static constexpr uint64_t X1[4] = {0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL};
+  static constexpr uint64_t Y0[4] = {0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL};
+  static constexpr uint64_t Y1[4] = {0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+  G2Jac g;
+  std::memcpy(g.x.c0.v, X0, 32); std::memcpy(g.x.c1.v, X1, 32);
+  std::memcpy(g.y.c0.v, Y0, 32); std::memcpy(g.y.c1.v, Y1, 32);
+  g.z = Fq2::one();
+  return g;
+}
+// Montgomery Fr scalar (32 B) -> canonical integer words: one Montgomery product with 1
+inline void fr_from_montgomery(const uint8_t in[32], uint64_t out[4]) {
+  static constexpr uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  static constexpr uint64_t RINV = 0xc2e1f593efffffffULL;
+  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::memcpy(t, in, 32);
+  uint64_t top = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t m = t[i] * RINV;
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)m * R[j] + t[i + j];
+      t[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    for (int k = i + 4; k < 8 && c; k++) {
+      c += t[k];
+      t[k] = (uint64_t)c;
+      c >>= 64;
+    }
+    top += (uint64_t)c;
+  }
+  (void)top;  // t[4..8) < 2r after the reduction of a value < r * 2^256
+  uint64_t r[4] = {t[4], t[5], t[6], t[7]};
+  bool ge = true;
+  for (int i = 3; i >= 0; i--) {
+    if (r[i] != R[i]) { ge = r[i] > R[i]; break; }
+  }
+  if (ge) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 d = (u128)r[i] - R[i] - borrow;
+      r[i] = (uint64_t)d;
+      borrow = (uint64_t)(d >> 64) & 1;
+    }
+  }
+  std::memcpy(out, r, 32);
+}
+// out = scalar * G2 generator as halo2curves G2Affine bytes (x.c0 || x.c1 || y.c0 || y.c1, Montgomery);
+// identity = 128 zero bytes
+inline void g2_generator_mul(const uint8_t scalar_mont[32], uint8_t out[128]) {
+  uint64_t k[4];
+  fr_from_montgomery(scalar_mont, k);
+  const G2Jac g = g2_generator();
+  G2Jac acc = G2Jac::identity();
+  for (int bit = 255; bit >= 0; bit--) {
+    acc = g2_double(acc);
+    if ((k[bit >> 6] >> (bit & 63)) & 1) acc = g2_add(acc, g);
+  }
+  if (acc.is_identity()) {
+    std::memset(out, 0, 128);
+    return;
+  }
+  Fq2 zi = acc.z.inv(), zi2 = zi.sqr();
+  Fq2 ax = acc.x * zi2, ay = acc.y * zi2 * zi;
+  std::memcpy(out, ax.c0.v, 32); std::memcpy(out + 32, ax.c1.v, 32);
+  std::memcpy(out + 64, ay.c0.v, 32); std::memcpy(out + 96, ay.c1.v, 32);
+}
+
 }  // namespace host
 }  // namespace sg

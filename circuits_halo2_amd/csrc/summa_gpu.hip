@@ -789,6 +789,12 @@ int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) 
   if (!n) return SG_OK;
   return download(out_affine, g_ctx->stage_b.p, n * 64, g_ctx->stream);
 }
+// Verifier side of ParamsKZG::setup: scalar * (G2 generator) on the host (g2 = 1 * G2, s_g2 = tau * G2)
+int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]) {
+  if (!scalar || !out) return fail(SG_ERR_INVALID, "sg_g2_generator_mul: null argument");
+  sg::host::g2_generator_mul(scalar, out);
+  return SG_OK;
+}
 // ParamsKZG::<Bn256>::setup(k, rng) with tau supplied by the caller's RNG (zk_prover/src/circuits/
 // utils.rs:70): g[i] = tau^i G, g_lagrange[i] = L_i(tau) G.  (g2 / s_g2 are verifier-side, not built.)
 int sg_kzg_setup_dev(uint32_t k, const uint8_t tau[32], void* d_g, void* d_g_lagrange, void* stream) {

@@ -54,7 +54,19 @@ class ParamsKZG:
         g = np.zeros(64 << k, dtype=np.uint8)
         gl = np.zeros(64 << k, dtype=np.uint8)
         ffi.check(ffi.lib().sg_kzg_setup(C.c_uint32(k), ffi.ptr(t), ffi.ptr(g), ffi.ptr(gl)))
-        return cls(k, g, gl)
+        # verifier side: g2 = G2 generator, s_g2 = tau * g2 (two scalar multiplications over Fq2, host code)
+        one = np.zeros(32, dtype=np.uint8)
+        one[:] = np.frombuffer(bytes.fromhex("fbffff4f1c3496ac29cd609f9576fc362e4679786fa36e662fdf079ac1770a0e"), dtype=np.uint8)
+        g2, s_g2 = np.zeros(128, dtype=np.uint8), np.zeros(128, dtype=np.uint8)
+        ffi.check(ffi.lib().sg_g2_generator_mul(ffi.ptr(one), ffi.ptr(g2)))
+        ffi.check(ffi.lib().sg_g2_generator_mul(ffi.ptr(t), ffi.ptr(s_g2)))
+        return cls(k, g, gl, g2.tobytes(), s_g2.tobytes())
+
+    def write(self) -> bytes:
+        """ParamsKZG::write (RawBytes): k || g || g_lagrange || g2 || s_g2 -- the container `read` parses"""
+        if len(self.g2) != 128 or len(self.s_g2) != 128:
+            raise ValueError("params without g2 / s_g2 cannot be serialised")
+        return struct.pack("<I", self.k) + self.g.tobytes() + self.g_lagrange.tobytes() + bytes(self.g2) + bytes(self.s_g2)
 
     @classmethod
     def setup_from_tau_powers(cls, k: int, tau_powers_mont: np.ndarray, lagrange_evals_mont: np.ndarray):

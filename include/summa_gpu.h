@@ -139,6 +139,9 @@ int sg_domain_constant(uint32_t k, int which, uint8_t out[32]);
 int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine);
 int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine, void* stream);
 
+/* The two G2 points of ParamsKZG (verifier side): out = scalar * G2 generator in halo2curves' G2Affine
+ * layout (x.c0 || x.c1 || y.c0 || y.c1, 32-B Montgomery Fq each); g2 = 1 * G2, s_g2 = tau * G2.  Host code. */
+int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]);
 /* ParamsKZG::<Bn256>::setup(k, rng) (zk_prover/src/circuits/utils.rs:70) with tau = the field
  * element the caller drew from its RNG (32 B Montgomery Fr): g[i] = tau^i * G,
  * g_lagrange[i] = L_i(tau) * G, 2^k points of 64 B each.  The G2 elements of the SRS are only

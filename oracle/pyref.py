@@ -455,3 +455,51 @@ def mst_build(entries):
         level = [mst_middle(level[i], level[i + 1]) for i in range(0, len(level), 2)]
         levels.append(level)
     return levels[-1][0], levels
+
+
+# --------------------------------------------------------------------------- G2 (verifier side of the SRS)
+# BN254 G2: y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2+1); only the group law is needed here (g2, s_g2 of
+# ParamsKZG: SURVEY.md K1 -- the container's last 256 bytes).  Elements of Fq2 are pairs (c0, c1).
+G2_GENERATOR = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+                 11559732032986387107991004021392285783925812861821192530917403151452391805634),
+                (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+                 4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def _f2_add(a, b): return ((a[0] + b[0]) % Q, (a[1] + b[1]) % Q)
+def _f2_sub(a, b): return ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)
+def _f2_mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+
+
+def _f2_inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, Q)
+    return (a[0] * n % Q, -a[1] * n % Q)
+
+
+def g2_add(p, q):
+    """affine addition on G2; None = identity"""
+    if p is None: return q
+    if q is None: return p
+    if p[0] == q[0]:
+        if p[1] != q[1] or p[1] == (0, 0):
+            return None
+        lam = _f2_mul(_f2_mul((3, 0), _f2_mul(p[0], p[0])), _f2_inv(_f2_add(p[1], p[1])))
+    else:
+        lam = _f2_mul(_f2_sub(q[1], p[1]), _f2_inv(_f2_sub(q[0], p[0])))
+    x3 = _f2_sub(_f2_sub(_f2_mul(lam, lam), p[0]), q[0])
+    return (x3, _f2_sub(_f2_mul(lam, _f2_sub(p[0], x3)), p[1]))
+
+
+def g2_mul(p, k: int):
+    acc = None
+    for bit in bin(k % R)[2:] if k % R else "":
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, p)
+    return acc
+
+
+def g2_to_bytes(p) -> bytes:
+    if p is None:
+        return bytes(128)
+    return b"".join(fq_to_bytes(c) for c in (p[0][0], p[0][1], p[1][0], p[1][1]))

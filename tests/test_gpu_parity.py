@@ -392,7 +392,23 @@ def test_params_setup_matches_bigint(gpu, O, P):
     evals = O.random_fr(9, n)
     coeffs = gpu.EvaluationDomain(3, k).lagrange_to_coeff(evals)
     assert (params.commit_lagrange(evals) == params.commit(coeffs)).all()
+    # verifier side and the RawBytes container: g2 = generator, s_g2 = tau * g2, write() / read() round trip
+    assert params.g2 == P.g2_to_bytes(P.G2_GENERATOR)
+    assert params.s_g2 == P.g2_to_bytes(P.g2_mul(P.G2_GENERATOR, tau))
+    raw = params.write()
+    assert len(raw) == 4 + 2 * 64 * n + 256
+    again = gpu.ParamsKZG.read(raw)
+    assert again.k == k and (again.g == params.g).all() and (again.g_lagrange == params.g_lagrange).all()
+    assert again.g2 == params.g2 and again.s_g2 == params.s_g2
     params.free()
+
+
+def test_params_write_reproduces_the_reference_container(gpu):
+    """read() then write() gives back the reference's SRS fixture byte for byte (K1)"""
+    import os
+    from conftest import GOLDEN
+    raw = open(os.path.join(GOLDEN, "hermez-raw-11"), "rb").read()
+    assert gpu.ParamsKZG.read(raw).write() == raw
 
 
 def test_k11_proof_op_shapes_on_reference_srs(gpu, O, srs11):

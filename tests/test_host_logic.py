@@ -122,3 +122,26 @@ def test_host_point_sum_matches_bigint(srs11):
     assert P.g1_from_bytes(out.tobytes()) == P.g1_mul(P.g1_from_bytes(p.tobytes()), 2)
     from circuits_halo2_amd.distributed import combine_partials
     assert P.g1_from_bytes(combine_partials(pts).tobytes()) == want
+
+
+def test_g2_generator_mul_matches_fixture_and_bigint(srs11):
+    """sg_g2_generator_mul (host code, the verifier half of ParamsKZG::setup): 1 * G2 reproduces the g2 bytes
+    of the reference's SRS container; tau * G2 and edge scalars match the big-integer group law"""
+    import os
+    from conftest import GOLDEN
+    from circuits_halo2_amd import ffi
+    from oracle import pyref as P
+    raw = open(os.path.join(GOLDEN, "hermez-raw-11"), "rb").read()
+    g2_fixture = raw[4 + 128 * 2048:4 + 128 * 2048 + 128]
+    assert g2_fixture == P.g2_to_bytes(P.G2_GENERATOR)
+    out = np.zeros(128, dtype=np.uint8)
+
+    def mul(k):
+        ffi.check(ffi.lib().sg_g2_generator_mul(ffi.ptr(np.frombuffer(P.fr_to_bytes(k % P.R), dtype=np.uint8).copy()), ffi.ptr(out)))
+        return out.tobytes()
+
+    assert mul(1) == g2_fixture
+    assert mul(0) == bytes(128)
+    for k in (2, 3, 0xDEADBEEF, P.R - 1, P.random_fr(5, 1)[0]):
+        assert mul(k) == P.g2_to_bytes(P.g2_mul(P.G2_GENERATOR, k))
+    assert mul(P.R - 1) == P.g2_to_bytes((P.G2_GENERATOR[0], ((-P.G2_GENERATOR[1][0]) % P.Q, (-P.G2_GENERATOR[1][1]) % P.Q)))
