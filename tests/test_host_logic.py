@@ -145,3 +145,25 @@ def test_g2_generator_mul_matches_fixture_and_bigint(srs11):
     for k in (2, 3, 0xDEADBEEF, P.R - 1, P.random_fr(5, 1)[0]):
         assert mul(k) == P.g2_to_bytes(P.g2_mul(P.G2_GENERATOR, k))
     assert mul(P.R - 1) == P.g2_to_bytes((P.G2_GENERATOR[0], ((-P.G2_GENERATOR[1][0]) % P.Q, (-P.G2_GENERATOR[1][1]) % P.Q)))
+
+
+def test_header_is_plain_c_and_a_c_client_links():
+    """the drop-in boundary is a C ABI: the header compiles as C99 (-pedantic) and a plain-C client links
+    against the library and runs its host-side entry points (tests/c/abi_client.c)"""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "summa_gpu.h")])
+    libdir = os.path.join(ROOT, "circuits_halo2_amd")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "abi_client")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc,
+                               os.path.join(ROOT, "tests", "c", "abi_client.c"), "-o", exe, "-L", libdir, "-lsumma_gpu",
+                               "-Wl,-rpath," + libdir])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        assert "abi client ok" in out.stdout
