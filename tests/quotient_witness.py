@@ -99,3 +99,40 @@ def lookup_witness(k, blinding, seed, beta, gamma):
 def top_coefficients_zero(coeffs, first_zero):
     """coeffs: full 2^ext_k coefficient vector (numpy bytes)"""
     return not coeffs[32 * first_zero:].any()
+
+
+def verifier_numerator(ev, beta, gamma, y, x, chunk_len):
+    """The constraint equation a halo2 verifier evaluates at the challenge point x, with Python integers, in the
+    order the reference's generated verifier folds it (contracts/src/InclusionVerifier.sol:903-997: quotient
+    numerator = ((...(gate) * y + perm_0) * y + ...) ; custom gates first, then permutation, then lookup).
+    ev: dict of evaluations (ints) -- see test_quotient_pipeline_satisfying_witness."""
+    R = P.R
+    acc = 0
+    fold = lambda acc, term: (acc * y + term) % R
+    # custom gate  q (ga * gb(omega x) - gc)
+    acc = fold(acc, ev["gq"] * (ev["ga"] * ev["gb_next"] - ev["gc"]))
+    # permutation argument
+    zs, zs_next, zs_last = ev["z"], ev["z_next"], ev["z_last"]
+    acc = fold(acc, ev["l0"] * (1 - zs[0]))
+    acc = fold(acc, ev["l_last"] * (zs[-1] * zs[-1] - zs[-1]))
+    for s in range(1, len(zs)):
+        acc = fold(acc, ev["l0"] * (zs[s] - zs_last[s - 1]))
+    delta_pow = 1
+    col = 0
+    ncols = len(ev["cols"])
+    for s in range(len(zs)):
+        left, right = zs_next[s], zs[s]
+        for _ in range(min(chunk_len, ncols - col)):
+            left = left * (ev["cols"][col] + beta * ev["sigma"][col] + gamma) % R
+            right = right * (ev["cols"][col] + beta * delta_pow * x + gamma) % R
+            delta_pow = delta_pow * P.DELTA % R
+            col += 1
+        acc = fold(acc, ev["l_active"] * (left - right))
+    # lookup argument
+    z, zn = ev["lz"], ev["lz_next"]
+    acc = fold(acc, ev["l0"] * (1 - z))
+    acc = fold(acc, ev["l_last"] * (z * z - z))
+    acc = fold(acc, ev["l_active"] * (zn * (ev["ap"] + beta) * (ev["sp"] + gamma) - z * (ev["a"] + beta) * (ev["s"] + gamma)))
+    acc = fold(acc, ev["l0"] * (ev["ap"] - ev["sp"]))
+    acc = fold(acc, ev["l_active"] * (ev["ap"] - ev["sp"]) * (ev["ap"] - ev["ap_prev"]))
+    return acc % R

@@ -987,6 +987,29 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     first_zero = (deg - 1) * n - deg + 1
     assert W.top_coefficients_zero(h(full), first_zero)
     assert h(ffi_check_full).any()
+    # the verifier's equation at a random point: h(x) (x^n - 1) == numerator(x), the right-hand side from the
+    # single-point formulas of the reference's generated verifier (W.verifier_numerator, Python integers) on
+    # evaluations of the committed polynomials -- ties the extended-coset pipeline to the verifier's view
+    from oracle import pyref as PR
+    toi = lambda b: PR.fr_from_bytes(bytes(b))
+    xi = PR.random_fr(4242 + k, 1)[0]
+    w = PR.omega_for(k)
+    pts = {"x": xi, "next": xi * w % PR.R, "prev": xi * pow(w, -1, PR.R) % PR.R,
+           "last": xi * pow(w, -(blinding + 1), PR.R) % PR.R}
+    co = lambda col: O.lagrange_to_coeff(col, k)
+    ev_at = lambda coeffs, pt: toi(O.fr_eval_poly(coeffs, fr_np([pts[pt]])))
+    c_z = [co(t) for t in zs]
+    c_lz, c_ap = co(z), co(ap)
+    ev = {"l0": ev_at(co(l0), "x"), "l_last": ev_at(co(l_last), "x"), "l_active": ev_at(co(l_active), "x"),
+          "z": [ev_at(c, "x") for c in c_z], "z_next": [ev_at(c, "next") for c in c_z],
+          "z_last": [ev_at(c, "last") for c in c_z],
+          "cols": [ev_at(co(c), "x") for c in cols], "sigma": [ev_at(co(c), "x") for c in sigmas],
+          "lz": ev_at(c_lz, "x"), "lz_next": ev_at(c_lz, "next"), "ap": ev_at(c_ap, "x"), "ap_prev": ev_at(c_ap, "prev"),
+          "sp": ev_at(co(sp), "x"), "a": ev_at(co(a), "x"), "s": ev_at(co(s), "x"),
+          "gq": ev_at(co(gq), "x"), "ga": ev_at(co(ga), "x"), "gb_next": ev_at(co(gb), "next"), "gc": ev_at(co(gc), "x")}
+    num_x = W.verifier_numerator(ev, toi(beta), toi(gamma), toi(y), xi, chunk_len)
+    h_x = toi(O.fr_eval_poly(h(full), fr_np([xi])))
+    assert h_x * (pow(xi, n, PR.R) - 1) % PR.R == num_x
     # tamper: one cell of one permutation column
     bad = cols[1].copy()
     bad[32 * 3:32 * 4] = O.fr_add(bad[32 * 3:32 * 4].copy(), W.fr_np([1]))
