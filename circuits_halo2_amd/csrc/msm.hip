@@ -1172,7 +1172,7 @@ hipError_t MsmEngine::enqueue_back() {
   const xyzz29_mem* cur = partial_[0].p;
   // quad-cooperative additions pay off while the reduction is a latency chain (few buckets in total);
   // with many windows it is throughput-bound and one lane per addition is the efficient shape
-  const bool quad = cfg_.quad == 2 || (cfg_.quad == 1 && NB <= (1u << 17));
+  const bool quad = cfg_.quad == 2 || (cfg_.quad == 1 && NB <= (1u << 18));  // measured crossover: tools/small_batches2.sh
   int lvl = 0, pbuf = 0;
   uint32_t items_ub = ntasks;  // upper bound of the number of partial sums alive at this level
   // heavy buckets: fold their partial sums until every bucket owns at most one
