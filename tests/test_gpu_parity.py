@@ -286,6 +286,39 @@ def test_msm_edge_cases(gpu, O, P, srs11):
         gpu.best_multiexp(fr_np([1, 2]), p)
 
 
+@pytest.mark.parametrize("n", [600, 5000, 1 << 15])
+def test_msm_repeated_and_opposite_bases(gpu, O, P, n):
+    """every special case of the group law inside the pipeline: the same point many times in one bucket
+    (P + P in accumulate, equal partial sums in merge / reduction: the doubling fallbacks, also of the
+    quad-cooperative addition), P and -P cancelling to the identity; generic, fixed-base and fused paths"""
+    g = O.g1_generator()
+    gi = P.g1_from_bytes(g.tobytes())
+    neg = point_np(P.g1_neg(gi))
+    rng = np.random.default_rng(n)
+    small = [int(v) for v in rng.integers(0, 4, size=n)]                    # few distinct digits: deep equal buckets
+    sc_small = fr_np(small)
+    sc_rand = O.random_fr(3000 + n, n)
+    same = np.tile(g, n)
+    total = lambda sc: O.fixed_base_mul(O.fr_dot(sc, fr_np([1] * n)), 1)   # (sum s_i) * G
+    assert (gpu.best_multiexp(sc_small, same) == total(sc_small)).all()
+    assert (gpu.best_multiexp(sc_rand, same) == total(sc_rand)).all()
+    assert (gpu.best_multiexp(np.tile(sc_rand[:32], n), same) == total(np.tile(sc_rand[:32], n))).all()
+    # alternating P, -P with equal scalars in pairs: everything cancels
+    alt = np.concatenate([g, neg] * (n // 2))
+    pair_sc = np.repeat(O.random_fr(3100 + n, n // 2).reshape(-1, 32), 2, axis=0).reshape(-1)
+    assert not gpu.best_multiexp(pair_sc, alt).any()
+    k = max(1, (n - 1).bit_length())
+    pad = (1 << k) - n
+    params = gpu.ParamsKZG(k, np.concatenate([same, np.tile(g, pad)]), np.concatenate([alt, np.tile(g, pad)]))
+    params.precompute()
+    assert (params.commit(sc_small) == total(sc_small)).all()
+    assert (params.commit(sc_rand) == total(sc_rand)).all()
+    assert not params.commit_lagrange(pair_sc).any()
+    got = params.commit_batch([dev(sc_small), dev(sc_rand), dev(sc_small)])
+    assert (got[0] == total(sc_small)).all() and (got[1] == total(sc_rand)).all() and (got[2] == got[0]).all()
+    params.free()
+
+
 def test_msm_skewed_buckets(gpu, O, P, srs11):
     """selector-like / sorted-lookup-like scalar vectors put most points in a few buckets:
     heavy buckets are split into tasks and folded in merge rounds"""
