@@ -41,6 +41,25 @@ extern "C" {
     // device-resident variants (`*_dev`) take HIP pointers; a Rust prover that keeps its
     // polynomials in HBM binds them the same way (see include/summa_gpu.h)
     pub fn sg_msm_g1_dev(s: *const c_void, b: *const c_void, n: size_t, stream: *mut c_void, out: *mut u8) -> c_int;
+    pub fn sg_commit_batch_dev(
+        handle: u64,
+        basis: c_int,
+        d_scalars: *const *const c_void,
+        count: size_t,
+        n: size_t,
+        stream: *mut c_void,
+        out_affine: *mut u8,
+    ) -> c_int;
+    pub fn sg_fr_eval_poly_batch_dev(
+        d_polys: *const *const c_void,
+        n: size_t,
+        points: *const u8,
+        m: u32,
+        stream: *mut c_void,
+        out: *mut u8,
+    ) -> c_int;
+    pub fn sg_fr_kate_division_dev(d_a: *const c_void, n: size_t, b: *const u8, d_q: *mut c_void, rem: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn sg_g2_generator_mul(scalar: *const u8, out128: *mut u8) -> c_int;
 }
 
 const _: () = assert!(std::mem::size_of::<Fr>() == 32);
@@ -117,6 +136,11 @@ impl SrsHandle {
         let mut h = 0u64;
         check(unsafe { sg_srs_upload(k, g.as_ptr() as *const u8, g_lagrange.as_ptr() as *const u8, &mut h) })?;
         Ok(SrsHandle(h))
+    }
+    /// Build the fixed-base window tables once (both bases); every later commit takes the fixed-base path.
+    pub fn precompute(&self) -> Result<(), GpuError> {
+        check(unsafe { sg_srs_precompute(self.0, 0, 0) })?;
+        check(unsafe { sg_srs_precompute(self.0, 1, 0) })
     }
     /// basis: false = `ParamsKZG::commit` (monomial g), true = `commit_lagrange`
     pub fn commit(&self, lagrange: bool, poly: &[Fr]) -> Result<G1, GpuError> {
