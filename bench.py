@@ -156,73 +156,76 @@ def main():
         line["batched"] = {"msms": 8, "ms_per_msm": bdt / 8 * 1e3, "points_per_s": 8 * n / bdt}
 
         if not args.no_extras and world == 1 and args.log_n >= 20:
-            line["ntt"] = {}
-            for lg in (17, 22):
-                a = fr_to_montgomery(torch.from_numpy(random_fr_canonical(DEFAULT_SEED + 100 + lg, 1 << lg)).cuda())
-                ms = C.c_float(0)
-                ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a), C.c_uint32(lg), 20, C.byref(ms)))
-                gbs = NTT_BYTES_PER_ELEM * (1 << lg) / (ms.value * 1e-3) / 1e9
-                line["ntt"][f"2^{lg}"] = {"ms": ms.value, "elements_per_s": (1 << lg) / (ms.value * 1e-3),
-                                          "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-                del a
-            # k = 17 proof op list: 16 MSM(2^17) + 9 iNTT(2^17) + 9 NTT(2^20) + 1 iNTT(2^20)
-            k = 17
-            s17, b17 = scal[: 32 << k], bases[: 64 << k]
-            sg.best_multiexp_batch([(s17, b17)] * 16)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            sg.best_multiexp_batch([(s17, b17)] * 16)
-            torch.cuda.synchronize()
-            msm17 = (time.perf_counter() - t1) * 1e3
-            a20 = scal[: 32 << 20].clone()
-            ms20 = C.c_float(0)
-            ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a20), C.c_uint32(20), 10, C.byref(ms20)))
-            ntt_ms = 9 * line["ntt"]["2^17"]["ms"] + 10 * ms20.value
-            # the same 16 commitments the way a prover with a resident SRS issues them: ParamsKZG.commit_batch
-            # over the precomputed window table (sg_srs_precompute; one-off cost reported beside it)
-            b17 = b17.cpu().numpy()
-            params = sg.ParamsKZG(k, b17, b17)
-            generic = params.commit_batch([s17] * 16)
-            t1 = time.perf_counter()
-            params.precompute(0)
-            pre_ms = (time.perf_counter() - t1) * 1e3
-            fixed = params.commit_batch([s17] * 16)
-            assert (fixed == generic).all(), "fixed-base commit differs from the generic MSM"
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                params.commit_batch([s17] * 16)
-            torch.cuda.synchronize()
-            msm17_fixed = (time.perf_counter() - t1) / 5 * 1e3
-            t1 = time.perf_counter()
-            for _ in range(10):
-                params.commit(s17)
-            one17_fixed = (time.perf_counter() - t1) / 10 * 1e3
-            params.free()
-            line["proof_oplist_k17"] = {"msm16x2^17_ms": msm17, "msm16x2^17_fixed_base_ms": msm17_fixed,
-                                        "single_commit_2^17_fixed_base_ms": one17_fixed,
-                                        "srs_precompute_once_ms": pre_ms, "ntt_19_ms": ntt_ms,
-                                        "sum_ms": msm17_fixed + ntt_ms, "sum_generic_msm_ms": msm17 + ntt_ms,
-                                        "rows_per_s": (1 << k) / ((msm17_fixed + ntt_ms) * 1e-3),
-                                        "note": "MSM+NTT kernel sum only; sum_ms uses the resident-SRS commit path "
-                                                "(fixed-base window table), sum_generic_msm_ms arbitrary bases"}
+            try:  # extras never cost the headline line
+                line["ntt"] = {}
+                for lg in (17, 22):
+                    a = fr_to_montgomery(torch.from_numpy(random_fr_canonical(DEFAULT_SEED + 100 + lg, 1 << lg)).cuda())
+                    ms = C.c_float(0)
+                    ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a), C.c_uint32(lg), 20, C.byref(ms)))
+                    gbs = NTT_BYTES_PER_ELEM * (1 << lg) / (ms.value * 1e-3) / 1e9
+                    line["ntt"][f"2^{lg}"] = {"ms": ms.value, "elements_per_s": (1 << lg) / (ms.value * 1e-3),
+                                              "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+                    del a
+                # k = 17 proof op list: 16 MSM(2^17) + 9 iNTT(2^17) + 9 NTT(2^20) + 1 iNTT(2^20)
+                k = 17
+                s17, b17 = scal[: 32 << k], bases[: 64 << k]
+                sg.best_multiexp_batch([(s17, b17)] * 16)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sg.best_multiexp_batch([(s17, b17)] * 16)
+                torch.cuda.synchronize()
+                msm17 = (time.perf_counter() - t1) * 1e3
+                a20 = scal[: 32 << 20].clone()
+                ms20 = C.c_float(0)
+                ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a20), C.c_uint32(20), 10, C.byref(ms20)))
+                ntt_ms = 9 * line["ntt"]["2^17"]["ms"] + 10 * ms20.value
+                # the same 16 commitments the way a prover with a resident SRS issues them: ParamsKZG.commit_batch
+                # over the precomputed window table (sg_srs_precompute; one-off cost reported beside it)
+                b17 = b17.cpu().numpy()
+                params = sg.ParamsKZG(k, b17, b17)
+                generic = params.commit_batch([s17] * 16)
+                t1 = time.perf_counter()
+                params.precompute(0)
+                pre_ms = (time.perf_counter() - t1) * 1e3
+                fixed = params.commit_batch([s17] * 16)
+                assert (fixed == generic).all(), "fixed-base commit differs from the generic MSM"
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    params.commit_batch([s17] * 16)
+                torch.cuda.synchronize()
+                msm17_fixed = (time.perf_counter() - t1) / 5 * 1e3
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    params.commit(s17)
+                one17_fixed = (time.perf_counter() - t1) / 10 * 1e3
+                params.free()
+                line["proof_oplist_k17"] = {"msm16x2^17_ms": msm17, "msm16x2^17_fixed_base_ms": msm17_fixed,
+                                            "single_commit_2^17_fixed_base_ms": one17_fixed,
+                                            "srs_precompute_once_ms": pre_ms, "ntt_19_ms": ntt_ms,
+                                            "sum_ms": msm17_fixed + ntt_ms, "sum_generic_msm_ms": msm17 + ntt_ms,
+                                            "rows_per_s": (1 << k) / ((msm17_fixed + ntt_ms) * 1e-3),
+                                            "note": "MSM+NTT kernel sum only; sum_ms uses the resident-SRS commit path "
+                                                    "(fixed-base window table), sum_generic_msm_ms arbitrary bases"}
 
-            # the whole create_proof op schedule at k = 17 with its Fiat-Shamir sync points (tools/proof_flow.py):
-            # 16 commitments in 6 groups, 9 + 9 + 1 transforms, evaluate_h (gates + permutation + lookup), 35
-            # evaluations, multi-open -- synthetic witness and a stand-in gate program, every op through the C ABI
-            try:
-                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-                from proof_flow import run_flow
-                del a20
-                torch.cuda.empty_cache()
-                flow = run_flow(17, n_gates=24, reps=3, overlap=False)
-                line["proof_flow_k17"] = {"ms": flow["total"], "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
-                                          "rows_per_s": (1 << 17) / (flow["total"] * 1e-3),
-                                          "note": "synthetic create_proof-shaped schedule (MstInclusion column/argument counts, "
-                                                  "24 stand-in Poseidon-round gates), host syncs at the 6 challenge points, "
-                                                  "Python/ctypes driver overhead included"}
-            except Exception as ex:  # the flow is an extra: never lose the headline line over it
-                line["proof_flow_k17"] = {"error": repr(ex)}
+                # the whole create_proof op schedule at k = 17 with its Fiat-Shamir sync points (tools/proof_flow.py):
+                # 16 commitments in 6 groups, 9 + 9 + 1 transforms, evaluate_h (gates + permutation + lookup), 35
+                # evaluations, multi-open -- synthetic witness and a stand-in gate program, every op through the C ABI
+                try:
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                    from proof_flow import run_flow
+                    del a20
+                    torch.cuda.empty_cache()
+                    flow = run_flow(17, n_gates=24, reps=3, overlap=False)
+                    line["proof_flow_k17"] = {"ms": flow["total"], "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
+                                              "rows_per_s": (1 << 17) / (flow["total"] * 1e-3),
+                                              "note": "synthetic create_proof-shaped schedule (MstInclusion column/argument counts, "
+                                                      "24 stand-in Poseidon-round gates), host syncs at the 6 challenge points, "
+                                                      "Python/ctypes driver overhead included"}
+                except Exception as ex:  # the flow is an extra: never lose the headline line over it
+                    line["proof_flow_k17"] = {"error": repr(ex)}
+            except Exception as ex:
+                line["extras_error"] = repr(ex)
 
         # ---- CPU baseline for the NTT numbers above (same oracle, same box)
         if not args.no_cpu and world == 1 and "ntt" in line:
