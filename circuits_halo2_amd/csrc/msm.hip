@@ -430,13 +430,8 @@ static inline uint32_t task_block_for(uint32_t NB, uint32_t nbins) {
   return tb;
 }
 
-__device__ __forceinline__ uint32_t task_len(uint32_t cnt, uint32_t seg, uint32_t log_L) {
-  uint32_t rem = cnt - (seg << log_L);
-  return min(rem, 1u << log_L);
-}
 // thist[bin * nblk + blk] = number of tasks of (clamped) length `bin` in block blk
-__global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict__ cnt,
-                                                     const uint32_t* __restrict__ ntask, uint32_t NB,
+__global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t NB,
                                                      uint32_t log_L, uint32_t task_block,
                                                      uint32_t* __restrict__ thist) {
   __shared__ uint32_t s_h[TASK_BINS];
@@ -496,8 +491,7 @@ __global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thi
   }
 }
 // order[pos] = (bucket, segment) of the task that runs as thread `pos`
-__global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restrict__ cnt,
-                                                        const uint32_t* __restrict__ ntask, uint32_t NB,
+__global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restrict__ cnt, uint32_t NB,
                                                         uint32_t log_L, uint32_t task_block,
                                                         const uint32_t* __restrict__ thist,
                                                         uint2* __restrict__ order) {
@@ -1163,9 +1157,9 @@ hipError_t MsmEngine::enqueue_back() {
     const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
     SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
     SG_TRY(order_.reserve(ntasks));
-    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, tb, thist_.p);
+    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
     msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins);
-    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, ntask_[0].p, NB, log_L, tb, thist_.p, order_.p);
+    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
   }
   msm_accumulate<<<(ntasks + 255) / 256, 256, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
                                                            toff_[0].p, order_.p, log_L, ntasks, partial_[0].p);
