@@ -649,6 +649,20 @@ def test_ntt_batch(gpu, O, log_n):
         assert (got.cpu().numpy() == v).all()
 
 
+def test_cpp_host_mirror_parity(gpu):
+    """include/summa_gpu.hpp (best_multiexp, best_fft, EvaluationDomain, ParamsKZG in C++ over the C ABI) against
+    the oracle: tests/cpp/parity_main.cpp, built by __graft_entry__.build()"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "parity_main")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/parity_main not built")
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "hermez-raw-11")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+
+
 def test_quad_cooperative_add_selftest(gpu):
     """xyzz29_add_quad (4 lanes per point addition, DPP exchanges) against the one-lane formulas on
     1024 operand pairs including P + P, P + (-P) and identity operands (tools/test_quad.hip, built by

@@ -167,3 +167,18 @@ def test_header_is_plain_c_and_a_c_client_links():
         out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
         assert "abi client ok" in out.stdout
+
+
+def test_cpp_host_mirror_compiles_and_links():
+    """include/summa_gpu.hpp + tests/cpp/parity_main.cpp build with g++ -Wall -Wextra -Werror (the program itself
+    needs a GPU and runs under -m gpu)"""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "parity_main.cpp"), "-o", os.path.join(tmp, "parity_main"),
+                               "-L", os.path.join(ROOT, "circuits_halo2_amd"), "-lsumma_gpu", "-L", os.path.join(ROOT, "oracle"),
+                               "-loracle"])
