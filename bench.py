@@ -208,6 +208,24 @@ def main():
                                             "note": "MSM+NTT kernel sum only; sum_ms uses the resident-SRS commit path "
                                                     "(fixed-base window table), sum_generic_msm_ms arbitrary bases"}
 
+                # witness side (row W): Merkle sum tree of 2^20 users, 1 currency (the reference bench's LEVELS = 20
+                # shape, zk_prover/benches/full_solvency_flow.rs:13-16): Poseidon leaves + 20 levels on the device
+                depth, nc = 20, 1
+                d_users, d_bals = scal[: 32 << depth], scal[: (32 * nc) << depth].clone()
+                d_bals.view(-1, 32)[:, 8:] = 0                      # 64-bit balances (N_BYTES = 8), Montgomery form not needed for timing
+                nodes = (2 << depth) - 1
+                d_h = torch.empty(32 * nodes, dtype=torch.uint8, device="cuda")
+                d_b = torch.empty(32 * nodes * nc, dtype=torch.uint8, device="cuda")
+                build = lambda: ffi.check(sg.lib().sg_mst_build_dev(ffi.dev_ptr(d_users), ffi.dev_ptr(d_bals), C.c_uint32(depth),
+                                                                    C.c_uint32(nc), ffi.dev_ptr(d_h), ffi.dev_ptr(d_b), None))
+                build(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                build(); torch.cuda.synchronize()
+                mst_ms = (time.perf_counter() - t1) * 1e3
+                line["witness_mst_2^20"] = {"ms": mst_ms, "poseidon_permutations_per_s": ((1 << depth) * (1 + nc) + ((1 << depth) - 1) * (2 + nc)) / (mst_ms * 1e-3),
+                                            "note": "leaf = H(username, balances) = 1 + nc absorptions, middle = H(sum balances, left, right) = 2 + nc; "
+                                                    "one permutation per absorbed element at rate 1"}
+                del d_h, d_b, d_bals
                 # the whole create_proof op schedule at k = 17 with its Fiat-Shamir sync points (tools/proof_flow.py):
                 # 16 commitments in 6 groups, 9 + 9 + 1 transforms, evaluate_h (gates + permutation + lookup), 35
                 # evaluations, multi-open -- synthetic witness and a stand-in gate program, every op through the C ABI
