@@ -136,6 +136,9 @@ struct Context {
   // in-place multi-pass transforms need a scratch vector; one per caller stream, so that transforms
   // enqueued on a side stream never share it with work in flight on another stream
   std::map<hipStream_t, DevBuf<uint8_t>> ntt_scratch;
+  // work space of the scan-type helpers (prefix / grand products, Kate division): per (stream, slot), so
+  // that the calls are asynchronous -- work on one stream is ordered, other streams own other buffers
+  std::map<std::pair<hipStream_t, int>, DevBuf<uint8_t>> stream_scratch;
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
@@ -213,6 +216,13 @@ int ntt_dev(const fp_words* in, size_t in_len, fp_words* out, uint32_t log_n, co
   hipError_t e = c.ntt.transform(in, in_len, out, scratch, log_n, omega, scale, pre3, post3, s);
   if (e != hipSuccess) return hip_fail("ntt", e);
   return SG_OK;
+}
+
+hipError_t scratch_for(hipStream_t s, int slot, size_t bytes, uint8_t** out) {
+  DevBuf<uint8_t>& buf = g_ctx->stream_scratch[std::make_pair(s, slot)];
+  hipError_t e = buf.reserve(bytes);  // growing frees the old buffer, which waits for the device: safe
+  *out = buf.p;
+  return e;
 }
 
 int upload(DevBuf<uint8_t>& buf, const uint8_t* host, size_t bytes, hipStream_t s) {
@@ -303,6 +313,8 @@ void sg_shutdown(void) {
   g_ctx->gate_blob.release();
   for (auto& kv : g_ctx->ntt_scratch) kv.second.release();
   g_ctx->ntt_scratch.clear();
+  for (auto& kv : g_ctx->stream_scratch) kv.second.release();
+  g_ctx->stream_scratch.clear();
   if (g_ctx->d_consts) (void)hipFree(g_ctx->d_consts);
   if (g_ctx->stream) (void)hipStreamDestroy(g_ctx->stream);
   delete g_ctx;
@@ -967,12 +979,12 @@ int sg_fr_prefix_product_dev(const void* d_a, size_t n, void* d_out, void* strea
   if (!d_out || (n && !d_a)) return fail(SG_ERR_INVALID, "sg_fr_prefix_product: null argument");
   if (n > (1ull << 21) - 1) return fail(SG_ERR_INVALID, "sg_fr_prefix_product: at most 2^21 - 1 elements");
   LOCKED_CTX();
-  hipError_t e = g_ctx->scratch.reserve(prefix_product_tmp_elems(n + 1) * 32 + 64);
-  if (e != hipSuccess) return hip_fail("prefix_product work space", e);
   hipStream_t s = pick_stream(stream);
-  e = poly_prefix_product(static_cast<const fp_words*>(d_a), n, reinterpret_cast<fp_words*>(g_ctx->scratch.p),
+  uint8_t* tmp = nullptr;
+  hipError_t e = scratch_for(s, 0, prefix_product_tmp_elems(n + 1) * 32 + 64, &tmp);
+  if (e != hipSuccess) return hip_fail("prefix_product work space", e);
+  e = poly_prefix_product(static_cast<const fp_words*>(d_a), n, reinterpret_cast<fp_words*>(tmp),
                           static_cast<fp_words*>(d_out), n + 1, nullptr, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the scratch buffer is shared
   if (e != hipSuccess) return hip_fail("prefix_product", e);
   return SG_OK;
 }
@@ -981,15 +993,15 @@ static const uint32_t DELTA_M[8] = {0xefd78855u, 0x9a0c322bu, 0x249b563cu, 0x46e
                                     0xe0b0b7a7u, 0x5983a663u, 0xaaa111adu, 0x22ab452bu};  // Montgomery-2^256 words
 static int grand_product_tail(fp_words* d_mod, size_t n, const uint8_t* z0, void* d_z, hipStream_t s) {
   // z[0] = z0 (or 1), z[i] = z[i-1] * mod[i-1], n values
-  hipError_t e = g_ctx->scratch.reserve(prefix_product_tmp_elems(n + 1) * 32 + 64);
+  uint8_t* tmp = nullptr;
+  hipError_t e = scratch_for(s, 0, prefix_product_tmp_elems(n + 1) * 32 + 64, &tmp);
   if (e != hipSuccess) return hip_fail("grand product work space", e);
   words8 init;
   if (z0) std::memcpy(&init, z0, 32);
-  e = poly_prefix_product(d_mod, n, reinterpret_cast<fp_words*>(g_ctx->scratch.p), static_cast<fp_words*>(d_z), n,
+  e = poly_prefix_product(d_mod, n, reinterpret_cast<fp_words*>(tmp), static_cast<fp_words*>(d_z), n,
                           z0 ? &init : nullptr, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return hip_fail("grand product", e);
-  return SG_OK;
+  return SG_OK;  // asynchronous: ordered on the caller's stream
 }
 int sg_permutation_product_dev(const void* const* d_values, const void* const* d_sigma, uint32_t ncols,
                                const uint8_t beta[32], const uint8_t gamma[32], const uint8_t delta_start[32],
@@ -1007,13 +1019,14 @@ int sg_permutation_product_dev(const void* const* d_values, const void* const* d
     cols.values[c] = static_cast<const fp_words*>(d_values[c]);
     cols.sigma[c] = static_cast<const fp_words*>(d_sigma[c]);
   }
-  hipError_t e = g_ctx->stage_b.reserve(n * 32 + 64);
+  hipStream_t s = pick_stream(stream);
+  uint8_t* modb = nullptr;
+  hipError_t e = scratch_for(s, 1, n * 32 + 64, &modb);
   if (e != hipSuccess) return hip_fail("grand product work space", e);
-  fp_words* mod = reinterpret_cast<fp_words*>(g_ctx->stage_b.p);
+  fp_words* mod = reinterpret_cast<fp_words*>(modb);
   words8 b, g, ds, dl;
   std::memcpy(&b, beta, 32); std::memcpy(&g, gamma, 32); std::memcpy(&ds, delta_start, 32);
   std::memcpy(&dl, DELTA_M, 32);
-  hipStream_t s = pick_stream(stream);
   e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 0, mod, s);
   if (e == hipSuccess) e = poly_batch_invert(mod, n, s);
   if (e == hipSuccess) e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 1, mod, s);
@@ -1027,12 +1040,13 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
       n > (1u << 21) - 1)
     return fail(SG_ERR_INVALID, "sg_lookup_product: bad argument");
   LOCKED_CTX();
-  hipError_t e = g_ctx->stage_b.reserve(n * 32 + 64);
+  hipStream_t s = pick_stream(stream);
+  uint8_t* modb = nullptr;
+  hipError_t e = scratch_for(s, 1, n * 32 + 64, &modb);
   if (e != hipSuccess) return hip_fail("grand product work space", e);
-  fp_words* mod = reinterpret_cast<fp_words*>(g_ctx->stage_b.p);
+  fp_words* mod = reinterpret_cast<fp_words*>(modb);
   words8 b, g;
   std::memcpy(&b, beta, 32); std::memcpy(&g, gamma, 32);
-  hipStream_t s = pick_stream(stream);
   e = poly_lookup_fraction(static_cast<const fp_words*>(d_permuted_input), static_cast<const fp_words*>(d_permuted_table),
                            b, g, n, 0, mod, s);
   if (e == hipSuccess) e = poly_batch_invert(mod, n, s);
@@ -1065,16 +1079,20 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
     return SG_OK;
   }
   LOCKED_CTX();
-  hipError_t e = g_ctx->scratch.reserve(1025 * 32 + 64);
-  if (e != hipSuccess) return hip_fail("kate_division work space", e);
   words8 bw;
   std::memcpy(&bw, b, 32);
   hipStream_t s = pick_stream(stream);
-  fp_words* tmp = reinterpret_cast<fp_words*>(g_ctx->scratch.p);
+  uint8_t* tb = nullptr;
+  hipError_t e = scratch_for(s, 0, 1025 * 32 + 64, &tb);
+  if (e != hipSuccess) return hip_fail("kate_division work space", e);
+  fp_words* tmp = reinterpret_cast<fp_words*>(tb);
   e = poly_kate_division(static_cast<const fp_words*>(d_a), n, bw, tmp, static_cast<fp_words*>(d_q),
                          remainder_out ? tmp + 1024 : nullptr, s);
-  if (e == hipSuccess && remainder_out) e = hipMemcpyAsync(remainder_out, tmp + 1024, 32, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the scratch buffer is shared
+  // asynchronous unless the caller wants the remainder on the host
+  if (e == hipSuccess && remainder_out) {
+    e = hipMemcpyAsync(remainder_out, tmp + 1024, 32, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
   if (e != hipSuccess) return hip_fail("kate_division", e);
   return SG_OK;
 }

@@ -23,7 +23,9 @@
  *
  * Conventions: every function returns SG_OK (0) or a negative sg_status; nothing throws or
  * aborts; pointers are borrowed for the duration of the call; the library is thread-safe
- * (calls from several host threads are serialised per device context).  "host" entry points
+ * (calls from several host threads are serialised per device context).  "_dev" entry points are
+ * asynchronous unless they return a value to the host: the work is ordered on the given stream and the
+ * library's work space is kept per stream, so independent ops may be issued on several streams.  "host" entry points
  * take host pointers and move data themselves; "_dev" entry points take HIP device pointers
  * (e.g. torch tensors' data_ptr()) and a hipStream_t passed as void* (NULL = default stream).
  */

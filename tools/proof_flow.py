@@ -49,6 +49,7 @@ def run_flow(k=17, n_gates=24, reps=3, overlap=True):
     delta4 = fr1(998)
 
     side = torch.cuda.Stream()
+    extra = [torch.cuda.Stream(), torch.cuda.Stream()]
     main = torch.cuda.current_stream()
 
     def to_extended(cols):
@@ -82,9 +83,25 @@ def run_flow(k=17, n_gates=24, reps=3, overlap=True):
         t["2_lookup_permuted_commit"] = time.perf_counter() - t1; t1 = time.perf_counter()
         beta, gamma = fr1(int(c_lk[0, 0]) + 501), fr1(int(c_lk[1, 0]) + 502)
         # 3: grand products + commitments
-        z0 = A.permutation_product(perm_cols_lag[:4], sigma_lag[:4], beta, gamma, one, k)
-        z1 = A.permutation_product(perm_cols_lag[4:], sigma_lag[4:], beta, gamma, delta4, k, z0=z0[32 * (n - 6):32 * (n - 5)].cpu().numpy())
-        zl = A.lookup_product(a_in, s_tab, a_perm, s_perm, beta, gamma)
+        if overlap:
+            # the three grand products are independent up to one scalar (z1 continues from z0's last usable value):
+            # issue them on three streams (each is a latency chain: a field inversion alone is ~170 us on one lane),
+            # then scale z1 by that scalar
+            for st in extra:
+                st.wait_stream(main)
+            z0 = A.permutation_product(perm_cols_lag[:4], sigma_lag[:4], beta, gamma, one, k)
+            with torch.cuda.stream(extra[0]):
+                z1 = A.permutation_product(perm_cols_lag[4:], sigma_lag[4:], beta, gamma, delta4, k)
+            with torch.cuda.stream(extra[1]):
+                zl = A.lookup_product(a_in, s_tab, a_perm, s_perm, beta, gamma)
+            for st in extra:
+                main.wait_stream(st)
+            last = z0[32 * (n - 6):32 * (n - 5)]
+            z1 = A.fr_mul(z1, last.repeat(n))
+        else:
+            z0 = A.permutation_product(perm_cols_lag[:4], sigma_lag[:4], beta, gamma, one, k)
+            z1 = A.permutation_product(perm_cols_lag[4:], sigma_lag[4:], beta, gamma, delta4, k, z0=z0[32 * (n - 6):32 * (n - 5)].cpu().numpy())
+            zl = A.lookup_product(a_in, s_tab, a_perm, s_perm, beta, gamma)
         if overlap:
             co3, ex3 = to_extended([z0, z1, zl])
         c_z = params.commit_batch([z0, z1, zl], lagrange=True)
@@ -121,11 +138,19 @@ def run_flow(k=17, n_gates=24, reps=3, overlap=True):
         vs = np.tile(v, 9)
         sets = [(coeffs, 1), (coeffs[:3] + coeffs[6:], 2), (coeffs[6:7], 3)]
         quots = []
-        for ps, npoints in sets:
-            comb = A.lincomb(ps, vs[:32 * len(ps)])
-            for _ in range(npoints):
-                comb = torch.cat([A.kate_division(comb, x), torch.zeros(32, dtype=torch.uint8, device="cuda")])
-            quots.append(comb)
+        streams = [main] + extra if overlap else [main] * 3
+        if overlap:
+            for st in extra:
+                st.wait_stream(main)
+        for (ps, npoints), st in zip(sets, streams):      # the rotation sets are independent: one stream each
+            with torch.cuda.stream(st):
+                comb = A.lincomb(ps, vs[:32 * len(ps)])
+                for _ in range(npoints):
+                    comb = torch.cat([A.kate_division(comb, x), torch.zeros(32, dtype=torch.uint8, device="cuda")])
+                quots.append(comb)
+        if overlap:
+            for st in extra:
+                main.wait_stream(st)
         hx = A.lincomb(quots, vs[:32 * len(quots)])
         c_w = params.commit(hx)
         u = fr1(int(c_w[0]) + 506)
