@@ -968,7 +968,7 @@ WindowPlan make_window_plan(uint32_t c) {
 uint32_t fixed_window_bits_for(size_t n) {
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  return std::min<uint32_t>(16, std::max<uint32_t>(4, lg + 2));
+  return std::min<uint32_t>(16, std::max<uint32_t>(4, lg));  // measured: tools/sweep_fixed_c.py (k = 11 .. 17)
 }
 
 // table rows: row w = 2^(offset of window w) * bases, W x n affine points

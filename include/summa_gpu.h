@@ -91,7 +91,7 @@ int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t 
  *   row w = 2^(bit offset of window w) * basis[i],   W x 2^k affine points (W = ceil(255 / window_bits)),
  * after which sg_commit / sg_commit_dev / sg_commit_batch_dev on that basis run all W digits of a scalar
  * into ONE bucket set (one bucket reduction instead of W; wider windows at small k).  Same result
- * bits.  window_bits = 0 chooses min(16, k + 2).  Memory: W * 64 * 2^k bytes per basis. */
+ * bits.  window_bits = 0 chooses min(16, k).  Memory: W * 64 * 2^k bytes per basis. */
 int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits);
 /* `count` commitments of n scalars each against one basis, issued as fused jobs; out_affine: count x 64 B */
 int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
