@@ -19,7 +19,7 @@ struct MsmConfig {
   uint32_t log_fuse_entries = 25;  // fused batches hold at most 2^x (window, scalar) entries
   uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
-  uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^17 entries), 2 always
+  uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^19 entries), 2 always
   uint32_t log_scatter_rounds = 0;  // the counting sort's scatter runs in 2^x bucket-range rounds
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };

@@ -1059,7 +1059,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   // bucket set, sized for ~4 Ki entries per bin (half an LDS tile, so Poisson tails still fit)
   const uint32_t sets = j.fixed ? (uint32_t)M : W;
   const size_t set_entries = entries / sets;
-  const bool two_pass = cfg_.two_pass == 2 || (cfg_.two_pass == 1 && entries >= ((size_t)1 << 17));
+  const bool two_pass = cfg_.two_pass == 2 || (cfg_.two_pass == 1 && entries >= ((size_t)1 << 19));  // measured crossover
   uint32_t B = 1, shift = c - 1;
   if (two_pass) {
     while (B < 1024 && B < nbw && (set_entries / B > 4096 || (nbw / B) > 8192)) B <<= 1;
