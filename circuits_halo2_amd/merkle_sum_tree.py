@@ -73,25 +73,66 @@ def parse_csv_to_entries(path: str, n_currencies: int):
     return entries, cryptocurrencies
 
 
-class MerkleSumTree:
-    """MerkleSumTree<N_CURRENCIES, N_BYTES>: `from_csv`, `from_entries`, `root`, `generate_proof`."""
+def _hash_batch(kind: str, *arrays, n: int, nc: int):
+    """one device call over n nodes: kind 'leaf' (usernames, balances) -> hashes; 'middle' (child hashes, child
+    balances of 2n children) -> (hashes, balances)"""
+    import torch
+    L = ffi.lib()
+    dev = [torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).cuda() for a in arrays]
+    h = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    if kind == "leaf":
+        ffi.check(L.sg_mst_leaves_dev(ffi.dev_ptr(dev[0]), ffi.dev_ptr(dev[1]), C.c_size_t(n), C.c_uint32(nc), ffi.dev_ptr(h),
+                                      ffi.current_stream_ptr()))
+        return h.cpu().numpy()
+    b = torch.empty(32 * n * nc, dtype=torch.uint8, device="cuda")
+    ffi.check(L.sg_mst_level_dev(ffi.dev_ptr(dev[0]), ffi.dev_ptr(dev[1]), C.c_size_t(n), C.c_uint32(nc), ffi.dev_ptr(h),
+                                 ffi.dev_ptr(b), ffi.current_stream_ptr()))
+    return h.cpu().numpy(), b.cpu().numpy()
 
-    def __init__(self, depth, n_currencies, entries, node_hashes, node_balances):
+
+class MerkleSumTree:
+    """MerkleSumTree<N_CURRENCIES, N_BYTES> (mst.rs): `from_csv`, `from_csv_sorted`, `from_entries`, `root`,
+    `leaves`, `entries`, `index_of_username`, `update_leaf`; Tree trait (tree.rs): `generate_proof`,
+    `verify_proof`.  All Poseidon hashing runs on the device; nodes are kept level-major on the host."""
+
+    def __init__(self, depth, n_currencies, entries, node_hashes, node_balances, is_sorted=False, cryptocurrencies=None):
         self.depth, self.n_currencies, self.entries = depth, n_currencies, entries
         self._h, self._b = node_hashes, node_balances  # level-major numpy buffers
+        self.is_sorted = is_sorted
+        self.cryptocurrencies = cryptocurrencies or []
 
     @classmethod
     def from_csv(cls, path: str, n_currencies: int, n_bytes: int = 8):
-        entries, _ = parse_csv_to_entries(path, n_currencies)
-        return cls.from_entries(entries, n_currencies, n_bytes)
+        entries, crypto = parse_csv_to_entries(path, n_currencies)
+        t = cls.from_entries(entries, n_currencies, n_bytes)
+        t.cryptocurrencies = crypto
+        return t
 
     @classmethod
-    def from_entries(cls, entries, n_currencies: int, n_bytes: int = 8):
+    def from_csv_sorted(cls, path: str, n_currencies: int, n_bytes: int = 8):
+        """mst.rs:89-100: leaves sorted by the username byte values"""
+        entries, crypto = parse_csv_to_entries(path, n_currencies)
+        entries.sort(key=lambda e: e[0].encode())
+        t = cls.from_entries(entries, n_currencies, n_bytes, is_sorted=True)
+        t.cryptocurrencies = crypto
+        return t
+
+    @staticmethod
+    def _entry_fields(name: str, bal):
+        """(username field element, balance field elements) as Montgomery bytes; the zero entry is ("0", 0...)
+        with username field element 0 (entry.rs:30-38)"""
+        u = 0 if name is None else int.from_bytes(keccak256(name.encode()), "big")
+        return _to_fr_bytes(u), b"".join(_to_fr_bytes(v) for v in bal)
+
+    @classmethod
+    def from_entries(cls, entries, n_currencies: int, n_bytes: int = 8, is_sorted: bool = False):
         import torch
         n = len(entries)
         if n == 0:
             raise ValueError("empty tree")
         for _, bal in entries:
+            if len(bal) != n_currencies:
+                raise ValueError("entry with a wrong number of balances")
             if any(b >= (1 << (8 * n_bytes)) for b in bal):
                 raise ValueError("balance does not fit N_BYTES")  # range the circuit can prove (mst.rs)
         depth = max(0, (n - 1).bit_length())
@@ -99,10 +140,9 @@ class MerkleSumTree:
         users = bytearray(32 * size)      # zero entries: username 0, balances 0 (entry.rs:30-38)
         bals = bytearray(32 * size * n_currencies)
         for i, (name, bal) in enumerate(entries):
-            users[32 * i:32 * i + 32] = _to_fr_bytes(int.from_bytes(keccak256(name.encode()), "big"))
-            for c, v in enumerate(bal):
-                o = 32 * (i * n_currencies + c)
-                bals[o:o + 32] = _to_fr_bytes(v)
+            u, b = cls._entry_fields(name, bal)
+            users[32 * i:32 * i + 32] = u
+            bals[32 * i * n_currencies:32 * (i + 1) * n_currencies] = b
         d_users = torch.from_numpy(np.frombuffer(bytes(users), dtype=np.uint8).copy()).cuda()
         d_bals = torch.from_numpy(np.frombuffer(bytes(bals), dtype=np.uint8).copy()).cuda()
         nodes = 2 * size - 1
@@ -112,7 +152,8 @@ class MerkleSumTree:
                                              C.c_uint32(n_currencies), ffi.dev_ptr(d_h), ffi.dev_ptr(d_b),
                                              ffi.current_stream_ptr()))
         torch.cuda.synchronize()
-        return cls(depth, n_currencies, list(entries), d_h.cpu().numpy(), d_b.cpu().numpy())
+        padded = list(entries) + [(None, [0] * n_currencies)] * (size - n)
+        return cls(depth, n_currencies, padded, d_h.cpu().numpy(), d_b.cpu().numpy(), is_sorted)
 
     def _level_offset(self, level: int) -> int:
         size = 1 << self.depth
@@ -123,14 +164,111 @@ class MerkleSumTree:
         nc = self.n_currencies
         return self._h[32 * o:32 * o + 32], self._b[32 * o * nc:32 * (o + 1) * nc]
 
+    def _set_node(self, level: int, index: int, h, b):
+        o = self._level_offset(level) + index
+        nc = self.n_currencies
+        self._h[32 * o:32 * o + 32] = h
+        self._b[32 * o * nc:32 * (o + 1) * nc] = b
+
     def root(self):
         return self.node(self.depth, 0)
 
+    def leaves(self):
+        """(hashes, balances) of level 0"""
+        size = 1 << self.depth
+        return self._h[:32 * size], self._b[:32 * size * self.n_currencies]
+
+    def index_of_username(self, username: str) -> int:
+        """mst.rs:207-223: linear scan, or binary search when the tree was built sorted"""
+        if self.is_sorted:
+            real = [e for e in self.entries if e[0] is not None]
+            lo, hi = 0, len(real)
+            key = username.encode()
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if real[mid][0].encode() < key:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            if lo < len(real) and real[lo][0] == username:
+                return lo
+            raise KeyError("Username not found")
+        for i, (name, _) in enumerate(self.entries):
+            if name == username:
+                return i
+        raise KeyError("Username not found")
+
+    def update_leaf(self, username: str, new_balances):
+        """mst.rs:169-204: new balances for one user, the leaf and its `depth` ancestors are re-hashed (device,
+        one call per level); returns the new root (hash, balances)"""
+        nc = self.n_currencies
+        if len(new_balances) != nc:
+            raise ValueError("wrong number of balances")
+        index = self.index_of_username(username)
+        self.entries[index] = (username, list(new_balances))
+        u, b = self._entry_fields(username, new_balances)
+        ub, bb = np.frombuffer(u, dtype=np.uint8), np.frombuffer(b, dtype=np.uint8)
+        self._set_node(0, index, _hash_batch("leaf", ub, bb, n=1, nc=nc), bb)
+        cur = index
+        for level in range(1, self.depth + 1):
+            parent = cur // 2
+            lh, lb = self.node(level - 1, 2 * parent)
+            rh, rb = self.node(level - 1, 2 * parent + 1)
+            h, bsum = _hash_batch("middle", np.concatenate([lh, rh]), np.concatenate([lb, rb]), n=1, nc=nc)
+            self._set_node(level, parent, h, bsum)
+            cur = parent
+        return self.root()
+
     def generate_proof(self, index: int):
-        """tree.rs:85-137: sibling (hash, balances) per level and the path bits"""
-        sib, bits, idx = [], [], index
+        """tree.rs:85-137.  Besides the sibling nodes (hash, balances) the proof carries what the reference's
+        MerkleProof holds: the sibling leaf's hash preimage [username, balances...] and, for every level above,
+        the sibling middle node's preimage [left.bal + right.bal ..., left.hash, right.hash]."""
+        if not 0 <= index < (1 << self.depth):
+            raise IndexError("Index out of bounds")
+        nc = self.n_currencies
+        sib, bits, pre_mid, idx = [], [], [], index
         for level in range(self.depth):
             bits.append(idx & 1)
-            sib.append(self.node(level, idx ^ 1))
+            sidx = idx ^ 1
+            sib.append(self.node(level, sidx))
+            if level > 0:
+                lh, _ = self.node(level - 1, 2 * sidx)
+                rh, _ = self.node(level - 1, 2 * sidx + 1)
+                pre_mid.append(np.concatenate([self.node(level, sidx)[1], lh, rh]))
             idx >>= 1
-        return {"leaf": self.node(0, index), "siblings": sib, "path_indices": bits, "root": self.root()}
+        pre_leaf = None
+        if self.depth:
+            name, bal = self.entries[index ^ 1]
+            u, b = self._entry_fields(name, bal)
+            pre_leaf = np.frombuffer(u + b, dtype=np.uint8).copy()
+        return {"entry": self.entries[index], "leaf": self.node(0, index), "siblings": sib, "path_indices": bits,
+                "root": self.root(), "sibling_leaf_node_hash_preimage": pre_leaf,
+                "sibling_middle_node_hash_preimages": pre_mid}
+
+    def verify_proof(self, proof) -> bool:
+        """tree.rs:140-190: recompute the path from the entry and the sibling preimages (hashes on the device),
+        compare the root hash and balances"""
+        nc = self.n_currencies
+        name, bal = proof["entry"]
+        u, b = self._entry_fields(name, bal)
+        bb = np.frombuffer(b, dtype=np.uint8)
+        node_h, node_b = _hash_batch("leaf", np.frombuffer(u, dtype=np.uint8), bb, n=1, nc=nc), bb
+        for level, bit in enumerate(proof["path_indices"]):
+            if level == 0:
+                pre = proof["sibling_leaf_node_hash_preimage"]
+                sib_b = pre[32:]
+                sib_h = _hash_batch("leaf", pre[:32], sib_b, n=1, nc=nc)
+            else:
+                pre = proof["sibling_middle_node_hash_preimages"][level - 1]
+                sib_b = pre[:32 * nc]
+                # a middle node is H(balances..., left.hash, right.hash): rebuild it from two pseudo-children whose
+                # balances add up to the preimage's (left = the sums, right = zero)
+                zeros = np.zeros(32 * nc, dtype=np.uint8)
+                sib_h, chk_b = _hash_batch("middle", pre[32 * nc:], np.concatenate([sib_b, zeros]), n=1, nc=nc)
+                if not (chk_b == sib_b).all():
+                    return False
+            pair_h = np.concatenate([sib_h, node_h]) if bit else np.concatenate([node_h, sib_h])
+            pair_b = np.concatenate([sib_b, node_b]) if bit else np.concatenate([node_b, sib_b])
+            node_h, node_b = _hash_batch("middle", pair_h, pair_b, n=1, nc=nc)
+        rh, rb = proof["root"]
+        return bool((node_h == rh).all() and (node_b == rb).all())

@@ -1101,6 +1101,54 @@ def test_k5_merkle_sum_tree_on_gpu(gpu, kat, P):
     assert node[0] == int(kat["k5"]["root"], 16)
 
 
+def test_merkle_sum_tree_reference_api(gpu, P):
+    """the rest of the reference's MerkleSumTree / Tree API on the device-hashed tree: proofs with sibling
+    preimages verify (tree.rs:85-190), a tampered proof does not, update_leaf (mst.rs:169-204) equals a rebuild,
+    from_csv_sorted + index_of_username (mst.rs:89-100, 207-223)"""
+    import os
+    from conftest import GOLDEN
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree, parse_csv_to_entries
+    path = os.path.join(GOLDEN, "entry_16.csv")
+    tree = MerkleSumTree.from_csv(path, 2)
+    entries, crypto = parse_csv_to_entries(path, 2)
+    assert len(crypto) == 2
+    for i in (0, 1, 7, 15):
+        proof = tree.generate_proof(i)
+        assert proof["entry"][0] == entries[i][0]
+        assert len(proof["sibling_middle_node_hash_preimages"]) == tree.depth - 1
+        assert tree.verify_proof(proof)
+    bad = tree.generate_proof(3)
+    bad["entry"] = (bad["entry"][0], [bad["entry"][1][0] + 1, bad["entry"][1][1]])
+    assert not tree.verify_proof(bad)
+    bad = tree.generate_proof(3)
+    bad["path_indices"][1] ^= 1
+    assert not tree.verify_proof(bad)
+    with pytest.raises(IndexError):
+        tree.generate_proof(16)
+    # update_leaf == rebuild from the modified entries == the big-integer tree
+    name = entries[5][0]
+    assert tree.index_of_username(name) == 5
+    new_root = tree.update_leaf(name, [123456, 7])
+    entries[5] = (name, [123456, 7])
+    rebuilt = MerkleSumTree.from_entries(entries, 2)
+    assert (new_root[0] == rebuilt.root()[0]).all() and (new_root[1] == rebuilt.root()[1]).all()
+    assert (tree._h == rebuilt._h).all() and (tree._b == rebuilt._b).all()
+    ref = P.mst_build([P.mst_entry(n, b) for n, b in entries])
+    assert P.fr_from_bytes(new_root[0].tobytes()) == ref[0][0]
+    assert tree.verify_proof(tree.generate_proof(5))
+    with pytest.raises(KeyError):
+        tree.index_of_username("nobody")
+    # sorted build: binary search finds every user at the position of the sorted order
+    st = MerkleSumTree.from_csv_sorted(path, 2)
+    order = sorted(e[0] for e in entries)
+    for pos, nm in enumerate(order):
+        assert st.index_of_username(nm) == pos
+    assert st.verify_proof(st.generate_proof(st.index_of_username(order[3])))
+    # a tree that needs padding: 13 users -> 16 leaves; the proof of the last real user has a zero-entry sibling
+    t13 = MerkleSumTree.from_entries(entries[:13], 2)
+    assert t13.depth == 4 and t13.verify_proof(t13.generate_proof(12))
+
+
 @pytest.mark.parametrize("n,nc", [(1, 1), (13, 2), (17, 2), (1000, 3), (1 << 14, 2)])
 def test_merkle_sum_tree_vs_oracle(gpu, O, n, nc):
     from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree, keccak256
