@@ -649,6 +649,19 @@ def test_ntt_batch(gpu, O, log_n):
         assert (got.cpu().numpy() == v).all()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_proof_flow_schedule_runs(gpu, overlap):
+    """tools/proof_flow.py (what bench.py reports as proof_flow_k17) at a small size: every phase executes, on one
+    stream and with the side-stream schedule"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from proof_flow import run_flow
+    t = run_flow(9, n_gates=3, reps=1, overlap=overlap)
+    assert set(t) >= {"1_advice_commit", "3_grand_products_commit", "4b_evaluate_h", "6_multiopen", "total"}
+    assert t["total"] > 0
+
+
 def test_cpp_host_mirror_parity(gpu):
     """include/summa_gpu.hpp (best_multiexp, best_fft, EvaluationDomain, ParamsKZG in C++ over the C ABI) against
     the oracle: tests/cpp/parity_main.cpp, built by __graft_entry__.build()"""
