@@ -116,7 +116,7 @@ def main():
         line = {
             "metric": "msm_points_per_sec", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "254-bit Montgomery integers: 8 x u32 words in memory, 9 x 29-bit limbs with 64-bit accumulators in registers",
             "data": "synthetic",
             "config": {"workload": f"standalone BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x synthetic-SRS "
                                    f"affine points per GPU (BASELINE configs[1])",
