@@ -931,9 +931,63 @@ hipError_t MsmEngine::init() {
   return hipSuccess;
 }
 
+// the same three scans for NB <= 4 Ki buckets in ONE workgroup (a small MSM is a chain of ~25 launches with
+// a ~5 us floor each; this replaces four of them -- memset + three kernels -- per scan): thread t owns
+// buckets [t*per, (t+1)*per)
+static constexpr uint32_t SCAN_SMALL_PER = 4;   // x 1024 threads = 4 Ki buckets (beyond that the strided stores cost more than the launches saved)
+__global__ void __launch_bounds__(1024) msm_scan_small(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
+                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ ntask,
+                                                       uint32_t* __restrict__ toff, uint32_t* __restrict__ meta) {
+  __shared__ uint32_t s_a[1024], s_t[1024], s_m[1024];
+  const uint32_t Lm1 = (1u << log_L) - 1, tid = threadIdx.x;
+  const uint32_t per = (NB + 1023) / 1024, lo = min(tid * per, NB);
+  uint32_t v[SCAN_SMALL_PER];                      // all loads of a thread in flight together
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_SMALL_PER; k++) v[k] = (k < per && lo + k < NB) ? cnt[lo + k] : 0u;
+  uint32_t a = 0, t = 0, m = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_SMALL_PER; k++) {
+    a += v[k];
+    t += (v[k] + Lm1) >> log_L;
+    m = max(m, v[k]);
+  }
+  s_a[tid] = a; s_t[tid] = t; s_m[tid] = m;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t va = 0, vt = 0, vm = 0;
+    if (tid >= d) { va = s_a[tid - d]; vt = s_t[tid - d]; vm = s_m[tid - d]; }
+    __syncthreads();
+    s_a[tid] += va; s_t[tid] += vt; s_m[tid] = max(s_m[tid], vm);
+    __syncthreads();
+  }
+  uint32_t ra = s_a[tid] - a, rt = s_t[tid] - t;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_SMALL_PER; k++) {
+    if (k < per && lo + k < NB) {
+      const uint32_t nt = (v[k] + Lm1) >> log_L;
+      if (off) off[lo + k] = ra;
+      ntask[lo + k] = nt;
+      toff[lo + k] = rt;
+      ra += v[k];
+      rt += nt;
+    }
+  }
+  if (tid == 1023) {
+    if (off) off[NB] = s_a[tid];
+    toff[NB] = s_t[tid];
+    meta[0] = s_a[tid];
+    meta[1] = s_t[tid];
+    meta[2] = s_m[tid];
+  }
+}
+
 // exclusive scans over NB buckets (three small launches)
 static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, uint32_t* off, uint32_t* ntask,
                               uint32_t* toff, uint32_t* bsum, uint32_t* meta, hipStream_t stream) {
+  if (NB <= SCAN_SMALL_PER * 1024) {
+    msm_scan_small<<<1, 1024, 0, stream>>>(cnt, NB, log_L, off, ntask, toff, meta);
+    return hipGetLastError();
+  }
   const uint32_t nblk = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   if (nblk > 1024) return hipErrorInvalidValue;
   SG_TRY(hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), stream));
