@@ -2,14 +2,16 @@
 Appendix C: 3 advice + 1 instance + 11 fixed columns, 2 permutation sets over 6 columns, 1 lookup, 5 quotient
 pieces, 35 evaluations, 16 commitments), every data-parallel step on the device through the C ABI, a host
 sync at every Fiat-Shamir boundary.  Inputs are random (timing only; each op is parity-tested on its own).
-The custom-gate program is a stand-in: N Poseidon-round-shaped gates."""
+The custom-gate program is a stand-in: N Poseidon-round-shaped gates (default 12 = 132 products per row; the
+reference's generated verifier evaluates 19 gate expressions with 127 multiplications per point,
+contracts/src/InclusionVerifier.sol:495-902, the first of which has exactly this shape)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
 
-def run_flow(k=17, n_gates=24, reps=3, overlap=True):
+def run_flow(k=17, n_gates=12, reps=3, overlap=True):
     import torch
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import arithmetic as A
