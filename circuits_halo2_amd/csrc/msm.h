@@ -99,7 +99,8 @@ class MsmEngine {
   size_t max_fused(size_t n) const;
   // the same over a precomputed window table (n <= tab.n): all M MSMs use the table's bases
   hipError_t enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
-                                 hipStream_t stream, uint8_t* out_affine, MsmTimings* tm);
+                                 hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
+                                 const g1_affine_mem* const* tables = nullptr);
   size_t max_fused_fixed(const FixedTable& tab, size_t n) const;
   hipError_t enqueue_back();
   hipError_t finish();

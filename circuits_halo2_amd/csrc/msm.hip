@@ -1049,10 +1049,12 @@ hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c
 }
 
 hipError_t MsmEngine::enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
-                                          hipStream_t stream, uint8_t* out_affine, MsmTimings* tm) {
+                                          hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
+                                          const g1_affine_mem* const* tables) {
   if (n > tab.n || !tab.table) return hipErrorInvalidValue;
   const g1_affine_mem* bs[MAX_FUSED];
-  for (size_t m = 0; m < M && m < MAX_FUSED; m++) bs[m] = tab.table;
+  // `tables` (optional): one window table per MSM, all built with tab's plan (same c and n), e.g. g and g_lagrange
+  for (size_t m = 0; m < M && m < MAX_FUSED; m++) bs[m] = tables ? tables[m] : tab.table;
   fixed_ = &tab;
   hipError_t e = enqueue_front_fused(d_scalars, bs, M, n, stream, out_affine, tm);
   fixed_ = nullptr;

@@ -395,9 +395,10 @@ static int msm_batch_locked(const void* const* d_scalars, const void* const* d_b
       if (e != hipSuccess) break;
     }
     const Group& g = groups[gi];
-    if (tab)
+    if (tab)  // d_bases then holds one window table per MSM (all with tab's plan)
       e = eng[k]->enqueue_front_fixed(reinterpret_cast<const fp_words* const*>(d_scalars + g.first), *tab, g.count,
-                                      n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr);
+                                      n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr,
+                                      reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first));
     else
       e = eng[k]->enqueue_front_fused(reinterpret_cast<const fp_words* const*>(d_scalars + g.first),
                                       reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), g.count,
@@ -571,9 +572,29 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
   if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   const Srs& s = it->second;
   std::vector<size_t> ns(count, n);
-  std::vector<const void*> bases(count, basis ? s.g_lagrange : s.g);
-  return msm_batch_locked(d_scalars, bases.data(), s.tab[basis].table ? &s.tab[basis] : nullptr, ns.data(), count, stream,
-                          out_affine);
+  const bool fixed = s.tab[basis].table != nullptr;
+  std::vector<const void*> bases(count, fixed ? (const void*)s.tab[basis].table : (const void*)(basis ? s.g_lagrange : s.g));
+  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[basis] : nullptr, ns.data(), count, stream, out_affine);
+}
+// the same with one basis per polynomial (0 = g, 1 = g_lagrange): e.g. the grand-product commitments (Lagrange)
+// and the random polynomial (coefficients) of one prover phase as ONE fused job
+int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
+                              void* stream, uint8_t* out_affine) {
+  if (count && (!d_scalars || !out_affine || !basis)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
+  for (size_t i = 0; i < count; i++)
+    if ((n && !d_scalars[i]) || (basis[i] != 0 && basis[i] != 1)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
+  LOCKED_CTX();
+  auto it = g_ctx->srs.find(srs_handle);
+  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  const Srs& s = it->second;
+  // fixed-base only when both tables exist with one plan; otherwise the generic fused path over g / g_lagrange
+  const bool fixed = s.tab[0].table && s.tab[1].table && s.tab[0].c == s.tab[1].c && s.tab[0].n == s.tab[1].n;
+  std::vector<size_t> ns(count, n);
+  std::vector<const void*> bases(count);
+  for (size_t i = 0; i < count; i++)
+    bases[i] = fixed ? (const void*)s.tab[basis[i]].table : (const void*)(basis[i] ? s.g_lagrange : s.g);
+  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[0] : nullptr, ns.data(), count, stream, out_affine);
 }
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && !scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");

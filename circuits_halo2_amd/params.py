@@ -145,6 +145,27 @@ class ParamsKZG:
                                                 C.c_size_t(m), C.c_size_t(n), ffi.current_stream_ptr(), ffi.ptr(out)))
         return out
 
+    def commit_batch_mixed(self, polys, lagrange_flags) -> np.ndarray:
+        """like commit_batch with one basis per polynomial (True = Lagrange form): one fused job for a phase that
+        commits to both kinds (grand products + the random polynomial)"""
+        m = len(polys)
+        out = np.zeros((m, 64), dtype=np.uint8)
+        if m == 0:
+            return out
+        if len(lagrange_flags) != m:
+            raise ValueError("commit_batch_mixed: one flag per polynomial")
+        n = polys[0].numel() // 32
+        for p in polys:
+            if not _is_torch_cuda(p) or p.numel() != 32 * n:
+                raise ValueError("commit_batch_mixed: equal-length device tensors expected")
+        if n > self.n:
+            raise ValueError("polynomial longer than the SRS")
+        ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+        flags = (C.c_int * m)(*[1 if f else 0 for f in lagrange_flags])
+        ffi.check(ffi.lib().sg_commit_batch_mixed_dev(C.c_uint64(self.handle()), flags, ptrs, C.c_size_t(m), C.c_size_t(n),
+                                                      ffi.current_stream_ptr(), ffi.ptr(out)))
+        return out
+
     def commit(self, poly):
         """commit to a polynomial in coefficient form: best_multiexp(poly, g)"""
         return self._commit(0, poly)

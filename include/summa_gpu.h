@@ -96,6 +96,10 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits);
 /* `count` commitments of n scalars each against one basis, issued as fused jobs; out_affine: count x 64 B */
 int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
                         void* stream, uint8_t* out_affine);
+/* the same with one basis per polynomial (0 = g, 1 = g_lagrange): the commitments of one prover phase that mix
+ * Lagrange- and coefficient-form polynomials as ONE fused job (fixed-base when both tables were precomputed) */
+int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
+                              void* stream, uint8_t* out_affine);
 /* Device pointers of a cached SRS (for callers that drive the *_dev entry points). */
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k);
 

@@ -746,6 +746,13 @@ def test_fixed_base_batch(gpu, O, srs11):
     params.precompute(0, window_bits=9)
     assert (params.commit_batch(short) == want_s).all()
     assert params.commit_batch([]).shape == (0, 64)
+    # one basis per polynomial: generic (one table only, different plans) and fixed-base (both tables, one plan)
+    flags = [True, False, True, True, False]
+    want_m = np.stack([O.best_multiexp(c, srs11["gl_np" if f else "g_np"], O.ncpu()) for c, f in zip(cols[:5], flags)])
+    assert (params.commit_batch_mixed(d[:5], flags) == want_m).all()
+    params.precompute()
+    assert (params.commit_batch_mixed(d[:5], flags) == want_m).all()
+    assert (params.commit_batch_mixed(d[1:2], [False]) == want_m[1:2]).all()
     params.free()
 
 

@@ -106,9 +106,9 @@ def run_flow(k=17, n_gates=12, reps=3, overlap=True):
             zl = A.lookup_product(a_in, s_tab, a_perm, s_perm, beta, gamma)
         if overlap:
             co3, ex3 = to_extended([z0, z1, zl])
-        c_z = params.commit_batch([z0, z1, zl], lagrange=True)
         rand_poly = advice[0]
-        c_r = params.commit(rand_poly)
+        c_z = params.commit_batch_mixed([z0, z1, zl, rand_poly], [True, True, True, False])   # one fused job
+        c_r = c_z[3]
         t["3_grand_products_commit"] = time.perf_counter() - t1; t1 = time.perf_counter()
         y = fr1(int(c_z[0, 0]) + 503)
         # 4: quotient
