@@ -50,6 +50,15 @@ extern "C" {
         stream: *mut c_void,
         out_affine: *mut u8,
     ) -> c_int;
+    pub fn sg_commit_batch_mixed_dev(
+        handle: u64,
+        basis: *const c_int,
+        d_scalars: *const *const c_void,
+        count: size_t,
+        n: size_t,
+        stream: *mut c_void,
+        out_affine: *mut u8,
+    ) -> c_int;
     pub fn sg_fr_eval_poly_batch_dev(
         d_polys: *const *const c_void,
         n: size_t,
