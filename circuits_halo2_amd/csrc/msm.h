@@ -21,6 +21,7 @@ struct MsmConfig {
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
   uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^19 entries), 2 always
   uint32_t log_scatter_rounds = 0;  // the counting sort's scatter runs in 2^x bucket-range rounds
+  uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
 
@@ -114,6 +115,7 @@ class MsmEngine {
     uint8_t* out = nullptr;
     MsmTimings* tm = nullptr;
     bool trivial = false, all_zero = false, fixed = false;
+    uint32_t red2d = 0;  // 0: scan-based reduction, 1: 2-D with host weights, 2: 2-D with device weights
     uint32_t n_tab = 0;
     uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0;
     WindowPlan wp{};

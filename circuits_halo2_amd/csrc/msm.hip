@@ -697,6 +697,95 @@ __global__ void __launch_bounds__(768) msm_reduce_items(ReduceOut in, uint32_t c
   tree_sum<Q>(arr, T1, li, role, true);
   if (li == 0 && role == 0) xyzz29_store((g == 0 ? out.r : g == 1 ? out.a : out.s) + blockIdx.y, xyzz29_load(&arr[0]));
 }
+// ------------------------------------------------------------------ 5b: 2-D bucket reduction (few bucket sets)
+// The scan-based reduction above is a chain of ~40 dependent additions whatever the size.  With the bucket index
+// split as b = hi * C + lo (C = 2^ceil(bits/2) columns, Rr = nbw / C rows),
+//     sum_b (b + 1) B_b = C * sum_hi hi * R_hi + sum_lo lo * C_lo + U,   R_hi / C_lo row / column sums, U the total,
+// and each small weighted sum by bits,  sum_x x * V_x = sum_j 2^j * (sum of the V_x with bit j of x set),
+// everything on the device is a PLAIN sum: lines (rows and columns) first, then one masked sum per bit --
+// two launches of ~9 dependent quad-cooperative additions each.  The powers of two are applied by the host tail,
+// which already places terms at bit offsets; it receives bits + 1 points per bucket set, so this path is for
+// jobs with few sets (fixed-base commits of up to 4 polynomials).
+struct Reduce2dShape {
+  uint32_t log_cols, log_rows;  // nbw = 2^(log_rows + log_cols)
+};
+// sum of up to 256 XYZZ values by one workgroup of 256 lanes: Q = 4: 64 quads (quad-cooperative additions, for
+// few sets: latency), Q = 1: 256 lanes, one addition each (many sets: throughput); `get(e)` yields element e
+template <int Q, typename F>
+__device__ __forceinline__ xyzz29 wg_sum(uint32_t n, F get, xyzz29_mem* lds) {
+  constexpr uint32_t NL = 256 / Q;  // logical threads
+  const uint32_t lt = threadIdx.x / Q, role = threadIdx.x % Q;
+  xyzz29 acc = xyzz29_identity();
+  for (uint32_t e = lt; e < n; e += NL) add_q<Q>(acc, get(e), role);
+  if (role == 0) xyzz29_store(&lds[lt], acc);
+  __syncthreads();
+  tree_sum<Q>(lds, NL, lt, role, true);
+  return xyzz29_load(&lds[0]);
+}
+// grid (rows + cols, sets): line sums.  lines[set * (rows + cols) + L]
+template <int Q>
+__global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __restrict__ partial,
+                                                          const uint32_t* __restrict__ toff,
+                                                          const uint32_t* __restrict__ ntask, Reduce2dShape sh,
+                                                          xyzz29_mem* __restrict__ lines) {
+  __shared__ xyzz29_mem lds[256 / Q];
+  const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols, L = blockIdx.x, set = blockIdx.y;
+  const uint32_t base = set << (sh.log_rows + sh.log_cols);
+  const bool is_row = L < rows;
+  const uint32_t n = is_row ? cols : rows;
+  auto get = [&](uint32_t e) {
+    const uint32_t b = base + (is_row ? (L << sh.log_cols) + e : (e << sh.log_cols) + (L - rows));
+    return ntask[b] ? xyzz29_load(partial + toff[b]) : xyzz29_identity();
+  };
+  xyzz29 sum = wg_sum<Q>(n, get, lds);
+  if (threadIdx.x == 0) xyzz29_store(lines + (size_t)set * (rows + cols) + L, sum);
+}
+// grid (log_rows + log_cols + 1, sets): WG j < log_cols: columns with bit j of lo set; next log_rows: rows with
+// bit j' of hi set; last: all columns (= the total).  out[set * (bits + 1) + j]
+template <int Q>
+__global__ void __launch_bounds__(256) msm_reduce2d_bits(const xyzz29_mem* __restrict__ lines, Reduce2dShape sh,
+                                                         xyzz29_mem* __restrict__ out) {
+  __shared__ xyzz29_mem lds[256 / Q];
+  const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols, j = blockIdx.x, set = blockIdx.y;
+  const uint32_t bits = sh.log_rows + sh.log_cols;
+  const xyzz29_mem* ln = lines + (size_t)set * (rows + cols);
+  xyzz29 sum;
+  if (j < sh.log_cols) {
+    sum = wg_sum<Q>(cols, [&](uint32_t e) { return ((e >> j) & 1) ? xyzz29_load(ln + rows + e) : xyzz29_identity(); }, lds);
+  } else if (j < bits) {
+    const uint32_t jr = j - sh.log_cols;
+    sum = wg_sum<Q>(rows, [&](uint32_t e) { return ((e >> jr) & 1) ? xyzz29_load(ln + e) : xyzz29_identity(); }, lds);
+  } else {
+    sum = wg_sum<Q>(cols, [&](uint32_t e) { return xyzz29_load(ln + rows + e); }, lds);
+  }
+  if (threadIdx.x == 0) xyzz29_store(out + (size_t)set * (bits + 1) + j, sum);
+}
+// many sets: the powers of two on the device as well -- thread t doubles term t t times (<= 14 doublings), then
+// a tree sum: one point per set.  grid (sets), 32 threads
+__global__ void __launch_bounds__(32) msm_reduce2d_combine(const xyzz29_mem* __restrict__ terms, uint32_t bits,
+                                                           xyzz29_mem* __restrict__ out) {
+  __shared__ xyzz29_mem lds[32];
+  const uint32_t t = threadIdx.x, set = blockIdx.x;
+  xyzz29 p = xyzz29_identity();
+  if (t <= bits) {
+    p = xyzz29_load(terms + (size_t)set * (bits + 1) + t);
+    if (t < bits)
+      for (uint32_t i = 0; i < t; i++) p = xyzz29_double(p);   // term t < bits has weight 2^t; term `bits` (the total) 1
+  }
+  xyzz29_store(&lds[t], p);
+  __syncthreads();
+  tree_sum<1>(lds, 32, t, 0, true);
+  if (t == 0) xyzz29_store(out + set, xyzz29_load(&lds[0]));
+}
+// canonical words of `count` XYZZ points for the host tail (32 words each)
+__global__ void msm_export_points(const xyzz29_mem* __restrict__ in, uint32_t count, uint32_t* __restrict__ out) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  uint32_t w[32];
+  xyzz29_to_words(xyzz29_load(in + q), w);
+  for (int i = 0; i < 32; i++) out[32 * q + i] = w[i];
+}
+
 // per-window (A, S, T) -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ each) for the
 // host tail; out[(3*j + which)*32 ..]
 __global__ void msm_export_windows(ReduceOut in, uint32_t W, uint32_t has_t, uint32_t* __restrict__ out) {
@@ -1254,6 +1343,41 @@ hipError_t MsmEngine::enqueue_back() {
     stream = tail_stream_;
   }
 
+  // 2-D reduction (rows / columns / bits): plain sums only, ~9 dependent additions per launch instead of a chain
+  // of ~40.  Few sets: quad-cooperative additions and the powers of two on the host (bits + 1 points per set);
+  // many sets: one lane per addition and a third launch that applies the powers of two (one point per set).
+  // Measured (profiles/r01_sweeps): a clear win for up to 4 sets (k = 17 single commit: reduction 190 -> 90 us); with
+  // many sets the tree sums waste lanes and the scan-based path below is faster, so the device-weights variant only
+  // runs when forced (msm.red2d = 2).
+  j.red2d = (cfg_.red2d && j.c >= 5) ? ((W <= 4) ? 1u : (cfg_.red2d >= 2 ? 2u : 0u)) : 0u;
+  if (j.red2d) {
+    const uint32_t bits = j.c - 1, sets = W;
+    Reduce2dShape sh{(bits + 1) / 2, bits / 2};
+    const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols;
+    SG_TRY(red_a_[0].reserve((size_t)sets * (rows + cols)));
+    SG_TRY(red_a_[1].reserve((size_t)sets * (bits + 1)));
+    if (quad) {
+      msm_reduce2d_lines<4><<<dim3(rows + cols, sets), 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, sh, red_a_[0].p);
+      msm_reduce2d_bits<4><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
+    } else {
+      msm_reduce2d_lines<1><<<dim3(rows + cols, sets), 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, sh, red_a_[0].p);
+      msm_reduce2d_bits<1><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
+    }
+    const xyzz29_mem* fin = red_a_[1].p;
+    uint32_t count = sets * (bits + 1);
+    if (j.red2d == 2) {
+      SG_TRY(red_s_[0].reserve(sets));
+      msm_reduce2d_combine<<<sets, 32, 0, stream>>>(red_a_[1].p, bits, red_s_[0].p);
+      fin = red_s_[0].p;
+      count = sets;
+    }
+    if (j.tm) SG_TRY(hipEventRecord(j.ev[4], stream));
+    msm_export_points<<<(count + 63) / 64, 64, 0, stream>>>(fin, count, win_words_.p);
+    SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 32 * count, hipMemcpyDeviceToHost, stream));
+    SG_TRY(hipEventRecord(ev_done_, stream));
+    return hipGetLastError();
+  }
+
   // bucket reduction: level 0 over the buckets, level 1 over the workgroup items.  Both are chains of
   // dependent point additions with most of the chip idle, so by default a point addition is spread
   // over the 4 lanes of a quad (cfg.quad; see `quad` above): 64 logical threads per workgroup.
@@ -1339,15 +1463,23 @@ hipError_t MsmEngine::finish() {
   }
   constexpr uint32_t MAXBIT = 254 + 16 + 16;
   Jac totals[MAX_FUSED];
+  // terms per window: legacy (A, S, T) at offsets (0, log_G, log_G + log_N); 2-D with host weights: term t < bits
+  // at offset t and the total at 0; 2-D with device weights: one term at 0
+  const uint32_t bits2d = j.c - 1;
+  const uint32_t per_win = j.red2d == 1 ? bits2d + 1 : j.red2d == 2 ? 1u : 3u;
   for (uint32_t m = 0; m < j.M; m++) {
     int head[MAXBIT + 1];
     int next[3 * 64];
     for (auto& h : head) h = -1;
     uint32_t top = 0;
     for (uint32_t w = 0; w < Wm; w++) {
-      for (uint32_t which = 0; which < 3; which++) {
-        const uint32_t bit = offs[w] + (which >= 1 ? j.log_G : 0) + (which == 2 ? j.log_N : 0);
-        const int id = (int)(3 * w + which);
+      for (uint32_t which = 0; which < per_win; which++) {
+        uint32_t rel;
+        if (j.red2d == 1) rel = which < bits2d ? which : 0u;
+        else if (j.red2d == 2) rel = 0;
+        else rel = (which >= 1 ? j.log_G : 0) + (which == 2 ? j.log_N : 0);
+        const uint32_t bit = offs[w] + rel;
+        const int id = (int)(per_win * w + which);
         next[id] = head[bit];
         head[bit] = id;
         top = std::max(top, bit);
@@ -1356,7 +1488,7 @@ hipError_t MsmEngine::finish() {
     Jac total = Jac::identity();
     for (int bit = (int)top; bit >= 0; bit--) {
       total = jac_double(total);
-      for (int id = head[bit]; id >= 0; id = next[id]) total = jac_add(total, point_at(3 * m * Wm + (uint32_t)id));
+      for (int id = head[bit]; id >= 0; id = next[id]) total = jac_add(total, point_at(per_win * m * Wm + (uint32_t)id));
     }
     totals[m] = total;
   }
