@@ -1349,7 +1349,7 @@ hipError_t MsmEngine::enqueue_back() {
   // Measured (profiles/r01_sweeps): a clear win for up to 4 sets (k = 17 single commit: reduction 190 -> 90 us); with
   // many sets the tree sums waste lanes and the scan-based path below is faster, so the device-weights variant only
   // runs when forced (msm.red2d = 2).
-  j.red2d = (cfg_.red2d && j.c >= 5) ? ((W <= 4) ? 1u : (cfg_.red2d >= 2 ? 2u : 0u)) : 0u;
+  j.red2d = (cfg_.red2d && j.c >= 5) ? ((W <= cfg_.red2d_max_sets && Wm <= 4) ? 1u : (cfg_.red2d >= 2 ? 2u : 0u)) : 0u;
   if (j.red2d) {
     const uint32_t bits = j.c - 1, sets = W;
     Reduce2dShape sh{(bits + 1) / 2, bits / 2};
