@@ -1197,7 +1197,8 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   j.log_L = cfg_.log_seg;
   if (!j.log_L) {
     const size_t share = 2 * entries / (256 * 4 * 64 * 4);  // entries per resident lane, x2
-    j.log_L = 4;
+    // small jobs are pure latency chains: shorter tasks (more lanes, more merging) win -- measured at k = 11 .. 17
+    j.log_L = entries < ((size_t)1 << 16) ? 2 : entries < ((size_t)1 << 19) ? 3 : 4;
     while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
   }
   // two-pass sort (msm_partition / msm_fine_sort) for everything but small jobs: B coarse bins per
