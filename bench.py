@@ -148,10 +148,12 @@ def main():
         # throughput mode: the same MSM issued as a batch of 8 (fused / pipelined jobs)
         sg.best_multiexp_batch([(scal, bases)] * 8)   # warms both engines' work spaces
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        outs = sg.best_multiexp_batch([(scal, bases)] * 8)
-        torch.cuda.synchronize()
-        bdt = time.perf_counter() - t1
+        bdt = 1e9
+        for _ in range(3):
+            t1 = time.perf_counter()
+            outs = sg.best_multiexp_batch([(scal, bases)] * 8)
+            torch.cuda.synchronize()
+            bdt = min(bdt, time.perf_counter() - t1)
         assert all((o == result).all() for o in outs) or world > 1
         line["batched"] = {"msms": 8, "ms_per_msm": bdt / 8 * 1e3, "points_per_s": 8 * n / bdt}
 
@@ -171,10 +173,12 @@ def main():
                 s17, b17 = scal[: 32 << k], bases[: 64 << k]
                 sg.best_multiexp_batch([(s17, b17)] * 16)
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                sg.best_multiexp_batch([(s17, b17)] * 16)
-                torch.cuda.synchronize()
-                msm17 = (time.perf_counter() - t1) * 1e3
+                msm17 = 1e9
+                for _ in range(3):   # best of 3: a single sample right after the NTT loops is noisy
+                    t1 = time.perf_counter()
+                    sg.best_multiexp_batch([(s17, b17)] * 16)
+                    torch.cuda.synchronize()
+                    msm17 = min(msm17, (time.perf_counter() - t1) * 1e3)
                 a20 = scal[: 32 << 20].clone()
                 ms20 = C.c_float(0)
                 ffi.check(sg.lib().sg_time_ntt_dev(ffi.dev_ptr(a20), C.c_uint32(20), 10, C.byref(ms20)))
