@@ -294,6 +294,8 @@ void sg_shutdown(void) {
   for (auto& kv : g_ctx->srs) {
     (void)hipFree(kv.second.g);
     (void)hipFree(kv.second.g_lagrange);
+    for (auto& t : kv.second.tab)
+      if (t.table) (void)hipFree(t.table);
   }
   for (auto& kv : g_ctx->t_evals) (void)hipFree(kv.second);
   g_ctx->ntt.clear();
