@@ -23,6 +23,7 @@ struct GateProgram {
   std::vector<uint32_t> const_words;  // 8 words per constant (memory-domain Fr)
   uint32_t n_slots = 0, result_kind = GK_SLOT, result_index = 0;
   uint32_t n_columns = 0;             // fixed ++ advice ++ instance
+  std::vector<uint8_t> signature;     // structure bytes this program was lowered from (cache confirmation)
 };
 
 // halo2-shaped graph -> compiled program (bound tracking, lazy reductions, slot allocation).

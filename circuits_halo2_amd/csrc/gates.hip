@@ -301,6 +301,19 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
         if (bad(g.horner_parts[cal.parts_offset + t])) return "intermediate used before it is defined";
     }
   }
+  {  // the lowering below recurses along dependencies: bound the depth (halo2 graphs are a few hundred deep)
+    std::vector<uint32_t> depth(g.n_calculations, 1);
+    auto dep = [&](const sg_value_source& s) { return s.kind == SG_VS_INTERMEDIATE ? depth[s.index] : 0u; };
+    for (uint32_t q = 0; q < g.n_calculations; q++) {
+      const sg_calculation& cal = g.calculations[q];
+      uint32_t d = dep(cal.a);
+      if (cal.op <= SG_OP_MUL || cal.op == SG_OP_HORNER) d = std::max(d, dep(cal.b));
+      if (cal.op == SG_OP_HORNER)
+        for (uint32_t t = 0; t < cal.parts_len; t++) d = std::max(d, dep(g.horner_parts[cal.parts_offset + t]));
+      depth[q] = d + 1;
+      if (depth[q] > 4096) return "dependency chain deeper than 4096 calculations";
+    }
+  }
   std::vector<uint8_t> done(g.n_calculations, 0);
   std::function<Val(const sg_value_source&)> need;
   std::function<void(uint32_t)> lower = [&](uint32_t q) {

@@ -133,6 +133,7 @@ struct Context {
   hipEvent_t ev_in = nullptr;
   DevBuf<uint8_t> stage_a, stage_b, scratch, gate_blob;
   std::vector<uint8_t> gate_blob_host;
+  std::map<uint64_t, GateProgram> gate_cache;  // lowered gate programs by structure hash
   // in-place multi-pass transforms need a scratch vector; one per caller stream, so that transforms
   // enqueued on a side stream never share it with work in flight on another stream
   std::map<hipStream_t, DevBuf<uint8_t>> ntt_scratch;
@@ -1216,10 +1217,50 @@ int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* con
     return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
   if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_gates: bad shape");
   LOCKED_CTX();
-  GateProgram prog;
-  std::string err = compile_gates(*graph, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y,
-                                  &prog);
-  if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_quotient_gates: " + err).c_str());
+  // the lowered program depends on the graph's structure only (constants / challenges are a table refreshed per
+  // call): cache it under a hash of the structure
+  uint64_t key = 1469598103934665603ull;
+  std::vector<uint8_t> sig;  // the exact structure: a cache hit is confirmed byte for byte
+  auto mix = [&](const void* p, size_t len) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < len; i++) key = (key ^ b[i]) * 1099511628211ull;
+    sig.insert(sig.end(), b, b + len);
+  };
+  {
+    const uint32_t hdr[8] = {graph->n_constants, graph->n_rotations, graph->n_calculations, graph->n_horner_parts, n_fixed,
+                             n_advice, n_instance, n_challenges};
+    mix(hdr, sizeof hdr);
+    if (graph->rotations) mix(graph->rotations, sizeof(int32_t) * graph->n_rotations);
+    if (graph->calculations) mix(graph->calculations, sizeof(sg_calculation) * graph->n_calculations);
+    if (graph->horner_parts) mix(graph->horner_parts, sizeof(sg_value_source) * graph->n_horner_parts);
+  }
+  GateProgram fresh;
+  std::string err = "";
+  auto hit = g_ctx->gate_cache.find(key);
+  if (hit != g_ctx->gate_cache.end() && hit->second.signature != sig) {  // 64-bit collision: recompile
+    g_ctx->gate_cache.erase(hit);
+    hit = g_ctx->gate_cache.end();
+  }
+  if (hit == g_ctx->gate_cache.end()) {
+    err = compile_gates(*graph, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y, &fresh);
+    if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_quotient_gates: " + err).c_str());
+    fresh.signature = std::move(sig);
+    if (g_ctx->gate_cache.size() >= 64) g_ctx->gate_cache.clear();
+    hit = g_ctx->gate_cache.emplace(key, std::move(fresh)).first;
+  }
+  GateProgram& prog = hit->second;
+  if ((graph->n_constants && !graph->constants)) return fail(SG_ERR_INVALID, "sg_quotient_gates: null constants");
+  {  // constant table of this call: constants ++ challenges ++ beta, gamma, theta, y (compile_gates' order)
+    prog.const_words.clear();
+    auto push = [&](const uint8_t* p) {
+      uint32_t w[8];
+      std::memcpy(w, p, 32);
+      prog.const_words.insert(prog.const_words.end(), w, w + 8);
+    };
+    for (uint32_t i = 0; i < graph->n_constants; i++) push(graph->constants + 32 * (size_t)i);
+    for (uint32_t i = 0; i < n_challenges; i++) push(challenges + 32 * (size_t)i);
+    push(beta); push(gamma); push(theta); push(y);
+  }
   if (prog.n_slots > 64) return fail(SG_ERR_INVALID, "sg_quotient_gates: more than 64 simultaneously live values");
   std::vector<const void*> cols;
   for (uint32_t i = 0; i < n_fixed; i++) cols.push_back(d_fixed[i]);
