@@ -145,6 +145,18 @@ def main():
                                "reduction on 9x29-bit limbs = 1467 v_mad_u64_u32 (70 % of its instructions); peak = "
                                "measured v_mad_u64_u32 issue rate (profiles/r01_microbench_instr_rates.txt)"}
 
+        # hardware-counter view of the same claim, from the newest committed VALU pass (profiles/*_valu.json)
+        import glob as _glob
+        for path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "*_valu.json")), reverse=True):
+            pg = json.load(open(path)).get("per_grid", {})
+            cands = [(abs(int(k.split("@grid")[1]) - (-(-reps[0]["tasks"] // 256) * 256)), v) for k, v in pg.items()
+                     if k.startswith("sg::msm_accumulate@")]
+            if cands:
+                v = min(cands, key=lambda kv: kv[0])[1]
+                line["alu"].update({"valu_busy_pct": v.get("VALUBusy_avg"), "valu_lane_utilization_pct": v.get("VALUUtilization_avg"),
+                                    "valu_source": os.path.basename(path)})
+                break
+
         # throughput mode: the same MSM issued as a batch of 8 (fused / pipelined jobs)
         sg.best_multiexp_batch([(scal, bases)] * 8)   # warms both engines' work spaces
         torch.cuda.synchronize()
