@@ -1343,6 +1343,7 @@ int sg_set_param(const char* name, int value) {
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; g_ctx->msm.config().red_threads = g_ctx->msm_b.config().red_threads = v; }
   else if (s == "msm.log_scatter_rounds") g_ctx->msm.config().log_scatter_rounds = g_ctx->msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));
   else if (s == "msm.two_pass") g_ctx->msm.config().two_pass = g_ctx->msm_b.config().two_pass = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "msm.acc_threads") g_ctx->msm.config().acc_threads = g_ctx->msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
   else if (s == "msm.red2d_max_sets") g_ctx->msm.config().red2d_max_sets = g_ctx->msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));
   else if (s == "msm.red2d") g_ctx->msm.config().red2d = g_ctx->msm_b.config().red2d = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.quad") g_ctx->msm.config().quad = g_ctx->msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
