@@ -252,7 +252,17 @@ def main():
                     torch.cuda.empty_cache()
                     flow = run_flow(17, n_gates=12, reps=3, overlap=False)
                     flow_ov = run_flow(17, n_gates=12, reps=3, overlap=True)
-                    line["proof_flow_k17"] = {"ms": flow["total"], "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
+                    cpp = {}
+                    exe = os.path.join(ROOT, "tools", "proof_flow_cpp")
+                    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)
+                    if os.path.exists(exe) and not profiled:   # the same schedule driven from C++ over the C ABI (own process / context)
+                        import subprocess
+                        torch.cuda.empty_cache()
+                        r = subprocess.run([exe, "17", "12", "5"], capture_output=True, text=True, timeout=300)
+                        if r.returncode == 0:
+                            cpp = json.loads(r.stdout.strip().splitlines()[-1])
+                    line["proof_flow_k17"] = {"ms": flow["total"], "ms_cpp_driver": cpp.get("total"),
+                                              "phases_ms_cpp_driver": {k_: v_ for k_, v_ in cpp.items() if k_[0].isdigit()}, "phases_ms": {k_: round(v_, 3) for k_, v_ in flow.items() if k_ != "total"},
                                               "ms_multi_stream": flow_ov["total"],
                                               "rows_per_s": (1 << 17) / (flow["total"] * 1e-3),
                                               "note": "synthetic create_proof-shaped schedule (MstInclusion column/argument counts, "

@@ -662,6 +662,20 @@ def test_proof_flow_schedule_runs(gpu, overlap):
     assert t["total"] > 0
 
 
+def test_cpp_proof_flow_driver_runs(gpu):
+    """tools/proof_flow.cpp: the op schedule driven from C++ over the C ABI (built by __graft_entry__.build())"""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "proof_flow_cpp")
+    if not os.path.exists(exe):
+        pytest.skip("tools/proof_flow_cpp not built")
+    out = subprocess.run([exe, "9", "3", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    t = json.loads(out.stdout.strip().splitlines()[-1])
+    assert t["driver"] == "c++" and t["total"] > 0 and "6_multiopen" in t
+
+
 def test_cpp_host_mirror_parity(gpu):
     """include/summa_gpu.hpp (best_multiexp, best_fft, EvaluationDomain, ParamsKZG in C++ over the C ABI) against
     the oracle: tests/cpp/parity_main.cpp, built by __graft_entry__.build()"""
