@@ -4,7 +4,9 @@
 // allows, 9 + 9 + 1 transforms, evaluate_h = gates + permutation + lookup, 35 evaluations, multi-open), random
 // inputs (timing only; every op is parity-tested on its own), a host sync wherever a challenge is derived.
 //   build: hipcc -O2 -std=c++17 -Iinclude tools/proof_flow.cpp -o tools/proof_flow_cpp -Lcircuits_halo2_amd -lsumma_gpu
-//   usage: proof_flow_cpp [k = 17] [n_gates = 12] [reps = 5]   -> one JSON line
+//   usage: proof_flow_cpp [k = 17] [n_gates = 12] [reps = 5] [multi_stream = 1]   -> one JSON line
+// multi_stream: the three grand products and the three rotation sets of the multi-open are independent latency
+// chains; each gets its own stream (the library keeps its work space per stream).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -61,6 +63,7 @@ static double ms_since(clk::time_point t) { return std::chrono::duration<double,
 int main(int argc, char** argv) {
   const uint32_t k = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 17, ext_k = k + 3;
   const int n_gates = argc > 2 ? std::atoi(argv[2]) : 12, reps = argc > 3 ? std::atoi(argv[3]) : 5;
+  const bool multi = argc > 4 ? std::atoi(argv[4]) != 0 : true;
   const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
   CK(sg_init(0));
   // SRS: valid points from random scalars; both bases resident, fixed-base tables built once
@@ -89,7 +92,9 @@ int main(int argc, char** argv) {
   void* values = dev_alloc(32 * ne);
   std::vector<void*> quot(3);
   for (auto& p : quot) p = dev_alloc(32 * n);
-  void *tmp_a = dev_alloc(32 * n), *tmp_b = dev_alloc(32 * n), *hx = dev_alloc(32 * n), *lx = dev_alloc(32 * n),
+  void* tmps[6];
+  for (auto& p : tmps) p = dev_alloc(32 * n);
+  void *hx = dev_alloc(32 * n), *lx = dev_alloc(32 * n),
        *wq = dev_alloc(32 * n);
   // stand-in gate program: n_gates Poseidon-round-shaped gates folded with y (see tools/proof_flow.py)
   std::vector<Fr> consts;
@@ -129,6 +134,22 @@ int main(int argc, char** argv) {
     return f;
   };
   auto b8 = [](const Fr& f) { return reinterpret_cast<const uint8_t*>(&f); };
+  hipStream_t st[2];
+  hipEvent_t ev_fork, ev_join[2];
+  for (auto& x : st) HK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+  HK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  for (auto& x : ev_join) HK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+  // fork: side streams wait for everything enqueued on the default stream; join: the default stream waits for them
+  auto fork = [&]() {
+    HK(hipEventRecord(ev_fork, nullptr));
+    for (auto& x : st) HK(hipStreamWaitEvent(x, ev_fork, 0));
+  };
+  auto join = [&]() {
+    for (int i = 0; i < 2; i++) {
+      HK(hipEventRecord(ev_join[i], st[i]));
+      HK(hipStreamWaitEvent(nullptr, ev_join[i], 0));
+    }
+  };
   std::map<std::string, double> best;
   for (int rep = 0; rep < reps + 1; rep++) {
     std::map<std::string, double> t;
@@ -145,11 +166,25 @@ int main(int argc, char** argv) {
     t["2_lookup_permuted_commit"] = ms_since(t1); t1 = clk::now();
     Fr beta = challenge(out), gamma = challenge(out + 64), one = rand_fr(), delta4 = rand_fr();
     // 3: grand products, one fused commitment job (three Lagrange-form, one coefficient-form)
-    CK(sg_permutation_product_dev(perm_cols, sigma_lag.data(), 4, b8(beta), b8(gamma), b8(one), k, nullptr, z0, nullptr));
-    uint8_t z0_last[32];
-    HK(hipMemcpy(z0_last, static_cast<uint8_t*>(z0) + 32 * (n - 6), 32, hipMemcpyDeviceToHost));
-    CK(sg_permutation_product_dev(perm_cols + 4, sigma_lag.data() + 4, 2, b8(beta), b8(gamma), b8(delta4), k, z0_last, z1, nullptr));
-    CK(sg_lookup_product_dev(advice[0], advice[1], advice[2], instance, b8(beta), b8(gamma), n, zl, nullptr));
+    if (multi) {
+      // z1 continues from z0's last usable value: compute it from 1 concurrently, scale afterwards
+      fork();
+      CK(sg_permutation_product_dev(perm_cols, sigma_lag.data(), 4, b8(beta), b8(gamma), b8(one), k, nullptr, z0, nullptr));
+      CK(sg_permutation_product_dev(perm_cols + 4, sigma_lag.data() + 4, 2, b8(beta), b8(gamma), b8(delta4), k, nullptr, z1, st[0]));
+      CK(sg_lookup_product_dev(advice[0], advice[1], advice[2], instance, b8(beta), b8(gamma), n, zl, st[1]));
+      uint8_t z0_last[32];   // waits for z0 only (default stream); z1 and zl keep running on their streams
+      HK(hipMemcpyAsync(z0_last, static_cast<uint8_t*>(z0) + 32 * (n - 6), 32, hipMemcpyDeviceToHost, nullptr));
+      HK(hipStreamSynchronize(nullptr));
+      join();
+      void* z1p[1] = {z1};
+      CK(sg_fr_lincomb_dev(z1p, z0_last, 1, n, z1, nullptr));   // z1 *= z0[n - 6]
+    } else {
+      CK(sg_permutation_product_dev(perm_cols, sigma_lag.data(), 4, b8(beta), b8(gamma), b8(one), k, nullptr, z0, nullptr));
+      uint8_t z0_last[32];
+      HK(hipMemcpy(z0_last, static_cast<uint8_t*>(z0) + 32 * (n - 6), 32, hipMemcpyDeviceToHost));
+      CK(sg_permutation_product_dev(perm_cols + 4, sigma_lag.data() + 4, 2, b8(beta), b8(gamma), b8(delta4), k, z0_last, z1, nullptr));
+      CK(sg_lookup_product_dev(advice[0], advice[1], advice[2], instance, b8(beta), b8(gamma), n, zl, nullptr));
+    }
     void* ph3[4] = {z0, z1, zl, advice[0]};
     int basis3[4] = {1, 1, 1, 0};
     CK(sg_commit_batch_mixed_dev(srs, basis3, ph3, 4, n, nullptr, out));
@@ -200,14 +235,17 @@ int main(int argc, char** argv) {
     std::vector<Set> sets = {{{coeff.begin(), coeff.end()}, 1},
                              {{coeff[0], coeff[1], coeff[2], coeff[6], coeff[7], coeff[8]}, 2},
                              {{coeff[6]}, 3}};
+    if (multi) fork();
     for (size_t s = 0; s < sets.size(); s++) {
-      CK(sg_fr_lincomb_dev(sets[s].polys.data(), b8(vsv[0]), (uint32_t)sets[s].polys.size(), n, tmp_a, nullptr));
-      void *src = tmp_a, *dst = tmp_b;
+      hipStream_t q = (multi && s > 0) ? st[s - 1] : nullptr;   // one rotation set per stream
+      void *src = tmps[2 * s], *dst = tmps[2 * s + 1];
+      CK(sg_fr_lincomb_dev(sets[s].polys.data(), b8(vsv[0]), (uint32_t)sets[s].polys.size(), n, src, q));
       for (int p = 0; p < sets[s].points; p++) {
-        CK(sg_fr_kate_division_dev(src, n, b8(x), p + 1 == sets[s].points ? quot[s] : dst, nullptr, nullptr));
+        CK(sg_fr_kate_division_dev(src, n, b8(x), p + 1 == sets[s].points ? quot[s] : dst, nullptr, q));
         std::swap(src, dst);
       }
     }
+    if (multi) join();
     CK(sg_fr_lincomb_dev(quot.data(), b8(vsv[0]), 3, n, hx, nullptr));
     CK(sg_commit_dev(srs, 0, hx, n, nullptr, out));
     Fr u = challenge(out);
@@ -219,7 +257,7 @@ int main(int argc, char** argv) {
     t["total"] = ms_since(t0);
     if (rep >= 1 && (best.empty() || t["total"] < best["total"])) best = t;  // rep 0 warms work spaces, plans, tables
   }
-  std::printf("{\"k\": %u, \"n_gates\": %d, \"driver\": \"c++\"", k, n_gates);
+  std::printf("{\"k\": %u, \"n_gates\": %d, \"driver\": \"c++\", \"multi_stream\": %d", k, n_gates, multi ? 1 : 0);
   for (auto& kv : best) std::printf(", \"%s\": %.4f", kv.first.c_str(), kv.second);
   std::printf("}\n");
   sg_srs_free(srs);
