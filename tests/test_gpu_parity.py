@@ -649,6 +649,40 @@ def test_ntt_batch(gpu, O, log_n):
         assert (got.cpu().numpy() == v).all()
 
 
+def test_independent_ops_on_several_streams(gpu, O):
+    """the work space of the NTT and of the scan-type helpers is per stream: in-place multi-pass transforms, grand
+    products and Kate divisions issued on three streams at once give the same bits as the oracle"""
+    import torch
+    from circuits_halo2_amd.arithmetic import kate_division, lookup_product, permutation_product
+    k = 14
+    n = 1 << k
+    dom = gpu.EvaluationDomain(6, k)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    cols = [O.random_fr(2700 + i, n) for i in range(9)]
+    beta, gamma, one, b = O.random_fr(2710, 1), O.random_fr(2711, 1), fr_np([1]), O.random_fr(2712, 1)
+    d = [dev(c) for c in cols]
+    torch.cuda.synchronize()
+    res = {}
+    for rep in range(3):                      # several rounds: buffers are reused while other streams still run
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                a = d[3 * si].clone()
+                res[("coeff", si)] = dom.lagrange_to_coeff(a)                       # 3-pass, in place, scratch
+                res[("ext", si)] = dom.coeff_to_extended(res[("coeff", si)])
+                res[("z", si)] = permutation_product([d[3 * si], d[3 * si + 1]], [d[3 * si + 2], d[3 * si]], beta, gamma, one, k)
+                res[("zl", si)] = lookup_product(d[3 * si], d[3 * si + 1], d[3 * si + 2], d[3 * si], beta, gamma)
+                res[("q", si)] = kate_division(d[3 * si + 1], b)
+    torch.cuda.synchronize()
+    for si in range(3):
+        c0, c1, c2 = cols[3 * si], cols[3 * si + 1], cols[3 * si + 2]
+        want_c = O.lagrange_to_coeff(c0, k)
+        assert (res[("coeff", si)].cpu().numpy() == want_c).all()
+        assert (res[("ext", si)].cpu().numpy() == O.coeff_to_extended(want_c, k, dom.extended_k)).all()
+        assert (res[("z", si)].cpu().numpy() == O.permutation_product([c0, c1], [c2, c0], beta, gamma, one, k)).all()
+        assert (res[("zl", si)].cpu().numpy() == O.lookup_product(c0, c1, c2, c0, beta, gamma)).all()
+        assert (res[("q", si)].cpu().numpy() == O.fr_kate_division(c1, b)[0]).all()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_proof_flow_schedule_runs(gpu, overlap):
     """tools/proof_flow.py (what bench.py reports as proof_flow_k17) at a small size: every phase executes, on one
