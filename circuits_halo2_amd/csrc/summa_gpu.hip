@@ -131,7 +131,7 @@ struct Context {
   hipStream_t bstream[2] = {nullptr, nullptr};
   hipStream_t tstream[2] = {nullptr, nullptr};  // high-priority tails
   hipEvent_t ev_in = nullptr;
-  DevBuf<uint8_t> stage_a, stage_b, scratch, gate_blob;
+  DevBuf<uint8_t> stage_a, stage_b, scratch;
   std::vector<uint8_t> gate_blob_host;
   std::map<uint64_t, GateProgram> gate_cache;  // lowered gate programs by structure hash
   // in-place multi-pass transforms need a scratch vector; one per caller stream, so that transforms
@@ -313,7 +313,6 @@ void sg_shutdown(void) {
   g_ctx->stage_a.release();
   g_ctx->stage_b.release();
   g_ctx->scratch.release();
-  g_ctx->gate_blob.release();
   for (auto& kv : g_ctx->ntt_scratch) kv.second.release();
   g_ctx->ntt_scratch.clear();
   for (auto& kv : g_ctx->stream_scratch) kv.second.release();
@@ -1269,12 +1268,14 @@ int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* con
   for (const void* c : cols)
     if (!c) return fail(SG_ERR_INVALID, "sg_quotient_gates: null column");
   hipStream_t s = pick_stream(stream);
-  // the staging vector lives in the context: it must outlive the asynchronous copy
+  // program + column pointers + constants: one blob per stream on the device (a call on another stream may still
+  // be running from its own); the host staging vector is free again once the small copy has completed
   const size_t bytes = gates_blob(prog, cols.data(), &g_ctx->gate_blob_host);
-  hipError_t e = g_ctx->gate_blob.reserve(bytes);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // a previous call's copy may still read the staging vector
-  if (e == hipSuccess) e = hipMemcpyAsync(g_ctx->gate_blob.p, g_ctx->gate_blob_host.data(), bytes, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = gates_run(prog, g_ctx->gate_blob.p, static_cast<fp_words*>(d_values), k, ext_k, s);
+  uint8_t* d_blob = nullptr;
+  hipError_t e = scratch_for(s, 2, bytes, &d_blob);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_blob, g_ctx->gate_blob_host.data(), bytes, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = gates_run(prog, d_blob, static_cast<fp_words*>(d_values), k, ext_k, s);
   if (e != hipSuccess) return hip_fail("quotient_gates", e);
   return SG_OK;
 }
