@@ -269,9 +269,15 @@ hipError_t NttEngine::local_twiddles(const words8& omega_r, uint32_t log_r, hipS
   hipError_t err = hipMalloc(&d, sizeof(fp_words) * count);
   if (err != hipSuccess) return err;
   fill_powers<<<(count + 255) / 256, 256, 0, stream>>>(d, omega_r, count);
+  err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);  // complete before any other stream may use the cached table
+  if (err != hipSuccess) {
+    (void)hipFree(d);
+    return err;
+  }
   local_tw_.push_back({log_r, omega_r, d});
   *out = d;
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 // choose the pass factorisation for a 2^log_n transform
