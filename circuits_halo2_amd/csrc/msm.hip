@@ -1192,6 +1192,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   const uint32_t NB = j.NB = (j.fixed ? (uint32_t)M : W) * nbw;
   if (NB > (1u << 21)) return hipErrorInvalidValue;
   const size_t entries = (size_t)W * n;
+  if (entries >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // bucket offsets are 32-bit (n <= 2^27 at c = 16)
   // task length: deep enough to amortise, shallow enough that the longest dependent chain of
   // additions stays a small multiple of the per-lane share of the work
   j.log_L = cfg_.log_seg;
