@@ -25,6 +25,7 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 };
 #endif
 
+static constexpr uint32_t NTT_BATCH_MAX = 16;
 struct NttPlan {
   uint32_t log_n;
   words8 omega;
@@ -47,6 +48,10 @@ class NttEngine {
   hipError_t transform(const fp_words* in, size_t in_len, fp_words* out, fp_words* scratch, uint32_t log_n,
                        const words8& omega, const words8* scale, const words8* pre3, const words8* post3,
                        hipStream_t stream);
+  // `count` <= NTT_BATCH_MAX in-place transforms of one size, one launch per pass (see ntt.hip)
+  hipError_t transform_batch(fp_words* const* a, uint32_t count, fp_words* scratch, uint32_t log_n, const words8& omega,
+                             const words8* scale, hipStream_t stream, const fp_words* const* src = nullptr,
+                             size_t src_len = 0, const words8* pre3 = nullptr);
   // cached table of omega_r^t, t < 2^(log_r - 1), as 2^261-domain words
   hipError_t local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out);
 

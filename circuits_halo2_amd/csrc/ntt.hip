@@ -44,6 +44,11 @@ struct PassArgs {
   uint32_t post3;            // multiply output j by post[j % 3] (extended_to_coeff / plain scale)
   uint32_t pre[3][8];        // Montgomery-2^256 words, converted once per workgroup
   uint32_t post[3][8];
+  // batched launch (nbatch > 0): blockIdx.y selects the vector; same plan for all (small transforms are a chain
+  // of launches at their ~5 us floor: the 9 iNTTs of a proof become 3 launches instead of 27)
+  uint32_t nbatch;
+  const fp_words* in_b[NTT_BATCH_MAX];
+  fp_words* out_b[NTT_BATCH_MAX];
 };
 
 struct LdsTile {
@@ -70,6 +75,8 @@ __device__ __forceinline__ f29 lds_get(const LdsTile& t, uint32_t i) {
 __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
   extern __shared__ uint4 lds[];
   typedef Fr29 P;
+  const fp_words* __restrict__ p_in = p.nbatch ? p.in_b[blockIdx.y] : p.in;
+  fp_words* __restrict__ p_out = p.nbatch ? p.out_b[blockIdx.y] : p.out;
   const uint32_t R = 1u << p.log_r, T = 1u << p.log_t;
   const uint32_t E = R << p.log_t, H = (R >> 1) + 8;  // twiddles + 6 converted constants
   LdsTile d{lds, lds + E, reinterpret_cast<uint32_t*>(lds + 2 * E)};
@@ -101,7 +108,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
     size_t gi = base + t + ((size_t)r << p.log_b);
     f29 v;
     if (gi < p.in_len) {
-      v = f29_load_r256<P>(p.in + gi);
+      v = f29_load_r256<P>(p_in + gi);
       if (p.pre3) {
         uint32_t m = (uint32_t)(gi % 3);
         if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       } else {
         v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
       }
-      f29_store_canonical<P>(p.out + go, v);
+      f29_store_canonical<P>(p_out + go, v);
     }
   } else {
     for (uint32_t e = tid; e < E; e += nthr) {
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       } else {
         v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
       }
-      f29_store_canonical<P>(p.out + go, v);
+      f29_store_canonical<P>(p_out + go, v);
     }
   }
 }
@@ -372,8 +379,80 @@ static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n,
   size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 8) * 36 + 64;
   uint32_t threads = (uint32_t)std::min<size_t>(cfg.threads, std::max<size_t>(64, E / 2));
   uint32_t tiles = 1u << (log_n - a.log_r - log_t);
-  hipLaunchKernelGGL(ntt_pass, dim3(tiles), dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL(ntt_pass, dim3(tiles, a.nbatch ? a.nbatch : 1), dim3(threads), lds, stream, a);
   return hipGetLastError();
+}
+
+// `count` in-place transforms of one size as ONE launch per pass.  scratch: count * 2^log_n elements (multi-pass plans)
+hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_words* scratch, uint32_t log_n,
+                                      const words8& omega, const words8* scale, hipStream_t stream,
+                                      const fp_words* const* src, size_t src_len, const words8* pre3) {
+  if (count == 0) return hipSuccess;
+  if (count > NTT_BATCH_MAX || log_n == 0) return hipErrorInvalidValue;
+  const NttPlan* pl;
+  const bool fold_scale = scale && log_n > cfg_.max_single_log;
+  hipError_t err = get_plan(log_n, omega, fold_scale ? scale : nullptr, stream, &pl);
+  if (err != hipSuccess) return err;
+  const size_t n = (size_t)1 << log_n;
+  // src == nullptr: in place (multi-pass plans go through `scratch`); otherwise out of place from src[i]
+  // (src_len <= n elements, zero beyond; optional pre-scaling by pre3[i % 3]) with a[i] as the intermediate
+  PassArgs p{};
+  p.nbatch = count;
+  enum Where { DATA, MID };
+  bool first = true;
+  auto io = [&](Where in, Where out) {
+    for (uint32_t i = 0; i < count; i++) {
+      fp_words* mid = src ? a[i] : scratch + (size_t)i * n;
+      p.in_b[i] = (first && src) ? src[i] : in == DATA ? a[i] : mid;
+      p.out_b[i] = out == DATA ? a[i] : mid;
+    }
+    p.in_len = (first && src) ? (uint32_t)std::min(src_len, n) : (uint32_t)n;
+    p.pre3 = 0;
+    if (first && pre3) {
+      p.pre3 = 1;
+      for (int i = 0; i < 3; i++) std::memcpy(p.pre[i], pre3[i].l, 32);
+    }
+    first = false;
+  };
+  auto last_scale = [&](bool last) {
+    p.post3 = 0;
+    if (last && scale && !fold_scale) {
+      p.post3 = 1;
+      for (int i = 0; i < 3; i++) std::memcpy(p.post[i], scale->l, 32);
+    }
+  };
+  if (pl->npass == 1) {
+    io(DATA, DATA);
+    p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = log_n; p.log_b = 0; p.kind = 0;
+    last_scale(true);
+    return launch_pass(cfg_, p, log_n, stream);
+  }
+  if (pl->npass == 2) {
+    const uint32_t l1 = pl->l[0], l2 = pl->l[1];
+    io(DATA, MID);
+    p.tw_local = pl->tw_local[1]; p.tw_pass = pl->tw_pass[0]; p.log_r = l2; p.log_b = l1; p.kind = 1; p.sig_lo = l1; p.sig_hi = 0;
+    last_scale(false);
+    err = launch_pass(cfg_, p, log_n, stream);
+    if (err != hipSuccess) return err;
+    io(MID, DATA);
+    p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2; p.kind = 0;
+    last_scale(true);
+    return launch_pass(cfg_, p, log_n, stream);
+  }
+  const uint32_t l1 = pl->l[0], l2 = pl->l[1], l3 = pl->l[2];
+  io(DATA, MID);
+  p.tw_local = pl->tw_local[2]; p.tw_pass = pl->tw_pass[0]; p.log_r = l3; p.log_b = l1 + l2; p.kind = 1; p.sig_lo = l1; p.sig_hi = l2;
+  last_scale(false);
+  err = launch_pass(cfg_, p, log_n, stream);
+  if (err != hipSuccess) return err;
+  io(MID, MID);
+  p.tw_local = pl->tw_local[1]; p.tw_pass = pl->tw_pass[1]; p.log_r = l2; p.log_b = l3; p.kind = 0;
+  err = launch_pass(cfg_, p, log_n, stream);
+  if (err != hipSuccess) return err;
+  io(MID, DATA);
+  p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2 + l3; p.kind = 0;
+  last_scale(true);
+  return launch_pass(cfg_, p, log_n, stream);
 }
 
 hipError_t NttEngine::init() {

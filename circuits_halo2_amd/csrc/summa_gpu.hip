@@ -644,6 +644,27 @@ int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32],
   if (divisor) std::memcpy(&dv, divisor, 32);
   const size_t n = (size_t)1 << log_n;
   const bool need_scratch = log_n > c.ntt.config().max_single_log;
+  if (log_n >= 1 && log_n <= 18) {
+    // small transforms: one launch per pass for up to 16 vectors (each launch is at its ~5 us floor otherwise);
+    // asynchronous on the caller's stream, scratch per stream
+    hipStream_t s = pick_stream(stream);
+    for (size_t first = 0; first < count; first += NTT_BATCH_MAX) {
+      const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - first);
+      fp_words* ptrs[NTT_BATCH_MAX];
+      for (uint32_t i = 0; i < cnt; i++) {
+        if (!d_a[first + i]) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch: null vector");
+        ptrs[i] = static_cast<fp_words*>(d_a[first + i]);
+      }
+      uint8_t* scr = nullptr;
+      if (need_scratch) {
+        hipError_t e = scratch_for(s, 3, (size_t)NTT_BATCH_MAX * n * 32, &scr);
+        if (e != hipSuccess) return hip_fail("ntt scratch", e);
+      }
+      hipError_t e = c.ntt.transform_batch(ptrs, cnt, reinterpret_cast<fp_words*>(scr), log_n, w, divisor ? &dv : nullptr, s);
+      if (e != hipSuccess) return hip_fail("ntt batch", e);
+    }
+    return SG_OK;
+  }
   // one scratch area per stream
   if (need_scratch) {
     hipError_t e = c.scratch.reserve(2 * n * 32);
@@ -715,6 +736,34 @@ int sg_coeff_to_extended_dev(const void* d_coeffs, uint32_t k, uint32_t ext_k, v
   words8 pre[3] = {dc->one, dc->zeta, dc->zeta2};
   return ntt_dev(static_cast<const fp_words*>(d_coeffs), (size_t)1 << k, static_cast<fp_words*>(d_out), ext_k, dc->omega,
                  nullptr, pre, nullptr, pick_stream(stream));
+}
+// several columns at once: one launch per pass while the extended domain is small (<= 2^18), one transform after
+// the other above that (a 2^20 transform fills the chip on its own)
+int sg_coeff_to_extended_batch_dev(const void* const* d_coeffs, void* const* d_out, size_t count, uint32_t k, uint32_t ext_k,
+                                   void* stream) {
+  if ((count && (!d_coeffs || !d_out)) || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_coeff_to_extended_batch: bad argument");
+  for (size_t i = 0; i < count; i++)
+    if (!d_coeffs[i] || !d_out[i] || d_coeffs[i] == d_out[i]) return fail(SG_ERR_INVALID, "sg_coeff_to_extended_batch: bad vector");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(ext_k, &dc));
+  hipStream_t s = pick_stream(stream);
+  TRY(sync_own_stream_into(s));
+  words8 pre[3] = {dc->one, dc->zeta, dc->zeta2};
+  if (ext_k >= 1 && ext_k <= 18) {
+    for (size_t first = 0; first < count; first += NTT_BATCH_MAX) {
+      const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - first);
+      hipError_t e = g_ctx->ntt.transform_batch(reinterpret_cast<fp_words* const*>(d_out + first), cnt, nullptr, ext_k, dc->omega,
+                                                nullptr, s, reinterpret_cast<const fp_words* const*>(d_coeffs + first),
+                                                (size_t)1 << k, pre);
+      if (e != hipSuccess) return hip_fail("coeff_to_extended batch", e);
+    }
+    return SG_OK;
+  }
+  for (size_t i = 0; i < count; i++)
+    TRY(ntt_dev(static_cast<const fp_words*>(d_coeffs[i]), (size_t)1 << k, static_cast<fp_words*>(d_out[i]), ext_k, dc->omega,
+                nullptr, pre, nullptr, s));
+  return SG_OK;
 }
 int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint8_t* out) {
   if (!coeffs || !out || ext_k > 28 || k > ext_k) return fail(SG_ERR_INVALID, "sg_coeff_to_extended: bad argument");

@@ -84,6 +84,21 @@ class EvaluationDomain:
         ffi.check(L.sg_coeff_to_extended(ffi.ptr(buf), C.c_uint32(self.k), C.c_uint32(self.extended_k), ffi.ptr(out)))
         return out
 
+    def coeff_to_extended_batch(self, polys):
+        """coeff_to_extended of several device polynomials (one launch per pass while the extended domain is small)"""
+        import torch
+        m = len(polys)
+        for p in polys:
+            if not _is_torch_cuda(p) or p.numel() != 32 << self.k:
+                raise ValueError("coeff_to_extended_batch: device tensors of 2^k elements expected")
+        outs = [torch.empty(32 << self.extended_k, dtype=torch.uint8, device=p.device) for p in polys]
+        if m:
+            pin = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+            pout = (C.c_void_p * m)(*[o.data_ptr() for o in outs])
+            ffi.check(ffi.lib().sg_coeff_to_extended_batch_dev(pin, pout, C.c_size_t(m), C.c_uint32(self.k),
+                                                               C.c_uint32(self.extended_k), ffi.current_stream_ptr()))
+        return outs
+
     def extended_to_coeff(self, a):
         """inverse of coeff_to_extended, truncated to n * quotient_poly_degree coefficients."""
         L = ffi.lib()

@@ -126,6 +126,9 @@ int sg_lagrange_to_coeff_dev(void* d_a, uint32_t k, void* stream);
  * (a[i] *= zeta^(i mod 3), zero-pad, best_fft with omega_ext); fused into one transform. */
 int sg_coeff_to_extended(const uint8_t* coeffs, uint32_t k, uint32_t ext_k, uint8_t* out);
 int sg_coeff_to_extended_dev(const void* d_coeffs, uint32_t k, uint32_t ext_k, void* d_out, void* stream);
+/* the same for `count` columns (the 9 coeff_to_extended calls of a proof): one launch per pass while 2^ext_k is small */
+int sg_coeff_to_extended_batch_dev(const void* const* d_coeffs, void* const* d_out, size_t count, uint32_t k, uint32_t ext_k,
+                                   void* stream);
 
 /* ---- N4: EvaluationDomain::extended_to_coeff: in place over 2^ext_k elements (iNTT with
  * omega_ext^-1 and 2^-ext_k, then a[i] *= zeta^-(i mod 3)); the caller truncates to

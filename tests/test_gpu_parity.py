@@ -636,6 +636,17 @@ def test_lookup_grand_product(gpu, O, n):
     assert (last == fr_np([1])).all()
 
 
+@pytest.mark.parametrize("k,j", [(4, 6), (9, 6), (13, 6), (15, 6), (16, 3), (17, 6)])
+def test_coeff_to_extended_batch(gpu, O, k, j):
+    """several columns per launch (extended domain <= 2^18) or one after the other: same bits as the oracle"""
+    dom = gpu.EvaluationDomain(j, k)
+    cols = [O.random_fr(2800 + i, 1 << k) for i in range(5)]
+    outs = dom.coeff_to_extended_batch([dev(c) for c in cols])
+    for c, o in zip(cols, outs):
+        assert (o.cpu().numpy() == O.coeff_to_extended(c, k, dom.extended_k, O.ncpu())).all()
+    assert dom.coeff_to_extended_batch([]) == []
+
+
 @pytest.mark.parametrize("log_n", [9, 13, 17])
 def test_ntt_batch(gpu, O, log_n):
     from circuits_halo2_amd.arithmetic import best_fft_batch

@@ -134,6 +134,9 @@ int main(int argc, char** argv) {
     return f;
   };
   auto b8 = [](const Fr& f) { return reinterpret_cast<const uint8_t*>(&f); };
+  uint8_t omega_inv[32], n_inv[32];
+  CK(sg_domain_constant(k, 1, omega_inv));
+  CK(sg_domain_constant(k, 2, n_inv));
   hipStream_t st[2];
   hipEvent_t ev_fork, ev_join[2];
   for (auto& x : st) HK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
@@ -192,11 +195,9 @@ int main(int argc, char** argv) {
     Fr y = challenge(out);
     // 4a: 9 x iNTT(2^k), 9 x coset NTT(2^(k+3))
     void* lag[9] = {advice[0], advice[1], advice[2], instance, advice[2], instance, z0, z1, zl};
-    for (int i = 0; i < 9; i++) {
-      HK(hipMemcpyAsync(coeff[i], lag[i], 32 * n, hipMemcpyDeviceToDevice, nullptr));
-      CK(sg_lagrange_to_coeff_dev(coeff[i], k, nullptr));
-      CK(sg_coeff_to_extended_dev(coeff[i], k, ext_k, ext[i], nullptr));
-    }
+    for (int i = 0; i < 9; i++) HK(hipMemcpyAsync(coeff[i], lag[i], 32 * n, hipMemcpyDeviceToDevice, nullptr));
+    CK(sg_ntt_fr_batch_dev(coeff.data(), 9, omega_inv, n_inv, k, nullptr));      // 9 iNTTs: one launch per pass
+    CK(sg_coeff_to_extended_batch_dev(coeff.data(), ext.data(), 9, k, ext_k, nullptr));
     HK(hipDeviceSynchronize());
     t["4a_ntts"] = ms_since(t1); t1 = clk::now();
     // 4b: evaluate_h

@@ -61,10 +61,10 @@ def run_flow(k=17, n_gates=12, reps=3, overlap=True):
         if overlap:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                co = [dom.lagrange_to_coeff(c.clone()) for c in cols]
-                return co, [dom.coeff_to_extended(c) for c in co]
-        co = [dom.lagrange_to_coeff(c.clone()) for c in cols]
-        return co, [dom.coeff_to_extended(c) for c in co]
+                co = A.best_fft_batch([c.clone() for c in cols], dom.get_omega_inv(), k, divisor=dom.ifft_divisor())
+                return co, dom.coeff_to_extended_batch(co)
+        co = A.best_fft_batch([c.clone() for c in cols], dom.get_omega_inv(), k, divisor=dom.ifft_divisor())   # one launch per pass
+        return co, dom.coeff_to_extended_batch(co)
 
     def flow():
         t = {}
