@@ -1199,8 +1199,16 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   if (!j.log_L) {
     const size_t share = 2 * entries / (256 * 4 * 64 * 4);  // entries per resident lane, x2
     // small jobs are pure latency chains: shorter tasks (more lanes, more merging) win -- measured at k = 11 .. 17
-    j.log_L = entries < ((size_t)1 << 16) ? 2 : entries < ((size_t)1 << 19) ? 3 : 4;
-    while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
+    // (tools/sweep_seg_batch.sh, time_fixed_phases.py: below ~12 M entries the chip is not full and long tasks only
+    // lengthen the chain: 6.3 M entries, L = 64 -> 16: 1.25 -> 1.02 ms)
+    if (entries < ((size_t)1 << 16)) j.log_L = 2;
+    else if (entries < ((size_t)1 << 19)) j.log_L = 3;
+    else if (entries <= (size_t)7 << 20) j.log_L = 4;
+    else if (entries <= (size_t)12 << 20) j.log_L = 5;
+    else {
+      j.log_L = 4;
+      while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
+    }
   }
   // two-pass sort (msm_partition / msm_fine_sort) for everything but small jobs: B coarse bins per
   // bucket set, sized for ~4 Ki entries per bin (half an LDS tile, so Poisson tails still fit)
