@@ -1201,8 +1201,15 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     // small jobs are pure latency chains: shorter tasks (more lanes, more merging) win -- measured at k = 11 .. 17
     // (tools/sweep_seg_batch.sh, time_fixed_phases.py: below ~12 M entries the chip is not full and long tasks only
     // lengthen the chain: 6.3 M entries, L = 64 -> 16: 1.25 -> 1.02 ms)
+    const size_t depth = entries / NB;  // mean entries per bucket
     if (entries < ((size_t)1 << 16)) j.log_L = 2;
     else if (entries < ((size_t)1 << 19)) j.log_L = 3;
+    else if (depth < 40 && entries >= ((size_t)1 << 20)) {
+      // large jobs with shallow buckets (arbitrary bases: ~n / 2^(c-1) per bucket): a task is a whole bucket, and L
+      // only has to exceed the largest bucket so that no merge round is needed (k = 18: L = 16 -> 64: 0.99 -> 0.88 ms)
+      j.log_L = 6;
+      while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
+    }
     else if (entries <= (size_t)7 << 20) j.log_L = 4;
     else if (entries <= (size_t)12 << 20) j.log_L = 5;
     else {
