@@ -1207,8 +1207,11 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     else if (depth < 40 && entries >= ((size_t)1 << 20)) {
       // large jobs with shallow buckets (arbitrary bases: ~n / 2^(c-1) per bucket): a task is a whole bucket, and L
       // only has to exceed the largest bucket so that no merge round is needed (k = 18: L = 16 -> 64: 0.99 -> 0.88 ms)
+      // (uniform scalars: the largest of NB Poisson(depth) buckets is ~ depth + 6 sqrt(depth), 66 at depth 32)
+      size_t need = depth + 8;
+      for (size_t r = 1; r * r <= 64 * depth; r++) need = depth + 8 + r;  // + 8 sqrt(depth)
       j.log_L = 6;
-      while (j.log_L < 8 && ((size_t)1 << j.log_L) < share) j.log_L++;
+      while (j.log_L < 8 && (((size_t)1 << j.log_L) < share || ((size_t)1 << j.log_L) < need)) j.log_L++;
     }
     else if (entries <= (size_t)7 << 20) j.log_L = 4;
     else if (entries <= (size_t)12 << 20) j.log_L = 5;
