@@ -1,0 +1,168 @@
+"""Constraint system of the reference's `MstInclusionCircuit<LEVELS, N_CURRENCIES = 2, N_BYTES = 8>` as input
+for the device-side `evaluate_h` (arithmetic.GraphEvaluator / quotient_permutation / quotient_lookup).
+
+Host mirror of what `halo2_proofs::plonk::Evaluator::new(cs)` derives from the circuit's `ConstraintSystem`
+[REF zk_prover/src/circuits/merkle_sum_tree.rs:143-196 (configure), chips/poseidon/poseidon_chip.rs (Pow5 chip,
+WIDTH 2 / RATE 1), chips/merkle_sum_tree.rs (swap / sum gates), chips/range/range_check.rs (8-bit lookup)];
+the resulting polynomial list is the one the generated verifier folds [REF contracts/src/InclusionVerifier.sol:495-1000]
+and is pinned against it by tests/test_verifier_cpu.py (same gate values as the restated verifier that accepts the
+reference's shipped proof) and, on the GPU, row by row by tests/test_gpu_parity.py.
+
+Column layout (halo2's column numbering after selector compression, as in the verifying key):
+  advice a0, a1 (Poseidon state / chip operands), a2 (partial-round s-box, swap bit, sum)
+  fixed  f0, f1 = rc_a; f2, f3 = rc_b; f4 = range table; f5 = lookup selector; f6 = compressed simple selector
+         (1: swap, 2: sum, 3 / 4: pad-and-add of Poseidon chip 1 / 2); f7, f8 = s_full, s_partial of chip 1; f9, f10 of chip 2
+  instance i0;  permutation over (f2, a0, a1, f3, a2, i0) in chunks of 4;  one lookup.
+"""
+from __future__ import annotations
+
+from . import arithmetic as A
+from functools import lru_cache
+
+from .poseidon_params import generate as _generate_poseidon
+
+
+@lru_cache(maxsize=None)
+def _poseidon():
+    return _generate_poseidon()
+
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+NUM_ADVICE, NUM_FIXED, NUM_INSTANCE = 3, 11, 1
+BLINDING_FACTORS = 5
+DEGREE = 6                      # cs.degree(): extended domain = 2^(k + 3), 5 quotient pieces
+PERMUTATION_COLUMNS = [(A.FIXED, 2), (A.ADVICE, 0), (A.ADVICE, 1), (A.FIXED, 3), (A.ADVICE, 2), (A.INSTANCE, 0)]
+PERMUTATION_CHUNK = DEGREE - 2
+
+
+class Expr:
+    """Polynomial expression over column queries (halo2's `Expression`), just enough for this circuit."""
+
+    def __init__(self, op, *args):
+        self.op, self.args = op, args
+
+    @staticmethod
+    def const(v: int):
+        return Expr("const", v % R)
+
+    @staticmethod
+    def query(kind: int, column: int, rotation: int = 0):
+        return Expr("query", kind, column, rotation)
+
+    def _wrap(self, o):
+        return o if isinstance(o, Expr) else Expr.const(o)
+
+    def __add__(self, o):
+        return Expr("add", self, self._wrap(o))
+
+    def __sub__(self, o):
+        return Expr("sub", self, self._wrap(o))
+
+    def __rsub__(self, o):
+        return Expr("sub", self._wrap(o), self)
+
+    def __mul__(self, o):
+        return Expr("mul", self, self._wrap(o))
+
+    __radd__, __rmul__ = __add__, __mul__
+
+    def pow5(self):
+        sq = self * self
+        return sq * sq * self
+
+    def degree(self) -> int:
+        if self.op == "const":
+            return 0
+        if self.op == "query":
+            return 1
+        d = [a.degree() for a in self.args]
+        return sum(d) if self.op == "mul" else max(d)
+
+    def evaluate(self, q) -> int:
+        """q(kind, column, rotation) -> int; integer evaluation (used by the CPU tests)"""
+        if self.op == "const":
+            return self.args[0]
+        if self.op == "query":
+            return q(*self.args)
+        a, b = (x.evaluate(q) for x in self.args)
+        return (a + b) % R if self.op == "add" else (a - b) % R if self.op == "sub" else a * b % R
+
+    def lower(self, g: A.GraphEvaluator):
+        """append to a GraphEvaluator the way upstream's `add_expression` does; returns the value source"""
+        if self.op == "const":
+            return g.add_constant(((self.args[0] << 256) % R).to_bytes(32, "little"))
+        if self.op == "query":
+            return g.query(*self.args)
+        a, b = self.args
+        if self.op == "mul" and a is b:
+            return g.add_calculation(A.SQUARE, a.lower(g))
+        va, vb = a.lower(g), b.lower(g)
+        if self.op == "mul" and va == vb:
+            return g.add_calculation(A.SQUARE, va)
+        return g.add_calculation({"add": A.ADD, "sub": A.SUB, "mul": A.MUL}[self.op], va, vb)
+
+
+def gates():
+    """the 19 gate polynomials in the constraint system's order"""
+    _, mds, mds_inv = _poseidon()
+    a = lambda c, r=0: Expr.query(A.ADVICE, c, r)
+    f = lambda c: Expr.query(A.FIXED, c, 0)
+    out = []
+
+    def poseidon_chip(s_full, s_partial):
+        sbox = [(a(j) + f(j)).pow5() for j in range(2)]
+        for i in range(2):   # full round
+            out.append(s_full * (sbox[0] * mds[i][0] + sbox[1] * mds[i][1] - a(i, 1)))
+        # two partial rounds per row
+        out.append(s_partial * (sbox[0] - a(2)))
+        mid = [a(2), a(1) + f(1)]
+        r_mid = [mid[0] * mds[i][0] + mid[1] * mds[i][1] for i in range(2)]
+        nxt = [a(0, 1) * mds_inv[i][0] + a(1, 1) * mds_inv[i][1] for i in range(2)]
+        out.append(s_partial * ((r_mid[0] + f(2)).pow5() - nxt[0]))
+        out.append(s_partial * (r_mid[1] + f(3) - nxt[1]))
+
+    def simple_selector(value):
+        s = f(6)
+        for v in range(1, 5):
+            if v != value:
+                s = s * (v - f(6))
+        return s
+
+    def pad_and_add(value):
+        s = simple_selector(value)
+        out.append(s * (a(0, -1) + a(0) - a(0, 1)))
+        out.append(s * (a(1, -1) - a(1, 1)))
+
+    poseidon_chip(f(7), f(8))
+    pad_and_add(3)
+    poseidon_chip(f(9), f(10))
+    pad_and_add(4)
+    s = simple_selector(1)
+    out.append(s * a(2) * (1 - a(2)))
+    out.append(s * ((a(1) - a(0)) * a(2) + a(0) - a(0, 1)))
+    out.append(s * ((a(0) - a(1)) * a(2) + a(1) - a(1, 1)))
+    s = simple_selector(2)
+    for _ in range(2):   # one sum gate per currency
+        out.append(s * (a(0) + a(1) - a(2)))
+    return out
+
+
+def lookup_expressions():
+    """(input, table) of the 8-bit range check: f5 * (a0 - 2^8 * a0_next) in f4"""
+    a0, a0n = Expr.query(A.ADVICE, 0, 0), Expr.query(A.ADVICE, 0, 1)
+    return Expr.query(A.FIXED, 5, 0) * (a0 - a0n * 256), Expr.query(A.FIXED, 4, 0)
+
+
+def gate_graph() -> A.GraphEvaluator:
+    """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y)"""
+    g = A.GraphEvaluator()
+    parts = [e.lower(g) for e in gates()]
+    g.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), (A.Y, 0, 0), parts)
+    return g
+
+
+def expression_graph(expr: Expr) -> A.GraphEvaluator:
+    """a program that stores one expression per row (the compressed lookup input / table columns)"""
+    g = A.GraphEvaluator()
+    g.add_calculation(A.STORE, expr.lower(g))
+    return g

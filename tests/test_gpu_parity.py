@@ -1249,3 +1249,42 @@ def test_merkle_sum_tree_vs_oracle(gpu, O, n, nc):
         m >>= 1
     with pytest.raises(ValueError):
         MerkleSumTree.from_entries([("x", [1 << 64] * nc)], nc, n_bytes=8)
+
+
+# ---------------------------------------------------------------- the reference circuit's own constraint system
+@pytest.mark.parametrize("k,ext_k,sample", [(5, 8, 0), (11, 14, 96)])
+def test_mst_inclusion_constraint_system_on_device(gpu, O, k, ext_k, sample):
+    """evaluate_h's custom-gate block with the constraint system of the reference's MstInclusionCircuit
+    (circuits_halo2_amd.mst_inclusion; k = 11 / 2^14 extended rows is the reference's own configuration):
+    bit-exact against (a) the C oracle's interpreter of the same program on every row and (b) the gate polynomials
+    of the restated verifier -- the one that accepts the reference's shipped proof, tests/test_verifier_cpu.py --
+    evaluated with Python integers row by row (every row at k = 5, a sample at k = 11).  Same for the lookup's
+    compressed input expression."""
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd import mst_inclusion as M
+    from oracle import pyref as PR
+    from oracle import summa_verifier as SV
+    ne, step = 1 << ext_k, 1 << (ext_k - k)
+    fixed = [O.random_fr(5100 + i, ne) for i in range(M.NUM_FIXED)]
+    advice = [O.random_fr(5200 + i, ne) for i in range(M.NUM_ADVICE)]
+    beta, gamma, theta, y = (O.random_fr(5300 + i, 1) for i in range(4))
+    start = O.random_fr(5310, ne)
+    none = np.zeros(0, dtype=np.uint8)
+    g = M.gate_graph()
+    want = O.quotient_gates(start, g.as_dict(), fixed, advice, [], none, beta, gamma, theta, y, k, ext_k)
+    got = A.quotient_gates(dev(start), g, [dev(c) for c in fixed], [dev(c) for c in advice], [], none, beta, gamma, theta, y,
+                           k, ext_k).cpu().numpy()
+    assert (got == want).all()
+    gi = M.expression_graph(M.lookup_expressions()[0])
+    got_in = A.quotient_gates(dev(start), gi, [dev(c) for c in fixed], [dev(c) for c in advice], [], none, beta, gamma, theta,
+                              y, k, ext_k).cpu().numpy()
+    cell = lambda arr, row: PR.fr_from_bytes(bytes(arr[32 * row:32 * row + 32]))
+    yi = PR.fr_from_bytes(bytes(y))
+    rows = range(ne) if not sample else [int(r) for r in np.random.default_rng(7).integers(0, ne, sample)] + [0, ne - 1]
+    for row in rows:
+        q = lambda kind, c, rot: cell((fixed if kind == "f" else advice)[c], (row + rot * step) % ne)
+        acc = cell(start, row)
+        for t in SV.gate_values(q):
+            acc = (acc * yi + t) % PR.R
+        assert cell(got, row) == acc, row
+        assert cell(got_in, row) == SV.lookup_input_table(q)[0], row

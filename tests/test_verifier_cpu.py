@@ -1,0 +1,144 @@
+"""The restated verifier (oracle/summa_verifier.py) against the reference's own artefacts: its shipped proof K6
+(tests/golden/k6_inclusion_proof_solidity_calldata.json, a data file of the reference:
+zk_prover/examples/inclusion_proof_solidity_calldata.json) and the values its generated verifier computes on that
+proof (tests/golden/k6_verifier_trace.json, produced by oracle/yul_verifier_run.py from
+contracts/src/InclusionVerifier.sol).  Also: the product-side constraint system (circuits_halo2_amd/mst_inclusion.py)
+yields the same gate values as the restatement."""
+import json
+import os
+
+import pytest
+
+from oracle import pairing as PA
+from oracle import pyref as PR
+from oracle import summa_verifier as SV
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H = lambda s: int(s, 16)
+
+
+def load_k6():
+    tr = json.load(open(os.path.join(GOLD, "k6_verifier_trace.json")))
+    v = tr["vk"]
+    comm = [(H(a), H(b)) for a, b in v["commitments"]]
+    vk = {"vk_digest": H(v["vk_digest"]), "fixed_comms": comm[:11], "permutation_comms": comm[11:],
+          "g2": ((H(v["g2_x_2"]), H(v["g2_x_1"])), (H(v["g2_y_2"]), H(v["g2_y_1"]))),
+          "neg_s_g2": ((H(v["neg_s_g2_x_2"]), H(v["neg_s_g2_x_1"])), (H(v["neg_s_g2_y_2"]), H(v["neg_s_g2_y_1"])))}
+    cd = json.load(open(os.path.join(GOLD, "k6_inclusion_proof_solidity_calldata.json")))
+    return bytes.fromhex(cd["proof"][2:]), [H(x) for x in cd["public_inputs"]], vk, tr
+
+
+def test_pairing_bilinear_and_nondegenerate():
+    g2 = PR.G2_GENERATOR
+    assert PA.g2_is_on_curve(g2)
+    a, b = 0x1234567, 0x89ABCDEF01
+    pa, qb = PR.g1_mul(PR.G1_GEN, a), PR.g2_mul(g2, b)
+    pab = PR.g1_mul(PR.G1_GEN, a * b % PR.R)
+    assert PA.pairing_check([(pa, qb), (PR.g1_neg(pab), g2)])          # e(aG, bH) = e(abG, H)
+    assert not PA.pairing_check([(pa, qb), (PR.g1_neg(pa), g2)])
+    assert PA.pairing_check([(None, g2), (pa, None)])                  # identities pair to 1
+    assert PA.pairing(g2, PR.G1_GEN) != PA.F12_ONE
+
+
+def test_vk_constants_match_the_committed_kat():
+    """the trace's verifying key equals the constants transcribed earlier from the same contract (kat.json) and
+    -[s]_2 is a point of G2"""
+    _, _, vk, tr = load_k6()
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    assert vk["vk_digest"] == H(kat["vk_digest"])
+    assert vk["fixed_comms"] == [(H(a), H(b)) for a, b in kat["fixed_comms"]]
+    assert vk["permutation_comms"] == [(H(a), H(b)) for a, b in kat["permutation_comms"]]
+    assert vk["g2"] == PR.G2_GENERATOR
+    assert PA.g2_is_on_curve(vk["neg_s_g2"])
+
+
+def test_k6_proof_verifies_and_every_intermediate_matches_the_reference():
+    proof, inst, vk, tr = load_k6()
+    assert tr["trace"]["result"] == 1
+    got = {}
+    assert SV.verify(proof, inst, vk, got)
+    for name, want in tr["trace"].items():
+        if name != "result":
+            assert got[name] == H(want), name
+
+
+@pytest.mark.parametrize("where", ["commitment", "evaluation", "opening", "instance", "quotient"])
+def test_k6_tampered_proof_is_rejected(where):
+    proof, inst, vk, _ = load_k6()
+    p = bytearray(proof)
+    if where == "commitment":      # a different valid curve point as a_0: the generator
+        p[0:64] = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    elif where == "evaluation":    # f_6 evaluation + 1
+        off = 0x380 + 32 * SV.EVAL_ORDER.index(("f", 6, 0))
+        p[off:off + 32] = ((int.from_bytes(p[off:off + 32], "big") + 1) % SV.R).to_bytes(32, "big")
+    elif where == "opening":       # W' replaced by W
+        p[0x820:0x860] = p[0x7e0:0x820]
+    elif where == "quotient":      # swap two quotient pieces
+        p[0x240:0x280], p[0x280:0x2c0] = p[0x280:0x2c0], p[0x240:0x280]
+    else:
+        inst = [inst[0], inst[1], inst[2] + 1, inst[3]]
+    assert not SV.verify(bytes(p), inst, vk)
+    # malformed inputs are rejected, not raised
+    assert not SV.verify(bytes(p[:-1]), inst, vk)
+    q = bytearray(proof)
+    q[63] ^= 1                     # off the curve
+    assert not SV.verify(bytes(q), inst, vk)
+
+
+def test_transcript_restates_the_evm_rule():
+    """challenge = keccak(buffer) mod r, the hash becomes the buffer; a second squeeze hashes hash || 0x01"""
+    t = SV.EvmTranscript(5)
+    t.absorb_scalar(7)
+    h = PR.keccak256((5).to_bytes(32, "big") + (7).to_bytes(32, "big"))
+    assert t.squeeze() == int.from_bytes(h, "big") % SV.R
+    h2 = PR.keccak256(h + b"\x01")
+    assert t.squeeze_again() == int.from_bytes(h2, "big") % SV.R
+    t.absorb_point((1, 2))
+    assert t.squeeze() == int.from_bytes(PR.keccak256(h2 + (1).to_bytes(32, "big") + (2).to_bytes(32, "big")), "big") % SV.R
+
+
+def test_poseidon_matrices_in_the_gates_are_the_contracts():
+    """the MDS / MDS^-1 entries the restated gates multiply by are the literals of the generated verifier
+    (first entries; contracts/src/InclusionVerifier.sol:508, 579)"""
+    _, mds, mds_inv = SV.poseidon_generate()
+    assert mds[0][0] == 0x066f6f85d6f68a85ec10345351a23a3aaf07f38af8c952a7bceca70bd2af7ad5
+    assert mds_inv[0][0] == 0x13abec390ada7f4370819ab1c7846f210554569d9b29d1ea8dbebd0fa8c53e66
+
+
+def test_product_constraint_system_equals_the_restatement():
+    """circuits_halo2_amd.mst_inclusion (what the GPU evaluates) and oracle.summa_verifier.gate_values agree on
+    random column values, gate by gate, as do the lookup expressions; degrees fit the extended domain"""
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd import mst_inclusion as M
+    vals = {}
+    rnd = iter(PR.random_fr(0xC0FFEE, 64))
+    kinds = {A.ADVICE: "a", A.FIXED: "f"}
+
+    def q_oracle(kind, c, rot):
+        if (kind, c, rot) not in vals:
+            vals[(kind, c, rot)] = next(rnd)
+        return vals[(kind, c, rot)]
+    want = SV.gate_values(q_oracle)
+    got = [e.evaluate(lambda kind, c, rot: q_oracle(kinds[kind], c, rot)) for e in M.gates()]
+    assert got == want and len(got) == 19
+    inp, tab = M.lookup_expressions()
+    q = lambda kind, c, rot: q_oracle(kinds[kind], c, rot)
+    assert (inp.evaluate(q), tab.evaluate(q)) == SV.lookup_input_table(q_oracle)
+    assert max(e.degree() for e in M.gates()) == M.DEGREE
+    assert [("f" if k == A.FIXED else "a" if k == A.ADVICE else "i", c) for k, c in M.PERMUTATION_COLUMNS] == SV.PERMUTATION_COLUMNS
+    g = M.gate_graph()
+    assert g.calculations[-1][0] == A.HORNER and len(g.calculations[-1][3]) == 19
+    assert sorted(g.rotations) == [-1, 0, 1]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/contracts/src/InclusionVerifier.sol"),
+                    reason="needs the reference checkout (authoring container only)")
+def test_trace_fixture_is_what_the_reference_verifier_computes():
+    """re-run the reference's generated verifier (read as text, interpreted by oracle/yul_verifier_run.py) on its
+    shipped proof: it accepts, and the committed fixture is its output"""
+    from oracle import yul_verifier_run as Y
+    out = Y.run()
+    assert out["trace"]["result"] == 1
+    assert out == json.load(open(os.path.join(GOLD, "k6_verifier_trace.json")))
+    cd = json.load(open(Y.CALLDATA))
+    assert cd == json.load(open(os.path.join(GOLD, "k6_inclusion_proof_solidity_calldata.json")))
