@@ -1,0 +1,339 @@
+"""`create_proof` for the constraint system of the reference's MstInclusionCircuit (mst_inclusion.py), with every
+data-parallel step on the GPU through the C ABI and the EVM / Keccak transcript of the generated verifier.
+
+Host mirror of `halo2_proofs::plonk::create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<_>, ..>` as the
+reference calls it [REF zk_prover/src/circuits/utils.rs:94-101, 171-178], restricted to what this constraint
+system needs (one phase, one lookup, six permutation columns in two chunks, five quotient pieces).  The steps
+and their order follow SURVEY.md §3.1 / Appendix C; the byte layout of the proof is the one the generated verifier
+reads [REF contracts/src/InclusionVerifier.sol:274-367].  What stays on the host is what upstream also does serially
+on the CPU: the transcript, the lookup's sort (`permute_expression_pair`), scalars of the multi-open.
+
+Inputs are a proving key made from Lagrange-basis fixed and permutation columns and an assignment of the three
+advice columns (rows beyond n - 6 are overwritten with blinding values); key generation for the *reference's own*
+circuit layout (its floor plan) is not restated -- tests/test_gpu_prover.py builds a satisfying assignment of the
+same constraint system with its own fixed columns and checks the proof with the restated verifier
+(oracle/summa_verifier.py), which also accepts the reference's shipped proof.
+"""
+from __future__ import annotations
+
+import secrets
+
+import numpy as np
+
+from . import arithmetic as A
+from . import mst_inclusion as M
+from .domain import EvaluationDomain
+from .merkle_sum_tree import keccak256
+from .utils import ints_to_fr
+
+R = M.R
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+DELTA = pow(7, 1 << 28, R)
+ROT_LAST = -(M.BLINDING_FACTORS + 1)
+
+# evaluations written to the proof, in order [REF InclusionVerifier.sol:500-1000, `calldataload` slots 0x03e4 ..]
+EVAL_ORDER = ([("a", 0, 0), ("a", 1, 0), ("a", 0, 1), ("a", 1, 1), ("a", 2, 0), ("a", 1, -1), ("a", 0, -1),
+               ("f", 2, 0), ("f", 3, 0), ("f", 0, 0), ("f", 1, 0)] + [("f", j, 0) for j in range(4, 11)] +
+              [("random", 0, 0)] + [("sigma", j, 0) for j in range(6)] +
+              [("z", 0, 0), ("z", 0, 1), ("z", 0, ROT_LAST), ("z", 1, 0), ("z", 1, 1),
+               ("lz", 0, 0), ("lz", 0, 1), ("pin", 0, 0), ("pin", 0, -1), ("ptab", 0, 0)])
+# rotation sets of the multi-open in nu order, polynomials of a set in increasing power of zeta [REF :1159-1340]
+ROTATION_SETS = [
+    ((-1, 0, 1), [("a", 0), ("a", 1)]),
+    ((0,), [("a", 2), ("ptab", 0), ("f", 2), ("f", 3), ("f", 0), ("f", 1)] + [("f", j) for j in range(4, 11)] +
+           [("sigma", j) for j in range(6)] + [("h", None), ("random", 0)]),
+    ((ROT_LAST, 0, 1), [("z", 0)]),
+    ((0, 1), [("z", 1), ("lz", 0)]),
+    ((-1, 0), [("pin", 0)]),
+]
+
+
+def _inv(a):
+    return pow(a, -1, R)
+
+
+def _dev(ints):
+    import torch
+    return torch.from_numpy(ints_to_fr(ints)).cuda()
+
+
+def _fr_bytes(v: int) -> np.ndarray:
+    return ints_to_fr([v])
+
+
+def _ints(t):
+    """device Montgomery tensor -> list of Python ints"""
+    raw = A.fr_from_montgomery(t).cpu().numpy().tobytes()
+    return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+
+
+def _point(c64: np.ndarray):
+    """64-byte Montgomery affine -> (x, y) integers"""
+    raw = bytes(c64)
+    rinv = pow(1 << 256, -1, Q)
+    return int.from_bytes(raw[:32], "little") * rinv % Q, int.from_bytes(raw[32:], "little") * rinv % Q
+
+
+class EvmTranscriptWriter:
+    """Keccak256 transcript + proof stream of halo2_solidity_verifier's `Keccak256Transcript` [REF :85-110]"""
+
+    def __init__(self, vk_digest: int):
+        self.buf = vk_digest.to_bytes(32, "big")
+        self.proof = bytearray()
+
+    def common_scalar(self, v: int):
+        self.buf += v.to_bytes(32, "big")
+
+    def write_scalar(self, v: int):
+        self.common_scalar(v)
+        self.proof += v.to_bytes(32, "big")
+
+    def write_point(self, p):
+        enc = p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
+        self.buf += enc
+        self.proof += enc
+
+    def squeeze_challenge(self) -> int:
+        h = keccak256(bytes(self.buf))
+        self.buf = h
+        return int.from_bytes(h, "big") % R
+
+    def squeeze_challenge_again(self) -> int:
+        h = keccak256(bytes(self.buf[:32]) + b"\x01")
+        self.buf = h
+        return int.from_bytes(h, "big") % R
+
+
+class ProvingKey:
+    """fixed and permutation columns in the three bases halo2's pk keeps (Lagrange, coefficients, extended coset),
+    the Lagrange selector polynomials l0 / l_last / l_active, and the verifying key's commitments"""
+
+    def __init__(self, params, k: int, fixed_lagrange, sigma_lagrange):
+        import torch
+        self.k, self.n = k, 1 << k
+        self.dom = EvaluationDomain(M.DEGREE, k)
+        n, u = self.n, self.n - (M.BLINDING_FACTORS + 1)
+        self.usable_rows = u
+        assert len(fixed_lagrange) == M.NUM_FIXED and len(sigma_lagrange) == len(M.PERMUTATION_COLUMNS)
+        self.fixed_lagrange, self.sigma_lagrange = list(fixed_lagrange), list(sigma_lagrange)
+        sel = [_dev([1] + [0] * (n - 1)), _dev([0] * u + [1] + [0] * (n - u - 1)), _dev([1] * u + [0] * (n - u))]
+        cols = self.fixed_lagrange + self.sigma_lagrange + sel
+        coeff = A.best_fft_batch([c.clone() for c in cols], self.dom.get_omega_inv(), k, divisor=self.dom.ifft_divisor())
+        ext = self.dom.coeff_to_extended_batch(coeff)
+        nf, ns = M.NUM_FIXED, len(sigma_lagrange)
+        self.fixed_coeff, self.sigma_coeff = coeff[:nf], coeff[nf:nf + ns]
+        self.fixed_ext, self.sigma_ext = ext[:nf], ext[nf:nf + ns]
+        self.l0_ext, self.l_last_ext, self.l_active_ext = ext[nf + ns:]
+        comms = params.commit_batch(self.fixed_lagrange + self.sigma_lagrange, lagrange=True)
+        self.fixed_comms = [_point(c) for c in comms[:nf]]
+        self.permutation_comms = [_point(c) for c in comms[nf:]]
+        digest = keccak256(b"".join(x.to_bytes(32, "big") + y.to_bytes(32, "big") for x, y in self.fixed_comms + self.permutation_comms))
+        self.vk_digest = int.from_bytes(digest, "big") % R
+        torch.cuda.synchronize()
+
+
+def permute_expression_pair(inp, table, usable_rows: int, rng):
+    """halo2 `lookup::prover::permute_expression_pair` on integers: A' = the usable input rows sorted, S' = the table
+    rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1]; blinding rows random"""
+    a = sorted(inp[:usable_rows])
+    leftover = {}
+    for v in table[:usable_rows]:
+        leftover[v] = leftover.get(v, 0) + 1
+    s = [None] * usable_rows
+    free_rows = []
+    for i, v in enumerate(a):
+        if i == 0 or v != a[i - 1]:
+            if not leftover.get(v):
+                raise ValueError("lookup input value not in the table")
+            leftover[v] -= 1
+            s[i] = v
+        else:
+            free_rows.append(i)
+    rest = [v for v, c in leftover.items() for _ in range(c)]
+    for i, v in zip(free_rows, rest):
+        s[i] = v
+    assert all(v is not None for v in s)
+    blind = lambda: [rng() for _ in range(len(inp) - usable_rows)]
+    return a + blind(), s + blind()
+
+
+def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None) -> bytes:
+    """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
+    `rng()` returns a uniform field element (blinding factors, the random polynomial); default: secrets."""
+    import torch
+    rng = rng or (lambda: secrets.randbelow(R))
+    k, n, u, dom = pk.k, pk.n, pk.usable_rows, pk.dom
+    ext_k = dom.extended_k
+    ne = 1 << ext_k
+    omega = pow(ROOT_OF_UNITY, 1 << (28 - k), R)
+    none = np.zeros(0, dtype=np.uint8)
+    tr = EvmTranscriptWriter(pk.vk_digest)
+    for v in instances:
+        tr.common_scalar(v)
+    polys = {}      # key -> coefficient-form device polynomial (n coefficients)
+
+    def to_coeff(cols):
+        return A.best_fft_batch([c.clone() for c in cols], dom.get_omega_inv(), k, divisor=dom.ifft_divisor())
+
+    def commit_lagrange(cols):
+        return [_point(c) for c in params.commit_batch(cols, lagrange=True)]
+
+    # -- 1: advice columns: blind the last rows, commit
+    advice = [a.clone() for a in advice]
+    for a in advice:
+        a[32 * u:] = _dev([rng() for _ in range(n - u)])
+    instance_col = _dev(list(instances) + [0] * (n - len(instances)))
+    for p in commit_lagrange(advice):
+        tr.write_point(p)
+    theta = tr.squeeze_challenge()  # one expression per side: theta only separates the phases
+    adv_coeff = to_coeff(advice + [instance_col])
+    for j in range(3):
+        polys[("a", j)] = adv_coeff[j]
+    ext1 = dom.coeff_to_extended_batch(adv_coeff)
+    adv_ext, inst_ext = ext1[:3], ext1[3]
+
+    # -- 2: lookup: compressed input / table over the rows, permuted pair (host sort, as upstream), commitments
+    a0 = _ints(advice[0])
+    f4, f5 = _ints(pk.fixed_lagrange[4]), _ints(pk.fixed_lagrange[5])
+    inp = [f5[i] * (a0[i] - 256 * a0[(i + 1) % n]) % R for i in range(n)]
+    pin_i, ptab_i = permute_expression_pair(inp, f4, u, rng)
+    inp_d, pin_d, ptab_d = _dev(inp), _dev(pin_i), _dev(ptab_i)
+    for p in commit_lagrange([pin_d, ptab_d]):
+        tr.write_point(p)
+    beta = tr.squeeze_challenge()
+    gamma = tr.squeeze_challenge_again()
+    b_beta, b_gamma, b_theta = _fr_bytes(beta), _fr_bytes(gamma), _fr_bytes(theta)
+
+    # -- 3: grand products (device scans), blinding rows, commitments; then the random polynomial
+    col_lag = {(A.ADVICE, j): advice[j] for j in range(3)}
+    col_lag.update({(A.FIXED, j): pk.fixed_lagrange[j] for j in range(M.NUM_FIXED)})
+    col_lag[(A.INSTANCE, 0)] = instance_col
+    zs, last, delta_start = [], None, 1
+    for c0 in range(0, len(M.PERMUTATION_COLUMNS), M.PERMUTATION_CHUNK):
+        chunk = M.PERMUTATION_COLUMNS[c0:c0 + M.PERMUTATION_CHUNK]
+        z = A.permutation_product([col_lag[c] for c in chunk], pk.sigma_lagrange[c0:c0 + len(chunk)], b_beta, b_gamma,
+                                  _fr_bytes(delta_start), k, z0=None if last is None else _fr_bytes(last))
+        last = _ints(z[32 * u:32 * (u + 1)])[0]
+        z[32 * (u + 1):] = _dev([rng() for _ in range(n - u - 1)])
+        zs.append(z)
+        delta_start = delta_start * pow(DELTA, len(chunk), R) % R
+    if last != 1:
+        raise ValueError("permutation argument not satisfied by the assignment")
+    lz = A.lookup_product(inp_d, pk.fixed_lagrange[4], pin_d, ptab_d, b_beta, b_gamma)
+    if _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
+        raise ValueError("lookup argument not satisfied by the assignment")
+    lz[32 * (u + 1):] = _dev([rng() for _ in range(n - u - 1)])
+    for p in commit_lagrange(zs + [lz]):
+        tr.write_point(p)
+    polys[("random", 0)] = _dev([rng() for _ in range(n)])
+    tr.write_point(_point(params.commit(polys[("random", 0)])))
+    y = tr.squeeze_challenge()
+    b_y = _fr_bytes(y)
+    co3 = to_coeff([pin_d, ptab_d] + zs + [lz])
+    polys[("pin", 0)], polys[("ptab", 0)], polys[("z", 0)], polys[("z", 1)], polys[("lz", 0)] = co3
+    pin_ext, ptab_ext, z0_ext, z1_ext, lz_ext = dom.coeff_to_extended_batch(co3)
+
+    # -- 4: quotient: evaluate_h over the extended coset, / (X^n - 1), back to coefficients, five pieces
+    values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(values, M.gate_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta, b_gamma, b_theta, b_y, k, ext_k)
+    col_ext = {(A.ADVICE, j): adv_ext[j] for j in range(3)}
+    col_ext.update({(A.FIXED, j): pk.fixed_ext[j] for j in range(M.NUM_FIXED)})
+    col_ext[(A.INSTANCE, 0)] = inst_ext
+    A.quotient_permutation(values, [z0_ext, z1_ext], [col_ext[c] for c in M.PERMUTATION_COLUMNS], pk.sigma_ext,
+                           M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext, pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k,
+                           M.BLINDING_FACTORS + 1)
+    input_ext = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(input_ext, M.expression_graph(M.lookup_expressions()[0]), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta,
+                     b_gamma, b_theta, b_y, k, ext_k)
+    A.quotient_lookup(values, lz_ext, pin_ext, ptab_ext, input_ext, pk.fixed_ext[4], pk.l0_ext, pk.l_last_ext, pk.l_active_ext,
+                      b_beta, b_gamma, b_y, k, ext_k)
+    dom.divide_by_vanishing_poly(values)
+    h = dom.extended_to_coeff(values)
+    pieces = [h[32 * n * i:32 * n * (i + 1)].clone() for i in range(M.DEGREE - 1)]
+    for c in params.commit_batch(pieces):
+        tr.write_point(_point(c))
+    x = tr.squeeze_challenge()
+    x_n = pow(x, n, R)
+
+    # -- 5: evaluations
+    for j in range(M.NUM_FIXED):
+        polys[("f", j)] = pk.fixed_coeff[j]
+    for j in range(len(pk.sigma_coeff)):
+        polys[("sigma", j)] = pk.sigma_coeff[j]
+    point = lambda rot: x * pow(omega, rot % n, R) % R
+    ev = A.eval_polynomial_batch([polys[(kind, c)] for kind, c, _ in EVAL_ORDER],
+                                 np.concatenate([_fr_bytes(point(rot)) for _, _, rot in EVAL_ORDER]))
+    rinv = pow(1 << 256, -1, R)
+    evals = {key: int.from_bytes(bytes(e), "little") * rinv % R for key, e in zip(EVAL_ORDER, ev)}
+    for key in EVAL_ORDER:
+        tr.write_scalar(evals[key])
+    polys[("h", None)] = A.lincomb(pieces, np.concatenate([_fr_bytes(pow(x_n, i, R)) for i in range(len(pieces))]))
+    h_eval = int.from_bytes(bytes(A.eval_polynomial_batch([polys[("h", None)]], _fr_bytes(x))[0]), "little") * rinv % R
+
+    def eval_of(key, rot):
+        return h_eval if key == ("h", None) else evals[(key[0], key[1], rot)]
+    if debug is not None:
+        debug.update({"h_eval": h_eval, "x": x, "y": y, "beta": beta, "gamma": gamma, "theta": theta, "evals": dict(evals)})
+
+    # -- 6: SHPLONK (BDFG21) multi-open
+    zeta = tr.squeeze_challenge()
+    nu = tr.squeeze_challenge_again()
+    zero_row = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    qs, rs, fs = [], [], []
+    for rots, keys in ROTATION_SETS:
+        q = A.lincomb([polys[key] for key in keys], np.concatenate([_fr_bytes(pow(zeta, j, R)) for j in range(len(keys))]))
+        pts = [point(r) for r in rots]
+        vals = [sum(pow(zeta, j, R) * eval_of(key, r) for j, key in enumerate(keys)) % R for r in rots]
+        # r(X): the polynomial of degree < |S| through (pts, vals) (Lagrange interpolation on integers)
+        r_coeff = [0] * len(pts)
+        for i, (pi, vi) in enumerate(zip(pts, vals)):
+            basis, denom = [1], 1
+            for j, pj in enumerate(pts):
+                if j != i:
+                    basis = [((basis[t - 1] if t else 0) - pj * (basis[t] if t < len(basis) else 0)) % R for t in range(len(basis) + 1)]
+                    denom = denom * (pi - pj) % R
+            scale = vi * _inv(denom) % R
+            for t, b in enumerate(basis):
+                r_coeff[t] = (r_coeff[t] + scale * b) % R
+        r_poly = _dev(r_coeff + [0] * (n - len(r_coeff)))
+        f = A.lincomb([q, r_poly], np.concatenate([_fr_bytes(1), _fr_bytes(R - 1)]))
+        for p in pts:
+            quo, rem = A.kate_division(f, _fr_bytes(p), with_remainder=True)
+            if bytes(rem) != bytes(32):
+                raise ValueError("opening claim does not hold")
+            f = torch.cat([quo, zero_row])
+        qs.append(q)
+        rs.append(r_coeff)
+        fs.append(f)
+    f_all = A.lincomb(fs, np.concatenate([_fr_bytes(pow(nu, i, R)) for i in range(len(fs))]))
+    w = _point(params.commit(f_all))
+    tr.write_point(w)
+    mu = tr.squeeze_challenge()
+    all_rots = sorted({r for rots, _ in ROTATION_SETS for r in rots})
+    mu_minus = {r: (mu - point(r)) % R for r in all_rots}
+    diffs = []
+    for rots, _ in ROTATION_SETS:
+        d = 1
+        for r in all_rots:
+            if r not in rots:
+                d = d * mu_minus[r] % R
+        diffs.append(d)
+    d0_inv = _inv(diffs[0])
+    z_s0 = 1
+    for r in ROTATION_SETS[0][0]:
+        z_s0 = z_s0 * mu_minus[r] % R
+    coeffs, const = [], 0
+    for i, (d, r_coeff) in enumerate(zip(diffs, rs)):
+        scale = pow(nu, i, R) * d % R * d0_inv % R
+        coeffs.append(scale)
+        r_at_mu = sum(c * pow(mu, t, R) for t, c in enumerate(r_coeff)) % R
+        const = (const + scale * r_at_mu) % R
+    one_poly = _dev([1] + [0] * (n - 1))
+    l_poly = A.lincomb(qs + [f_all, one_poly],
+                       np.concatenate([_fr_bytes(c) for c in coeffs] + [_fr_bytes((-z_s0) % R), _fr_bytes((-const) % R)]))
+    quo, rem = A.kate_division(l_poly, _fr_bytes(mu), with_remainder=True)
+    if bytes(rem) != bytes(32):
+        raise ValueError("multi-open linearisation does not vanish at mu")
+    tr.write_point(_point(params.commit(torch.cat([quo, zero_row]))))
+    return bytes(tr.proof)

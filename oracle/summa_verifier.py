@@ -285,7 +285,7 @@ def shplonk_pairing_inputs(comms, evals_of, x, zeta, nu, mu, w, w2, k=K):
 
 
 def verify(proof: bytes, instances, vk, trace=None) -> bool:
-    """vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"} (integers / int tuples).
+    """vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"[, "k": 11]} (integers / int tuples).
     `trace`, if given, is filled with the intermediate values named as in tests/golden/k6_verifier_trace.json."""
     try:
         comms, evals, w, w2 = parse_proof(proof)
@@ -315,7 +315,8 @@ def verify(proof: bytes, instances, vk, trace=None) -> bool:
     ch["mu"] = t.squeeze()
 
     x = ch["x"]
-    lag = lagrange_evaluations(x, instances)
+    k = vk.get("k", K)
+    lag = lagrange_evaluations(x, instances, k)
     q = lambda kind, c, rot: evals[(kind, c, rot)]
     numer = quotient_numerator(q, ch, lag)
     quotient_eval = numer * inv((lag["x_n"] - 1) % R) % R
@@ -334,7 +335,7 @@ def verify(proof: bytes, instances, vk, trace=None) -> bool:
         if key == ("h", None):
             return quotient_eval
         return evals[(key[0], key[1], rot)]
-    lhs, rhs, r_eval = shplonk_pairing_inputs(all_comms, evals_of, x, ch["zeta"], ch["nu"], ch["mu"], w, w2)
+    lhs, rhs, r_eval = shplonk_pairing_inputs(all_comms, evals_of, x, ch["zeta"], ch["nu"], ch["mu"], w, w2, k)
     if trace is not None:
         trace.update(ch)
         trace.update({k_: lag[k_] for k_ in ("x_n", "l_last", "l_blind", "l_0", "instance_eval")})
