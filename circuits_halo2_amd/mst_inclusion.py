@@ -17,6 +17,7 @@ Column layout (halo2's column numbering after selector compression, as in the ve
 from __future__ import annotations
 
 from . import arithmetic as A
+from .arithmetic import ADVICE, FIXED, INSTANCE
 from functools import lru_cache
 
 from .poseidon_params import generate as _generate_poseidon
@@ -153,6 +154,7 @@ def lookup_expressions():
     return Expr.query(A.FIXED, 5, 0) * (a0 - a0n * 256), Expr.query(A.FIXED, 4, 0)
 
 
+@lru_cache(maxsize=None)
 def gate_graph() -> A.GraphEvaluator:
     """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y)"""
     g = A.GraphEvaluator()
@@ -161,8 +163,114 @@ def gate_graph() -> A.GraphEvaluator:
     return g
 
 
+@lru_cache(maxsize=None)
+def lookup_input_graph() -> A.GraphEvaluator:
+    """the lookup's input expression as a program (one value per row)"""
+    return expression_graph(lookup_expressions()[0])
+
+
 def expression_graph(expr: Expr) -> A.GraphEvaluator:
     """a program that stores one expression per row (the compressed lookup input / table columns)"""
     g = A.GraphEvaluator()
     g.add_calculation(A.STORE, expr.lower(g))
     return g
+
+
+def example_assignment(k: int):
+    """A satisfying assignment of this constraint system on 2^k rows (k >= 9) with a floor plan of this repository's
+    own: one whole Poseidon permutation on chip 1 (4 + 56 + 4 rounds in 36 rows), single rounds on chip 2, both
+    pad-and-add gates, two swaps, a sum, a two-byte range decomposition, copy constraints across advice, fixed and
+    instance columns.  Python integers: {fixed [11][n], advice [3][n], instances [4], sigma [6][n], usable_rows, ..}.
+    (The reference circuit's own layout is produced by halo2's layouter from zk_prover/src/circuits/merkle_sum_tree.rs
+    and is not restated; the constraint system is the same.)"""
+    from .prover import DELTA, ROOT_OF_UNITY
+    n = 1 << k
+    u = n - (BLINDING_FACTORS + 1)
+    if n < 512:
+        raise ValueError("the 8-bit range table needs 2^9 rows")
+    rcs, mds, _ = _poseidon()
+    fixed = [[0] * n for _ in range(NUM_FIXED)]
+    adv = [[0] * n for _ in range(NUM_ADVICE)]
+    pow5 = lambda v: pow(v, 5, R)
+    mix = lambda s: [(mds[i][0] * s[0] + mds[i][1] * s[1]) % R for i in range(2)]
+
+    def full_round(row, state, rc, sel):
+        fixed[sel][row] = 1
+        fixed[0][row], fixed[1][row] = rc
+        adv[0][row], adv[1][row] = state
+        return mix([pow5((state[j] + rc[j]) % R) for j in range(2)])
+
+    def partial_pair(row, state, rc_a, rc_b, sel):
+        fixed[sel][row] = 1
+        fixed[0][row], fixed[1][row] = rc_a
+        fixed[2][row], fixed[3][row] = rc_b
+        adv[0][row], adv[1][row] = state
+        adv[2][row] = pow5((state[0] + rc_a[0]) % R)
+        mid = mix([adv[2][row], (state[1] + rc_a[1]) % R])
+        return mix([pow5((mid[0] + rc_b[0]) % R), (mid[1] + rc_b[1]) % R])
+
+    # chip 1: a whole permutation, rows 0 .. 36
+    state = poseidon_in = [0x1234567, (3 << 64) % R]
+    row = 0
+    for r in range(4):
+        state = full_round(row, state, rcs[r], 7)
+        row += 1
+    for j in range(28):
+        state = partial_pair(row, state, rcs[4 + 2 * j], rcs[5 + 2 * j], 8)
+        row += 1
+    for r in range(60, 64):
+        state = full_round(row, state, rcs[r], 7)
+        row += 1
+    adv[0][row], adv[1][row] = state          # row 36: the output
+    poseidon_out = list(state)
+    # sum gate (row 55) feeds pad-and-add of chip 1 (rows 37 .. 39) through a copy constraint
+    adv[0][55], adv[1][55], adv[2][55] = 1000, 234, 1234
+    fixed[6][55] = 2
+    adv[0][37], adv[0][38], adv[0][39] = 1234, 66, 1300
+    adv[1][37] = adv[1][39] = 77
+    fixed[6][38] = 3
+    # chip 2: one full round (41 -> 42), one pair of partial rounds (44 -> 45), pad-and-add (46 .. 48)
+    adv[0][42], adv[1][42] = full_round(41, [5, 6], rcs[10], 9)
+    adv[0][45], adv[1][45] = partial_pair(44, [7, 8], rcs[20], rcs[21], 10)
+    adv[0][46], adv[0][47], adv[0][48] = 40, 9, 49
+    fixed[6][47] = 4
+    # swaps
+    adv[0][50], adv[1][50], adv[2][50] = 111, 222, 1
+    adv[0][51], adv[1][51] = 222, 111
+    fixed[6][50] = 1
+    adv[0][52], adv[1][52], adv[2][52] = 333, 444, 0
+    adv[0][53], adv[1][53] = 333, 444
+    fixed[6][52] = 1
+    # range check: 0xABCD = 0xAB * 256 + 0xCD
+    adv[0][60], adv[0][61], adv[0][62] = 0xABCD, 0xAB, 0
+    fixed[5][60] = fixed[5][61] = 1
+    for i in range(256):
+        fixed[4][i] = i
+    # a constant in a permutation-enabled fixed column, copied into advice
+    fixed[2][70] = 5
+    adv[1][70] = 5
+    instances = [poseidon_out[0], adv[1][51], 556862, 556862]
+    inst_col = instances + [0] * (n - len(instances))
+    # copy constraints over the permutation columns
+    cells = {(ADVICE, j): adv[j] for j in range(NUM_ADVICE)}
+    cells.update({(FIXED, 2): fixed[2], (FIXED, 3): fixed[3], (INSTANCE, 0): inst_col})
+    groups = [[((ADVICE, 0), 36), ((INSTANCE, 0), 0)], [((ADVICE, 1), 51), ((INSTANCE, 0), 1)],
+              [((ADVICE, 2), 55), ((ADVICE, 0), 37)], [((FIXED, 2), 70), ((ADVICE, 1), 70)], [((ADVICE, 0), 53), ((ADVICE, 0), 52)]]
+    omega = pow(ROOT_OF_UNITY, 1 << (28 - k), R)
+    sigma = []
+    for c in range(len(PERMUTATION_COLUMNS)):
+        col, v = [], pow(DELTA, c, R)
+        for _ in range(n):
+            col.append(v)
+            v = v * omega % R
+        sigma.append(col)
+    label = lambda c, i: sigma_identity[c][i]
+    sigma_identity = [list(col) for col in sigma]
+    for grp in groups:
+        if len({cells[col][i] for col, i in grp}) != 1:
+            raise AssertionError(grp)
+        idx = [(PERMUTATION_COLUMNS.index(col), i) for col, i in grp]
+        for (c, i), (c2, i2) in zip(idx, idx[1:] + idx[:1]):
+            sigma[c][i] = label(c2, i2)
+    return {"fixed": fixed, "advice": adv, "instances": instances, "sigma": sigma, "usable_rows": u,
+            "poseidon_in": poseidon_in, "poseidon_out": poseidon_out}

@@ -16,15 +16,13 @@ same constraint system with its own fixed columns and checks the proof with the 
 """
 from __future__ import annotations
 
-import secrets
-
 import numpy as np
 
 from . import arithmetic as A
 from . import mst_inclusion as M
 from .domain import EvaluationDomain
 from .merkle_sum_tree import keccak256
-from .utils import ints_to_fr
+from .utils import ints_to_fr, random_fr_secure
 
 R = M.R
 Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -66,6 +64,25 @@ def _ints(t):
     """device Montgomery tensor -> list of Python ints"""
     raw = A.fr_from_montgomery(t).cpu().numpy().tobytes()
     return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+
+
+def _head(values, n: int):
+    """device column of n rows: the given integers, then zeros"""
+    import torch
+    t = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    if values:
+        t[:32 * len(values)] = torch.from_numpy(ints_to_fr(values)).cuda()
+    return t
+
+
+def _canonical_rows(t) -> np.ndarray:
+    """device Montgomery column -> (rows, 4) uint64 little-endian limbs of the canonical integers (host)"""
+    return A.fr_from_montgomery(t).cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+def _sort_rows(limbs: np.ndarray) -> np.ndarray:
+    """rows of 4 LE uint64 limbs in increasing integer order"""
+    return limbs[np.lexsort((limbs[:, 0], limbs[:, 1], limbs[:, 2], limbs[:, 3]))]
 
 
 def _point(c64: np.ndarray):
@@ -133,36 +150,46 @@ class ProvingKey:
         torch.cuda.synchronize()
 
 
-def permute_expression_pair(inp, table, usable_rows: int, rng):
-    """halo2 `lookup::prover::permute_expression_pair` on integers: A' = the usable input rows sorted, S' = the table
-    rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1]; blinding rows random"""
-    a = sorted(inp[:usable_rows])
-    leftover = {}
-    for v in table[:usable_rows]:
-        leftover[v] = leftover.get(v, 0) + 1
-    s = [None] * usable_rows
-    free_rows = []
-    for i, v in enumerate(a):
-        if i == 0 or v != a[i - 1]:
-            if not leftover.get(v):
-                raise ValueError("lookup input value not in the table")
-            leftover[v] -= 1
-            s[i] = v
-        else:
-            free_rows.append(i)
-    rest = [v for v, c in leftover.items() for _ in range(c)]
-    for i, v in zip(free_rows, rest):
-        s[i] = v
-    assert all(v is not None for v in s)
-    blind = lambda: [rng() for _ in range(len(inp) - usable_rows)]
-    return a + blind(), s + blind()
+def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
+    """halo2 `lookup::prover::permute_expression_pair` on the usable rows, as (rows, 4) uint64 limb arrays of
+    canonical integers: A' = the input sorted, S' = the table rearranged so that every row has A'[i] == S'[i] or
+    A'[i] == A'[i-1] (the leftover table values fill the repeated rows).  Host work, as upstream."""
+    a = _sort_rows(inp)
+    first = np.ones(len(a), dtype=bool)
+    first[1:] = (a[1:] != a[:-1]).any(axis=1)
+    # multiset difference  table - {distinct input values}; one-limb tables (range checks) take the 1-D path
+    small = not table[:, 1:].any()
+    if small and a[:, 1:].any():
+        raise ValueError("lookup input value not in the table")
+    s = np.empty_like(a)
+    s[first] = a[first]
+    if small:
+        t_sorted, distinct = np.sort(table[:, 0]), a[first, 0]
+        at = np.searchsorted(t_sorted, distinct)
+        if (at >= len(t_sorted)).any() or (t_sorted[np.minimum(at, len(t_sorted) - 1)] != distinct).any():
+            raise ValueError("lookup input value not in the table")
+        keep = np.ones(len(t_sorted), dtype=bool)
+        keep[at] = False                                   # one occurrence per distinct input value
+        s[~first] = 0
+        s[~first, 0] = t_sorted[keep]
+    else:
+        both, inverse = np.unique(np.concatenate([table, a[first]]), axis=0, return_inverse=True)
+        inverse = inverse.reshape(-1)
+        have = np.bincount(inverse[:len(table)], minlength=len(both))
+        need = np.bincount(inverse[len(table):], minlength=len(both))
+        if (have < need).any():
+            raise ValueError("lookup input value not in the table")
+        s[~first] = np.repeat(both, have - need, axis=0)
+    return a, s
 
 
 def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None) -> bytes:
     """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
-    `rng()` returns a uniform field element (blinding factors, the random polynomial); default: secrets."""
+    `rng(count)` returns `count` uniform field elements as canonical 32-byte little-endian integers (blinding
+    factors, the random polynomial); default: the OS entropy source."""
     import torch
-    rng = rng or (lambda: secrets.randbelow(R))
+    rng = rng or random_fr_secure
+    rand = lambda count: A.fr_to_montgomery(torch.from_numpy(np.ascontiguousarray(rng(count))).cuda())
     k, n, u, dom = pk.k, pk.n, pk.usable_rows, pk.dom
     ext_k = dom.extended_k
     ne = 1 << ext_k
@@ -182,8 +209,8 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     # -- 1: advice columns: blind the last rows, commit
     advice = [a.clone() for a in advice]
     for a in advice:
-        a[32 * u:] = _dev([rng() for _ in range(n - u)])
-    instance_col = _dev(list(instances) + [0] * (n - len(instances)))
+        a[32 * u:] = rand(n - u)
+    instance_col = _head(list(instances), n)
     for p in commit_lagrange(advice):
         tr.write_point(p)
     theta = tr.squeeze_challenge()  # one expression per side: theta only separates the phases
@@ -194,11 +221,12 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     adv_ext, inst_ext = ext1[:3], ext1[3]
 
     # -- 2: lookup: compressed input / table over the rows, permuted pair (host sort, as upstream), commitments
-    a0 = _ints(advice[0])
-    f4, f5 = _ints(pk.fixed_lagrange[4]), _ints(pk.fixed_lagrange[5])
-    inp = [f5[i] * (a0[i] - 256 * a0[(i + 1) % n]) % R for i in range(n)]
-    pin_i, ptab_i = permute_expression_pair(inp, f4, u, rng)
-    inp_d, pin_d, ptab_d = _dev(inp), _dev(pin_i), _dev(ptab_i)
+    inp_d = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(inp_d, M.lookup_input_graph(), pk.fixed_lagrange, advice, [instance_col], none,
+                     _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), k, k)   # the expression row by row (stride 1)
+    pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
+    pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
+                     for rows in (pin_rows, ptab_rows))                              # blinding rows random
     for p in commit_lagrange([pin_d, ptab_d]):
         tr.write_point(p)
     beta = tr.squeeze_challenge()
@@ -215,7 +243,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
         z = A.permutation_product([col_lag[c] for c in chunk], pk.sigma_lagrange[c0:c0 + len(chunk)], b_beta, b_gamma,
                                   _fr_bytes(delta_start), k, z0=None if last is None else _fr_bytes(last))
         last = _ints(z[32 * u:32 * (u + 1)])[0]
-        z[32 * (u + 1):] = _dev([rng() for _ in range(n - u - 1)])
+        z[32 * (u + 1):] = rand(n - u - 1)
         zs.append(z)
         delta_start = delta_start * pow(DELTA, len(chunk), R) % R
     if last != 1:
@@ -223,10 +251,10 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     lz = A.lookup_product(inp_d, pk.fixed_lagrange[4], pin_d, ptab_d, b_beta, b_gamma)
     if _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
         raise ValueError("lookup argument not satisfied by the assignment")
-    lz[32 * (u + 1):] = _dev([rng() for _ in range(n - u - 1)])
+    lz[32 * (u + 1):] = rand(n - u - 1)
     for p in commit_lagrange(zs + [lz]):
         tr.write_point(p)
-    polys[("random", 0)] = _dev([rng() for _ in range(n)])
+    polys[("random", 0)] = rand(n)
     tr.write_point(_point(params.commit(polys[("random", 0)])))
     y = tr.squeeze_challenge()
     b_y = _fr_bytes(y)
@@ -244,7 +272,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
                            M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext, pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k,
                            M.BLINDING_FACTORS + 1)
     input_ext = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(input_ext, M.expression_graph(M.lookup_expressions()[0]), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta,
+    A.quotient_gates(input_ext, M.lookup_input_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta,
                      b_gamma, b_theta, b_y, k, ext_k)
     A.quotient_lookup(values, lz_ext, pin_ext, ptab_ext, input_ext, pk.fixed_ext[4], pk.l0_ext, pk.l_last_ext, pk.l_active_ext,
                       b_beta, b_gamma, b_y, k, ext_k)
@@ -296,7 +324,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
             scale = vi * _inv(denom) % R
             for t, b in enumerate(basis):
                 r_coeff[t] = (r_coeff[t] + scale * b) % R
-        r_poly = _dev(r_coeff + [0] * (n - len(r_coeff)))
+        r_poly = _head(r_coeff, n)
         f = A.lincomb([q, r_poly], np.concatenate([_fr_bytes(1), _fr_bytes(R - 1)]))
         for p in pts:
             quo, rem = A.kate_division(f, _fr_bytes(p), with_remainder=True)
@@ -329,7 +357,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
         coeffs.append(scale)
         r_at_mu = sum(c * pow(mu, t, R) for t, c in enumerate(r_coeff)) % R
         const = (const + scale * r_at_mu) % R
-    one_poly = _dev([1] + [0] * (n - 1))
+    one_poly = _head([1], n)
     l_poly = A.lincomb(qs + [f_all, one_poly],
                        np.concatenate([_fr_bytes(c) for c in coeffs] + [_fr_bytes((-z_s0) % R), _fr_bytes((-const) % R)]))
     quo, rem = A.kate_division(l_poly, _fr_bytes(mu), with_remainder=True)

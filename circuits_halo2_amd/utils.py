@@ -58,6 +58,21 @@ def random_fr_canonical(seed: int, n: int) -> np.ndarray:
     return limbs.view(np.uint8).reshape(-1)
 
 
+def random_fr_secure(n: int) -> np.ndarray:
+    """n uniform values in [0, r) from the OS entropy source (blinding factors of a proof): 254-bit candidates,
+    rejection-sampled; canonical 32-B little-endian integers"""
+    import os
+    out = np.zeros((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        cand = np.frombuffer(os.urandom(32 * todo.size), dtype=np.uint64).reshape(-1, 4).copy()
+        cand[:, 3] &= np.uint64((1 << 62) - 1)
+        ok = _lt_r(cand)
+        out[todo[ok]] = cand[ok]
+        todo = todo[~ok]
+    return out.view(np.uint8).reshape(-1)
+
+
 def to_montgomery_host(canon: np.ndarray) -> np.ndarray:
     """canonical -> Montgomery with Python integers (small inputs / CPU-only tests)."""
     out = bytearray(canon.size)

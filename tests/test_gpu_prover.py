@@ -14,8 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup():
+def make_setup(k):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU")
@@ -25,9 +24,9 @@ def setup():
     import mst_assignment as MA
     from oracle import pyref as PR
     ffi.check(ffi.lib().sg_init(0))
-    k = 9
     asg = MA.build(k)
-    assert MA.check_gates(asg, k)
+    if k <= 10:
+        assert MA.check_gates(asg, k)      # row by row with Python integers (the floor plan does not depend on k)
     tau = ints_to_fr([0x1D0C0FFEE1234567890ABCDEF])
     params = sg.ParamsKZG.setup(k, tau)
     dev = lambda ints: torch.from_numpy(ints_to_fr(ints)).cuda()
@@ -37,17 +36,23 @@ def setup():
     s_g2 = (f2(params.s_g2[:64]), f2(params.s_g2[64:]))
     vk = {"k": k, "vk_digest": pk.vk_digest, "fixed_comms": pk.fixed_comms, "permutation_comms": pk.permutation_comms, "g2": g2,
           "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
-    yield {"k": k, "asg": asg, "params": params, "pk": pk, "vk": vk, "dev": dev, "prover": prover}
-    params.free()
+    return {"k": k, "asg": asg, "params": params, "pk": pk, "vk": vk, "dev": dev, "prover": prover}
+
+
+@pytest.fixture(scope="module")
+def setup():
+    s = make_setup(9)
+    yield s
+    s["params"].free()
 
 
 def seeded_rng(seed):
-    from oracle import pyref as PR
+    from circuits_halo2_amd.utils import random_fr_canonical
     state = {"i": 0}
 
-    def rng():
+    def rng(count):
         state["i"] += 1
-        return PR.random_fr(seed + state["i"], 1)[0]
+        return random_fr_canonical(seed + 7919 * state["i"], count)
     return rng
 
 
@@ -93,3 +98,23 @@ def test_gpu_prover_unsatisfied_assignments(setup, what):
     else:
         with pytest.raises(ValueError):
             s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], seeded_rng(7))
+
+
+def test_gpu_proof_at_k17(gpu_time_budget=None):
+    """the configuration the reference benchmarks (k = 17: 2^17 rows, 2^20 extended rows): one proof, verified"""
+    import time
+    from oracle import summa_verifier as SV
+    s = make_setup(17)
+    try:
+        advice = [s["dev"](c) for c in s["asg"]["advice"]]
+        s["params"].precompute()
+        s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], seeded_rng(5))   # warm-up
+        t = time.perf_counter()
+        proof = s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], seeded_rng(6))
+        print(f"create_proof k=17: {(time.perf_counter() - t) * 1e3:.1f} ms")
+        assert SV.verify(proof, s["asg"]["instances"], s["vk"])
+        p = bytearray(proof)
+        p[0x400] ^= 1
+        assert not SV.verify(bytes(p), s["asg"]["instances"], s["vk"])
+    finally:
+        s["params"].free()

@@ -142,3 +142,26 @@ def test_trace_fixture_is_what_the_reference_verifier_computes():
     assert out == json.load(open(os.path.join(GOLD, "k6_verifier_trace.json")))
     cd = json.load(open(Y.CALLDATA))
     assert cd == json.load(open(os.path.join(GOLD, "k6_inclusion_proof_solidity_calldata.json")))
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_permute_expression_pair_host_logic(small):
+    """the prover's lookup permutation (halo2's permute_expression_pair): A' sorted, every row has A'[i] == S'[i]
+    or A'[i] == A'[i-1], both are permutations of their inputs; a value outside the table is an error"""
+    import numpy as np
+    from circuits_halo2_amd.prover import permute_expression_pair
+    rng = np.random.default_rng(3)
+    n = 777
+    table = np.zeros((n, 4), dtype=np.uint64)
+    table[:256, 0] = np.arange(256)
+    if not small:
+        table[:, 2] = 9                      # multi-limb values take the general path
+    inp = table[rng.integers(0, 256, n)]
+    a, s = permute_expression_pair(inp, table)
+    assert all((a[i] == s[i]).all() or (a[i] == a[i - 1]).all() for i in range(n))
+    srt = lambda x: x[np.lexsort((x[:, 0], x[:, 1], x[:, 2], x[:, 3]))]
+    assert (srt(s) == srt(table)).all() and (a == srt(inp)).all()
+    bad = inp.copy()
+    bad[5, 0] = 999
+    with pytest.raises(ValueError):
+        permute_expression_pair(bad, table)

@@ -1,0 +1,47 @@
+"""wall time of circuits_halo2_amd.prover.create_proof for the reference circuit's constraint system (example
+assignment), k from argv (default 17); PROFILE=1 prints the host-side profile of one call"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import circuits_halo2_amd as sg
+from circuits_halo2_amd import ffi, prover, mst_inclusion as M
+from circuits_halo2_amd.utils import ints_to_fr
+
+
+def setup(k):
+    asg = M.example_assignment(k)
+    params = sg.ParamsKZG.setup(k, ints_to_fr([0x1D0C0FFEE1234567890ABCDEF]))
+    params.precompute()
+    dev = lambda ints: torch.from_numpy(ints_to_fr(ints)).cuda()
+    pk = prover.ProvingKey(params, k, [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]])
+    return params, pk, [dev(c) for c in asg["advice"]], asg["instances"]
+
+
+def run(k=17, reps=5):
+    params, pk, advice, instances = setup(k)
+    prover.create_proof(params, pk, advice, instances)
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        proof = prover.create_proof(params, pk, advice, instances)
+        best = min(best, time.perf_counter() - t)
+    params.free()
+    return best * 1e3, len(proof)
+
+
+if __name__ == "__main__":
+    ffi.check(ffi.lib().sg_init(0))
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+    if os.environ.get("PROFILE"):
+        import cProfile, pstats
+        params, pk, advice, instances = setup(k)
+        prover.create_proof(params, pk, advice, instances)
+        pr = cProfile.Profile()
+        pr.enable()
+        prover.create_proof(params, pk, advice, instances)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    else:
+        ms, nbytes = run(k)
+        print(f"create_proof k={k}: {ms:.2f} ms per proof ({nbytes} bytes), best of 5")
