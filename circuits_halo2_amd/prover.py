@@ -183,13 +183,22 @@ def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
     return a, s
 
 
-def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None) -> bytes:
+def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None, timings=None) -> bytes:
     """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
     `rng(count)` returns `count` uniform field elements as canonical 32-byte little-endian integers (blinding
     factors, the random polynomial); default: the OS entropy source."""
     import torch
     rng = rng or random_fr_secure
     rand = lambda count: A.fr_to_montgomery(torch.from_numpy(np.ascontiguousarray(rng(count))).cuda())
+    import time
+    clock = [time.perf_counter()]
+
+    def lap(name):   # per-phase wall clock (device drained), only when asked for
+        if timings is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - clock[0]) * 1e3
+            clock[0] = now
     k, n, u, dom = pk.k, pk.n, pk.usable_rows, pk.dom
     ext_k = dom.extended_k
     ne = 1 << ext_k
@@ -220,6 +229,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     ext1 = dom.coeff_to_extended_batch(adv_coeff)
     adv_ext, inst_ext = ext1[:3], ext1[3]
 
+    lap("1_advice")
     # -- 2: lookup: compressed input / table over the rows, permuted pair (host sort, as upstream), commitments
     inp_d = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
     A.quotient_gates(inp_d, M.lookup_input_graph(), pk.fixed_lagrange, advice, [instance_col], none,
@@ -233,6 +243,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     gamma = tr.squeeze_challenge_again()
     b_beta, b_gamma, b_theta = _fr_bytes(beta), _fr_bytes(gamma), _fr_bytes(theta)
 
+    lap("2_lookup")
     # -- 3: grand products (device scans), blinding rows, commitments; then the random polynomial
     col_lag = {(A.ADVICE, j): advice[j] for j in range(3)}
     col_lag.update({(A.FIXED, j): pk.fixed_lagrange[j] for j in range(M.NUM_FIXED)})
@@ -262,6 +273,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     polys[("pin", 0)], polys[("ptab", 0)], polys[("z", 0)], polys[("z", 1)], polys[("lz", 0)] = co3
     pin_ext, ptab_ext, z0_ext, z1_ext, lz_ext = dom.coeff_to_extended_batch(co3)
 
+    lap("3_grand_products")
     # -- 4: quotient: evaluate_h over the extended coset, / (X^n - 1), back to coefficients, five pieces
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
     A.quotient_gates(values, M.gate_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta, b_gamma, b_theta, b_y, k, ext_k)
@@ -284,6 +296,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     x = tr.squeeze_challenge()
     x_n = pow(x, n, R)
 
+    lap("4_quotient")
     # -- 5: evaluations
     for j in range(M.NUM_FIXED):
         polys[("f", j)] = pk.fixed_coeff[j]
@@ -304,6 +317,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     if debug is not None:
         debug.update({"h_eval": h_eval, "x": x, "y": y, "beta": beta, "gamma": gamma, "theta": theta, "evals": dict(evals)})
 
+    lap("5_evaluations")
     # -- 6: SHPLONK (BDFG21) multi-open
     zeta = tr.squeeze_challenge()
     nu = tr.squeeze_challenge_again()
@@ -364,4 +378,5 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     if bytes(rem) != bytes(32):
         raise ValueError("multi-open linearisation does not vanish at mu")
     tr.write_point(_point(params.commit(torch.cat([quo, zero_row]))))
+    lap("6_multiopen")
     return bytes(tr.proof)
