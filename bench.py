@@ -280,6 +280,7 @@ def main():
                     torch.cuda.empty_cache()
                     ms17, nbytes = run_create_proof(17, reps=3)
                     line["create_proof_k17"] = {"ms": ms17, "proof_bytes": nbytes, "rows_per_s": (1 << 17) / (ms17 * 1e-3),
+                                                "phases_ms_synchronised": run_create_proof.phases, "keygen_ms": run_create_proof.keygen_ms,
                                                 "note": "whole create_proof (EVM transcript, SHPLONK) for MstInclusionCircuit's constraint system "
                                                         "(19 gates, 1 lookup, 6 permutation columns) at k = 17 on the example assignment, wall clock "
                                                         "incl. the host glue (transcript, lookup sort, blinding from os.urandom); best of 3"}

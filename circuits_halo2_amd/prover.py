@@ -134,7 +134,10 @@ class ProvingKey:
         self.usable_rows = u
         assert len(fixed_lagrange) == M.NUM_FIXED and len(sigma_lagrange) == len(M.PERMUTATION_COLUMNS)
         self.fixed_lagrange, self.sigma_lagrange = list(fixed_lagrange), list(sigma_lagrange)
-        sel = [_dev([1] + [0] * (n - 1)), _dev([0] * u + [1] + [0] * (n - u - 1)), _dev([1] * u + [0] * (n - u))]
+        one = torch.from_numpy(ints_to_fr([1])).cuda()
+        l_last = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+        l_last[32 * u:32 * (u + 1)] = one
+        sel = [_head([1], n), l_last, torch.cat([one.repeat(u), torch.zeros(32 * (n - u), dtype=torch.uint8, device="cuda")])]
         cols = self.fixed_lagrange + self.sigma_lagrange + sel
         coeff = A.best_fft_batch([c.clone() for c in cols], self.dom.get_omega_inv(), k, divisor=self.dom.ifft_divisor())
         ext = self.dom.coeff_to_extended_batch(coeff)
@@ -188,6 +191,14 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     `rng(count)` returns `count` uniform field elements as canonical 32-byte little-endian integers (blinding
     factors, the random polynomial); default: the OS entropy source."""
     import torch
+    background = None
+    if rng is None:
+        # the n coefficients of the random polynomial depend on nothing: draw them (4 MiB of OS entropy at k = 17,
+        # rejection-sampled) on a worker thread while the first phases run
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+        background = pool.submit(random_fr_secure, pk.n)
+        pool.shutdown(wait=False)
     rng = rng or random_fr_secure
     rand = lambda count: A.fr_to_montgomery(torch.from_numpy(np.ascontiguousarray(rng(count))).cuda())
     import time
@@ -263,10 +274,10 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     if _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
         raise ValueError("lookup argument not satisfied by the assignment")
     lz[32 * (u + 1):] = rand(n - u - 1)
-    for p in commit_lagrange(zs + [lz]):
-        tr.write_point(p)
-    polys[("random", 0)] = rand(n)
-    tr.write_point(_point(params.commit(polys[("random", 0)])))
+    polys[("random", 0)] = rand(n) if background is None else \
+        A.fr_to_montgomery(torch.from_numpy(background.result()).cuda())
+    for c in params.commit_batch_mixed(zs + [lz, polys[("random", 0)]], [True, True, True, False]):   # one fused job
+        tr.write_point(_point(c))
     y = tr.squeeze_challenge()
     b_y = _fr_bytes(y)
     co3 = to_coeff([pin_d, ptab_d] + zs + [lz])
@@ -340,11 +351,8 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
                 r_coeff[t] = (r_coeff[t] + scale * b) % R
         r_poly = _head(r_coeff, n)
         f = A.lincomb([q, r_poly], np.concatenate([_fr_bytes(1), _fr_bytes(R - 1)]))
-        for p in pts:
-            quo, rem = A.kate_division(f, _fr_bytes(p), with_remainder=True)
-            if bytes(rem) != bytes(32):
-                raise ValueError("opening claim does not hold")
-            f = torch.cat([quo, zero_row])
+        for p in pts:   # exact divisions (q - r vanishes on the set); the final remainder check below covers them
+            f = torch.cat([A.kate_division(f, _fr_bytes(p)), zero_row])
         qs.append(q)
         rs.append(r_coeff)
         fs.append(f)

@@ -100,6 +100,38 @@ def test_gpu_prover_unsatisfied_assignments(setup, what):
             s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], seeded_rng(7))
 
 
+def test_gpu_proof_under_the_reference_srs_and_contract_constants():
+    """k = 11 with the reference's own SRS file (backend/ptau/hermez-raw-11, the reference circuit's size): the proof
+    verifies with the G2 constants of the reference's verifier contract (tests/golden/k6_verifier_trace.json)"""
+    import json
+    import torch
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi, prover
+    from circuits_halo2_amd import mst_inclusion as M
+    from circuits_halo2_amd.utils import ints_to_fr
+    from oracle import summa_verifier as SV
+    ffi.check(ffi.lib().sg_init(0))
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    params = sg.ParamsKZG.read(open(os.path.join(gold, "hermez-raw-11"), "rb"))
+    try:
+        k = params.k
+        assert k == 11
+        asg = M.example_assignment(k)
+        dev = lambda ints: torch.from_numpy(ints_to_fr(ints)).cuda()
+        pk = prover.ProvingKey(params, k, [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]])
+        proof = prover.create_proof(params, pk, [dev(c) for c in asg["advice"]], asg["instances"], seeded_rng(11))
+        v = json.load(open(os.path.join(gold, "k6_verifier_trace.json")))["vk"]
+        H = lambda s: int(s, 16)
+        vk = {"k": k, "vk_digest": pk.vk_digest, "fixed_comms": pk.fixed_comms, "permutation_comms": pk.permutation_comms,
+              "g2": ((H(v["g2_x_2"]), H(v["g2_x_1"])), (H(v["g2_y_2"]), H(v["g2_y_1"]))),
+              "neg_s_g2": ((H(v["neg_s_g2_x_2"]), H(v["neg_s_g2_x_1"])), (H(v["neg_s_g2_y_2"]), H(v["neg_s_g2_y_1"])))}
+        assert SV.verify(proof, asg["instances"], vk)
+        # the range table's commitment is the reference's own fixed_comms[4] (K2): same column, same SRS
+        assert pk.fixed_comms[4] == (H(v["commitments"][4][0]), H(v["commitments"][4][1]))
+    finally:
+        params.free()
+
+
 def test_gpu_proof_at_k17(gpu_time_budget=None):
     """the configuration the reference benchmarks (k = 17: 2^17 rows, 2^20 extended rows): one proof, verified"""
     import time

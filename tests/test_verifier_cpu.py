@@ -165,3 +165,15 @@ def test_permute_expression_pair_host_logic(small):
     bad[5, 0] = 999
     with pytest.raises(ValueError):
         permute_expression_pair(bad, table)
+
+
+def test_contract_pairing_constants_are_the_srs_files():
+    """the verifier contract's G2 constants are the last 256 bytes of the reference's SRS file
+    (backend/ptau/hermez-raw-11: g2, s_g2): generator, and -[s]_2 = the negated s_g2"""
+    _, _, vk, _ = load_k6()
+    raw = open(os.path.join(GOLD, "hermez-raw-11"), "rb").read()
+    tail = raw[4 + 128 * 2048:]
+    f2 = lambda b: (PR.fq_from_bytes(b[:32]), PR.fq_from_bytes(b[32:64]))
+    g2, s_g2 = (f2(tail[:64]), f2(tail[64:128])), (f2(tail[128:192]), f2(tail[192:256]))
+    assert vk["g2"] == g2
+    assert vk["neg_s_g2"] == (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))

@@ -14,6 +14,11 @@ def setup(k):
     params.precompute()
     dev = lambda ints: torch.from_numpy(ints_to_fr(ints)).cuda()
     pk = prover.ProvingKey(params, k, [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]])
+    fixed, sigma = [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]]
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    pk = prover.ProvingKey(params, k, fixed, sigma)      # second construction: work spaces and plans are warm
+    setup.keygen_ms = (time.perf_counter() - t) * 1e3
     return params, pk, [dev(c) for c in asg["advice"]], asg["instances"]
 
 
@@ -30,6 +35,7 @@ def run(k=17, reps=5):
     prover.create_proof(params, pk, advice, instances, timings=tm)
     params.free()
     run.phases = {k_: round(v_, 2) for k_, v_ in tm.items()}
+    run.keygen_ms = setup.keygen_ms
     return best * 1e3, len(proof)
 
 
@@ -47,4 +53,5 @@ if __name__ == "__main__":
         pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
     else:
         ms, nbytes = run(k)
-        print(f"create_proof k={k}: {ms:.2f} ms per proof ({nbytes} bytes), best of 5; phases (synchronised run): {run.phases}")
+        print(f"create_proof k={k}: {ms:.2f} ms per proof ({nbytes} bytes), best of 5; phases (synchronised run): {run.phases}; "
+              f"proving-key construction from Lagrange columns (17 commitments, 20 iNTT + 20 coset NTT): {run.keygen_ms:.2f} ms")
