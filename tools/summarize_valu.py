@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>_valu (rocprofv3 --pmc VALUBusy VALUUtilization) -> profiles/<tag>_valu.json"""
+import collections, csv, glob, json, sys
+tag = sys.argv[1]
+cc = glob.glob(f"gpurun_out/prof_{tag}_valu/*/*_counter_collection.csv")[0]
+per_k, per_g = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(cc)):
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    per_k[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    per_g[f"{name}@grid{r['Grid_Size']}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = lambda d: {f"{c}_avg": round(sum(v) / len(v), 2) for c, v in d.items()}
+main = ("msm_accumulate", "ntt_pass", "gates_kernel", "quot_", "mst_", "msm_reduce")
+out = {"tag": tag, "note": "rocprofv3 --pmc VALUBusy VALUUtilization over the default bench.py run (separate pass): VALUBusy = % of cycles "
+                           "the vector ALUs are busy, VALUUtilization = % of active lanes",
+       "kernels": {k: dict(avg(v), launches=len(next(iter(v.values())))) for k, v in sorted(per_k.items())},
+       "per_grid": {k: avg(v) for k, v in sorted(per_g.items()) if any(m in k for m in main)}}
+json.dump(out, open(f"profiles/{tag}_valu.json", "w"), indent=1)
+print("wrote", f"profiles/{tag}_valu.json", len(out["kernels"]), "kernels")
