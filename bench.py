@@ -279,7 +279,25 @@ def main():
                     from time_create_proof import run as run_create_proof
                     torch.cuda.empty_cache()
                     ms17, nbytes = run_create_proof(17, reps=3)
-                    line["create_proof_k17"] = {"ms": ms17, "proof_bytes": nbytes, "rows_per_s": (1 << 17) / (ms17 * 1e-3),
+                    cpp17 = {}
+                    exe17 = os.path.join(ROOT, "tools", "create_proof_cpp")
+                    if os.path.exists(exe17) and not profiled:   # the same prover as compiled host code (include/summa_prover.hpp), own process
+                        import subprocess, tempfile
+                        from time_create_proof import setup as cp_setup
+                        from circuits_halo2_amd import prover as _prover
+                        with tempfile.TemporaryDirectory() as td:
+                            params17, pk17, adv17, inst17 = cp_setup(17)
+                            _prover.export_bundle(os.path.join(td, "bundle.bin"), params17, pk17, adv17, inst17)
+                            params17.free()
+                            del pk17, adv17
+                            torch.cuda.empty_cache()
+                            r = subprocess.run([exe17, os.path.join(td, "bundle.bin"), os.path.join(td, "proof.bin"), "8"],
+                                               capture_output=True, text=True, timeout=300)
+                            if r.returncode == 0:
+                                cpp17 = json.loads(r.stdout.strip().splitlines()[-1])
+                    line["create_proof_k17"] = {"ms": ms17, "ms_cpp_driver": cpp17.get("create_proof_ms"),
+                                                "phases_ms_cpp_driver_synchronised": {k_: v_ for k_, v_ in cpp17.items() if k_[0].isdigit()},
+                                                "proof_bytes": nbytes, "rows_per_s": (1 << 17) / ((cpp17.get("create_proof_ms") or ms17) * 1e-3),
                                                 "phases_ms_synchronised": run_create_proof.phases, "keygen_ms": run_create_proof.keygen_ms,
                                                 "note": "whole create_proof (EVM transcript, SHPLONK) for MstInclusionCircuit's constraint system "
                                                         "(19 gates, 1 lookup, 6 permutation columns) at k = 17 on the example assignment, wall clock "

@@ -388,3 +388,32 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     tr.write_point(_point(params.commit(torch.cat([quo, zero_row]))))
     lap("6_multiopen")
     return bytes(tr.proof)
+
+
+def export_bundle(path: str, params, pk: ProvingKey, advice, instances) -> None:
+    """everything the C++ driver (include/summa_prover.hpp, tools/create_proof_main.cpp) needs for one proof: SRS,
+    the proving key's Lagrange columns, the two GraphEvaluator programs, the assignment and the public inputs"""
+    import struct
+
+    def graph_bytes(g: A.GraphEvaluator) -> bytes:
+        out = struct.pack("<I", len(g.constants)) + b"".join(g.constants)
+        out += struct.pack("<I", len(g.rotations)) + struct.pack(f"<{len(g.rotations)}i", *g.rotations)
+        parts, calcs = [], b""
+        for cal in g.calculations:
+            off, ln = 0, 0
+            if len(cal) > 3:
+                off, ln = len(parts), len(cal[3])
+                parts.extend(cal[3])
+            calcs += struct.pack("<9I", cal[0], *cal[1], *cal[2], off, ln)
+        out += struct.pack("<I", len(g.calculations)) + calcs
+        out += struct.pack("<I", len(parts)) + b"".join(struct.pack("<3I", *p) for p in parts)
+        return out
+    host = lambda t: t.cpu().numpy().tobytes()
+    with open(path, "wb") as f:
+        f.write(b"SGPB1\0\0\0" + struct.pack("<II", pk.k, len(instances)))
+        f.write(params.g.tobytes() + params.g_lagrange.tobytes())
+        for col in pk.fixed_lagrange + pk.sigma_lagrange + list(advice):
+            f.write(host(col))
+        f.write(ints_to_fr(list(instances)).tobytes())
+        f.write(pk.vk_digest.to_bytes(32, "big"))
+        f.write(graph_bytes(M.gate_graph()) + graph_bytes(M.lookup_input_graph()))

@@ -1,0 +1,863 @@
+// create_proof for the constraint system of the reference's MstInclusionCircuit, driven from C++ over the C ABI
+// (include/summa_gpu.h): the compiled-host counterpart of circuits_halo2_amd/prover.py, same steps, same transcript,
+// same 2144-byte proof [REF zk_prover/src/circuits/utils.rs:94-101 -> halo2_proofs::plonk::create_proof with
+// ProverSHPLONK; proof layout and Keccak transcript: contracts/src/InclusionVerifier.sol:85-110, 274-367].
+// Every data-parallel step runs on the device; the host does what upstream also does serially (transcript, the
+// lookup's sort, scalars of the multi-open, blinding factors from the OS entropy source).
+// The circuit-specific inputs -- fixed / permutation columns, the GraphEvaluator programs of the gates and of the
+// lookup input -- come from the proving key (here: a bundle file written by circuits_halo2_amd.prover.export_bundle).
+// Header-only; needs the HIP runtime for device buffers.  Proofs are checked by tests/test_gpu_prover.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <functional>
+#include <future>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "summa_gpu.h"
+
+namespace summa {
+namespace prover {
+
+// ------------------------------------------------------------------ BN254 Fr on the host (Montgomery, 4 x 64)
+struct Fr {
+  uint64_t l[4];
+  static constexpr uint64_t P[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  static constexpr uint64_t INV = 0xc2e1f593efffffffULL;  // -p^-1 mod 2^64
+  static constexpr uint64_t R1[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+  static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+  static Fr zero() { return Fr{{0, 0, 0, 0}}; }
+  static Fr one() { return Fr{{R1[0], R1[1], R1[2], R1[3]}}; }
+  static bool geq_p(const uint64_t a[4]) {
+    for (int i = 3; i >= 0; i--) {
+      if (a[i] != P[i]) return a[i] > P[i];
+    }
+    return true;
+  }
+  static void sub_p(uint64_t a[4]) {
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 t = (unsigned __int128)a[i] - P[i] - (uint64_t)borrow;
+      a[i] = (uint64_t)t;
+      borrow = (t >> 64) & 1;
+    }
+  }
+  Fr operator+(const Fr& o) const {
+    Fr r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (unsigned __int128)l[i] + o.l[i];
+      r.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (c || geq_p(r.l)) sub_p(r.l);
+    return r;
+  }
+  Fr operator-(const Fr& o) const {
+    Fr r;
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 t = (unsigned __int128)l[i] - o.l[i] - (uint64_t)borrow;
+      r.l[i] = (uint64_t)t;
+      borrow = (t >> 64) & 1;
+    }
+    if (borrow) {
+      unsigned __int128 c = 0;
+      for (int i = 0; i < 4; i++) {
+        c += (unsigned __int128)r.l[i] + P[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    return r;
+  }
+  Fr operator-() const { return zero() - *this; }
+  Fr operator*(const Fr& o) const {  // CIOS Montgomery product
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; j++) {
+        c += (unsigned __int128)l[j] * o.l[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[4] = (uint64_t)c;
+      t[5] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * INV;
+      c = (unsigned __int128)m * P[0] + t[0];
+      c >>= 64;
+      for (int j = 1; j < 4; j++) {
+        c += (unsigned __int128)m * P[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[3] = (uint64_t)c;
+      t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fr r{{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_p(r.l)) sub_p(r.l);
+    return r;
+  }
+  bool operator==(const Fr& o) const { return !std::memcmp(l, o.l, 32); }
+  bool operator!=(const Fr& o) const { return !(*this == o); }
+  bool is_zero() const { return !(l[0] | l[1] | l[2] | l[3]); }
+  Fr pow(const uint64_t e[4]) const {
+    Fr r = one();
+    for (int i = 255; i >= 0; i--) {
+      r = r * r;
+      if ((e[i / 64] >> (i % 64)) & 1) r = r * *this;
+    }
+    return r;
+  }
+  Fr pow(uint64_t e) const {
+    const uint64_t ee[4] = {e, 0, 0, 0};
+    return pow(ee);
+  }
+  Fr inv() const {
+    const uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
+    return pow(e);
+  }
+  static Fr from_u64(uint64_t v) { return from_canonical_limbs(std::array<uint64_t, 4>{v, 0, 0, 0}.data()); }
+  static Fr from_canonical_limbs(const uint64_t c[4]) {  // c < p
+    Fr a{{c[0], c[1], c[2], c[3]}}, r2{{R2[0], R2[1], R2[2], R2[3]}};
+    return a * r2;
+  }
+  // any 256-bit big-endian integer, reduced mod p (challenges: keccak output)
+  static Fr from_be_bytes_reduced(const uint8_t b[32]) {
+    uint64_t c[4];
+    for (int i = 0; i < 4; i++) {
+      uint64_t w = 0;
+      for (int j = 0; j < 8; j++) w = (w << 8) | b[8 * (3 - i) + j];
+      c[i] = w;
+    }
+    while (geq_p(c)) sub_p(c);
+    return from_canonical_limbs(c);
+  }
+  void to_canonical_limbs(uint64_t out[4]) const {
+    Fr o{{1, 0, 0, 0}};
+    Fr c = *this * o;
+    std::memcpy(out, c.l, 32);
+  }
+  void to_be_bytes(uint8_t out[32]) const {
+    uint64_t c[4];
+    to_canonical_limbs(c);
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 8; j++) out[8 * (3 - i) + j] = (uint8_t)(c[i] >> (8 * (7 - j)));
+  }
+  const uint8_t* bytes() const { return reinterpret_cast<const uint8_t*>(l); }  // Montgomery, as the ABI takes it
+};
+
+// Fq only appears as bytes to convert: Montgomery little-endian (ABI) -> canonical big-endian (proof / transcript)
+inline void fq_mont_to_be(const uint8_t in[32], uint8_t out[32]) {
+  static constexpr uint64_t Q[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  static constexpr uint64_t QINV = 0x87d20782e4866389ULL;
+  uint64_t t[5];
+  std::memcpy(t, in, 32);
+  t[4] = 0;
+  for (int i = 0; i < 4; i++) {  // Montgomery reduction of (in * 1)
+    const uint64_t m = t[0] * QINV;
+    unsigned __int128 c = (unsigned __int128)m * Q[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (unsigned __int128)m * Q[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = (uint64_t)(c >> 64);
+  }
+  bool ge = true;
+  for (int i = 3; i >= 0; i--) {
+    if (t[i] != Q[i]) {
+      ge = t[i] > Q[i];
+      break;
+    }
+  }
+  if (ge) {
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 d = (unsigned __int128)t[i] - Q[i] - (uint64_t)borrow;
+      t[i] = (uint64_t)d;
+      borrow = (d >> 64) & 1;
+    }
+  }
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 8; j++) out[8 * (3 - i) + j] = (uint8_t)(t[i] >> (8 * (7 - j)));
+}
+
+// ------------------------------------------------------------------ Keccak-256 (Ethereum's) and the EVM transcript
+inline void keccak_f(uint64_t s[25]) {
+  static constexpr uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+      0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  static constexpr int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+  static constexpr int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+  for (int round = 0; round < 24; round++) {
+    uint64_t bc[5];
+    for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+    for (int i = 0; i < 5; i++) {
+      const uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
+      for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+    }
+    uint64_t t = s[1];
+    for (int i = 0; i < 24; i++) {
+      const int j = PIL[i];
+      const uint64_t b = s[j];
+      s[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
+      t = b;
+    }
+    for (int j = 0; j < 25; j += 5) {
+      for (int i = 0; i < 5; i++) bc[i] = s[j + i];
+      for (int i = 0; i < 5; i++) s[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+    }
+    s[0] ^= RC[round];
+  }
+}
+inline std::array<uint8_t, 32> keccak256(const uint8_t* data, size_t len) {
+  uint64_t s[25] = {0};
+  constexpr size_t rate = 136;
+  std::vector<uint8_t> buf(data, data + len);
+  buf.push_back(0x01);
+  while (buf.size() % rate) buf.push_back(0);
+  buf.back() |= 0x80;
+  for (size_t off = 0; off < buf.size(); off += rate) {
+    for (size_t i = 0; i < rate / 8; i++) {
+      uint64_t w;
+      std::memcpy(&w, buf.data() + off + 8 * i, 8);
+      s[i] ^= w;
+    }
+    keccak_f(s);
+  }
+  std::array<uint8_t, 32> out;
+  std::memcpy(out.data(), s, 32);
+  return out;
+}
+
+struct EvmTranscript {
+  std::vector<uint8_t> buf, proof;
+  explicit EvmTranscript(const uint8_t vk_digest_be[32]) : buf(vk_digest_be, vk_digest_be + 32) {}
+  void common_scalar(const Fr& v) {
+    uint8_t b[32];
+    v.to_be_bytes(b);
+    buf.insert(buf.end(), b, b + 32);
+  }
+  void write_scalar(const Fr& v) {
+    uint8_t b[32];
+    v.to_be_bytes(b);
+    buf.insert(buf.end(), b, b + 32);
+    proof.insert(proof.end(), b, b + 32);
+  }
+  void write_point(const uint8_t affine_mont[64]) {  // as the ABI returns commitments
+    uint8_t b[64];
+    fq_mont_to_be(affine_mont, b);
+    fq_mont_to_be(affine_mont + 32, b + 32);
+    buf.insert(buf.end(), b, b + 64);
+    proof.insert(proof.end(), b, b + 64);
+  }
+  Fr squeeze() {
+    auto h = keccak256(buf.data(), buf.size());
+    buf.assign(h.begin(), h.end());
+    return Fr::from_be_bytes_reduced(h.data());
+  }
+  Fr squeeze_again() {
+    buf.resize(32);
+    buf.push_back(0x01);
+    return squeeze();
+  }
+};
+
+// ------------------------------------------------------------------ inputs
+struct Graph {  // a GraphEvaluator program as the C ABI takes it
+  std::vector<uint8_t> constants;
+  std::vector<int32_t> rotations;
+  std::vector<sg_calculation> calculations;
+  std::vector<sg_value_source> parts;
+  sg_graph view() const {
+    return sg_graph{constants.data(), (uint32_t)(constants.size() / 32), rotations.data(), (uint32_t)rotations.size(),
+                    calculations.data(), (uint32_t)calculations.size(), parts.data(), (uint32_t)parts.size()};
+  }
+};
+
+inline void ck(int rc, const char* what) {
+  if (rc != SG_OK) throw std::runtime_error(std::string(what) + ": " + sg_last_error());
+}
+inline void hk(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+// freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device and cost ~100 us each)
+inline std::multimap<size_t, void*>& column_pool() {
+  static std::multimap<size_t, void*> pool;
+  return pool;
+}
+inline void release_column_pool() {
+  for (auto& kv : column_pool()) (void)hipFree(kv.second);
+  column_pool().clear();
+}
+struct DevCol {  // device column of Fr (Montgomery), owned
+  void* p = nullptr;
+  size_t rows = 0;
+  DevCol() = default;
+  explicit DevCol(size_t r) : rows(r) {
+    auto it = column_pool().find(r);
+    if (it != column_pool().end()) {
+      p = it->second;
+      column_pool().erase(it);
+    } else {
+      hk(hipMalloc(&p, 32 * r), "hipMalloc");
+    }
+  }
+  DevCol(const DevCol&) = delete;
+  DevCol& operator=(const DevCol&) = delete;
+  DevCol(DevCol&& o) noexcept : p(o.p), rows(o.rows) { o.p = nullptr; }
+  DevCol& operator=(DevCol&& o) noexcept {
+    if (p) column_pool().emplace(rows, p);
+    p = o.p;
+    rows = o.rows;
+    o.p = nullptr;
+    return *this;
+  }
+  ~DevCol() {
+    if (p) column_pool().emplace(rows, p);
+  }
+  uint8_t* at(size_t row) const { return static_cast<uint8_t*>(p) + 32 * row; }
+  void upload(const void* host, size_t first, size_t count) { hk(hipMemcpy(at(first), host, 32 * count, hipMemcpyHostToDevice), "H2D"); }
+  void zero() { hk(hipMemsetAsync(p, 0, 32 * rows, nullptr), "memset"); }
+};
+
+// constraint-system constants of MstInclusionCircuit (circuits_halo2_amd/mst_inclusion.py)
+constexpr uint32_t NUM_ADVICE = 3, NUM_FIXED = 11, NUM_SIGMA = 6, BLINDING = 5, CHUNK = 4, QUOTIENT_PIECES = 5;
+constexpr int ROT_LAST = -(int)(BLINDING + 1);
+enum Kind { A_, F_, SIGMA_, Z_, LZ_, PIN_, PTAB_, RANDOM_, H_ };
+struct Key {
+  Kind kind;
+  uint32_t index;
+  bool operator<(const Key& o) const { return kind != o.kind ? kind < o.kind : index < o.index; }
+};
+struct Query { Key key; int rot; };
+
+inline std::vector<Query> eval_order() {  // [REF InclusionVerifier.sol:500-1000, calldata slots 0x03e4 ..]
+  std::vector<Query> q = {{{A_, 0}, 0}, {{A_, 1}, 0}, {{A_, 0}, 1}, {{A_, 1}, 1}, {{A_, 2}, 0}, {{A_, 1}, -1}, {{A_, 0}, -1},
+                          {{F_, 2}, 0}, {{F_, 3}, 0}, {{F_, 0}, 0}, {{F_, 1}, 0}};
+  for (uint32_t j = 4; j < 11; j++) q.push_back({{F_, j}, 0});
+  q.push_back({{RANDOM_, 0}, 0});
+  for (uint32_t j = 0; j < 6; j++) q.push_back({{SIGMA_, j}, 0});
+  for (Query x : std::vector<Query>{{{Z_, 0}, 0}, {{Z_, 0}, 1}, {{Z_, 0}, ROT_LAST}, {{Z_, 1}, 0}, {{Z_, 1}, 1}, {{LZ_, 0}, 0},
+                                    {{LZ_, 0}, 1}, {{PIN_, 0}, 0}, {{PIN_, 0}, -1}, {{PTAB_, 0}, 0}})
+    q.push_back(x);
+  return q;
+}
+struct RotationSet { std::vector<int> rots; std::vector<Key> polys; };
+inline std::vector<RotationSet> rotation_sets() {  // nu order; polynomials in increasing power of zeta [REF :1159-1340]
+  std::vector<RotationSet> s(5);
+  s[0] = {{-1, 0, 1}, {{A_, 0}, {A_, 1}}};
+  s[1].rots = {0};
+  s[1].polys = {{A_, 2}, {PTAB_, 0}, {F_, 2}, {F_, 3}, {F_, 0}, {F_, 1}};
+  for (uint32_t j = 4; j < 11; j++) s[1].polys.push_back({F_, j});
+  for (uint32_t j = 0; j < 6; j++) s[1].polys.push_back({SIGMA_, j});
+  s[1].polys.push_back({H_, 0});
+  s[1].polys.push_back({RANDOM_, 0});
+  s[2] = {{ROT_LAST, 0, 1}, {{Z_, 0}}};
+  s[3] = {{0, 1}, {{Z_, 1}, {LZ_, 0}}};
+  s[4] = {{-1, 0}, {{PIN_, 0}}};
+  return s;
+}
+
+struct ProvingKey {
+  std::vector<uint64_t> table_rows;  // the lookup table column (fixed 4), canonical limbs of the usable rows (host copy)
+  uint32_t k = 0;
+  size_t n = 0, usable = 0;
+  uint64_t srs = 0;
+  uint8_t vk_digest_be[32] = {0};
+  Graph gates, lookup_input;
+  std::vector<DevCol> fixed_lag, sigma_lag, fixed_coeff, sigma_coeff, fixed_ext, sigma_ext;
+  DevCol l0_ext, l_last_ext, l_active_ext;
+  uint32_t ext_k() const { return k + 3; }  // degree 6: extended domain 2^(k + 3)
+
+  // fixed / sigma: Lagrange-basis device columns (moved in); builds the coefficient and extended-coset forms
+  void build(uint32_t k_, uint64_t srs_, std::vector<DevCol>&& fixed, std::vector<DevCol>&& sigma) {
+    k = k_;
+    n = (size_t)1 << k;
+    usable = n - (BLINDING + 1);
+    srs = srs_;
+    fixed_lag = std::move(fixed);
+    sigma_lag = std::move(sigma);
+    const size_t ne = (size_t)1 << ext_k();
+    uint8_t omega_inv[32], n_inv[32];
+    ck(sg_domain_constant(k, 1, omega_inv), "domain constant");
+    ck(sg_domain_constant(k, 2, n_inv), "domain constant");
+    std::vector<DevCol> sel;
+    const Fr one = Fr::one();
+    for (int s = 0; s < 3; s++) {
+      sel.emplace_back(n);
+      sel.back().zero();
+    }
+    sel[0].upload(one.l, 0, 1);
+    sel[1].upload(one.l, usable, 1);
+    {
+      std::vector<Fr> ones(usable, one);
+      sel[2].upload(ones.data(), 0, usable);
+    }
+    auto transform = [&](std::vector<DevCol>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext) {
+      std::vector<void*> pc, pe;
+      for (auto& c : lag) {
+        coeff.emplace_back(n);
+        hk(hipMemcpy(coeff.back().p, c.p, 32 * n, hipMemcpyDeviceToDevice), "D2D");
+        ext.emplace_back(ne);
+        pc.push_back(coeff.back().p);
+        pe.push_back(ext.back().p);
+      }
+      for (size_t i = 0; i < pc.size(); i += 16) {   // batched launches hold at most 16 vectors
+        const size_t m = std::min<size_t>(16, pc.size() - i);
+        ck(sg_ntt_fr_batch_dev(pc.data() + i, m, omega_inv, n_inv, k, nullptr), "iNTT batch");
+        ck(sg_coeff_to_extended_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), nullptr), "coset NTT batch");
+      }
+    };
+    transform(fixed_lag, fixed_coeff, fixed_ext);
+    transform(sigma_lag, sigma_coeff, sigma_ext);
+    std::vector<DevCol> sel_coeff, sel_ext;
+    transform(sel, sel_coeff, sel_ext);
+    l0_ext = std::move(sel_ext[0]);
+    l_last_ext = std::move(sel_ext[1]);
+    l_active_ext = std::move(sel_ext[2]);
+    {
+      DevCol canon(n);
+      table_rows.resize(4 * n);
+      ck(sg_fr_from_montgomery_dev(fixed_lag[4].p, canon.p, n, nullptr), "from_montgomery");
+      hk(hipMemcpy(table_rows.data(), canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
+    }
+    hk(hipDeviceSynchronize(), "sync");
+  }
+};
+
+// uniform field elements (canonical limbs) from the OS entropy source: 254-bit candidates, rejection-sampled
+inline void random_canonical(uint64_t* out, size_t count) {
+  thread_local FILE* f = std::fopen("/dev/urandom", "rb");   // one handle per thread: a large read must not block the others
+  if (!f) throw std::runtime_error("/dev/urandom");
+  size_t done = 0;
+  std::vector<uint64_t> buf;
+  while (done < count) {
+    const size_t want = (count - done) + (count - done) / 3 + 8;
+    buf.resize(4 * want);
+    if (std::fread(buf.data(), 32, want, f) != want) throw std::runtime_error("short read from /dev/urandom");
+    for (size_t i = 0; i < want && done < count; i++) {
+      uint64_t* c = buf.data() + 4 * i;
+      c[3] &= (1ULL << 62) - 1;
+      if (!Fr::geq_p(c)) {
+        std::memcpy(out + 4 * done, c, 32);
+        done++;
+      }
+    }
+  }
+}
+
+inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept
+  static uint64_t* p = nullptr;
+  static size_t cap = 0;
+  if (rows > cap) {
+    if (p) (void)hipHostFree(p);
+    hk(hipHostMalloc(reinterpret_cast<void**>(&p), 32 * rows), "hipHostMalloc");
+    cap = rows;
+  }
+  return p;
+}
+
+// halo2 `permute_expression_pair` on the usable rows (canonical limbs, rows of 4): A' sorted; S' such that every row
+// has A'[i] == S'[i] or A'[i] == A'[i-1].  One-limb tables (range checks) sort by the low limb only.
+inline void permute_expression_pair(const uint64_t* inp, const uint64_t* table, size_t rows, uint64_t* a_out, uint64_t* s_out) {
+  using Row = std::array<uint64_t, 4>;
+  auto less = [](const Row& x, const Row& y) {
+    for (int i = 3; i >= 0; i--)
+      if (x[i] != y[i]) return x[i] < y[i];
+    return false;
+  };
+  std::vector<Row> a(rows), t(rows);
+  std::memcpy(a.data(), inp, 32 * rows);
+  std::memcpy(t.data(), table, 32 * rows);
+  bool small = true;
+  for (auto& r : t) small = small && !(r[1] | r[2] | r[3]);
+  if (small) {  // sort 8-byte keys instead of 32-byte rows
+    std::vector<uint64_t> ka(rows), kt(rows);
+    for (size_t i = 0; i < rows; i++) {
+      if (a[i][1] | a[i][2] | a[i][3]) throw std::runtime_error("lookup input value not in the table");
+      ka[i] = a[i][0];
+      kt[i] = t[i][0];
+    }
+    const uint64_t top = *std::max_element(kt.begin(), kt.end());
+    if (top < (1u << 20)) {  // range tables: counting sort
+      std::vector<uint32_t> ca(top + 1, 0), ct(top + 1, 0);
+      for (size_t i = 0; i < rows; i++) {
+        if (ka[i] > top) throw std::runtime_error("lookup input value not in the table");
+        ca[ka[i]]++;
+        ct[kt[i]]++;
+      }
+      size_t ia = 0, it = 0;
+      for (uint64_t v = 0; v <= top; v++) {
+        for (uint32_t c = 0; c < ca[v]; c++) ka[ia++] = v;
+        for (uint32_t c = 0; c < ct[v]; c++) kt[it++] = v;
+      }
+    } else {
+      std::sort(ka.begin(), ka.end());
+      std::sort(kt.begin(), kt.end());
+    }
+    for (size_t i = 0; i < rows; i++) {
+      a[i] = Row{ka[i], 0, 0, 0};
+      t[i] = Row{kt[i], 0, 0, 0};
+    }
+  } else {
+    std::sort(a.begin(), a.end(), less);
+    std::sort(t.begin(), t.end(), less);
+  }
+  std::vector<Row> s(rows);
+  std::vector<size_t> repeated;
+  std::vector<bool> used(rows, false);
+  size_t ti = 0;
+  for (size_t i = 0; i < rows; i++) {
+    if (i && a[i] == a[i - 1]) {
+      repeated.push_back(i);
+      continue;
+    }
+    while (ti < rows && less(t[ti], a[i])) ti++;   // both sorted: one forward sweep
+    if (ti == rows || t[ti] != a[i]) throw std::runtime_error("lookup input value not in the table");
+    used[ti] = true;
+    s[i] = t[ti++];
+  }
+  size_t ri = 0;
+  for (size_t j = 0; j < rows; j++)
+    if (!used[j]) s[repeated[ri++]] = t[j];
+  std::memcpy(a_out, a.data(), 32 * rows);
+  std::memcpy(s_out, s.data(), 32 * rows);
+}
+
+struct Timings { std::map<std::string, double> ms; };
+
+// advice: 3 device columns (Lagrange, n rows; the last 6 rows are overwritten with blinding values)
+inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCol>& advice, const std::vector<Fr>& instances,
+                                         Timings* timings = nullptr) {
+  const uint32_t k = pk.k, ext_k = pk.ext_k();
+  const size_t n = pk.n, u = pk.usable, ne = (size_t)1 << ext_k;
+  auto clock = std::chrono::steady_clock::now();
+  auto lap = [&](const char* name) {  // per-phase wall clock with the device drained, only when asked for
+    if (!timings) return;
+    hk(hipDeviceSynchronize(), "sync");
+    const auto now = std::chrono::steady_clock::now();
+    timings->ms[name] += std::chrono::duration<double, std::milli>(now - clock).count();
+    clock = now;
+  };
+  // the n coefficients of the random polynomial depend on nothing: draw them on a worker thread meanwhile
+  auto random_coeffs = std::async(std::launch::async, [n]() {
+    std::vector<uint64_t> c(4 * n);
+    random_canonical(c.data(), n);
+    return c;
+  });
+  const Fr zero = Fr::zero();
+  uint8_t omega_inv_b[32], n_inv_b[32], omega_b[32];
+  ck(sg_domain_constant(k, 0, omega_b), "domain constant");
+  ck(sg_domain_constant(k, 1, omega_inv_b), "domain constant");
+  ck(sg_domain_constant(k, 2, n_inv_b), "domain constant");
+  Fr omega, omega_inv;
+  std::memcpy(omega.l, omega_b, 32);
+  std::memcpy(omega_inv.l, omega_inv_b, 32);
+  const Fr delta = Fr::from_u64(7).pow((uint64_t)1 << 28);
+  EvmTranscript tr(pk.vk_digest_be);
+  for (auto& v : instances) tr.common_scalar(v);
+
+  auto rand_rows = [&](DevCol& col, size_t first, size_t count) {  // canonical -> Montgomery on the device
+    std::vector<uint64_t> c(4 * count);
+    random_canonical(c.data(), count);
+    col.upload(c.data(), first, count);
+    ck(sg_fr_to_montgomery_dev(col.at(first), col.at(first), count, nullptr), "to_montgomery");
+  };
+  auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext) {
+    std::vector<void*> pc, pe;
+    for (void* c : lag) {
+      coeff.emplace_back(n);
+      hk(hipMemcpyAsync(coeff.back().p, c, 32 * n, hipMemcpyDeviceToDevice, nullptr), "D2D");
+      ext.emplace_back(ne);
+      pc.push_back(coeff.back().p);
+      pe.push_back(ext.back().p);
+    }
+    ck(sg_ntt_fr_batch_dev(pc.data(), pc.size(), omega_inv_b, n_inv_b, k, nullptr), "iNTT batch");
+    ck(sg_coeff_to_extended_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, nullptr), "coset NTT batch");
+  };
+  auto commit_batch = [&](std::vector<void*> cols, std::vector<int> basis) {
+    std::vector<uint8_t> out(64 * cols.size());
+    ck(sg_commit_batch_mixed_dev(pk.srs, basis.data(), cols.data(), cols.size(), n, nullptr, out.data()), "commit");
+    for (size_t i = 0; i < cols.size(); i++) tr.write_point(out.data() + 64 * i);
+  };
+
+  // -- 1: advice
+  for (auto& a : advice) rand_rows(a, u, n - u);
+  DevCol instance_col(n);
+  instance_col.zero();
+  if (!instances.empty()) instance_col.upload(instances.data(), 0, instances.size());
+  commit_batch({advice[0].p, advice[1].p, advice[2].p}, {1, 1, 1});
+  const Fr theta = tr.squeeze();
+  std::vector<DevCol> co1, ex1;
+  to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1);
+
+  lap("1_advice");
+  // -- 2: lookup
+  const sg_graph g_in = pk.lookup_input.view(), g_gates = pk.gates.view();
+  std::vector<void*> fixed_lag_p, fixed_ext_p, adv_lag_p = {advice[0].p, advice[1].p, advice[2].p}, inst_lag_p = {instance_col.p};
+  for (auto& c : pk.fixed_lag) fixed_lag_p.push_back(c.p);
+  for (auto& c : pk.fixed_ext) fixed_ext_p.push_back(c.p);
+  DevCol inp(n);
+  inp.zero();
+  ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
+                           zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, nullptr), "lookup input");
+  DevCol canon(n);
+  uint64_t* stage = pinned_rows(3 * n);   // page-locked staging: the three 32 n-byte transfers run at link speed
+  uint64_t *h_inp = stage, *h_a = stage + 4 * n, *h_s = stage + 8 * n;
+  ck(sg_fr_from_montgomery_dev(inp.p, canon.p, n, nullptr), "from_montgomery");
+  hk(hipMemcpy(h_inp, canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
+  permute_expression_pair(h_inp, pk.table_rows.data(), u, h_a, h_s);
+  DevCol pin(n), ptab(n);
+  pin.upload(h_a, 0, u);
+  ptab.upload(h_s, 0, u);
+  ck(sg_fr_to_montgomery_dev(pin.p, pin.p, u, nullptr), "to_montgomery");
+  ck(sg_fr_to_montgomery_dev(ptab.p, ptab.p, u, nullptr), "to_montgomery");
+  rand_rows(pin, u, n - u);
+  rand_rows(ptab, u, n - u);
+  commit_batch({pin.p, ptab.p}, {1, 1});
+  const Fr beta = tr.squeeze(), gamma = tr.squeeze_again();
+
+  lap("2_lookup");
+  // -- 3: grand products, random polynomial
+  auto lag_col = [&](uint32_t kind, uint32_t idx) -> void* {
+    return kind == SG_VS_ADVICE ? advice[idx].p : kind == SG_VS_FIXED ? pk.fixed_lag[idx].p : instance_col.p;
+  };
+  const uint32_t perm_kind[6] = {SG_VS_FIXED, SG_VS_ADVICE, SG_VS_ADVICE, SG_VS_FIXED, SG_VS_ADVICE, SG_VS_INSTANCE};
+  const uint32_t perm_idx[6] = {2, 0, 1, 3, 2, 0};
+  std::vector<DevCol> zs;
+  Fr last = Fr::one(), delta_start = Fr::one();
+  for (uint32_t c0 = 0; c0 < NUM_SIGMA; c0 += CHUNK) {
+    const uint32_t m = std::min(CHUNK, NUM_SIGMA - c0);
+    std::vector<void*> vals, sig;
+    for (uint32_t c = c0; c < c0 + m; c++) {
+      vals.push_back(lag_col(perm_kind[c], perm_idx[c]));
+      sig.push_back(pk.sigma_lag[c].p);
+    }
+    zs.emplace_back(n);
+    ck(sg_permutation_product_dev(vals.data(), sig.data(), m, beta.bytes(), gamma.bytes(), delta_start.bytes(), k,
+                                  c0 ? last.bytes() : nullptr, zs.back().p, nullptr), "permutation product");
+    hk(hipMemcpy(last.l, zs.back().at(u), 32, hipMemcpyDeviceToHost), "D2H");
+    rand_rows(zs.back(), u + 1, n - u - 1);
+    delta_start = delta_start * delta.pow(m);
+  }
+  if (last != Fr::one()) throw std::runtime_error("permutation argument not satisfied by the assignment");
+  DevCol lz(n);
+  ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, nullptr), "lookup product");
+  hk(hipMemcpy(last.l, lz.at(u), 32, hipMemcpyDeviceToHost), "D2H");
+  if (last != Fr::one()) throw std::runtime_error("lookup argument not satisfied by the assignment");
+  rand_rows(lz, u + 1, n - u - 1);
+  DevCol random_poly(n);
+  {
+    const std::vector<uint64_t> c = random_coeffs.get();
+    random_poly.upload(c.data(), 0, n);
+    ck(sg_fr_to_montgomery_dev(random_poly.p, random_poly.p, n, nullptr), "to_montgomery");
+  }
+  commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {1, 1, 1, 0});
+  const Fr y = tr.squeeze();
+  std::vector<DevCol> co3, ex3;
+  to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3);
+
+  lap("3_grand_products");
+  // -- 4: quotient
+  DevCol values(ne), input_ext(ne);
+  hk(hipMemsetAsync(values.p, 0, 32 * ne, nullptr), "memset");
+  hk(hipMemsetAsync(input_ext.p, 0, 32 * ne, nullptr), "memset");
+  std::vector<void*> adv_ext_p = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_ext_p = {ex1[3].p};
+  ck(sg_quotient_gates_dev(values.p, &g_gates, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
+                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "gates");
+  std::vector<void*> col_ext, sig_ext, z_ext = {ex3[2].p, ex3[3].p};
+  for (uint32_t c = 0; c < NUM_SIGMA; c++) {
+    col_ext.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
+    sig_ext.push_back(pk.sigma_ext[c].p);
+  }
+  ck(sg_quotient_permutation_dev(values.p, z_ext.data(), 2, col_ext.data(), sig_ext.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p,
+                                 pk.l_last_ext.p, pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, BLINDING + 1,
+                                 nullptr), "permutation quotient");
+  ck(sg_quotient_gates_dev(input_ext.p, &g_in, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
+                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "lookup input (ext)");
+  ck(sg_quotient_lookup_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_ext.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
+                            pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, nullptr), "lookup quotient");
+  ck(sg_divide_by_vanishing_poly_dev(values.p, k, ext_k, nullptr), "divide by vanishing");
+  ck(sg_extended_to_coeff_dev(values.p, k, ext_k, nullptr), "extended_to_coeff");
+  std::vector<void*> pieces;
+  for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces.push_back(values.at(n * i));
+  commit_batch(pieces, std::vector<int>(QUOTIENT_PIECES, 0));
+  const Fr x = tr.squeeze();
+  const uint64_t n_limbs[4] = {n, 0, 0, 0};
+  const Fr x_n = x.pow(n_limbs);
+
+  lap("4_quotient");
+  // -- 5: evaluations
+  std::map<Key, void*> poly;
+  for (uint32_t j = 0; j < NUM_ADVICE; j++) poly[{A_, j}] = co1[j].p;
+  for (uint32_t j = 0; j < NUM_FIXED; j++) poly[{F_, j}] = pk.fixed_coeff[j].p;
+  for (uint32_t j = 0; j < NUM_SIGMA; j++) poly[{SIGMA_, j}] = pk.sigma_coeff[j].p;
+  poly[{PIN_, 0}] = co3[0].p;
+  poly[{PTAB_, 0}] = co3[1].p;
+  poly[{Z_, 0}] = co3[2].p;
+  poly[{Z_, 1}] = co3[3].p;
+  poly[{LZ_, 0}] = co3[4].p;
+  poly[{RANDOM_, 0}] = random_poly.p;
+  auto point = [&](int rot) { return rot >= 0 ? x * omega.pow((uint64_t)rot) : x * omega_inv.pow((uint64_t)(-rot)); };
+  const auto order = eval_order();
+  std::vector<void*> ev_polys;
+  std::vector<Fr> ev_points;
+  for (auto& q : order) {
+    ev_polys.push_back(poly.at(q.key));
+    ev_points.push_back(point(q.rot));
+  }
+  std::vector<Fr> ev(order.size());
+  ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)order.size(), nullptr,
+                               reinterpret_cast<uint8_t*>(ev.data())), "evaluations");
+  std::map<std::pair<Key, int>, Fr> evals;
+  for (size_t i = 0; i < order.size(); i++) {
+    evals[{order[i].key, order[i].rot}] = ev[i];
+    tr.write_scalar(ev[i]);
+  }
+  DevCol h_comb(n);
+  {
+    std::vector<Fr> pw(QUOTIENT_PIECES);
+    pw[0] = Fr::one();
+    for (uint32_t i = 1; i < QUOTIENT_PIECES; i++) pw[i] = pw[i - 1] * x_n;
+    ck(sg_fr_lincomb_dev(pieces.data(), pw[0].bytes(), QUOTIENT_PIECES, n, h_comb.p, nullptr), "h lincomb");
+  }
+  poly[{H_, 0}] = h_comb.p;
+  Fr h_eval;
+  {
+    void* hp[1] = {h_comb.p};
+    ck(sg_fr_eval_poly_batch_dev(hp, n, x.bytes(), 1, nullptr, reinterpret_cast<uint8_t*>(h_eval.l)), "h evaluation");
+  }
+  auto eval_of = [&](const Key& key, int rot) { return key.kind == H_ ? h_eval : evals.at({key, rot}); };
+
+  lap("5_evaluations");
+  // -- 6: SHPLONK
+  const Fr zeta = tr.squeeze(), nu = tr.squeeze_again();
+  const auto sets = rotation_sets();
+  std::vector<DevCol> qs, fs;
+  std::vector<std::vector<Fr>> rs;
+  DevCol r_poly(n), tmp(n);
+  r_poly.zero();
+  for (auto& set : sets) {
+    std::vector<void*> ps;
+    std::vector<Fr> zp(set.polys.size());
+    for (size_t j = 0; j < set.polys.size(); j++) {
+      ps.push_back(poly.at(set.polys[j]));
+      zp[j] = j ? zp[j - 1] * zeta : Fr::one();
+    }
+    qs.emplace_back(n);
+    ck(sg_fr_lincomb_dev(ps.data(), zp[0].bytes(), (uint32_t)ps.size(), n, qs.back().p, nullptr), "set lincomb");
+    std::vector<Fr> pts, vals;
+    for (int r : set.rots) {
+      pts.push_back(point(r));
+      Fr v = Fr::zero();
+      for (size_t j = 0; j < set.polys.size(); j++) v = v + zp[j] * eval_of(set.polys[j], r);
+      vals.push_back(v);
+    }
+    // r(X) through (pts, vals)
+    std::vector<Fr> rc(pts.size(), Fr::zero());
+    for (size_t i = 0; i < pts.size(); i++) {
+      std::vector<Fr> basis = {Fr::one()};
+      Fr denom = Fr::one();
+      for (size_t j = 0; j < pts.size(); j++) {
+        if (j == i) continue;
+        std::vector<Fr> nb(basis.size() + 1, Fr::zero());
+        for (size_t t = 0; t < basis.size(); t++) {
+          nb[t + 1] = nb[t + 1] + basis[t];
+          nb[t] = nb[t] - pts[j] * basis[t];
+        }
+        basis = nb;
+        denom = denom * (pts[i] - pts[j]);
+      }
+      const Fr scale = vals[i] * denom.inv();
+      for (size_t t = 0; t < basis.size(); t++) rc[t] = rc[t] + scale * basis[t];
+    }
+    r_poly.upload(rc.data(), 0, rc.size());
+    fs.emplace_back(n);
+    {
+      void* two[2] = {qs.back().p, r_poly.p};
+      const Fr cf[2] = {Fr::one(), -Fr::one()};
+      ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, nullptr), "q - r");
+    }
+    hk(hipMemsetAsync(r_poly.p, 0, 32 * rc.size(), nullptr), "memset");
+    void *src = fs.back().p, *dst = tmp.p;
+    for (auto& p : pts) {  // exact divisions; kate_division writes n elements (the last one 0)
+      ck(sg_fr_kate_division_dev(src, n, p.bytes(), dst, nullptr, nullptr), "kate division");
+      std::swap(src, dst);
+    }
+    if (src != fs.back().p) hk(hipMemcpyAsync(fs.back().p, src, 32 * n, hipMemcpyDeviceToDevice, nullptr), "D2D");
+    rs.push_back(rc);
+  }
+  DevCol f_all(n);
+  {
+    std::vector<void*> ps;
+    std::vector<Fr> np(fs.size());
+    for (size_t i = 0; i < fs.size(); i++) {
+      ps.push_back(fs[i].p);
+      np[i] = i ? np[i - 1] * nu : Fr::one();
+    }
+    ck(sg_fr_lincomb_dev(ps.data(), np[0].bytes(), (uint32_t)ps.size(), n, f_all.p, nullptr), "f lincomb");
+  }
+  commit_batch({f_all.p}, {0});
+  const Fr mu = tr.squeeze();
+  std::vector<int> all_rots = {ROT_LAST, -1, 0, 1};
+  std::map<int, Fr> mu_minus;
+  for (int r : all_rots) mu_minus[r] = mu - point(r);
+  std::vector<Fr> diffs;
+  for (auto& set : sets) {
+    Fr d = Fr::one();
+    for (int r : all_rots)
+      if (std::find(set.rots.begin(), set.rots.end(), r) == set.rots.end()) d = d * mu_minus[r];
+    diffs.push_back(d);
+  }
+  const Fr d0_inv = diffs[0].inv();
+  Fr z_s0 = Fr::one();
+  for (int r : sets[0].rots) z_s0 = z_s0 * mu_minus[r];
+  std::vector<Fr> coeffs;
+  Fr konst = Fr::zero(), nu_pow = Fr::one();
+  for (size_t i = 0; i < sets.size(); i++) {
+    const Fr scale = nu_pow * diffs[i] * d0_inv;
+    coeffs.push_back(scale);
+    Fr r_at_mu = Fr::zero();
+    for (size_t t = rs[i].size(); t-- > 0;) r_at_mu = r_at_mu * mu + rs[i][t];
+    konst = konst + scale * r_at_mu;
+    nu_pow = nu_pow * nu;
+  }
+  const Fr one = Fr::one();
+  r_poly.upload(one.l, 0, 1);  // the constant polynomial 1
+  std::vector<void*> lp;
+  for (auto& q : qs) lp.push_back(q.p);
+  lp.push_back(f_all.p);
+  lp.push_back(r_poly.p);
+  coeffs.push_back(-z_s0);
+  coeffs.push_back(-konst);
+  DevCol l_poly(n), w2(n);
+  ck(sg_fr_lincomb_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, l_poly.p, nullptr), "L lincomb");
+  Fr rem;
+  ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), nullptr), "final division");
+  if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");
+  commit_batch({w2.p}, {0});
+  lap("6_multiopen");
+  return tr.proof;
+}
+
+}  // namespace prover
+}  // namespace summa

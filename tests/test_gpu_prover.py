@@ -150,3 +150,33 @@ def test_gpu_proof_at_k17(gpu_time_budget=None):
         assert not SV.verify(bytes(p), s["asg"]["instances"], s["vk"])
     finally:
         s["params"].free()
+
+
+@pytest.mark.parametrize("k", [9, 17])
+def test_cpp_prover_proof_is_accepted(k, tmp_path):
+    """include/summa_prover.hpp (the compiled-host create_proof over the C ABI), run as its own process on a bundle
+    exported from the Python proving key: the proof it writes is accepted by the restated verifier"""
+    import json
+    import subprocess
+    from oracle import summa_verifier as SV
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "create_proof_cpp")
+    if not os.path.exists(exe):
+        pytest.skip("tools/create_proof_cpp not built (python __graft_entry__.py)")
+    s = make_setup(k)
+    try:
+        advice = [s["dev"](c) for c in s["asg"]["advice"]]
+        bundle, out = str(tmp_path / "bundle.bin"), str(tmp_path / "proof.bin")
+        s["prover"].export_bundle(bundle, s["params"], s["pk"], advice, s["asg"]["instances"])
+    finally:
+        s["params"].free()
+    r = subprocess.run([exe, bundle, out, "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print(info)
+    proof = open(out, "rb").read()
+    assert len(proof) == 2144 == info["proof_bytes"]
+    assert SV.verify(proof, s["asg"]["instances"], s["vk"])
+    p = bytearray(proof)
+    p[0x3a0] ^= 1
+    assert not SV.verify(bytes(p), s["asg"]["instances"], s["vk"])
