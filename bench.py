@@ -281,7 +281,8 @@ def main():
                     ms17, nbytes = run_create_proof(17, reps=3)
                     cpp17 = {}
                     exe17 = os.path.join(ROOT, "tools", "create_proof_cpp")
-                    if os.path.exists(exe17) and not profiled:   # the same prover as compiled host code (include/summa_prover.hpp), own process
+                    profiled17 = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)
+                    if os.path.exists(exe17) and not profiled17:   # the same prover as compiled host code (include/summa_prover.hpp), own process
                         import subprocess, tempfile
                         from time_create_proof import setup as cp_setup
                         from circuits_halo2_amd import prover as _prover

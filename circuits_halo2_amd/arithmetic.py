@@ -135,6 +135,17 @@ def fr_from_montgomery(mont):
     return out
 
 
+def fr_random(key: bytes, stream_id: int, n: int):
+    """n uniform field elements on the device from ChaCha20(key) (sg_fr_random_dev): blinding values of a proof"""
+    import torch
+    if len(key) != 32:
+        raise ValueError("fr_random: 32-byte key")
+    out = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    ffi.check(ffi.lib().sg_fr_random_dev(ffi.ptr(np.frombuffer(key, dtype=np.uint8).copy()), C.c_uint64(stream_id), ffi.dev_ptr(out),
+                                         C.c_size_t(n), ffi.current_stream_ptr()))
+    return out
+
+
 # ---- SURVEY.md §8f-2: helpers that keep vectors on the device between NTTs and MSMs ---------
 def eval_polynomial(poly, point):
     """halo2_proofs::arithmetic::eval_polynomial: sum_i poly[i] * point^i -> 32-byte Fr"""

@@ -42,6 +42,11 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
 static constexpr uint32_t LINCOMB_MAX = 32;
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
                         hipStream_t stream);
+// n uniform field elements from ChaCha20 (RFC 8439 block function) keyed by `key` (8 LE words): element i takes the
+// first 32 bytes of block (counter = i, nonce = (attempt, stream_lo, stream_hi)), top two bits cleared, and is
+// redrawn with attempt + 1 while >= r (~24 %); the accepted limbs are written as they are (a uniform value in any
+// fixed representation is uniform).  Blinding rows / the random polynomial of a proof, without host traffic.
+hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_words* d_out, hipStream_t stream);
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,
                                 hipStream_t stream);
 }  // namespace sg

@@ -470,4 +470,60 @@ hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, ui
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ ChaCha20-keyed uniform field elements
+struct ChaChaKey {
+  uint32_t w[8];
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+#define SG_QR(a, b, c, d)        \
+  a += b; d ^= a; d = rotl32(d, 16); \
+  c += d; b ^= c; b = rotl32(b, 12); \
+  a += b; d ^= a; d = rotl32(d, 8);  \
+  c += d; b ^= c; b = rotl32(b, 7);
+__global__ void __launch_bounds__(256) fr_random_kernel(ChaChaKey key, uint32_t stream_lo, uint32_t stream_hi, size_t n,
+                                                        fp_words* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // r as 8 LE words
+  const uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  for (uint32_t attempt = 0;; attempt++) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.w[0], key.w[1], key.w[2], key.w[3],
+                       key.w[4],    key.w[5],    key.w[6],    key.w[7],    (uint32_t)i, attempt, stream_lo, stream_hi};
+    uint32_t x[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) x[t] = in[t];
+#pragma unroll 1
+    for (int round = 0; round < 10; round++) {
+      SG_QR(x[0], x[4], x[8], x[12]) SG_QR(x[1], x[5], x[9], x[13]) SG_QR(x[2], x[6], x[10], x[14]) SG_QR(x[3], x[7], x[11], x[15])
+      SG_QR(x[0], x[5], x[10], x[15]) SG_QR(x[1], x[6], x[11], x[12]) SG_QR(x[2], x[7], x[8], x[13]) SG_QR(x[3], x[4], x[9], x[14])
+    }
+    uint32_t c[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) c[t] = x[t] + in[t];
+    c[7] &= 0x3fffffffu;
+    bool lt = false, eq = true;  // c < r ?
+#pragma unroll
+    for (int t = 7; t >= 0; t--) {
+      lt = lt || (eq && c[t] < R[t]);
+      eq = eq && c[t] == R[t];
+    }
+    if (lt) {
+      fp_words w;
+      w.q[0] = make_uint4(c[0], c[1], c[2], c[3]);
+      w.q[1] = make_uint4(c[4], c[5], c[6], c[7]);
+      out[i] = w;
+      return;
+    }
+  }
+}
+#undef SG_QR
+hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_words* d_out, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  if (n >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // the block counter is the element index
+  ChaChaKey k;
+  for (int t = 0; t < 8; t++) k.w[t] = key[t];
+  fr_random_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(k, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), n, d_out);
+  return hipGetLastError();
+}
+
 }  // namespace sg

@@ -970,6 +970,15 @@ int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* strea
   if (e != hipSuccess) return hip_fail("fr_to_montgomery", e);
   return SG_OK;
 }
+int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream) {
+  if (!key || (n && !d_out)) return fail(SG_ERR_INVALID, "sg_fr_random: null argument");
+  LOCKED_CTX();
+  uint32_t k[8];
+  std::memcpy(k, key, 32);
+  hipError_t e = poly_random(k, stream_id, n, static_cast<fp_words*>(d_out), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fr_random", e);
+  return SG_OK;
+}
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream) {
   if (n && (!d_in || !d_out)) return fail(SG_ERR_INVALID, "null argument");
   LOCKED_CTX();

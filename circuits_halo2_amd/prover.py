@@ -6,7 +6,8 @@ reference calls it [REF zk_prover/src/circuits/utils.rs:94-101, 171-178], restri
 system needs (one phase, one lookup, six permutation columns in two chunks, five quotient pieces).  The steps
 and their order follow SURVEY.md §3.1 / Appendix C; the byte layout of the proof is the one the generated verifier
 reads [REF contracts/src/InclusionVerifier.sol:274-367].  What stays on the host is what upstream also does serially
-on the CPU: the transcript, the lookup's sort (`permute_expression_pair`), scalars of the multi-open.
+on the CPU: the transcript, the lookup's sort (`permute_expression_pair`), scalars of the multi-open; blinding
+values come from a per-proof OS-random key expanded by ChaCha20 on the device (`sg_fr_random_dev`).
 
 Inputs are a proving key made from Lagrange-basis fixed and permutation columns and an assignment of the three
 advice columns (rows beyond n - 6 are overwritten with blinding values); key generation for the *reference's own*
@@ -22,7 +23,7 @@ from . import arithmetic as A
 from . import mst_inclusion as M
 from .domain import EvaluationDomain
 from .merkle_sum_tree import keccak256
-from .utils import ints_to_fr, random_fr_secure
+from .utils import ints_to_fr
 
 R = M.R
 Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -186,21 +187,20 @@ def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
     return a, s
 
 
-def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None, timings=None) -> bytes:
+def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None = None, debug=None, timings=None) -> bytes:
     """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
-    `rng(count)` returns `count` uniform field elements as canonical 32-byte little-endian integers (blinding
-    factors, the random polynomial); default: the OS entropy source."""
+    `seed`: 32-byte ChaCha20 key for the blinding factors and the random polynomial (tests); default: the OS
+    entropy source."""
     import torch
-    background = None
-    if rng is None:
-        # the n coefficients of the random polynomial depend on nothing: draw them (4 MiB of OS entropy at k = 17,
-        # rejection-sampled) on a worker thread while the first phases run
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=1)
-        background = pool.submit(random_fr_secure, pk.n)
-        pool.shutdown(wait=False)
-    rng = rng or random_fr_secure
-    rand = lambda count: A.fr_to_montgomery(torch.from_numpy(np.ascontiguousarray(rng(count))).cuda())
+    # blinding values: a 32-byte key from the OS entropy source per proof, expanded by ChaCha20 on the device
+    # (sg_fr_random_dev); every draw takes its own stream id
+    import os
+    key = seed if seed is not None else os.urandom(32)
+    draws = [0]
+
+    def rand(count):
+        draws[0] += 1
+        return A.fr_random(key, draws[0], count)
     import time
     clock = [time.perf_counter()]
 
@@ -274,8 +274,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, rng=None, debug=None
     if _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
         raise ValueError("lookup argument not satisfied by the assignment")
     lz[32 * (u + 1):] = rand(n - u - 1)
-    polys[("random", 0)] = rand(n) if background is None else \
-        A.fr_to_montgomery(torch.from_numpy(background.result()).cuda())
+    polys[("random", 0)] = rand(n)
     for c in params.commit_batch_mixed(zs + [lz, polys[("random", 0)]], [True, True, True, False]):   # one fused job
         tr.write_point(_point(c))
     y = tr.squeeze_challenge()

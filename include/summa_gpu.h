@@ -169,6 +169,11 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange);
 /* ---- helpers: Fr canonical <-> Montgomery (PrimeField::from_repr / to_repr in bulk) */
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
+/* n uniform field elements written to d_out (blinding rows, the random polynomial of create_proof -- upstream draws
+ * them from `OsRng`; here the OS supplies a 32-byte key per proof and ChaCha20, RFC 8439's block function, expands it
+ * on the device): element i = the first 32 bytes of block(key, counter = i, nonce = (attempt, stream_id)) with the top
+ * two bits cleared, redrawn with attempt + 1 while >= r.  Deterministic in (key, stream_id, i). */
+int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream);
 
 /* ---- first "next" row: device-resident helpers between NTTs and MSMs.
  * halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i

@@ -17,7 +17,6 @@
 #include <cstring>
 #include <chrono>
 #include <functional>
-#include <future>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -444,25 +443,13 @@ struct ProvingKey {
   }
 };
 
-// uniform field elements (canonical limbs) from the OS entropy source: 254-bit candidates, rejection-sampled
-inline void random_canonical(uint64_t* out, size_t count) {
-  thread_local FILE* f = std::fopen("/dev/urandom", "rb");   // one handle per thread: a large read must not block the others
-  if (!f) throw std::runtime_error("/dev/urandom");
-  size_t done = 0;
-  std::vector<uint64_t> buf;
-  while (done < count) {
-    const size_t want = (count - done) + (count - done) / 3 + 8;
-    buf.resize(4 * want);
-    if (std::fread(buf.data(), 32, want, f) != want) throw std::runtime_error("short read from /dev/urandom");
-    for (size_t i = 0; i < want && done < count; i++) {
-      uint64_t* c = buf.data() + 4 * i;
-      c[3] &= (1ULL << 62) - 1;
-      if (!Fr::geq_p(c)) {
-        std::memcpy(out + 4 * done, c, 32);
-        done++;
-      }
-    }
+inline void os_random(uint8_t* out, size_t bytes) {
+  FILE* f = std::fopen("/dev/urandom", "rb");
+  if (!f || std::fread(out, 1, bytes, f) != bytes) {
+    if (f) std::fclose(f);
+    throw std::runtime_error("/dev/urandom");
   }
+  std::fclose(f);
 }
 
 inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept
@@ -558,12 +545,6 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     timings->ms[name] += std::chrono::duration<double, std::milli>(now - clock).count();
     clock = now;
   };
-  // the n coefficients of the random polynomial depend on nothing: draw them on a worker thread meanwhile
-  auto random_coeffs = std::async(std::launch::async, [n]() {
-    std::vector<uint64_t> c(4 * n);
-    random_canonical(c.data(), n);
-    return c;
-  });
   const Fr zero = Fr::zero();
   uint8_t omega_inv_b[32], n_inv_b[32], omega_b[32];
   ck(sg_domain_constant(k, 0, omega_b), "domain constant");
@@ -576,11 +557,12 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   EvmTranscript tr(pk.vk_digest_be);
   for (auto& v : instances) tr.common_scalar(v);
 
-  auto rand_rows = [&](DevCol& col, size_t first, size_t count) {  // canonical -> Montgomery on the device
-    std::vector<uint64_t> c(4 * count);
-    random_canonical(c.data(), count);
-    col.upload(c.data(), first, count);
-    ck(sg_fr_to_montgomery_dev(col.at(first), col.at(first), count, nullptr), "to_montgomery");
+  // blinding values: a 32-byte key from the OS per proof, expanded by ChaCha20 on the device; one stream id per draw
+  uint8_t key[32];
+  os_random(key, 32);
+  uint64_t draws = 0;
+  auto rand_rows = [&](DevCol& col, size_t first, size_t count) {
+    ck(sg_fr_random_dev(key, ++draws, col.at(first), count, nullptr), "fr_random");
   };
   auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext) {
     std::vector<void*> pc, pe;
@@ -666,11 +648,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   if (last != Fr::one()) throw std::runtime_error("lookup argument not satisfied by the assignment");
   rand_rows(lz, u + 1, n - u - 1);
   DevCol random_poly(n);
-  {
-    const std::vector<uint64_t> c = random_coeffs.get();
-    random_poly.upload(c.data(), 0, n);
-    ck(sg_fr_to_montgomery_dev(random_poly.p, random_poly.p, n, nullptr), "to_montgomery");
-  }
+  rand_rows(random_poly, 0, n);
   commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {1, 1, 1, 0});
   const Fr y = tr.squeeze();
   std::vector<DevCol> co3, ex3;

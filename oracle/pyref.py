@@ -503,3 +503,39 @@ def g2_to_bytes(p) -> bytes:
     if p is None:
         return bytes(128)
     return b"".join(fq_to_bytes(c) for c in (p[0][0], p[0][1], p[1][0], p[1][1]))
+
+
+# --------------------------------------------------------------------------- ChaCha20 (RFC 8439) and the field-element stream of sg_fr_random_dev
+def chacha20_block(key: bytes, counter: int, nonce: bytes) -> bytes:
+    """RFC 8439 section 2.3: 32-byte key, 32-bit block counter, 12-byte nonce -> 64 bytes"""
+    M = 0xFFFFFFFF
+    rotl = lambda v, c: ((v << c) & M) | (v >> (32 - c))
+    init = list(struct.unpack("<4I", b"expand 32-byte k")) + list(struct.unpack("<8I", key)) + [counter & M] + list(struct.unpack("<3I", nonce))
+    x = list(init)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return struct.pack("<16I", *[(a + b) & M for a, b in zip(x, init)])
+
+
+def chacha_field_elements(key: bytes, stream_id: int, n: int):
+    """the n integers sg_fr_random_dev writes (as raw 32-byte little-endian values, no representation change):
+    element i = first 32 bytes of block(counter = i, nonce = (attempt, stream_lo, stream_hi)), top two bits cleared,
+    redrawn with attempt + 1 while >= r"""
+    out = []
+    for i in range(n):
+        attempt = 0
+        while True:
+            nonce = struct.pack("<3I", attempt, stream_id & 0xFFFFFFFF, stream_id >> 32)
+            v = int.from_bytes(chacha20_block(key, i, nonce)[:32], "little") & ((1 << 254) - 1)
+            if v < R:
+                out.append(v)
+                break
+            attempt += 1
+    return out

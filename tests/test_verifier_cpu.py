@@ -177,3 +177,14 @@ def test_contract_pairing_constants_are_the_srs_files():
     g2, s_g2 = (f2(tail[:64]), f2(tail[64:128])), (f2(tail[128:192]), f2(tail[192:256]))
     assert vk["g2"] == g2
     assert vk["neg_s_g2"] == (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))
+
+
+def test_chacha20_block_matches_rfc8439():
+    """the twin of sg_fr_random_dev's generator: RFC 8439 section 2.3.2 test vector; field elements are < r"""
+    key, nonce = bytes(range(32)), bytes.fromhex("000000090000004a00000000")
+    assert PR.chacha20_block(key, 1, nonce).hex() == (
+        "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+        "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    vals = PR.chacha_field_elements(key, 7, 64)
+    assert all(v < PR.R for v in vals) and len(set(vals)) == 64
+    assert vals != PR.chacha_field_elements(key, 8, 64)
