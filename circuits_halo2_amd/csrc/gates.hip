@@ -19,6 +19,8 @@
 #include "gates.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -423,10 +425,17 @@ hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_va
   const size_t n_ext = (size_t)1 << ext_k;
   // rows per workgroup from the LDS budget: (constants + slots * T) * 36 B <= 144 KiB
   const size_t budget = 144 * 1024, cbytes = (size_t)a.n_consts * 36;
+  // rows per workgroup: the largest shape that fits (measured: for programs of few slots 256 rows beat 64 rows
+  // although the latter keeps one more wave per CU; what limits the interpreter is waves per SIMD, i.e. the slot
+  // count: 7 slots -> 8 waves per CU, 67 % VALU busy; the reference circuit's 17 slots -> 4 waves, 38 %)
   uint32_t T = 256;
   while (T > 64 && cbytes + (size_t)p.n_slots * T * 36 > budget) T >>= 1;
+  const uint32_t best_waves = (uint32_t)(160 * 1024 / (cbytes + (size_t)p.n_slots * T * 36)) * (T / 64);
   const size_t lds = cbytes + (size_t)p.n_slots * T * 36;
   if (lds > budget) return hipErrorInvalidValue;
+  if (std::getenv("SG_GATES_DEBUG"))
+    std::fprintf(stderr, "gates: %zu ops, %u slots, %u constants -> %u rows per workgroup, %u waves per CU by LDS\n", p.ops.size(),
+                 p.n_slots, a.n_consts, T, best_waves);
   const unsigned blocks = (unsigned)((n_ext + T - 1) / T);
   hipError_t e;
   if (T == 256) {
