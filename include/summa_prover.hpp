@@ -564,17 +564,37 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   auto rand_rows = [&](DevCol& col, size_t first, size_t count) {
     ck(sg_fr_random_dev(key, ++draws, col.at(first), count, nullptr), "fr_random");
   };
-  auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext) {
+  // two side streams: independent latency chains (the transforms of a phase under its commitments, the three grand
+  // products, the rotation sets of the multi-open) run next to the main (null) stream; the library keeps its work
+  // space per stream.  fork: the side streams wait for everything enqueued on the main stream; join: the reverse
+  static hipStream_t side[2] = {nullptr, nullptr};
+  static hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  if (!side[0]) {
+    for (auto& st : side) hk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+    hk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "event");
+    for (auto& e : ev_join) hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+  }
+  auto fork = [&]() {
+    hk(hipEventRecord(ev_fork, nullptr), "event");
+    for (auto& st : side) hk(hipStreamWaitEvent(st, ev_fork, 0), "wait");
+  };
+  auto join = [&]() {
+    for (int i = 0; i < 2; i++) {
+      hk(hipEventRecord(ev_join[i], side[i]), "event");
+      hk(hipStreamWaitEvent(nullptr, ev_join[i], 0), "wait");
+    }
+  };
+  auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext, hipStream_t st) {
     std::vector<void*> pc, pe;
     for (void* c : lag) {
       coeff.emplace_back(n);
-      hk(hipMemcpyAsync(coeff.back().p, c, 32 * n, hipMemcpyDeviceToDevice, nullptr), "D2D");
+      hk(hipMemcpyAsync(coeff.back().p, c, 32 * n, hipMemcpyDeviceToDevice, st), "D2D");
       ext.emplace_back(ne);
       pc.push_back(coeff.back().p);
       pe.push_back(ext.back().p);
     }
-    ck(sg_ntt_fr_batch_dev(pc.data(), pc.size(), omega_inv_b, n_inv_b, k, nullptr), "iNTT batch");
-    ck(sg_coeff_to_extended_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, nullptr), "coset NTT batch");
+    ck(sg_ntt_fr_batch_dev(pc.data(), pc.size(), omega_inv_b, n_inv_b, k, st), "iNTT batch");
+    ck(sg_coeff_to_extended_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, st), "coset NTT batch");
   };
   auto commit_batch = [&](std::vector<void*> cols, std::vector<int> basis) {
     std::vector<uint8_t> out(64 * cols.size());
@@ -587,10 +607,11 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   DevCol instance_col(n);
   instance_col.zero();
   if (!instances.empty()) instance_col.upload(instances.data(), 0, instances.size());
+  std::vector<DevCol> co1, ex1;
+  fork();
+  to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);   // under the commitments
   commit_batch({advice[0].p, advice[1].p, advice[2].p}, {1, 1, 1});
   const Fr theta = tr.squeeze();
-  std::vector<DevCol> co1, ex1;
-  to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1);
 
   lap("1_advice");
   // -- 2: lookup
@@ -625,34 +646,47 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   };
   const uint32_t perm_kind[6] = {SG_VS_FIXED, SG_VS_ADVICE, SG_VS_ADVICE, SG_VS_FIXED, SG_VS_ADVICE, SG_VS_INSTANCE};
   const uint32_t perm_idx[6] = {2, 0, 1, 3, 2, 0};
+  // the three grand products are independent up to one scalar (z1 continues from z0's last usable value): z1 is
+  // built from 1 on a side stream and scaled afterwards, the lookup product runs on the other side stream
   std::vector<DevCol> zs;
-  Fr last = Fr::one(), delta_start = Fr::one();
-  for (uint32_t c0 = 0; c0 < NUM_SIGMA; c0 += CHUNK) {
-    const uint32_t m = std::min(CHUNK, NUM_SIGMA - c0);
-    std::vector<void*> vals, sig;
-    for (uint32_t c = c0; c < c0 + m; c++) {
-      vals.push_back(lag_col(perm_kind[c], perm_idx[c]));
-      sig.push_back(pk.sigma_lag[c].p);
-    }
-    zs.emplace_back(n);
-    ck(sg_permutation_product_dev(vals.data(), sig.data(), m, beta.bytes(), gamma.bytes(), delta_start.bytes(), k,
-                                  c0 ? last.bytes() : nullptr, zs.back().p, nullptr), "permutation product");
-    hk(hipMemcpy(last.l, zs.back().at(u), 32, hipMemcpyDeviceToHost), "D2H");
-    rand_rows(zs.back(), u + 1, n - u - 1);
-    delta_start = delta_start * delta.pow(m);
-  }
-  if (last != Fr::one()) throw std::runtime_error("permutation argument not satisfied by the assignment");
+  zs.emplace_back(n);
+  zs.emplace_back(n);
   DevCol lz(n);
-  ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, nullptr), "lookup product");
-  hk(hipMemcpy(last.l, lz.at(u), 32, hipMemcpyDeviceToHost), "D2H");
-  if (last != Fr::one()) throw std::runtime_error("lookup argument not satisfied by the assignment");
+  {
+    std::vector<void*> vals[2], sig[2];
+    for (uint32_t c = 0; c < NUM_SIGMA; c++) {
+      vals[c / CHUNK].push_back(lag_col(perm_kind[c], perm_idx[c]));
+      sig[c / CHUNK].push_back(pk.sigma_lag[c].p);
+    }
+    const Fr delta_chunk = delta.pow((uint64_t)CHUNK);
+    fork();
+    ck(sg_permutation_product_dev(vals[0].data(), sig[0].data(), (uint32_t)vals[0].size(), beta.bytes(), gamma.bytes(),
+                                  Fr::one().bytes(), k, nullptr, zs[0].p, nullptr), "permutation product");
+    ck(sg_permutation_product_dev(vals[1].data(), sig[1].data(), (uint32_t)vals[1].size(), beta.bytes(), gamma.bytes(),
+                                  delta_chunk.bytes(), k, nullptr, zs[1].p, side[0]), "permutation product");
+    ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, side[1]), "lookup product");
+    Fr z0_last, last;
+    hk(hipMemcpyAsync(z0_last.l, zs[0].at(u), 32, hipMemcpyDeviceToHost, nullptr), "D2H");
+    hk(hipStreamSynchronize(nullptr), "sync");   // z0 only; the other two keep running
+    join();
+    void* z1p[1] = {zs[1].p};
+    ck(sg_fr_lincomb_dev(z1p, z0_last.bytes(), 1, n, zs[1].p, nullptr), "z1 *= z0[u]");
+    hk(hipMemcpy(last.l, zs[1].at(u), 32, hipMemcpyDeviceToHost), "D2H");
+    if (last != Fr::one()) throw std::runtime_error("permutation argument not satisfied by the assignment");
+    hk(hipMemcpy(last.l, lz.at(u), 32, hipMemcpyDeviceToHost), "D2H");
+    if (last != Fr::one()) throw std::runtime_error("lookup argument not satisfied by the assignment");
+  }
+  rand_rows(zs[0], u + 1, n - u - 1);
+  rand_rows(zs[1], u + 1, n - u - 1);
   rand_rows(lz, u + 1, n - u - 1);
   DevCol random_poly(n);
   rand_rows(random_poly, 0, n);
+  std::vector<DevCol> co3, ex3;
+  fork();
+  to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
   commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {1, 1, 1, 0});
   const Fr y = tr.squeeze();
-  std::vector<DevCol> co3, ex3;
-  to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3);
+  join();
 
   lap("3_grand_products");
   // -- 4: quotient
@@ -732,9 +766,17 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   const auto sets = rotation_sets();
   std::vector<DevCol> qs, fs;
   std::vector<std::vector<Fr>> rs;
-  DevCol r_poly(n), tmp(n);
-  r_poly.zero();
-  for (auto& set : sets) {
+  std::vector<DevCol> r_polys, tmps;
+  for (size_t i = 0; i < sets.size(); i++) {
+    r_polys.emplace_back(n);
+    r_polys.back().zero();
+    tmps.emplace_back(n);
+  }
+  fork();
+  for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
+    const auto& set = sets[si];
+    hipStream_t st = si % 3 == 0 ? nullptr : side[si % 3 - 1];
+    DevCol &r_poly = r_polys[si], &tmp = tmps[si];
     std::vector<void*> ps;
     std::vector<Fr> zp(set.polys.size());
     for (size_t j = 0; j < set.polys.size(); j++) {
@@ -742,7 +784,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
       zp[j] = j ? zp[j - 1] * zeta : Fr::one();
     }
     qs.emplace_back(n);
-    ck(sg_fr_lincomb_dev(ps.data(), zp[0].bytes(), (uint32_t)ps.size(), n, qs.back().p, nullptr), "set lincomb");
+    ck(sg_fr_lincomb_dev(ps.data(), zp[0].bytes(), (uint32_t)ps.size(), n, qs.back().p, st), "set lincomb");
     std::vector<Fr> pts, vals;
     for (int r : set.rots) {
       pts.push_back(point(r));
@@ -768,22 +810,23 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
       const Fr scale = vals[i] * denom.inv();
       for (size_t t = 0; t < basis.size(); t++) rc[t] = rc[t] + scale * basis[t];
     }
-    r_poly.upload(rc.data(), 0, rc.size());
+    hk(hipMemcpyAsync(r_poly.p, rc.data(), 32 * rc.size(), hipMemcpyHostToDevice, st), "H2D");
+    hk(hipStreamSynchronize(st), "sync");   // rc is a local: the copy must have left the host buffer
     fs.emplace_back(n);
     {
       void* two[2] = {qs.back().p, r_poly.p};
       const Fr cf[2] = {Fr::one(), -Fr::one()};
-      ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, nullptr), "q - r");
+      ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, st), "q - r");
     }
-    hk(hipMemsetAsync(r_poly.p, 0, 32 * rc.size(), nullptr), "memset");
     void *src = fs.back().p, *dst = tmp.p;
     for (auto& p : pts) {  // exact divisions; kate_division writes n elements (the last one 0)
-      ck(sg_fr_kate_division_dev(src, n, p.bytes(), dst, nullptr, nullptr), "kate division");
+      ck(sg_fr_kate_division_dev(src, n, p.bytes(), dst, nullptr, st), "kate division");
       std::swap(src, dst);
     }
-    if (src != fs.back().p) hk(hipMemcpyAsync(fs.back().p, src, 32 * n, hipMemcpyDeviceToDevice, nullptr), "D2D");
+    if (src != fs.back().p) hk(hipMemcpyAsync(fs.back().p, src, 32 * n, hipMemcpyDeviceToDevice, st), "D2D");
     rs.push_back(rc);
   }
+  join();
   DevCol f_all(n);
   {
     std::vector<void*> ps;
@@ -820,6 +863,8 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     nu_pow = nu_pow * nu;
   }
   const Fr one = Fr::one();
+  DevCol& r_poly = r_polys[0];
+  hk(hipMemsetAsync(r_poly.p, 0, 32 * 4, nullptr), "memset");
   r_poly.upload(one.l, 0, 1);  // the constant polynomial 1
   std::vector<void*> lp;
   for (auto& q : qs) lp.push_back(q.p);
