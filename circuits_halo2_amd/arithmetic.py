@@ -135,6 +135,23 @@ def fr_from_montgomery(mont):
     return out
 
 
+def lookup_permute_small(inp, table, rows: int):
+    """halo2's permute_expression_pair on the device for range tables (all table values < 2^16): returns the
+    permuted input / table columns over `rows` usable rows (device tensors), or None when the table is outside
+    that range (sort on the host instead); raises ValueError when an input value is not in the table"""
+    import torch
+    a = torch.empty(32 * rows, dtype=torch.uint8, device="cuda")
+    s = torch.empty(32 * rows, dtype=torch.uint8, device="cuda")
+    rc = ffi.lib().sg_lookup_permute_small_dev(ffi.dev_ptr(inp), ffi.dev_ptr(table), C.c_size_t(rows), ffi.dev_ptr(a), ffi.dev_ptr(s),
+                                               ffi.current_stream_ptr())
+    if rc == -5:
+        return None
+    if rc == -1:
+        raise ValueError("lookup input value not in the table")
+    ffi.check(rc)
+    return a, s
+
+
 def fr_random(key: bytes, stream_id: int, n: int):
     """n uniform field elements on the device from ChaCha20(key) (sg_fr_random_dev): blinding values of a proof"""
     import torch

@@ -42,6 +42,16 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
 static constexpr uint32_t LINCOMB_MAX = 32;
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
                         hipStream_t stream);
+// halo2 lookup::prover::permute_expression_pair for range tables (every table value < 2^16), on the device:
+// A' = the input rows sorted, S' = the table rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1]
+// (first occurrences take their value from the table, the leftover table values fill the repeated rows in
+// increasing order).  d_work: LOOKUP_PERMUTE_WORK u32.  d_flag (u32, device): 0 ok, 1 an input value that is
+// not in the table, 2 a table value >= 2^16 (the caller takes the general path; wins over 1).
+static constexpr uint32_t LOOKUP_BINS = 1u << 16;
+static constexpr size_t LOOKUP_PERMUTE_WORK = 6 * (size_t)LOOKUP_BINS + 16;
+hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_table, size_t rows, uint32_t* d_work,
+                                     fp_words* d_permuted_input, fp_words* d_permuted_table, uint32_t* d_flag,
+                                     hipStream_t stream);
 // n uniform field elements from ChaCha20 (RFC 8439 block function) keyed by `key` (8 LE words): element i takes the
 // first 32 bytes of block (counter = i, nonce = (attempt, stream_lo, stream_hi)), top two bits cleared, and is
 // redrawn with attempt + 1 while >= r (~24 %); the accepted limbs are written as they are (a uniform value in any

@@ -526,4 +526,118 @@ hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_w
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ lookup permutation for range tables
+// work layout (u32): hist_a[B] | hist_t[B] | pre_a[B] | pre_rep[B] | pre_left[B] | left[B]
+__device__ __forceinline__ bool small_canonical(const fp_words* p, uint32_t* v) {
+  f29 k = f29_zero();
+  k.l[0] = 32;  // canonical = x~ * 2^5 * 2^-261
+  uint32_t w[8];
+  f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(p), k)), w);
+  *v = w[0];
+  return !(w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) && w[0] < LOOKUP_BINS;
+}
+__global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __restrict__ input, const fp_words* __restrict__ table,
+                                                           size_t rows, uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  uint32_t a, t;
+  if (!small_canonical(table + i, &t)) {
+    atomicMax(flag, 2u);
+    return;
+  }
+  atomicAdd(&work[LOOKUP_BINS + t], 1u);
+  if (!small_canonical(input + i, &a)) {
+    atomicMax(flag, 1u);
+    return;
+  }
+  atomicAdd(&work[a], 1u);
+}
+// one workgroup: three exclusive prefix sums over the bins (input counts, repeated rows, leftover table values)
+__global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
+  __shared__ uint32_t s_sum[3][1024];
+  constexpr uint32_t PER = LOOKUP_BINS / 1024;
+  const uint32_t tid = threadIdx.x;
+  uint32_t* hist_a = work;
+  uint32_t* hist_t = work + LOOKUP_BINS;
+  uint32_t* pre[3] = {work + 2 * LOOKUP_BINS, work + 3 * LOOKUP_BINS, work + 4 * LOOKUP_BINS};
+  uint32_t* left = work + 5 * LOOKUP_BINS;
+  uint32_t tot[3] = {0, 0, 0};
+  bool missing = false;
+  for (uint32_t j = 0; j < PER; j++) {
+    const uint32_t v = tid * PER + j, ca = hist_a[v], ct = hist_t[v];
+    const uint32_t used = ca ? 1u : 0u;
+    missing = missing || ct < used;
+    tot[0] += ca;
+    tot[1] += ca - used;
+    tot[2] += ct - min(ct, used);
+  }
+  if (missing) atomicMax(flag, 1u);
+  for (int q = 0; q < 3; q++) s_sum[q][tid] = tot[q];
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t add[3] = {0, 0, 0};
+    if (tid >= d)
+      for (int q = 0; q < 3; q++) add[q] = s_sum[q][tid - d];
+    __syncthreads();
+    for (int q = 0; q < 3; q++) s_sum[q][tid] += add[q];
+    __syncthreads();
+  }
+  uint32_t run[3];
+  for (int q = 0; q < 3; q++) run[q] = s_sum[q][tid] - tot[q];
+  for (uint32_t j = 0; j < PER; j++) {
+    const uint32_t v = tid * PER + j, ca = hist_a[v], ct = hist_t[v];
+    const uint32_t used = ca ? 1u : 0u, lf = ct - min(ct, used);
+    pre[0][v] = run[0];
+    pre[1][v] = run[1];
+    pre[2][v] = run[2];
+    left[v] = lf;
+    run[0] += ca;
+    run[1] += ca - used;
+    run[2] += lf;
+  }
+}
+// largest v with pre[v] <= x among the bins that own at least one element (count[v] > 0 and pre[v] <= x < pre[v] + count[v])
+__device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, const uint32_t* __restrict__ count, uint32_t x) {
+  uint32_t lo = 0, hi = LOOKUP_BINS - 1;
+  while (lo < hi) {   // last v with pre[v] <= x
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (pre[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  while (count[lo] == 0 && lo > 0) lo--;   // empty bins share their prefix with the owner before them
+  return lo;
+}
+__global__ void __launch_bounds__(256) lookup_permute_write(size_t rows, const uint32_t* __restrict__ work,
+                                                            fp_words* __restrict__ out_a, fp_words* __restrict__ out_s) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const uint32_t* hist_a = work;
+  const uint32_t *pre_a = work + 2 * LOOKUP_BINS, *pre_rep = work + 3 * LOOKUP_BINS, *pre_left = work + 4 * LOOKUP_BINS,
+                 *left = work + 5 * LOOKUP_BINS;
+  const uint32_t v = bin_of(pre_a, hist_a, (uint32_t)i);
+  uint32_t s = v;
+  const uint32_t within = (uint32_t)i - pre_a[v];
+  if (within) s = bin_of(pre_left, left, pre_rep[v] + within - 1);
+  fp_words w;   // canonical small integers; the caller converts both columns to Montgomery form
+  w.q[0] = make_uint4(v, 0, 0, 0);
+  w.q[1] = make_uint4(0, 0, 0, 0);
+  out_a[i] = w;
+  w.q[0].x = s;
+  out_s[i] = w;
+}
+hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_table, size_t rows, uint32_t* d_work,
+                                     fp_words* d_permuted_input, fp_words* d_permuted_table, uint32_t* d_flag,
+                                     hipStream_t stream) {
+  if (!rows) return hipSuccess;
+  if (rows >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(d_work, 0, 2 * (size_t)LOOKUP_BINS * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  lookup_permute_hist<<<blocks, 256, 0, stream>>>(d_input, d_table, rows, d_work, d_flag);
+  lookup_permute_scan<<<1, 1024, 0, stream>>>(d_work, d_flag);
+  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_permuted_input, d_permuted_table);
+  return hipGetLastError();
+}
+
 }  // namespace sg

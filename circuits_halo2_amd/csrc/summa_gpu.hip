@@ -970,6 +970,29 @@ int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* strea
   if (e != hipSuccess) return hip_fail("fr_to_montgomery", e);
   return SG_OK;
 }
+int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                void* d_permuted_table, void* stream) {
+  if (rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table)) return fail(SG_ERR_INVALID, "sg_lookup_permute: null argument");
+  if (rows == 0) return SG_OK;
+  LOCKED_CTX();
+  hipStream_t s = pick_stream(stream);
+  uint8_t* wb = nullptr;
+  hipError_t e = scratch_for(s, 4, (LOOKUP_PERMUTE_WORK + 16) * sizeof(uint32_t), &wb);
+  if (e != hipSuccess) return hip_fail("lookup permutation work space", e);
+  uint32_t* work = reinterpret_cast<uint32_t*>(wb);
+  uint32_t* flag = work + LOOKUP_PERMUTE_WORK;
+  fp_words *pa = static_cast<fp_words*>(d_permuted_input), *ps = static_cast<fp_words*>(d_permuted_table);
+  e = poly_lookup_permute_small(static_cast<const fp_words*>(d_input), static_cast<const fp_words*>(d_table), rows, work, pa, ps, flag, s);
+  if (e == hipSuccess) e = fr_montgomery(pa, pa, rows, 1, s);
+  if (e == hipSuccess) e = fr_montgomery(ps, ps, rows, 1, s);
+  uint32_t h_flag = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag, sizeof h_flag, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail("lookup permutation", e);
+  if (h_flag == 2) return fail(SG_ERR_UNSUPPORTED, "sg_lookup_permute_small: a table value is not below 2^16 (use the general path)");
+  if (h_flag == 1) return fail(SG_ERR_INVALID, "sg_lookup_permute_small: an input value is not in the table");
+  return SG_OK;
+}
 int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream) {
   if (!key || (n && !d_out)) return fail(SG_ERR_INVALID, "sg_fr_random: null argument");
   LOCKED_CTX();

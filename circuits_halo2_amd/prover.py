@@ -245,9 +245,13 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     inp_d = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
     A.quotient_gates(inp_d, M.lookup_input_graph(), pk.fixed_lagrange, advice, [instance_col], none,
                      _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), k, k)   # the expression row by row (stride 1)
-    pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
-    pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
-                     for rows in (pin_rows, ptab_rows))                              # blinding rows random
+    on_device = A.lookup_permute_small(inp_d, pk.fixed_lagrange[4], u)   # range tables: no host round trip
+    if on_device is not None:
+        pin_d, ptab_d = (torch.cat([col, rand(n - u)]) for col in on_device)             # blinding rows random
+    else:
+        pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
+        pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
+                         for rows in (pin_rows, ptab_rows))
     for p in commit_lagrange([pin_d, ptab_d]):
         tr.write_point(p)
     beta = tr.squeeze_challenge()

@@ -44,7 +44,8 @@ typedef enum {
   SG_ERR_INVALID = -1,   /* bad argument (null pointer, size/length mismatch, k out of range) */
   SG_ERR_NO_DEVICE = -2, /* no usable HIP device / sg_init not called */
   SG_ERR_HIP = -3,       /* a HIP runtime call failed; see sg_last_error() */
-  SG_ERR_NOMEM = -4      /* device or host allocation failed */
+  SG_ERR_NOMEM = -4,     /* device or host allocation failed */
+  SG_ERR_UNSUPPORTED = -5 /* the inputs are outside what this entry point handles; a general path exists */
 } sg_status;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -169,6 +170,13 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange);
 /* ---- helpers: Fr canonical <-> Montgomery (PrimeField::from_repr / to_repr in bulk) */
 int sg_fr_to_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
 int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* stream);
+/* halo2 lookup::prover::permute_expression_pair (§3.1 step 4) for range tables, on the device: rows = the usable
+ * rows; A' (d_permuted_input) = the input rows in increasing order, S' (d_permuted_table) = the table rows
+ * rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1].  Handles tables whose values are all below
+ * 2^16 (SG_ERR_UNSUPPORTED otherwise: sort on the host as upstream does); SG_ERR_INVALID if an input value is not
+ * in the table.  Synchronises the stream (the status is known on return). */
+int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                void* d_permuted_table, void* stream);
 /* n uniform field elements written to d_out (blinding rows, the random polynomial of create_proof -- upstream draws
  * them from `OsRng`; here the OS supplies a 32-byte key per proof and ChaCha20, RFC 8439's block function, expands it
  * on the device): element i = the first 32 bytes of block(key, counter = i, nonce = (attempt, stream_id)) with the top

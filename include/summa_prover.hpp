@@ -623,17 +623,24 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   inp.zero();
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
                            zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, nullptr), "lookup input");
-  DevCol canon(n);
-  uint64_t* stage = pinned_rows(3 * n);   // page-locked staging: the three 32 n-byte transfers run at link speed
-  uint64_t *h_inp = stage, *h_a = stage + 4 * n, *h_s = stage + 8 * n;
-  ck(sg_fr_from_montgomery_dev(inp.p, canon.p, n, nullptr), "from_montgomery");
-  hk(hipMemcpy(h_inp, canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
-  permute_expression_pair(h_inp, pk.table_rows.data(), u, h_a, h_s);
   DevCol pin(n), ptab(n);
-  pin.upload(h_a, 0, u);
-  ptab.upload(h_s, 0, u);
-  ck(sg_fr_to_montgomery_dev(pin.p, pin.p, u, nullptr), "to_montgomery");
-  ck(sg_fr_to_montgomery_dev(ptab.p, ptab.p, u, nullptr), "to_montgomery");
+  const int prc = sg_lookup_permute_small_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, nullptr);   // range tables: on the device
+  if (prc == SG_ERR_UNSUPPORTED) {   // general tables: sort on the host, as upstream does
+    DevCol canon(n);
+    uint64_t* stage = pinned_rows(3 * n);   // page-locked staging: the three 32 n-byte transfers run at link speed
+    uint64_t *h_inp = stage, *h_a = stage + 4 * n, *h_s = stage + 8 * n;
+    ck(sg_fr_from_montgomery_dev(inp.p, canon.p, n, nullptr), "from_montgomery");
+    hk(hipMemcpy(h_inp, canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
+    permute_expression_pair(h_inp, pk.table_rows.data(), u, h_a, h_s);
+    pin.upload(h_a, 0, u);
+    ptab.upload(h_s, 0, u);
+    ck(sg_fr_to_montgomery_dev(pin.p, pin.p, u, nullptr), "to_montgomery");
+    ck(sg_fr_to_montgomery_dev(ptab.p, ptab.p, u, nullptr), "to_montgomery");
+  } else if (prc == SG_ERR_INVALID) {
+    throw std::runtime_error("lookup input value not in the table");
+  } else {
+    ck(prc, "lookup permutation");
+  }
   rand_rows(pin, u, n - u);
   rand_rows(ptab, u, n - u);
   commit_batch({pin.p, ptab.p}, {1, 1});

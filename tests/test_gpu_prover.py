@@ -197,3 +197,36 @@ def test_fr_random_matches_the_chacha20_twin():
         assert mk(None) != mk(None)
     finally:
         s["params"].free()
+
+
+@pytest.mark.parametrize("rows,top,seed", [(500, 256, 1), (4090, 65536, 2), (131066, 256, 3), (7, 3, 4)])
+def test_lookup_permute_on_device(rows, top, seed):
+    """sg_lookup_permute_small_dev == the host permutation (prover.permute_expression_pair, itself checked on the CPU
+    against the defining properties): A' sorted, S' a rearrangement with A'[i] == S'[i] or A'[i] == A'[i-1]"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi
+    from circuits_halo2_amd.prover import permute_expression_pair
+    ffi.check(ffi.lib().sg_init(0))
+    rng = np.random.default_rng(seed)
+    table = np.zeros((rows, 4), dtype=np.uint64)
+    m = min(rows, top)
+    table[:m, 0] = rng.permutation(top)[:m] if top <= rows * 4 else rng.integers(0, top, m)
+    inp = table[rng.integers(0, m, rows)]
+    if rows > 100:
+        inp[rng.integers(0, rows, rows // 2)] = table[0]          # long runs of one value
+    dev = lambda limbs: A.fr_to_montgomery(torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).cuda())
+    want_a, want_s = permute_expression_pair(inp, table)
+    got = A.lookup_permute_small(dev(inp), dev(table), rows)
+    canon = lambda t: A.fr_from_montgomery(t).cpu().numpy().view(np.uint64).reshape(-1, 4)
+    assert (canon(got[0]) == want_a).all() and (canon(got[1]) == want_s).all()
+    # an input value outside the table; a table outside the range this entry point handles
+    bad = inp.copy()
+    bad[rows // 2, 0] = int(table[:, 0].max()) + 1
+    if bad[rows // 2, 0] < 65536:
+        with pytest.raises(ValueError):
+            A.lookup_permute_small(dev(bad), dev(table), rows)
+    big = table.copy()
+    big[0, 0] = 70000
+    assert A.lookup_permute_small(dev(inp), dev(big), rows) is None
+    big[0] = [5, 1, 0, 0]
+    assert A.lookup_permute_small(dev(inp), dev(big), rows) is None

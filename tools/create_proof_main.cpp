@@ -65,6 +65,10 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int reps = argc > 3 ? std::atoi(argv[3]) : 5;
+  // the prover issues independent chains on side streams; with HIP's default of 4 hardware queues they end up sharing
+  // a queue with the main stream (measured: the phase-1 transforms serialised with the commitments) -- ask for more
+  // before the runtime initialises
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   try {
     ck(sg_init(0), "sg_init");
     Reader rd(argv[1]);
