@@ -545,12 +545,23 @@ __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __res
     atomicMax(flag, 2u);
     return;
   }
-  atomicAdd(&work[LOOKUP_BINS + t], 1u);
+  // most rows of a range check hold the same value (unused rows: 0): lanes that agree with the first active lane
+  // are counted with one atomic per wave
+  auto count = [&](uint32_t* bins, uint32_t v) {
+    const uint32_t lead = __builtin_amdgcn_readfirstlane(v);
+    const uint64_t same = __ballot(v == lead);
+    if (v == lead) {
+      if ((uint32_t)__lane_id() == (uint32_t)__ffsll((long long)same) - 1) atomicAdd(&bins[lead], (uint32_t)__popcll(same));
+    } else {
+      atomicAdd(&bins[v], 1u);
+    }
+  };
+  count(work + LOOKUP_BINS, t);
   if (!small_canonical(input + i, &a)) {
     atomicMax(flag, 1u);
     return;
   }
-  atomicAdd(&work[a], 1u);
+  count(work, a);
 }
 // one workgroup: three exclusive prefix sums over the bins (input counts, repeated rows, leftover table values)
 __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
