@@ -154,12 +154,34 @@ def lookup_expressions():
     return Expr.query(A.FIXED, 5, 0) * (a0 - a0n * 256), Expr.query(A.FIXED, 4, 0)
 
 
+# The two Poseidon chips share columns, so gates 0-4 and 7-11 share their expensive subexpressions (the s-boxes, the
+# partial-round sums).  Folded strictly in order, those values stay live across gates 5-6 and the program needs 17
+# LDS slots per row (4 waves per CU, 38 % VALU busy on MI355X).  The same polynomial
+#     values * y^19 + sum_i G_i y^(18 - i)
+# is therefore evaluated as  ((Horner(values; G0..G6) * y^5 + Horner(G7; G8..G11)) folded on with G12..G18,  with the
+# second chip's block lowered first and y^5 supplied as challenge 0 (gate_challenges): one more product per row, the
+# shared values die after twelve gates.
+GATE_BLOCKS = ((0, 7), (7, 12), (12, 19))
+
+
+def gate_challenges(y: int):
+    """the `challenges` array the gate program expects: [y^5]"""
+    from .utils import ints_to_fr
+    return ints_to_fr([pow(y, GATE_BLOCKS[1][1] - GATE_BLOCKS[1][0], R)])
+
+
 @lru_cache(maxsize=None)
 def gate_graph() -> A.GraphEvaluator:
-    """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y)"""
+    """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y), see GATE_BLOCKS"""
     g = A.GraphEvaluator()
     parts = [e.lower(g) for e in gates()]
-    g.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), (A.Y, 0, 0), parts)
+    y = (A.Y, 0, 0)
+    (a0, a1), (b0, b1), (c0, c1) = GATE_BLOCKS
+    second = g.add_calculation(A.HORNER, parts[b0], y, parts[b0 + 1:b1])
+    first = g.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), y, parts[a0:a1])
+    shifted = g.add_calculation(A.MUL, first, (A.CHALLENGE, 0, 0))
+    joined = g.add_calculation(A.ADD, second, shifted)          # operand order = lowering order: second chip first
+    g.add_calculation(A.HORNER, joined, y, parts[c0:c1])
     return g
 
 

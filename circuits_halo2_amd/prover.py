@@ -290,7 +290,8 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     lap("3_grand_products")
     # -- 4: quotient: evaluate_h over the extended coset, / (X^n - 1), back to coefficients, five pieces
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(values, M.gate_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta, b_gamma, b_theta, b_y, k, ext_k)
+    A.quotient_gates(values, M.gate_graph(), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k,
+                     ext_k)
     col_ext = {(A.ADVICE, j): adv_ext[j] for j in range(3)}
     col_ext.update({(A.FIXED, j): pk.fixed_ext[j] for j in range(M.NUM_FIXED)})
     col_ext[(A.INSTANCE, 0)] = inst_ext

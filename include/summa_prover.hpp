@@ -701,8 +701,10 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   hk(hipMemsetAsync(values.p, 0, 32 * ne, nullptr), "memset");
   hk(hipMemsetAsync(input_ext.p, 0, 32 * ne, nullptr), "memset");
   std::vector<void*> adv_ext_p = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_ext_p = {ex1[3].p};
+  // the gate program folds its second block with y^5 supplied as challenge 0 (mst_inclusion.py: GATE_BLOCKS)
+  const Fr y5 = y.pow((uint64_t)5);
   ck(sg_quotient_gates_dev(values.p, &g_gates, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
-                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "gates");
+                           y5.bytes(), 1, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "gates");
   std::vector<void*> col_ext, sig_ext, z_ext = {ex3[2].p, ex3[3].p};
   for (uint32_t c = 0; c < NUM_SIGMA; c++) {
     col_ext.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);

@@ -127,8 +127,21 @@ def test_product_constraint_system_equals_the_restatement():
     assert max(e.degree() for e in M.gates()) == M.DEGREE
     assert [("f" if k == A.FIXED else "a" if k == A.ADVICE else "i", c) for k, c in M.PERMUTATION_COLUMNS] == SV.PERMUTATION_COLUMNS
     g = M.gate_graph()
-    assert g.calculations[-1][0] == A.HORNER and len(g.calculations[-1][3]) == 19
+    horners = [c for c in g.calculations if c[0] == A.HORNER]
+    assert g.calculations[-1][0] == A.HORNER and sum(len(c[3]) for c in horners) + 1 == 19   # one gate starts a block
     assert sorted(g.rotations) == [-1, 0, 1]
+    # the blocked fold is the plain one: values * y^19 + sum_i G_i y^(18 - i), checked with integers
+    y, prev = 0x1234567, 0x7654321
+    parts = [e.evaluate(q) for e in M.gates()]
+    plain = prev
+    for t in parts:
+        plain = (plain * y + t) % PR.R
+    (a0, a1), (b0, b1), (c0, c1) = M.GATE_BLOCKS
+    fold = lambda start, ps: (lambda acc: [acc := (acc * y + t) % PR.R for t in ps][-1] if ps else acc)(start)
+    first, second = fold(prev, parts[a0:a1]), fold(parts[b0], parts[b0 + 1:b1])
+    y5 = PR.fr_from_bytes(bytes(M.gate_challenges(y)))
+    assert y5 == pow(y, 5, PR.R)
+    assert fold((second + first * y5) % PR.R, parts[c0:c1]) == plain
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/contracts/src/InclusionVerifier.sol"),
