@@ -1,6 +1,6 @@
 """known-answer check of a large MSM: bases s_i * G, result must be <k, s> * G (oracle for the scalar side)"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import circuits_halo2_amd as sg
 from circuits_halo2_amd import ffi

@@ -1,10 +1,10 @@
-// CPU check of bn254_curve29.cuh (driven by tools/test_curve29.py).
+// CPU check of bn254_curve29.cuh (driven by tests/checks/limb_curve29_check.py).
 // input: lines "madd <16 hex words> <neg>" | "reset" | "swap" (acc <-> other) | "addother" | "double" | "dump"
 #include <cstdio>
 #include <iostream>
 #include <sstream>
 #include <string>
-#include "../circuits_halo2_amd/csrc/bn254_curve29.cuh"
+#include "../../circuits_halo2_amd/csrc/bn254_curve29.cuh"
 using namespace sg;
 int main() {
   xyzz29 acc = xyzz29_identity(), other = xyzz29_identity();

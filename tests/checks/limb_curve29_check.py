@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 import os, random, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyref as P
-exe = "/tmp/test_curve29"
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools/test_curve29.cpp")])
+exe = "/tmp/limb_curve29_check"
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_curve29_check.cpp")])
 rnd = random.Random(7)
 def words(pt):
     b = P.g1_to_bytes(pt)

@@ -1,11 +1,11 @@
 // CPU check of circuits_halo2_amd/csrc/bn254_f29.cuh against big integers (driven by
-// tools/test_f29.py): reads "op field a b" lines, a/b as 9 hex limbs each, prints the result limbs.
+// tests/checks/limb_f29_check.py): reads "op field a b" lines, a/b as 9 hex limbs each, prints the result limbs.
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <iostream>
 #include <sstream>
-#include "../circuits_halo2_amd/csrc/bn254_f29.cuh"
+#include "../../circuits_halo2_amd/csrc/bn254_f29.cuh"
 using namespace sg;
 template <class P> void run(const std::string& op, const f29& a, const f29& b) {
   f29 r = f29_zero();

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Checks bn254_f29.cuh (compiled for the host) against Python integers."""
 import os, random, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyref as P
 M = (1 << 29) - 1
-exe = "/tmp/test_f29"
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools/test_f29.cpp")])
+exe = "/tmp/limb_f29_check"
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_f29_check.cpp")])
 def limbs(x): return [(x >> (29 * i)) & M if i < 8 else x >> (29 * i) for i in range(9)]
 def val(l): return sum(v << (29 * i) for i, v in enumerate(l))
 def lazy(x, rnd):

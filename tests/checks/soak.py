@@ -1,7 +1,7 @@
 """randomised soak of the MSM paths against the oracle: sizes, batch shapes, fixed / generic, skewed scalars,
 parameter toggles; stops after SECONDS (default 120).  Exit code 1 on the first mismatch."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import numpy as np, torch
 import circuits_halo2_amd as sg

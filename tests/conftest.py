@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+collect_ignore_glob = ["checks/*"]   # stand-alone checkers (driven by test_limb29_cpu.py / run by hand on the GPU box)
 
 
 def pytest_configure(config):

@@ -10,14 +10,14 @@ from conftest import ROOT
 
 
 def _run(script):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "bad 0" in r.stdout
 
 
 def test_field_limbs_vs_bigints():
-    _run("test_f29.py")
+    _run("limb_f29_check.py")
 
 
 def test_curve_limbs_vs_bigints():
-    _run("test_curve29.py")
+    _run("limb_curve29_check.py")
