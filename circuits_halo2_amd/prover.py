@@ -211,6 +211,12 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
             timings[name] = timings.get(name, 0.0) + (now - clock[0]) * 1e3
             clock[0] = now
     k, n, u, dom = pk.k, pk.n, pk.usable_rows, pk.dom
+    if len(advice) != M.NUM_ADVICE or any(a.numel() != 32 * n for a in advice):
+        raise ValueError(f"create_proof: {M.NUM_ADVICE} advice columns of 2^k rows expected")
+    if len(instances) > u or any(not 0 <= v < R for v in instances):
+        raise ValueError("create_proof: instances are field elements on usable rows")
+    if seed is not None and len(seed) != 32:
+        raise ValueError("create_proof: the seed is a 32-byte key")
     ext_k = dom.extended_k
     ne = 1 << ext_k
     omega = pow(ROOT_OF_UNITY, 1 << (28 - k), R)

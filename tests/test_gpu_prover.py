@@ -93,6 +93,13 @@ def test_gpu_prover_unsatisfied_assignments(setup, what):
     else:
         with pytest.raises(ValueError):
             s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], seeded_rng(7))
+    # malformed calls are refused before anything is enqueued
+    for bad in (lambda: s["prover"].create_proof(s["params"], s["pk"], advice[:2], s["asg"]["instances"]),
+                lambda: s["prover"].create_proof(s["params"], s["pk"], [advice[0][:64]] * 3, s["asg"]["instances"]),
+                lambda: s["prover"].create_proof(s["params"], s["pk"], advice, [1 << 255]),
+                lambda: s["prover"].create_proof(s["params"], s["pk"], advice, s["asg"]["instances"], b"short")):
+        with pytest.raises(ValueError):
+            bad()
 
 
 def test_gpu_proof_under_the_reference_srs_and_contract_constants():
