@@ -296,3 +296,181 @@ def example_assignment(k: int):
             sigma[c][i] = label(c2, i2)
     return {"fixed": fixed, "advice": adv, "instances": instances, "sigma": sigma, "usable_rows": u,
             "poseidon_in": poseidon_in, "poseidon_out": poseidon_out}
+
+
+class _Layout:
+    """a small region allocator over the constraint system's columns: Poseidon hashes on either chip, swap / sum /
+    range-check regions, copy constraints -- enough to assign a Merkle-sum-tree inclusion witness (assign_inclusion)"""
+
+    def __init__(self, k: int):
+        self.k, self.n = k, 1 << k
+        self.u = self.n - (BLINDING_FACTORS + 1)
+        self.fixed = [[0] * self.n for _ in range(NUM_FIXED)]
+        self.adv = [[0] * self.n for _ in range(NUM_ADVICE)]
+        self.inst = []
+        self.row = 0
+        self.const_row = self.u - 1          # constants live in f2 from the top of the usable rows downwards
+        self.consts = {}
+        self.copies = []
+        self.rcs, self.mds, _ = _poseidon()
+        for i in range(256):
+            self.fixed[4][i] = i
+
+    def constant(self, v: int):
+        if v not in self.consts:
+            self.fixed[2][self.const_row] = v
+            self.consts[v] = ((FIXED, 2), self.const_row)
+            self.const_row -= 1
+        return self.consts[v]
+
+    def copy(self, a, b):
+        self.copies.append((a, b))
+
+    def _mix(self, s):
+        m = self.mds
+        return [(m[i][0] * s[0] + m[i][1] * s[1]) % R for i in range(2)]
+
+    def _full(self, row, state, rc, sel):
+        self.fixed[sel][row] = 1
+        self.fixed[0][row], self.fixed[1][row] = rc
+        self.adv[0][row], self.adv[1][row] = state
+        return self._mix([pow((state[j] + rc[j]) % R, 5, R) for j in range(2)])
+
+    def _partial(self, row, state, rc_a, rc_b, sel):
+        self.fixed[sel][row] = 1
+        self.fixed[0][row], self.fixed[1][row] = rc_a
+        self.fixed[2][row], self.fixed[3][row] = rc_b
+        self.adv[0][row], self.adv[1][row] = state
+        self.adv[2][row] = pow((state[0] + rc_a[0]) % R, 5, R)
+        mid = self._mix([self.adv[2][row], (state[1] + rc_a[1]) % R])
+        return self._mix([pow((mid[0] + rc_b[0]) % R, 5, R), (mid[1] + rc_b[1]) % R])
+
+    def hash(self, chip: int, inputs):
+        """Poseidon(t = 2, rate 1) of `inputs` = [(value, source cell or None)]: initial state [0, L * 2^64] from
+        constants, one pad-and-add row + 36 round rows per input; returns (digest, its cell)"""
+        s_full, s_partial, pad = (7, 8, 3) if chip == 1 else (9, 10, 4)
+        r = self.row
+        state = [0, (len(inputs) << 64) % R]
+        self.adv[0][r], self.adv[1][r] = state
+        self.copy(((ADVICE, 0), r), self.constant(0))
+        self.copy(((ADVICE, 1), r), self.constant(state[1]))
+        for value, src in inputs:
+            self.adv[0][r + 1] = value % R
+            self.fixed[6][r + 1] = pad
+            if src is not None:
+                self.copy(((ADVICE, 0), r + 1), src)
+            state = [(state[0] + value) % R, state[1]]
+            row = r + 2
+            for j in range(4):
+                state = self._full(row, state, self.rcs[j], s_full)
+                row += 1
+            for j in range(28):
+                state = self._partial(row, state, self.rcs[4 + 2 * j], self.rcs[5 + 2 * j], s_partial)
+                row += 1
+            for j in range(60, 64):
+                state = self._full(row, state, self.rcs[j], s_full)
+                row += 1
+            self.adv[0][row], self.adv[1][row] = state
+            r = row
+        self.row = r + 2
+        return state[0], ((ADVICE, 0), r)
+
+    def range_check(self, value: int, n_bytes: int = 8):
+        """value < 2^(8 n_bytes) by a running decomposition a0[i+1] = (a0[i] - byte) / 2^8, each byte looked up"""
+        t = self.row
+        v = value
+        for i in range(n_bytes):
+            self.adv[0][t + i] = v
+            self.fixed[5][t + i] = 1
+            v >>= 8
+        if v:
+            raise ValueError("balance out of range")
+        self.adv[0][t + n_bytes] = 0
+        self.copy(((ADVICE, 0), t + n_bytes), self.constant(0))
+        self.row = t + n_bytes + 2
+        return ((ADVICE, 0), t)
+
+    def swap(self, cur, cur_cell, sibling, bit: int):
+        t = self.row
+        self.adv[0][t], self.adv[1][t], self.adv[2][t] = cur, sibling, bit
+        self.fixed[6][t] = 1
+        self.copy(((ADVICE, 0), t), cur_cell)
+        left, right = (sibling, cur) if bit else (cur, sibling)
+        self.adv[0][t + 1], self.adv[1][t + 1] = left, right
+        self.row = t + 3
+        return (left, ((ADVICE, 0), t + 1)), (right, ((ADVICE, 1), t + 1))
+
+    def add(self, a, a_cell, b, b_cell):
+        t = self.row
+        self.adv[0][t], self.adv[1][t], self.adv[2][t] = a, b, (a + b) % R
+        self.fixed[6][t] = 2
+        self.copy(((ADVICE, 0), t), a_cell)
+        self.copy(((ADVICE, 1), t), b_cell)
+        self.row = t + 2
+        return (a + b) % R, ((ADVICE, 2), t)
+
+    def expose(self, value, cell):
+        self.copy(cell, ((INSTANCE, 0), len(self.inst)))
+        self.inst.append(value)
+
+    def finish(self):
+        from .prover import DELTA, ROOT_OF_UNITY
+        if self.row > self.const_row:
+            raise ValueError("the assignment does not fit 2^k rows")
+        n = self.n
+        inst_col = self.inst + [0] * (n - len(self.inst))
+        cells = {(ADVICE, j): self.adv[j] for j in range(NUM_ADVICE)}
+        cells.update({(FIXED, 2): self.fixed[2], (FIXED, 3): self.fixed[3], (INSTANCE, 0): inst_col})
+        omega = pow(ROOT_OF_UNITY, 1 << (28 - self.k), R)
+        identity = []
+        for c in range(len(PERMUTATION_COLUMNS)):
+            col, v = [], pow(DELTA, c, R)
+            for _ in range(n):
+                col.append(v)
+                v = v * omega % R
+            identity.append(col)
+        # union the copy constraints into classes, one cycle per class
+        parent = {}
+
+        def find(x):
+            while parent.setdefault(x, x) != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for a, b in self.copies:
+            if cells[a[0]][a[1]] != cells[b[0]][b[1]]:
+                raise AssertionError((a, b))
+            parent[find(a)] = find(b)
+        classes = {}
+        for x in list(parent):
+            classes.setdefault(find(x), []).append(x)
+        sigma = [list(col) for col in identity]
+        for members in classes.values():
+            idx = [(PERMUTATION_COLUMNS.index(col), row) for col, row in members]
+            for (c, i), (c2, i2) in zip(idx, idx[1:] + idx[:1]):
+                sigma[c][i] = identity[c2][i2]
+        return {"fixed": self.fixed, "advice": self.adv, "instances": list(self.inst), "sigma": sigma, "usable_rows": self.u,
+                "rows_used": self.row, "copies": len(self.copies)}
+
+
+def assign_inclusion(k: int, username: int, balances, siblings, path_bits):
+    """Witness of "this entry is a leaf of the Merkle sum tree with that root" over this constraint system, with the
+    public inputs of the reference circuit [REF zk_prover/src/circuits/merkle_sum_tree.rs:40-60, 198-330: leaf hash,
+    root hash, root balances]: leaf = H(username, balances..) on the first Poseidon chip, per level a range check of
+    the sibling's balances, the swap by the path bit, the per-currency sums and the middle node
+    H(sums.., left, right) on the second chip.  siblings: [(hash, [balances])] bottom-up; integers throughout.
+    The floor plan is this repository's (see example_assignment); the relations enforced are the circuit's."""
+    lay = _Layout(k)
+    bal_cells = [lay.range_check(b) for b in balances]
+    cur_hash, cur_cell = lay.hash(1, [(username, None)] + list(zip(balances, bal_cells)))
+    lay.expose(cur_hash, cur_cell)
+    cur_bal = list(zip(balances, bal_cells))
+    for (sib_hash, sib_bal), bit in zip(siblings, path_bits):
+        sib_cells = [lay.range_check(b) for b in sib_bal]
+        (left, left_cell), (right, right_cell) = lay.swap(cur_hash, cur_cell, sib_hash, bit)
+        cur_bal = [lay.add(a, a_cell, b, b_cell) for (a, a_cell), b, b_cell in zip(cur_bal, sib_bal, sib_cells)]
+        cur_hash, cur_cell = lay.hash(2, cur_bal + [(left, left_cell), (right, right_cell)])
+    lay.expose(cur_hash, cur_cell)
+    for v, cell in cur_bal:
+        lay.expose(v, cell)
+    return lay.finish()

@@ -201,3 +201,34 @@ def test_chacha20_block_matches_rfc8439():
     vals = PR.chacha_field_elements(key, 7, 64)
     assert all(v < PR.R for v in vals) and len(set(vals)) == 64
     assert vals != PR.chacha_field_elements(key, 8, 64)
+
+
+@pytest.mark.parametrize("index", [0, 5, 15])
+def test_inclusion_assignment_reproduces_the_reference_public_inputs(index):
+    """mst_inclusion.assign_inclusion on the reference's csv/entry_16.csv (tree from the oracle's Poseidon): the
+    witness satisfies every gate and lookup of the restated constraint system, its copy constraints hold, and the
+    public inputs are the leaf hash, the root hash and the root balances -- for user 0 the reference's own expected
+    values (K5: zk_prover/src/circuits/tests.rs:341,346)"""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mst_assignment as MA
+    from circuits_halo2_amd import mst_inclusion as M
+    rows = list(csv.reader(open(os.path.join(GOLD, "entry_16.csv"))))[1:]
+    entries = [PR.mst_entry(r[0], [int(r[1]), int(r[2])]) for r in rows]
+    root, levels = PR.mst_build(entries)
+    siblings, bits, i = [], [], index
+    for level in range(4):
+        siblings.append(levels[level][i ^ 1])
+        bits.append(i & 1)
+        i >>= 1
+    asg = M.assign_inclusion(11, entries[index][0], entries[index][1], siblings, bits)
+    assert MA.check_gates(asg, 11)
+    assert asg["instances"] == [levels[0][index][0], root[0]] + root[1]
+    if index == 0:
+        k5 = json.load(open(os.path.join(GOLD, "kat.json")))["k5"]
+        assert asg["instances"] == [int(k5["leaf0"], 16), int(k5["root"], 16)] + k5["root_balances"]
+    assert asg["rows_used"] < asg["usable_rows"] and asg["copies"] > 50
+    # every copy class really is a cycle of sigma: following sigma from a constrained cell returns to it
+    with pytest.raises(ValueError):
+        M.assign_inclusion(11, entries[index][0], [1 << 64, 5], siblings, bits)     # a balance beyond N_BYTES = 8
