@@ -306,6 +306,17 @@ def main():
                                                         "in its own process, best of 8; tests/test_gpu_prover.py verifies such proofs with the restated verifier"}
                 except Exception as ex:
                     line["create_proof_k17"] = {"error": repr(ex)}
+                # the reference criterion bench's shape (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13): tree of
+                # 2^20 users on the device, inclusion witness of one user, key generation, proof (tools/full_flow.py)
+                try:
+                    from full_flow import run as run_full_flow
+                    torch.cuda.empty_cache()
+                    line["full_flow_levels20_k13"] = dict(run_full_flow(20, 13, cpp=not profiled17),
+                                                          note="2^20-user Merkle sum tree (2 currencies) on the device, inclusion witness over the "
+                                                               "reference circuit's constraint system (host, Python integers), proving-key construction "
+                                                               "from Lagrange columns, create_proof (Python driver / C++ driver)")
+                except Exception as ex:
+                    line["full_flow_levels20_k13"] = {"error": repr(ex)}
             except Exception as ex:
                 line["extras_error"] = repr(ex)
 

@@ -300,3 +300,31 @@ def test_inclusion_proof_of_the_reference_csv_and_srs(tmp_path):
             assert SV.verify(open(out, "rb").read(), asg["instances"], vk)
     finally:
         params.free()
+
+
+def test_inclusion_proof_levels20_k13():
+    """the reference bench's shape (LEVELS = 20, k = 13): a 2^20-user Merkle sum tree on the device, the inclusion
+    witness of one user (3633 rows), proof, verification; the public inputs are the device tree's leaf and root"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi
+    from circuits_halo2_amd.utils import ints_to_fr
+    from oracle import pyref as PR
+    from oracle import summa_verifier as SV
+    import full_flow
+    import mst_assignment as MA
+    ffi.check(ffi.lib().sg_init(0))
+    k = 13
+    asg = full_flow.build(20, k)
+    assert MA.check_gates(asg, k)
+    params = sg.ParamsKZG.setup(k, ints_to_fr([0xABCDEF0123456789]))
+    try:
+        pk, advice, proof = full_flow.keygen_and_prove(asg, k, params, reps=1)
+        f2 = lambda b: (PR.fq_from_bytes(b[:32]), PR.fq_from_bytes(b[32:64]))
+        s_g2 = (f2(params.s_g2[:64]), f2(params.s_g2[64:]))
+        vk = {"k": k, "vk_digest": pk.vk_digest, "fixed_comms": pk.fixed_comms, "permutation_comms": pk.permutation_comms,
+              "g2": PR.G2_GENERATOR, "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
+        assert SV.verify(proof, asg["instances"], vk)
+        assert not SV.verify(proof, asg["instances"][:1] + [asg["instances"][1] ^ 1] + asg["instances"][2:], vk)
+    finally:
+        params.free()

@@ -229,6 +229,5 @@ def test_inclusion_assignment_reproduces_the_reference_public_inputs(index):
         k5 = json.load(open(os.path.join(GOLD, "kat.json")))["k5"]
         assert asg["instances"] == [int(k5["leaf0"], 16), int(k5["root"], 16)] + k5["root_balances"]
     assert asg["rows_used"] < asg["usable_rows"] and asg["copies"] > 50
-    # every copy class really is a cycle of sigma: following sigma from a constrained cell returns to it
     with pytest.raises(ValueError):
         M.assign_inclusion(11, entries[index][0], [1 << 64, 5], siblings, bits)     # a balance beyond N_BYTES = 8

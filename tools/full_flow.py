@@ -1,0 +1,92 @@
+"""The shape of the reference's criterion bench (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13): a
+Merkle sum tree of 2^LEVELS synthetic users on the device, an inclusion witness for one user over the reference
+circuit's constraint system (N_CURRENCIES = 2), key generation from the Lagrange columns, create_proof.
+`build(levels, k)` returns everything a caller needs (tests/test_gpu_prover.py verifies the proof); run as a script
+it prints the timings."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np, torch
+import circuits_halo2_amd as sg
+from circuits_halo2_amd import ffi, prover, arithmetic as A, mst_inclusion as M
+from circuits_halo2_amd.utils import ints_to_fr, random_fr_canonical
+
+R = M.R
+
+
+def build(levels=20, k=13, user=123457, nc=2, timings=None):
+    t = {} if timings is None else timings
+    size = 1 << levels
+    d_users = A.fr_random(bytes(range(32)), 1, size)                       # usernames: any field elements
+    bal = random_fr_canonical(77, size * nc).reshape(-1, 32).copy()
+    bal[:, 5:] = 0                                                         # 40-bit balances: sums stay below 2^64 (N_BYTES = 8)
+    d_bals = A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda())
+    nodes = 2 * size - 1
+    d_h = torch.empty(32 * nodes, dtype=torch.uint8, device="cuda")
+    d_b = torch.empty(32 * nodes * nc, dtype=torch.uint8, device="cuda")
+    run_build = lambda: ffi.check(ffi.lib().sg_mst_build_dev(ffi.dev_ptr(d_users), ffi.dev_ptr(d_bals), C.c_uint32(levels), C.c_uint32(nc),
+                                                             ffi.dev_ptr(d_h), ffi.dev_ptr(d_b), ffi.current_stream_ptr()))
+    run_build(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run_build(); torch.cuda.synchronize()
+    t["mst_build_ms"] = (time.perf_counter() - t0) * 1e3
+    # the user's path: sibling (hash, balances) per level, bottom-up (level-major node arrays)
+    t0 = time.perf_counter()
+    rinv = pow(1 << 256, -1, R)
+    toi = lambda tens: [int.from_bytes(bytes(row), "little") * rinv % R for row in tens.cpu().numpy().reshape(-1, 32)]
+    off, idx, siblings, bits = 0, user, [], []
+    for level in range(levels):
+        s = off + (idx ^ 1)
+        siblings.append((toi(d_h[32 * s:32 * s + 32])[0], toi(d_b[32 * s * nc:32 * (s + 1) * nc])))
+        bits.append(idx & 1)
+        off += size >> level
+        idx >>= 1
+    username = toi(d_users[32 * user:32 * user + 32])[0]
+    balances = toi(d_bals[32 * user * nc:32 * (user + 1) * nc])
+    root = (toi(d_h[32 * (nodes - 1):])[0], toi(d_b[32 * (nodes - 1) * nc:]))
+    leaf = toi(d_h[32 * user:32 * user + 32])[0]
+    asg = M.assign_inclusion(k, username, balances, siblings, bits)
+    t["witness_assignment_host_ms"] = (time.perf_counter() - t0) * 1e3
+    assert asg["instances"] == [leaf, root[0]] + root[1], "the assignment's public inputs are the device tree's leaf / root"
+    return asg
+
+
+def keygen_and_prove(asg, k, params, reps=3, timings=None):
+    t = {} if timings is None else timings
+    dev = lambda v: torch.from_numpy(ints_to_fr(v)).cuda()
+    fixed, sigma, advice = [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]], [dev(c) for c in asg["advice"]]
+    pk = prover.ProvingKey(params, k, fixed, sigma)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pk = prover.ProvingKey(params, k, fixed, sigma)
+    t["keygen_ms"] = (time.perf_counter() - t0) * 1e3
+    proof = prover.create_proof(params, pk, advice, asg["instances"])
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        proof = prover.create_proof(params, pk, advice, asg["instances"])
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    t["create_proof_ms"] = best
+    return pk, advice, proof
+
+
+def run(levels=20, k=13, cpp=True):
+    import json, subprocess, tempfile
+    t = {}
+    asg = build(levels, k, timings=t)
+    params = sg.ParamsKZG.setup(k, ints_to_fr([0x1D0C0FFEE1234567890ABCDEF]))
+    params.precompute()
+    pk, advice, proof = keygen_and_prove(asg, k, params, timings=t)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "create_proof_cpp")
+    if cpp and os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as td:
+            prover.export_bundle(os.path.join(td, "b.bin"), params, pk, advice, asg["instances"])
+            r = subprocess.run([exe, os.path.join(td, "b.bin"), os.path.join(td, "p.bin"), "8"], capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                t["create_proof_ms_cpp_driver"] = json.loads(r.stdout.strip().splitlines()[-1])["create_proof_ms"]
+    params.free()
+    t.update({"levels": levels, "k": k, "n_currencies": 2, "rows_used": asg["rows_used"]})
+    return t
+
+
+if __name__ == "__main__":
+    ffi.check(ffi.lib().sg_init(0))
+    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 13))
