@@ -474,3 +474,237 @@ def assign_inclusion(k: int, username: int, balances, siblings, path_bits):
     for v, cell in cur_bal:
         lay.expose(v, cell)
     return lay.finish()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference circuit's OWN floor plan.  `MstInclusionCircuit::synthesize` [REF zk_prover/src/circuits/merkle_sum_tree.rs:
+# 225-519] calls its chips in a fixed order; halo2's SimpleFloorPlanner (upstream: halo2_proofs circuit/floor_planner/
+# single_pass.rs) starts every region at the first row where none of the region's columns (advice, fixed, selectors) is in
+# use, and assigns a region's constants to the constants column (fixed column 2 here, `enable_constant`, :160) right after
+# the region, at that column's next free row.  Region shapes: the reference's own chips [REF chips/merkle_sum_tree.rs:104-
+# 226 (swap: 2 rows, sum: 1 row), chips/range/range_check.rs:93-153 (N_BYTES + 1 rows, the final running sum constrained to
+# the constant 0), circuits/traits.rs:21-52 (single witness cells; the 256-row table)] and halo2_gadgets' Pow5Chip / sponge
+# (upstream, restated from its published source: "initial state" 1 row with two constants, per absorbed word "add input"
+# 3 rows with the pad-and-add selector on the middle one and "permute state" 37 rows: state, 4 full rounds, 28 rows of two
+# partial rounds, 4 full rounds).  Copy constraints are replayed in call order through halo2's permutation assembly
+# (upstream permutation/keygen.rs: cycles merged smaller-into-larger, then the two mapping entries swapped).
+# PINNED: with these rules the 11 fixed-column and 6 permutation commitments of the reference's verifying key
+# [REF contracts/src/InclusionVerifier.sol:238-271] come out bit for bit (tests/test_verifier_cpu.py).
+class _PermutationAssembly:
+    def __init__(self, n: int, columns: int):
+        self.mapping = [[(i, j) for j in range(n)] for i in range(columns)]
+        self.aux = [[(i, j) for j in range(n)] for i in range(columns)]
+        self.sizes = [[1] * n for _ in range(columns)]
+
+    def copy(self, left, right):
+        left_cycle, right_cycle = self.aux[left[0]][left[1]], self.aux[right[0]][right[1]]
+        if left_cycle == right_cycle:
+            return
+        if self.sizes[left_cycle[0]][left_cycle[1]] < self.sizes[right_cycle[0]][right_cycle[1]]:
+            left_cycle, right_cycle = right_cycle, left_cycle
+        self.sizes[left_cycle[0]][left_cycle[1]] += self.sizes[right_cycle[0]][right_cycle[1]]
+        i = right_cycle
+        while True:
+            self.aux[i[0]][i[1]] = left_cycle
+            i = self.mapping[i[0]][i[1]]
+            if i == right_cycle:
+                break
+        (self.mapping[left[0]][left[1]], self.mapping[right[0]][right[1]]) = (self.mapping[right[0]][right[1]],
+                                                                              self.mapping[left[0]][left[1]])
+
+
+class _ReferenceFloorPlan:
+    """cells are (column key, row) with the keys of PERMUTATION_COLUMNS; values are tracked next to the layout"""
+
+    def __init__(self, k: int):
+        self.k, self.n = k, 1 << k
+        self.next_free = {}
+        self.fixed = [[0] * self.n for _ in range(NUM_FIXED)]
+        self.adv = [[0] * self.n for _ in range(NUM_ADVICE)]
+        self.instances = {}
+        self.asm = _PermutationAssembly(self.n, len(PERMUTATION_COLUMNS))
+        self.rcs, self.mds, _ = _poseidon()
+
+    # -- floor planner
+    def region(self, columns, rows: int) -> int:
+        start = max([self.next_free.get(c, 0) for c in columns] + [0])
+        for c in columns:
+            self.next_free[c] = start + rows
+        if start + rows > self.n - (BLINDING_FACTORS + 1):
+            raise ValueError("the circuit does not fit 2^k rows")
+        return start
+
+    def copy(self, left, right):
+        for cell in (left, right):
+            pass
+        lv, rv = self.value(left), self.value(right)
+        if lv != rv:
+            raise AssertionError(("copy constraint between unequal cells", left, right))
+        self.asm.copy((PERMUTATION_COLUMNS.index(left[0]), left[1]), (PERMUTATION_COLUMNS.index(right[0]), right[1]))
+
+    def value(self, cell):
+        (kind, idx), row = cell
+        if kind == ADVICE:
+            return self.adv[idx][row]
+        if kind == FIXED:
+            return self.fixed[idx][row]
+        return self.instances.get(row, 0)
+
+    def constants(self, items):
+        col = (FIXED, 2)
+        for v, cell in items:
+            row = self.next_free.get(col, 0)
+            self.next_free[col] = row + 1
+            self.fixed[2][row] = v % R
+            self.copy((col, row), cell)
+
+    def set(self, cell, v):
+        (kind, idx), row = cell
+        self.adv[idx][row] = v % R
+        return cell
+
+    # -- chips
+    def witness(self, column: int, v: int):
+        return self.set(((ADVICE, column), self.region([(ADVICE, column)], 1)), v)
+
+    def hash(self, chip: int, inputs):
+        s_full, s_partial, pad = (7, 8, 3) if chip == 1 else (9, 10, 4)
+        a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
+        st = self.region([a0, a1], 1)
+        vals = [0, (len(inputs) << 64) % R]
+        state = [self.set((a0, st), vals[0]), self.set((a1, st), vals[1])]
+        self.constants([(vals[0], state[0]), (vals[1], state[1])])
+        mix = lambda s: [(self.mds[i][0] * s[0] + self.mds[i][1] * s[1]) % R for i in range(2)]
+        for cell in inputs:
+            st = self.region([a0, a1, ("selector", "pad", chip)], 3)
+            self.fixed[6][st + 1] = pad
+            self.set((a0, st), vals[0]); self.set((a1, st), vals[1])
+            self.copy((a0, st), state[0])
+            self.copy((a1, st), state[1])
+            self.set((a0, st + 1), self.value(cell))
+            self.copy((a0, st + 1), cell)
+            vals = [(vals[0] + self.value(cell)) % R, vals[1]]
+            state = [self.set((a0, st + 2), vals[0]), self.set((a1, st + 2), vals[1])]
+            st = self.region([a0, a1, a2] + [(FIXED, j) for j in range(4)] + [("selector", "full", chip), ("selector", "partial", chip)], 37)
+            self.set((a0, st), vals[0]); self.set((a1, st), vals[1])
+            self.copy((a0, st), state[0])
+            self.copy((a1, st), state[1])
+            row = st
+            for half in (range(0, 4), None, range(60, 64)):
+                if half is None:
+                    for j in range(28):
+                        rc_a, rc_b = self.rcs[4 + 2 * j], self.rcs[5 + 2 * j]
+                        self.fixed[s_partial][row] = 1
+                        self.fixed[0][row], self.fixed[1][row] = rc_a
+                        self.fixed[2][row], self.fixed[3][row] = rc_b
+                        sbox = pow((vals[0] + rc_a[0]) % R, 5, R)
+                        self.adv[2][row] = sbox
+                        mid = mix([sbox, (vals[1] + rc_a[1]) % R])
+                        vals = mix([pow((mid[0] + rc_b[0]) % R, 5, R), (mid[1] + rc_b[1]) % R])
+                        row += 1
+                        self.adv[0][row], self.adv[1][row] = vals
+                else:
+                    for r in half:
+                        self.fixed[s_full][row] = 1
+                        self.fixed[0][row], self.fixed[1][row] = self.rcs[r]
+                        vals = mix([pow((vals[j] + self.rcs[r][j]) % R, 5, R) for j in range(2)])
+                        row += 1
+                        self.adv[0][row], self.adv[1][row] = vals
+            state = [(a0, st + 36), (a1, st + 36)]
+        return state[0]
+
+    def range_check(self, cell, n_bytes: int):
+        a0 = (ADVICE, 0)
+        st = self.region([a0, ("selector", "lookup")], n_bytes + 1)
+        v = self.value(cell)
+        for i in range(n_bytes):
+            self.fixed[5][st + i] = 1
+            self.adv[0][st + i] = v
+            v >>= 8
+        if v:
+            raise ValueError("balance out of range")
+        self.adv[0][st + n_bytes] = 0
+        self.copy((a0, st), cell)
+        self.constants([(0, (a0, st + n_bytes))])
+
+    def swap(self, cur, sibling, bit):
+        a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
+        st = self.region([a0, a1, a2, ("selector", "swap")], 2)
+        self.fixed[6][st] = 1
+        for col, cell in ((a0, cur), (a1, sibling), (a2, bit)):
+            self.set((col, st), self.value(cell))
+            self.copy((col, st), cell)
+        l, r = self.value(cur), self.value(sibling)
+        if self.value(bit):
+            l, r = r, l
+        return self.set((a0, st + 1), l), self.set((a1, st + 1), r)
+
+    def add(self, cur, sibling):
+        a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
+        st = self.region([a0, a1, a2, ("selector", "sum")], 1)
+        self.fixed[6][st] = 2
+        for col, cell in ((a0, cur), (a1, sibling)):
+            self.set((col, st), self.value(cell))
+            self.copy((col, st), cell)
+        return self.set((a2, st), self.value(cur) + self.value(sibling))
+
+    def expose(self, cell, row: int):
+        self.instances[row] = self.value(cell)
+        self.copy(cell, ((INSTANCE, 0), row))
+
+    def finish(self):
+        from .prover import DELTA, ROOT_OF_UNITY
+        omega = pow(ROOT_OF_UNITY, 1 << (28 - self.k), R)
+        labels = []
+        for c in range(len(PERMUTATION_COLUMNS)):
+            col, v = [], pow(DELTA, c, R)
+            for _ in range(self.n):
+                col.append(v)
+                v = v * omega % R
+            labels.append(col)
+        sigma = [[labels[m[0]][m[1]] for m in col] for col in self.asm.mapping]
+        inst = [self.instances[i] for i in range(len(self.instances))]
+        return {"fixed": self.fixed, "advice": self.adv, "instances": inst, "sigma": sigma,
+                "usable_rows": self.n - (BLINDING_FACTORS + 1), "rows_used": max(self.next_free.values())}
+
+
+def reference_assignment(k: int, username: int, balances, path_bits, sibling_leaf_preimage, sibling_middle_preimages,
+                         n_bytes: int = 8):
+    """`MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>::synthesize` replayed over the reference's own floor plan
+    (see above): fixed columns, permutation and advice assignment exactly as halo2's keygen / prover would hold them.
+    Inputs as in the reference's MerkleProof [REF merkle_sum_tree/tree.rs, circuits/merkle_sum_tree.rs:30-60]:
+    sibling_leaf_preimage = [username, balances..], sibling_middle_preimages[level - 1] = [balances.., left hash,
+    right hash]; integers.  Empty inputs (zeros) give the key-generation view (`init_empty`)."""
+    fp = _ReferenceFloorPlan(k)
+    nc = len(balances)
+    user = fp.witness(0, username)
+    cur_bal = [fp.witness(1, b) for b in balances]
+    cur_hash = fp.hash(1, [user] + cur_bal)
+    fp.expose(cur_hash, 0)
+    st = fp.region([(FIXED, 4)], 256)
+    for i in range(256):
+        fp.fixed[4][st + i] = i
+    for level, bit_value in enumerate(path_bits):
+        if level == 0:
+            sib_user = fp.witness(0, sibling_leaf_preimage[0])
+            sib_bal = [fp.witness(1, b) for b in sibling_leaf_preimage[1:1 + nc]]
+            sib_hash = fp.hash(1, [sib_user] + sib_bal)
+            for c in range(nc):
+                fp.range_check(cur_bal[c], n_bytes)
+                fp.range_check(sib_bal[c], n_bytes)
+        else:
+            pre = sibling_middle_preimages[level - 1]
+            sib_bal = [fp.witness(1, b) for b in pre[:nc]]
+            left = fp.witness(2, pre[nc])
+            right = fp.witness(2, pre[nc + 1])
+            sib_hash = fp.hash(2, sib_bal + [left, right])
+            for c in range(nc):
+                fp.range_check(sib_bal[c], n_bytes)
+        bit = fp.witness(0, bit_value)
+        left, right = fp.swap(cur_hash, sib_hash, bit)
+        cur_bal = [fp.add(cur_bal[c], sib_bal[c]) for c in range(nc)]
+        cur_hash = fp.hash(2, cur_bal + [left, right])
+    fp.expose(cur_hash, 1)
+    for c, cell in enumerate(cur_bal):
+        fp.expose(cell, 2 + c)
+    return fp.finish()

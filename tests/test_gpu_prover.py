@@ -328,3 +328,55 @@ def test_inclusion_proof_levels20_k13():
         assert not SV.verify(proof, asg["instances"][:1] + [asg["instances"][1] ^ 1] + asg["instances"][2:], vk)
     finally:
         params.free()
+
+
+def test_reference_floor_plan_proof_under_the_reference_verifying_key():
+    """The reference circuit's OWN layout (mst_inclusion.reference_assignment: halo2's floor planner and permutation
+    assembly replayed over the reference's synthesize), csv/entry_16.csv user 0, the reference's SRS: key generation on
+    the GPU reproduces the reference's verifying key -- all 11 fixed and 6 permutation commitments of
+    contracts/src/InclusionVerifier.sol:238-271 --, and a proof made here with the contract's vk digest is accepted by
+    the restated verifier running on the REFERENCE'S verifying key (tests/golden/k6_verifier_trace.json), with the
+    reference's expected public inputs (K5).  The proof is also written to gpurun_out/ so that the reference's
+    contract itself can be run on it (tests/test_verifier_cpu.py, where the reference checkout exists)."""
+    import json
+    import torch
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi, prover
+    from circuits_halo2_amd import mst_inclusion as M
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from circuits_halo2_amd.utils import ints_to_fr
+    from oracle import pyref as PR
+    from oracle import summa_verifier as SV
+    ffi.check(ffi.lib().sg_init(0))
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    tree = MerkleSumTree.from_csv(os.path.join(gold, "entry_16.csv"), 2)
+    mp = tree.generate_proof(0)
+    toi = lambda b: PR.fr_from_bytes(bytes(b))
+    ints = lambda b: [toi(b[i:i + 32]) for i in range(0, len(b), 32)]
+    name, bal = mp["entry"]
+    username = int.from_bytes(PR.keccak256(name.encode()), "big") % PR.R
+    asg = M.reference_assignment(11, username, [int(x) for x in bal], mp["path_indices"], ints(mp["sibling_leaf_node_hash_preimage"]),
+                                 [ints(p) for p in mp["sibling_middle_node_hash_preimages"]])
+    trace = json.load(open(os.path.join(gold, "k6_verifier_trace.json")))["vk"]
+    H = lambda s: int(s, 16)
+    ref_comms = [(H(a), H(b)) for a, b in trace["commitments"]]
+    params = sg.ParamsKZG.read(open(os.path.join(gold, "hermez-raw-11"), "rb"))
+    try:
+        dev = lambda v: torch.from_numpy(ints_to_fr(v)).cuda()
+        pk = prover.ProvingKey(params, 11, [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]])
+        assert pk.fixed_comms == ref_comms[:11]              # the reference's verifying key, from this key generation
+        assert pk.permutation_comms == ref_comms[11:]
+        pk.vk_digest = H(trace["vk_digest"])                  # the transcript starts from the contract's digest
+        proof = prover.create_proof(params, pk, [dev(c) for c in asg["advice"]], asg["instances"])
+        vk = {"k": 11, "vk_digest": H(trace["vk_digest"]), "fixed_comms": ref_comms[:11], "permutation_comms": ref_comms[11:],
+              "g2": ((H(trace["g2_x_2"]), H(trace["g2_x_1"])), (H(trace["g2_y_2"]), H(trace["g2_y_1"]))),
+              "neg_s_g2": ((H(trace["neg_s_g2_x_2"]), H(trace["neg_s_g2_x_1"])), (H(trace["neg_s_g2_y_2"]), H(trace["neg_s_g2_y_1"])))}
+        assert SV.verify(proof, asg["instances"], vk)
+        kat = json.load(open(os.path.join(gold, "kat.json")))["k5"]
+        assert asg["instances"] == [int(kat["leaf0"], 16), int(kat["root"], 16)] + kat["root_balances"]
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump({"proof": "0x" + proof.hex(), "public_inputs": [hex(v) for v in asg["instances"]]},
+                  open(os.path.join(out, "gpu_proof_entry16_user0.json"), "w"))
+    finally:
+        params.free()

@@ -231,3 +231,74 @@ def test_inclusion_assignment_reproduces_the_reference_public_inputs(index):
     assert asg["rows_used"] < asg["usable_rows"] and asg["copies"] > 50
     with pytest.raises(ValueError):
         M.assign_inclusion(11, entries[index][0], [1 << 64, 5], siblings, bits)     # a balance beyond N_BYTES = 8
+
+
+def _entry16_reference_inputs(index=0):
+    import csv
+    rows = list(csv.reader(open(os.path.join(GOLD, "entry_16.csv"))))[1:]
+    entries = [PR.mst_entry(r[0], [int(r[1]), int(r[2])]) for r in rows]
+    root, levels = PR.mst_build(entries)
+    bits, pre_mid, i = [], [], index
+    for level in range(4):
+        bits.append(i & 1)
+        s = i ^ 1
+        if level:
+            pre_mid.append(levels[level][s][1] + [levels[level - 1][2 * s][0], levels[level - 1][2 * s + 1][0]])
+        i >>= 1
+    sib = entries[index ^ 1]
+    return entries[index][0], entries[index][1], bits, [sib[0]] + sib[1], pre_mid, root, levels
+
+
+@pytest.mark.parametrize("witness", ["entry_16.csv user 0", "empty (keygen view)"])
+def test_reference_verifying_key_is_reproduced(witness):
+    """KEYGEN LEVEL, bit-exact: replaying the reference circuit's synthesize over halo2's floor planner and permutation
+    assembly (circuits_halo2_amd.mst_inclusion.reference_assignment) yields fixed and permutation columns whose KZG
+    commitments under the reference's SRS are the 11 fixed_comms and 6 permutation_comms of the reference's verifying
+    key (contracts/src/InclusionVerifier.sol:238-271; SURVEY.md "pinned bit-exactly but needs a layout restatement").
+    The key does not depend on the witness; the real witness also satisfies every gate and gives the K5 public inputs."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mst_assignment as MA
+    from circuits_halo2_amd import mst_inclusion as M
+    from oracle import oracle as O
+    if witness.startswith("entry"):
+        user, bal, bits, pre_leaf, pre_mid, root, levels = _entry16_reference_inputs(0)
+    else:
+        user, bal, bits, pre_leaf, pre_mid = 0, [0, 0], [0] * 4, [0, 0, 0], [[0, 0, 0, 0]] * 3
+    asg = M.reference_assignment(11, user, bal, bits, pre_leaf, pre_mid)
+    assert asg["rows_used"] == 1489
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    gl = np.frombuffer(PR.parse_srs(open(os.path.join(GOLD, "hermez-raw-11"), "rb").read())["g_lagrange"], dtype=np.uint8).copy()
+
+    def commit(col):
+        sc = np.frombuffer(b"".join(PR.fr_to_bytes(v) for v in col), dtype=np.uint8).copy()
+        return PR.g1_from_bytes(bytes(O.best_multiexp(sc, gl, O.ncpu())))
+    for j in range(11):
+        assert commit(asg["fixed"][j]) == (H(kat["fixed_comms"][j][0]), H(kat["fixed_comms"][j][1])), f"fixed_comms[{j}]"
+    for j in range(6):
+        assert commit(asg["sigma"][j]) == (H(kat["permutation_comms"][j][0]), H(kat["permutation_comms"][j][1])), f"permutation_comms[{j}]"
+    assert MA.check_gates(asg, 11)
+    if witness.startswith("entry"):
+        assert asg["instances"] == [H(kat["k5"]["leaf0"]), H(kat["k5"]["root"])] + kat["k5"]["root_balances"]
+
+
+def test_gpu_made_proof_under_the_reference_key():
+    """tests/golden/gpu_proof_entry16_user0.json was produced on an MI355X by tests/test_gpu_prover.py::
+    test_reference_floor_plan_proof_under_the_reference_verifying_key (reference layout, reference SRS, entry_16.csv
+    user 0).  The restated verifier accepts it on the REFERENCE'S verifying key, and -- where the reference checkout
+    exists -- so does the reference's own verifier contract (contracts/src/InclusionVerifier.sol::verifyProof, run by
+    oracle/yul_verifier_run.py), which rejects it after a flipped byte."""
+    proof_k6, _, vk, _ = load_k6()
+    d = json.load(open(os.path.join(GOLD, "gpu_proof_entry16_user0.json")))
+    proof, inst = bytes.fromhex(d["proof"][2:]), [H(x) for x in d["public_inputs"]]
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))["k5"]
+    assert inst == [H(kat["leaf0"]), H(kat["root"])] + kat["root_balances"] and proof != proof_k6
+    assert SV.verify(proof, inst, vk)
+    if os.path.exists("/root/reference/contracts/src/InclusionVerifier.sol"):
+        from oracle import yul_verifier_run as Y
+        assert Y.run(proof=proof, instances=inst)["trace"]["result"] == 1
+        bad = bytearray(proof)
+        bad[0x500] ^= 1
+        assert Y.run(proof=bytes(bad), instances=inst)["trace"]["result"] == 0
+        assert Y.run(proof=proof, instances=inst[:3] + [inst[3] + 1])["trace"]["result"] == 0
