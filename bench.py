@@ -306,6 +306,52 @@ def main():
                                                         "in its own process, best of 8; tests/test_gpu_prover.py verifies such proofs with the restated verifier"}
                 except Exception as ex:
                     line["create_proof_k17"] = {"error": repr(ex)}
+                # the reference circuit itself (its own floor plan, verifying key and SRS; csv/entry_16.csv user 0, k = 11):
+                # key generation reproduces the contract's 17 commitments, create_proof from the C++ driver
+                try:
+                    import subprocess, tempfile
+                    from circuits_halo2_amd import mst_inclusion as _M, prover as _pv
+                    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree, keccak256 as _keccak
+                    from circuits_halo2_amd.utils import ints_to_fr as _itf
+                    gold = os.path.join(ROOT, "tests", "golden")
+                    rinv = pow(1 << 256, -1, _M.R)
+                    _ints = lambda b: [int.from_bytes(bytes(b[i:i + 32]), "little") * rinv % _M.R for i in range(0, len(b), 32)]
+                    tree = MerkleSumTree.from_csv(os.path.join(gold, "entry_16.csv"), 2)
+                    mp = tree.generate_proof(0)
+                    asg = _M.reference_assignment(11, int.from_bytes(_keccak(mp["entry"][0].encode()), "big") % _M.R, [int(x) for x in mp["entry"][1]],
+                                                  mp["path_indices"], _ints(mp["sibling_leaf_node_hash_preimage"]),
+                                                  [_ints(p_) for p_ in mp["sibling_middle_node_hash_preimages"]])
+                    p11 = sg.ParamsKZG.read(open(os.path.join(gold, "hermez-raw-11"), "rb"))
+                    p11.precompute()
+                    dv = lambda v: torch.from_numpy(_itf(v)).cuda()
+                    fx, sgm, adv = [dv(c) for c in asg["fixed"]], [dv(c) for c in asg["sigma"]], [dv(c) for c in asg["advice"]]
+                    pk11 = _pv.ProvingKey(p11, 11, fx, sgm)
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    pk11 = _pv.ProvingKey(p11, 11, fx, sgm)
+                    kg_ms = (time.perf_counter() - t1) * 1e3
+                    kat = json.load(open(os.path.join(gold, "kat.json")))
+                    want = [(int(a, 16), int(b, 16)) for a, b in kat["fixed_comms"] + kat["permutation_comms"]]
+                    pk11.vk_digest = int(kat["vk_digest"], 16)
+                    _pv.create_proof(p11, pk11, adv, asg["instances"])
+                    t1 = time.perf_counter()
+                    _pv.create_proof(p11, pk11, adv, asg["instances"])
+                    py_ms = (time.perf_counter() - t1) * 1e3
+                    ref = {"keygen_ms": kg_ms, "create_proof_ms": py_ms, "rows_used": asg["rows_used"],
+                           "verifying_key_matches_reference": pk11.fixed_comms + pk11.permutation_comms == want,
+                           "public_inputs_match_reference_K5": [hex(v) for v in asg["instances"]][:2] == [kat["k5"]["leaf0"], kat["k5"]["root"]]}
+                    exe11 = os.path.join(ROOT, "tools", "create_proof_cpp")
+                    if os.path.exists(exe11) and not ("rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)):
+                        with tempfile.TemporaryDirectory() as td:
+                            _pv.export_bundle(os.path.join(td, "b.bin"), p11, pk11, adv, asg["instances"])
+                            r = subprocess.run([exe11, os.path.join(td, "b.bin"), os.path.join(td, "p.bin"), "8"], capture_output=True, text=True, timeout=300)
+                            if r.returncode == 0:
+                                ref["create_proof_ms_cpp_driver"] = json.loads(r.stdout.strip().splitlines()[-1])["create_proof_ms"]
+                    p11.free()
+                    ref["note"] = ("MstInclusionCircuit<4,2,8> in the reference's own floor plan (mst_inclusion.reference_assignment), reference SRS, "
+                                   "csv/entry_16.csv user 0; proofs of this kind are accepted by the reference's verifier contract (tests/test_verifier_cpu.py)")
+                    line["reference_circuit_k11"] = ref
+                except Exception as ex:
+                    line["reference_circuit_k11"] = {"error": repr(ex)}
                 # the reference criterion bench's shape (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13): tree of
                 # 2^20 users on the device, inclusion witness of one user, key generation, proof (tools/full_flow.py)
                 try:

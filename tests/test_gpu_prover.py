@@ -378,5 +378,18 @@ def test_reference_floor_plan_proof_under_the_reference_verifying_key():
         os.makedirs(out, exist_ok=True)
         json.dump({"proof": "0x" + proof.hex(), "public_inputs": [hex(v) for v in asg["instances"]]},
                   open(os.path.join(out, "gpu_proof_entry16_user0.json"), "w"))
+        # the compiled-host prover on the same key and witness
+        exe = os.path.join(os.path.dirname(out), "tools", "create_proof_cpp")
+        if os.path.exists(exe):
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                prover.export_bundle(os.path.join(td, "b.bin"), params, pk, [dev(c) for c in asg["advice"]], asg["instances"])
+                r = subprocess.run([exe, os.path.join(td, "b.bin"), os.path.join(td, "p.bin"), "3"], capture_output=True, text=True, timeout=300)
+                assert r.returncode == 0, r.stderr
+                cpp_proof = open(os.path.join(td, "p.bin"), "rb").read()
+            assert SV.verify(cpp_proof, asg["instances"], vk)
+            json.dump({"proof": "0x" + cpp_proof.hex(), "public_inputs": [hex(v) for v in asg["instances"]]},
+                      open(os.path.join(out, "gpu_proof_entry16_user0_cpp.json"), "w"))
     finally:
         params.free()

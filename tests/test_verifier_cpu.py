@@ -283,14 +283,15 @@ def test_reference_verifying_key_is_reproduced(witness):
         assert asg["instances"] == [H(kat["k5"]["leaf0"]), H(kat["k5"]["root"])] + kat["k5"]["root_balances"]
 
 
-def test_gpu_made_proof_under_the_reference_key():
+@pytest.mark.parametrize("fixture", ["gpu_proof_entry16_user0.json", "gpu_proof_entry16_user0_cpp.json"])
+def test_gpu_made_proof_under_the_reference_key(fixture):
     """tests/golden/gpu_proof_entry16_user0.json was produced on an MI355X by tests/test_gpu_prover.py::
     test_reference_floor_plan_proof_under_the_reference_verifying_key (reference layout, reference SRS, entry_16.csv
     user 0).  The restated verifier accepts it on the REFERENCE'S verifying key, and -- where the reference checkout
     exists -- so does the reference's own verifier contract (contracts/src/InclusionVerifier.sol::verifyProof, run by
     oracle/yul_verifier_run.py), which rejects it after a flipped byte."""
     proof_k6, _, vk, _ = load_k6()
-    d = json.load(open(os.path.join(GOLD, "gpu_proof_entry16_user0.json")))
+    d = json.load(open(os.path.join(GOLD, fixture)))      # Python driver / C++ driver (include/summa_prover.hpp)
     proof, inst = bytes.fromhex(d["proof"][2:]), [H(x) for x in d["public_inputs"]]
     kat = json.load(open(os.path.join(GOLD, "kat.json")))["k5"]
     assert inst == [H(kat["leaf0"]), H(kat["root"])] + kat["root_balances"] and proof != proof_k6
