@@ -304,7 +304,8 @@ def test_inclusion_proof_of_the_reference_csv_and_srs(tmp_path):
 
 def test_inclusion_proof_levels20_k13():
     """the reference bench's shape (LEVELS = 20, k = 13): a 2^20-user Merkle sum tree on the device, the inclusion
-    witness of one user (3633 rows), proof, verification; the public inputs are the device tree's leaf and root"""
+    witness of one user in the reference circuit's own floor plan (7041 rows), proof, verification; the public inputs
+    are the device tree's leaf and root"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import ffi

@@ -1,6 +1,7 @@
 """The shape of the reference's criterion bench (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13): a
-Merkle sum tree of 2^LEVELS synthetic users on the device, an inclusion witness for one user over the reference
-circuit's constraint system (N_CURRENCIES = 2), key generation from the Lagrange columns, create_proof.
+Merkle sum tree of 2^LEVELS synthetic users on the device, the inclusion witness of one user in the reference circuit's
+own floor plan (mst_inclusion.reference_assignment, N_CURRENCIES = 2), key generation from the Lagrange columns,
+create_proof.
 `build(levels, k)` returns everything a caller needs (tests/test_gpu_prover.py verifies the proof); run as a script
 it prints the timings."""
 import os, sys, time
@@ -33,18 +34,26 @@ def build(levels=20, k=13, user=123457, nc=2, timings=None):
     t0 = time.perf_counter()
     rinv = pow(1 << 256, -1, R)
     toi = lambda tens: [int.from_bytes(bytes(row), "little") * rinv % R for row in tens.cpu().numpy().reshape(-1, 32)]
-    off, idx, siblings, bits = 0, user, [], []
+    offs = [0]
     for level in range(levels):
-        s = off + (idx ^ 1)
-        siblings.append((toi(d_h[32 * s:32 * s + 32])[0], toi(d_b[32 * s * nc:32 * (s + 1) * nc])))
+        offs.append(offs[-1] + (size >> level))
+    node_h = lambda level, i: toi(d_h[32 * (offs[level] + i):32 * (offs[level] + i) + 32])[0]
+    node_b = lambda level, i: toi(d_b[32 * (offs[level] + i) * nc:32 * (offs[level] + i + 1) * nc])
+    idx, bits, pre_mid = user, [], []
+    for level in range(levels):
         bits.append(idx & 1)
-        off += size >> level
+        s = idx ^ 1
+        if level:   # the sibling middle node's preimage: its balances, its children's hashes
+            pre_mid.append(node_b(level, s) + [node_h(level - 1, 2 * s), node_h(level - 1, 2 * s + 1)])
         idx >>= 1
+    sib = user ^ 1
+    pre_leaf = toi(d_users[32 * sib:32 * sib + 32]) + toi(d_bals[32 * sib * nc:32 * (sib + 1) * nc])
     username = toi(d_users[32 * user:32 * user + 32])[0]
     balances = toi(d_bals[32 * user * nc:32 * (user + 1) * nc])
-    root = (toi(d_h[32 * (nodes - 1):])[0], toi(d_b[32 * (nodes - 1) * nc:]))
-    leaf = toi(d_h[32 * user:32 * user + 32])[0]
-    asg = M.assign_inclusion(k, username, balances, siblings, bits)
+    root = (node_h(levels, 0), node_b(levels, 0))
+    leaf = node_h(0, user)
+    # the reference circuit's own floor plan (mst_inclusion.reference_assignment), as its keygen / prover would lay it out
+    asg = M.reference_assignment(k, username, balances, bits, pre_leaf, pre_mid)
     t["witness_assignment_host_ms"] = (time.perf_counter() - t0) * 1e3
     assert asg["instances"] == [leaf, root[0]] + root[1], "the assignment's public inputs are the device tree's leaf / root"
     return asg
