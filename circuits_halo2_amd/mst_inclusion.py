@@ -535,8 +535,6 @@ class _ReferenceFloorPlan:
         return start
 
     def copy(self, left, right):
-        for cell in (left, right):
-            pass
         lv, rv = self.value(left), self.value(right)
         if lv != rv:
             raise AssertionError(("copy constraint between unequal cells", left, right))
