@@ -301,7 +301,8 @@ def main():
                                                 "proof_bytes": nbytes, "rows_per_s": (1 << 17) / ((cpp17.get("create_proof_ms") or ms17) * 1e-3),
                                                 "phases_ms_synchronised": run_create_proof.phases, "keygen_ms": run_create_proof.keygen_ms,
                                                 "note": "whole create_proof (EVM transcript, SHPLONK) for MstInclusionCircuit's constraint system "
-                                                        "(19 gates, 1 lookup, 6 permutation columns) at k = 17 on the example assignment, wall clock incl. the host "
+                                                        "(19 gates, 1 lookup, 6 permutation columns) at k = 17, MstInclusionCircuit<20,2,8> in the reference's own floor plan with the "
+                                                        "inclusion witness of one user of a device-built 2^20-user tree, wall clock incl. the host "
                                                         "glue (transcript, multi-open scalars); ms: Python driver, best of 3; ms_cpp_driver: include/summa_prover.hpp "
                                                         "in its own process, best of 8; tests/test_gpu_prover.py verifies such proofs with the restated verifier"}
                 except Exception as ex:

@@ -1,4 +1,4 @@
-"""writes the prover bundle of the example assignment at k (argv[1], default 17) to argv[2] (for tools/create_proof_cpp)"""
+"""writes the prover bundle of the time_create_proof.setup(k) witness (reference floor plan) at k (argv[1], default 17) to argv[2] (for tools/create_proof_cpp)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from circuits_halo2_amd import ffi, prover

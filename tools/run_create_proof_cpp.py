@@ -1,4 +1,4 @@
-"""exports a bundle of the example assignment at k (default 17) and runs tools/create_proof_cpp on it"""
+"""exports a bundle of the time_create_proof.setup(k) witness (reference floor plan) at k (default 17) and runs tools/create_proof_cpp on it"""
 import os, sys, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,6 @@
-"""wall time of circuits_halo2_amd.prover.create_proof for the reference circuit's constraint system (example
-assignment), k from argv (default 17); PROFILE=1 prints the host-side profile of one call"""
+"""wall time of circuits_halo2_amd.prover.create_proof for the reference circuit in its own floor plan
+(mst_inclusion.reference_assignment; a real inclusion witness from a device-built tree: LEVELS = 20 for k >= 13 -- the
+reference bench's shape --, LEVELS = 4 below), k from argv (default 17); PROFILE=1 prints the host-side profile of one call"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +10,8 @@ from circuits_halo2_amd.utils import ints_to_fr
 
 
 def setup(k):
-    asg = M.example_assignment(k)
+    from full_flow import build
+    asg = build(20 if k >= 13 else 4, k, user=5)
     params = sg.ParamsKZG.setup(k, ints_to_fr([0x1D0C0FFEE1234567890ABCDEF]))
     params.precompute()
     dev = lambda ints: torch.from_numpy(ints_to_fr(ints)).cuda()
