@@ -358,9 +358,10 @@ def main():
                 try:
                     from full_flow import run as run_full_flow
                     torch.cuda.empty_cache()
-                    line["full_flow_levels20_k13"] = dict(run_full_flow(20, 13, cpp=not profiled17),
-                                                          note="2^20-user Merkle sum tree (2 currencies) on the device, inclusion witness over the "
-                                                               "reference circuit's constraint system (host, Python integers), proving-key construction "
+                    line["full_flow_levels20_k13"] = dict(run_full_flow(20, 13, cpp=not profiled17, nc=1),
+                                                          note="the reference bench's configuration (LEVELS = 20, N_CURRENCIES = 1, N_BYTES = 8, k = 13): 2^20-user "
+                                                               "Merkle sum tree on the device, inclusion witness in the reference circuit's floor plan "
+                                                               "(host, Python integers), proving-key construction "
                                                                "from Lagrange columns, create_proof (Python driver / C++ driver)")
                 except Exception as ex:
                     line["full_flow_levels20_k13"] = {"error": repr(ex)}

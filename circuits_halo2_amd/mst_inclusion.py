@@ -103,8 +103,9 @@ class Expr:
         return g.add_calculation({"add": A.ADD, "sub": A.SUB, "mul": A.MUL}[self.op], va, vb)
 
 
-def gates():
-    """the 19 gate polynomials in the constraint system's order"""
+def gates(n_currencies: int = 2):
+    """the gate polynomials in the constraint system's order: 17 + one sum gate per currency (19 for the reference's
+    `MstInclusionCircuit<4, 2, 8>`)"""
     _, mds, mds_inv = _poseidon()
     a = lambda c, r=0: Expr.query(A.ADVICE, c, r)
     f = lambda c: Expr.query(A.FIXED, c, 0)
@@ -143,7 +144,7 @@ def gates():
     out.append(s * ((a(1) - a(0)) * a(2) + a(0) - a(0, 1)))
     out.append(s * ((a(0) - a(1)) * a(2) + a(1) - a(1, 1)))
     s = simple_selector(2)
-    for _ in range(2):   # one sum gate per currency
+    for _ in range(n_currencies):   # one sum gate per currency
         out.append(s * (a(0) + a(1) - a(2)))
     return out
 
@@ -171,12 +172,12 @@ def gate_challenges(y: int):
 
 
 @lru_cache(maxsize=None)
-def gate_graph() -> A.GraphEvaluator:
+def gate_graph(n_currencies: int = 2) -> A.GraphEvaluator:
     """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y), see GATE_BLOCKS"""
     g = A.GraphEvaluator()
-    parts = [e.lower(g) for e in gates()]
+    parts = [e.lower(g) for e in gates(n_currencies)]
     y = (A.Y, 0, 0)
-    (a0, a1), (b0, b1), (c0, c1) = GATE_BLOCKS
+    (a0, a1), (b0, b1), (c0, c1) = GATE_BLOCKS[0], GATE_BLOCKS[1], (GATE_BLOCKS[2][0], len(parts))
     second = g.add_calculation(A.HORNER, parts[b0], y, parts[b0 + 1:b1])
     first = g.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), y, parts[a0:a1])
     shifted = g.add_calculation(A.MUL, first, (A.CHALLENGE, 0, 0))

@@ -127,9 +127,10 @@ class ProvingKey:
     """fixed and permutation columns in the three bases halo2's pk keeps (Lagrange, coefficients, extended coset),
     the Lagrange selector polynomials l0 / l_last / l_active, and the verifying key's commitments"""
 
-    def __init__(self, params, k: int, fixed_lagrange, sigma_lagrange):
+    def __init__(self, params, k: int, fixed_lagrange, sigma_lagrange, n_currencies: int = 2):
         import torch
         self.k, self.n = k, 1 << k
+        self.n_currencies = n_currencies          # one sum gate per currency in the gate program
         self.dom = EvaluationDomain(M.DEGREE, k)
         n, u = self.n, self.n - (M.BLINDING_FACTORS + 1)
         self.usable_rows = u
@@ -296,7 +297,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     lap("3_grand_products")
     # -- 4: quotient: evaluate_h over the extended coset, / (X^n - 1), back to coefficients, five pieces
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(values, M.gate_graph(), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k,
+    A.quotient_gates(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k,
                      ext_k)
     col_ext = {(A.ADVICE, j): adv_ext[j] for j in range(3)}
     col_ext.update({(A.FIXED, j): pk.fixed_ext[j] for j in range(M.NUM_FIXED)})
@@ -426,4 +427,4 @@ def export_bundle(path: str, params, pk: ProvingKey, advice, instances) -> None:
             f.write(host(col))
         f.write(ints_to_fr(list(instances)).tobytes())
         f.write(pk.vk_digest.to_bytes(32, "big"))
-        f.write(graph_bytes(M.gate_graph()) + graph_bytes(M.lookup_input_graph()))
+        f.write(graph_bytes(M.gate_graph(pk.n_currencies)) + graph_bytes(M.lookup_input_graph()))

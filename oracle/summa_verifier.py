@@ -121,7 +121,7 @@ def on_curve(p) -> bool:
 
 
 # ------------------------------------------------------------------ constraint system
-def gate_values(q):
+def gate_values(q, n_currencies: int = 2):
     """The 19 gate polynomials of the circuit at one point; `q(kind, column, rotation)` returns the value of a
     column there (an evaluation at x * omega^rotation for the verifier, a cell of the row for a row-wise check).
 
@@ -175,7 +175,7 @@ def gate_values(q):
     out.append(s * (((a(0) - a(1)) * a(2) + a(1) - a(1, 1)) % R) % R)
     # sum gate, once per currency
     s = simple_selector(2)
-    for _ in range(2):
+    for _ in range(n_currencies):
         out.append(s * ((a(0) + a(1) - a(2)) % R) % R)
     return out
 
@@ -185,13 +185,13 @@ def lookup_input_table(q):
     return q("f", 5, 0) * ((q("a", 0, 0) - 256 * q("a", 0, 1)) % R) % R, q("f", 4, 0)
 
 
-def quotient_numerator(q, ch, lag):
+def quotient_numerator(q, ch, lag, n_currencies: int = 2):
     """All constraints folded with powers of y (Horner, first gate highest), :495-1000.
     ch: challenges theta beta gamma y x;  lag: l_0, l_last, l_blind, instance_eval."""
     beta, gamma, y, x = ch["beta"], ch["gamma"], ch["y"], ch["x"]
     l_0, l_last, l_blind = lag["l_0"], lag["l_last"], lag["l_blind"]
     active = (1 - l_last - l_blind) % R
-    terms = list(gate_values(q))
+    terms = list(gate_values(q, n_currencies))
     # permutation argument
     chunks = [PERMUTATION_COLUMNS[i:i + PERMUTATION_CHUNK] for i in range(0, len(PERMUTATION_COLUMNS), PERMUTATION_CHUNK)]
     z = lambda j, r=0: q("z", j, r)
@@ -285,7 +285,7 @@ def shplonk_pairing_inputs(comms, evals_of, x, zeta, nu, mu, w, w2, k=K):
 
 
 def verify(proof: bytes, instances, vk, trace=None) -> bool:
-    """vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"[, "k": 11]} (integers / int tuples).
+    """vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"[, "k": 11, "n_currencies": 2]} (integers / int tuples).
     `trace`, if given, is filled with the intermediate values named as in tests/golden/k6_verifier_trace.json."""
     try:
         comms, evals, w, w2 = parse_proof(proof)
@@ -318,7 +318,7 @@ def verify(proof: bytes, instances, vk, trace=None) -> bool:
     k = vk.get("k", K)
     lag = lagrange_evaluations(x, instances, k)
     q = lambda kind, c, rot: evals[(kind, c, rot)]
-    numer = quotient_numerator(q, ch, lag)
+    numer = quotient_numerator(q, ch, lag, vk.get("n_currencies", 2))
     quotient_eval = numer * inv((lag["x_n"] - 1) % R) % R
     # h(X) = sum_i x^(n i) h_i(X): one commitment for the five pieces
     h_comm = None

@@ -302,8 +302,10 @@ def test_inclusion_proof_of_the_reference_csv_and_srs(tmp_path):
         params.free()
 
 
-def test_inclusion_proof_levels20_k13():
-    """the reference bench's shape (LEVELS = 20, k = 13): a 2^20-user Merkle sum tree on the device, the inclusion
+@pytest.mark.parametrize("nc", [1, 2])
+def test_inclusion_proof_levels20_k13(nc):
+    """the reference bench's shape (LEVELS = 20, k = 13; N_CURRENCIES = 1 is its exact configuration,
+    zk_prover/benches/full_solvency_flow.rs:13-16): a 2^20-user Merkle sum tree on the device, the inclusion
     witness of one user in the reference circuit's own floor plan (7041 rows), proof, verification; the public inputs
     are the device tree's leaf and root"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -316,15 +318,16 @@ def test_inclusion_proof_levels20_k13():
     import mst_assignment as MA
     ffi.check(ffi.lib().sg_init(0))
     k = 13
-    asg = full_flow.build(20, k)
-    assert MA.check_gates(asg, k)
+    asg = full_flow.build(20, k, nc=nc)
+    assert MA.check_gates(asg, k, nc)
     params = sg.ParamsKZG.setup(k, ints_to_fr([0xABCDEF0123456789]))
     try:
-        pk, advice, proof = full_flow.keygen_and_prove(asg, k, params, reps=1)
+        pk, advice, proof = full_flow.keygen_and_prove(asg, k, params, reps=1, nc=nc)
         f2 = lambda b: (PR.fq_from_bytes(b[:32]), PR.fq_from_bytes(b[32:64]))
         s_g2 = (f2(params.s_g2[:64]), f2(params.s_g2[64:]))
-        vk = {"k": k, "vk_digest": pk.vk_digest, "fixed_comms": pk.fixed_comms, "permutation_comms": pk.permutation_comms,
-              "g2": PR.G2_GENERATOR, "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
+        vk = {"k": k, "n_currencies": nc, "vk_digest": pk.vk_digest, "fixed_comms": pk.fixed_comms,
+              "permutation_comms": pk.permutation_comms, "g2": PR.G2_GENERATOR,
+              "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
         assert SV.verify(proof, asg["instances"], vk)
         assert not SV.verify(proof, asg["instances"][:1] + [asg["instances"][1] ^ 1] + asg["instances"][2:], vk)
     finally:

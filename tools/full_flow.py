@@ -59,13 +59,13 @@ def build(levels=20, k=13, user=123457, nc=2, timings=None):
     return asg
 
 
-def keygen_and_prove(asg, k, params, reps=3, timings=None):
+def keygen_and_prove(asg, k, params, reps=3, timings=None, nc=2):
     t = {} if timings is None else timings
     dev = lambda v: torch.from_numpy(ints_to_fr(v)).cuda()
     fixed, sigma, advice = [dev(c) for c in asg["fixed"]], [dev(c) for c in asg["sigma"]], [dev(c) for c in asg["advice"]]
-    pk = prover.ProvingKey(params, k, fixed, sigma)
+    pk = prover.ProvingKey(params, k, fixed, sigma, nc)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    pk = prover.ProvingKey(params, k, fixed, sigma)
+    pk = prover.ProvingKey(params, k, fixed, sigma, nc)
     t["keygen_ms"] = (time.perf_counter() - t0) * 1e3
     proof = prover.create_proof(params, pk, advice, asg["instances"])
     best = 1e9
@@ -77,13 +77,13 @@ def keygen_and_prove(asg, k, params, reps=3, timings=None):
     return pk, advice, proof
 
 
-def run(levels=20, k=13, cpp=True):
+def run(levels=20, k=13, cpp=True, nc=2):
     import json, subprocess, tempfile
     t = {}
-    asg = build(levels, k, timings=t)
+    asg = build(levels, k, nc=nc, timings=t)
     params = sg.ParamsKZG.setup(k, ints_to_fr([0x1D0C0FFEE1234567890ABCDEF]))
     params.precompute()
-    pk, advice, proof = keygen_and_prove(asg, k, params, timings=t)
+    pk, advice, proof = keygen_and_prove(asg, k, params, timings=t, nc=nc)
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "create_proof_cpp")
     if cpp and os.path.exists(exe):
         with tempfile.TemporaryDirectory() as td:
@@ -92,10 +92,11 @@ def run(levels=20, k=13, cpp=True):
             if r.returncode == 0:
                 t["create_proof_ms_cpp_driver"] = json.loads(r.stdout.strip().splitlines()[-1])["create_proof_ms"]
     params.free()
-    t.update({"levels": levels, "k": k, "n_currencies": 2, "rows_used": asg["rows_used"]})
+    t.update({"levels": levels, "k": k, "n_currencies": nc, "rows_used": asg["rows_used"]})
     return t
 
 
 if __name__ == "__main__":
     ffi.check(ffi.lib().sg_init(0))
-    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 13))
+    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 13,
+              nc=int(sys.argv[3]) if len(sys.argv) > 3 else 2))
