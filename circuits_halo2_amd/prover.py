@@ -52,11 +52,6 @@ def _inv(a):
     return pow(a, -1, R)
 
 
-def _dev(ints):
-    import torch
-    return torch.from_numpy(ints_to_fr(ints)).cuda()
-
-
 def _fr_bytes(v: int) -> np.ndarray:
     return ints_to_fr([v])
 
@@ -188,7 +183,7 @@ def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
     return a, s
 
 
-def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None = None, debug=None, timings=None) -> bytes:
+def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None = None, timings=None) -> bytes:
     """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
     `seed`: 32-byte ChaCha20 key for the blinding factors and the random polynomial (tests); default: the OS
     entropy source."""
@@ -336,8 +331,6 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
 
     def eval_of(key, rot):
         return h_eval if key == ("h", None) else evals[(key[0], key[1], rot)]
-    if debug is not None:
-        debug.update({"h_eval": h_eval, "x": x, "y": y, "beta": beta, "gamma": gamma, "theta": theta, "evals": dict(evals)})
 
     lap("5_evaluations")
     # -- 6: SHPLONK (BDFG21) multi-open

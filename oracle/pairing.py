@@ -15,7 +15,7 @@ proof K6 verifying through it.
 """
 from __future__ import annotations
 
-from .pyref import Q, R, G1_GEN, G2_GENERATOR, g1_mul, g2_mul  # noqa: F401
+from .pyref import Q, R
 
 ATE_LOOP_COUNT = 29793968203157093288  # 6u + 2, u = 4965661367192848881
 LOG_ATE_LOOP_COUNT = 63

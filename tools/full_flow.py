@@ -7,7 +7,7 @@ it prints the timings."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
-import numpy as np, torch
+import torch
 import circuits_halo2_amd as sg
 from circuits_halo2_amd import ffi, prover, arithmetic as A, mst_inclusion as M
 from circuits_halo2_amd.utils import ints_to_fr, random_fr_canonical
