@@ -557,6 +557,9 @@ __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __res
     }
   };
   count(work + LOOKUP_BINS, t);
+  // highest table value: bounds the scans and searches below (a range table uses 256 of the 65536 bins); the plain
+  // read only filters -- the maximum itself is maintained atomically
+  if (t > *reinterpret_cast<volatile uint32_t*>(flag + 1)) atomicMax(flag + 1, t);
   if (!small_canonical(input + i, &a)) {
     atomicMax(flag, 1u);
     return;
@@ -564,9 +567,9 @@ __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __res
   count(work, a);
 }
 // one workgroup: three exclusive prefix sums over the bins (input counts, repeated rows, leftover table values)
-__global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
+__global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag, uint32_t rows) {
   __shared__ uint32_t s_sum[3][1024];
-  constexpr uint32_t PER = LOOKUP_BINS / 1024;
+  const uint32_t bound = min(flag[1] + 1, LOOKUP_BINS), PER = (bound + 1023) / 1024;
   const uint32_t tid = threadIdx.x;
   uint32_t* hist_a = work;
   uint32_t* hist_t = work + LOOKUP_BINS;
@@ -575,7 +578,9 @@ __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict
   uint32_t tot[3] = {0, 0, 0};
   bool missing = false;
   for (uint32_t j = 0; j < PER; j++) {
-    const uint32_t v = tid * PER + j, ca = hist_a[v], ct = hist_t[v];
+    const uint32_t v = tid * PER + j;
+    if (v >= bound) break;
+    const uint32_t ca = hist_a[v], ct = hist_t[v];
     const uint32_t used = ca ? 1u : 0u;
     missing = missing || ct < used;
     tot[0] += ca;
@@ -593,10 +598,14 @@ __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict
     for (int q = 0; q < 3; q++) s_sum[q][tid] += add[q];
     __syncthreads();
   }
+  // an input above the table's maximum sits in a bin that was not scanned: the counts do not add up
+  if (tid == 1023 && s_sum[0][1023] != rows) atomicMax(flag, 1u);
   uint32_t run[3];
   for (int q = 0; q < 3; q++) run[q] = s_sum[q][tid] - tot[q];
   for (uint32_t j = 0; j < PER; j++) {
-    const uint32_t v = tid * PER + j, ca = hist_a[v], ct = hist_t[v];
+    const uint32_t v = tid * PER + j;
+    if (v >= bound) break;
+    const uint32_t ca = hist_a[v], ct = hist_t[v];
     const uint32_t used = ca ? 1u : 0u, lf = ct - min(ct, used);
     pre[0][v] = run[0];
     pre[1][v] = run[1];
@@ -608,8 +617,9 @@ __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict
   }
 }
 // largest v with pre[v] <= x among the bins that own at least one element (count[v] > 0 and pre[v] <= x < pre[v] + count[v])
-__device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, const uint32_t* __restrict__ count, uint32_t x) {
-  uint32_t lo = 0, hi = LOOKUP_BINS - 1;
+__device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, const uint32_t* __restrict__ count, uint32_t x,
+                                           uint32_t bound) {
+  uint32_t lo = 0, hi = bound - 1;
   while (lo < hi) {   // last v with pre[v] <= x
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (pre[mid] <= x) lo = mid; else hi = mid - 1;
@@ -618,16 +628,18 @@ __device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, con
   return lo;
 }
 __global__ void __launch_bounds__(256) lookup_permute_write(size_t rows, const uint32_t* __restrict__ work,
-                                                            fp_words* __restrict__ out_a, fp_words* __restrict__ out_s) {
+                                                            const uint32_t* __restrict__ flag, fp_words* __restrict__ out_a,
+                                                            fp_words* __restrict__ out_s) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
+  if (i >= rows || flag[0]) return;   // flagged inputs: the caller discards the outputs
+  const uint32_t bound = min(flag[1] + 1, LOOKUP_BINS);
   const uint32_t* hist_a = work;
   const uint32_t *pre_a = work + 2 * LOOKUP_BINS, *pre_rep = work + 3 * LOOKUP_BINS, *pre_left = work + 4 * LOOKUP_BINS,
                  *left = work + 5 * LOOKUP_BINS;
-  const uint32_t v = bin_of(pre_a, hist_a, (uint32_t)i);
+  const uint32_t v = bin_of(pre_a, hist_a, (uint32_t)i, bound);
   uint32_t s = v;
   const uint32_t within = (uint32_t)i - pre_a[v];
-  if (within) s = bin_of(pre_left, left, pre_rep[v] + within - 1);
+  if (within) s = bin_of(pre_left, left, pre_rep[v] + within - 1, bound);
   fp_words w;   // canonical small integers; the caller converts both columns to Montgomery form
   w.q[0] = make_uint4(v, 0, 0, 0);
   w.q[1] = make_uint4(0, 0, 0, 0);
@@ -642,12 +654,12 @@ hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_
   if (rows >= ((size_t)1 << 31)) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(d_work, 0, 2 * (size_t)LOOKUP_BINS * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream);
+  e = hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)((rows + 255) / 256);
   lookup_permute_hist<<<blocks, 256, 0, stream>>>(d_input, d_table, rows, d_work, d_flag);
-  lookup_permute_scan<<<1, 1024, 0, stream>>>(d_work, d_flag);
-  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_permuted_input, d_permuted_table);
+  lookup_permute_scan<<<1, 1024, 0, stream>>>(d_work, d_flag, (uint32_t)rows);
+  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_flag, d_permuted_input, d_permuted_table);
   return hipGetLastError();
 }
 
