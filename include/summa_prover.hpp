@@ -781,6 +781,33 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     r_polys.back().zero();
     tmps.emplace_back(n);
   }
+  // the Lagrange denominators prod_{j != i} (p_i - p_j) of every set depend only on x: one host inversion for all
+  // of them (Montgomery's trick) instead of one 254-step exponentiation each
+  std::vector<std::vector<Fr>> denom_inv(sets.size());
+  {
+    std::vector<Fr*> slots;
+    for (size_t si = 0; si < sets.size(); si++) {
+      const auto& rots = sets[si].rots;
+      denom_inv[si].assign(rots.size(), Fr::one());
+      for (size_t i = 0; i < rots.size(); i++) {
+        for (size_t j = 0; j < rots.size(); j++)
+          if (j != i) denom_inv[si][i] = denom_inv[si][i] * (point(rots[i]) - point(rots[j]));
+        slots.push_back(&denom_inv[si][i]);
+      }
+    }
+    std::vector<Fr> prefix(slots.size());
+    Fr run = Fr::one();
+    for (size_t t = 0; t < slots.size(); t++) {
+      prefix[t] = run;
+      run = run * *slots[t];
+    }
+    Fr inv = run.inv();
+    for (size_t t = slots.size(); t-- > 0;) {
+      const Fr v = *slots[t];
+      *slots[t] = inv * prefix[t];
+      inv = inv * v;
+    }
+  }
   fork();
   for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
     const auto& set = sets[si];
@@ -805,7 +832,6 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     std::vector<Fr> rc(pts.size(), Fr::zero());
     for (size_t i = 0; i < pts.size(); i++) {
       std::vector<Fr> basis = {Fr::one()};
-      Fr denom = Fr::one();
       for (size_t j = 0; j < pts.size(); j++) {
         if (j == i) continue;
         std::vector<Fr> nb(basis.size() + 1, Fr::zero());
@@ -814,9 +840,8 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
           nb[t] = nb[t] - pts[j] * basis[t];
         }
         basis = nb;
-        denom = denom * (pts[i] - pts[j]);
       }
-      const Fr scale = vals[i] * denom.inv();
+      const Fr scale = vals[i] * denom_inv[si][i];
       for (size_t t = 0; t < basis.size(); t++) rc[t] = rc[t] + scale * basis[t];
     }
     hk(hipMemcpyAsync(r_poly.p, rc.data(), 32 * rc.size(), hipMemcpyHostToDevice, st), "H2D");
