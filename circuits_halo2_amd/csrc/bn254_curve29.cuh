@@ -234,17 +234,10 @@ __device__ __forceinline__ void fp_words_store(fp_words* p, const uint32_t w[8])
   p->q[0] = make_uint4(w[0], w[1], w[2], w[3]);
   p->q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// a^(p-2) in the 2^261 domain (off the hot path only)
+// (x^)^-1 in the 2^261 domain, 0 -> 0: division steps instead of a^(p-2) (bn254_f29.cuh: f29_inv_safegcd)
 template <class P>
 __device__ inline f29 f29_inv(const f29& x) {
-  f29 acc = f29_one<P>();
-  for (int i = 253; i >= 0; i--) {
-    acc = f29_sqr<P>(acc);
-    // bit i of p - 2 (p[0] is odd and >= 3, so only limb 0 changes)
-    uint32_t limb = P::p[i / 29] - ((i / 29) == 0 ? 2u : 0u);
-    if ((limb >> (i % 29)) & 1) acc = f29_mul<P>(acc, x);
-  }
-  return acc;
+  return f29_inv_safegcd<P>(x);
 }
 template <class P>
 __device__ inline f29 f29_pow_u64(f29 x, uint64_t e) {

@@ -38,6 +38,9 @@ struct f29 {
 static constexpr uint32_t M29 = (1u << 29) - 1;
 
 struct Fq29 {
+  static constexpr int32_t p30[9] = {0x187cfd47, 0x3082305b, 0x071ca8d3, 0x205aa45a, 0x01585d97, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x00003064};
+  static constexpr uint32_t pinv30 = 0x1b799c77u;
+  static constexpr uint32_t r783[9] = {0x0e2312b2u, 0x16c05ca2u, 0x0bc84389u, 0x1cdf310bu, 0x11adafddu, 0x032e568eu, 0x1d6ae48cu, 0x10d4cd1fu, 0x0026c2d2u};
   static constexpr uint32_t p[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
                                     0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
   static constexpr uint32_t inv = 0x04866389u;      // -p^-1 mod 2^29
@@ -61,6 +64,10 @@ struct Fq29 {
       {0x5f3f51c0u, 0x41182daeu, 0x5ca8d3c0u, 0x5548b436u, 0x41765e03u, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au}};
 };
 struct Fr29 {
+  // modulus in signed 30-bit limbs, p^-1 mod 2^30 and 2^783 mod p (29-bit limbs): f29_inv
+  static constexpr int32_t p30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x00003064};
+  static constexpr uint32_t pinv30 = 0x10000001u;
+  static constexpr uint32_t r783[9] = {0x001fddb2u, 0x17d30b63u, 0x1a2600eeu, 0x09507c47u, 0x1496b29bu, 0x0b00a268u, 0x15b645ebu, 0x1f9fcb3du, 0x001baa96u};
   static constexpr uint32_t p[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
                                     0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
   static constexpr uint32_t inv = 0x0fffffffu;
@@ -321,6 +328,125 @@ SG_HD void f29_to_words(const f29& a, uint32_t w[8]) {
     if (sh + 32 > 58 && k + 2 < 9) v |= a.l[k + 2] << (58 - sh);
     w[i] = v;
   }
+}
+
+// ---- modular inversion by Bernstein-Yang division steps ("safegcd") ---------------------------
+// (x^)^-1 in the 2^261 domain: (x^-1)^.  Fermat's a^(p-2) is 254 squarings + ~127 products, ~200 us as a
+// dependent chain on one lane; the division-step iteration works on 30-bit signed limbs with small 2x2 transition
+// matrices: 20 rounds of 30 branch-free steps (600 >= the 590 steps that suffice for 256-bit moduli), each round
+// 30 x ~14 scalar operations plus ~90 multiply-adds to apply the matrix to (d, e) and (f, g) -- about a tenth of the
+// instructions.  Constant iteration count: no divergence between lanes.  Inverse of 0 is 0.
+struct s30 {
+  int32_t v[9];  // value = sum v[i] * 2^(30 i), limbs in (-2^30, 2^30)
+};
+template <class P>
+SG_HD f29 f29_inv_safegcd(const f29& x) {
+  constexpr int32_t M30 = (int32_t)(0xffffffffu >> 2);
+  // canonical integer of x^ as 30-bit limbs
+  uint32_t w[9];
+  f29_to_words(f29_canonical<P>(x), w);
+  w[8] = 0;
+  s30 d{}, e{}, f, g;
+  e.v[0] = 1;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    f.v[i] = P::p30[i];
+    const int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+    const uint64_t two = (uint64_t)w[wi] | (wi + 1 < 9 ? (uint64_t)w[wi + 1] << 32 : 0);
+    g.v[i] = (int32_t)((uint32_t)(two >> sh) & (uint32_t)M30);
+  }
+  int32_t zeta = -1;
+  for (int round = 0; round < 20; round++) {
+    // 30 division steps on the low limbs -> transition matrix t = [[u, v], [q, r]] (scaled by 2^30)
+    uint32_t u = 1, v = 0, q = 0, r = 1, f0 = (uint32_t)f.v[0], g0 = (uint32_t)g.v[0];
+    for (int i = 0; i < 30; i++) {
+      uint32_t c1 = (uint32_t)(zeta >> 31), c2 = 0u - (g0 & 1u);
+      const uint32_t xx = (f0 ^ c1) - c1, yy = (u ^ c1) - c1, zz = (v ^ c1) - c1;
+      g0 += xx & c2;
+      q += yy & c2;
+      r += zz & c2;
+      c1 &= c2;
+      zeta = (int32_t)(((uint32_t)zeta ^ c1) - 1u);
+      f0 += g0 & c1;
+      u += q & c1;
+      v += r & c1;
+      g0 >>= 1;
+      u <<= 1;
+      v <<= 1;
+    }
+    const int32_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+    {  // (d, e) <- t * (d, e) / 2^30 mod p
+      const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+      int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+      int64_t cd = (int64_t)tu * d.v[0] + (int64_t)tv * e.v[0];
+      int64_t ce = (int64_t)tq * d.v[0] + (int64_t)tr * e.v[0];
+      md -= (int32_t)((P::pinv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+      me -= (int32_t)((P::pinv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+      cd += (int64_t)P::p30[0] * md;
+      ce += (int64_t)P::p30[0] * me;
+      cd >>= 30;
+      ce >>= 30;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        cd += (int64_t)tu * d.v[i] + (int64_t)tv * e.v[i] + (int64_t)P::p30[i] * md;
+        ce += (int64_t)tq * d.v[i] + (int64_t)tr * e.v[i] + (int64_t)P::p30[i] * me;
+        d.v[i - 1] = (int32_t)cd & M30;
+        e.v[i - 1] = (int32_t)ce & M30;
+        cd >>= 30;
+        ce >>= 30;
+      }
+      d.v[8] = (int32_t)cd;
+      e.v[8] = (int32_t)ce;
+    }
+    {  // (f, g) <- t * (f, g) / 2^30 (exact)
+      int64_t cf = (int64_t)tu * f.v[0] + (int64_t)tv * g.v[0];
+      int64_t cg = (int64_t)tq * f.v[0] + (int64_t)tr * g.v[0];
+      cf >>= 30;
+      cg >>= 30;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        cf += (int64_t)tu * f.v[i] + (int64_t)tv * g.v[i];
+        cg += (int64_t)tq * f.v[i] + (int64_t)tr * g.v[i];
+        f.v[i - 1] = (int32_t)cf & M30;
+        g.v[i - 1] = (int32_t)cg & M30;
+        cf >>= 30;
+        cg >>= 30;
+      }
+      f.v[8] = (int32_t)cf;
+      g.v[8] = (int32_t)cg;
+    }
+  }
+  // g = 0 and f = +-1 (or f = +-p when x = 0): d = +-x^-1; bring it to [0, p)
+  {
+    int32_t cond_add = d.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] += P::p30[i] & cond_add;
+    const int32_t cond_negate = f.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] = (d.v[i] ^ cond_negate) - cond_negate;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      d.v[i + 1] += d.v[i] >> 30;
+      d.v[i] &= M30;
+    }
+    cond_add = d.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] += P::p30[i] & cond_add;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      d.v[i + 1] += d.v[i] >> 30;
+      d.v[i] &= M30;
+    }
+  }
+  // 30-bit limbs -> 29-bit limbs; X^-1 = x^-1 * 2^-261, times 2^783 * 2^-261 gives x^-1 * 2^261
+  f29 out;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int bit = 29 * k, li = bit / 30, sh = bit % 30;
+    uint64_t two = (uint64_t)(uint32_t)d.v[li] | (li + 1 < 9 ? (uint64_t)(uint32_t)d.v[li + 1] << 30 : 0);
+    out.l[k] = (uint32_t)(two >> sh) & M29;
+  }
+  return f29_mul<P>(out, f29_const<P>(P::r783));
 }
 
 }  // namespace sg
