@@ -238,34 +238,44 @@ __device__ __forceinline__ f29 kd_local(const fp_words* __restrict__ a, uint32_t
   }
   return acc;
 }
-// w[j] = b^(KD_CH * 2^j), j < count: the scan weights, by repeated squaring (every thread, 3 + count squarings)
-__device__ __forceinline__ void kd_powers(const f29& b_hat, f29* w, int count, int skip) {
-  f29 t = b_hat;
-  for (int i = 0; i < 3 + skip; i++) t = f29_sqr<P>(t);       // b^(8 * 2^skip)
-  for (int j = 0; j < count; j++) {
-    w[j] = t;
+// the scan weights b^(KD_CH * 2^j) (within a block) and b^(KD_BLOCK * 2^j) (across blocks), hat form: 21 dependent
+// squarings that every thread of every launch used to repeat (they were a third of a division's latency); computed
+// once on the host with the same limb code and passed as a kernel argument
+struct KatePowers {
+  f29 b_hat;
+  f29 chunk[8];   // b^(8 * 2^j)
+  f29 block[10];  // b^(2048 * 2^j)
+};
+static KatePowers kate_powers(const words8& b) {
+  KatePowers pw;
+  pw.b_hat = f29_mul<P>(f29_from_words<0>(b.l), f29_const<P>(P::r266));   // = f29_words_to_r261
+  f29 t = pw.b_hat;
+  for (int i = 0; i < 3; i++) t = f29_sqr<P>(t);
+  for (int j = 0; j < 8; j++) {
+    pw.chunk[j] = t;
     t = f29_sqr<P>(t);
   }
+  for (int j = 0; j < 10; j++) {   // t = b^(8 * 2^8) = b^2048 here
+    pw.block[j] = t;
+    t = f29_sqr<P>(t);
+  }
+  return pw;
 }
-__global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ a, uint32_t n, words8 b,
+__global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ a, uint32_t n, KatePowers pw,
                                                    fp_words* __restrict__ bval) {
   __shared__ uint32_t sh[KD_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
-  f29 w[8], vals[KD_CH];
-  const f29 b_hat = f29_words_to_r261<P>(b.l);
-  kd_powers(b_hat, w, 8, 0);
-  f29 local = kd_local(a, n, first, b_hat, vals);
-  f29 s = block_suffix_geometric(local, w, sh, tid, KD_THREADS);
+  f29 vals[KD_CH];
+  f29 local = kd_local(a, n, first, pw.b_hat, vals);
+  f29 s = block_suffix_geometric(local, pw.chunk, sh, tid, KD_THREADS);
   if (tid == 0) store_hat(bval + blockIdx.x, s);
 }
 // carry[k] = sum_{u > k} bval[u] * (b^KD_BLOCK)^(u - k - 1): the value of s just above block k
-__global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ bval, uint32_t nblk, words8 b) {
+__global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ bval, uint32_t nblk, KatePowers pw) {
   __shared__ uint32_t sh[1024][9];
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;        // nthr = power of two >= nblk: log2(nthr) scan steps
-  f29 w[10];
-  kd_powers(f29_words_to_r261<P>(b.l), w, 10, 8);             // b^(KD_BLOCK * 2^j)
   f29 mine = tid < nblk ? load_hat(bval + tid) : f29_zero();
-  block_suffix_geometric(mine, w, sh, tid, nthr);             // sh[t] = inclusive suffix value
+  block_suffix_geometric(mine, pw.block, sh, tid, nthr);      // sh[t] = inclusive suffix value
   f29 carry = f29_zero();
   if (tid + 1 < nthr) {
 #pragma unroll
@@ -274,23 +284,24 @@ __global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ 
   __syncthreads();
   if (tid < nblk) store_hat(bval + tid, carry);
 }
-__global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a, uint32_t n, words8 b,
+__global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a, uint32_t n, KatePowers pw,
                                                   const fp_words* __restrict__ carry, fp_words* __restrict__ q_out,
                                                   fp_words* __restrict__ rem_out) {
   __shared__ uint32_t sh[KD_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
-  f29 w[8], vals[KD_CH];
-  const f29 b_hat = f29_words_to_r261<P>(b.l);
-  kd_powers(b_hat, w, 8, 0);
+  f29 vals[KD_CH];
+  const f29& b_hat = pw.b_hat;
+  const f29* w = pw.chunk;
   f29 local = kd_local(a, n, first, b_hat, vals);
   // the top thread's chunk sees the block carry: s(lo) = local + b^KD_CH * carry
-  if (tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), w[0]);
+  // (a single-block division has no carries: carry == nullptr)
+  if (carry && tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), w[0]);
   block_suffix_geometric(local, w, sh, tid, KD_THREADS);      // sh[t] = s at the bottom of thread t's chunk
   f29 run = f29_zero();                                        // s just above this thread's chunk
   if (tid + 1 < KD_THREADS) {
 #pragma unroll
     for (int q = 0; q < 9; q++) run.l[q] = sh[tid + 1][q];
-  } else {
+  } else if (carry) {
     run = load_hat(carry + blockIdx.x);
   }
 #pragma unroll
@@ -450,11 +461,16 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
   if (n == 0) return hipSuccess;
   const uint32_t nblk = (uint32_t)((n + KD_BLOCK - 1) / KD_BLOCK);
   if (nblk > 1024) return hipErrorInvalidValue;
-  kate_blocks<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp);
+  const KatePowers pw = kate_powers(b);
+  if (nblk == 1) {  // n <= 2048: the block's suffix scan is the whole division, one launch instead of three
+    kate_write<<<1, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, pw, nullptr, d_q, d_rem);
+    return hipGetLastError();
+  }
+  kate_blocks<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, pw, d_tmp);
   uint32_t scan_threads = 64;
   while (scan_threads < nblk) scan_threads <<= 1;
-  kate_scan_blocks<<<1, scan_threads, 0, stream>>>(d_tmp, nblk, b);
-  kate_write<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, b, d_tmp, d_q, d_rem);
+  kate_scan_blocks<<<1, scan_threads, 0, stream>>>(d_tmp, nblk, pw);
+  kate_write<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, pw, d_tmp, d_q, d_rem);
   return hipGetLastError();
 }
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
