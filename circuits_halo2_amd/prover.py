@@ -320,14 +320,16 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     for j in range(len(pk.sigma_coeff)):
         polys[("sigma", j)] = pk.sigma_coeff[j]
     point = lambda rot: x * pow(omega, rot % n, R) % R
-    ev = A.eval_polynomial_batch([polys[(kind, c)] for kind, c, _ in EVAL_ORDER],
-                                 np.concatenate([_fr_bytes(point(rot)) for _, _, rot in EVAL_ORDER]))
+    ev = A.eval_polynomial_batch([polys[(kind, c)] for kind, c, _ in EVAL_ORDER] + pieces,     # the quotient pieces ride along
+                                 np.concatenate([_fr_bytes(point(rot)) for _, _, rot in EVAL_ORDER] + [_fr_bytes(x)] * len(pieces)))
     rinv = pow(1 << 256, -1, R)
     evals = {key: int.from_bytes(bytes(e), "little") * rinv % R for key, e in zip(EVAL_ORDER, ev)}
     for key in EVAL_ORDER:
         tr.write_scalar(evals[key])
     polys[("h", None)] = A.lincomb(pieces, np.concatenate([_fr_bytes(pow(x_n, i, R)) for i in range(len(pieces))]))
-    h_eval = int.from_bytes(bytes(A.eval_polynomial_batch([polys[("h", None)]], _fr_bytes(x))[0]), "little") * rinv % R
+    h_eval = 0                                                    # h(x) = sum_i x^(n i) h_i(x)
+    for e in reversed(ev[len(EVAL_ORDER):]):
+        h_eval = (h_eval * x_n + int.from_bytes(bytes(e), "little") * rinv) % R
 
     def eval_of(key, rot):
         return h_eval if key == ("h", None) else evals[(key[0], key[1], rot)]

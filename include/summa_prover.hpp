@@ -746,8 +746,12 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     ev_polys.push_back(poly.at(q.key));
     ev_points.push_back(point(q.rot));
   }
-  std::vector<Fr> ev(order.size());
-  ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)order.size(), nullptr,
+  for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) {   // the quotient pieces at x ride along: h(x) = sum_i x^(n i) h_i(x)
+    ev_polys.push_back(pieces[i]);
+    ev_points.push_back(x);
+  }
+  std::vector<Fr> ev(ev_polys.size());
+  ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)ev_polys.size(), nullptr,
                                reinterpret_cast<uint8_t*>(ev.data())), "evaluations");
   std::map<std::pair<Key, int>, Fr> evals;
   for (size_t i = 0; i < order.size(); i++) {
@@ -762,11 +766,8 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     ck(sg_fr_lincomb_dev(pieces.data(), pw[0].bytes(), QUOTIENT_PIECES, n, h_comb.p, nullptr), "h lincomb");
   }
   poly[{H_, 0}] = h_comb.p;
-  Fr h_eval;
-  {
-    void* hp[1] = {h_comb.p};
-    ck(sg_fr_eval_poly_batch_dev(hp, n, x.bytes(), 1, nullptr, reinterpret_cast<uint8_t*>(h_eval.l)), "h evaluation");
-  }
+  Fr h_eval = Fr::zero();
+  for (uint32_t i = QUOTIENT_PIECES; i-- > 0;) h_eval = h_eval * x_n + ev[order.size() + i];
   auto eval_of = [&](const Key& key, int rot) { return key.kind == H_ ? h_eval : evals.at({key, rot}); };
 
   lap("5_evaluations");
