@@ -71,6 +71,17 @@ int main(int argc, char** argv) {
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
   try {
     ck(sg_init(0), "sg_init");
+    if (const char* sp = std::getenv("SG_PARAMS")) {   // e.g. SG_PARAMS=msm.log_seg=4,msm.quad=0 (tuning sweeps)
+      std::string all(sp);
+      size_t pos = 0;
+      while (pos < all.size()) {
+        const size_t end = all.find(',', pos) == std::string::npos ? all.size() : all.find(',', pos);
+        const std::string kv = all.substr(pos, end - pos);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos) ck(sg_set_param(kv.substr(0, eq).c_str(), std::atoll(kv.substr(eq + 1).c_str())), "sg_set_param");
+        pos = end + 1;
+      }
+    }
     Reader rd(argv[1]);
     char magic[8];
     rd.read(magic, 8);
