@@ -112,7 +112,7 @@ class MsmEngine {
   struct Job {
     BatchPtrs bp{};
     uint32_t M = 1;
-    size_t n = 0;
+    size_t n = 0, entries = 0;
     hipStream_t stream = nullptr;
     uint8_t* out = nullptr;
     MsmTimings* tm = nullptr;

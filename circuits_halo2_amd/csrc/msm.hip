@@ -521,9 +521,11 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ toff,
                                                       const uint2* __restrict__ order, uint32_t log_L,
-                                                      uint32_t ntasks, xyzz29_mem* __restrict__ partial) {
+                                                      const uint32_t* __restrict__ meta, xyzz29_mem* __restrict__ partial) {
+  // the grid covers a host-side upper bound (launched before the host has read the counters back, so that the read
+  // overlaps this kernel instead of leaving the queue empty); the exact task count is meta[1]
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntasks) return;
+  if (t >= meta[1]) return;
   const uint2 o = order[t];
   const uint32_t b = o.x, seg = o.y;
   const g1_affine_mem* __restrict__ bases = bp.bases[b / buckets_per_msm];
@@ -1192,6 +1194,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
   const uint32_t NB = j.NB = (j.fixed ? (uint32_t)M : W) * nbw;
   if (NB > (1u << 21)) return hipErrorInvalidValue;
   const size_t entries = (size_t)W * n;
+  j.entries = entries;
   if (entries >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // bucket offsets are 32-bit (n <= 2^27 at c = 16)
   // task length: deep enough to amortise, shallow enough that the longest dependent chain of
   // additions stays a small multiple of the per-lane share of the work
@@ -1307,28 +1310,31 @@ hipError_t MsmEngine::enqueue_back() {
   Job& j = job_;
   if (j.trivial) return hipSuccess;
   hipStream_t stream = j.stream;
-  SG_TRY(hipEventSynchronize(ev_meta_));
-  const uint32_t ntasks = j.ntasks = h_meta_[1], max_cnt = j.max_cnt = h_meta_[2];
-  if (!ntasks) {  // every digit was zero
-    j.all_zero = true;
-    return hipSuccess;
-  }
   const uint32_t Wm = j.fixed ? 1u : j.wp.W;  // bucket sets ("windows") per MSM
   const uint32_t NB = j.NB, W = Wm * j.M, nbw = j.nbw, log_L = j.log_L;
+  // tasks: sum_b ceil(cnt_b / L) <= (#non-empty buckets) + entries / L -- enough to size the task tables and the
+  // accumulation launch without the counters; the host reads them (for the merge rounds) while that launch runs
+  const uint32_t ntasks_ub = (uint32_t)(std::min<size_t>(NB, j.entries) + (j.entries >> log_L));
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
-  SG_TRY(partial_[0].reserve(ntasks));
+  SG_TRY(partial_[0].reserve(ntasks_ub));
   {
     const uint32_t nbins = std::min<uint32_t>(1u << log_L, TASK_BINS - 1) + 1;  // task lengths 0 .. L
     const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
     SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
-    SG_TRY(order_.reserve(ntasks));
+    SG_TRY(order_.reserve(ntasks_ub));
     msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
     msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins);
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
   }
   const uint32_t at = cfg_.acc_threads ? cfg_.acc_threads : 128;  // measured: 128 beats 256 by 5 % at 2^20 (finer-grained tail), 64 loses in fixed mode
-  msm_accumulate<<<(ntasks + at - 1) / at, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
-                                                           toff_[0].p, order_.p, log_L, ntasks, partial_[0].p);
+  msm_accumulate<<<(ntasks_ub + at - 1) / at, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
+                                                              toff_[0].p, order_.p, log_L, meta_.p, partial_[0].p);
+  SG_TRY(hipEventSynchronize(ev_meta_));
+  const uint32_t ntasks = j.ntasks = h_meta_[1], max_cnt = j.max_cnt = h_meta_[2];
+  if (!ntasks) {  // every digit was zero (the launches above found nothing to do)
+    j.all_zero = true;
+    return hipSuccess;
+  }
   const xyzz29_mem* cur = partial_[0].p;
   // quad-cooperative additions pay off while the reduction is a latency chain (few buckets in total);
   // with many windows it is throughput-bound and one lane per addition is the efficient shape
