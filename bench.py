@@ -29,7 +29,7 @@ MADS_PER_MIXED_ADD = 6 * 162 + 2 * 126 + 243   # v_mad_u64_u32 per XYZZ += affin
 MAD_PEAK = 30.1e12             # measured v_mad_u64_u32 lane-ops/s, full occupancy (microbench2)
 
 
-def pmc_traffic(kernel, log_n, grid_threads=None):
+def pmc_traffic(kernel, log_n, grid_threads=None, job_threads=None):
     """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/*_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     same command at the default 2^20 workload); null when no matching profile exists."""
@@ -38,8 +38,11 @@ def pmc_traffic(kernel, log_n, grid_threads=None):
         return {}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
         pm = json.load(open(path)).get("pmc", {})
+        exact = pm.get(f"{kernel}@grid{grid_threads}@job{job_threads}")   # the timed job's own launches (same grid AND job shape)
+        if exact and "FETCH_SIZE_KB_avg" in exact and "WRITE_SIZE_KB_avg" in exact:
+            pm = {f"{kernel}@grid{grid_threads}": exact}
         cands = [(int(k.split("@grid")[1]), v) for k, v in pm.items()
-                 if k.startswith(kernel + "@") and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v]
+                 if k.startswith(kernel + "@") and "@job" not in k and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v]
         if cands:
             # the same kernel also runs at other sizes (fused batches): take the launch shape of the timed MSM
             _, v = min(cands, key=lambda gv: abs(gv[0] - grid_threads)) if grid_threads else max(cands)
@@ -131,10 +134,10 @@ def main():
         line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
-        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, -(-reps[0]["tasks"] // 256) * 256))
+        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, reps[0]["accumulate_threads"], n))
         line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
                                  ("digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}
-        line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket")})
+        line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket", "accumulate_threads")})
         # integer-ALU view (MSM is VALU-bound): mixed adds * 10 products * ~560 VALU instr
         adds = reps[0]["windows"] * n
         mads = adds * MADS_PER_MIXED_ADD
@@ -149,8 +152,9 @@ def main():
         import glob as _glob
         for path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "*_valu.json")), reverse=True):
             pg = json.load(open(path)).get("per_grid", {})
-            cands = [(abs(int(k.split("@grid")[1]) - (-(-reps[0]["tasks"] // 256) * 256)), v) for k, v in pg.items()
-                     if k.startswith("sg::msm_accumulate@")]
+            exact = pg.get(f"sg::msm_accumulate@grid{reps[0]['accumulate_threads']}@job{n}")
+            cands = [(0, exact)] if exact else [(abs(int(k.split("@grid")[1]) - reps[0]["accumulate_threads"]), v) for k, v in pg.items()
+                                                if k.startswith("sg::msm_accumulate@") and "@job" not in k]
             if cands:
                 v = min(cands, key=lambda kv: kv[0])[1]
                 line["alu"].update({"valu_busy_pct": v.get("VALUBusy_avg"), "valu_lane_utilization_pct": v.get("VALUUtilization_avg"),

@@ -29,7 +29,7 @@ struct MsmConfig {
 
 struct MsmTimings {
   float digits_ms = 0, sort_ms = 0, accumulate_ms = 0, reduce_ms = 0, total_ms = 0;
-  uint32_t window_bits = 0, windows = 0, tasks = 0, max_bucket = 0;
+  uint32_t window_bits = 0, windows = 0, tasks = 0, max_bucket = 0, accumulate_threads = 0;
 };
 
 template <typename T>
@@ -119,7 +119,7 @@ class MsmEngine {
     bool trivial = false, all_zero = false, fixed = false;
     uint32_t red2d = 0;  // 0: scan-based reduction, 1: 2-D with host weights, 2: 2-D with device weights
     uint32_t n_tab = 0;
-    uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0;
+    uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0, acc_threads = 0;
     WindowPlan wp{};
     hipEvent_t ev[5];
   };

@@ -1327,6 +1327,7 @@ hipError_t MsmEngine::enqueue_back() {
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
   }
   const uint32_t at = cfg_.acc_threads ? cfg_.acc_threads : 128;  // measured: 128 beats 256 by 5 % at 2^20 (finer-grained tail), 64 loses in fixed mode
+  j.acc_threads = (ntasks_ub + at - 1) / at * at;
   msm_accumulate<<<(ntasks_ub + at - 1) / at, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
                                                               toff_[0].p, order_.p, log_L, meta_.p, partial_[0].p);
   SG_TRY(hipEventSynchronize(ev_meta_));
@@ -1556,6 +1557,7 @@ hipError_t MsmEngine::finish() {
     tm->windows = j.wp.W;
     tm->tasks = j.ntasks;
     tm->max_bucket = j.max_cnt;
+    tm->accumulate_threads = j.acc_threads;
     drop_events();
   }
   return hipSuccess;

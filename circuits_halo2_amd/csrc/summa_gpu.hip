@@ -336,6 +336,7 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
     timings->digits_ms = tm.digits_ms; timings->sort_ms = tm.sort_ms; timings->accumulate_ms = tm.accumulate_ms;
     timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
     timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
+    timings->accumulate_threads = tm.accumulate_threads;
   }
   return SG_OK;
 }
@@ -554,6 +555,7 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
     timings->digits_ms = tm.digits_ms; timings->sort_ms = tm.sort_ms; timings->accumulate_ms = tm.accumulate_ms;
     timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
     timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
+    timings->accumulate_threads = tm.accumulate_threads;
   }
   return SG_OK;
 }

@@ -37,7 +37,8 @@ class SummaGpuError(RuntimeError):
 class MsmTimings(C.Structure):
     _fields_ = [("digits_ms", C.c_float), ("sort_ms", C.c_float), ("accumulate_ms", C.c_float),
                 ("reduce_ms", C.c_float), ("total_ms", C.c_float), ("window_bits", C.c_uint32),
-                ("windows", C.c_uint32), ("tasks", C.c_uint32), ("max_bucket", C.c_uint32)]
+                ("windows", C.c_uint32), ("tasks", C.c_uint32), ("max_bucket", C.c_uint32),
+                ("accumulate_threads", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -298,6 +298,7 @@ int sg_mst_build_dev(const void* d_usernames, const void* d_leaf_balances, uint3
 typedef struct {
   float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream */
   uint32_t window_bits, windows, tasks, max_bucket;
+  uint32_t accumulate_threads; /* threads of the msm_accumulate launch (sized by an upper bound of `tasks`) */
 } sg_msm_timings;
 /* as sg_msm_g1_dev, additionally fills per-phase HIP event timings */
 int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64],

@@ -17,25 +17,43 @@ if ks:
 # per (kernel, grid) durations from the trace: needed because one kernel runs at several sizes
 tr = glob.glob(os.path.join(src, "*", "*_kernel_trace.csv"))
 per = collections.defaultdict(list)
+# msm_accumulate launches of different jobs can share a grid (the launch is sized by an upper bound of the task count):
+# they are told apart by the job shape, i.e. the thread count of the msm_digits launch that precedes them on the queue
+acc_jobs = collections.defaultdict(list)
 if tr:
-    for r in csv.DictReader(open(tr[0])):
-        per[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])].append(
-            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    last_digits = {}
+    for r in sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"])):
+        name, grid = r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"])
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        per[(name, grid, r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])].append(dur)
+        if name == "sg::msm_digits":
+            last_digits[r["Queue_Id"]] = grid
+        elif name == "sg::msm_accumulate":
+            acc_jobs[(grid, last_digits.get(r["Queue_Id"], 0))].append(dur)
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     cc = glob.glob(os.path.join(f"{src}_{kind}", "*", "*_counter_collection.csv"))
     if not cc:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(cc[0])):
+    last_digits = {}
+    for r in sorted(csv.DictReader(open(cc[0])), key=lambda r: int(r["Start_Timestamp"])):
+        name, grid = r["Kernel_Name"].split("(")[0], int(r["Grid_Size"])
+        if name == "sg::msm_digits":
+            last_digits[r["Queue_Id"]] = grid
         if r["Counter_Name"] == ctr:
-            agg[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+            agg[(name, grid)].append(float(r["Counter_Value"]))
+            if name == "sg::msm_accumulate":
+                agg[(name, f"{grid}@job{last_digits.get(r['Queue_Id'], 0)}")].append(float(r["Counter_Value"]))
     for (k, g), v in agg.items():
         pmc.setdefault(f"{k}@grid{g}", {})[ctr + "_KB_avg"] = sum(v) / len(v)
         pmc[f"{k}@grid{g}"]["launches_" + kind] = len(v)
 summary = {"tag": tag, "kernels": [
     {"kernel": k, "grid_threads": g, "vgpr": vg, "lds": lds, "scratch": sc, "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
-    for (k, g, vg, lds, sc), v in sorted(per.items(), key=lambda kv: -sum(kv[1]))], "pmc": pmc,
+    for (k, g, vg, lds, sc), v in sorted(per.items(), key=lambda kv: -sum(kv[1]))],
+    "msm_accumulate_by_job": [{"grid_threads": g, "job_threads": j, "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+                              for (g, j), v in sorted(acc_jobs.items(), key=lambda kv: -sum(kv[1]))],
+    "pmc": pmc,
     "note": "PMC units as reported by rocprofv3 (KB). gfx950: FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md); 64-B gathers are uncalibrated. Collected in separate --pmc passes of the same bench command."}
 json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
 print("wrote", out, tag, len(per), "kernel configs")

@@ -4,10 +4,15 @@ import collections, csv, glob, json, sys
 tag = sys.argv[1]
 cc = glob.glob(f"gpurun_out/prof_{tag}_valu/*/*_counter_collection.csv")[0]
 per_k, per_g = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(cc)):
+last_digits = {}
+for r in sorted(csv.DictReader(open(cc)), key=lambda r: int(r["Start_Timestamp"])):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    if name == "sg::msm_digits":
+        last_digits[r["Queue_Id"]] = r["Grid_Size"]
     per_k[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     per_g[f"{name}@grid{r['Grid_Size']}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if name == "sg::msm_accumulate":   # launches of different jobs can share a grid: also keyed by the job shape
+        per_g[f"{name}@grid{r['Grid_Size']}@job{last_digits.get(r['Queue_Id'], 0)}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = lambda d: {f"{c}_avg": round(sum(v) / len(v), 2) for c, v in d.items()}
 main = ("msm_accumulate", "ntt_pass", "gates_kernel", "quot_", "mst_", "msm_reduce")
 out = {"tag": tag, "note": "rocprofv3 --pmc VALUBusy VALUUtilization over the default bench.py run (separate pass): VALUBusy = % of cycles "
