@@ -69,6 +69,17 @@ extern "C" {
     ) -> c_int;
     pub fn sg_fr_kate_division_dev(d_a: *const c_void, n: size_t, b: *const u8, d_q: *mut c_void, rem: *mut u8, stream: *mut c_void) -> c_int;
     pub fn sg_g2_generator_mul(scalar: *const u8, out128: *mut u8) -> c_int;
+    // blinding factors / the random polynomial (OsRng upstream): a 32-byte OS-random key expanded by ChaCha20 on the device
+    pub fn sg_fr_random_dev(key: *const u8, stream_id: u64, d_out: *mut c_void, n: size_t, stream: *mut c_void) -> c_int;
+    // lookup::prover::permute_expression_pair for range tables (returns -5 when the table is not small integers)
+    pub fn sg_lookup_permute_small_dev(
+        d_input: *const c_void,
+        d_table: *const c_void,
+        rows: size_t,
+        d_permuted_input: *mut c_void,
+        d_permuted_table: *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
 }
 
 const _: () = assert!(std::mem::size_of::<Fr>() == 32);
