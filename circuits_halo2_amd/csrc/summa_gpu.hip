@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "host_curve.h"
+#include "host_pairing.h"
 #include "msm.h"
 #include "ntt.h"
 #include "quotient.h"
@@ -879,6 +880,53 @@ int sg_g1_fixed_base_mul(const uint8_t* scalars, size_t n, uint8_t* out_affine) 
 int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]) {
   if (!scalar || !out) return fail(SG_ERR_INVALID, "sg_g2_generator_mul: null argument");
   sg::host::g2_generator_mul(scalar, out);
+  return SG_OK;
+}
+// The verifier's last step (halo2 `SingleStrategy` -> multi_miller_loop + final_exponentiation; the EVM's precompile
+// 0x08): *ok = (prod_i e(g1[i], g2[i]) == 1).  Host code (host_pairing.h); the slopes of a G2 point are computed once
+// and cached by its bytes (the two G2 points of a KZG check are fixed per SRS).
+int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok) {
+  if (!ok || (n && (!g1_points || !g2_points))) return fail(SG_ERR_INVALID, "sg_pairing_check: null argument");
+  if (n > 64) return fail(SG_ERR_INVALID, "sg_pairing_check: at most 64 pairs");
+  using namespace sg::host;
+  static std::mutex cache_mu;
+  static std::map<std::string, PreparedG2> cache;
+  std::vector<Affine> ps;
+  std::vector<const PreparedG2*> qs;
+  const Fq three = fq_from_u64(3);
+  for (size_t i = 0; i < n; i++) {
+    Affine p;
+    std::memcpy(p.x.v, g1_points + 64 * i, 32);
+    std::memcpy(p.y.v, g1_points + 64 * i + 32, 32);
+    const bool p_inf = p.x.is_zero() && p.y.is_zero();
+    if (Fq::geq_p(p.x.v) || Fq::geq_p(p.y.v)) return fail(SG_ERR_INVALID, "sg_pairing_check: G1 coordinate not reduced");
+    if (!p_inf && !(p.y.sqr() == p.x.sqr() * p.x + three)) return fail(SG_ERR_INVALID, "sg_pairing_check: G1 point not on the curve");
+    const uint8_t* qb = g2_points + 128 * i;
+    G2AffinePt q;
+    std::memcpy(q.x.c0.v, qb, 32); std::memcpy(q.x.c1.v, qb + 32, 32);
+    std::memcpy(q.y.c0.v, qb + 64, 32); std::memcpy(q.y.c1.v, qb + 96, 32);
+    q.inf = q.x.is_zero() && q.y.is_zero();
+    if (Fq::geq_p(q.x.c0.v) || Fq::geq_p(q.x.c1.v) || Fq::geq_p(q.y.c0.v) || Fq::geq_p(q.y.c1.v))
+      return fail(SG_ERR_INVALID, "sg_pairing_check: G2 coordinate not reduced");
+    if (!g2_on_curve(q)) return fail(SG_ERR_INVALID, "sg_pairing_check: G2 point not on the twist");
+    if (p_inf || q.inf) continue;  // e(O, Q) = e(P, O) = 1
+    const PreparedG2* prep;
+    {
+      std::lock_guard<std::mutex> lk(cache_mu);
+      std::string key(reinterpret_cast<const char*>(qb), 128);
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        if (cache.size() >= 64) cache.clear();
+        it = cache.emplace(key, prepare_g2(q)).first;
+      }
+      prep = &it->second;   // std::map nodes are stable; entries are only dropped by the clear() above
+      ps.push_back(p);
+      qs.push_back(new PreparedG2(*prep));
+    }
+  }
+  Fq12 f = final_exponentiation(multi_miller_loop(ps, qs));
+  for (const PreparedG2* q : qs) delete q;
+  *ok = f.is_one() ? 1 : 0;
   return SG_OK;
 }
 // ParamsKZG::<Bn256>::setup(k, rng) with tau supplied by the caller's RNG (zk_prover/src/circuits/

@@ -89,33 +89,117 @@ def _point(c64: np.ndarray):
 
 
 class EvmTranscriptWriter:
-    """Keccak256 transcript + proof stream of halo2_solidity_verifier's `Keccak256Transcript` [REF :85-110]"""
+    """Keccak256 transcript + proof stream of halo2_solidity_verifier's `Keccak256Transcript` [REF :85-110], the
+    flavour `gen_proof_solidity_calldata` proves with [REF zk_prover/src/circuits/utils.rs:170].  `vk.hash_into` is
+    `common_scalar(vk digest)`: the buffer starts with it [REF InclusionVerifier.sol:217, 280-296]."""
 
-    def __init__(self, vk_digest: int):
-        self.buf = vk_digest.to_bytes(32, "big")
+    def __init__(self, vk_digest: int | None = None):
+        self.buf = b""
         self.proof = bytearray()
+        self._squeezed = False
+        if vk_digest is not None:
+            self.common_scalar(vk_digest)
 
     def common_scalar(self, v: int):
         self.buf += v.to_bytes(32, "big")
+        self._squeezed = False
 
     def write_scalar(self, v: int):
         self.common_scalar(v)
         self.proof += v.to_bytes(32, "big")
 
+    def common_point(self, p):
+        if p is None:
+            raise ValueError("cannot write points at infinity to the transcript")
+        self.buf += p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
+        self._squeezed = False
+
     def write_point(self, p):
-        enc = p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
-        self.buf += enc
-        self.proof += enc
+        self.common_point(p)
+        self.proof += p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
 
     def squeeze_challenge(self) -> int:
-        h = keccak256(bytes(self.buf))
+        """keccak(buffer) mod r, the hash becomes the buffer; a squeeze right after a squeeze hashes `hash || 0x01`"""
+        h = keccak256(bytes(self.buf[:32]) + b"\x01") if self._squeezed else keccak256(bytes(self.buf))
         self.buf = h
+        self._squeezed = True
         return int.from_bytes(h, "big") % R
 
-    def squeeze_challenge_again(self) -> int:
-        h = keccak256(bytes(self.buf[:32]) + b"\x01")
-        self.buf = h
-        return int.from_bytes(h, "big") % R
+    squeeze_challenge_again = squeeze_challenge
+
+    def finalize(self) -> bytes:
+        return bytes(self.proof)
+
+
+def compress_g1(p) -> bytes:
+    """halo2curves `G1Affine::to_bytes` (GroupEncoding): x as 32 bytes little-endian, bit 6 of the last byte = the
+    parity of y, bit 7 = the point at infinity (bn256 Fq leaves two spare bits)  [UPSTREAM-RECALL: halo2curves 0.1.0
+    derive/curve.rs `new_curve_impl!`; no fixture of the reference holds a compressed point]"""
+    if p is None:
+        return bytes(31) + b"\x80"
+    enc = bytearray(p[0].to_bytes(32, "little"))
+    enc[31] |= (p[1] & 1) << 6
+    return bytes(enc)
+
+
+class Blake2bWrite:
+    """`Blake2bWrite<_, G1Affine, Challenge255<_>>`, the transcript `full_prover` proves with
+    [REF zk_prover/src/circuits/utils.rs:93-101] (halo2_proofs transcript.rs): Blake2b-512
+    personalised "Halo2-Transcript"; a point is absorbed as prefix 1 || x || y (32-byte little-endian canonical
+    reprs) and written to the proof compressed (32 B), a scalar as prefix 2 || repr; a challenge absorbs prefix 0,
+    finalises a CLONE of the state to 64 bytes and reduces them as a 512-bit little-endian integer mod r
+    (`from_uniform_bytes`).  The hash itself is the standard library's (as upstream takes it from blake2b_simd);
+    the oracle carries an independent implementation pinned on RFC 7693 (tests/test_transcript_cpu.py)."""
+
+    def __init__(self, vk_digest: int | None = None):
+        import hashlib
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.proof = bytearray()
+        if vk_digest is not None:
+            self.common_scalar(vk_digest)
+
+    def common_scalar(self, v: int):
+        self.state.update(b"\x02" + v.to_bytes(32, "little"))
+
+    def write_scalar(self, v: int):
+        self.common_scalar(v)
+        self.proof += v.to_bytes(32, "little")
+
+    def common_point(self, p):
+        if p is None:
+            raise ValueError("cannot write points at infinity to the transcript")
+        self.state.update(b"\x01" + p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little"))
+
+    def write_point(self, p):
+        self.common_point(p)
+        self.proof += compress_g1(p)
+
+    def squeeze_challenge(self) -> int:
+        self.state.update(b"\x00")
+        return int.from_bytes(self.state.copy().digest(), "little") % R
+
+    squeeze_challenge_again = squeeze_challenge
+
+    def finalize(self) -> bytes:
+        return bytes(self.proof)
+
+
+def verifying_key_digest(k: int, n_currencies: int, fixed_comms, permutation_comms) -> int:
+    """The scalar `vk.hash_into` feeds the transcript (`VerifyingKey::transcript_repr`).  Upstream derives it as
+    Blake2b-512 (personalised "Halo2-Verify-Key") of  len(s) || s  with s = the `{:?}` rendering of the pinned
+    verification key, reduced from 64 bytes mod r.  The construction here is the same; the rendered string is this
+    repository's own (domain size, circuit shape, the commitments): halo2's Debug output of the whole constraint
+    system lives in the un-vendored crate and is not reproduced, so the value differs from a Rust-built key's.  For
+    the one key whose halo2 value the reference holds -- MstInclusionCircuit<4,2,8>, k = 11, its SRS: `vk_digest` of
+    contracts/src/InclusionVerifier.sol:217 -- callers inject that value (tests/golden/kat.json)."""
+    import hashlib
+    pt = lambda p: "(0x%064x, 0x%064x)" % p
+    s = ("PinnedVerificationKey { scalar_modulus: \"0x%064x\", k: %d, circuit: MstInclusion { n_currencies: %d }, "
+         "fixed_commitments: [%s], permutation: VerifyingKey { commitments: [%s] } }"
+         % (R, k, n_currencies, ", ".join(pt(p) for p in fixed_comms), ", ".join(pt(p) for p in permutation_comms)))
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    h.update(len(s).to_bytes(8, "little") + s.encode())
+    return int.from_bytes(h.digest(), "little") % R
 
 
 class ProvingKey:
@@ -145,8 +229,7 @@ class ProvingKey:
         comms = params.commit_batch(self.fixed_lagrange + self.sigma_lagrange, lagrange=True)
         self.fixed_comms = [_point(c) for c in comms[:nf]]
         self.permutation_comms = [_point(c) for c in comms[nf:]]
-        digest = keccak256(b"".join(x.to_bytes(32, "big") + y.to_bytes(32, "big") for x, y in self.fixed_comms + self.permutation_comms))
-        self.vk_digest = int.from_bytes(digest, "big") % R
+        self.vk_digest = verifying_key_digest(k, n_currencies, self.fixed_comms, self.permutation_comms)
         torch.cuda.synchronize()
 
 
@@ -183,10 +266,16 @@ def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
     return a, s
 
 
-def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None = None, timings=None) -> bytes:
+def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None = None, timings=None, transcript=None,
+                 sanity_checks: bool = True) -> bytes:
     """advice: 3 device tensors (Lagrange, 2^k rows, Montgomery Fr); instances: list of ints -> proof bytes.
     `seed`: 32-byte ChaCha20 key for the blinding factors and the random polynomial (tests); default: the OS
-    entropy source."""
+    entropy source.  `transcript`: a fresh EvmTranscriptWriter (default; `gen_proof_solidity_calldata`'s flavour) or
+    Blake2bWrite (`full_prover`'s) -- upstream's `create_proof` takes it as an argument the same way.
+    `sanity_checks` (upstream's cargo feature of that name): refuse an assignment whose permutation or lookup grand
+    product does not close; without it such a witness yields a proof the verifier rejects, as upstream's default
+    build does (the reference's test of a wrong public input relies on that, circuits/tests.rs:125-152).  A lookup
+    input outside the table always raises (upstream: `permute_expression_pair` fails the prover)."""
     import torch
     # blinding values: a 32-byte key from the OS entropy source per proof, expanded by ChaCha20 on the device
     # (sg_fr_random_dev); every draw takes its own stream id
@@ -217,7 +306,8 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     ne = 1 << ext_k
     omega = pow(ROOT_OF_UNITY, 1 << (28 - k), R)
     none = np.zeros(0, dtype=np.uint8)
-    tr = EvmTranscriptWriter(pk.vk_digest)
+    tr = transcript if transcript is not None else EvmTranscriptWriter()
+    tr.common_scalar(pk.vk_digest)                    # vk.hash_into(transcript)
     for v in instances:
         tr.common_scalar(v)
     polys = {}      # key -> coefficient-form device polynomial (n coefficients)
@@ -274,10 +364,10 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
         z[32 * (u + 1):] = rand(n - u - 1)
         zs.append(z)
         delta_start = delta_start * pow(DELTA, len(chunk), R) % R
-    if last != 1:
+    if sanity_checks and last != 1:
         raise ValueError("permutation argument not satisfied by the assignment")
     lz = A.lookup_product(inp_d, pk.fixed_lagrange[4], pin_d, ptab_d, b_beta, b_gamma)
-    if _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
+    if sanity_checks and _ints(lz[32 * u:32 * (u + 1)])[0] != 1:
         raise ValueError("lookup argument not satisfied by the assignment")
     lz[32 * (u + 1):] = rand(n - u - 1)
     polys[("random", 0)] = rand(n)
@@ -393,7 +483,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
         raise ValueError("multi-open linearisation does not vanish at mu")
     tr.write_point(_point(params.commit(torch.cat([quo, zero_row]))))
     lap("6_multiopen")
-    return bytes(tr.proof)
+    return tr.finalize()
 
 
 def export_bundle(path: str, params, pk: ProvingKey, advice, instances) -> None:

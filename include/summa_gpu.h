@@ -152,6 +152,13 @@ int sg_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_affine
 /* The two G2 points of ParamsKZG (verifier side): out = scalar * G2 generator in halo2curves' G2Affine
  * layout (x.c0 || x.c1 || y.c0 || y.c1, 32-B Montgomery Fq each); g2 = 1 * G2, s_g2 = tau * G2.  Host code. */
 int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]);
+/* The pairing check that ends `verify_proof` (halo2 `SingleStrategy::process` -> `multi_miller_loop` +
+ * `final_exponentiation`, reached from `full_verifier` / `create_proof_checked`, zk_prover/src/circuits/utils.rs:
+ * 123-130, 185-191; precompile 0x08 in contracts/src/InclusionVerifier.sol:185-202):
+ * *ok = 1 iff prod_i e(g1[i], g2[i]) == 1.  g1: n x 64 B G1Affine, g2: n x 128 B G2Affine (halo2curves layout,
+ * Montgomery; identity = zeros).  Host code.  Points off the curve are SG_ERR_INVALID; G2 points are taken from
+ * the (trusted) SRS and are not subgroup-checked. */
+int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok);
 /* ParamsKZG::<Bn256>::setup(k, rng) (zk_prover/src/circuits/utils.rs:70) with tau = the field
  * element the caller drew from its RNG (32 B Montgomery Fr): g[i] = tau^i * G,
  * g_lagrange[i] = L_i(tau) * G, 2^k points of 64 B each.  The G2 elements of the SRS are only

@@ -539,3 +539,56 @@ def chacha_field_elements(key: bytes, stream_id: int, n: int):
                 break
             attempt += 1
     return out
+
+
+# ------------------------------------------------------------------ Blake2b (RFC 7693), for the Blake2b transcript
+# Independent of hashlib (the product uses the standard library's): pinned on the RFC's "abc" vector and against
+# hashlib on random inputs / personalisations by tests/test_transcript_cpu.py.
+_B2B_IV = [0x6A09E667F3BCC908, 0xBB67AE8584CAA73B, 0x3C6EF372FE94F82B, 0xA54FF53A5F1D36F1,
+           0x510E527FADE682D1, 0x9B05688C2B3E6C1F, 0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179]
+_B2B_SIGMA = [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], [14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3],
+              [11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4], [7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8],
+              [9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13], [2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9],
+              [12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11], [13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10],
+              [6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5], [10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0]]
+
+
+def _b2b_compress(h, block: bytes, t: int, last: bool):
+    m = [int.from_bytes(block[8 * i:8 * i + 8], "little") for i in range(16)]
+    v = list(h) + list(_B2B_IV)
+    v[12] ^= t & MASK64
+    v[13] ^= t >> 64
+    if last:
+        v[14] ^= MASK64
+    rotr = lambda x, n: ((x >> n) | (x << (64 - n))) & MASK64
+
+    def g(a, b, c, d, x, y):
+        v[a] = (v[a] + v[b] + x) & MASK64; v[d] = rotr(v[d] ^ v[a], 32)
+        v[c] = (v[c] + v[d]) & MASK64; v[b] = rotr(v[b] ^ v[c], 24)
+        v[a] = (v[a] + v[b] + y) & MASK64; v[d] = rotr(v[d] ^ v[a], 16)
+        v[c] = (v[c] + v[d]) & MASK64; v[b] = rotr(v[b] ^ v[c], 63)
+    for rnd in range(12):
+        s = _B2B_SIGMA[rnd % 10]
+        g(0, 4, 8, 12, m[s[0]], m[s[1]]); g(1, 5, 9, 13, m[s[2]], m[s[3]])
+        g(2, 6, 10, 14, m[s[4]], m[s[5]]); g(3, 7, 11, 15, m[s[6]], m[s[7]])
+        g(0, 5, 10, 15, m[s[8]], m[s[9]]); g(1, 6, 11, 12, m[s[10]], m[s[11]])
+        g(2, 7, 8, 13, m[s[12]], m[s[13]]); g(3, 4, 9, 14, m[s[14]], m[s[15]])
+    return [h[i] ^ v[i] ^ v[i + 8] for i in range(8)]
+
+
+def blake2b(data: bytes, digest_size: int = 64, person: bytes = b"", salt: bytes = b"", key: bytes = b"") -> bytes:
+    """unkeyed / keyed sequential Blake2b with salt and personalisation (parameter block of RFC 7693 section 2.5 with
+    the salt / personal words of the BLAKE2 specification)"""
+    assert 1 <= digest_size <= 64 and len(person) <= 16 and len(salt) <= 16 and len(key) <= 64
+    param = bytes([digest_size, len(key), 1, 1]) + bytes(28) + salt.ljust(16, b"\0") + person.ljust(16, b"\0")
+    h = [_B2B_IV[i] ^ int.from_bytes(param[8 * i:8 * i + 8], "little") for i in range(8)]
+    if key:
+        data = key.ljust(128, b"\0") + data
+    t = 0
+    while len(data) > 128:
+        t += 128
+        h = _b2b_compress(h, data[:128], t, False)
+        data = data[128:]
+    t += len(data)
+    h = _b2b_compress(h, data.ljust(128, b"\0"), t, True)
+    return b"".join(x.to_bytes(8, "little") for x in h)[:digest_size]

@@ -96,6 +96,68 @@ class EvmTranscript:
         return int.from_bytes(h, "big") % R
 
 
+class Blake2bTranscript:
+    """`Blake2bRead<_, G1Affine, Challenge255<_>>` as `full_verifier` uses it [REF zk_prover/src/circuits/utils.rs:118]
+    (halo2_proofs transcript.rs, restated from its published source -- SURVEY.md Appendix A): Blake2b-512 personalised
+    "Halo2-Transcript" over  prefix 1 || x || y  per point,  prefix 2 || repr  per scalar (32-byte little-endian
+    canonical values), prefix 0 per challenge; a challenge is the digest of the stream so far as a 512-bit
+    little-endian integer mod r.  Uses this directory's own Blake2b (pyref.blake2b, pinned on RFC 7693)."""
+
+    def __init__(self, vk_digest: int):
+        self.stream = b""
+        self.absorb_scalar(vk_digest)
+
+    def absorb_scalar(self, v: int):
+        self.stream += b"\x02" + v.to_bytes(32, "little")
+
+    def absorb_point(self, p):
+        self.stream += b"\x01" + p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little")
+
+    def squeeze(self) -> int:
+        from .pyref import blake2b
+        self.stream += b"\x00"
+        return int.from_bytes(blake2b(self.stream, 64, b"Halo2-Transcript"), "little") % R
+
+    squeeze_again = squeeze
+
+
+def decompress_g1(enc: bytes):
+    """halo2curves `G1Affine::from_bytes`: x little-endian, bit 6 of the last byte = parity of y, bit 7 = infinity
+    (recalled layout, see circuits_halo2_amd/prover.py::compress_g1); raises ValueError for a non-point"""
+    if len(enc) != 32:
+        raise ValueError("compressed point length")
+    last = enc[31]
+    x = int.from_bytes(enc[:31] + bytes([last & 0x3F]), "little")
+    if last & 0x80:
+        if x or last & 0x40:
+            raise ValueError("non-canonical identity")
+        raise ValueError("point at infinity in a proof")
+    if x >= Q:
+        raise ValueError("x not reduced")
+    y = pow((x * x * x + 3) % Q, (Q + 1) // 4, Q)       # q = 3 mod 4
+    if (y * y - x * x * x - 3) % Q:
+        raise ValueError("not on the curve")
+    if (y & 1) != ((last >> 6) & 1):
+        y = Q - y
+    return (x, y)
+
+
+def parse_proof_blake2b(proof: bytes):
+    """1632 bytes: the same sequence as parse_proof with compressed points and little-endian scalars"""
+    if len(proof) != 32 * (len(COMMIT_ORDER) + len(EVAL_ORDER) + 2):
+        raise ValueError("proof length")
+    pos = 0
+    comms = {}
+    for key in COMMIT_ORDER:
+        comms[key] = decompress_g1(proof[pos:pos + 32])
+        pos += 32
+    evals = {}
+    for key in EVAL_ORDER:
+        evals[key] = int.from_bytes(proof[pos:pos + 32], "little")
+        pos += 32
+    return comms, evals, decompress_g1(proof[pos:pos + 32]), decompress_g1(proof[pos + 32:pos + 64])
+
+
 def parse_proof(proof: bytes):
     """2144 bytes: 14 commitments (x || y big-endian), 35 evaluations, W, W' (SURVEY.md appendix C)."""
     if len(proof) != 64 * len(COMMIT_ORDER) + 32 * len(EVAL_ORDER) + 128:
@@ -284,18 +346,20 @@ def shplonk_pairing_inputs(comms, evals_of, x, zeta, nu, mu, w, w2, k=K):
     return lhs, w2, r_eval
 
 
-def verify(proof: bytes, instances, vk, trace=None) -> bool:
-    """vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"[, "k": 11, "n_currencies": 2]} (integers / int tuples).
+def verify(proof: bytes, instances, vk, trace=None, flavour: str = "evm") -> bool:
+    """flavour "evm": Keccak transcript, 2144-byte proof (the generated verifier's); "blake2b": `full_verifier`'s
+    Blake2b / Challenge255 transcript and compressed 1632-byte proof -- same protocol, same checks.
+    vk: {"vk_digest", "fixed_comms" [11], "permutation_comms" [6], "g2", "neg_s_g2"[, "k": 11, "n_currencies": 2]} (integers / int tuples).
     `trace`, if given, is filled with the intermediate values named as in tests/golden/k6_verifier_trace.json."""
     try:
-        comms, evals, w, w2 = parse_proof(proof)
+        comms, evals, w, w2 = parse_proof(proof) if flavour == "evm" else parse_proof_blake2b(proof)
     except ValueError:
         return False
     if any(v >= R for v in instances) or any(v >= R for v in evals.values()):
         return False
     if not all(on_curve(p) for p in list(comms.values()) + [w, w2]):
         return False
-    t = EvmTranscript(vk["vk_digest"])
+    t = EvmTranscript(vk["vk_digest"]) if flavour == "evm" else Blake2bTranscript(vk["vk_digest"])
     for v in instances:
         t.absorb_scalar(v)
     ch = {}

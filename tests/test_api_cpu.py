@@ -1,0 +1,226 @@
+"""CPU checks of the reference's L3 API mirror (circuits_halo2_amd/api.py), of the two transcript flavours, and of the
+product-side verifier (circuits_halo2_amd/verifier.py + the library's host-side pairing), pinned on the reference's own
+artefacts: its shipped proof K6 is accepted by the PRODUCT verifier (with the oracle's MSM injected for the one
+multi-scalar multiplication that needs the GPU), RFC 7693's vector pins the oracle's Blake2b, and the oracle's Blake2b /
+Keccak transcripts agree with the product's writers challenge by challenge."""
+import ctypes as C
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, fr_np
+
+from oracle import pairing as PA
+from oracle import pyref as PR
+from oracle import summa_verifier as SV
+
+H = lambda s: int(s, 16)
+
+
+# ------------------------------------------------------------------ Blake2b and the transcripts
+def test_oracle_blake2b_rfc7693_vector_and_hashlib():
+    want = ("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+            "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")
+    assert PR.blake2b(b"abc").hex() == want                                 # RFC 7693 appendix A
+    assert PR.blake2b(b"", 64).hex().startswith("786a02f742015903c6c6fd852552d272")
+    rng = random.Random(5)
+    for n in (0, 1, 63, 64, 127, 128, 129, 255, 256, 257, 1000):
+        d = bytes(rng.randrange(256) for _ in range(n))
+        assert PR.blake2b(d, 64, b"Halo2-Transcript") == hashlib.blake2b(d, digest_size=64, person=b"Halo2-Transcript").digest()
+        assert PR.blake2b(d, 32, b"p", b"s", b"key") == hashlib.blake2b(d, digest_size=32, person=b"p", salt=b"s", key=b"key").digest()
+
+
+def _random_points(rng, count):
+    return [PR.g1_mul(PR.G1_GEN, rng.randrange(1, PR.R)) for _ in range(count)]
+
+
+@pytest.mark.parametrize("flavour", ["evm", "blake2b"])
+def test_product_transcript_writers_match_the_oracle_readers(flavour):
+    """same absorb / squeeze sequence (the shape of a proof: digest, instances, point groups, consecutive challenges)
+    through the product's writer and the oracle's restated reader: equal challenges; the proof stream parses back"""
+    from circuits_halo2_amd import prover as P
+    rng = random.Random(11)
+    digest = rng.randrange(PR.R)
+    w = (P.EvmTranscriptWriter if flavour == "evm" else P.Blake2bWrite)()
+    w.common_scalar(digest)
+    o = (SV.EvmTranscript if flavour == "evm" else SV.Blake2bTranscript)(digest)
+    pts, scalars = _random_points(rng, 5), [rng.randrange(PR.R) for _ in range(4)]
+    for v in scalars[:2]:
+        w.common_scalar(v); o.absorb_scalar(v)
+    for p in pts[:3]:
+        w.write_point(p); o.absorb_point(p)
+    assert w.squeeze_challenge() == o.squeeze()
+    for p in pts[3:]:
+        w.write_point(p); o.absorb_point(p)
+    assert w.squeeze_challenge() == o.squeeze()
+    assert w.squeeze_challenge() == o.squeeze_again()            # beta, gamma: two challenges without new input
+    for v in scalars[2:]:
+        w.write_scalar(v); o.absorb_scalar(v)
+    c1, c2 = w.squeeze_challenge(), w.squeeze_challenge()
+    assert (c1, c2) == (o.squeeze(), o.squeeze_again()) and c1 != c2
+    proof = w.finalize()
+    if flavour == "evm":
+        assert len(proof) == 64 * 5 + 32 * 2
+        assert proof[:32] == pts[0][0].to_bytes(32, "big") and proof[-32:] == scalars[3].to_bytes(32, "big")
+    else:
+        assert len(proof) == 32 * 5 + 32 * 2
+        assert [SV.decompress_g1(proof[32 * i:32 * i + 32]) for i in range(5)] == pts
+        assert proof[-32:] == scalars[3].to_bytes(32, "little")
+    with pytest.raises(ValueError):
+        w.write_point(None)                                       # "cannot write points at infinity to the transcript"
+
+
+def test_blake2b_challenge_is_the_wide_reduction_of_the_stream_digest():
+    from circuits_halo2_amd import prover as P
+    w = P.Blake2bWrite()
+    w.common_scalar(7)
+    p = PR.g1_mul(PR.G1_GEN, 12345)
+    w.write_point(p)
+    stream = b"\x02" + (7).to_bytes(32, "little") + b"\x01" + p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little") + b"\x00"
+    want = int.from_bytes(hashlib.blake2b(stream, digest_size=64, person=b"Halo2-Transcript").digest(), "little") % PR.R
+    assert w.squeeze_challenge() == want
+
+
+def test_point_compression_round_trip_and_rejections():
+    from circuits_halo2_amd import prover as P, verifier as V
+    rng = random.Random(3)
+    for p in _random_points(rng, 20) + [PR.G1_GEN]:
+        enc = P.compress_g1(p)
+        assert len(enc) == 32 and enc[31] & 0x80 == 0 and (enc[31] >> 6) & 1 == p[1] & 1
+        assert V.decompress_g1(enc) == p == SV.decompress_g1(enc)
+        flipped = bytearray(enc); flipped[31] ^= 0x40
+        assert V.decompress_g1(bytes(flipped)) == (p[0], PR.Q - p[1])
+    assert P.compress_g1(None) == bytes(31) + b"\x80"
+    off = next(x for x in range(1, 50) if pow(x ** 3 + 3, (PR.Q - 1) // 2, PR.Q) != 1)           # no y with y^2 = x^3 + 3
+    for bad in (bytes(31) + b"\x80", (PR.Q).to_bytes(32, "little"), off.to_bytes(32, "little")):   # infinity, x >= q, off the curve
+        for fn in (V.decompress_g1, SV.decompress_g1):
+            with pytest.raises(ValueError):
+                fn(bad)
+
+
+# ------------------------------------------------------------------ pairing (host code of the library)
+def _pairing_check(pairs):
+    from circuits_halo2_amd import ffi
+    g1 = np.frombuffer(b"".join(PR.g1_to_bytes(p) for p, _ in pairs), dtype=np.uint8).copy()
+    g2 = np.frombuffer(b"".join(PR.g2_to_bytes(q) for _, q in pairs), dtype=np.uint8).copy()
+    ok = C.c_int(-1)
+    rc = ffi.lib().sg_pairing_check(ffi.ptr(g1), ffi.ptr(g2), C.c_size_t(len(pairs)), C.byref(ok))
+    return rc, ok.value
+
+
+def test_library_pairing_check_agrees_with_the_oracle():
+    g2 = PR.G2_GENERATOR
+    rng = random.Random(9)
+    for _ in range(3):
+        a, b = rng.randrange(1, PR.R), rng.randrange(1, PR.R)
+        pa, qb = PR.g1_mul(PR.G1_GEN, a), PR.g2_mul(g2, b)
+        pab = PR.g1_mul(PR.G1_GEN, a * b % PR.R)
+        good, bad = [(pa, qb), (PR.g1_neg(pab), g2)], [(pa, qb), (PR.g1_neg(pa), g2)]
+        assert _pairing_check(good) == (0, 1) and _pairing_check(bad) == (0, 0)
+    assert PA.pairing_check(good) and not PA.pairing_check(bad)              # the oracle on the last case
+    # three pairs: e(aG, H) e(bG, H) e(-(a+b)G, H) = 1
+    pb, pc = PR.g1_mul(PR.G1_GEN, b), PR.g1_neg(PR.g1_mul(PR.G1_GEN, (a + b) % PR.R))
+    assert _pairing_check([(pa, g2), (pb, g2), (pc, g2)]) == (0, 1)
+    assert _pairing_check([(None, g2), (pa, None)]) == (0, 1)               # identities pair to 1
+    assert _pairing_check([(pa, g2)]) == (0, 0)
+    assert _pairing_check([]) == (0, 1)
+    # points off the curve are refused, not paired
+    rc, _ = _pairing_check([((1, 3), g2)])
+    assert rc < 0
+    rc, _ = _pairing_check([(pa, ((1, 2), (3, 4)))])
+    assert rc < 0
+
+
+# ------------------------------------------------------------------ the product verifier on the reference's shipped proof
+def _k6():
+    from circuits_halo2_amd import api, params as PM
+    tr = json.load(open(os.path.join(GOLDEN, "k6_verifier_trace.json")))["vk"]
+    comm = [(H(a), H(b)) for a, b in tr["commitments"]]
+    vk = api.VerifyingKey(11, 2, comm[:11], comm[11:], H(tr["vk_digest"]))
+    cd = json.load(open(os.path.join(GOLDEN, "k6_inclusion_proof_solidity_calldata.json")))
+    params = PM.ParamsKZG.read(open(os.path.join(GOLDEN, "hermez-raw-11"), "rb"))
+    return params, vk, bytes.fromhex(cd["proof"][2:]), [H(x) for x in cd["public_inputs"]]
+
+
+@pytest.fixture()
+def oracle_msm(monkeypatch):
+    """the verifier's one multi-scalar multiplication runs on the GPU in the product; on the CPU box the oracle's MSM
+    stands in for it (the pairing, transcript and scalar side under test are the product's own)"""
+    from circuits_halo2_amd import verifier as V
+    from oracle import oracle as O
+    monkeypatch.setattr(V, "best_multiexp", lambda s, b: O.best_multiexp(np.ascontiguousarray(s), np.ascontiguousarray(b), 2))
+    return V
+
+
+def test_product_verifier_accepts_the_reference_shipped_proof(oracle_msm):
+    V = oracle_msm
+    params, vk, proof, inst = _k6()
+    assert V.verify_proof(params, vk, proof, inst, "evm")
+    # the SRS file's g2 / s_g2 are what the contract pairs against: same verdict as the restated verifier
+    for off in (0x10, 0x150, 0x390, 0x700, 0x7f0, 0x850):
+        p = bytearray(proof)
+        p[off] ^= 1
+        assert not V.verify_proof(params, vk, bytes(p), inst, "evm"), hex(off)
+    assert not V.verify_proof(params, vk, proof, [inst[0], inst[1], inst[2] + 1, inst[3]], "evm")
+    assert not V.verify_proof(params, vk, proof[:-1], inst, "evm")
+    assert not V.verify_proof(params, vk, proof + b"\0", inst, "evm")
+    assert not V.verify_proof(params, vk, proof, inst, "blake2b")            # wrong flavour: does not even parse
+    assert not V.verify_proof(params, vk, proof, [PR.R] + inst[1:], "evm")   # unreduced public input
+    wrong_key = type(vk)(vk.k, vk.n_currencies, vk.fixed_comms, vk.permutation_comms, vk.transcript_repr + 1)
+    assert not V.verify_proof(params, wrong_key, proof, inst, "evm")
+
+
+# ------------------------------------------------------------------ API host logic
+def test_generate_setup_artifacts_k_too_large():
+    from circuits_halo2_amd import api
+    circuit = api.MstInclusionCircuit.init_empty(4, 2, 8)
+    with pytest.raises(ValueError, match="k is too large for the given params"):       # utils.rs:58-60
+        api.generate_setup_artifacts(12, os.path.join(GOLDEN, "hermez-raw-11"), circuit)
+    with pytest.raises(OSError):                                                        # "couldn't load params"
+        api.generate_setup_artifacts(11, os.path.join(GOLDEN, "no-such-file"), circuit)
+
+
+def test_mst_inclusion_circuit_init_shapes():
+    from circuits_halo2_amd import api
+    c = api.MstInclusionCircuit.init_empty(4, 2, 8)
+    assert c.num_instances() == 4 and len(c.path_indices) == 4 and len(c.sibling_middle_node_hash_preimages) == 4
+    assert c.entry == (0, [0, 0]) and c.root == (0, [0, 0])
+
+
+def test_empty_and_real_circuits_share_fixed_columns_and_permutation(kat):
+    """keygen from `init_empty` and proving from `init` must agree on everything that enters the keys"""
+    from circuits_halo2_amd import api
+    empty = api.MstInclusionCircuit.init_empty(4, 2, 8).synthesize(11)
+    rng = random.Random(1)
+    real = api.MstInclusionCircuit(4, 2, 8, (rng.randrange(PR.R), [5, 7]), [1, 0, 1, 1], [rng.randrange(PR.R), 11, 13],
+                                   [[rng.randrange(1 << 40), rng.randrange(1 << 40), rng.randrange(PR.R), rng.randrange(PR.R)] for _ in range(3)],
+                                   (0, [0, 0])).synthesize(11)
+    assert empty["sigma"] == real["sigma"]
+    # fixed columns are equal too (round constants, table, selectors, the constants 0 and L * 2^64)
+    assert empty["fixed"] == real["fixed"]
+    assert len(real["instances"]) == 4
+
+
+def test_init_asserts_the_reference_lengths():
+    from circuits_halo2_amd import api
+    z32 = np.zeros(32, dtype=np.uint8)
+    mp = {"entry": ("alice", [1, 2]), "path_indices": [0, 1, 0], "root": (z32, np.zeros(64, dtype=np.uint8)),
+          "sibling_leaf_node_hash_preimage": np.zeros(96, dtype=np.uint8),
+          "sibling_middle_node_hash_preimages": [np.zeros(128, dtype=np.uint8)] * 2}
+    c = api.MstInclusionCircuit.init(mp, 3)
+    assert c.shape() == (3, 2, 8) and c.entry[0] == int.from_bytes(PR.keccak256(b"alice"), "big") % PR.R
+    with pytest.raises(AssertionError):
+        api.MstInclusionCircuit.init(mp, 4)                         # assert_eq!(path_indices.len(), LEVELS)
+    mp2 = dict(mp, sibling_middle_node_hash_preimages=[np.zeros(128, dtype=np.uint8)] * 3)
+    with pytest.raises(AssertionError):
+        api.MstInclusionCircuit.init(mp2, 3)                        # assert_eq!(preimages.len(), LEVELS - 1)
+
+
+def test_field_element_to_solidity_calldata():
+    from circuits_halo2_amd import api
+    assert api.field_element_to_solidity_calldata(556862) == 556862
+    assert api.field_element_to_solidity_calldata(PR.R + 5) == 5

@@ -1,0 +1,162 @@
+"""The reference's own prover tests, on the GPU back-end, through the mirror of its L3 API (circuits_halo2_amd/api.py):
+zk_prover/src/circuits/tests.rs:45-88 (`test_valid_merkle_sum_tree_with_full_prover`), :125-152
+(`test_invalid_root_hash_as_instance_with_full_prover`), the production path of backend/src/apis/round.rs:153-174
+(`gen_proof_solidity_calldata` under the reference's SRS and verifying key) and `generate_setup_artifacts`' three ways
+to obtain parameters (utils.rs:52-72).  Every proof is also checked by the oracle's restated verifier."""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+N_CURRENCIES, LEVELS, N_BYTES, K = 2, 4, 8, 11
+CSV = os.path.join(GOLDEN, "entry_16.csv")
+SRS = os.path.join(GOLDEN, "hermez-raw-11")
+H = lambda s: int(s, 16)
+
+
+def _gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from circuits_halo2_amd import ffi
+    ffi.check(ffi.lib().sg_init(0))
+
+
+def oracle_vk(params, vk):
+    """the verifying key in the form the oracle's restated verifier takes"""
+    from oracle import pyref as PR
+    f2 = lambda b: (PR.fq_from_bytes(b[:32]), PR.fq_from_bytes(b[32:64]))
+    g2 = (f2(params.g2[:64]), f2(params.g2[64:]))
+    s_g2 = (f2(params.s_g2[:64]), f2(params.s_g2[64:]))
+    return {"k": vk.k, "n_currencies": vk.n_currencies, "vk_digest": vk.transcript_repr, "fixed_comms": vk.fixed_comms,
+            "permutation_comms": vk.permutation_comms, "g2": g2, "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
+
+
+@pytest.fixture(scope="module")
+def artifacts():
+    """`generate_setup_artifacts(K, None, init_empty())`: unsafe setup + keys, shared by the tests below"""
+    _gpu()
+    from circuits_halo2_amd.api import MstInclusionCircuit, generate_setup_artifacts
+    circuit = MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES)
+    params, pk, vk = generate_setup_artifacts(K, None, circuit)
+    yield params, pk, vk
+    params.free()
+
+
+def test_valid_merkle_sum_tree_with_full_prover(artifacts, kat):
+    from circuits_halo2_amd.api import MstInclusionCircuit, full_prover, full_verifier
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from oracle import summa_verifier as SV
+    params, pk, vk = artifacts
+    merkle_sum_tree = MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES)
+    user_index = 0
+    merkle_proof = merkle_sum_tree.generate_proof(user_index)
+    # only now the circuit is instantiated with the actual inputs
+    circuit = MstInclusionCircuit.init(merkle_proof, LEVELS)
+    proof = full_prover(params, pk, circuit, circuit.instances())
+    assert full_verifier(params, vk, proof, circuit.instances())
+    assert len(proof) == 1632                                   # 16 compressed points + 35 scalars (Blake2b flavour)
+    # the oracle's restated verifier (its own Blake2b, its own pairing) agrees
+    assert SV.verify(proof, circuit.instances()[0], oracle_vk(params, vk), flavour="blake2b")
+    # public input #0 is the leaf hash, #1 the root hash, then the root balances -- the reference's expected values (K5)
+    inst = circuit.instances()[0]
+    k5 = kat["k5"]
+    assert len(inst) == circuit.num_instances() == 2 + N_CURRENCIES
+    assert inst == [H(k5["leaf0"]), H(k5["root"])] + k5["root_balances"]
+    # a second proof of the same statement differs (OsRng blinding) and verifies; a flipped byte does not
+    proof2 = full_prover(params, pk, circuit, circuit.instances())
+    assert proof2 != proof and full_verifier(params, vk, proof2, circuit.instances())
+    for off in (5, 300, 600, 1000, 1600):
+        bad = bytearray(proof)
+        bad[off] ^= 1
+        assert not full_verifier(params, vk, bytes(bad), circuit.instances()), off
+        assert not SV.verify(bytes(bad), inst, oracle_vk(params, vk), flavour="blake2b")
+
+
+def test_invalid_root_hash_as_instance_with_full_prover(artifacts):
+    from circuits_halo2_amd.api import MstInclusionCircuit, full_prover, full_verifier
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from oracle import summa_verifier as SV
+    params, pk, vk = artifacts
+    merkle_proof = MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES).generate_proof(0)
+    circuit = MstInclusionCircuit.init(merkle_proof, LEVELS)
+    instances = circuit.instances()
+    instances[0][1] = 1000                                      # invalid root hash
+    proof = full_prover(params, pk, circuit, instances)        # the prover does not fail ...
+    assert not full_verifier(params, vk, proof, instances)     # ... the proof is rejected
+    assert not SV.verify(proof, instances[0], oracle_vk(params, vk), flavour="blake2b")
+
+
+def test_every_user_of_the_csv_gets_a_valid_proof(artifacts):
+    """tests.rs:25-43 loops over the 16 users with the MockProver; here each gets a real proof, both flavours alternating"""
+    from circuits_halo2_amd.api import MstInclusionCircuit, full_prover, full_verifier, gen_proof_solidity_calldata
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from circuits_halo2_amd import verifier as V
+    params, pk, vk = artifacts
+    tree = MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES)
+    for user_index in range(16):
+        circuit = MstInclusionCircuit.init(tree.generate_proof(user_index), LEVELS)
+        if user_index % 2:
+            proof, public_inputs = gen_proof_solidity_calldata(params, pk, circuit)     # re-verified inside
+            assert len(proof) == 2144 and public_inputs == circuit.instances()[0]
+            assert V.verify_proof(params, vk, proof, public_inputs, "evm")
+        else:
+            assert full_verifier(params, vk, full_prover(params, pk, circuit, circuit.instances()), circuit.instances())
+
+
+def test_gen_proof_solidity_calldata_under_the_reference_srs_and_key(kat):
+    """backend/src/apis/round.rs:136-174: `Snapshot::new` loads ptau/hermez-raw-11 and generates the keys from the empty
+    circuit; `generate_proof_of_inclusion` is `gen_proof_solidity_calldata`.  Key generation must reproduce the verifying
+    key baked into the reference's verifier contract, and the calldata proof must be accepted on that key."""
+    _gpu()
+    from circuits_halo2_amd.api import MstInclusionCircuit, gen_proof_solidity_calldata, generate_setup_artifacts
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from oracle import summa_verifier as SV
+    want = [(H(a), H(b)) for a, b in kat["fixed_comms"] + kat["permutation_comms"]]
+    params, pk, vk = generate_setup_artifacts(K, SRS, MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES),
+                                              vk_transcript_repr=H(kat["vk_digest"]))
+    try:
+        assert vk.fixed_comms + vk.permutation_comms == want
+        tree = MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES)
+        circuit = MstInclusionCircuit.init(tree.generate_proof(0), LEVELS)
+        proof, public_inputs = gen_proof_solidity_calldata(params, pk, circuit)
+        tr = json.load(open(os.path.join(GOLDEN, "k6_verifier_trace.json")))["vk"]
+        ref_vk = {"k": K, "vk_digest": H(tr["vk_digest"]), "fixed_comms": want[:11], "permutation_comms": want[11:],
+                  "g2": ((H(tr["g2_x_2"]), H(tr["g2_x_1"])), (H(tr["g2_y_2"]), H(tr["g2_y_1"]))),
+                  "neg_s_g2": ((H(tr["neg_s_g2_x_2"]), H(tr["neg_s_g2_x_1"])), (H(tr["neg_s_g2_y_2"]), H(tr["neg_s_g2_y_1"])))}
+        assert SV.verify(proof, public_inputs, ref_vk)          # the contract's constants, not this run's
+        assert public_inputs[:2] == [H(kat["k5"]["leaf0"]), H(kat["k5"]["root"])]
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump({"proof": "0x" + proof.hex(), "public_inputs": [hex(v) for v in public_inputs]},
+                  open(os.path.join(out, "api_calldata_entry16_user0.json"), "w"))
+    finally:
+        params.free()
+
+
+def test_generate_setup_artifacts_downsizes_larger_params():
+    """utils.rs:62-66: a params file with a larger k is downsized (g truncated, g_lagrange recomputed by a G1 FFT on
+    the device); proofs under the downsized parameters verify"""
+    _gpu()
+    from circuits_halo2_amd.api import MstInclusionCircuit, full_prover, full_verifier, generate_setup_artifacts
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from oracle import summa_verifier as SV
+    levels, k = 2, 10
+    params, pk, vk = generate_setup_artifacts(k, SRS, MstInclusionCircuit.init_empty(levels, N_CURRENCIES, N_BYTES))
+    try:
+        assert params.k == k
+        entries = [(f"user{i}", [100 + i, 7 * i]) for i in range(4)]
+        tree = MerkleSumTree.from_entries(entries, N_CURRENCIES, N_BYTES)
+        circuit = MstInclusionCircuit.init(tree.generate_proof(3), levels)
+        proof = full_prover(params, pk, circuit, circuit.instances())
+        assert full_verifier(params, vk, proof, circuit.instances())
+        assert SV.verify(proof, circuit.instances()[0], oracle_vk(params, vk), flavour="blake2b")
+        # a key made for other dimensions is refused before anything is proven
+        with pytest.raises(ValueError):
+            full_prover(params, pk, MstInclusionCircuit.init_empty(3, N_CURRENCIES, N_BYTES), circuit.instances())
+    finally:
+        params.free()
