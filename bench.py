@@ -5,10 +5,13 @@ inputs resident in HBM.  With --gpus N (launched by torch.distributed.run, one r
 the N shards form one N*2^20-point MSM: every rank reduces its shard, the 64-byte partial
 points are exchanged with one RCCL all_gather and summed (weak scaling, per-GPU work fixed).
 
+`python bench.py --gpus N` launched bare starts its own N ranks (a torch.distributed.run child, before any GPU call).
+
 Also reported in the same JSON line: the NTT rates (configs[2]), the MSM+NTT kernel sum for
-the k=17 proof op list, `roofline` for the dominant kernel
-(msm_accumulate) and `cpu_baseline` (the oracle's restated halo2 best_multiexp on this box's
-host cores)."""
+the k=17 proof op list, a real and VERIFIED k=17 proof through the reference's API
+(configs[3]) with the restated-reference CPU op list beside it, the proof-level batch (configs[4] in small:
+`batch_k17`, `proofs_per_s`), `roofline` for the dominant kernel (msm_accumulate) and `cpu_baseline` (the oracle's
+restated halo2 best_multiexp on this box's host cores)."""
 import argparse
 import ctypes as C
 import json
@@ -54,6 +57,128 @@ def pmc_traffic(kernel, log_n, grid_threads=None, job_threads=None):
     return {}
 
 
+def snapshot_tree(levels=20, nc=2):
+    """a synthetic snapshot of 2^levels users (the reference bench downloads its CSVs from S3): username
+    field elements from ChaCha20, 40-bit balances; the Merkle sum tree is built and kept on the device"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.utils import random_fr_canonical
+    size = 1 << levels
+    d_users = A.fr_random(bytes(range(32)), 1, size)
+    bal = random_fr_canonical(77, size * nc).reshape(-1, 32).copy()
+    bal[:, 5:] = 0                                           # sums stay below 2^64 (N_BYTES = 8)
+    d_bals = A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda())
+    return DeviceMerkleSumTree(d_users, d_bals, levels, nc)
+
+
+def oracle_vk(params, vk):
+    """the verifying key in the form the oracle's restated verifier takes (checker leg only)"""
+    from oracle import pyref as PR
+    f2 = lambda b: (PR.fq_from_bytes(b[:32]), PR.fq_from_bytes(b[32:64]))
+    s_g2 = (f2(params.s_g2[:64]), f2(params.s_g2[64:]))
+    return {"k": vk.k, "n_currencies": vk.n_currencies, "vk_digest": vk.transcript_repr, "fixed_comms": vk.fixed_comms,
+            "permutation_comms": vk.permutation_comms, "g2": (f2(params.g2[:64]), f2(params.g2[64:])),
+            "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
+
+
+def batch_extra(args, rank, world):
+    """BASELINE configs[4] in small: inclusion proofs for `--batch-proofs` users per GPU of a 2^20-user snapshot at
+    k = 17 (MstInclusionCircuit<20,2,8>), through circuits_halo2_amd.batch: the setup artifacts are generated on rank 0
+    and broadcast, users are dealt round-robin, several proofs in flight per GPU.  Every rank takes part; returns the
+    extra key's dict on rank 0.  Also returns what the single-proof extras reuse."""
+    import torch
+    import torch.distributed as dist
+    from circuits_halo2_amd import batch as B
+    levels, k, nc = 20, 17, 2
+    t0 = time.perf_counter()
+    params, pk, vk = B.setup_on_all_ranks(k, None, levels, nc)
+    setup_s = time.perf_counter() - t0
+    params.precompute()
+    tree = snapshot_tree(levels, nc)
+    torch.cuda.synchronize()
+    out = {"k": k, "levels": levels, "n_currencies": nc, "proofs_per_gpu": args.batch_proofs, "n_gpus": world,
+           "setup_artifacts_s": setup_s, "by_in_flight": {}}
+    users = [(7919 * i + 13) % (1 << levels) for i in range(args.batch_proofs * world)]
+    B.prove_batch(tree, users[:2 * world], params, pk, levels, in_flight=2)                 # warm-up: plans, pools, streams
+    best = None
+    for in_flight in (1, 2, 3):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = B.prove_batch(tree, users, params, pk, levels, flavour="evm", in_flight=in_flight)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        done = torch.tensor([len(res.proofs), len(res.errors)], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(done)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rate = float(done[0].item()) / float(tmax.item())
+        out["by_in_flight"][str(in_flight)] = {"proofs": int(done[0].item()), "errors": int(done[1].item()), "seconds": float(tmax.item()),
+                                                "proofs_per_s": rate}
+        if best is None or rate > best[0]:
+            best = (rate, in_flight, res)
+    out["proofs_per_s"], out["in_flight"] = best[0], best[1]
+    if rank == 0:   # checker leg, outside every timed region: the oracle's verifier on a sample of the proofs made
+        from oracle import summa_verifier as SV
+        ovk = oracle_vk(params, vk)
+        sample = sorted(best[2].proofs)[:3]
+        out["verified_sample"] = all(SV.verify(best[2].proofs[u][0], best[2].proofs[u][1], ovk) for u in sample) and bool(sample)
+        out["note"] = ("gen_proof_solidity_calldata per user (Keccak transcript, each proof re-verified by the product's verifier as the "
+                       "reference's create_proof_checked does), witness synthesis included; whole-job rate = proofs of all ranks / "
+                       "max-over-ranks time; per-GPU work fixed as N grows")
+    return (out if rank == 0 else None), (tree, params, pk, vk)
+
+
+def cpu_oplist_baseline(k, cores):
+    """restated-reference CPU op list of ONE k = 17 proof on this box's cores (context, never the target): the oracle's
+    halo2-shaped best_multiexp / best_fft / evaluate_h blocks in the counts of SURVEY.md section 3.1 -- 16 MSM(2^k),
+    9 iNTT(2^k), 9 coset NTT(2^(k+3)), 1 iNTT(2^(k+3)), the gate / permutation / lookup folds over 2^(k+3) rows
+    [REF zk_prover/src/circuits/utils.rs:88,105: the reference times create_proof as a whole]"""
+    from circuits_halo2_amd import mst_inclusion as M
+    from oracle import oracle as O
+    n, ext_k = 1 << k, k + 3
+    ne = 1 << ext_k
+    t = {}
+    sc, bases = O.random_fr(901, n), O.fixed_base_mul(O.random_fr(902, n), cores)
+    t0 = time.perf_counter()
+    for _ in range(16):
+        O.best_multiexp(sc, bases, cores)
+    t["msm_16x2^k_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    for _ in range(9):
+        co = O.lagrange_to_coeff(sc, k, cores)
+    t["intt_9x2^k_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    for _ in range(9):
+        ext = O.coeff_to_extended(co, k, ext_k, cores)
+    t["coset_ntt_9x2^(k+3)_ms"] = (time.perf_counter() - t0) * 1e3
+    cols = [ext, O.random_fr(903, ne), O.random_fr(904, ne)]
+    pick = lambda i: cols[i % 3]
+    beta, gamma, theta, y = (O.random_fr(910 + i, 1) for i in range(4))
+    O.set_quotient_threads(cores)
+    try:
+        t0 = time.perf_counter()
+        v = O.quotient_gates(np.zeros(32 * ne, dtype=np.uint8), M.gate_graph(2).as_dict(), [pick(i) for i in range(11)],
+                             [pick(i + 1) for i in range(3)], [pick(2)], M.gate_challenges(5), beta, gamma, theta, y, k, ext_k)
+        v = O.quotient_permutation(v, [pick(0), pick(1)], [pick(i) for i in range(6)], [pick(i + 1) for i in range(6)], 4, pick(0), pick(1),
+                                   pick(2), beta, gamma, y, k, ext_k, 6)
+        v = O.quotient_lookup(v, pick(0), pick(1), pick(2), pick(0), pick(1), pick(2), pick(0), pick(1), beta, gamma, y, k, ext_k)
+        t["evaluate_h_2^(k+3)_rows_ms"] = (time.perf_counter() - t0) * 1e3
+    finally:
+        O.set_quotient_threads(1)
+    t0 = time.perf_counter()
+    O.extended_to_coeff(O.divide_by_vanishing_poly(v, k, ext_k), k, ext_k, cores)
+    t["intt_1x2^(k+3)_ms"] = (time.perf_counter() - t0) * 1e3
+    return {"total_ms": sum(t.values()), "parts_ms": {a: round(b, 1) for a, b in t.items()}, "cores": cores, "nproc": os.cpu_count(),
+            "kind": "port", "label": "restated-reference CPU op list (MSM + NTT + evaluate_h of one proof; grand products, "
+                                     "evaluations and the multi-open's polynomial arithmetic not included)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,14 +187,33 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
+    ap.add_argument("--batch-proofs", type=int, default=12, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, BEFORE anything
+        # in this process touches the GPU (a child process, never an exec of a process that has initialised HIP);
+        # rank 0 of the children prints the JSON line, which passes through
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -111,6 +255,15 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    batch_line, k17 = None, None
+    if args.batch_proofs > 0 and not args.no_extras and args.log_n >= 20:
+        try:
+            batch_line, k17 = batch_extra(args, rank, world)
+        except Exception as ex:   # an extra never costs the headline line; every rank takes the same exit
+            batch_line = {"error": repr(ex)} if rank == 0 else None
+            if world > 1:
+                dist.barrier()
 
     line = None
     if rank == 0:
@@ -276,39 +429,76 @@ def main():
                                                       "three grand products and the rotation sets of the multi-open on side streams"}
                 except Exception as ex:  # the flow is an extra: never lose the headline line over it
                     line["proof_flow_k17"] = {"error": repr(ex)}
-                # a REAL proof at k = 17: circuits_halo2_amd.prover.create_proof for the reference circuit's constraint
-                # system on a satisfying assignment (tools/time_create_proof.py); tests/test_gpu_prover.py verifies such
-                # proofs with the restated verifier
+                # a REAL proof at k = 17 through the reference's API (circuits_halo2_amd/api.py): MstInclusionCircuit<20,2,8> in the
+                # reference's own floor plan, the inclusion witness of one user of the device-resident 2^20-user snapshot;
+                # the timed proof itself is verified (product verifier AND the oracle's, outside the timed region)
+                profiled17 = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)
                 try:
-                    from time_create_proof import run as run_create_proof
+                    from circuits_halo2_amd import api as _api, prover as _prover, verifier as _verifier
                     torch.cuda.empty_cache()
-                    ms17, nbytes = run_create_proof(17, reps=3)
+                    if k17 is None:
+                        tree17 = snapshot_tree(20, 2)
+                        params17, pk17, vk17 = _api.generate_setup_artifacts(17, None, _api.MstInclusionCircuit.init_empty(20, 2, 8))
+                        params17.precompute()
+                    else:
+                        tree17, params17, pk17, vk17 = k17
+                    t1 = time.perf_counter()
+                    circuit17 = _api.MstInclusionCircuit.init(tree17.generate_proof(5), 20)
+                    inst17 = circuit17.instances()[0]
+                    adv17 = _api._advice_columns(pk17, circuit17)
+                    torch.cuda.synchronize()
+                    witness_ms = (time.perf_counter() - t1) * 1e3
+                    _prover.create_proof(params17, pk17, adv17, inst17)
+                    ms17, proof17 = 1e9, None
+                    for _ in range(3):
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        pr = _prover.create_proof(params17, pk17, adv17, inst17)
+                        d_ = (time.perf_counter() - t1) * 1e3
+                        if d_ < ms17:
+                            ms17, proof17 = d_, pr
+                    phases17 = {}
+                    _prover.create_proof(params17, pk17, adv17, inst17, timings=phases17)
+                    t1 = time.perf_counter()
+                    ok_product = _verifier.verify_proof(params17, vk17, proof17, inst17, "evm")
+                    verify_ms = (time.perf_counter() - t1) * 1e3
+                    t1 = time.perf_counter()
+                    calldata = _api.gen_proof_solidity_calldata(params17, pk17, _api.MstInclusionCircuit.init(tree17.generate_proof(6), 20))
+                    calldata_ms = (time.perf_counter() - t1) * 1e3
+                    from oracle import summa_verifier as _SV     # checker leg
+                    ok_oracle = _SV.verify(proof17, inst17, oracle_vk(params17, vk17)) and _SV.verify(calldata[0], calldata[1], oracle_vk(params17, vk17))
+                    t1 = time.perf_counter()
+                    blake = _api.full_prover(params17, pk17, circuit17, [inst17])
+                    blake_ms = (time.perf_counter() - t1) * 1e3
+                    ok_blake = _api.full_verifier(params17, vk17, blake, [inst17]) and _SV.verify(blake, inst17, oracle_vk(params17, vk17), flavour="blake2b")
                     cpp17 = {}
                     exe17 = os.path.join(ROOT, "tools", "create_proof_cpp")
-                    profiled17 = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)
                     if os.path.exists(exe17) and not profiled17:   # the same prover as compiled host code (include/summa_prover.hpp), own process
                         import subprocess, tempfile
-                        from time_create_proof import setup as cp_setup
-                        from circuits_halo2_amd import prover as _prover
                         with tempfile.TemporaryDirectory() as td:
-                            params17, pk17, adv17, inst17 = cp_setup(17)
                             _prover.export_bundle(os.path.join(td, "bundle.bin"), params17, pk17, adv17, inst17)
-                            params17.free()
-                            del pk17, adv17
-                            torch.cuda.empty_cache()
                             r = subprocess.run([exe17, os.path.join(td, "bundle.bin"), os.path.join(td, "proof.bin"), "8"],
                                                capture_output=True, text=True, timeout=300)
                             if r.returncode == 0:
                                 cpp17 = json.loads(r.stdout.strip().splitlines()[-1])
-                    line["create_proof_k17"] = {"ms": ms17, "ms_cpp_driver": cpp17.get("create_proof_ms"),
+                                cpp17["verified"] = bool(_SV.verify(open(os.path.join(td, "proof.bin"), "rb").read(), inst17, oracle_vk(params17, vk17)))
+                    line["create_proof_k17"] = {"ms": ms17, "ms_cpp_driver": cpp17.get("create_proof_ms"), "verified": bool(ok_product and ok_oracle),
+                                                "verified_cpp_driver_proof": cpp17.get("verified"),
+                                                "gen_proof_solidity_calldata_ms": calldata_ms, "full_prover_blake2b_ms": blake_ms,
+                                                "blake2b_proof_bytes": len(blake), "blake2b_verified": bool(ok_blake),
+                                                "witness_synthesis_ms": witness_ms, "verify_ms_product": verify_ms,
                                                 "phases_ms_cpp_driver_synchronised": {k_: v_ for k_, v_ in cpp17.items() if k_[0].isdigit()},
-                                                "proof_bytes": nbytes, "rows_per_s": (1 << 17) / ((cpp17.get("create_proof_ms") or ms17) * 1e-3),
-                                                "phases_ms_synchronised": run_create_proof.phases, "keygen_ms": run_create_proof.keygen_ms,
-                                                "note": "whole create_proof (EVM transcript, SHPLONK) for MstInclusionCircuit's constraint system "
-                                                        "(19 gates, 1 lookup, 6 permutation columns) at k = 17, MstInclusionCircuit<20,2,8> in the reference's own floor plan with the "
-                                                        "inclusion witness of one user of a device-built 2^20-user tree, wall clock incl. the host "
-                                                        "glue (transcript, multi-open scalars); ms: Python driver, best of 3; ms_cpp_driver: include/summa_prover.hpp "
-                                                        "in its own process, best of 8; tests/test_gpu_prover.py verifies such proofs with the restated verifier"}
+                                                "proof_bytes": len(proof17), "rows_per_s": (1 << 17) / ((cpp17.get("create_proof_ms") or ms17) * 1e-3),
+                                                "phases_ms_synchronised": {k_: round(v_, 2) for k_, v_ in phases17.items()},
+                                                "note": "whole create_proof (EVM transcript, SHPLONK) for MstInclusionCircuit<20,2,8> at k = 17 in the reference's own floor plan, "
+                                                        "inclusion witness of one user of a device-resident 2^20-user snapshot, wall clock incl. the host glue; "
+                                                        "ms: Python driver, best of 3, and THAT proof is the one verified (product verifier + oracle verifier); "
+                                                        "ms_cpp_driver: include/summa_prover.hpp in its own process, best of 8; gen_proof_solidity_calldata_ms: "
+                                                        "the backend's call = witness synthesis + proof + immediate re-verification"}
+                    if not args.no_cpu:
+                        from oracle import oracle as _O
+                        line["create_proof_k17"]["cpu_baseline_oplist_ms"] = cpu_oplist_baseline(17, min(_O.ncpu(), 16))
+                    if k17 is None:
+                        params17.free()
                 except Exception as ex:
                     line["create_proof_k17"] = {"error": repr(ex)}
                 # the reference circuit itself (its own floor plan, verifying key and SRS; csv/entry_16.csv user 0, k = 11):
@@ -385,16 +575,20 @@ def main():
         # ---- CPU baseline: the oracle's restated halo2 best_multiexp on this box's cores
         if not args.no_cpu and world == 1:
             from oracle import oracle as O
-            cores = min(O.ncpu(), 16)  # the GPU box gives a 16-core share per GPU
+            cores = min(O.ncpu(), 16)  # threads used; the GPU box gives a 16-core share per GPU (nproc is reported beside it)
             hs, hb = scal.cpu().numpy(), bases.cpu().numpy()
             t1 = time.perf_counter()
             ref = O.best_multiexp(hs, hb, cores)
             cdt = time.perf_counter() - t1
             ok = bool((ref == result).all()) if world == 1 else None
-            line["cpu_baseline"] = {"value": n / cdt, "unit": "points/s", "cores": cores, "kind": "port",
+            line["cpu_baseline"] = {"value": n / cdt, "unit": "points/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
                                     "sample": f"one full 2^{args.log_n} MSM on the same inputs ({cdt:.2f} s), "
                                               f"halo2-shaped per-thread-chunked Pippenger (oracle/bn254_oracle.c)",
                                     "matches_gpu_result": ok}
+        if batch_line is not None:
+            line["batch_k17"] = batch_line
+            if "proofs_per_s" in batch_line:
+                line["proofs_per_s"] = batch_line["proofs_per_s"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -85,7 +85,8 @@ class MstInclusionCircuit:
         assert len(merkle_proof["path_indices"]) == levels
         assert len(merkle_proof["sibling_middle_node_hash_preimages"]) == levels - 1
         assert len(balances) == nc
-        username = 0 if name is None else int.from_bytes(keccak256(name.encode()), "big") % R
+        # a username is hashed to its field element (entry.rs:21); device snapshots hand the field element over as an int
+        username = 0 if name is None else name % R if isinstance(name, int) else int.from_bytes(keccak256(name.encode()), "big") % R
         root_hash, root_bal = merkle_proof["root"]
         return cls(levels, nc, n_bytes, (username, [int(b) for b in balances]), merkle_proof["path_indices"],
                    _fr_ints(merkle_proof["sibling_leaf_node_hash_preimage"]),

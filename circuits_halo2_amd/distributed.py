@@ -60,9 +60,9 @@ def sharded_msm(local_scalars, local_bases, msm=None) -> np.ndarray:
     With no process group this is plain best_multiexp."""
     part = (msm or best_multiexp)(local_scalars, local_bases)
     d = _dist()
-    if d is None or d.get_world_size() == 1:
+    if d is None:
         return part
-    import torch
+    import torch        # with a process group the exchange step always runs (world 1 included: same code path at every N)
     world = d.get_world_size()
     dev = "cuda" if d.get_backend() == "nccl" else "cpu"
     mine = torch.from_numpy(np.ascontiguousarray(part)).to(dev)

@@ -272,3 +272,76 @@ class MerkleSumTree:
             node_h, node_b = _hash_batch("middle", pair_h, pair_b, n=1, nc=nc)
         rh, rb = proof["root"]
         return bool((node_h == rh).all() and (node_b == rb).all())
+
+
+class DeviceMerkleSumTree:
+    """A Merkle sum tree whose leaves are already field elements on the device (a snapshot of 2^depth users: username
+    field elements and balances as Montgomery Fr), built and KEPT in HBM: level-major node arrays as `sg_mst_build_dev`
+    lays them out.  The reference's `Tree` trait [REF zk_prover/src/merkle_sum_tree/tree.rs:8-137] for the two methods a
+    prover needs -- `root`, `generate_proof` --; a Merkle proof costs one gather of 3 * depth + 2 rows and one small
+    device-to-host copy.  (MerkleSumTree above is the CSV / entries flavour with the nodes mirrored on the host.)"""
+
+    def __init__(self, d_usernames, d_balances, depth: int, n_currencies: int):
+        import torch
+        size = 1 << depth
+        if d_usernames.numel() != 32 * size or d_balances.numel() != 32 * size * n_currencies:
+            raise ValueError("DeviceMerkleSumTree: 2^depth usernames and 2^depth * n_currencies balances expected")
+        self.depth, self.n_currencies = depth, n_currencies
+        self.d_users, self.d_bals = d_usernames, d_balances
+        nodes = 2 * size - 1
+        self.d_h = torch.empty(32 * nodes, dtype=torch.uint8, device="cuda")
+        self.d_b = torch.empty(32 * nodes * n_currencies, dtype=torch.uint8, device="cuda")
+        ffi.check(ffi.lib().sg_mst_build_dev(ffi.dev_ptr(d_usernames), ffi.dev_ptr(d_balances), C.c_uint32(depth),
+                                             C.c_uint32(n_currencies), ffi.dev_ptr(self.d_h), ffi.dev_ptr(self.d_b),
+                                             ffi.current_stream_ptr()))
+        self.offsets = [0]
+        for level in range(depth):
+            self.offsets.append(self.offsets[-1] + (size >> level))
+        self._root = None
+
+    def _rows(self, hash_nodes, balance_nodes, users):
+        """one gather + one copy: rows of the hash array, of the balance array (n_currencies rows per node), leaf inputs"""
+        import torch
+        nc = self.n_currencies
+        dev = lambda idx: torch.tensor(idx, dtype=torch.int64, device="cuda")
+        parts = [self.d_h.view(-1, 32)[dev(hash_nodes)].reshape(-1) if hash_nodes else None,
+                 self.d_b.view(-1, 32 * nc)[dev(balance_nodes)].reshape(-1) if balance_nodes else None,
+                 self.d_users.view(-1, 32)[dev(users)].reshape(-1) if users else None,
+                 self.d_bals.view(-1, 32 * nc)[dev(users)].reshape(-1) if users else None]
+        flat = torch.cat([p for p in parts if p is not None]).cpu().numpy()
+        out, pos = [], 0
+        for p, width in zip(parts, (32, 32 * nc, 32, 32 * nc)):
+            count = 0 if p is None else p.numel() // width
+            out.append([flat[pos + width * i:pos + width * (i + 1)] for i in range(count)])
+            pos += width * count
+        return out
+
+    def root(self):
+        if self._root is None:
+            h, b, _, _ = self._rows([self.offsets[self.depth]], [self.offsets[self.depth]], [])
+            self._root = (h[0], b[0])
+        return self._root
+
+    def generate_proof(self, index: int):
+        """the fields of the reference's MerkleProof (see MerkleSumTree.generate_proof); `entry` carries the username as
+        its field element (int), since a device snapshot holds no names"""
+        if not 0 <= index < (1 << self.depth):
+            raise IndexError("Index out of bounds")
+        hash_nodes, bal_nodes, bits = [self.offsets[0] + index], [], []
+        idx = index
+        for level in range(self.depth):
+            bits.append(idx & 1)
+            sib = idx ^ 1
+            if level > 0:   # the sibling middle node's preimage: its balances, its children's hashes
+                bal_nodes.append(self.offsets[level] + sib)
+                hash_nodes += [self.offsets[level - 1] + 2 * sib, self.offsets[level - 1] + 2 * sib + 1]
+            idx >>= 1
+        h, b, users, bals = self._rows(hash_nodes, bal_nodes, [index, index ^ 1] if self.depth else [index])
+        rinv = pow(1 << 256, -1, R_MODULUS)
+        to_int = lambda row: int.from_bytes(bytes(row), "little") * rinv % R_MODULUS
+        nc = self.n_currencies
+        entry = (to_int(users[0]), [to_int(bals[0][32 * c:32 * c + 32]) for c in range(nc)])
+        pre_mid = [np.concatenate([b[l], h[1 + 2 * l], h[2 + 2 * l]]) for l in range(max(0, self.depth - 1))]
+        pre_leaf = np.concatenate([users[1], bals[1]]) if self.depth else None
+        return {"entry": entry, "leaf": (h[0], bals[0]), "path_indices": bits, "root": self.root(),
+                "sibling_leaf_node_hash_preimage": pre_leaf, "sibling_middle_node_hash_preimages": pre_mid}

@@ -675,70 +675,114 @@ void orc_lookup_product(const uint8_t *a, const uint8_t *s, const uint8_t *ap, c
  * contracts/src/InclusionVerifier.sol:903-997.  Row i of the extended domain is zeta*omega_ext^i;
  * r_next / r_prev / r_last are index shifts by 2^(ext_k-k) * {+1, -1, -last_rotation_abs}. */
 static inline const fe *row(const uint8_t *a, size_t i) { return (const fe *)(a + 32 * i); }
+/* rows of the extended domain are independent (upstream's `parallelize` splits them over rayon threads): the three
+ * quotient blocks below run their row loop on orc_set_quotient_threads() pthreads (default 1) */
+static int g_quotient_threads = 1;
+void orc_set_quotient_threads(int threads) { g_quotient_threads = threads < 1 ? 1 : threads > 256 ? 256 : threads; }
+typedef void (*row_range_fn)(void *ctx, size_t lo, size_t hi);
+typedef struct { row_range_fn fn; void *ctx; size_t lo, hi; } row_job;
+static void *row_worker(void *p) { row_job *j = (row_job *)p; j->fn(j->ctx, j->lo, j->hi); return NULL; }
+static void par_rows(row_range_fn fn, void *ctx, size_t n) {
+    int t = g_quotient_threads;
+    if (t <= 1 || n < 1024) { fn(ctx, 0, n); return; }
+    row_job *jobs = (row_job *)calloc((size_t)t, sizeof(row_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)t, sizeof(pthread_t));
+    size_t per = (n + (size_t)t - 1) / (size_t)t;
+    for (int k = 0; k < t; k++) {
+        jobs[k].fn = fn; jobs[k].ctx = ctx; jobs[k].lo = (size_t)k * per < n ? (size_t)k * per : n;
+        jobs[k].hi = jobs[k].lo + per < n ? jobs[k].lo + per : n;
+        pthread_create(&tid[k], NULL, row_worker, &jobs[k]);
+    }
+    for (int k = 0; k < t; k++) pthread_join(tid[k], NULL);
+    free(jobs); free(tid);
+}
 static void fold_term(fe *acc, const fe *y, const fe *term) {
     fe_mul(&FR, acc, acc, y);
     fe_add(&FR, acc, acc, term);
+}
+typedef struct {
+    uint8_t *values; const uint8_t *const *z; uint32_t nsets; const uint8_t *const *cols; const uint8_t *const *sigma;
+    uint32_t ncols, chunk_len; const uint8_t *l0, *l_last, *l_active; fe b, g, y, delta, beta_zeta, w_ext;
+    size_t n_ext, rot, last_rotation_abs;
+} perm_ctx;
+static void quotient_permutation_rows(void *p, size_t lo, size_t hi) {
+    const perm_ctx *c = (const perm_ctx *)p;
+    const size_t n_ext = c->n_ext, rot = c->rot, mask = n_ext - 1;
+    const uint8_t *const *z = c->z, *const *cols = c->cols, *const *sigma = c->sigma;
+    const uint32_t nsets = c->nsets;
+    fe beta_term = c->beta_zeta, wl = c->w_ext, acc_w = FR.r1;  /* beta * zeta * omega_ext^lo */
+    for (size_t e = lo; e; e >>= 1) {
+        if (e & 1) fe_mul(&FR, &acc_w, &acc_w, &wl);
+        fe_sqr(&FR, &wl, &wl);
+    }
+    fe_mul(&FR, &beta_term, &beta_term, &acc_w);
+    for (size_t i = lo; i < hi; i++) {
+        const size_t i_next = (i + rot) & mask, i_last = (i + n_ext - c->last_rotation_abs * rot) & mask;
+        fe acc = *row(c->values, i), t, u;
+        /* l0 (1 - z_0) */
+        fe_sub(&FR, &t, &FR.r1, row(z[0], i));
+        fe_mul(&FR, &t, &t, row(c->l0, i));
+        fold_term(&acc, &c->y, &t);
+        /* l_last (z_l^2 - z_l) */
+        fe_sqr(&FR, &t, row(z[nsets - 1], i));
+        fe_sub(&FR, &t, &t, row(z[nsets - 1], i));
+        fe_mul(&FR, &t, &t, row(c->l_last, i));
+        fold_term(&acc, &c->y, &t);
+        /* l0 (z_s - z_{s-1}(omega^-last X)) */
+        for (uint32_t s = 1; s < nsets; s++) {
+            fe_sub(&FR, &t, row(z[s], i), row(z[s - 1], i_last));
+            fe_mul(&FR, &t, &t, row(c->l0, i));
+            fold_term(&acc, &c->y, &t);
+        }
+        fe cur = beta_term;
+        uint32_t col = 0;
+        for (uint32_t s = 0; s < nsets; s++) {
+            fe left = *row(z[s], i_next), right = *row(z[s], i);
+            for (uint32_t j = 0; j < c->chunk_len && col < c->ncols; j++, col++) {
+                fe_mul(&FR, &t, &c->b, row(sigma[col], i));
+                fe_add(&FR, &t, &t, row(cols[col], i));
+                fe_add(&FR, &t, &t, &c->g);
+                fe_mul(&FR, &left, &left, &t);
+                fe_add(&FR, &u, row(cols[col], i), &cur);
+                fe_add(&FR, &u, &u, &c->g);
+                fe_mul(&FR, &right, &right, &u);
+                fe_mul(&FR, &cur, &cur, &c->delta);
+            }
+            fe_sub(&FR, &t, &left, &right);
+            fe_mul(&FR, &t, &t, row(c->l_active, i));
+            fold_term(&acc, &c->y, &t);
+        }
+        memcpy(c->values + 32 * i, &acc, 32);
+        fe_mul(&FR, &beta_term, &beta_term, &c->w_ext);
+    }
 }
 void orc_quotient_permutation(uint8_t *values, const uint8_t *const *z, uint32_t nsets, const uint8_t *const *cols,
                               const uint8_t *const *sigma, uint32_t ncols, uint32_t chunk_len, const uint8_t *l0,
                               const uint8_t *l_last, const uint8_t *l_active, const uint8_t beta[32],
                               const uint8_t gamma[32], const uint8_t y_[32], uint32_t k, uint32_t ext_k,
                               uint32_t last_rotation_abs) {
-    const size_t n_ext = (size_t)1 << ext_k, rot = (size_t)1 << (ext_k - k), mask = n_ext - 1;
-    fe b, g, y, delta, dc, zeta, zc, w_ext, beta_term;
-    memcpy(&b, beta, 32); memcpy(&g, gamma, 32); memcpy(&y, y_, 32);
-    memcpy(dc.l, DELTA_CANON, 32); fe_to_mont(&FR, &delta, &dc);
+    perm_ctx c;
+    fe dc, zeta, zc;
+    c.values = values; c.z = z; c.nsets = nsets; c.cols = cols; c.sigma = sigma; c.ncols = ncols; c.chunk_len = chunk_len;
+    c.l0 = l0; c.l_last = l_last; c.l_active = l_active;
+    c.n_ext = (size_t)1 << ext_k; c.rot = (size_t)1 << (ext_k - k); c.last_rotation_abs = last_rotation_abs;
+    memcpy(&c.b, beta, 32); memcpy(&c.g, gamma, 32); memcpy(&c.y, y_, 32);
+    memcpy(dc.l, DELTA_CANON, 32); fe_to_mont(&FR, &c.delta, &dc);
     memcpy(zc.l, ZETA_CANON, 32); fe_to_mont(&FR, &zeta, &zc);
-    fr_omega(ext_k, &w_ext);
-    fe_mul(&FR, &beta_term, &b, &zeta);               /* beta * zeta * omega_ext^i, advanced per row */
-    for (size_t i = 0; i < n_ext; i++) {
-        const size_t i_next = (i + rot) & mask, i_last = (i + n_ext - last_rotation_abs * rot) & mask;
-        fe acc = *row(values, i), t, u;
-        /* l0 (1 - z_0) */
-        fe_sub(&FR, &t, &FR.r1, row(z[0], i));
-        fe_mul(&FR, &t, &t, row(l0, i));
-        fold_term(&acc, &y, &t);
-        /* l_last (z_l^2 - z_l) */
-        fe_sqr(&FR, &t, row(z[nsets - 1], i));
-        fe_sub(&FR, &t, &t, row(z[nsets - 1], i));
-        fe_mul(&FR, &t, &t, row(l_last, i));
-        fold_term(&acc, &y, &t);
-        /* l0 (z_s - z_{s-1}(omega^-last X)) */
-        for (uint32_t s = 1; s < nsets; s++) {
-            fe_sub(&FR, &t, row(z[s], i), row(z[s - 1], i_last));
-            fe_mul(&FR, &t, &t, row(l0, i));
-            fold_term(&acc, &y, &t);
-        }
-        fe cur = beta_term;
-        uint32_t c = 0;
-        for (uint32_t s = 0; s < nsets; s++) {
-            fe left = *row(z[s], i_next), right = *row(z[s], i);
-            for (uint32_t j = 0; j < chunk_len && c < ncols; j++, c++) {
-                fe_mul(&FR, &t, &b, row(sigma[c], i));
-                fe_add(&FR, &t, &t, row(cols[c], i));
-                fe_add(&FR, &t, &t, &g);
-                fe_mul(&FR, &left, &left, &t);
-                fe_add(&FR, &u, row(cols[c], i), &cur);
-                fe_add(&FR, &u, &u, &g);
-                fe_mul(&FR, &right, &right, &u);
-                fe_mul(&FR, &cur, &cur, &delta);
-            }
-            fe_sub(&FR, &t, &left, &right);
-            fe_mul(&FR, &t, &t, row(l_active, i));
-            fold_term(&acc, &y, &t);
-        }
-        memcpy(values + 32 * i, &acc, 32);
-        fe_mul(&FR, &beta_term, &beta_term, &w_ext);
-    }
+    fr_omega(ext_k, &c.w_ext);
+    fe_mul(&FR, &c.beta_zeta, &c.b, &zeta);               /* beta * zeta * omega_ext^i, advanced per row */
+    par_rows(quotient_permutation_rows, &c, c.n_ext);
 }
-void orc_quotient_lookup(uint8_t *values, const uint8_t *z, const uint8_t *ap, const uint8_t *sp, const uint8_t *a,
-                         const uint8_t *s, const uint8_t *l0, const uint8_t *l_last, const uint8_t *l_active,
-                         const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y_[32], uint32_t k,
-                         uint32_t ext_k) {
-    const size_t n_ext = (size_t)1 << ext_k, rot = (size_t)1 << (ext_k - k), mask = n_ext - 1;
-    fe b, g, y;
-    memcpy(&b, beta, 32); memcpy(&g, gamma, 32); memcpy(&y, y_, 32);
-    for (size_t i = 0; i < n_ext; i++) {
+typedef struct {
+    uint8_t *values; const uint8_t *z, *ap, *sp, *a, *s, *l0, *l_last, *l_active; fe b, g, y; size_t n_ext, rot;
+} lookup_ctx;
+static void quotient_lookup_rows(void *p, size_t lo, size_t hi) {
+    const lookup_ctx *c = (const lookup_ctx *)p;
+    const size_t n_ext = c->n_ext, rot = c->rot, mask = n_ext - 1;
+    uint8_t *values = c->values;
+    const uint8_t *z = c->z, *ap = c->ap, *sp = c->sp, *a = c->a, *s = c->s, *l0 = c->l0, *l_last = c->l_last, *l_active = c->l_active;
+    const fe b = c->b, g = c->g, y = c->y;
+    for (size_t i = lo; i < hi; i++) {
         const size_t i_next = (i + rot) & mask, i_prev = (i + n_ext - rot) & mask;
         fe acc = *row(values, i), t, u, v, d;
         fe_sub(&FR, &t, &FR.r1, row(z, i));                       /* l0 (1 - z) */
@@ -768,6 +812,16 @@ void orc_quotient_lookup(uint8_t *values, const uint8_t *z, const uint8_t *ap, c
         fold_term(&acc, &y, &t);
         memcpy(values + 32 * i, &acc, 32);
     }
+}
+void orc_quotient_lookup(uint8_t *values, const uint8_t *z, const uint8_t *ap, const uint8_t *sp, const uint8_t *a,
+                         const uint8_t *s, const uint8_t *l0, const uint8_t *l_last, const uint8_t *l_active,
+                         const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y_[32], uint32_t k,
+                         uint32_t ext_k) {
+    lookup_ctx c;
+    c.values = values; c.z = z; c.ap = ap; c.sp = sp; c.a = a; c.s = s; c.l0 = l0; c.l_last = l_last; c.l_active = l_active;
+    c.n_ext = (size_t)1 << ext_k; c.rot = (size_t)1 << (ext_k - k);
+    memcpy(&c.b, beta, 32); memcpy(&c.g, gamma, 32); memcpy(&c.y, y_, 32);
+    par_rows(quotient_lookup_rows, &c, c.n_ext);
 }
 
 /* ---------------------------------------------------------------- 8f-1: custom gates
@@ -813,17 +867,15 @@ static fe gate_value(const gate_ctx *c, const orc_value_source *v) {
     default: return c->prev;
     }
 }
-void orc_quotient_gates(uint8_t *values, const orc_graph *g, const uint8_t *const *fixed, const uint8_t *const *advice,
-                        const uint8_t *const *instance, const uint8_t *challenges, const uint8_t beta[32],
-                        const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32], uint32_t k,
-                        uint32_t ext_k) {
-    gate_ctx c;
-    c.g = g; c.fixed = fixed; c.advice = advice; c.instance = instance; c.challenges = challenges;
-    memcpy(&c.beta, beta, 32); memcpy(&c.gamma, gamma, 32); memcpy(&c.theta, theta, 32); memcpy(&c.y, y, 32);
-    c.n_ext = (size_t)1 << ext_k; c.rot_scale = (size_t)1 << (ext_k - k);
+typedef struct { gate_ctx base; uint8_t *values; } gates_job;
+static void quotient_gates_rows(void *p, size_t lo, size_t hi) {
+    const gates_job *job = (const gates_job *)p;
+    gate_ctx c = job->base;
+    const orc_graph *g = c.g;
+    uint8_t *values = job->values;
     fe *inter = (fe *)malloc(sizeof(fe) * (g->n_calculations ? g->n_calculations : 1));
     c.inter = inter;
-    for (size_t i = 0; i < c.n_ext; i++) {
+    for (size_t i = lo; i < hi; i++) {
         c.row = i;
         c.prev = *row(values, i);
         for (uint32_t q = 0; q < g->n_calculations; q++) {
@@ -853,6 +905,19 @@ void orc_quotient_gates(uint8_t *values, const orc_graph *g, const uint8_t *cons
         if (g->n_calculations) memcpy(values + 32 * i, &inter[g->n_calculations - 1], 32);
     }
     free(inter);
+}
+void orc_quotient_gates(uint8_t *values, const orc_graph *g, const uint8_t *const *fixed, const uint8_t *const *advice,
+                        const uint8_t *const *instance, const uint8_t *challenges, const uint8_t beta[32],
+                        const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32], uint32_t k,
+                        uint32_t ext_k) {
+    gates_job job;
+    gate_ctx *c = &job.base;
+    c->g = g; c->fixed = fixed; c->advice = advice; c->instance = instance; c->challenges = challenges;
+    memcpy(&c->beta, beta, 32); memcpy(&c->gamma, gamma, 32); memcpy(&c->theta, theta, 32); memcpy(&c->y, y, 32);
+    c->n_ext = (size_t)1 << ext_k; c->rot_scale = (size_t)1 << (ext_k - k);
+    c->inter = NULL; c->row = 0;
+    job.values = values;
+    par_rows(quotient_gates_rows, &job, c->n_ext);
 }
 
 /* ---------------------------------------------------------------- witness side (row W)

@@ -234,6 +234,11 @@ def lookup_product(a, s, ap, sp, beta, gamma) -> np.ndarray:
     return out
 
 
+def set_quotient_threads(threads: int) -> None:
+    """row loops of the three quotient blocks below on `threads` pthreads (upstream parallelises them with rayon)"""
+    lib().orc_set_quotient_threads(C.c_int(threads))
+
+
 def quotient_permutation(values, zs, cols, sigmas, chunk_len, l0, l_last, l_active, beta, gamma, y, k, ext_k,
                          last_rotation_abs) -> np.ndarray:
     """returns the updated numerator (values is not modified)"""

@@ -47,3 +47,76 @@ def test_point_sharded_msm_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+BATCH_WORKER = r'''
+import os, sys, threading, time
+import numpy as np
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import torch.distributed as dist
+from circuits_halo2_amd import batch as B
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# --- the setup artifacts exist once: rank 0 holds them, the broadcast hands every rank the same bytes
+rng = np.random.default_rng(7)
+k = 5
+setup = None
+if rank == 0:
+    setup = {"k": k, "shape": (4, 2, 8), "g": rng.integers(0, 256, 64 << k, dtype=np.uint8), "g_lagrange": rng.integers(0, 256, 64 << k, dtype=np.uint8),
+             "g2": bytes(range(128)), "s_g2": bytes(range(128, 256)), "fixed": [rng.integers(0, 256, 32 << k, dtype=np.uint8) for _ in range(11)],
+             "sigma": [rng.integers(0, 256, 32 << k, dtype=np.uint8) for _ in range(6)], "vk_digest": 0x1234567890ABCDEF << 100}
+got = B.broadcast_setup(setup, 0)
+ref = np.random.default_rng(7)                      # every rank re-derives what rank 0 drew
+assert got["k"] == k and got["shape"] == (4, 2, 8) and got["vk_digest"] == 0x1234567890ABCDEF << 100
+assert (got["g"] == ref.integers(0, 256, 64 << k, dtype=np.uint8)).all() and (got["g_lagrange"] == ref.integers(0, 256, 64 << k, dtype=np.uint8)).all()
+assert bytes(got["g2"]) == bytes(range(128)) and bytes(got["s_g2"]) == bytes(range(128, 256))
+for col in got["fixed"] + got["sigma"]:
+    assert (col == ref.integers(0, 256, 32 << k, dtype=np.uint8)).all()
+assert len(got["fixed"]) == 11 and len(got["sigma"]) == 6
+# --- users are dealt round-robin; every user is proven exactly once across the group; several proofs in flight
+users = list(range(3, 40))
+mine = B.deal(users)
+assert mine == users[rank::world] and all(B.owner_of(users.index(u), world) == rank for u in mine)
+peak, live, lock = [0], [0], threading.Lock()
+def prove(circuit):
+    with lock:
+        live[0] += 1
+        peak[0] = max(peak[0], live[0])
+    time.sleep(0.02)
+    with lock:
+        live[0] -= 1
+    if circuit == 17:
+        raise ValueError("lookup input value not in the table")
+    return (b"proof-%d" % circuit, [circuit, rank])
+res = B.prove_batch(None, users, None, None, levels=4, in_flight=3, prove=prove, make_circuit=lambda i: i)
+assert sorted(list(res.proofs) + list(res.errors)) == mine
+assert (17 in res.errors) == (17 in mine) and all(res.proofs[u] == (b"proof-%d" % u, [u, rank]) for u in res.proofs)
+assert peak[0] == 3, peak                                 # three proofs were in flight on this rank
+assert res.proofs_per_s() > 0
+serial = B.prove_batch(None, users, None, None, levels=4, in_flight=1, prove=prove, make_circuit=lambda i: i)
+assert serial.seconds > res.seconds * 1.5                  # the in-flight overlap is real
+merged = B.gather_proofs(res, 0)
+if rank == 0:
+    assert sorted(merged) == [u for u in users if u != 17]
+    assert all(merged[u][1][1] == B.owner_of(users.index(u), world) for u in merged)
+else:
+    assert merged is None
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_proof_batch_scheduler_gloo_world2(tmp_path):
+    """bookkeeping of the proof-level batch driver (circuits_halo2_amd/batch.py) with two ranks: the setup broadcast,
+    the round-robin deal, proofs in flight per rank, error isolation, the gather -- with stand-in provers (the real
+    prover needs the GPU; tests/test_gpu_batch.py runs it)"""
+    script = tmp_path / "batch_worker.py"
+    script.write_text(BATCH_WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2

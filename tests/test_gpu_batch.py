@@ -1,0 +1,118 @@
+"""Multi-GPU / batch paths on the real device (one rank: the GPU box has one GPU): the point-sharded MSM's exchange and
+combination steps with the HIP MSM (no injected oracle), the setup export / import that the broadcast carries, and the
+proof-level batch driver with several proofs in flight -- BASELINE configs[4] at a size a test can afford."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from circuits_halo2_amd import ffi
+    ffi.check(ffi.lib().sg_init(0))
+
+
+def test_sharded_msm_hip_path_with_an_rccl_group_of_one():
+    """`sharded_msm` with the product's own MSM (HIP) and a real RCCL process group (world 1 here): per-shard partials,
+    `all_gather_into_tensor` on the device, `combine_partials` through sg_g1_sum_affine -- compared with the oracle"""
+    _gpu()
+    import torch
+    import torch.distributed as dist
+    from circuits_halo2_amd.distributed import combine_partials, shard_bounds, sharded_msm
+    from circuits_halo2_amd import best_multiexp
+    from oracle import oracle as O
+    n = 5000
+    sc, bases = O.random_fr(52, n), O.fixed_base_mul(O.random_fr(53, n), 4)
+    want = O.best_multiexp(sc, bases, 4)
+    d_sc, d_b = torch.from_numpy(sc).cuda(), torch.from_numpy(bases).cuda()
+    # the combination step on partials of 1, 2, 3, 8 shards, each reduced by the HIP MSM
+    for world in (1, 2, 3, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_bounds(n, r, world)
+            parts.append(best_multiexp(d_sc[32 * lo:32 * hi].contiguous(), d_b[64 * lo:64 * hi].contiguous()))
+        assert (combine_partials(np.concatenate(parts)) == want).all(), world
+    # identity partials (empty shards) and P + (-P)
+    zero = np.zeros(64, dtype=np.uint8)
+    assert (combine_partials(np.concatenate([zero, want, zero])) == want).all()
+    neg = want.copy()
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    neg[32:] = np.frombuffer(((q - int.from_bytes(bytes(want[32:]), "little")) % q).to_bytes(32, "little"), dtype=np.uint8)
+    assert (combine_partials(np.concatenate([want, neg])) == zero).all()
+    # the collective path itself
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert (sharded_msm(d_sc, d_b) == want).all()
+        assert (sharded_msm(d_sc[:0], d_b[:0]) == zero).all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_setup_export_import_round_trip_and_batch_of_proofs():
+    """what `broadcast_setup` carries rebuilds an equal proving key on the receiving side; `prove_batch` with two and
+    three proofs in flight proves every user of the reference's CSV, each proof checked by the oracle's verifier"""
+    _gpu()
+    from circuits_halo2_amd import api, batch as B
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from oracle import summa_verifier as SV
+    from test_gpu_api import oracle_vk
+    levels, nc, k = 4, 2, 11
+    params, pk, vk = B.setup_on_all_ranks(k, os.path.join(GOLDEN, "hermez-raw-11"), levels, nc)
+    try:
+        params2, pk2, vk2 = B.import_setup(B.export_setup(params, pk))
+        assert vk2.fixed_comms == vk.fixed_comms and vk2.permutation_comms == vk.permutation_comms
+        assert vk2.transcript_repr == vk.transcript_repr and pk2.circuit_shape == pk.circuit_shape
+        tree = MerkleSumTree.from_csv(os.path.join(GOLDEN, "entry_16.csv"), nc)
+        ovk = oracle_vk(params, vk)
+        for in_flight, flavour, (p_, k_) in ((2, "evm", (params2, pk2)), (3, "blake2b", (params, pk))):
+            res = B.prove_batch(tree, list(range(16)), p_, k_, levels, flavour=flavour, in_flight=in_flight)
+            assert not res.errors and sorted(res.proofs) == list(range(16))
+            for user, (proof, inst) in res.proofs.items():
+                assert inst[1:] == [int.from_bytes(bytes(tree.root()[0]), "little") * pow(1 << 256, -1, SV.R) % SV.R, 556862, 556862]
+                assert SV.verify(proof, inst, ovk, flavour=flavour), (user, flavour)
+            print(f"in_flight={in_flight} {flavour}: {res.proofs_per_s():.1f} proofs/s (k = 11)")
+        params2.free()
+    finally:
+        params.free()
+
+
+def test_device_snapshot_tree_and_its_merkle_proofs():
+    """DeviceMerkleSumTree (nodes resident in HBM) hands out the same Merkle proofs as the host-mirrored tree, and a
+    proof made from one is accepted"""
+    _gpu()
+    import torch
+    from circuits_halo2_amd import api
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree, MerkleSumTree
+    from circuits_halo2_amd.utils import ints_to_fr
+    from oracle import pyref as PR
+    nc, depth = 2, 5
+    entries = [(f"user{i}", [1000 + 3 * i, 17 * i]) for i in range(1 << depth)]
+    host_tree = MerkleSumTree.from_entries(entries, nc)
+    users = ints_to_fr([int.from_bytes(PR.keccak256(name.encode()), "big") for name, _ in entries])
+    bals = ints_to_fr([b for _, bal in entries for b in bal])
+    dev_tree = DeviceMerkleSumTree(torch.from_numpy(users).cuda(), torch.from_numpy(bals).cuda(), depth, nc)
+    assert bytes(dev_tree.root()[0]) == bytes(host_tree.root()[0]) and bytes(dev_tree.root()[1]) == bytes(host_tree.root()[1])
+    for index in (0, 1, 13, 31):
+        a, b = dev_tree.generate_proof(index), host_tree.generate_proof(index)
+        assert a["path_indices"] == b["path_indices"] and a["entry"][1] == b["entry"][1]
+        assert a["entry"][0] == int.from_bytes(PR.keccak256(b["entry"][0].encode()), "big") % PR.R
+        assert bytes(a["sibling_leaf_node_hash_preimage"]) == bytes(b["sibling_leaf_node_hash_preimage"])
+        assert [bytes(x) for x in a["sibling_middle_node_hash_preimages"]] == [bytes(x) for x in b["sibling_middle_node_hash_preimages"]]
+        ca, cb = api.MstInclusionCircuit.init(a, depth), api.MstInclusionCircuit.init(b, depth)
+        assert ca.instances() == cb.instances() and ca.entry == cb.entry
+    params, pk, vk = api.generate_setup_artifacts(12, None, api.MstInclusionCircuit.init_empty(depth, nc))
+    try:
+        circuit = api.MstInclusionCircuit.init(dev_tree.generate_proof(13), depth)
+        proof = api.full_prover(params, pk, circuit, circuit.instances())
+        assert api.full_verifier(params, vk, proof, circuit.instances())
+    finally:
+        params.free()

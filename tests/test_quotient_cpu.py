@@ -135,3 +135,32 @@ def test_oracle_gate_interpreter_vs_python_integers(seed):
     for rowi in range(ne):
         want = _py_eval_graph(graph, rowi, cols, chal, *ints, P.fr_from_bytes(start[32 * rowi:32 * rowi + 32].tobytes()), ne, scale)
         assert P.fr_from_bytes(got[32 * rowi:32 * rowi + 32].tobytes()) == want
+
+
+def test_threaded_row_loops_equal_the_serial_ones():
+    """orc_set_quotient_threads (used by bench.py's proof-level CPU baseline): the three quotient blocks on 3 pthreads
+    give the serial result, also with row counts that do not divide evenly"""
+    k, ext_k = 9, 11
+    ne = 1 << ext_k
+    rnd = lambda s: O.random_fr(s, ne)
+    beta, gamma, theta, y = (O.random_fr(300 + i, 1) for i in range(4))
+    graph = {"constants": O.random_fr(310, 2), "rotations": [0, 1, -1],
+             "calculations": [(2, (3, 0, 1), (2, 1, 2)), (0, (1, 0, 0), (0, 1, 0)), (3, (1, 1, 0), (0, 0, 0)),
+                              (6, (10, 0, 0), (9, 0, 0), [(1, 2, 0), (3, 1, 0)])]}
+    fixed, advice, inst = [rnd(320), rnd(321)], [rnd(322), rnd(323)], [rnd(324)]
+    perm_args = ([rnd(330), rnd(331)], [rnd(332 + i) for i in range(5)], [rnd(340 + i) for i in range(5)], 3, rnd(350), rnd(351), rnd(352),
+                 beta, gamma, y, k, ext_k, 6)
+    look_args = (rnd(360), rnd(361), rnd(362), rnd(363), rnd(364), rnd(365), rnd(366), rnd(367), beta, gamma, y, k, ext_k)
+    start = rnd(370)
+
+    def run():
+        return (O.quotient_gates(start, graph, fixed, advice, inst, O.random_fr(311, 1), beta, gamma, theta, y, k, ext_k),
+                O.quotient_permutation(start, *perm_args), O.quotient_lookup(start, *look_args))
+    try:
+        serial = run()
+        for threads in (3, 7):
+            O.set_quotient_threads(threads)
+            for a, b in zip(serial, run()):
+                assert (a == b).all(), threads
+    finally:
+        O.set_quotient_threads(1)
