@@ -70,6 +70,7 @@ class MstInclusionCircuit:
         self.sibling_middle_node_hash_preimages = [list(p) for p in sibling_middle_node_hash_preimages]
         self.root = root
         self._assignment = {}
+        self._device = None       # (DeviceMerkleSumTree, user index): the witness is synthesized on the device
 
     @classmethod
     def init_empty(cls, levels: int, n_currencies: int = 2, n_bytes: int = 8) -> "MstInclusionCircuit":
@@ -93,6 +94,17 @@ class MstInclusionCircuit:
                    [_fr_ints(p) for p in merkle_proof["sibling_middle_node_hash_preimages"]],
                    (_fr_ints(root_hash)[0], _fr_ints(root_bal)))
 
+    @classmethod
+    def init_from_tree(cls, tree, user_index: int, n_bytes: int = 8) -> "MstInclusionCircuit":
+        """`init(tree.generate_proof(user_index))` for a snapshot that lives on the device (DeviceMerkleSumTree): the
+        Merkle proof is not brought to the host at all -- the advice columns are laid out by a kernel straight from
+        the tree's node arrays (sg_mst_inclusion_witness_dev), only the public inputs come back"""
+        if not 0 <= user_index < (1 << tree.depth):
+            raise IndexError("Index out of bounds")
+        c = cls(tree.depth, tree.n_currencies, n_bytes, None, [(user_index >> l) & 1 for l in range(tree.depth)], None, None, None)
+        c._device = (tree, int(user_index))
+        return c
+
     # --- WithInstances [REF circuits/mod.rs:9-12, merkle_sum_tree.rs:47-60]
     def num_instances(self) -> int:
         return 2 + self.n_currencies
@@ -106,12 +118,19 @@ class MstInclusionCircuit:
 
     def instances(self) -> list:
         """[[leaf hash, root hash, root balances..]]"""
+        if self._device is not None:
+            return [self._device[0].public_inputs(self._device[1])]
         return [[self.leaf_hash(), self.root[0]] + list(self.root[1])]
 
     # --- Circuit::synthesize, through halo2's floor planner [REF merkle_sum_tree.rs:228-520]
     def synthesize(self, k: int):
         """the assignment of this circuit over 2^k rows in the reference's own floor plan: fixed columns, permutation,
         advice columns, the values exposed as public inputs (mst_inclusion.reference_assignment)"""
+        if self._device is not None and self.entry is None:   # host view of a device-side circuit: fetch the Merkle proof
+            mp = MstInclusionCircuit.init(self._device[0].generate_proof(self._device[1]), self.levels, self.n_currencies, self.n_bytes)
+            self.entry, self.root = mp.entry, mp.root
+            self.sibling_leaf_node_hash_preimage = mp.sibling_leaf_node_hash_preimage
+            self.sibling_middle_node_hash_preimages = mp.sibling_middle_node_hash_preimages
         if k not in self._assignment:
             self._assignment[k] = M.reference_assignment(k, self.entry[0], list(self.entry[1]), self.path_indices,
                                                           self.sibling_leaf_node_hash_preimage,
@@ -171,9 +190,35 @@ def generate_setup_artifacts(k: int, params_path: str | None, circuit: MstInclus
     return params, pk, vk
 
 
+def synthesize_on_device(pk, tree, user_indices):
+    """advice columns of `len(user_indices)` inclusion circuits in one launch: a (users, 3, 32 n) uint8 tensor.  The floor
+    plan enters as mst_inclusion.witness_program (cached on the proving key, resident on the device)."""
+    import ctypes as C
+    import torch
+    from . import ffi
+    levels, nc, nb = pk.circuit_shape
+    if (tree.depth, tree.n_currencies) != (levels, nc):
+        raise ValueError("the proving key was generated for a circuit of other dimensions")
+    cached = getattr(pk, "_witness_program", None)
+    if cached is None:
+        prog, n_items, n_absorbs, _, rows_used = M.witness_program(pk.k, levels, nc, nb)
+        cached = pk._witness_program = (torch.from_numpy(prog.view(np.int32).copy()).cuda(), n_items, n_absorbs)
+    d_prog, n_items, n_absorbs = cached
+    idx = torch.tensor([int(i) for i in user_indices], dtype=torch.int32, device="cuda")
+    advice = torch.empty((len(user_indices), 3, 32 * pk.n), dtype=torch.uint8, device="cuda")
+    ffi.check(ffi.lib().sg_mst_inclusion_witness_dev(
+        ffi.dev_ptr(d_prog), C.c_uint32(n_items), C.c_uint32(n_absorbs), ffi.dev_ptr(tree.d_users), ffi.dev_ptr(tree.d_h),
+        ffi.dev_ptr(tree.d_b), C.c_uint32(levels), C.c_uint32(nc), ffi.dev_ptr(idx), C.c_uint32(len(user_indices)),
+        ffi.dev_ptr(advice), C.c_uint64(pk.n), ffi.current_stream_ptr()))
+    return advice
+
+
 def _advice_columns(pk, circuit: MstInclusionCircuit):
     if getattr(pk, "circuit_shape", circuit.shape()) != circuit.shape():
         raise ValueError("the proving key was generated for a circuit of other dimensions")
+    if circuit._device is not None:
+        adv = synthesize_on_device(pk, circuit._device[0], [circuit._device[1]])
+        return [adv[0, j] for j in range(3)]
     asg = circuit.synthesize(pk.k)
     return [_device_column(c, pk.n) for c in asg["advice"]]
 

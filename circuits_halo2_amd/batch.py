@@ -153,7 +153,10 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     mine = deal(list(user_indices))
     res = BatchResult()
     if make_circuit is None:
-        make_circuit = lambda i: api.MstInclusionCircuit.init(tree.generate_proof(i), levels)
+        if hasattr(tree, "d_h"):      # a device-resident snapshot: the witness never visits the host
+            make_circuit = lambda i: api.MstInclusionCircuit.init_from_tree(tree, i)
+        else:
+            make_circuit = lambda i: api.MstInclusionCircuit.init(tree.generate_proof(i), levels)
     if prove is None:
         if flavour == "evm":
             prove = lambda c: api.gen_proof_solidity_calldata(params, pk, c)

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -144,38 +145,149 @@ struct Context {
   DomainConsts* d_consts = nullptr;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
-  std::map<uint64_t, Srs> srs;
-  uint64_t next_handle = 1;
 };
 
-std::mutex g_mu;
-Context* g_ctx = nullptr;
+// What every lane shares: the device index, the SRS cache (read-only after upload / precompute) and the runtime
+// parameters.  Guarded by its own short mutex (never held across device work).
+struct Shared {
+  std::mutex mu;
+  int device = -1;
+  std::map<uint64_t, Srs> srs;
+  uint64_t next_handle = 1;
+  std::vector<std::pair<std::string, int>> params;  // sg_set_param history, replayed on every new lane
+};
 
-int need_ctx() {
-  if (!g_ctx) {
-    // lazy default initialisation on device 0 keeps the seam a pure function call, like
-    // best_multiexp / best_fft
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
-    Context* c = new Context();
-    hipError_t e = hipSetDevice(0);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = c->ntt.init();
-    if (e == hipSuccess) e = c->msm.init();
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[1], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
-    if (e != hipSuccess) {
-      delete c;
-      return hip_fail("sg_init", e);
-    }
-    c->device = 0;
-    g_ctx = c;
+// Concurrency model.  The library keeps kLanes independent contexts ("lanes"), each with its own streams, MSM
+// engines, NTT plans, staging and scratch buffers.  A call takes ONE lane for its whole duration (lane 0 when it is
+// free, so a single-threaded caller always works in the same warm work space) and touches nothing of the others:
+// calls from different host threads -- halo2 reaches best_multiexp / best_fft from rayon iterators; the batch driver
+// keeps several proofs in flight -- run side by side on the device, host tails included.  Asynchronous `_dev` calls
+// leave work behind only in buffers keyed by the caller's stream, so a lane can be handed to the next caller as soon
+// as the call returns.  The lock is per lane and re-entrant for the owning thread (entry points that stage host
+// buffers and then call their `_dev` form keep the lane in between).
+Shared g_sh;
+static constexpr int kLanes = 4;
+struct Lane {
+  std::mutex mu;
+  Context* ctx = nullptr;
+};
+Lane g_lanes[kLanes];
+std::atomic<unsigned> g_rr{0};
+thread_local Context* g_ctx = nullptr;   // the lane this thread holds (valid inside LOCKED_CTX scopes only)
+thread_local Lane* g_held = nullptr;
+thread_local int g_depth = 0;
+
+int apply_param(Context& c, const std::string& s, int value);
+
+int make_context(int device, Context** out) {
+  Context* c = new Context();
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = c->ntt.init();
+  if (e == hipSuccess) e = c->msm.init();
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[1], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail("sg_init", e);
   }
-  hipError_t e = hipSetDevice(g_ctx->device);
-  if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+  c->device = device;
+  *out = c;
   return SG_OK;
+}
+
+void destroy_context(Context* c) {
+  for (auto& kv : c->t_evals) (void)hipFree(kv.second);
+  c->ntt.clear();
+  c->msm.release();
+  c->msm_b.release();
+  c->witness.release();
+  for (auto& bs : c->bstream) {
+    if (bs) (void)hipStreamDestroy(bs);
+  }
+  for (auto& ts : c->tstream) {
+    if (ts) (void)hipStreamDestroy(ts);
+  }
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  c->stage_a.release();
+  c->stage_b.release();
+  c->scratch.release();
+  for (auto& kv : c->ntt_scratch) kv.second.release();
+  for (auto& kv : c->stream_scratch) kv.second.release();
+  if (c->d_consts) (void)hipFree(c->d_consts);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// take a lane for the calling thread (g_ctx / g_held): lane 0 if free, else the first free one, else wait
+int acquire_lane() {
+  int device;
+  std::vector<std::pair<std::string, int>> params;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    if (g_sh.device < 0) {
+      // lazy default initialisation on device 0 keeps the seam a pure function call, like best_multiexp / best_fft
+      int n = 0;
+      if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
+      g_sh.device = 0;
+    }
+    device = g_sh.device;
+    params = g_sh.params;
+  }
+  Lane* lane = nullptr;
+  for (int i = 0; i < kLanes && !lane; i++)
+    if (g_lanes[i].mu.try_lock()) lane = &g_lanes[i];
+  if (!lane) {
+    lane = &g_lanes[g_rr.fetch_add(1) % kLanes];
+    lane->mu.lock();
+  }
+  if (!lane->ctx) {
+    int rc = make_context(device, &lane->ctx);
+    if (rc != SG_OK) {
+      lane->mu.unlock();
+      return rc;
+    }
+    for (auto& kv : params) (void)apply_param(*lane->ctx, kv.first, kv.second);
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    lane->mu.unlock();
+    return hip_fail("hipSetDevice", e);
+  }
+  g_held = lane;
+  g_ctx = lane->ctx;
+  return SG_OK;
+}
+struct LaneHold {
+  int rc = SG_OK;
+  LaneHold() {
+    if (g_depth > 0) {
+      g_depth++;
+      return;
+    }
+    rc = acquire_lane();
+    if (rc == SG_OK) g_depth = 1;
+  }
+  ~LaneHold() {
+    if (rc != SG_OK) return;
+    if (--g_depth == 0) {
+      Lane* l = g_held;
+      g_held = nullptr;
+      g_ctx = nullptr;
+      l->mu.unlock();
+    }
+  }
+  LaneHold(const LaneHold&) = delete;
+  LaneHold& operator=(const LaneHold&) = delete;
+};
+
+// the SRS behind a handle; entries live until sg_srs_free / sg_shutdown (std::map nodes are stable)
+Srs* find_srs(uint64_t handle) {
+  std::lock_guard<std::mutex> lk(g_sh.mu);
+  auto it = g_sh.srs.find(handle);
+  return it == g_sh.srs.end() ? nullptr : &it->second;
 }
 
 int get_consts(uint32_t k, const DomainConsts** out) {
@@ -239,17 +351,34 @@ int download(uint8_t* host, const void* dev, size_t bytes, hipStream_t s) {
   return SG_OK;
 }
 
-#define LOCKED_CTX()                          \
-  std::lock_guard<std::mutex> _lk(g_mu);      \
-  {                                           \
-    int _rc = need_ctx();                     \
-    if (_rc != SG_OK) return _rc;             \
-  }
+#define LOCKED_CTX()     \
+  LaneHold _hold;        \
+  if (_hold.rc != SG_OK) return _hold.rc;
 #define TRY(x)                  \
   do {                          \
     int _rc = (x);              \
     if (_rc != SG_OK) return _rc; \
   } while (0)
+
+int apply_param(Context& c, const std::string& s, int value) {
+  if (s == "msm.window_bits") c.msm.config().window_bits = c.msm_b.config().window_bits = (uint32_t)value;
+  else if (s == "msm.log_seg") c.msm.config().log_seg = c.msm_b.config().log_seg = (uint32_t)std::min(12, value);
+  else if (s == "msm.log_fuse_entries") { c.msm.config().log_fuse_entries = c.msm_b.config().log_fuse_entries = (uint32_t)std::max(16, std::min(30, value)); }
+  else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; c.msm.config().red_threads = c.msm_b.config().red_threads = v; }
+  else if (s == "msm.log_scatter_rounds") c.msm.config().log_scatter_rounds = c.msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));
+  else if (s == "msm.two_pass") c.msm.config().two_pass = c.msm_b.config().two_pass = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "msm.acc_threads") c.msm.config().acc_threads = c.msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
+  else if (s == "msm.red2d_max_sets") c.msm.config().red2d_max_sets = c.msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));
+  else if (s == "msm.red2d") c.msm.config().red2d = c.msm_b.config().red2d = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "msm.quad") c.msm.config().quad = c.msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "msm.log_red_chunk") c.msm.config().log_red_chunk = c.msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
+  else if (s == "ntt.tile_log") c.ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
+  else if (s == "ntt.threads") c.ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));
+  else if (s == "ntt.max_single_log") { c.ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); c.ntt.clear(); }
+  else if (s == "ntt.max_multi_log") { c.ntt.config().max_multi_log = (uint32_t)std::max(4, std::min(12, value)); c.ntt.clear(); }
+  else return fail(SG_ERR_INVALID, "sg_set_param: unknown parameter");
+  return SG_OK;
+}
 
 }  // namespace
 
@@ -264,64 +393,46 @@ const char* sg_version(void) { return "summa_gpu 0.1.0 gfx950"; }
 const char* sg_last_error(void) { return g_err; }
 
 int sg_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx && g_ctx->device == device) return SG_OK;
-  if (g_ctx) return fail(SG_ERR_INVALID, "sg_init: already bound to another device (one process per GPU)");
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n) return fail(SG_ERR_INVALID, "sg_init: device index out of range");
-  Context* c = new Context();
-  hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = c->ntt.init();
-  if (e == hipSuccess) e = c->msm.init();
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[1], hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc(&c->d_consts, sizeof(DomainConsts));
-  if (e != hipSuccess) {
-    delete c;
-    return hip_fail("sg_init", e);
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    if (g_sh.device == device) return SG_OK;
+    if (g_sh.device >= 0) return fail(SG_ERR_INVALID, "sg_init: already bound to another device (one process per GPU)");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SG_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(SG_ERR_INVALID, "sg_init: device index out of range");
+    g_sh.device = device;
   }
-  c->device = device;
-  g_ctx = c;
+  LOCKED_CTX();   // creates lane 0: streams, plans' home, MSM engine attributes
   return SG_OK;
 }
 
 void sg_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx) return;
-  (void)hipSetDevice(g_ctx->device);
-  (void)hipDeviceSynchronize();
-  for (auto& kv : g_ctx->srs) {
-    (void)hipFree(kv.second.g);
-    (void)hipFree(kv.second.g_lagrange);
-    for (auto& t : kv.second.tab)
-      if (t.table) (void)hipFree(t.table);
+  if (g_depth > 0) return;   // never from inside a call
+  for (auto& l : g_lanes) l.mu.lock();
+  int device;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    device = g_sh.device;
   }
-  for (auto& kv : g_ctx->t_evals) (void)hipFree(kv.second);
-  g_ctx->ntt.clear();
-  g_ctx->msm.release();
-  g_ctx->msm_b.release();
-  g_ctx->witness.release();
-  for (auto& bs : g_ctx->bstream) {
-    if (bs) (void)hipStreamDestroy(bs);
+  if (device >= 0) {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    for (auto& l : g_lanes) {
+      if (l.ctx) destroy_context(l.ctx);
+      l.ctx = nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    for (auto& kv : g_sh.srs) {
+      (void)hipFree(kv.second.g);
+      (void)hipFree(kv.second.g_lagrange);
+      for (auto& t : kv.second.tab)
+        if (t.table) (void)hipFree(t.table);
+    }
+    g_sh.srs.clear();
+    g_sh.params.clear();
+    g_sh.device = -1;
   }
-  for (auto& ts : g_ctx->tstream) {
-    if (ts) (void)hipStreamDestroy(ts);
-  }
-  if (g_ctx->ev_in) (void)hipEventDestroy(g_ctx->ev_in);
-  g_ctx->stage_a.release();
-  g_ctx->stage_b.release();
-  g_ctx->scratch.release();
-  for (auto& kv : g_ctx->ntt_scratch) kv.second.release();
-  g_ctx->ntt_scratch.clear();
-  for (auto& kv : g_ctx->stream_scratch) kv.second.release();
-  g_ctx->stream_scratch.clear();
-  if (g_ctx->d_consts) (void)hipFree(g_ctx->d_consts);
-  if (g_ctx->stream) (void)hipStreamDestroy(g_ctx->stream);
-  delete g_ctx;
-  g_ctx = nullptr;
+  for (auto& l : g_lanes) l.mu.unlock();
 }
 
 // ------------------------------------------------------------------ MSM
@@ -430,8 +541,8 @@ int sg_msm_g1_batch(const uint8_t* const* scalars, const uint8_t* const* bases, 
                     uint8_t* out_affine) {
   if (count && (!scalars || !bases || !n || !out_affine)) return fail(SG_ERR_INVALID, "sg_msm_g1_batch: null argument");
   std::vector<const void*> ds(count), db(count);
+  LOCKED_CTX();   // held across staging AND the batch: the staging buffers are this lane's
   {
-    LOCKED_CTX();
     size_t tot_s = 0, tot_b = 0;
     for (size_t i = 0; i < count; i++) { tot_s += n[i] * 32; tot_b += n[i] * 64; }
     hipError_t e = g_ctx->stage_a.reserve(tot_s + 64);
@@ -485,20 +596,28 @@ int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint6
     if (s.g_lagrange) (void)hipFree(s.g_lagrange);
     return hip_fail("sg_srs_upload", e);
   }
-  uint64_t h = g_ctx->next_handle++;
-  g_ctx->srs[h] = s;
-  *handle_out = h;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    const uint64_t h = g_sh.next_handle++;
+    g_sh.srs[h] = s;
+    *handle_out = h;
+  }
   return SG_OK;
 }
 int sg_srs_free(uint64_t handle) {
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "sg_srs_free: unknown handle");
-  (void)hipFree(it->second.g);
-  (void)hipFree(it->second.g_lagrange);
-  for (auto& t : it->second.tab)
+  Srs gone;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    auto it = g_sh.srs.find(handle);
+    if (it == g_sh.srs.end()) return fail(SG_ERR_INVALID, "sg_srs_free: unknown handle");
+    gone = it->second;
+    g_sh.srs.erase(it);
+  }
+  (void)hipFree(gone.g);          // hipFree waits for the device: work in flight on these bases completes first
+  (void)hipFree(gone.g_lagrange);
+  for (auto& t : gone.tab)
     if (t.table) (void)hipFree(t.table);
-  g_ctx->srs.erase(it);
   return SG_OK;
 }
 // Precompute the fixed-base window table of one basis: W x 2^k points, row w = 2^(offset_w) * basis.
@@ -507,9 +626,9 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
   if (basis != 0 && basis != 1) return fail(SG_ERR_INVALID, "sg_srs_precompute: bad basis");
   if (window_bits && (window_bits < 4 || window_bits > 16)) return fail(SG_ERR_INVALID, "sg_srs_precompute: window_bits in [4, 16]");
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  Srs& s = it->second;
+  Srs* srs_p = find_srs(handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs& s = (*srs_p);
   const size_t n = (size_t)1 << s.k;
   const uint32_t c = window_bits ? window_bits : fixed_window_bits_for(n);
   FixedTable t;
@@ -522,11 +641,11 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
 }
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k) {
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  if (d_g) *d_g = it->second.g;
-  if (d_g_lagrange) *d_g_lagrange = it->second.g_lagrange;
-  if (k) *k = it->second.k;
+  Srs* srs_p = find_srs(handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (d_g) *d_g = (*srs_p).g;
+  if (d_g_lagrange) *d_g_lagrange = (*srs_p).g_lagrange;
+  if (k) *k = (*srs_p).k;
   return SG_OK;
 }
 static hipError_t commit_run(const Srs& s, int basis, const fp_words* d_scalars, size_t n, hipStream_t stream,
@@ -545,11 +664,11 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
                         uint8_t out_affine[64], sg_msm_timings* timings) {
   if (!out_affine || (n && !d_scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(srs_handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  Srs* srs_p = find_srs(srs_handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   MsmTimings tm;
-  hipError_t e = commit_run(it->second, basis, static_cast<const fp_words*>(d_scalars), n, pick_stream(stream), out_affine,
+  hipError_t e = commit_run((*srs_p), basis, static_cast<const fp_words*>(d_scalars), n, pick_stream(stream), out_affine,
                             timings ? &tm : nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
   if (timings) {
@@ -572,10 +691,10 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
   for (size_t i = 0; i < count; i++)
     if (n && !d_scalars[i]) return fail(SG_ERR_INVALID, "sg_commit_batch: null argument");
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(srs_handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
-  const Srs& s = it->second;
+  Srs* srs_p = find_srs(srs_handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  const Srs& s = (*srs_p);
   std::vector<size_t> ns(count, n);
   const bool fixed = s.tab[basis].table != nullptr;
   std::vector<const void*> bases(count, fixed ? (const void*)s.tab[basis].table : (const void*)(basis ? s.g_lagrange : s.g));
@@ -589,10 +708,10 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
   for (size_t i = 0; i < count; i++)
     if ((n && !d_scalars[i]) || (basis[i] != 0 && basis[i] != 1)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(srs_handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
-  const Srs& s = it->second;
+  Srs* srs_p = find_srs(srs_handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  const Srs& s = (*srs_p);
   // fixed-base only when both tables exist with one plan; otherwise the generic fused path over g / g_lagrange
   const bool fixed = s.tab[0].table && s.tab[1].table && s.tab[0].c == s.tab[1].c && s.tab[0].n == s.tab[1].n;
   std::vector<size_t> ns(count, n);
@@ -604,11 +723,11 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && !scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
-  auto it = g_ctx->srs.find(srs_handle);
-  if (it == g_ctx->srs.end()) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  if (n > ((size_t)1 << it->second.k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  Srs* srs_p = find_srs(srs_handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
-  hipError_t e = commit_run(it->second, basis, reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, g_ctx->stream,
+  hipError_t e = commit_run((*srs_p), basis, reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, g_ctx->stream,
                             out_affine);
   if (e != hipSuccess) return hip_fail("msm", e);
   return SG_OK;
@@ -995,8 +1114,8 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange) {
   if (!g || !g_lagrange || k > 28) return fail(SG_ERR_INVALID, "sg_g1_to_lagrange: bad argument");
   const size_t bytes = (size_t)64 << k;
   words8 wi, ni;
+  LOCKED_CTX();   // one lane for staging, transform and read-back
   {
-    LOCKED_CTX();
     const DomainConsts* dc;
     TRY(get_consts(k, &dc));
     wi = dc->omega_inv;
@@ -1009,7 +1128,6 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange) {
   int rc = sg_g1_fft_dev(g_ctx->stage_a.p, g_ctx->stage_b.p, reinterpret_cast<const uint8_t*>(&wi),
                          reinterpret_cast<const uint8_t*>(&ni), k, g_ctx->stream);
   if (rc != SG_OK) return rc;
-  LOCKED_CTX();
   return download(g_lagrange, g_ctx->stage_b.p, bytes, g_ctx->stream);
 }
 
@@ -1113,13 +1231,9 @@ int sg_fr_eval_poly_batch_dev(const void* const* d_polys, size_t n, const uint8_
 }
 int sg_fr_eval_poly(const uint8_t* coeffs, size_t n, const uint8_t x[32], uint8_t out[32]) {
   if (!x || !out || (n && !coeffs)) return fail(SG_ERR_INVALID, "sg_fr_eval_poly: null argument");
-  const void* d = nullptr;
-  {
-    LOCKED_CTX();
-    TRY(upload(g_ctx->stage_a, coeffs, n * 32, g_ctx->stream));
-    d = g_ctx->stage_a.p;
-  }
-  return sg_fr_eval_poly_dev(d, n, x, g_ctx->stream, out);
+  LOCKED_CTX();   // the staging buffer is this lane's until the evaluation has read it
+  TRY(upload(g_ctx->stage_a, coeffs, n * 32, g_ctx->stream));
+  return sg_fr_eval_poly_dev(g_ctx->stage_a.p, n, x, g_ctx->stream, out);
 }
 int sg_fr_batch_invert_dev(void* d_a, size_t n, void* stream) {
   if (n && !d_a) return fail(SG_ERR_INVALID, "sg_fr_batch_invert: null argument");
@@ -1465,26 +1579,45 @@ int sg_mst_build_dev(const void* d_usernames, const void* d_leaf_balances, uint3
   return SG_OK;
 }
 
+// Circuit::synthesize on the device for users of a device-resident tree (witness.hip: the program is the floor plan)
+int sg_mst_inclusion_witness_dev(const void* d_program, uint32_t n_items, uint32_t n_absorbs, const void* d_usernames,
+                                 const void* d_node_hashes, const void* d_node_balances, uint32_t depth, uint32_t n_currencies,
+                                 const void* d_user_indices, uint32_t n_users, void* d_advice, uint64_t rows, void* stream) {
+  if (!d_program || !d_usernames || !d_node_hashes || !d_node_balances || !d_user_indices || !d_advice)
+    return fail(SG_ERR_INVALID, "sg_mst_inclusion_witness: null argument");
+  if (depth > 30 || n_currencies == 0 || n_currencies > 64 || rows == 0 || rows > (1ull << 28) || n_items > (1u << 24) || n_users > 65535)
+    return fail(SG_ERR_INVALID, "sg_mst_inclusion_witness: bad size");
+  LOCKED_CTX();
+  hipStream_t s = pick_stream(stream);
+  hipError_t e = g_ctx->witness.init(g_ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_advice, 0, (size_t)n_users * 3 * rows * 32, s);
+  if (e == hipSuccess)
+    e = g_ctx->witness.inclusion_witness(static_cast<const uint32_t*>(d_program), n_items, n_absorbs,
+                                         static_cast<const fp_words*>(d_usernames), static_cast<const fp_words*>(d_node_hashes),
+                                         static_cast<const fp_words*>(d_node_balances), depth, n_currencies,
+                                         static_cast<const uint32_t*>(d_user_indices), n_users, static_cast<fp_words*>(d_advice),
+                                         (size_t)rows, s);
+  if (e != hipSuccess) return hip_fail("mst inclusion witness", e);
+  return SG_OK;
+}
+
 int sg_set_param(const char* name, int value) {
   if (!name || value < 0) return fail(SG_ERR_INVALID, "sg_set_param: bad argument");
-  LOCKED_CTX();
-  std::string s(name);
-  if (s == "msm.window_bits") g_ctx->msm.config().window_bits = g_ctx->msm_b.config().window_bits = (uint32_t)value;
-  else if (s == "msm.log_seg") g_ctx->msm.config().log_seg = g_ctx->msm_b.config().log_seg = (uint32_t)std::min(12, value);
-  else if (s == "msm.log_fuse_entries") { g_ctx->msm.config().log_fuse_entries = g_ctx->msm_b.config().log_fuse_entries = (uint32_t)std::max(16, std::min(30, value)); }
-  else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; g_ctx->msm.config().red_threads = g_ctx->msm_b.config().red_threads = v; }
-  else if (s == "msm.log_scatter_rounds") g_ctx->msm.config().log_scatter_rounds = g_ctx->msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));
-  else if (s == "msm.two_pass") g_ctx->msm.config().two_pass = g_ctx->msm_b.config().two_pass = (uint32_t)std::min(2, std::max(0, value));
-  else if (s == "msm.acc_threads") g_ctx->msm.config().acc_threads = g_ctx->msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
-  else if (s == "msm.red2d_max_sets") g_ctx->msm.config().red2d_max_sets = g_ctx->msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));
-  else if (s == "msm.red2d") g_ctx->msm.config().red2d = g_ctx->msm_b.config().red2d = (uint32_t)std::min(2, std::max(0, value));
-  else if (s == "msm.quad") g_ctx->msm.config().quad = g_ctx->msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
-  else if (s == "msm.log_red_chunk") g_ctx->msm.config().log_red_chunk = g_ctx->msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
-  else if (s == "ntt.tile_log") g_ctx->ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
-  else if (s == "ntt.threads") g_ctx->ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));
-  else if (s == "ntt.max_single_log") { g_ctx->ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); g_ctx->ntt.clear(); }
-  else if (s == "ntt.max_multi_log") { g_ctx->ntt.config().max_multi_log = (uint32_t)std::max(4, std::min(12, value)); g_ctx->ntt.clear(); }
-  else return fail(SG_ERR_INVALID, "sg_set_param: unknown parameter");
+  if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_set_param: not from inside a call");
+  LOCKED_CTX();   // makes sure a context exists to validate the name against
+  const std::string s(name);
+  int rc = apply_param(*g_ctx, s, value);
+  if (rc != SG_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    g_sh.params.emplace_back(s, value);   // lanes created later replay it
+  }
+  Lane* mine = g_held;
+  for (auto& l : g_lanes) {               // lanes that exist already: when they are idle
+    if (&l == mine) continue;
+    std::lock_guard<std::mutex> lk(l.mu);
+    if (l.ctx) (void)apply_param(*l.ctx, s, value);
+  }
   return SG_OK;
 }
 

@@ -322,6 +322,16 @@ class DeviceMerkleSumTree:
             self._root = (h[0], b[0])
         return self._root
 
+    def public_inputs(self, index: int):
+        """[leaf hash, root hash, root balances..] of user `index` as integers: `circuit.instances()[0]`"""
+        if not 0 <= index < (1 << self.depth):
+            raise IndexError("Index out of bounds")
+        h, _, _, _ = self._rows([index], [], [])
+        rinv = pow(1 << 256, -1, R_MODULUS)
+        to_int = lambda row: int.from_bytes(bytes(row), "little") * rinv % R_MODULUS
+        rh, rb = self.root()
+        return [to_int(h[0]), to_int(rh)] + [to_int(rb[32 * c:32 * c + 32]) for c in range(self.n_currencies)]
+
     def generate_proof(self, index: int):
         """the fields of the reference's MerkleProof (see MerkleSumTree.generate_proof); `entry` carries the username as
         its field element (int), since a device snapshot holds no names"""

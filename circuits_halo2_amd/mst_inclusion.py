@@ -707,3 +707,90 @@ def reference_assignment(k: int, username: int, balances, path_bits, sibling_lea
     for c, cell in enumerate(cur_bal):
         fp.expose(cell, 2 + c)
     return fp.finish()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same floor plan as a PROGRAM for the device (csrc/witness.hip, C ABI sg_mst_inclusion_witness_dev): where
+# reference_assignment above writes values, witness_program records which tree node every cell holds.  In an inclusion
+# circuit every witnessed value is a node of the Merkle sum tree or a path bit -- the running hash / balances are the
+# path's nodes, the swap outputs are the two children of the path's parent -- so a cell is a "symbol" relative to the
+# user's leaf index and the whole assignment of any number of users is one kernel launch.
+SYM_USER, SYM_HASH, SYM_BAL, SYM_BIT = 0, 1, 2, 3
+MODE_PATH, MODE_SIBLING, MODE_SIBLING_CHILD, MODE_ORDERED_CHILD = 0, 1, 2, 3
+
+
+def sym(kind: int, level: int = 0, mode: int = 0, lane: int = 0) -> int:
+    return kind | level << 4 | mode << 10 | lane << 13
+
+
+@lru_cache(maxsize=None)
+def witness_program(k: int, levels: int, nc: int, n_bytes: int = 8):
+    """-> (program uint32 array: n_items x 5 items then n_absorbs x 3 absorbs, n_items, n_absorbs, instance symbols,
+    rows used).  Walks `MstInclusionCircuit::synthesize` exactly as reference_assignment does (same regions in the same
+    order through the same floor planner, constants column included); checked cell by cell against it."""
+    import numpy as np
+    fp = _ReferenceFloorPlan(k)               # for its floor planner only
+    a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
+    cells, ranges, hashes, absorbs = [], [], [], []
+
+    def constants(count):
+        col = (FIXED, 2)
+        fp.next_free[col] = fp.next_free.get(col, 0) + count
+
+    def witness(column, s):
+        cells.append((column, fp.region([(ADVICE, column)], 1), s))
+        return s
+
+    def hash_(chip, inputs, digest):
+        st = fp.region([a0, a1], 1)
+        constants(2)
+        first = len(absorbs)
+        for s in inputs:
+            add = fp.region([a0, a1, ("selector", "pad", chip)], 3)
+            perm = fp.region([a0, a1, a2] + [(FIXED, j) for j in range(4)] + [("selector", "full", chip), ("selector", "partial", chip)], 37)
+            absorbs.append((add, perm, s))
+        hashes.append((st, first, len(inputs), chip))
+        return digest
+
+    def range_check(s):
+        ranges.append((fp.region([a0, ("selector", "lookup")], n_bytes + 1), s))
+        constants(1)
+
+    path_hash = lambda level: sym(SYM_HASH, level, MODE_PATH)
+    user = witness(0, sym(SYM_USER))
+    cur_bal = [witness(1, sym(SYM_BAL, 0, MODE_PATH, c)) for c in range(nc)]
+    cur_hash = hash_(1, [user] + cur_bal, path_hash(0))
+    fp.region([(FIXED, 4)], 256)
+    for level in range(levels):
+        if level == 0:
+            sib_user = witness(0, sym(SYM_USER, 0, 1))
+            sib_bal = [witness(1, sym(SYM_BAL, 0, MODE_SIBLING, c)) for c in range(nc)]
+            sib_hash = hash_(1, [sib_user] + sib_bal, sym(SYM_HASH, 0, MODE_SIBLING))
+            for c in range(nc):
+                range_check(cur_bal[c])
+                range_check(sib_bal[c])
+        else:
+            sib_bal = [witness(1, sym(SYM_BAL, level, MODE_SIBLING, c)) for c in range(nc)]
+            left = witness(2, sym(SYM_HASH, level, MODE_SIBLING_CHILD, 0))
+            right = witness(2, sym(SYM_HASH, level, MODE_SIBLING_CHILD, 1))
+            sib_hash = hash_(2, sib_bal + [left, right], sym(SYM_HASH, level, MODE_SIBLING))
+            for c in range(nc):
+                range_check(sib_bal[c])
+        bit = witness(0, sym(SYM_BIT, level))
+        st = fp.region([a0, a1, a2, ("selector", "swap")], 2)
+        left, right = sym(SYM_HASH, level, MODE_ORDERED_CHILD, 0), sym(SYM_HASH, level, MODE_ORDERED_CHILD, 1)
+        cells.extend([(0, st, cur_hash), (1, st, sib_hash), (2, st, bit), (0, st + 1, left), (1, st + 1, right)])
+        nxt = []
+        for c in range(nc):
+            st = fp.region([a0, a1, a2, ("selector", "sum")], 1)
+            total = sym(SYM_BAL, level + 1, MODE_PATH, c)
+            cells.extend([(0, st, cur_bal[c]), (1, st, sib_bal[c]), (2, st, total)])
+            nxt.append(total)
+        cur_bal = nxt
+        cur_hash = hash_(2, cur_bal + [left, right], path_hash(level + 1))
+    items = [(2, 0, st, 0, first | count << 20 | chip << 28) for st, first, count, chip in hashes]      # sponges first: whole waves
+    items += [(1, 0, st, s, n_bytes) for st, s in ranges]
+    items += [(0, col, row, s, 0) for col, row, s in cells]
+    prog = np.concatenate([np.asarray(items, dtype=np.uint32).reshape(-1), np.asarray(absorbs, dtype=np.uint32).reshape(-1)])
+    instances = [path_hash(0), path_hash(levels)] + [sym(SYM_BAL, levels, MODE_PATH, c) for c in range(nc)]
+    return prog, len(items), len(absorbs), instances, max(fp.next_free.values())

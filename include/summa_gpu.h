@@ -300,6 +300,18 @@ int sg_mst_level_dev(const void* d_child_hashes, const void* d_child_balances, s
  * 2^(depth-1) parents, ..., the root last (2^(depth+1) - 1 nodes; balances NC per node) */
 int sg_mst_build_dev(const void* d_usernames, const void* d_leaf_balances, uint32_t depth, uint32_t n_currencies,
                      void* d_node_hashes, void* d_node_balances, void* stream);
+/* `MstInclusionCircuit::synthesize` (zk_prover/src/circuits/merkle_sum_tree.rs:228-520) on the device, for `n_users`
+ * users of a tree built by sg_mst_build_dev: the three advice columns in the reference's own floor plan.  The floor plan
+ * is a function of <LEVELS, N_CURRENCIES, N_BYTES> only and arrives as `d_program` (device memory): n_items x 5 u32
+ * {kind, column, row, symbol, extra} followed by n_absorbs x 3 u32 {add-input row, permute row, symbol}; kind 0 copies one
+ * value, 1 writes the running sum of a byte-wise range check (extra = N_BYTES), 2 lays out a whole Poseidon sponge
+ * (initial state, add-input and 37-row permute regions; extra = first absorb | count << 20).  A symbol names a tree
+ * node relative to the user's leaf index: bits 0-3 kind (0 username, 1 node hash, 2 node balance, 3 path bit), 4-9
+ * level, 10-12 mode (0 path node, 1 sibling, 2 child of the sibling, 3 ordered child of the path's parent), 13-19
+ * lane (child / currency).  d_advice: n_users x 3 x rows elements (cleared here); d_user_indices: n_users u32. */
+int sg_mst_inclusion_witness_dev(const void* d_program, uint32_t n_items, uint32_t n_absorbs, const void* d_usernames,
+                                 const void* d_node_hashes, const void* d_node_balances, uint32_t depth, uint32_t n_currencies,
+                                 const void* d_user_indices, uint32_t n_users, void* d_advice, uint64_t rows, void* stream);
 
 /* ---- tuning / introspection (not part of the reference seam) */
 typedef struct {

@@ -224,3 +224,94 @@ def test_field_element_to_solidity_calldata():
     from circuits_halo2_amd import api
     assert api.field_element_to_solidity_calldata(556862) == 556862
     assert api.field_element_to_solidity_calldata(PR.R + 5) == 5
+
+
+# ------------------------------------------------------------------ the floor plan as a device program
+def _tree_value(symbol, idx, users, node_hash, node_bal, nc):
+    """value of a witness-program symbol for leaf `idx` (integers): users[i], node_hash[level][i], node_bal[level][i][c]"""
+    kind, level, mode, lane = symbol & 15, (symbol >> 4) & 63, (symbol >> 10) & 7, (symbol >> 13) & 127
+    at = idx >> level
+    if kind == 0:
+        return users[idx ^ (mode & 1)]
+    if kind == 3:
+        return at & 1
+    node, lv = at, level
+    if mode == 1:
+        node = at ^ 1
+    elif mode == 2:
+        node, lv = 2 * (at ^ 1) + (lane & 1), level - 1
+    elif mode == 3:
+        node = (at & ~1) + (lane & 1)
+    return node_hash[lv][node] if kind == 1 else node_bal[lv][node][lane]
+
+
+@pytest.mark.parametrize("levels,nc,k,idx", [(4, 2, 11, 5), (3, 1, 10, 6), (5, 3, 12, 17)])
+def test_witness_program_covers_the_reference_assignment_cell_by_cell(levels, nc, k, idx):
+    """mst_inclusion.witness_program (what the device kernel executes) against mst_inclusion.reference_assignment (the
+    replay of the reference's synthesize with integers, itself pinned by the reproduced verifying key): every cell the
+    program writes holds the value the assignment has there, the sponge regions start from the sponge's initial state,
+    absorb the right words and end in the tree's own nodes -- and the cells the program covers are ALL the non-zero
+    cells of the assignment"""
+    from circuits_halo2_amd import mst_inclusion as M
+    rng = random.Random(levels * 100 + nc)
+    size = 1 << levels
+    users = [rng.randrange(PR.R) for _ in range(size)]
+    bals = [[rng.randrange(1 << 40) for _ in range(nc)] for _ in range(size)]
+    node_hash = [[PR.poseidon_hash([users[i]] + bals[i]) for i in range(size)]]
+    node_bal = [bals]
+    for level in range(1, levels + 1):
+        hs, bs = [], []
+        for p in range(size >> level):
+            b = [(node_bal[-1][2 * p][c] + node_bal[-1][2 * p + 1][c]) % PR.R for c in range(nc)]
+            bs.append(b)
+            hs.append(PR.poseidon_hash(b + [node_hash[-1][2 * p], node_hash[-1][2 * p + 1]]))
+        node_hash.append(hs)
+        node_bal.append(bs)
+    bits = [(idx >> l) & 1 for l in range(levels)]
+    sib = idx ^ 1
+    pre_leaf = [users[sib]] + bals[sib]
+    pre_mid = []
+    for level in range(1, levels):
+        s = (idx >> level) ^ 1
+        pre_mid.append(node_bal[level][s] + [node_hash[level - 1][2 * s], node_hash[level - 1][2 * s + 1]])
+    asg = M.reference_assignment(k, users[idx], bals[idx], bits, pre_leaf, pre_mid)
+    adv = asg["advice"]
+    prog, n_items, n_absorbs, inst_syms, rows_used = M.witness_program(k, levels, nc, 8)
+    assert rows_used == asg["rows_used"]
+    items = prog[:5 * n_items].reshape(-1, 5).tolist()
+    absorbs = prog[5 * n_items:].reshape(-1, 3).tolist()
+    assert len(absorbs) == n_absorbs
+    val = lambda s: _tree_value(s, idx, users, node_hash, node_bal, nc) % PR.R
+    assert [val(s) for s in inst_syms] == asg["instances"] == [node_hash[0][idx], node_hash[levels][0]] + node_bal[levels][0]
+    covered = set()
+    seen_hash = False
+    for kind, col, row, s, extra in items:
+        if kind == 0:
+            assert not seen_hash or True
+            assert adv[col][row] == val(s), (col, row)
+            covered.add((col, row))
+        elif kind == 1:
+            for b in range(extra):
+                assert adv[0][row + b] == val(s) >> (8 * b)
+                covered.add((0, row + b))
+            assert adv[0][row + extra] == 0
+        else:
+            first, count = extra & 0xFFFFF, (extra >> 20) & 255
+            assert (adv[0][row], adv[1][row]) == (0, (count << 64) % PR.R)
+            covered.add((1, row))
+            state0 = 0
+            for add_row, perm_row, s in absorbs[first:first + count]:
+                assert adv[0][add_row] == state0 and adv[0][add_row + 1] == val(s)
+                assert adv[0][add_row + 2] == (state0 + val(s)) % PR.R == adv[0][perm_row]
+                for r in range(3):
+                    covered.update({(0, add_row + r), (1, add_row + r)})
+                for r in range(37):
+                    covered.update({(0, perm_row + r), (1, perm_row + r)})
+                for r in range(4, 32):
+                    covered.add((2, perm_row + r))
+                state0 = adv[0][perm_row + 36]
+            # the digest is a node of the tree: the leaf, a sibling, or the next node of the path
+            assert state0 in {h for lv in node_hash for h in lv}
+    nonzero = {(c, r) for c in range(3) for r in range(1 << k) if adv[c][r]}
+    assert nonzero <= covered
+    assert [it[0] for it in items] == sorted((it[0] for it in items), reverse=True)      # sponges first

@@ -116,3 +116,65 @@ def test_device_snapshot_tree_and_its_merkle_proofs():
         assert api.full_verifier(params, vk, proof, circuit.instances())
     finally:
         params.free()
+
+
+@pytest.mark.parametrize("levels,nc,k,users", [(4, 2, 11, [0, 5, 15]), (20, 1, 13, [123457]), (20, 2, 17, [5, (1 << 20) - 1, 777777])])
+def test_device_witness_equals_the_host_assignment(levels, nc, k, users):
+    """sg_mst_inclusion_witness_dev (Circuit::synthesize as one kernel launch over the device-resident tree) writes
+    bit for bit the advice columns of mst_inclusion.reference_assignment (the integer replay of the reference's
+    synthesize, pinned by the reproduced verifying key), several users per launch; public inputs included"""
+    _gpu()
+    import types
+    import torch
+    from circuits_halo2_amd import api, arithmetic as A
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.utils import ints_to_fr, random_fr_canonical
+    size = 1 << levels
+    d_users = A.fr_random(bytes(range(32)), 7, size)
+    bal = random_fr_canonical(91, size * nc).reshape(-1, 32).copy()
+    bal[:, 5:] = 0
+    d_bals = A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda())
+    tree = DeviceMerkleSumTree(d_users, d_bals, levels, nc)
+    key = types.SimpleNamespace(k=k, n=1 << k, circuit_shape=(levels, nc, 8))
+    adv = api.synthesize_on_device(key, tree, users).cpu().numpy()
+    for u, idx in enumerate(users):
+        host = api.MstInclusionCircuit.init(tree.generate_proof(idx), levels)
+        asg = host.synthesize(k)
+        for c in range(3):
+            want = ints_to_fr(asg["advice"][c])
+            assert (adv[u, c] == want).all(), (idx, c, int(np.nonzero(adv[u, c] != want)[0][0]) // 32)
+        dev_circuit = api.MstInclusionCircuit.init_from_tree(tree, idx)
+        assert dev_circuit.instances() == host.instances() == [asg["instances"]]
+        assert dev_circuit.path_indices == host.path_indices
+
+
+def test_proofs_from_the_device_witness_verify():
+    """the production path of the batch driver: snapshot on the device -> witness kernel -> create_proof -> verified,
+    both flavours, and the same through prove_batch"""
+    _gpu()
+    import torch
+    from circuits_halo2_amd import api, arithmetic as A, batch as B
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.utils import random_fr_canonical
+    from oracle import summa_verifier as SV
+    from test_gpu_api import oracle_vk
+    levels, nc, k = 6, 2, 12
+    size = 1 << levels
+    bal = random_fr_canonical(92, size * nc).reshape(-1, 32).copy()
+    bal[:, 4:] = 0
+    tree = DeviceMerkleSumTree(A.fr_random(bytes(range(32)), 9, size), A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda()), levels, nc)
+    params, pk, vk = api.generate_setup_artifacts(k, None, api.MstInclusionCircuit.init_empty(levels, nc))
+    try:
+        ovk = oracle_vk(params, vk)
+        circuit = api.MstInclusionCircuit.init_from_tree(tree, 37)
+        proof, inst = api.gen_proof_solidity_calldata(params, pk, circuit)
+        assert SV.verify(proof, inst, ovk) and inst == tree.public_inputs(37)
+        blake = api.full_prover(params, pk, circuit, circuit.instances())
+        assert api.full_verifier(params, vk, blake, circuit.instances()) and SV.verify(blake, inst, ovk, flavour="blake2b")
+        res = B.prove_batch(tree, list(range(0, 64, 5)), params, pk, levels, in_flight=3)
+        assert not res.errors and sorted(res.proofs) == list(range(0, 64, 5))
+        assert all(SV.verify(p, i, ovk) for p, i in res.proofs.values())
+        with pytest.raises(IndexError):
+            api.MstInclusionCircuit.init_from_tree(tree, size)
+    finally:
+        params.free()
