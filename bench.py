@@ -443,11 +443,19 @@ def main():
                     else:
                         tree17, params17, pk17, vk17 = k17
                     t1 = time.perf_counter()
-                    circuit17 = _api.MstInclusionCircuit.init(tree17.generate_proof(5), 20)
+                    host_circuit = _api.MstInclusionCircuit.init(tree17.generate_proof(5), 20)
+                    _api._advice_columns(pk17, host_circuit)
+                    torch.cuda.synchronize()
+                    witness_host_ms = (time.perf_counter() - t1) * 1e3     # Merkle proof to the host + synthesize with Python integers
+                    _api._advice_columns(pk17, _api.MstInclusionCircuit.init_from_tree(tree17, 6))   # warm: program upload
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    circuit17 = _api.MstInclusionCircuit.init_from_tree(tree17, 5)
                     inst17 = circuit17.instances()[0]
                     adv17 = _api._advice_columns(pk17, circuit17)
                     torch.cuda.synchronize()
-                    witness_ms = (time.perf_counter() - t1) * 1e3
+                    witness_ms = (time.perf_counter() - t1) * 1e3          # synthesize on the device (sg_mst_inclusion_witness_dev)
+                    assert inst17 == host_circuit.instances()[0]
                     _prover.create_proof(params17, pk17, adv17, inst17)
                     ms17, proof17 = 1e9, None
                     for _ in range(3):
@@ -462,7 +470,7 @@ def main():
                     ok_product = _verifier.verify_proof(params17, vk17, proof17, inst17, "evm")
                     verify_ms = (time.perf_counter() - t1) * 1e3
                     t1 = time.perf_counter()
-                    calldata = _api.gen_proof_solidity_calldata(params17, pk17, _api.MstInclusionCircuit.init(tree17.generate_proof(6), 20))
+                    calldata = _api.gen_proof_solidity_calldata(params17, pk17, _api.MstInclusionCircuit.init_from_tree(tree17, 6))
                     calldata_ms = (time.perf_counter() - t1) * 1e3
                     from oracle import summa_verifier as _SV     # checker leg
                     ok_oracle = _SV.verify(proof17, inst17, oracle_vk(params17, vk17)) and _SV.verify(calldata[0], calldata[1], oracle_vk(params17, vk17))
@@ -485,7 +493,8 @@ def main():
                                                 "verified_cpp_driver_proof": cpp17.get("verified"),
                                                 "gen_proof_solidity_calldata_ms": calldata_ms, "full_prover_blake2b_ms": blake_ms,
                                                 "blake2b_proof_bytes": len(blake), "blake2b_verified": bool(ok_blake),
-                                                "witness_synthesis_ms": witness_ms, "verify_ms_product": verify_ms,
+                                                "witness_synthesis_ms": witness_ms, "witness_synthesis_host_python_ms": witness_host_ms,
+                                                "verify_ms_product": verify_ms,
                                                 "phases_ms_cpp_driver_synchronised": {k_: v_ for k_, v_ in cpp17.items() if k_[0].isdigit()},
                                                 "proof_bytes": len(proof17), "rows_per_s": (1 << 17) / ((cpp17.get("create_proof_ms") or ms17) * 1e-3),
                                                 "phases_ms_synchronised": {k_: round(v_, 2) for k_, v_ in phases17.items()},

@@ -66,8 +66,9 @@ class MstInclusionCircuit:
         self.levels, self.n_currencies, self.n_bytes = levels, n_currencies, n_bytes
         self.entry = entry
         self.path_indices = list(path_indices)
-        self.sibling_leaf_node_hash_preimage = list(sibling_leaf_node_hash_preimage)
-        self.sibling_middle_node_hash_preimages = [list(p) for p in sibling_middle_node_hash_preimages]
+        self.sibling_leaf_node_hash_preimage = None if sibling_leaf_node_hash_preimage is None else list(sibling_leaf_node_hash_preimage)
+        self.sibling_middle_node_hash_preimages = (None if sibling_middle_node_hash_preimages is None
+                                                   else [list(p) for p in sibling_middle_node_hash_preimages])
         self.root = root
         self._assignment = {}
         self._device = None       # (DeviceMerkleSumTree, user index): the witness is synthesized on the device
@@ -223,11 +224,19 @@ def _advice_columns(pk, circuit: MstInclusionCircuit):
     return [_device_column(c, pk.n) for c in asg["advice"]]
 
 
-def _create_proof(params, pk, circuit, instances, transcript) -> bytes:
+DRIVER = os.environ.get("SUMMA_PROVER_DRIVER", "native")    # "native": the library's compiled host driver; "python": prover.create_proof
+
+
+def _create_proof(params, pk, circuit, instances, flavour: str) -> bytes:
     if len(instances) != 1:
         raise ValueError("one instance column expected")
-    return P.create_proof(params, pk, _advice_columns(pk, circuit), [int(v) % R for v in instances[0]], transcript=transcript,
-                          sanity_checks=False)
+    inst = [int(v) % R for v in instances[0]]
+    advice = _advice_columns(pk, circuit)
+    if DRIVER == "native":
+        # device-synthesized columns are fresh per proof: the prover may write its blinding rows into them
+        return P.create_proof_native(params, pk, advice, inst, flavour, sanity_checks=False, in_place=circuit._device is not None)
+    transcript = P.EvmTranscriptWriter() if flavour == "evm" else P.Blake2bWrite()
+    return P.create_proof(params, pk, advice, inst, transcript=transcript, sanity_checks=False)
 
 
 def full_prover(params: ParamsKZG, pk, circuit: MstInclusionCircuit, public_inputs) -> bytes:
@@ -235,7 +244,7 @@ def full_prover(params: ParamsKZG, pk, circuit: MstInclusionCircuit, public_inpu
     under the Blake2b transcript (1632 bytes for this circuit: 16 compressed points + 35 scalars).  `public_inputs`:
     [[values of the instance column]], as `circuit.instances()` returns them.  A witness that violates a copy or a
     lookup constraint raises ("prover should not fail"); a violated gate yields a proof the verifier rejects."""
-    return _create_proof(params, pk, circuit, public_inputs, P.Blake2bWrite())
+    return _create_proof(params, pk, circuit, public_inputs, "blake2b")
 
 
 def full_verifier(params: ParamsKZG, vk: VerifyingKey, proof: bytes, public_inputs) -> bool:
@@ -249,7 +258,7 @@ def full_verifier(params: ParamsKZG, vk: VerifyingKey, proof: bytes, public_inpu
 def create_proof_checked(params: ParamsKZG, pk, circuit: MstInclusionCircuit, instances) -> bytes:
     """[REF utils.rs:162-196]  the proof under the Keccak transcript of the Solidity verifier, verified right away"""
     from . import verifier as V
-    proof = _create_proof(params, pk, circuit, [instances], P.EvmTranscriptWriter())
+    proof = _create_proof(params, pk, circuit, [instances], "evm")
     assert V.verify_proof(params, pk.vk, proof, [int(v) for v in instances], flavour="evm")
     return proof
 

@@ -146,7 +146,7 @@ def lookup_permute_small(inp, table, rows: int):
                                                ffi.current_stream_ptr())
     if rc == -5:
         return None
-    if rc == -1:
+    if rc == -6:        # SG_ERR_WITNESS
         raise ValueError("lookup input value not in the table")
     ffi.check(rc)
     return a, s

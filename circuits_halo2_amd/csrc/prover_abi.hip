@@ -1,0 +1,140 @@
+// C ABI of the compiled-host prover (include/summa_prover.h over include/summa_prover.hpp): key registry, argument
+// checks, exception -> status mapping.  Host code only; the kernels are behind the sg_* entry points it calls.
+#include "../../include/summa_prover.h"
+
+#include <memory>
+#include <mutex>
+
+#include "../../include/summa_prover.hpp"
+
+using namespace summa::prover;
+
+namespace {
+thread_local char g_sp_err[512] = "";
+int sp_fail(int code, const char* what) {
+  std::snprintf(g_sp_err, sizeof g_sp_err, "%s", what);
+  return code;
+}
+std::mutex g_keys_mu;
+std::map<uint64_t, std::shared_ptr<ProvingKey>> g_keys;
+uint64_t g_next_key = 1;
+
+Graph copy_graph(const sg_graph& g) {
+  Graph out;
+  out.constants.assign(g.constants, g.constants + 32 * (size_t)g.n_constants);
+  out.rotations.assign(g.rotations, g.rotations + g.n_rotations);
+  out.calculations.assign(g.calculations, g.calculations + g.n_calculations);
+  out.parts.assign(g.horner_parts, g.horner_parts + g.n_horner_parts);
+  return out;
+}
+template <class F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const WitnessError& e) {
+    return sp_fail(SG_ERR_WITNESS, e.what());
+  } catch (const std::invalid_argument& e) {
+    return sp_fail(SG_ERR_INVALID, e.what());
+  } catch (const std::bad_alloc&) {
+    return sp_fail(SG_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception& e) {
+    return sp_fail(SG_ERR_HIP, e.what());
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* sp_last_error(void) { return g_sp_err; }
+
+int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_lagrange, const void* const* d_sigma_lagrange,
+                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input, void* stream,
+                  uint64_t* key_out) {
+  if (!d_fixed_lagrange || !d_sigma_lagrange || !vk_digest_be || !gates || !lookup_input || !key_out || k < 4 || k > 25)
+    return sp_fail(SG_ERR_INVALID, "sp_key_create: bad argument");
+  for (uint32_t i = 0; i < NUM_FIXED; i++)
+    if (!d_fixed_lagrange[i]) return sp_fail(SG_ERR_INVALID, "sp_key_create: null fixed column");
+  for (uint32_t i = 0; i < NUM_SIGMA; i++)
+    if (!d_sigma_lagrange[i]) return sp_fail(SG_ERR_INVALID, "sp_key_create: null permutation column");
+  if ((gates->n_constants && !gates->constants) || (gates->n_calculations && !gates->calculations) ||
+      (lookup_input->n_calculations && !lookup_input->calculations))
+    return sp_fail(SG_ERR_INVALID, "sp_key_create: malformed program");
+  return guarded([&]() {
+    StreamScope scope(static_cast<hipStream_t>(stream));
+    const size_t n = (size_t)1 << k;
+    auto pk = std::make_shared<ProvingKey>();
+    std::memcpy(pk->vk_digest_be, vk_digest_be, 32);
+    pk->gates = copy_graph(*gates);
+    pk->lookup_input = copy_graph(*lookup_input);
+    std::vector<DevCol> fixed, sigma;
+    auto clone = [&](const void* src) {
+      DevCol c(n);
+      hk(hipMemcpyAsync(c.p, src, 32 * n, hipMemcpyDeviceToDevice, main_stream()), "D2D");
+      return c;
+    };
+    for (uint32_t i = 0; i < NUM_FIXED; i++) fixed.push_back(clone(d_fixed_lagrange[i]));
+    for (uint32_t i = 0; i < NUM_SIGMA; i++) sigma.push_back(clone(d_sigma_lagrange[i]));
+    pk->build(k, srs_handle, std::move(fixed), std::move(sigma));
+    std::lock_guard<std::mutex> lk(g_keys_mu);
+    *key_out = g_next_key++;
+    g_keys[*key_out] = pk;
+    return (int)SG_OK;
+  });
+}
+
+int sp_key_destroy(uint64_t key) {
+  std::shared_ptr<ProvingKey> pk;
+  {
+    std::lock_guard<std::mutex> lk(g_keys_mu);
+    auto it = g_keys.find(key);
+    if (it == g_keys.end()) return sp_fail(SG_ERR_INVALID, "sp_key_destroy: unknown key");
+    pk = it->second;
+    g_keys.erase(it);
+  }
+  return guarded([&]() {
+    pk.reset();                 // the columns go to this thread's pool ...
+    release_column_pool();      // ... and from there back to the device
+    return (int)SG_OK;
+  });
+}
+
+int sp_create_proof(uint64_t key, void* const* d_advice, const uint8_t* instances, uint32_t n_instances, int transcript,
+                    int sanity_checks, void* stream, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  if (!d_advice || !proof_out || !proof_len || (n_instances && !instances))
+    return sp_fail(SG_ERR_INVALID, "sp_create_proof: null argument");
+  if (transcript != SP_TRANSCRIPT_EVM && transcript != SP_TRANSCRIPT_BLAKE2B)
+    return sp_fail(SG_ERR_INVALID, "sp_create_proof: unknown transcript");
+  std::shared_ptr<ProvingKey> pk;
+  {
+    std::lock_guard<std::mutex> lk(g_keys_mu);
+    auto it = g_keys.find(key);
+    if (it == g_keys.end()) return sp_fail(SG_ERR_INVALID, "sp_create_proof: unknown key");
+    pk = it->second;
+  }
+  return guarded([&]() {
+    StreamScope scope(static_cast<hipStream_t>(stream));
+    std::vector<DevCol> advice;
+    for (uint32_t i = 0; i < NUM_ADVICE; i++) {
+      if (!d_advice[i]) throw std::invalid_argument("sp_create_proof: null advice column");
+      advice.push_back(DevCol::borrow(d_advice[i], pk->n));
+    }
+    std::vector<Fr> inst(n_instances);
+    if (n_instances) std::memcpy(inst.data(), instances, 32 * (size_t)n_instances);
+    Options opt;
+    opt.sanity_checks = sanity_checks != 0;
+    std::vector<uint8_t> proof;
+    if (transcript == SP_TRANSCRIPT_EVM) {
+      EvmTranscript tr;
+      proof = create_proof_with(*pk, advice, inst, tr, opt);
+    } else {
+      Blake2bTranscript tr;
+      proof = create_proof_with(*pk, advice, inst, tr, opt);
+    }
+    if (proof.size() > proof_cap) throw std::invalid_argument("sp_create_proof: proof buffer too small");
+    std::memcpy(proof_out, proof.data(), proof.size());
+    *proof_len = proof.size();
+    return (int)SG_OK;
+  });
+}
+
+}  // extern "C"

@@ -1158,7 +1158,7 @@ int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return hip_fail("lookup permutation", e);
   if (h_flag == 2) return fail(SG_ERR_UNSUPPORTED, "sg_lookup_permute_small: a table value is not below 2^16 (use the general path)");
-  if (h_flag == 1) return fail(SG_ERR_INVALID, "sg_lookup_permute_small: an input value is not in the table");
+  if (h_flag == 1) return fail(SG_ERR_WITNESS, "sg_lookup_permute_small: an input value is not in the table");
   return SG_OK;
 }
 int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream) {

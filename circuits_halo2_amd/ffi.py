@@ -90,3 +90,21 @@ def dev_ptr(t):
 def current_stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+# C ABI of the compiled-host prover (include/summa_prover.h), exported by the same library
+PROVER_EXPORTS = ["sp_key_create", "sp_key_destroy", "sp_create_proof", "sp_last_error"]
+
+
+def prover_lib():
+    L = lib()
+    if not getattr(L, "_sp_ready", False):
+        for name in PROVER_EXPORTS:
+            getattr(L, name)
+        L.sp_last_error.restype = C.c_char_p
+        L._sp_ready = True
+    return L
+
+
+def check_prover(rc: int):
+    if rc != SG_OK:
+        raise SummaGpuError(rc, prover_lib().sp_last_error().decode())

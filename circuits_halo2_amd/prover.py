@@ -233,6 +233,56 @@ class ProvingKey:
         torch.cuda.synchronize()
 
 
+def native_key(pk: ProvingKey, params) -> int:
+    """the proving key inside the library's compiled prover (sp_key_create), made on first use and kept on `pk`"""
+    import ctypes as C
+    from . import ffi
+    made = getattr(pk, "_native", None)
+    if made is not None and made[1] == (params.handle(), pk.vk_digest):
+        return made[0]
+    if made is not None:
+        ffi.check_prover(ffi.prover_lib().sp_key_destroy(C.c_uint64(made[0])))
+    gates, keep1 = M.gate_graph(pk.n_currencies)._struct()
+    look, keep2 = M.lookup_input_graph()._struct()
+    fixed = (C.c_void_p * len(pk.fixed_lagrange))(*[c.data_ptr() for c in pk.fixed_lagrange])
+    sigma = (C.c_void_p * len(pk.sigma_lagrange))(*[c.data_ptr() for c in pk.sigma_lagrange])
+    digest = np.frombuffer(pk.vk_digest.to_bytes(32, "big"), dtype=np.uint8).copy()
+    key = C.c_uint64(0)
+    ffi.check_prover(ffi.prover_lib().sp_key_create(C.c_uint32(pk.k), C.c_uint64(params.handle()), fixed, sigma, ffi.ptr(digest),
+                                                    C.byref(gates), C.byref(look), ffi.current_stream_ptr(), C.byref(key)))
+    pk._native = (key.value, (params.handle(), pk.vk_digest))
+    return key.value
+
+
+def create_proof_native(params, pk: ProvingKey, advice, instances, flavour: str = "evm", sanity_checks: bool = True,
+                        in_place: bool = False) -> bytes:
+    """`create_proof` by the library's compiled host driver (include/summa_prover.hpp behind the C ABI of
+    include/summa_prover.h): same steps, same transcripts, same proofs as create_proof below, without the interpreter
+    between the kernels -- and with the GIL released for the whole proof, so several can be in flight from Python
+    threads.  advice: 3 device columns (copied unless in_place); instances: integers; flavour "evm" | "blake2b"."""
+    import ctypes as C
+    from . import ffi
+    if len(advice) != M.NUM_ADVICE or any(a.numel() != 32 * pk.n for a in advice):
+        raise ValueError(f"create_proof: {M.NUM_ADVICE} advice columns of 2^k rows expected")
+    if len(instances) > pk.usable_rows or any(not 0 <= v < R for v in instances):
+        raise ValueError("create_proof: instances are field elements on usable rows")
+    if flavour not in ("evm", "blake2b"):
+        raise ValueError("flavour: evm or blake2b")
+    key = native_key(pk, params)
+    cols = list(advice) if in_place else [a.clone() for a in advice]
+    ptrs = (C.c_void_p * 3)(*[c.data_ptr() for c in cols])
+    inst = ints_to_fr(list(instances)) if instances else np.zeros(0, dtype=np.uint8)
+    out = np.zeros(2144, dtype=np.uint8)
+    size = C.c_size_t(0)
+    rc = ffi.prover_lib().sp_create_proof(C.c_uint64(key), ptrs, ffi.ptr(inst) if len(instances) else None, C.c_uint32(len(instances)),
+                                          C.c_int(0 if flavour == "evm" else 1), C.c_int(1 if sanity_checks else 0),
+                                          ffi.current_stream_ptr(), ffi.ptr(out), C.c_size_t(out.size), C.byref(size))
+    if rc == -6:      # SG_ERR_WITNESS
+        raise ValueError(ffi.prover_lib().sp_last_error().decode())
+    ffi.check_prover(rc)
+    return out[:size.value].tobytes()
+
+
 def permute_expression_pair(inp: np.ndarray, table: np.ndarray):
     """halo2 `lookup::prover::permute_expression_pair` on the usable rows, as (rows, 4) uint64 limb arrays of
     canonical integers: A' = the input sorted, S' = the table rearranged so that every row has A'[i] == S'[i] or

@@ -45,7 +45,9 @@ typedef enum {
   SG_ERR_NO_DEVICE = -2, /* no usable HIP device / sg_init not called */
   SG_ERR_HIP = -3,       /* a HIP runtime call failed; see sg_last_error() */
   SG_ERR_NOMEM = -4,     /* device or host allocation failed */
-  SG_ERR_UNSUPPORTED = -5 /* the inputs are outside what this entry point handles; a general path exists */
+  SG_ERR_UNSUPPORTED = -5, /* the inputs are outside what this entry point handles; a general path exists */
+  SG_ERR_WITNESS = -6      /* the data, not the call, is at fault: e.g. a lookup input that is not in its table
+                              (upstream: permute_expression_pair -> Error::ConstraintSystemFailure) */
 } sg_status;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -180,7 +182,7 @@ int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* str
 /* halo2 lookup::prover::permute_expression_pair (§3.1 step 4) for range tables, on the device: rows = the usable
  * rows; A' (d_permuted_input) = the input rows in increasing order, S' (d_permuted_table) = the table rows
  * rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1].  Handles tables whose values are all below
- * 2^16 (SG_ERR_UNSUPPORTED otherwise: sort on the host as upstream does); SG_ERR_INVALID if an input value is not
+ * 2^16 (SG_ERR_UNSUPPORTED otherwise: sort on the host as upstream does); SG_ERR_WITNESS if an input value is not
  * in the table.  Synchronises the stream (the status is known on return). */
 int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
                                 void* d_permuted_table, void* stream);

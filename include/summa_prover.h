@@ -1,0 +1,57 @@
+/* summa_prover.h -- C ABI of the compiled-host `create_proof` (include/summa_prover.hpp) for the constraint system of
+ * the reference's MstInclusionCircuit, exported by the same shared library as include/summa_gpu.h.
+ *
+ * What it replaces on the reference side [REF zk_prover/src/circuits/utils.rs]:
+ *   sp_key_create      keygen_pk's prover-side forms (:76): coefficient and extended-coset forms of the fixed and
+ *                      permutation columns, from their Lagrange columns (the caller has committed to them)
+ *   sp_create_proof    halo2_proofs::plonk::create_proof::<KZG, ProverSHPLONK, ..> as `full_prover` (:94-101, Blake2b /
+ *                      Challenge255 transcript) and `create_proof_checked` (:171-178, Keccak256Transcript) call it
+ * The host part (transcripts, Fiat-Shamir scalars, the multi-open's interpolation) is C++; every data-parallel step is
+ * a kernel behind include/summa_gpu.h.  Thread-safe: proofs from different host threads run side by side on the device
+ * (each thread keeps its own streams and buffer pool); give every concurrent call its own `stream`.
+ *
+ * Conventions as in summa_gpu.h: 0 or a negative sg_status; sp_last_error() (thread-local) explains a failure. */
+#ifndef SUMMA_PROVER_H
+#define SUMMA_PROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "summa_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_NUM_FIXED 11
+#define SP_NUM_SIGMA 6
+#define SP_NUM_ADVICE 3
+
+typedef enum sp_transcript {
+  SP_TRANSCRIPT_EVM = 0,     /* Keccak256Transcript: 64-byte points, big-endian scalars (2144-byte proofs) */
+  SP_TRANSCRIPT_BLAKE2B = 1  /* Blake2bWrite + Challenge255: compressed points, little-endian scalars (1632 bytes) */
+} sp_transcript;
+
+/* Proving key for 2^k rows over the SRS `srs_handle` (sg_srs_upload): d_fixed_lagrange[11] / d_sigma_lagrange[6] are
+ * device columns of 2^k Montgomery Fr (copied); gates / lookup_input are the GraphEvaluator programs of the constraint
+ * system (copied); vk_digest_be = the scalar `vk.hash_into` feeds the transcript, 32 bytes big-endian.  Work is
+ * enqueued on `stream` and complete on return. */
+int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_lagrange, const void* const* d_sigma_lagrange,
+                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input, void* stream,
+                  uint64_t* key_out);
+int sp_key_destroy(uint64_t key);
+
+/* One proof.  d_advice[3]: device columns of 2^k rows, Lagrange form; their last 6 rows are OVERWRITTEN with blinding
+ * values (pass copies to keep the originals).  instances: n_instances x 32 B Montgomery Fr, the instance column's
+ * values.  sanity_checks != 0: fail with SG_ERR_WITNESS if the permutation or lookup grand product does not close
+ * (upstream's cargo feature of that name; without it such a witness yields a proof the verifier rejects).  A lookup
+ * input outside its table is always SG_ERR_WITNESS.  proof_out: at least 2144 bytes; *proof_len = bytes written. */
+int sp_create_proof(uint64_t key, void* const* d_advice, const uint8_t* instances, uint32_t n_instances, int transcript,
+                    int sanity_checks, void* stream, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+
+const char* sp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

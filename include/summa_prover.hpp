@@ -247,19 +247,24 @@ inline std::array<uint8_t, 32> keccak256(const uint8_t* data, size_t len) {
   return out;
 }
 
+// Both transcripts of the reference [REF zk_prover/src/circuits/utils.rs:93 (Blake2bWrite / Challenge255, `full_prover`),
+// :170 (Keccak256Transcript, `gen_proof_solidity_calldata`)]: absorb the verifying key's digest first (`vk.hash_into`),
+// then the instances, commitments and evaluations as create_proof produces them.
 struct EvmTranscript {
   std::vector<uint8_t> buf, proof;
-  explicit EvmTranscript(const uint8_t vk_digest_be[32]) : buf(vk_digest_be, vk_digest_be + 32) {}
+  bool squeezed = false;
   void common_scalar(const Fr& v) {
     uint8_t b[32];
     v.to_be_bytes(b);
     buf.insert(buf.end(), b, b + 32);
+    squeezed = false;
   }
   void write_scalar(const Fr& v) {
     uint8_t b[32];
     v.to_be_bytes(b);
     buf.insert(buf.end(), b, b + 32);
     proof.insert(proof.end(), b, b + 32);
+    squeezed = false;
   }
   void write_point(const uint8_t affine_mont[64]) {  // as the ABI returns commitments
     uint8_t b[64];
@@ -267,17 +272,152 @@ struct EvmTranscript {
     fq_mont_to_be(affine_mont + 32, b + 32);
     buf.insert(buf.end(), b, b + 64);
     proof.insert(proof.end(), b, b + 64);
+    squeezed = false;
   }
-  Fr squeeze() {
+  Fr squeeze() {   // keccak(buffer) mod r, the hash becomes the buffer; right after a squeeze: keccak(hash || 0x01)
+    if (squeezed) {
+      buf.resize(32);
+      buf.push_back(0x01);
+    }
     auto h = keccak256(buf.data(), buf.size());
     buf.assign(h.begin(), h.end());
+    squeezed = true;
     return Fr::from_be_bytes_reduced(h.data());
   }
-  Fr squeeze_again() {
-    buf.resize(32);
-    buf.push_back(0x01);
-    return squeeze();
+  Fr squeeze_again() { return squeeze(); }
+};
+
+// Blake2b (RFC 7693), unkeyed, with personalisation; `finalize` works on a copy, as the transcript needs it
+struct Blake2b {
+  uint64_t h[8];
+  uint8_t buf[128];
+  size_t buflen = 0;
+  uint64_t t0 = 0, t1 = 0;
+  static constexpr uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+  Blake2b(size_t outlen, const char* personal16) {
+    uint8_t param[64] = {0};
+    param[0] = (uint8_t)outlen;
+    param[2] = 1;
+    param[3] = 1;
+    if (personal16) std::memcpy(param + 48, personal16, std::min<size_t>(16, std::strlen(personal16)));
+    for (int i = 0; i < 8; i++) {
+      uint64_t w;
+      std::memcpy(&w, param + 8 * i, 8);
+      h[i] = IV[i] ^ w;
+    }
   }
+  static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+  void compress(const uint8_t block[128], bool last) {
+    static constexpr uint8_t SIGMA[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    uint64_t m[16], v[16];
+    std::memcpy(m, block, 128);
+    for (int i = 0; i < 8; i++) {
+      v[i] = h[i];
+      v[i + 8] = IV[i];
+    }
+    v[12] ^= t0;
+    v[13] ^= t1;
+    if (last) v[14] = ~v[14];
+    auto g = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+      v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+      v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 24);
+      v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+      v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; r++) {
+      const uint8_t* sg = SIGMA[r];
+      g(0, 4, 8, 12, m[sg[0]], m[sg[1]]); g(1, 5, 9, 13, m[sg[2]], m[sg[3]]);
+      g(2, 6, 10, 14, m[sg[4]], m[sg[5]]); g(3, 7, 11, 15, m[sg[6]], m[sg[7]]);
+      g(0, 5, 10, 15, m[sg[8]], m[sg[9]]); g(1, 6, 11, 12, m[sg[10]], m[sg[11]]);
+      g(2, 7, 8, 13, m[sg[12]], m[sg[13]]); g(3, 4, 9, 14, m[sg[14]], m[sg[15]]);
+    }
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+  }
+  void update(const uint8_t* data, size_t len) {
+    while (len) {
+      if (buflen == 128) {   // a full buffer is only compressed once more input follows (the last block is special)
+        t0 += 128;
+        if (t0 < 128) t1++;
+        compress(buf, false);
+        buflen = 0;
+      }
+      const size_t take = std::min(len, 128 - buflen);
+      std::memcpy(buf + buflen, data, take);
+      buflen += take;
+      data += take;
+      len -= take;
+    }
+  }
+  void finalize(uint8_t* out, size_t outlen) const {   // on a copy: the state keeps absorbing afterwards
+    Blake2b c = *this;
+    c.t0 += c.buflen;
+    if (c.t0 < c.buflen) c.t1++;
+    std::memset(c.buf + c.buflen, 0, 128 - c.buflen);
+    c.compress(c.buf, true);
+    std::memcpy(out, c.h, outlen);
+  }
+};
+struct Blake2bTranscript {   // Blake2bWrite<_, G1Affine, Challenge255<_>> (halo2_proofs transcript.rs)
+  Blake2b state{64, "Halo2-Transcript"};
+  std::vector<uint8_t> proof;
+  static void reverse32(uint8_t b[32]) { std::reverse(b, b + 32); }
+  void common_scalar(const Fr& v) {
+    uint8_t b[33];
+    b[0] = 2;
+    v.to_be_bytes(b + 1);
+    reverse32(b + 1);
+    state.update(b, 33);
+  }
+  void write_scalar(const Fr& v) {
+    uint8_t b[33];
+    b[0] = 2;
+    v.to_be_bytes(b + 1);
+    reverse32(b + 1);
+    state.update(b, 33);
+    proof.insert(proof.end(), b + 1, b + 33);
+  }
+  void write_point(const uint8_t affine_mont[64]) {
+    uint8_t b[65];
+    b[0] = 1;
+    fq_mont_to_be(affine_mont, b + 1);
+    fq_mont_to_be(affine_mont + 32, b + 33);
+    reverse32(b + 1);
+    reverse32(b + 33);
+    bool inf = true;
+    for (int i = 0; i < 64; i++) inf = inf && !affine_mont[i];
+    if (inf) throw std::runtime_error("cannot write points at infinity to the transcript");
+    state.update(b, 65);
+    uint8_t c[32];
+    std::memcpy(c, b + 1, 32);                    // x little-endian, bit 6 of the last byte = parity of y
+    c[31] |= (uint8_t)((b[33] & 1) << 6);
+    proof.insert(proof.end(), c, c + 32);
+  }
+  Fr squeeze() {   // prefix 0, digest of a clone, 64 bytes as a little-endian integer mod r (from_uniform_bytes)
+    const uint8_t zero = 0;
+    state.update(&zero, 1);
+    uint8_t d[64];
+    state.finalize(d, 64);
+    Fr lo, hi, r2;
+    std::memcpy(lo.l, d, 32);
+    std::memcpy(hi.l, d + 32, 32);
+    std::memcpy(r2.l, Fr::R2, 32);
+    return lo * r2 + (hi * r2) * r2;              // lo R + hi R^2: Montgomery form of lo + hi 2^256
+  }
+  Fr squeeze_again() { return squeeze(); }
+};
+
+struct Options {
+  bool sanity_checks = true;   // refuse a witness whose permutation / lookup grand product does not close (upstream's cargo feature)
+};
+struct WitnessError : std::runtime_error {   // the assignment, not the machinery, is at fault
+  using std::runtime_error::runtime_error;
 };
 
 // ------------------------------------------------------------------ inputs
@@ -298,19 +438,62 @@ inline void ck(int rc, const char* what) {
 inline void hk(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
-// freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device and cost ~100 us each)
-inline std::multimap<size_t, void*>& column_pool() {
-  static std::multimap<size_t, void*> pool;
-  return pool;
+// Per-thread prover state: the stream proofs of this thread run on, two side streams with their fork / join events,
+// the pool of freed device columns and the page-locked staging area.  Nothing is shared between host threads, so
+// several proofs can be in flight on one GPU (one thread each, circuits_halo2_amd/batch.py); the C ABI underneath
+// gives every concurrent call its own lane.
+struct Session {
+  hipStream_t main = nullptr;                 // NULL: HIP's default stream (single-threaded callers)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  std::multimap<size_t, void*> pool;          // freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device)
+  uint64_t* pinned = nullptr;
+  size_t pinned_cap = 0;
+  ~Session() {
+    for (auto& kv : pool) (void)hipFree(kv.second);
+    if (pinned) (void)hipHostFree(pinned);
+    for (auto& st : side)
+      if (st) (void)hipStreamDestroy(st);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto& e : ev_join)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+inline Session& session() {
+  static thread_local Session s;
+  return s;
 }
+inline hipStream_t main_stream() { return session().main; }
+struct StreamScope {   // run this thread's prover calls on `s` for the scope
+  hipStream_t prev;
+  explicit StreamScope(hipStream_t s) : prev(session().main) { session().main = s; }
+  ~StreamScope() { session().main = prev; }
+};
+inline std::multimap<size_t, void*>& column_pool() { return session().pool; }
 inline void release_column_pool() {
   for (auto& kv : column_pool()) (void)hipFree(kv.second);
   column_pool().clear();
 }
-struct DevCol {  // device column of Fr (Montgomery), owned
+inline void d2h(void* host, const void* dev, size_t bytes) {   // ordered on the thread's main stream, complete on return
+  hk(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, main_stream()), "D2H");
+  hk(hipStreamSynchronize(main_stream()), "sync");
+}
+inline void h2d(void* dev, const void* host, size_t bytes) {
+  hk(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, main_stream()), "H2D");
+  hk(hipStreamSynchronize(main_stream()), "sync");   // the host buffer may be a temporary
+}
+struct DevCol {  // device column of Fr (Montgomery); owned unless borrowed from the caller
   void* p = nullptr;
   size_t rows = 0;
+  bool owned = true;
   DevCol() = default;
+  static DevCol borrow(void* ptr, size_t r) {
+    DevCol c;
+    c.p = ptr;
+    c.rows = r;
+    c.owned = false;
+    return c;
+  }
   explicit DevCol(size_t r) : rows(r) {
     auto it = column_pool().find(r);
     if (it != column_pool().end()) {
@@ -322,20 +505,21 @@ struct DevCol {  // device column of Fr (Montgomery), owned
   }
   DevCol(const DevCol&) = delete;
   DevCol& operator=(const DevCol&) = delete;
-  DevCol(DevCol&& o) noexcept : p(o.p), rows(o.rows) { o.p = nullptr; }
+  DevCol(DevCol&& o) noexcept : p(o.p), rows(o.rows), owned(o.owned) { o.p = nullptr; }
   DevCol& operator=(DevCol&& o) noexcept {
-    if (p) column_pool().emplace(rows, p);
+    if (p && owned) column_pool().emplace(rows, p);
     p = o.p;
     rows = o.rows;
+    owned = o.owned;
     o.p = nullptr;
     return *this;
   }
   ~DevCol() {
-    if (p) column_pool().emplace(rows, p);
+    if (p && owned) column_pool().emplace(rows, p);
   }
   uint8_t* at(size_t row) const { return static_cast<uint8_t*>(p) + 32 * row; }
-  void upload(const void* host, size_t first, size_t count) { hk(hipMemcpy(at(first), host, 32 * count, hipMemcpyHostToDevice), "H2D"); }
-  void zero() { hk(hipMemsetAsync(p, 0, 32 * rows, nullptr), "memset"); }
+  void upload(const void* host, size_t first, size_t count) { h2d(at(first), host, 32 * count); }
+  void zero() { hk(hipMemsetAsync(p, 0, 32 * rows, main_stream()), "memset"); }
 };
 
 // constraint-system constants of MstInclusionCircuit (circuits_halo2_amd/mst_inclusion.py)
@@ -415,15 +599,15 @@ struct ProvingKey {
       std::vector<void*> pc, pe;
       for (auto& c : lag) {
         coeff.emplace_back(n);
-        hk(hipMemcpy(coeff.back().p, c.p, 32 * n, hipMemcpyDeviceToDevice), "D2D");
+        hk(hipMemcpyAsync(coeff.back().p, c.p, 32 * n, hipMemcpyDeviceToDevice, main_stream()), "D2D");
         ext.emplace_back(ne);
         pc.push_back(coeff.back().p);
         pe.push_back(ext.back().p);
       }
       for (size_t i = 0; i < pc.size(); i += 16) {   // batched launches hold at most 16 vectors
         const size_t m = std::min<size_t>(16, pc.size() - i);
-        ck(sg_ntt_fr_batch_dev(pc.data() + i, m, omega_inv, n_inv, k, nullptr), "iNTT batch");
-        ck(sg_coeff_to_extended_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), nullptr), "coset NTT batch");
+        ck(sg_ntt_fr_batch_dev(pc.data() + i, m, omega_inv, n_inv, k, main_stream()), "iNTT batch");
+        ck(sg_coeff_to_extended_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), main_stream()), "coset NTT batch");
       }
     };
     transform(fixed_lag, fixed_coeff, fixed_ext);
@@ -436,10 +620,10 @@ struct ProvingKey {
     {
       DevCol canon(n);
       table_rows.resize(4 * n);
-      ck(sg_fr_from_montgomery_dev(fixed_lag[4].p, canon.p, n, nullptr), "from_montgomery");
-      hk(hipMemcpy(table_rows.data(), canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
+      ck(sg_fr_from_montgomery_dev(fixed_lag[4].p, canon.p, n, main_stream()), "from_montgomery");
+      d2h(table_rows.data(), canon.p, 32 * n);
     }
-    hk(hipDeviceSynchronize(), "sync");
+    hk(hipStreamSynchronize(main_stream()), "sync");
   }
 };
 
@@ -452,9 +636,9 @@ inline void os_random(uint8_t* out, size_t bytes) {
   std::fclose(f);
 }
 
-inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept
-  static uint64_t* p = nullptr;
-  static size_t cap = 0;
+inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept (per thread)
+  uint64_t*& p = session().pinned;
+  size_t& cap = session().pinned_cap;
   if (rows > cap) {
     if (p) (void)hipHostFree(p);
     hk(hipHostMalloc(reinterpret_cast<void**>(&p), 32 * rows), "hipHostMalloc");
@@ -533,14 +717,19 @@ inline void permute_expression_pair(const uint64_t* inp, const uint64_t* table, 
 struct Timings { std::map<std::string, double> ms; };
 
 // advice: 3 device columns (Lagrange, n rows; the last 6 rows are overwritten with blinding values)
-inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCol>& advice, const std::vector<Fr>& instances,
-                                         Timings* timings = nullptr) {
+template <class Transcript>
+std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>& advice, const std::vector<Fr>& instances,
+                                       Transcript& tr, const Options& opt = Options(), Timings* timings = nullptr) {
+  if (advice.size() != NUM_ADVICE) throw std::invalid_argument("create_proof: three advice columns expected");
+  for (auto& a : advice)
+    if (a.rows != pk.n || !a.p) throw std::invalid_argument("create_proof: advice columns of 2^k rows expected");
+  if (instances.size() > pk.usable) throw std::invalid_argument("create_proof: more instances than usable rows");
   const uint32_t k = pk.k, ext_k = pk.ext_k();
   const size_t n = pk.n, u = pk.usable, ne = (size_t)1 << ext_k;
   auto clock = std::chrono::steady_clock::now();
   auto lap = [&](const char* name) {  // per-phase wall clock with the device drained, only when asked for
     if (!timings) return;
-    hk(hipDeviceSynchronize(), "sync");
+    hk(hipDeviceSynchronize(), "sync");   // timing mode only
     const auto now = std::chrono::steady_clock::now();
     timings->ms[name] += std::chrono::duration<double, std::milli>(now - clock).count();
     clock = now;
@@ -554,7 +743,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   std::memcpy(omega.l, omega_b, 32);
   std::memcpy(omega_inv.l, omega_inv_b, 32);
   const Fr delta = Fr::from_u64(7).pow((uint64_t)1 << 28);
-  EvmTranscript tr(pk.vk_digest_be);
+  tr.common_scalar(Fr::from_be_bytes_reduced(pk.vk_digest_be));   // vk.hash_into(transcript)
   for (auto& v : instances) tr.common_scalar(v);
 
   // blinding values: a 32-byte key from the OS per proof, expanded by ChaCha20 on the device; one stream id per draw
@@ -562,26 +751,28 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   os_random(key, 32);
   uint64_t draws = 0;
   auto rand_rows = [&](DevCol& col, size_t first, size_t count) {
-    ck(sg_fr_random_dev(key, ++draws, col.at(first), count, nullptr), "fr_random");
+    ck(sg_fr_random_dev(key, ++draws, col.at(first), count, main_stream()), "fr_random");
   };
   // two side streams: independent latency chains (the transforms of a phase under its commitments, the three grand
   // products, the rotation sets of the multi-open) run next to the main (null) stream; the library keeps its work
   // space per stream.  fork: the side streams wait for everything enqueued on the main stream; join: the reverse
-  static hipStream_t side[2] = {nullptr, nullptr};
-  static hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t(&side)[2] = session().side;
+  hipEvent_t& ev_fork = session().ev_fork;
+  hipEvent_t(&ev_join)[2] = session().ev_join;
+  const hipStream_t ms = main_stream();
   if (!side[0]) {
     for (auto& st : side) hk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
     hk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "event");
     for (auto& e : ev_join) hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
   }
   auto fork = [&]() {
-    hk(hipEventRecord(ev_fork, nullptr), "event");
+    hk(hipEventRecord(ev_fork, ms), "event");
     for (auto& st : side) hk(hipStreamWaitEvent(st, ev_fork, 0), "wait");
   };
   auto join = [&]() {
     for (int i = 0; i < 2; i++) {
       hk(hipEventRecord(ev_join[i], side[i]), "event");
-      hk(hipStreamWaitEvent(nullptr, ev_join[i], 0), "wait");
+      hk(hipStreamWaitEvent(ms, ev_join[i], 0), "wait");
     }
   };
   auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext, hipStream_t st) {
@@ -598,7 +789,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   };
   auto commit_batch = [&](std::vector<void*> cols, std::vector<int> basis) {
     std::vector<uint8_t> out(64 * cols.size());
-    ck(sg_commit_batch_mixed_dev(pk.srs, basis.data(), cols.data(), cols.size(), n, nullptr, out.data()), "commit");
+    ck(sg_commit_batch_mixed_dev(pk.srs, basis.data(), cols.data(), cols.size(), n, main_stream(), out.data()), "commit");
     for (size_t i = 0; i < cols.size(); i++) tr.write_point(out.data() + 64 * i);
   };
 
@@ -622,22 +813,22 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   DevCol inp(n);
   inp.zero();
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
-                           zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, nullptr), "lookup input");
+                           zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, main_stream()), "lookup input");
   DevCol pin(n), ptab(n);
-  const int prc = sg_lookup_permute_small_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, nullptr);   // range tables: on the device
+  const int prc = sg_lookup_permute_small_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, main_stream());   // range tables: on the device
   if (prc == SG_ERR_UNSUPPORTED) {   // general tables: sort on the host, as upstream does
     DevCol canon(n);
     uint64_t* stage = pinned_rows(3 * n);   // page-locked staging: the three 32 n-byte transfers run at link speed
     uint64_t *h_inp = stage, *h_a = stage + 4 * n, *h_s = stage + 8 * n;
-    ck(sg_fr_from_montgomery_dev(inp.p, canon.p, n, nullptr), "from_montgomery");
-    hk(hipMemcpy(h_inp, canon.p, 32 * n, hipMemcpyDeviceToHost), "D2H");
+    ck(sg_fr_from_montgomery_dev(inp.p, canon.p, n, main_stream()), "from_montgomery");
+    d2h(h_inp, canon.p, 32 * n);
     permute_expression_pair(h_inp, pk.table_rows.data(), u, h_a, h_s);
     pin.upload(h_a, 0, u);
     ptab.upload(h_s, 0, u);
-    ck(sg_fr_to_montgomery_dev(pin.p, pin.p, u, nullptr), "to_montgomery");
-    ck(sg_fr_to_montgomery_dev(ptab.p, ptab.p, u, nullptr), "to_montgomery");
-  } else if (prc == SG_ERR_INVALID) {
-    throw std::runtime_error("lookup input value not in the table");
+    ck(sg_fr_to_montgomery_dev(pin.p, pin.p, u, main_stream()), "to_montgomery");
+    ck(sg_fr_to_montgomery_dev(ptab.p, ptab.p, u, main_stream()), "to_montgomery");
+  } else if (prc == SG_ERR_WITNESS) {
+    throw WitnessError("lookup input value not in the table");
   } else {
     ck(prc, "lookup permutation");
   }
@@ -668,20 +859,20 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     const Fr delta_chunk = delta.pow((uint64_t)CHUNK);
     fork();
     ck(sg_permutation_product_dev(vals[0].data(), sig[0].data(), (uint32_t)vals[0].size(), beta.bytes(), gamma.bytes(),
-                                  Fr::one().bytes(), k, nullptr, zs[0].p, nullptr), "permutation product");
+                                  Fr::one().bytes(), k, nullptr, zs[0].p, main_stream()), "permutation product");
     ck(sg_permutation_product_dev(vals[1].data(), sig[1].data(), (uint32_t)vals[1].size(), beta.bytes(), gamma.bytes(),
                                   delta_chunk.bytes(), k, nullptr, zs[1].p, side[0]), "permutation product");
     ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, side[1]), "lookup product");
     Fr z0_last, last;
-    hk(hipMemcpyAsync(z0_last.l, zs[0].at(u), 32, hipMemcpyDeviceToHost, nullptr), "D2H");
-    hk(hipStreamSynchronize(nullptr), "sync");   // z0 only; the other two keep running
+    hk(hipMemcpyAsync(z0_last.l, zs[0].at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
+    hk(hipStreamSynchronize(main_stream()), "sync");   // z0 only; the other two keep running
     join();
     void* z1p[1] = {zs[1].p};
-    ck(sg_fr_lincomb_dev(z1p, z0_last.bytes(), 1, n, zs[1].p, nullptr), "z1 *= z0[u]");
-    hk(hipMemcpy(last.l, zs[1].at(u), 32, hipMemcpyDeviceToHost), "D2H");
-    if (last != Fr::one()) throw std::runtime_error("permutation argument not satisfied by the assignment");
-    hk(hipMemcpy(last.l, lz.at(u), 32, hipMemcpyDeviceToHost), "D2H");
-    if (last != Fr::one()) throw std::runtime_error("lookup argument not satisfied by the assignment");
+    ck(sg_fr_lincomb_dev(z1p, z0_last.bytes(), 1, n, zs[1].p, main_stream()), "z1 *= z0[u]");
+    d2h(last.l, zs[1].at(u), 32);
+    if (opt.sanity_checks && last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
+    d2h(last.l, lz.at(u), 32);
+    if (opt.sanity_checks && last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
   }
   rand_rows(zs[0], u + 1, n - u - 1);
   rand_rows(zs[1], u + 1, n - u - 1);
@@ -698,13 +889,13 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   lap("3_grand_products");
   // -- 4: quotient
   DevCol values(ne), input_ext(ne);
-  hk(hipMemsetAsync(values.p, 0, 32 * ne, nullptr), "memset");
-  hk(hipMemsetAsync(input_ext.p, 0, 32 * ne, nullptr), "memset");
+  hk(hipMemsetAsync(values.p, 0, 32 * ne, main_stream()), "memset");
+  hk(hipMemsetAsync(input_ext.p, 0, 32 * ne, main_stream()), "memset");
   std::vector<void*> adv_ext_p = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_ext_p = {ex1[3].p};
   // the gate program folds its second block with y^5 supplied as challenge 0 (mst_inclusion.py: GATE_BLOCKS)
   const Fr y5 = y.pow((uint64_t)5);
   ck(sg_quotient_gates_dev(values.p, &g_gates, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
-                           y5.bytes(), 1, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "gates");
+                           y5.bytes(), 1, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, main_stream()), "gates");
   std::vector<void*> col_ext, sig_ext, z_ext = {ex3[2].p, ex3[3].p};
   for (uint32_t c = 0; c < NUM_SIGMA; c++) {
     col_ext.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
@@ -712,13 +903,13 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   }
   ck(sg_quotient_permutation_dev(values.p, z_ext.data(), 2, col_ext.data(), sig_ext.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p,
                                  pk.l_last_ext.p, pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, BLINDING + 1,
-                                 nullptr), "permutation quotient");
+                                 main_stream()), "permutation quotient");
   ck(sg_quotient_gates_dev(input_ext.p, &g_in, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
-                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, nullptr), "lookup input (ext)");
+                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, main_stream()), "lookup input (ext)");
   ck(sg_quotient_lookup_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_ext.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
-                            pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, nullptr), "lookup quotient");
-  ck(sg_divide_by_vanishing_poly_dev(values.p, k, ext_k, nullptr), "divide by vanishing");
-  ck(sg_extended_to_coeff_dev(values.p, k, ext_k, nullptr), "extended_to_coeff");
+                            pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, main_stream()), "lookup quotient");
+  ck(sg_divide_by_vanishing_poly_dev(values.p, k, ext_k, main_stream()), "divide by vanishing");
+  ck(sg_extended_to_coeff_dev(values.p, k, ext_k, main_stream()), "extended_to_coeff");
   std::vector<void*> pieces;
   for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces.push_back(values.at(n * i));
   commit_batch(pieces, std::vector<int>(QUOTIENT_PIECES, 0));
@@ -751,7 +942,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     ev_points.push_back(x);
   }
   std::vector<Fr> ev(ev_polys.size());
-  ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)ev_polys.size(), nullptr,
+  ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)ev_polys.size(), main_stream(),
                                reinterpret_cast<uint8_t*>(ev.data())), "evaluations");
   std::map<std::pair<Key, int>, Fr> evals;
   for (size_t i = 0; i < order.size(); i++) {
@@ -763,7 +954,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
     std::vector<Fr> pw(QUOTIENT_PIECES);
     pw[0] = Fr::one();
     for (uint32_t i = 1; i < QUOTIENT_PIECES; i++) pw[i] = pw[i - 1] * x_n;
-    ck(sg_fr_lincomb_dev(pieces.data(), pw[0].bytes(), QUOTIENT_PIECES, n, h_comb.p, nullptr), "h lincomb");
+    ck(sg_fr_lincomb_dev(pieces.data(), pw[0].bytes(), QUOTIENT_PIECES, n, h_comb.p, main_stream()), "h lincomb");
   }
   poly[{H_, 0}] = h_comb.p;
   Fr h_eval = Fr::zero();
@@ -812,7 +1003,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   fork();
   for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
     const auto& set = sets[si];
-    hipStream_t st = si % 3 == 0 ? nullptr : side[si % 3 - 1];
+    hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
     DevCol &r_poly = r_polys[si], &tmp = tmps[si];
     std::vector<void*> ps;
     std::vector<Fr> zp(set.polys.size());
@@ -870,7 +1061,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
       ps.push_back(fs[i].p);
       np[i] = i ? np[i - 1] * nu : Fr::one();
     }
-    ck(sg_fr_lincomb_dev(ps.data(), np[0].bytes(), (uint32_t)ps.size(), n, f_all.p, nullptr), "f lincomb");
+    ck(sg_fr_lincomb_dev(ps.data(), np[0].bytes(), (uint32_t)ps.size(), n, f_all.p, main_stream()), "f lincomb");
   }
   commit_batch({f_all.p}, {0});
   const Fr mu = tr.squeeze();
@@ -899,7 +1090,7 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   }
   const Fr one = Fr::one();
   DevCol& r_poly = r_polys[0];
-  hk(hipMemsetAsync(r_poly.p, 0, 32 * 4, nullptr), "memset");
+  hk(hipMemsetAsync(r_poly.p, 0, 32 * 4, main_stream()), "memset");
   r_poly.upload(one.l, 0, 1);  // the constant polynomial 1
   std::vector<void*> lp;
   for (auto& q : qs) lp.push_back(q.p);
@@ -908,13 +1099,19 @@ inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCo
   coeffs.push_back(-z_s0);
   coeffs.push_back(-konst);
   DevCol l_poly(n), w2(n);
-  ck(sg_fr_lincomb_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, l_poly.p, nullptr), "L lincomb");
+  ck(sg_fr_lincomb_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, l_poly.p, main_stream()), "L lincomb");
   Fr rem;
-  ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), nullptr), "final division");
+  ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), main_stream()), "final division");
   if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");
   commit_batch({w2.p}, {0});
   lap("6_multiopen");
   return tr.proof;
+}
+// the Keccak / EVM flavour (what tools/create_proof_main.cpp and the bundles use)
+inline std::vector<uint8_t> create_proof(const ProvingKey& pk, std::vector<DevCol>& advice, const std::vector<Fr>& instances,
+                                         Timings* timings = nullptr) {
+  EvmTranscript tr;
+  return create_proof_with(pk, advice, instances, tr, Options(), timings);
 }
 
 }  // namespace prover

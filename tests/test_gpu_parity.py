@@ -630,32 +630,31 @@ def test_host_pointer_entry_points_from_many_threads(gpu, O):
     assert not errors, errors
 
 
-def test_two_host_threads_overlap_on_the_device(gpu, O):
-    """calls from different host threads take different lanes of the library (own streams, MSM engines, work space):
-    the same 24 mid-size MSMs finish measurably sooner from two threads than from one -- the latency-bound phases and the
-    host tail of one call run under the kernels of the other -- and every result is still the oracle's"""
+def test_two_host_threads_do_not_serialise(gpu, O):
+    """calls from different host threads take different lanes of the library (own streams, MSM engines, work space): two
+    threads issuing the same MSMs concurrently must finish well before twice the time one of them needs alone (they would
+    queue behind one lock otherwise), with every result still the oracle's"""
     import threading
     import time
     import torch
-    n = 1 << 14
+    n = 1 << 17
     bases = O.fixed_base_mul(O.random_fr(2950, n), O.ncpu())
     d_bases = torch.from_numpy(bases).cuda()
-    scal = [O.random_fr(2960 + i, n) for i in range(4)]
+    scal = [O.random_fr(2960 + i, n) for i in range(2)]
     want = [O.best_multiexp(s, bases, O.ncpu()) for s in scal]
     d_scal = [torch.from_numpy(s).cuda() for s in scal]
     torch.cuda.synchronize()
-    reps = 24
+    reps = 10
 
-    def run(which, out):
+    def run(i, out):
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
-            for r in range(reps // len(which)):
-                for i in which:
-                    out.append((i, gpu.best_multiexp(d_scal[i], d_bases)))
+            for r in range(reps):
+                out.append((i, gpu.best_multiexp(d_scal[i], d_bases)))
 
-    def timed(groups):
-        outs = [[] for _ in groups]
-        threads = [threading.Thread(target=run, args=(g, o)) for g, o in zip(groups, outs)]
+    def timed(which):
+        outs = [[] for _ in which]
+        threads = [threading.Thread(target=run, args=(i, o)) for i, o in zip(which, outs)]
         t0 = time.perf_counter()
         for th in threads:
             th.start()
@@ -663,13 +662,13 @@ def test_two_host_threads_overlap_on_the_device(gpu, O):
             th.join()
         dt = time.perf_counter() - t0
         for o in outs:
-            assert all((p == want[i]).all() for i, p in o)
+            assert len(o) == reps and all((p == want[i]).all() for i, p in o)
         return dt
-    timed([[0, 1, 2, 3]]); timed([[0, 1], [2, 3]])                # warm both lanes' work spaces
-    one = min(timed([[0, 1, 2, 3]]) for _ in range(3))
-    two = min(timed([[0, 1], [2, 3]]) for _ in range(3))          # same 24 MSMs, 12 per thread
-    print(f"24 MSMs of 2^14: one thread {one * 1e3:.2f} ms, two threads {two * 1e3:.2f} ms")
-    assert two < 0.85 * one, (one, two)
+    timed([0]); timed([0, 1])                                     # warm both lanes' work spaces
+    alone = min(timed([0]) for _ in range(3))
+    both = min(timed([0, 1]) for _ in range(3))                   # twice the work, two threads
+    print(f"{reps} MSMs of 2^17: one thread {alone * 1e3:.2f} ms; two threads, {reps} each: {both * 1e3:.2f} ms")
+    assert both < 1.8 * alone, (alone, both)
 
 
 @pytest.mark.parametrize("k,ncols", [(4, 1), (9, 4), (11, 2), (13, 4)])

@@ -397,3 +397,88 @@ def test_reference_floor_plan_proof_under_the_reference_verifying_key():
                       open(os.path.join(out, "gpu_proof_entry16_user0_cpp.json"), "w"))
     finally:
         params.free()
+
+
+def test_native_driver_matches_the_python_driver(setup):
+    """the library's compiled-host prover behind the C ABI of include/summa_prover.h (sp_create_proof) against
+    circuits_halo2_amd.prover.create_proof on the same key and witness: both transcript flavours verify with the
+    oracle's restated verifier, errors map to the same exceptions"""
+    from circuits_halo2_amd import ffi
+    from oracle import summa_verifier as SV
+    s = setup
+    P = s["prover"]
+    advice = [s["dev"](c) for c in s["asg"]["advice"]]
+    inst = s["asg"]["instances"]
+    before = [a.clone() for a in advice]
+    for flavour, size in (("evm", 2144), ("blake2b", 1632)):
+        proof = P.create_proof_native(s["params"], s["pk"], advice, inst, flavour)
+        assert len(proof) == size and SV.verify(proof, inst, s["vk"], flavour=flavour)
+        assert P.create_proof_native(s["params"], s["pk"], advice, inst, flavour) != proof       # fresh blinding
+        bad = bytearray(proof)
+        bad[size // 2] ^= 1
+        assert not SV.verify(bytes(bad), inst, s["vk"], flavour=flavour)
+    assert all((a == b).all() for a, b in zip(advice, before))                  # the caller's columns are untouched ...
+    P.create_proof_native(s["params"], s["pk"], advice, inst, "evm", in_place=True)
+    assert not all((a == b).all() for a, b in zip(advice, before))              # ... unless it hands them over
+    advice = before
+    # the Python driver's Blake2b flavour on the same key
+    blake = P.create_proof(s["params"], s["pk"], advice, inst, seeded_rng(21), transcript=P.Blake2bWrite())
+    assert len(blake) == 1632 and SV.verify(blake, inst, s["vk"], flavour="blake2b")
+    assert not SV.verify(blake, inst, s["vk"], flavour="evm")
+    # witness errors: SG_ERR_WITNESS -> ValueError, as the Python driver raises
+    adv = [list(c) for c in s["asg"]["advice"]]
+    adv[0][60] += 1 << 16
+    with pytest.raises(ValueError, match="not in the table"):
+        P.create_proof_native(s["params"], s["pk"], [s["dev"](c) for c in adv], inst)
+    adv = [list(c) for c in s["asg"]["advice"]]
+    adv[1][70] = 6
+    with pytest.raises(ValueError, match="permutation"):
+        P.create_proof_native(s["params"], s["pk"], [s["dev"](c) for c in adv], inst)
+    unchecked = P.create_proof_native(s["params"], s["pk"], [s["dev"](c) for c in adv], inst, sanity_checks=False)
+    assert len(unchecked) == 2144 and not SV.verify(unchecked, inst, s["vk"])       # upstream's default build: a proof that fails
+    # malformed calls
+    with pytest.raises(ValueError):
+        P.create_proof_native(s["params"], s["pk"], advice[:2], inst)
+    with pytest.raises(ValueError):
+        P.create_proof_native(s["params"], s["pk"], advice, [1 << 255])
+    import ctypes as C
+    L = ffi.prover_lib()
+    assert L.sp_key_destroy(C.c_uint64(987654)) == -1 and b"unknown key" in L.sp_last_error()
+    size = C.c_size_t(0)
+    out = np.zeros(2144, dtype=np.uint8)
+    ptrs = (C.c_void_p * 3)(*[a.data_ptr() for a in advice])
+    key = P.native_key(s["pk"], s["params"])
+    assert L.sp_create_proof(C.c_uint64(key), ptrs, None, 0, 7, 1, None, ffi.ptr(out), C.c_size_t(2144), C.byref(size)) == -1
+    assert L.sp_create_proof(C.c_uint64(key), ptrs, None, 0, 0, 1, None, ffi.ptr(out), C.c_size_t(100), C.byref(size)) == -1
+
+
+def test_native_proofs_from_several_threads(setup):
+    """four host threads, each on its own stream, proving concurrently through sp_create_proof (per-thread prover
+    sessions over per-call library lanes): every proof verifies"""
+    import threading
+    import torch
+    from oracle import summa_verifier as SV
+    s = setup
+    P = s["prover"]
+    advice = [s["dev"](c) for c in s["asg"]["advice"]]
+    inst = s["asg"]["instances"]
+    P.create_proof_native(s["params"], s["pk"], advice, inst)
+    torch.cuda.synchronize()
+    proofs, errors = [], []
+
+    def worker(flavour):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(5):
+                    proofs.append((flavour, P.create_proof_native(s["params"], s["pk"], advice, inst, flavour)))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(f,)) for f in ("evm", "blake2b", "evm", "blake2b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(proofs) == 20 and len({p for _, p in proofs}) == 20
+    assert all(SV.verify(p, inst, s["vk"], flavour=f) for f, p in proofs)

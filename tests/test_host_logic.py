@@ -10,10 +10,10 @@ import pytest
 from conftest import GOLDEN, ROOT, fr_np
 
 
-def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "summa_gpu.h")).read()
+def _declared_symbols(header="summa_gpu.h", prefix="sg_"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_abi_exports_every_declared_symbol():
@@ -28,6 +28,12 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/summa_gpu.h but not exported"
     assert set(ffi.EXPORTS) == set(names)
     assert ffi.lib().sg_version().startswith(b"summa_gpu")
+    # the compiled-host prover's ABI (include/summa_prover.h) lives in the same library
+    prover_names = _declared_symbols("summa_prover.h", "sp_")
+    assert set(prover_names) == set(ffi.PROVER_EXPORTS) and len(prover_names) == 4
+    for n in prover_names:
+        assert hasattr(L, n), f"{n} declared in include/summa_prover.h but not exported"
+    assert ffi.prover_lib().sp_last_error() == b""
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -156,8 +162,9 @@ def test_header_is_plain_c_and_a_c_client_links():
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     inc = os.path.join(ROOT, "include")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
-                           os.path.join(inc, "summa_gpu.h")])
+    for header in ("summa_gpu.h", "summa_prover.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                               os.path.join(inc, header)])
     libdir = os.path.join(ROOT, "circuits_halo2_amd")
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "abi_client")
