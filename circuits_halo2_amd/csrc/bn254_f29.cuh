@@ -254,6 +254,23 @@ SG_HD f29 f29_mul2(const f29& a, const f29& b, const f29& c, const f29& d) {
   return r;
 }
 
+// ONE Montgomery limb step: a * 2^-29 mod p.  a normalised with bound <= 170; returns exactly normalised limbs,
+// value < (170 / 2^29 + 1) p < 2p.  9 multiply-adds instead of the 162 of a product: the closing reduction of an NTT
+// pass whose data carries a factor 2^29 on purpose (ntt.hip: the last inter-pass twiddle table is scaled by it).
+template <class P>
+SG_HD f29 f29_mont_step(const f29& a) {
+  const uint32_t m = (a.l[0] * P::inv) & M29;
+  uint64_t acc = (uint64_t)a.l[0] + (uint64_t)m * P::p[0];   // == 0 mod 2^29
+  f29 r;
+#pragma unroll
+  for (int j = 1; j < 9; j++) {
+    acc = (acc >> 29) + (uint64_t)a.l[j] + (uint64_t)m * P::p[j];
+    r.l[j - 1] = (uint32_t)acc & M29;
+  }
+  r.l[8] = (uint32_t)(acc >> 29);
+  return r;
+}
+
 // value < 2p with exactly normalised limbs -> canonical [0, p)
 template <class P>
 SG_HD f29 f29_cond_sub_p(const f29& a) {

@@ -42,6 +42,9 @@ struct PassArgs {
   uint32_t in_len;           // elements present in `in`; beyond that the input reads as zero
   uint32_t pre3;             // multiply input i by pre[i % 3]   (coeff_to_extended)
   uint32_t post3;            // multiply output j by post[j % 3] (extended_to_coeff / plain scale)
+  uint32_t fold29;           // the data of this (last) pass carries a factor 2^29 (the plan's last twiddle table holds
+                             // it): close with one Montgomery limb step instead of a product by 1^; post[] absorbs 2^-29
+  uint32_t skip;             // leading DIT stages whose second operand is zero (zero-padded first pass): not executed
   uint32_t pre[3][8];        // Montgomery-2^256 words, converted once per workgroup
   uint32_t post[3][8];
   // batched launch (nbatch > 0): blockIdx.y selects the vector; same plan for all (small transforms are a chain
@@ -97,12 +100,35 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
     uint32_t tmp[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) tmp[i] = src[i];
-    lds_put(w, CONST0 + tid, f29_words_to_r261<P>(tmp));
+    f29 c = f29_words_to_r261<P>(tmp);
+    if (tid >= 3 && p.fold29) {   // c * 2^232 * 2^-261 = c * 2^-29
+      f29 k = f29_zero();
+      k.l[8] = 1;
+      c = f29_mul<P>(c, k);
+    }
+    lds_put(w, CONST0 + tid, c);
   }
   if (p.pre3) __syncthreads();
   // load the tile: rows are bit-reversed on the way in so that the DIT stages below leave
   // natural order
   const uint32_t rshift = 32 - p.log_r;
+  if (p.skip) {
+    // zero-padded input (coeff_to_extended: 2^k coefficients in a 2^(k+3) transform): only rows r < R >> skip exist,
+    // they land on the positions that are multiples of 2^skip, and the first `skip` stages would only add zeros to
+    // them -- u + w*0, u - w*0 -- i.e. copy each value over its block of 2^skip positions.  Load them replicated.
+    const uint32_t keep = ~((1u << p.skip) - 1);
+    for (uint32_t e = tid; e < E; e += nthr) {
+      const uint32_t t = e & (T - 1), rr = e >> p.log_t;
+      const uint32_t r = __brev(rr & keep) >> rshift;
+      const size_t gi = base + t + ((size_t)r << p.log_b);
+      f29 v = f29_load_r256<P>(p_in + gi);
+      if (p.pre3) {
+        uint32_t m = (uint32_t)(gi % 3);
+        if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
+      }
+      lds_put(d, e, v);
+    }
+  } else {
   for (uint32_t e = tid; e < E; e += nthr) {
     uint32_t t = e & (T - 1), r = e >> p.log_t;
     size_t gi = base + t + ((size_t)r << p.log_b);
@@ -119,10 +145,11 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
     uint32_t rr = p.log_r ? (__brev(r) >> rshift) : 0;
     lds_put(d, (rr << p.log_t) + t, v);
   }
+  }
   __syncthreads();
 
   // log2(R) radix-2 DIT stages, one butterfly per thread per sweep
-  for (uint32_t s = 0; s < p.log_r; s++) {
+  for (uint32_t s = p.skip; s < p.log_r; s++) {
     const uint32_t h = 1u << s;
     for (uint32_t q = tid; q < (E >> 1); q += nthr) {
       uint32_t t = q & (T - 1), pr = q >> p.log_t;
@@ -155,8 +182,10 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       if (p.tw_pass) {
         v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
         if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
+      } else if (p.post3) {
+        v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
       } else {
-        v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
+        v = p.fold29 ? f29_mont_step<P>(v) : f29_mul<P>(v, one);
       }
       f29_store_canonical<P>(p_out + go, v);
     }
@@ -170,8 +199,10 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       if (p.tw_pass) {
         v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
         if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
+      } else if (p.post3) {
+        v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
       } else {
-        v = f29_mul<P>(v, p.post3 ? lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)) : one);
+        v = p.fold29 ? f29_mont_step<P>(v) : f29_mul<P>(v, one);
       }
       f29_store_canonical<P>(p_out + go, v);
     }
@@ -189,8 +220,9 @@ __global__ void fill_powers(fp_words* tw, words8 w, uint32_t count) {
 //  mode 0 (2-pass, pass X):   idx = j2 + n2*i1            -> w^(i1*j2) * scale
 //  mode 1 (3-pass, pass A):   idx = j3 + n3*(i2 + n2*i1)  -> w^(n1*i2*j3) * scale
 //  mode 2 (3-pass, pass B):   idx = j3 + n3*j2 + n2n3*i1  -> w^(i1*(j3 + n3*j2))
+//  times29: the table additionally carries the factor 2^29 that the last pass removes with f29_mont_step
 __global__ void fill_pass_twiddles(fp_words* tw, words8 w, words8 scale, uint32_t has_scale, uint32_t mode,
-                                   uint32_t l1, uint32_t l2, uint32_t l3, uint32_t log_n) {
+                                   uint32_t l1, uint32_t l2, uint32_t l3, uint32_t log_n, uint32_t times29) {
   typedef Fr29 P;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >> log_n) return;
@@ -208,6 +240,11 @@ __global__ void fill_pass_twiddles(fp_words* tw, words8 w, words8 scale, uint32_
   e &= (1ull << log_n) - 1;
   f29 v = f29_pow_u64<P>(f29_words_to_r261<P>(w.l), e);
   if (has_scale) v = f29_mul<P>(v, f29_words_to_r261<P>(scale.l));
+  if (times29) {   // v * (2^29 * 2^261) * 2^-261: the integer 2^290 mod r as limbs = (2^261 mod r) doubled 29 times
+    f29 k = f29_one<P>();
+    for (int i = 0; i < 29; i++) k = f29_cond_sub_p<P>(f29_normalize(f29_dbl(k)));
+    v = f29_mul<P>(v, k);
+  }
   f29_store_canonical<P>(tw + idx, v);
 }
 // out = w^e as Montgomery-2^256 words (host-visible domain constants)
@@ -347,16 +384,16 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8
     err = hipMalloc(&pl.tw_pass[0], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
     fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
-                                                                         scale ? 1 : 0, 0, pl.l[0], pl.l[1], 0, log_n);
+                                                                         scale ? 1 : 0, 0, pl.l[0], pl.l[1], 0, log_n, 1);
   } else if (pl.npass == 3) {
     err = hipMalloc(&pl.tw_pass[0], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
     err = hipMalloc(&pl.tw_pass[1], sizeof(fp_words) * n);
     if (err != hipSuccess) return err;
     fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[0], omega, one_or_scale,
-                                                                         scale ? 1 : 0, 1, pl.l[0], pl.l[1], pl.l[2], log_n);
+                                                                         scale ? 1 : 0, 1, pl.l[0], pl.l[1], pl.l[2], log_n, 0);
     fill_pass_twiddles<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pl.tw_pass[1], omega, one_or_scale, 0, 2,
-                                                                         pl.l[0], pl.l[1], pl.l[2], log_n);
+                                                                         pl.l[0], pl.l[1], pl.l[2], log_n, 1);
   }
   err = hipGetLastError();
   if (err != hipSuccess) return err;
@@ -369,7 +406,18 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8
 }
 
 
+// leading stages of a zero-padded FIRST pass that can be skipped: rows r >= in_len >> log_b are zero
+static uint32_t skippable_stages(const PassArgs& a, uint32_t log_n) {
+  if (a.kind != 1 || a.in_len == 0 || (a.in_len & (a.in_len - 1)) || a.in_len >= (1u << log_n)) return 0;
+  const uint32_t rows = a.in_len >> a.log_b;   // nonzero rows of every column (in_len is a power of two)
+  if (rows == 0 || rows >= (1u << a.log_r)) return 0;
+  uint32_t z = 0;
+  while ((1u << z) < rows) z++;
+  return a.log_r - z;
+}
+
 static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n, hipStream_t stream) {
+  a.skip = skippable_stages(a, log_n);
   // tile width: as many contiguous columns as the LDS budget allows
   uint32_t log_e = std::min<uint32_t>(cfg.tile_log, log_n);
   if (log_e < a.log_r) log_e = a.log_r;
@@ -435,7 +483,7 @@ hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_wor
     err = launch_pass(cfg_, p, log_n, stream);
     if (err != hipSuccess) return err;
     io(MID, DATA);
-    p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2; p.kind = 0;
+    p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2; p.kind = 0; p.fold29 = 1;
     last_scale(true);
     return launch_pass(cfg_, p, log_n, stream);
   }
@@ -450,7 +498,7 @@ hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_wor
   err = launch_pass(cfg_, p, log_n, stream);
   if (err != hipSuccess) return err;
   io(MID, DATA);
-  p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2 + l3; p.kind = 0;
+  p.tw_local = pl->tw_local[0]; p.tw_pass = nullptr; p.log_r = l1; p.log_b = l2 + l3; p.kind = 0; p.fold29 = 1;
   last_scale(true);
   return launch_pass(cfg_, p, log_n, stream);
 }
@@ -509,7 +557,7 @@ hipError_t NttEngine::transform(const fp_words* in, size_t in_len, fp_words* out
     if (err != hipSuccess) return err;
     // pass Y: DFT over i1 (length n1, stride n2), columns j2 contiguous
     a.in = mid; a.out = out; a.tw_local = pl->tw_local[0]; a.tw_pass = nullptr;
-    a.log_r = l1; a.log_b = l2; a.kind = 0; a.in_len = 1u << log_n;
+    a.log_r = l1; a.log_b = l2; a.kind = 0; a.in_len = 1u << log_n; a.fold29 = 1;
     set_prepost(false, true);
     return launch_pass(cfg_, a, log_n, stream);
   }
@@ -530,7 +578,7 @@ hipError_t NttEngine::transform(const fp_words* in, size_t in_len, fp_words* out
   if (err != hipSuccess) return err;
   // pass C: DFT over i1 (length n1, stride n2 n3)
   a.in = mid; a.out = out; a.tw_local = pl->tw_local[0]; a.tw_pass = nullptr;
-  a.log_r = l1; a.log_b = l2 + l3; a.kind = 0;
+  a.log_r = l1; a.log_b = l2 + l3; a.kind = 0; a.fold29 = 1;
   set_prepost(false, true);
   return launch_pass(cfg_, a, log_n, stream);
 }

@@ -16,7 +16,9 @@ int sp_fail(int code, const char* what) {
   return code;
 }
 std::mutex g_keys_mu;
-std::map<uint64_t, std::shared_ptr<ProvingKey>> g_keys;
+// never destroyed: keys still registered at process exit must not run their destructors after the HIP runtime and
+// the threads' sessions are gone
+std::map<uint64_t, std::shared_ptr<ProvingKey>>& g_keys = *new std::map<uint64_t, std::shared_ptr<ProvingKey>>();
 uint64_t g_next_key = 1;
 
 Graph copy_graph(const sg_graph& g) {

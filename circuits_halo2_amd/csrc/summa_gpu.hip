@@ -16,6 +16,7 @@
 
 #include "host_curve.h"
 #include "host_pairing.h"
+#include "../../include/summa_prover.hpp"
 #include "msm.h"
 #include "ntt.h"
 #include "quotient.h"
@@ -1004,7 +1005,7 @@ int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]) {
 // The verifier's last step (halo2 `SingleStrategy` -> multi_miller_loop + final_exponentiation; the EVM's precompile
 // 0x08): *ok = (prod_i e(g1[i], g2[i]) == 1).  Host code (host_pairing.h); the slopes of a G2 point are computed once
 // and cached by its bytes (the two G2 points of a KZG check are fixed per SRS).
-int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok) {
+static int pairing_check_impl(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok, bool plain_check) {
   if (!ok || (n && (!g1_points || !g2_points))) return fail(SG_ERR_INVALID, "sg_pairing_check: null argument");
   if (n > 64) return fail(SG_ERR_INVALID, "sg_pairing_check: at most 64 pairs");
   using namespace sg::host;
@@ -1043,9 +1044,26 @@ int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t 
       qs.push_back(new PreparedG2(*prep));
     }
   }
-  Fq12 f = final_exponentiation(multi_miller_loop(ps, qs));
+  const Fq12 ml = multi_miller_loop(ps, qs);
   for (const PreparedG2* q : qs) delete q;
-  *ok = f.is_one() ? 1 : 0;
+  const bool one = final_exponentiation(ml).is_one();
+  if (plain_check && final_exponentiation_plain(ml).is_one() != one) return fail(SG_ERR_HIP, "sg_pairing_check: the two final exponentiations disagree");
+  *ok = one ? 1 : 0;
+  return SG_OK;
+}
+int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok) {
+  return pairing_check_impl(g1_points, g2_points, n, ok, false);
+}
+// the same with the final exponentiation cross-checked against its definition (tests)
+int sg_pairing_check_slow(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok) {
+  return pairing_check_impl(g1_points, g2_points, n, ok, true);
+}
+// Keccak-256 as Ethereum uses it (`ethers::utils::keccak256`, zk_prover/src/merkle_sum_tree/entry.rs:21; the EVM
+// transcript's hash, contracts/src/InclusionVerifier.sol:85-110): host utility for the host-language bindings
+int sg_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  if (!out || (len && !data)) return fail(SG_ERR_INVALID, "sg_keccak256: null argument");
+  const auto h = summa::prover::keccak256(data, len);
+  std::memcpy(out, h.data(), 32);
   return SG_OK;
 }
 // ParamsKZG::<Bn256>::setup(k, rng) with tau supplied by the caller's RNG (zk_prover/src/circuits/

@@ -25,7 +25,16 @@ _M64 = (1 << 64) - 1
 
 
 def keccak256(data: bytes) -> bytes:
-    """Keccak-256 as Ethereum uses it (`ethers::utils::keccak256`, entry.rs:21); lanes indexed x + 5y"""
+    """Keccak-256 as Ethereum uses it (`ethers::utils::keccak256`, entry.rs:21): the library's host routine
+    (sg_keccak256; the EVM transcript hashes a few KiB per proof)"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.zeros(32, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_keccak256(ffi.ptr(buf) if buf.size else None, C.c_size_t(buf.size), ffi.ptr(out)))
+    return out.tobytes()
+
+
+def keccak256_python(data: bytes) -> bytes:
+    """the same with Python integers (lanes indexed x + 5y): the independent twin the library routine is checked against"""
     rate = 136
     msg = bytearray(data) + b"\x01"
     msg += bytes(-len(msg) % rate)

@@ -161,6 +161,11 @@ int sg_g2_generator_mul(const uint8_t scalar[32], uint8_t out[128]);
  * Montgomery; identity = zeros).  Host code.  Points off the curve are SG_ERR_INVALID; G2 points are taken from
  * the (trusted) SRS and are not subgroup-checked. */
 int sg_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok);
+/* the same, with the final exponentiation's addition chain cross-checked against the plain exponentiation (tests) */
+int sg_pairing_check_slow(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* ok);
+/* Keccak-256 as Ethereum uses it (`ethers::utils::keccak256`: usernames, zk_prover/src/merkle_sum_tree/entry.rs:21; the
+ * hash of the EVM transcript).  Host code, for host-language bindings without a fast Keccak of their own. */
+int sg_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 /* ParamsKZG::<Bn256>::setup(k, rng) (zk_prover/src/circuits/utils.rs:70) with tau = the field
  * element the caller drew from its RNG (32 B Montgomery Fr): g[i] = tau^i * G,
  * g_lagrange[i] = L_i(tau) * G, 2^k points of 64 B each.  The G2 elements of the SRS are only

@@ -442,6 +442,10 @@ inline void hk(hipError_t e, const char* what) {
 // the pool of freed device columns and the page-locked staging area.  Nothing is shared between host threads, so
 // several proofs can be in flight on one GPU (one thread each, circuits_halo2_amd/batch.py); the C ABI underneath
 // gives every concurrent call its own lane.
+inline bool& session_gone() {   // trivially destructible, so still readable after this thread's Session has been destroyed
+  static thread_local bool gone = false;
+  return gone;
+}
 struct Session {
   hipStream_t main = nullptr;                 // NULL: HIP's default stream (single-threaded callers)
   hipStream_t side[2] = {nullptr, nullptr};
@@ -457,6 +461,7 @@ struct Session {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto& e : ev_join)
       if (e) (void)hipEventDestroy(e);
+    session_gone() = true;
   }
 };
 inline Session& session() {
@@ -506,17 +511,19 @@ struct DevCol {  // device column of Fr (Montgomery); owned unless borrowed from
   DevCol(const DevCol&) = delete;
   DevCol& operator=(const DevCol&) = delete;
   DevCol(DevCol&& o) noexcept : p(o.p), rows(o.rows), owned(o.owned) { o.p = nullptr; }
+  void give_back() {   // to this thread's pool; objects that outlive the thread's session (process exit) just let go
+    if (p && owned && !session_gone()) column_pool().emplace(rows, p);
+    p = nullptr;
+  }
   DevCol& operator=(DevCol&& o) noexcept {
-    if (p && owned) column_pool().emplace(rows, p);
+    give_back();
     p = o.p;
     rows = o.rows;
     owned = o.owned;
     o.p = nullptr;
     return *this;
   }
-  ~DevCol() {
-    if (p && owned) column_pool().emplace(rows, p);
-  }
+  ~DevCol() { give_back(); }
   uint8_t* at(size_t row) const { return static_cast<uint8_t*>(p) + 32 * row; }
   void upload(const void* host, size_t first, size_t count) { h2d(at(first), host, 32 * count); }
   void zero() { hk(hipMemsetAsync(p, 0, 32 * rows, main_stream()), "memset"); }

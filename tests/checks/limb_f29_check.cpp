@@ -17,6 +17,7 @@ template <class P> void run(const std::string& op, const f29& a, const f29& b) {
   else if (op == "sub8") r = f29_sub<P, 2>(a, b);
   else if (op == "sub64") r = f29_sub<P, 5>(a, b);
   else if (op == "canon") r = f29_canonical<P>(a);
+  else if (op == "step") r = f29_mont_step<P>(a);
   else if (op == "inv") r = f29_canonical<P>(f29_inv_safegcd<P>(a));
   else if (op == "iszero") { r.l[0] = f29_is_zero_mod_p<P>(a); }
   else if (op == "norm") r = f29_normalize(a);

@@ -38,6 +38,8 @@ for fld, p in (("q", P.Q), ("r", P.R)):
         b64 = rnd.randrange(64 * p)
         cases.append(("sub64", fld, limbs(a8), limbs(b64), ("sub", p, a8, b64, 64)))
         cases.append(("canon", fld, limbs(a), limbs(0), ("canon", p, a)))
+        st = rnd.choice([0, p, 170 * p - 1, p - 1]) if rnd.random() < 0.1 else rnd.randrange(rnd.choice([1, 2, 25, 170]) * p)
+        cases.append(("step", fld, limbs(st), limbs(0), ("step", p, st)))
         ai = rnd.choice([0, 1, 2, p - 1, p, p + 1, 3 * p, (1 << 261) % p]) if rnd.random() < 0.2 else rnd.randrange(rnd.choice([1, 2, 64, 170]) * p)
         cases.append(("inv", fld, limbs(ai), limbs(0), ("inv", p, ai)))
         z = rnd.choice([k * p for k in range(0, 65)] + [rnd.randrange(64 * p) for _ in range(8)] + [k * p + 1 for k in range(3)])
@@ -71,6 +73,10 @@ for (op, f, a, b, exp), line in zip(cases, out):
     elif exp[0] == "canon":
         _, p, x = exp
         ok = val(l) == x % p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "step":    # one Montgomery limb step: x * 2^-29 mod p, < 2p, exactly normalised limbs
+        _, p, x = exp
+        v = val(l)
+        ok = v % p == x * pow(1 << 29, -1, p) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
     elif exp[0] == "inv":     # (x^)^-1 in the 2^261 domain: A -> A^-1 * 2^522 (0 -> 0), canonical
         _, p, x = exp
         want = 0 if x % p == 0 else pow(x, -1, p) * pow(2, 522, p) % p

@@ -315,3 +315,24 @@ def test_witness_program_covers_the_reference_assignment_cell_by_cell(levels, nc
     nonzero = {(c, r) for c in range(3) for r in range(1 << k) if adv[c][r]}
     assert nonzero <= covered
     assert [it[0] for it in items] == sorted((it[0] for it in items), reverse=True)      # sponges first
+
+
+def test_library_keccak_and_the_cross_checked_final_exponentiation():
+    """host utilities of the library: sg_keccak256 against the Python twin and the oracle's Keccak (padding edge cases
+    around the 136-byte rate); sg_pairing_check_slow = the same verdicts with the final exponentiation's addition chain
+    compared against the plain exponentiation by (q^12 - 1) / r"""
+    from circuits_halo2_amd import merkle_sum_tree as T
+    rng = random.Random(17)
+    for n in (0, 1, 31, 135, 136, 137, 271, 272, 273, 1000, 4321):
+        d = bytes(rng.randrange(256) for _ in range(n))
+        assert T.keccak256(d) == T.keccak256_python(d) == PR.keccak256(d), n
+    assert T.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    from circuits_halo2_amd import ffi
+    g2 = PR.G2_GENERATOR
+    a, b = rng.randrange(1, PR.R), rng.randrange(1, PR.R)
+    pa, qb, pab = PR.g1_mul(PR.G1_GEN, a), PR.g2_mul(g2, b), PR.g1_mul(PR.G1_GEN, a * b % PR.R)
+    for pairs, want in (([(pa, qb), (PR.g1_neg(pab), g2)], 1), ([(pa, qb), (PR.g1_neg(pa), g2)], 0)):
+        g1b = np.frombuffer(b"".join(PR.g1_to_bytes(p) for p, _ in pairs), dtype=np.uint8).copy()
+        g2b = np.frombuffer(b"".join(PR.g2_to_bytes(q) for _, q in pairs), dtype=np.uint8).copy()
+        ok = C.c_int(-1)
+        assert ffi.lib().sg_pairing_check_slow(ffi.ptr(g1b), ffi.ptr(g2b), C.c_size_t(2), C.byref(ok)) == 0 and ok.value == want

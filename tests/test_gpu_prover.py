@@ -448,8 +448,13 @@ def test_native_driver_matches_the_python_driver(setup):
     out = np.zeros(2144, dtype=np.uint8)
     ptrs = (C.c_void_p * 3)(*[a.data_ptr() for a in advice])
     key = P.native_key(s["pk"], s["params"])
-    assert L.sp_create_proof(C.c_uint64(key), ptrs, None, 0, 7, 1, None, ffi.ptr(out), C.c_size_t(2144), C.byref(size)) == -1
-    assert L.sp_create_proof(C.c_uint64(key), ptrs, None, 0, 0, 1, None, ffi.ptr(out), C.c_size_t(100), C.byref(size)) == -1
+    from circuits_halo2_amd.utils import ints_to_fr
+    inst_b = ints_to_fr(inst)
+    args = (C.c_uint64(key), ptrs, ffi.ptr(inst_b), C.c_uint32(len(inst)))
+    assert L.sp_create_proof(*args, 7, 1, None, ffi.ptr(out), C.c_size_t(2144), C.byref(size)) == -1                  # unknown transcript
+    assert L.sp_create_proof(*args, 0, 1, None, ffi.ptr(out), C.c_size_t(100), C.byref(size)) == -1                   # proof buffer too small
+    assert L.sp_create_proof(C.c_uint64(key), ptrs, None, C.c_uint32(0), 0, 1, None, ffi.ptr(out), C.c_size_t(2144), C.byref(size)) == -6   # no instances: the copy constraints to the instance column fail
+    assert L.sp_create_proof(*args, 0, 1, None, ffi.ptr(out), C.c_size_t(2144), C.byref(size)) == 0 and size.value == 2144
 
 
 def test_native_proofs_from_several_threads(setup):
