@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
+    ap.add_argument("--in-flight", type=int, default=3, help="steps in flight per GPU: host threads issuing MSMs (library lanes); 1 = strictly one after the other")
     ap.add_argument("--batch-proofs", type=int, default=12, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
     args = ap.parse_args()
 
@@ -205,6 +206,7 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.run(cmd, env=env).returncode)
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # lanes and proofs in flight use many streams; HIP's default is 4 hardware queues
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +224,7 @@ def main():
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import ffi
     from circuits_halo2_amd.arithmetic import fr_to_montgomery, g1_fixed_base_mul
-    from circuits_halo2_amd.distributed import sharded_msm
+    from circuits_halo2_amd.distributed import exchange_partials
     from circuits_halo2_amd.utils import DEFAULT_SEED, random_fr_canonical
     ffi.check(sg.lib().sg_init(local_rank))
     for kv in filter(None, os.environ.get("SG_PARAMS", "").split(",")):  # e.g. SG_PARAMS=msm.log_seg=6
@@ -236,25 +238,52 @@ def main():
     bases = g1_fixed_base_mul(base_scal)  # s_i * G: valid, distinct curve points
     torch.cuda.synchronize()
 
-    def step():
-        return sharded_msm(scal, bases)
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    tls = threading.local()
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def partial():
+        """this rank's shard of one step: a whole 2^log_n MSM (digits .. host tail), result = the 64-byte point"""
+        if not hasattr(tls, "stream"):
+            tls.stream = torch.cuda.Stream()
+        with torch.cuda.stream(tls.stream):
+            return sg.best_multiexp(scal, bases)
+
+    def run_steps(count, in_flight):
+        """`count` steps; with in_flight > 1 the MSMs of consecutive steps are issued from that many host threads (each call
+        takes its own lane of the library: streams, engines, work space), while the exchange step of every MSM -- the
+        collective -- stays on this thread, in step order on every rank"""
+        if in_flight <= 1:
+            return [exchange_partials(partial()) for _ in range(count)]
+        futures = [pool.submit(partial) for _ in range(count)]
+        return [exchange_partials(f.result()) for f in futures]
+
+    def timed(count, in_flight):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        results = run_steps(count, in_flight)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, results
+
+    in_flight = max(1, args.in_flight)
+    pool = ThreadPoolExecutor(max_workers=in_flight)
+    run_steps(args.warmup, in_flight)
+    dt, results = timed(args.steps, in_flight)
+    result = results[-1]
+    assert all((r == result).all() for r in results), "steps of one input must agree"
+    # the same steps strictly one after the other (the latency of one MSM, round 1's headline)
+    run_steps(2, 1)
+    dt_seq, _ = timed(args.steps, 1)
+    pool.shutdown()
 
     batch_line, k17 = None, None
     if args.batch_proofs > 0 and not args.no_extras and args.log_n >= 20:
@@ -276,7 +305,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"standalone BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x synthetic-SRS "
                                    f"affine points per GPU (BASELINE configs[1])",
-                       "points_per_gpu": n, "sharding": "point-sharded, all_gather of 64-B partials" if world > 1 else "none"},
+                       "points_per_gpu": n, "sharding": "point-sharded, all_gather of 64-B partials" if world > 1 else "none",
+                       "steps_in_flight": in_flight,
+                       "step": "one whole MSM per GPU (digits, sort, accumulate, reduce, host tail; result = the 64-byte point); "
+                               "consecutive steps are issued from steps_in_flight host threads, each call on its own lane of the library"},
+            "sequential": {"ms_per_step": dt_seq / args.steps * 1e3, "value": world * n * args.steps / dt_seq,
+                           "note": "the same steps strictly one after the other (--in-flight 1): the latency of one MSM"},
         }
         # ---- roofline of the dominant kernel (msm_accumulate), HIP events on its stream
         _, tm = sg.best_multiexp(scal, bases, timings=True)

@@ -55,10 +55,10 @@ def combine_partials(partials: np.ndarray, msm=None) -> np.ndarray:
     return out
 
 
-def sharded_msm(local_scalars, local_bases, msm=None) -> np.ndarray:
-    """sum over ALL ranks' shards of sum_i s_i P_i; every rank returns the same 64-byte point.
-    With no process group this is plain best_multiexp."""
-    part = (msm or best_multiexp)(local_scalars, local_bases)
+def exchange_partials(part: np.ndarray, msm=None) -> np.ndarray:
+    """the exchange step of a point-sharded MSM: every rank contributes its 64-byte partial point, ONE all_gather
+    (RCCL over xGMI with the nccl backend), a local sum of world_size points; every rank returns the same point.
+    With no process group: the partial itself."""
     d = _dist()
     if d is None:
         return part
@@ -69,3 +69,9 @@ def sharded_msm(local_scalars, local_bases, msm=None) -> np.ndarray:
     gathered = torch.empty(64 * world, dtype=torch.uint8, device=dev)
     d.all_gather_into_tensor(gathered, mine)
     return combine_partials(gathered.cpu().numpy(), msm)
+
+
+def sharded_msm(local_scalars, local_bases, msm=None) -> np.ndarray:
+    """sum over ALL ranks' shards of sum_i s_i P_i; every rank returns the same 64-byte point.
+    With no process group this is plain best_multiexp."""
+    return exchange_partials((msm or best_multiexp)(local_scalars, local_bases), msm)
