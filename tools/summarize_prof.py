@@ -2,6 +2,21 @@
 """Condenses rocprofv3 output directories (gpurun_out/prof_<tag>{,_fetch,_write}) into the
 small files committed under profiles/: kernel stats CSV, per-kernel PMC averages (JSON)."""
 import collections, csv, glob, json, os, sys
+import sqlite3
+
+
+def rocpd_rows(directory, view):
+    """rows of a view of rocprofv3's SQLite output (ROCm 7: `<dir>/<host>/<pid>_results.db`), as dicts"""
+    out = []
+    for path in glob.glob(os.path.join(directory, "*", "*_results.db")):
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        cur.execute(f"select * from {view}")
+        names = [d[0] for d in cur.description]
+        out += [dict(zip(names, r)) for r in cur.fetchall()]
+    return out
+
+
 tag = sys.argv[1]                      # e.g. r01b
 src = os.path.join("gpurun_out", f"prof_{tag}")
 out = "profiles"
@@ -14,6 +29,16 @@ if ks:
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+elif glob.glob(os.path.join(src, "*", "*_results.db")):
+    agg = collections.defaultdict(list)
+    for r in rocpd_rows(src, "kernels"):
+        agg[r["name"].split("(")[0]].append(r["duration"])
+    total = sum(sum(v) for v in agg.values()) or 1
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 3), min(v), max(v)])
 # per (kernel, grid) durations from the trace: needed because one kernel runs at several sizes
 tr = glob.glob(os.path.join(src, "*", "*_kernel_trace.csv"))
 per = collections.defaultdict(list)
@@ -30,8 +55,33 @@ if tr:
             last_digits[r["Queue_Id"]] = grid
         elif name == "sg::msm_accumulate":
             acc_jobs[(grid, last_digits.get(r["Queue_Id"], 0))].append(dur)
+elif glob.glob(os.path.join(src, "*", "*_results.db")):
+    last_digits = {}
+    for r in sorted(rocpd_rows(src, "kernels"), key=lambda r: r["start"]):
+        name, grid = r["name"].split("(")[0], int(r["grid_x"]) * int(r["grid_y"]) * int(r["grid_z"])
+        dur = r["duration"] / 1e3
+        per[(name, grid, str(r["vgpr_count"]), str(r["lds_size"]), str(r["scratch_size"]))].append(dur)
+        if name == "sg::msm_digits":
+            last_digits[r["queue_id"]] = grid
+        elif name == "sg::msm_accumulate":
+            acc_jobs[(grid, last_digits.get(r["queue_id"], 0))].append(dur)
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    if not glob.glob(os.path.join(f"{src}_{kind}", "*", "*_counter_collection.csv")) and glob.glob(os.path.join(f"{src}_{kind}", "*", "*_results.db")):
+        agg = collections.defaultdict(list)
+        last_digits = {}
+        for r in sorted(rocpd_rows(f"{src}_{kind}", "counters_collection"), key=lambda r: r["start"]):
+            name, grid = r["kernel_name"].split("(")[0], int(r["grid_size"])
+            if name == "sg::msm_digits":
+                last_digits[r["queue_id"]] = grid
+            if r["counter_name"] == ctr:
+                agg[(name, grid)].append(float(r["value"]))
+                if name == "sg::msm_accumulate":
+                    agg[(name, f"{grid}@job{last_digits.get(r['queue_id'], 0)}")].append(float(r["value"]))
+        for (k, g), v in agg.items():
+            pmc.setdefault(f"{k}@grid{g}", {})[ctr + "_KB_avg"] = sum(v) / len(v)
+            pmc[f"{k}@grid{g}"]["launches_" + kind] = len(v)
+        continue
     cc = glob.glob(os.path.join(f"{src}_{kind}", "*", "*_counter_collection.csv"))
     if not cc:
         continue

@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_<tag>_valu (rocprofv3 --pmc VALUBusy VALUUtilization) -> profiles/<tag>_valu.json"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, sqlite3, sys
 tag = sys.argv[1]
-cc = glob.glob(f"gpurun_out/prof_{tag}_valu/*/*_counter_collection.csv")[0]
+found = glob.glob(f"gpurun_out/prof_{tag}_valu/*/*_counter_collection.csv")
+if found:
+    rows = list(csv.DictReader(open(found[0])))
+else:   # ROCm 7: rocprofv3 writes a SQLite database; same fields through its counters_collection view
+    rows = []
+    for path in glob.glob(f"gpurun_out/prof_{tag}_valu/*/*_results.db"):
+        cur = sqlite3.connect(path).cursor()
+        cur.execute("select kernel_name, grid_size, queue_id, counter_name, value, start from counters_collection")
+        rows += [{"Kernel_Name": a, "Grid_Size": str(b), "Queue_Id": c, "Counter_Name": d, "Counter_Value": e, "Start_Timestamp": f} for a, b, c, d, e, f in cur.fetchall()]
 per_k, per_g = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(lambda: collections.defaultdict(list))
 last_digits = {}
-for r in sorted(csv.DictReader(open(cc)), key=lambda r: int(r["Start_Timestamp"])):
+for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
     if name == "sg::msm_digits":
         last_digits[r["Queue_Id"]] = r["Grid_Size"]
