@@ -100,7 +100,7 @@ def batch_extra(args, rank, world):
     out = {"k": k, "levels": levels, "n_currencies": nc, "proofs_per_gpu": args.batch_proofs, "n_gpus": world,
            "setup_artifacts_s": setup_s, "by_in_flight": {}}
     users = [(7919 * i + 13) % (1 << levels) for i in range(args.batch_proofs * world)]
-    B.prove_batch(tree, users[:2 * world], params, pk, levels, in_flight=2)                 # warm-up: plans, pools, streams
+    B.prove_batch(tree, users[:6 * world], params, pk, levels, in_flight=3)                 # warm-up: every lane's plans, pools, streams
     best = None
     for in_flight in (1, 2, 3):
         if world > 1:
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight per GPU: host threads issuing MSMs (library lanes); 1 = strictly one after the other")
-    ap.add_argument("--batch-proofs", type=int, default=12, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
+    ap.add_argument("--batch-proofs", type=int, default=24, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

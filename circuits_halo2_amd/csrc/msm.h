@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bn254_curve29.cuh"
+#include "devmem.h"
 
 namespace sg {
 
@@ -38,13 +39,18 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t reserve(size_t need) {
     if (p && need <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = need + need / 8 + 64;
-    hipError_t e = hipMalloc(&p, want * sizeof(T));
-    if (e == hipSuccess) cap = want;
-    return e;
+    const size_t want = need + need / 4 + 64;
+    T* q = nullptr;
+    hipError_t e = hipMalloc(&q, want * sizeof(T));
+    if (e != hipSuccess) {   // out of memory: give the retired blocks back and try once more
+      retired_device_memory_collect();
+      e = hipMalloc(&q, want * sizeof(T));
+      if (e != hipSuccess) return e;
+    }
+    retire_device_memory(p);   // kernels enqueued earlier may still be reading the old block
+    p = q;
+    cap = want;
+    return hipSuccess;
   }
   void release() {
     if (p) (void)hipFree(p);

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "bn254_curve29.cuh"
+#include "devmem.h"
 
 namespace sg {
 

@@ -316,7 +316,7 @@ hipError_t NttEngine::local_twiddles(const words8& omega_r, uint32_t log_r, hipS
   err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(stream);  // complete before any other stream may use the cached table
   if (err != hipSuccess) {
-    (void)hipFree(d);
+    retire_device_memory(d);
     return err;
   }
   local_tw_.push_back({log_r, omega_r, d});
@@ -369,7 +369,7 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8
     pow_single<<<1, 1, 0, stream>>>(d, omega, 1ull << times);
     e = hipMemcpyAsync(res, d, sizeof(fp_words), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d);
+    retire_device_memory(d);   // a few bytes per plan; hipFree would wait for every other stream of the device
     return e;
   };
   for (int i = 0; i < pl.npass; i++) {

@@ -432,6 +432,7 @@ void sg_shutdown(void) {
     g_sh.srs.clear();
     g_sh.params.clear();
     g_sh.device = -1;
+    retired_device_memory_collect();
   }
   for (auto& l : g_lanes) l.mu.unlock();
 }

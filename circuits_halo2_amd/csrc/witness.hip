@@ -283,8 +283,8 @@ hipError_t WitnessEngine::init(hipStream_t stream) {
     poseidon_table_kernel<<<2, 128, 0, stream>>>(d_rc, d_mds, static_cast<PoseidonTable*>(table_));
     e = hipStreamSynchronize(stream);
   }
-  if (d_rc) (void)hipFree(d_rc);
-  if (d_mds) (void)hipFree(d_mds);
+  retire_device_memory(d_rc);
+  retire_device_memory(d_mds);
   return e;
 }
 void WitnessEngine::release() {
