@@ -160,3 +160,42 @@ def test_generate_setup_artifacts_downsizes_larger_params():
             full_prover(params, pk, MstInclusionCircuit.init_empty(3, N_CURRENCIES, N_BYTES), circuit.instances())
     finally:
         params.free()
+
+
+def test_prove_from_csv_compiled_program(tmp_path, kat):
+    """tools/prove_from_csv (C++ over the library, include/summa_circuit.hpp + summa_prover.hpp; no interpreter): the
+    reference's SRS file + its csv/entry_16.csv + user 0 -> calldata.  Key generation inside the program reproduces the
+    reference's verifying key, the public inputs are the reference's expected values (K5), and with the contract's vk digest
+    the proof is accepted on the reference's key by the oracle's verifier"""
+    import subprocess
+    from oracle import summa_verifier as SV
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "prove_from_csv")
+    if not os.path.exists(exe):
+        pytest.skip("tools/prove_from_csv not built (python __graft_entry__.py)")
+    out = str(tmp_path / "calldata.json")
+    r = subprocess.run([exe, SRS, CSV, "0", str(K), out, kat["vk_digest"] if len(kat["vk_digest"]) == 66 else "0x" + kat["vk_digest"][2:].rjust(64, "0"), "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    print(info)
+    assert (info["k"], info["levels"], info["n_currencies"], info["users"], info["rows_used"]) == (11, 4, 2, 16, 1489)
+    cd = json.load(open(out))
+    want = [(H(a), H(b)) for a, b in kat["fixed_comms"] + kat["permutation_comms"]]
+    assert [(H(a), H(b)) for a, b in cd["commitments"]] == want                  # the reference's verifying key
+    inst = [H(v) for v in cd["public_inputs"]]
+    assert inst == [H(kat["k5"]["leaf0"]), H(kat["k5"]["root"])] + kat["k5"]["root_balances"]
+    tr = json.load(open(os.path.join(GOLDEN, "k6_verifier_trace.json")))["vk"]
+    ref_vk = {"k": K, "vk_digest": H(tr["vk_digest"]), "fixed_comms": want[:11], "permutation_comms": want[11:],
+              "g2": ((H(tr["g2_x_2"]), H(tr["g2_x_1"])), (H(tr["g2_y_2"]), H(tr["g2_y_1"]))),
+              "neg_s_g2": ((H(tr["neg_s_g2_x_2"]), H(tr["neg_s_g2_x_1"])), (H(tr["neg_s_g2_y_2"]), H(tr["neg_s_g2_y_1"])))}
+    proof = bytes.fromhex(cd["proof"][2:])
+    assert len(proof) == 2144 and SV.verify(proof, inst, ref_vk)
+    # another user, this build's own digest, a key for more levels than the tree has is refused
+    r = subprocess.run([exe, SRS, CSV, "11", str(K), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    cd2 = json.load(open(out))
+    vk2 = dict(ref_vk, vk_digest=H(cd2["vk_digest"]))
+    assert H(cd2["vk_digest"]) != H(tr["vk_digest"]) and SV.verify(bytes.fromhex(cd2["proof"][2:]), [H(v) for v in cd2["public_inputs"]], vk2)
+    assert subprocess.run([exe, SRS, CSV, "16", str(K), out], capture_output=True, text=True).returncode == 1     # user index out of bounds
+    assert subprocess.run([exe, SRS, CSV, "0", "12", out], capture_output=True, text=True).returncode == 1        # k is too large for the given params

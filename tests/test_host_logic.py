@@ -189,3 +189,49 @@ def test_cpp_host_mirror_compiles_and_links():
                                os.path.join(ROOT, "tests", "cpp", "parity_main.cpp"), "-o", os.path.join(tmp, "parity_main"),
                                "-L", os.path.join(ROOT, "circuits_halo2_amd"), "-lsumma_gpu", "-L", os.path.join(ROOT, "oracle"),
                                "-loracle"])
+
+
+@pytest.mark.parametrize("k,levels,nc,nb", [(11, 4, 2, 8), (10, 3, 1, 8), (12, 5, 3, 4)])
+def test_cpp_circuit_equals_the_python_twin(k, levels, nc, nb, tmp_path):
+    """include/summa_circuit.hpp (the constraint system's GraphEvaluator programs, the reference circuit's floor plan, the
+    witness program, the verifying-key digest, username / balance parsing as compiled host code) against
+    circuits_halo2_amd/mst_inclusion.py -- byte for byte: fixed columns, sigma columns, program, both graphs"""
+    import shutil
+    import struct
+    import subprocess
+    if not shutil.which("g++") or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("no g++ / HIP headers")
+    from circuits_halo2_amd import api, mst_inclusion as M, prover as P
+    from circuits_halo2_amd.utils import ints_to_fr
+    from oracle import pyref as PR
+    exe = str(tmp_path / "circuit_dump")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "circuit_dump.cpp"), "-o", exe,
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    out = str(tmp_path / "dump.bin")
+    r = subprocess.run([exe, str(k), str(levels), str(nc), str(nb), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+
+    def graph_bytes(g):
+        b = struct.pack("<I", len(g.constants)) + b"".join(g.constants)
+        b += struct.pack("<I", len(g.rotations)) + struct.pack(f"<{len(g.rotations)}i", *g.rotations)
+        parts, calcs = [], b""
+        for cal in g.calculations:
+            off, ln = 0, 0
+            if len(cal) > 3:
+                off, ln = len(parts), len(cal[3])
+                parts.extend(cal[3])
+            calcs += struct.pack("<9I", cal[0], *cal[1], *cal[2], off, ln)
+        return b + struct.pack("<I", len(g.calculations)) + calcs + struct.pack("<I", len(parts)) + b"".join(struct.pack("<3I", *p) for p in parts)
+    prog, n_items, n_abs, inst, rows = M.witness_program(k, levels, nc, nb)
+    asg = api.MstInclusionCircuit.init_empty(levels, nc, nb).synthesize(k)
+    want = struct.pack("<4I", n_items, n_abs, rows, len(inst)) + struct.pack(f"<{len(inst)}I", *inst) + prog.tobytes()
+    want += b"".join(ints_to_fr(c).tobytes() for c in asg["fixed"]) + b"".join(ints_to_fr(c).tobytes() for c in asg["sigma"])
+    want += graph_bytes(M.gate_graph(nc)) + graph_bytes(M.lookup_input_graph())
+    rinv = pow(1 << 256, -1, PR.Q)
+    pts = [((2 * i + 1) * rinv % PR.Q, (2 * i + 2) * rinv % PR.Q) for i in range(17)]
+    want += P.verifying_key_digest(k, nc, pts[:11], pts[11:]).to_bytes(32, "big")
+    want += ints_to_fr([int.from_bytes(PR.keccak256(b"dxGaEAii"), "big"), 11888]).tobytes()
+    assert len(raw) == len(want)
+    assert raw == want
