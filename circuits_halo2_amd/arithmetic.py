@@ -234,6 +234,26 @@ def kate_division(a, b, with_remainder: bool = False):
     return (q, rem) if with_remainder else q
 
 
+def kate_division_batch(polys, points):
+    """exact quotients polys[j] / (X - points[j]) of equal-length device polynomials (m <= 16; a polynomial may appear
+    several times), one launch per scan step for all of them: returns m device tensors of n coefficients (the last one 0)"""
+    import torch
+    m = len(polys)
+    pts = ffi.u8(points)
+    if pts.size != 32 * m or m > 16:
+        raise ValueError("kate_division_batch: one point per polynomial, at most 16")
+    if m == 0:
+        return []
+    n = polys[0].numel() // 32
+    if any(p.numel() != 32 * n for p in polys):
+        raise ValueError("kate_division_batch: equal lengths expected")
+    outs = [torch.empty(32 * n, dtype=torch.uint8, device=polys[0].device) for _ in range(m)]
+    pa = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+    pq = (C.c_void_p * m)(*[q.data_ptr() for q in outs])
+    ffi.check(ffi.lib().sg_fr_kate_division_batch_dev(pa, C.c_size_t(n), ffi.ptr(pts), C.c_uint32(m), pq, ffi.current_stream_ptr()))
+    return outs
+
+
 def lincomb(polys, coeffs):
     """sum_j coeffs[j] * polys[j] over equal-length device tensors; coeffs: m x 32 bytes"""
     import torch

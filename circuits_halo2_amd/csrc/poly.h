@@ -36,6 +36,10 @@ hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const 
 size_t prefix_product_tmp_elems(size_t n);
 // Kate division a(X) = q(X)(X - b) + a(b): q_out gets n slots (q_0..q_{n-2}, then a zero) and must not alias a,
 // rem_out (optional) a(b); n <= 2^21; d_tmp: 1024 elements
+size_t kate_batch_powers_bytes(uint32_t m);
+size_t kate_batch_tmp_elems(size_t n, uint32_t m);
+hipError_t poly_kate_division_batch(const fp_words* const* d_a, size_t n, const words8* b, uint32_t m, fp_words* const* d_q,
+                                    uint8_t* h_pw, uint8_t* d_pw, fp_words* d_tmp, hipStream_t stream);
 hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,
                               fp_words* d_rem, hipStream_t stream);
 // out[i] = sum_j coeffs[j] * polys[j][i], m <= LINCOMB_MAX

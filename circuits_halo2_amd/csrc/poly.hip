@@ -316,6 +316,79 @@ __global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a
   if (first <= n - 1 && n - 1 < first + KD_CH) store_hat(q_out + n - 1, f29_zero());   // padding slot
 }
 
+// ---- several Kate divisions in one launch per step (grid.y = division): the quotients of SHPLONK's rotation sets.  By
+// partial fractions 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j), so the |S| divisions of a set are independent divisions
+// of ONE polynomial (it vanishes on the whole set) instead of a chain; all sets' divisions go in one batch.  The scan
+// weights live in device memory (one KatePowers per division, uploaded by the caller).
+static constexpr uint32_t KATE_BATCH_MAX = 16;
+struct KateBatch {
+  const fp_words* a[KATE_BATCH_MAX];
+  fp_words* q[KATE_BATCH_MAX];
+};
+__global__ void __launch_bounds__(256) kate_blocks_batch(KateBatch bt, uint32_t n, const KatePowers* __restrict__ pws,
+                                                         fp_words* __restrict__ bval, uint32_t nblk) {
+  __shared__ uint32_t sh[KD_THREADS][9];
+  __shared__ KatePowers pw;
+  for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&pw)[i] = reinterpret_cast<const uint32_t*>(pws + blockIdx.y)[i];
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
+  f29 vals[KD_CH];
+  f29 local = kd_local(bt.a[blockIdx.y], n, first, pw.b_hat, vals);
+  f29 s = block_suffix_geometric(local, pw.chunk, sh, tid, KD_THREADS);
+  if (tid == 0) store_hat(bval + (size_t)blockIdx.y * nblk + blockIdx.x, s);
+}
+__global__ void __launch_bounds__(1024) kate_scan_blocks_batch(fp_words* __restrict__ bval, uint32_t nblk,
+                                                               const KatePowers* __restrict__ pws) {
+  __shared__ uint32_t sh[1024][9];
+  __shared__ KatePowers pw;
+  for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&pw)[i] = reinterpret_cast<const uint32_t*>(pws + blockIdx.y)[i];
+  __syncthreads();
+  fp_words* mine_b = bval + (size_t)blockIdx.y * nblk;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  f29 mine = tid < nblk ? load_hat(mine_b + tid) : f29_zero();
+  block_suffix_geometric(mine, pw.block, sh, tid, nthr);
+  f29 carry = f29_zero();
+  if (tid + 1 < nthr) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) carry.l[q] = sh[tid + 1][q];
+  }
+  __syncthreads();
+  if (tid < nblk) store_hat(mine_b + tid, carry);
+}
+__global__ void __launch_bounds__(256) kate_write_batch(KateBatch bt, uint32_t n, const KatePowers* __restrict__ pws,
+                                                        const fp_words* __restrict__ carry_all, uint32_t nblk) {
+  __shared__ uint32_t sh[KD_THREADS][9];
+  __shared__ KatePowers pw;
+  for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&pw)[i] = reinterpret_cast<const uint32_t*>(pws + blockIdx.y)[i];
+  __syncthreads();
+  const fp_words* __restrict__ a = bt.a[blockIdx.y];
+  fp_words* __restrict__ q_out = bt.q[blockIdx.y];
+  const fp_words* carry = nblk > 1 ? carry_all + (size_t)blockIdx.y * nblk : nullptr;
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
+  f29 vals[KD_CH];
+  const f29 b_hat = pw.b_hat;
+  f29 local = kd_local(a, n, first, b_hat, vals);
+  if (carry && tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), pw.chunk[0]);
+  block_suffix_geometric(local, pw.chunk, sh, tid, KD_THREADS);
+  f29 run = f29_zero();
+  if (tid + 1 < KD_THREADS) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) run.l[q] = sh[tid + 1][q];
+  } else if (carry) {
+    run = load_hat(carry + blockIdx.x);
+  }
+#pragma unroll
+  for (uint32_t k = KD_CH; k-- > 0;) {
+    const uint32_t i = first + k;
+    run = f29_mul2<P>(run, b_hat, vals[k], f29_one<P>());      // s_i; s_0 = a(b) is the remainder, dropped (exact divisions)
+    if (i < n && i >= 1) store_hat(q_out + i - 1, run);
+  }
+  if (first <= n - 1 && n - 1 < first + KD_CH) store_hat(q_out + n - 1, f29_zero());   // padding slot
+}
+
 // ---- out[i] = sum_j c_j * p_j[i] ------------------------------------------------------------------
 struct LinCombArgs {
   const fp_words* polys[LINCOMB_MAX];
@@ -471,6 +544,35 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
   while (scan_threads < nblk) scan_threads <<= 1;
   kate_scan_blocks<<<1, scan_threads, 0, stream>>>(d_tmp, nblk, pw);
   kate_write<<<nblk, KD_THREADS, 0, stream>>>(d_a, (uint32_t)n, pw, d_tmp, d_q, d_rem);
+  return hipGetLastError();
+}
+size_t kate_batch_powers_bytes(uint32_t m) { return (size_t)m * sizeof(KatePowers); }
+size_t kate_batch_tmp_elems(size_t n, uint32_t m) { return (size_t)m * ((n + KD_BLOCK - 1) / KD_BLOCK) + 1; }
+// q[j] = a[j] / (X - b[j]) for m <= 16 polynomials of n coefficients (n written per quotient, the last one 0); h_pw: m
+// KatePowers on the host (scratch), d_pw / d_tmp: device scratch (kate_batch_powers_bytes / kate_batch_tmp_elems)
+hipError_t poly_kate_division_batch(const fp_words* const* d_a, size_t n, const words8* b, uint32_t m, fp_words* const* d_q,
+                                    uint8_t* h_pw, uint8_t* d_pw, fp_words* d_tmp, hipStream_t stream) {
+  if (m == 0 || n == 0) return hipSuccess;
+  if (m > KATE_BATCH_MAX) return hipErrorInvalidValue;
+  const uint32_t nblk = (uint32_t)((n + KD_BLOCK - 1) / KD_BLOCK);
+  if (nblk > 1024) return hipErrorInvalidValue;
+  KatePowers* hp = reinterpret_cast<KatePowers*>(h_pw);
+  KateBatch bt{};
+  for (uint32_t j = 0; j < m; j++) {
+    hp[j] = kate_powers(b[j]);
+    bt.a[j] = d_a[j];
+    bt.q[j] = d_q[j];
+  }
+  hipError_t e = hipMemcpyAsync(d_pw, h_pw, kate_batch_powers_bytes(m), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  const KatePowers* dp = reinterpret_cast<const KatePowers*>(d_pw);
+  if (nblk > 1) {
+    kate_blocks_batch<<<dim3(nblk, m), KD_THREADS, 0, stream>>>(bt, (uint32_t)n, dp, d_tmp, nblk);
+    uint32_t scan_threads = 64;
+    while (scan_threads < nblk) scan_threads <<= 1;
+    kate_scan_blocks_batch<<<dim3(1, m), scan_threads, 0, stream>>>(d_tmp, nblk, dp);
+  }
+  kate_write_batch<<<dim3(nblk, m), KD_THREADS, 0, stream>>>(bt, (uint32_t)n, dp, d_tmp, nblk);
   return hipGetLastError();
 }
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,

@@ -1383,6 +1383,33 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
   if (e != hipSuccess) return hip_fail("kate_division", e);
   return SG_OK;
 }
+// m <= 16 exact divisions q_j = a_j / (X - b_j) in one launch per scan step (a_j may repeat: by partial fractions the
+// divisions of one rotation set are independent divisions of the same polynomial).  Asynchronous on `stream`.
+int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
+                                  void* stream) {
+  if (m && (!d_a || !points || !d_q)) return fail(SG_ERR_INVALID, "sg_fr_kate_division_batch: null argument");
+  if (m > 16) return fail(SG_ERR_INVALID, "sg_fr_kate_division_batch: at most 16 divisions per call");
+  if (n > (1ull << 21)) return fail(SG_ERR_INVALID, "sg_fr_kate_division_batch: at most 2^21 coefficients");
+  for (uint32_t j = 0; j < m; j++)
+    if (n && (!d_a[j] || !d_q[j] || d_a[j] == d_q[j])) return fail(SG_ERR_INVALID, "sg_fr_kate_division_batch: bad vector");
+  if (m == 0 || n == 0) return SG_OK;
+  LOCKED_CTX();
+  hipStream_t s = pick_stream(stream);
+  uint8_t *d_pw = nullptr, *d_tmp = nullptr;
+  hipError_t e = scratch_for(s, 5, kate_batch_powers_bytes(16), &d_pw);
+  if (e == hipSuccess) e = scratch_for(s, 6, kate_batch_tmp_elems(n, 16) * 32 + 64, &d_tmp);
+  if (e != hipSuccess) return hip_fail("kate_division_batch work space", e);
+  std::vector<words8> b(m);
+  std::memcpy(b.data(), points, 32 * (size_t)m);
+  std::vector<uint8_t> h_pw(kate_batch_powers_bytes(m));
+  e = poly_kate_division_batch(reinterpret_cast<const fp_words* const*>(d_a), n, b.data(), m, reinterpret_cast<fp_words* const*>(d_q),
+                               h_pw.data(), d_pw, reinterpret_cast<fp_words*>(d_tmp), s);
+  // h_pw is a local: the (pageable) upload has been staged by the time hipMemcpyAsync returns only if it was synchronous;
+  // make sure before the buffer dies
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail("kate_division_batch", e);
+  return SG_OK;
+}
 // out[i] = sum_j coeffs[j] * polys[j][i]: the random linear combinations of SHPLONK / multi-open
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream) {
   if (!d_polys || !coeffs || (n && !d_out)) return fail(SG_ERR_INVALID, "sg_fr_lincomb: null argument");

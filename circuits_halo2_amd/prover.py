@@ -479,30 +479,37 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     zeta = tr.squeeze_challenge()
     nu = tr.squeeze_challenge_again()
     zero_row = torch.zeros(32, dtype=torch.uint8, device="cuda")
-    qs, rs, fs = [], [], []
-    for rots, keys in ROTATION_SETS:
+    qs, rs, fs, div_in, div_pts, weights = [], [], [], [], [], []
+    for si, (rots, keys) in enumerate(ROTATION_SETS):
         q = A.lincomb([polys[key] for key in keys], np.concatenate([_fr_bytes(pow(zeta, j, R)) for j in range(len(keys))]))
         pts = [point(r) for r in rots]
         vals = [sum(pow(zeta, j, R) * eval_of(key, r) for j, key in enumerate(keys)) % R for r in rots]
         # r(X): the polynomial of degree < |S| through (pts, vals) (Lagrange interpolation on integers)
         r_coeff = [0] * len(pts)
+        denoms = []
         for i, (pi, vi) in enumerate(zip(pts, vals)):
             basis, denom = [1], 1
             for j, pj in enumerate(pts):
                 if j != i:
                     basis = [((basis[t - 1] if t else 0) - pj * (basis[t] if t < len(basis) else 0)) % R for t in range(len(basis) + 1)]
                     denom = denom * (pi - pj) % R
-            scale = vi * _inv(denom) % R
+            denoms.append(_inv(denom))
+            scale = vi * denoms[-1] % R
             for t, b in enumerate(basis):
                 r_coeff[t] = (r_coeff[t] + scale * b) % R
         r_poly = _head(r_coeff, n)
         f = A.lincomb([q, r_poly], np.concatenate([_fr_bytes(1), _fr_bytes(R - 1)]))
-        for p in pts:   # exact divisions (q - r vanishes on the set); the final remainder check below covers them
-            f = torch.cat([A.kate_division(f, _fr_bytes(p)), zero_row])
+        # (q - r) / Z_S: q - r vanishes on the whole set and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with the Lagrange
+        # denominators c_j = 1 / prod_{t != j} (p_j - p_t): every division of every set is an independent exact Kate division
+        for pj, cj in zip(pts, denoms):
+            div_in.append(f)
+            div_pts.append(_fr_bytes(pj))
+            weights.append(_fr_bytes(pow(nu, si, R) * cj % R))
         qs.append(q)
         rs.append(r_coeff)
         fs.append(f)
-    f_all = A.lincomb(fs, np.concatenate([_fr_bytes(pow(nu, i, R)) for i in range(len(fs))]))
+    quotients = A.kate_division_batch(div_in, np.concatenate(div_pts))            # all eleven in one batch
+    f_all = A.lincomb(quotients, np.concatenate(weights))                          # sum_i nu^i (q_i - r_i) / Z_{S_i}
     w = _point(params.commit(f_all))
     tr.write_point(w)
     mu = tr.squeeze_challenge()

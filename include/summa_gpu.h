@@ -233,6 +233,12 @@ int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void*
  * remainder_out (optional, host) receives a(b).  n <= 2^21. */
 int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void* d_q, uint8_t* remainder_out,
                             void* stream);
+/* m <= 16 exact divisions q_j = a_j / (X - points_j) of n coefficients each (n written per quotient, the last one 0), one
+ * launch per scan step for all of them.  The multi-open's use: by partial fractions 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j),
+ * so the divisions of a rotation set are independent divisions of the same polynomial (which vanishes on the whole set)
+ * instead of a chain, and all sets go in one batch.  Remainders are not returned.  Complete on return. */
+int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
+                                  void* stream);
 /* out[i] = sum_j coeffs[j] * polys[j][i], 1 <= m <= 32 (the random linear combinations of the multi-open) */
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
 

@@ -974,11 +974,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   const auto sets = rotation_sets();
   std::vector<DevCol> qs, fs;
   std::vector<std::vector<Fr>> rs;
-  std::vector<DevCol> r_polys, tmps;
+  std::vector<DevCol> r_polys;
   for (size_t i = 0; i < sets.size(); i++) {
     r_polys.emplace_back(n);
     r_polys.back().zero();
-    tmps.emplace_back(n);
   }
   // the Lagrange denominators prod_{j != i} (p_i - p_j) of every set depend only on x: one host inversion for all
   // of them (Montgomery's trick) instead of one 254-step exponentiation each
@@ -1011,7 +1010,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
     const auto& set = sets[si];
     hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
-    DevCol &r_poly = r_polys[si], &tmp = tmps[si];
+    DevCol& r_poly = r_polys[si];
     std::vector<void*> ps;
     std::vector<Fr> zp(set.polys.size());
     for (size_t j = 0; j < set.polys.size(); j++) {
@@ -1051,24 +1050,33 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       const Fr cf[2] = {Fr::one(), -Fr::one()};
       ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, st), "q - r");
     }
-    void *src = fs.back().p, *dst = tmp.p;
-    for (auto& p : pts) {  // exact divisions; kate_division writes n elements (the last one 0)
-      ck(sg_fr_kate_division_dev(src, n, p.bytes(), dst, nullptr, st), "kate division");
-      std::swap(src, dst);
-    }
-    if (src != fs.back().p) hk(hipMemcpyAsync(fs.back().p, src, 32 * n, hipMemcpyDeviceToDevice, st), "D2D");
     rs.push_back(rc);
   }
   join();
+  // f_i / Z_{S_i}: q_i - r_i vanishes on the whole set, and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with
+  // c_j = 1 / prod_{t != j} (p_j - p_t) -- the Lagrange denominators already inverted above.  So every division of every
+  // set is an independent exact Kate division: ONE batch (three launches for all eleven), and
+  // f = sum_i nu^i f_i / Z_{S_i} is one linear combination of the eleven quotients
   DevCol f_all(n);
   {
-    std::vector<void*> ps;
-    std::vector<Fr> np(fs.size());
-    for (size_t i = 0; i < fs.size(); i++) {
-      ps.push_back(fs[i].p);
-      np[i] = i ? np[i - 1] * nu : Fr::one();
+    std::vector<void*> div_in, div_out;
+    std::vector<Fr> div_pts, weights;
+    std::vector<DevCol> quotients;
+    Fr nu_pow = Fr::one();
+    for (size_t si = 0; si < sets.size(); si++) {
+      for (size_t j = 0; j < sets[si].rots.size(); j++) {
+        quotients.emplace_back(n);
+        div_in.push_back(fs[si].p);
+        div_out.push_back(quotients.back().p);
+        div_pts.push_back(point(sets[si].rots[j]));
+        weights.push_back(nu_pow * denom_inv[si][j]);
+      }
+      nu_pow = nu_pow * nu;
     }
-    ck(sg_fr_lincomb_dev(ps.data(), np[0].bytes(), (uint32_t)ps.size(), n, f_all.p, main_stream()), "f lincomb");
+    ck(sg_fr_kate_division_batch_dev(div_in.data(), n, div_pts[0].bytes(), (uint32_t)div_in.size(), div_out.data(), main_stream()),
+       "kate division batch");
+    ck(sg_fr_lincomb_dev(div_out.data(), weights[0].bytes(), (uint32_t)div_out.size(), n, f_all.p, main_stream()), "f lincomb");
+    hk(hipStreamSynchronize(main_stream()), "sync");   // the quotient columns go back to the pool with this scope
   }
   commit_batch({f_all.p}, {0});
   const Fr mu = tr.squeeze();

@@ -934,6 +934,50 @@ def test_kate_division(gpu, O, n):
     assert (q0.cpu().numpy() == a[32:]).all()
 
 
+@pytest.mark.parametrize("n,m", [(1, 2), (7, 3), (2048, 4), (2049, 16), (1 << 13, 11), (1 << 17, 11), (300001, 5)])
+def test_kate_division_batch(gpu, O, n, m):
+    """sg_fr_kate_division_batch_dev: every quotient bit-exact vs the oracle's recurrence (the same polynomial may be divided
+    by several points); and the multi-open's use of it: for f vanishing on a set S, sum_j c_j f / (X - p_j) with the Lagrange
+    denominators c_j equals the chained division f / prod_j (X - p_j)"""
+    from circuits_halo2_amd.arithmetic import kate_division, kate_division_batch, lincomb
+    polys = [O.random_fr(2700 + j % 3, n) for j in range(m)]
+    d_polys = [dev(p) for p in polys]
+    for j in range(3, m):
+        d_polys[j] = d_polys[j % 3]                      # repeated inputs, as in the multi-open
+        polys[j] = polys[j % 3]
+    pts = O.random_fr(2750 + m, m)
+    got = kate_division_batch(d_polys, pts)
+    for j in range(m):
+        want_q, _ = O.fr_kate_division(polys[j], pts[32 * j:32 * j + 32].copy())
+        q = got[j].cpu().numpy()
+        assert (q[:32 * (n - 1)] == want_q).all() and not q[32 * (n - 1):].any(), j
+    if n >= 8:
+        from oracle import pyref as PR
+        # f = g * (X - p0)(X - p1)(X - p2): vanishes on {p0, p1, p2}
+        g = O.random_fr(2790, n - 3)
+        p = [PR.fr_from_bytes(bytes(pts[32 * j:32 * j + 32])) for j in range(3)]
+        f = np.concatenate([g, np.zeros(96, dtype=np.uint8)])
+        for pj in p:                                      # multiply by (X - pj) with integers (small n) or on the oracle
+            shifted = np.concatenate([np.zeros(32, dtype=np.uint8), f[:-32]])
+            scaled = np.concatenate([O.fr_mul(f[32 * i:32 * i + 32].copy(), fr_np([PR.R - pj])) for i in range(n)]) if n <= 4096 else None
+            if scaled is None:
+                break
+            f = np.concatenate([O.fr_add(shifted[32 * i:32 * i + 32].copy(), scaled[32 * i:32 * i + 32].copy()) for i in range(n)])
+        else:
+            df = dev(f)
+            qs = kate_division_batch([df, df, df], pts[:96].copy())
+            c = [pow((p[j] - p[(j + 1) % 3]) * (p[j] - p[(j + 2) % 3]) % PR.R, -1, PR.R) for j in range(3)]
+            combined = lincomb(qs, fr_np(c)).cpu().numpy()
+            assert (combined[:32 * (n - 3)] == g).all() and not combined[32 * (n - 3):].any()
+            chained = df
+            for j in range(3):
+                import torch
+                chained = torch.cat([kate_division(chained, pts[32 * j:32 * j + 32].copy()), torch.zeros(32, dtype=torch.uint8, device="cuda")])
+            assert (chained.cpu().numpy() == combined).all()
+    with pytest.raises(ValueError):
+        kate_division_batch(d_polys[:1] * 17, np.tile(pts[:32], 17))
+
+
 @pytest.mark.parametrize("n,m", [(1, 3), (100, 1), (8192, 5), (8193, 2), (1 << 17, 35), (300000, 41)])
 def test_eval_polynomial_batch(gpu, O, n, m):
     from circuits_halo2_amd.arithmetic import eval_polynomial_batch
