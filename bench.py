@@ -112,8 +112,9 @@ def batch_extra(args, rank, world):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        done = torch.tensor([len(res.proofs), len(res.errors)], device="cuda", dtype=torch.float64)
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        coll_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+        done = torch.tensor([len(res.proofs), len(res.errors)], device=coll_dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(done)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -187,6 +188,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1: nccl (= RCCL, one GPU per rank); gloo rehearses the multi-rank logic on a "
+                         "box with fewer GPUs than ranks (host-side collectives, ranks share GPUs round-robin)")
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight per GPU: host threads issuing MSMs (library lanes); 1 = strictly one after the other")
     ap.add_argument("--batch-proofs", type=int, default=24, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
     args = ap.parse_args()
@@ -214,12 +218,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.backend == "gloo" and torch.cuda.device_count() >= 1:
+        local_rank %= torch.cuda.device_count()          # rehearsal: more ranks than GPUs
     if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the small tensors of the timing collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import ffi
@@ -269,7 +279,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, results
@@ -311,6 +321,7 @@ def main():
             "config": {"workload": f"standalone BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x synthetic-SRS "
                                    f"affine points per GPU (BASELINE configs[1])",
                        "points_per_gpu": n, "sharding": "point-sharded, all_gather of 64-B partials" if world > 1 else "none",
+                       "backend": ("nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal: ranks share GPUs)") if world > 1 else None,
                        "steps_in_flight": in_flight,
                        "step": "one whole MSM per GPU (digits, sort, accumulate, reduce, host tail; result = the 64-byte point); "
                                "consecutive steps are issued from steps_in_flight host threads, each call on its own lane of the library"},

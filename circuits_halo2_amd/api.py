@@ -182,6 +182,7 @@ def generate_setup_artifacts(k: int, params_path: str | None, circuit: MstInclus
             params = ParamsKZG.read(f)
         if params.k < k:
             raise ValueError("k is too large for the given params")
+        params.check()                                          # RawBytes: points off the curve fail the read
         if params.k > k:
             params.downsize(k)
     else:

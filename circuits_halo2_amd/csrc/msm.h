@@ -151,5 +151,7 @@ class MsmEngine {
 hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_n, const words8& omega,
                   const words8* scale, xyzz29_mem* d_work, hipStream_t stream);
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream);
+// *d_bad = number of points that are neither on y^2 = x^3 + 3 nor the identity
+hipError_t g1_on_curve(const g1_affine_mem* d_points, size_t n, uint32_t* d_bad, hipStream_t stream);
 
 }  // namespace sg

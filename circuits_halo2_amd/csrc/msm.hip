@@ -1570,6 +1570,27 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   return finish();
 }
 
+// points[i] on y^2 = x^3 + 3 (or the identity, 64 zero bytes)?  *bad counts the points that are not
+__global__ void __launch_bounds__(256) g1_on_curve_kernel(const g1_affine_mem* __restrict__ points, uint32_t n, uint32_t* bad) {
+  typedef Fq29 P;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const affine29 p = affine29_load(points + i);
+  if (p.inf) return;
+  const f29 one = f29_one<P>();
+  const f29 x = f29_mul<P>(p.x, one), y = f29_mul<P>(p.y, one);       // bound 32 -> < 2
+  const f29 x3 = f29_mul<P>(f29_sqr<P>(x), x), y2 = f29_sqr<P>(y);
+  const f29 three = f29_add(f29_add(one, one), one);
+  const f29 d = f29_sub<P, 1>(f29_sub<P, 0>(y2, x3), three);          // y^2 - x^3 - 3 (+ multiples of q)
+  if (!f29_is_zero_mod_p<P>(d)) atomicAdd(bad, 1u);
+}
+hipError_t g1_on_curve(const g1_affine_mem* d_points, size_t n, uint32_t* d_bad, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess || !n) return e;
+  g1_on_curve_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_points, (uint32_t)n, d_bad);
+  return hipGetLastError();
+}
+
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream) {
   if (!n) return hipSuccess;
   g1_fixed_base_mul<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_scalars, (uint32_t)n, d_out);

@@ -606,6 +606,27 @@ int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint6
   }
   return SG_OK;
 }
+// `SerdeFormat::RawBytes` validation of ParamsKZG::read (halo2: from_raw_bytes rejects points off the curve; the
+// `RawBytesUnchecked` format skips this): *bad_out = number of points of the resident SRS that fail y^2 = x^3 + 3
+int sg_srs_check(uint64_t handle, uint64_t* bad_out) {
+  if (!bad_out) return fail(SG_ERR_INVALID, "sg_srs_check: null argument");
+  LOCKED_CTX();
+  Srs* srs_p = find_srs(handle);
+  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  uint8_t* cnt = nullptr;
+  hipStream_t s = g_ctx->stream;
+  hipError_t e = scratch_for(s, 7, 64, &cnt);
+  uint32_t h[2] = {0, 0};
+  const size_t n = (size_t)1 << srs_p->k;
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = g1_on_curve(b ? srs_p->g_lagrange : srs_p->g, n, reinterpret_cast<uint32_t*>(cnt), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h[b], cnt, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) return hip_fail("sg_srs_check", e);
+  *bad_out = (uint64_t)h[0] + h[1];
+  return SG_OK;
+}
 int sg_srs_free(uint64_t handle) {
   LOCKED_CTX();
   Srs gone;

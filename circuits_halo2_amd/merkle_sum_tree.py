@@ -78,7 +78,12 @@ def parse_csv_to_entries(path: str, n_currencies: int):
     if len(header) - 1 != n_currencies:
         raise ValueError(f"csv has {len(header) - 1} balance columns, N_CURRENCIES = {n_currencies}")
     cryptocurrencies = [tuple(h.split("_")[1:3]) for h in header[1:]]
-    entries = [(r[0], [int(x) for x in r[1:1 + n_currencies]]) for r in body if r]
+    def balance(text: str) -> int:
+        # BigUint::parse_bytes(.., 10): decimal digits only -- no sign, blanks or underscores (csv_parser.rs:45-50)
+        if not text or not text.isascii() or not text.isdigit():
+            raise ValueError("Invalid balance")
+        return int(text)
+    entries = [(r[0], [balance(x) for x in r[1:1 + n_currencies]]) for r in body if r]
     return entries, cryptocurrencies
 
 
@@ -142,7 +147,7 @@ class MerkleSumTree:
         for _, bal in entries:
             if len(bal) != n_currencies:
                 raise ValueError("entry with a wrong number of balances")
-            if any(b >= (1 << (8 * n_bytes)) for b in bal):
+            if any(b < 0 or b >= (1 << (8 * n_bytes)) for b in bal):
                 raise ValueError("balance does not fit N_BYTES")  # range the circuit can prove (mst.rs)
         depth = max(0, (n - 1).bit_length())
         size = 1 << depth
@@ -213,6 +218,8 @@ class MerkleSumTree:
         nc = self.n_currencies
         if len(new_balances) != nc:
             raise ValueError("wrong number of balances")
+        if any(int(b) < 0 for b in new_balances):
+            raise ValueError("Invalid balance")
         index = self.index_of_username(username)
         self.entries[index] = (username, list(new_balances))
         u, b = self._entry_fields(username, new_balances)

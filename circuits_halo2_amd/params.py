@@ -98,6 +98,15 @@ class ParamsKZG:
             self._handle = h.value
         return self._handle
 
+    def check(self) -> None:
+        """what `ParamsKZG::read` checks with SerdeFormat::RawBytes and this mirror's `read` leaves to the first use of
+        the device: every point of g / g_lagrange is on the curve (halo2's `from_raw_bytes`); raises "Failed to read
+        params" otherwise.  `read(..)` itself stays byte-level (`RawBytesUnchecked`) so that it works without a GPU."""
+        bad = C.c_uint64(0)
+        ffi.check(ffi.lib().sg_srs_check(C.c_uint64(self.handle()), C.byref(bad)))
+        if bad.value:
+            raise ValueError(f"Failed to read params: {bad.value} points are not on the curve")
+
     def precompute(self, basis: int | None = None, window_bits: int = 0) -> None:
         """build the fixed-base window table(s) of the resident SRS (sg_srs_precompute): later
         commit / commit_lagrange / commit_batch calls take the fixed-base path (same results).

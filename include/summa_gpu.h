@@ -84,6 +84,10 @@ int sg_g1_sum_affine(const uint8_t* points, size_t n, uint8_t out_affine[64]);
 /* SRS cache: keeps ParamsKZG's g[] / g_lagrange[] resident in HBM across proofs
  * (the reference re-reads the file per Snapshot: backend/src/apis/round.rs:136-145). */
 int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint64_t* handle_out);
+/* The validation `ParamsKZG::read` performs with SerdeFormat::RawBytes (points off the curve are rejected; the
+ * RawBytesUnchecked format skips it): *bad_out = number of points of the resident SRS (g and g_lagrange) that are neither on
+ * y^2 = x^3 + 3 nor the identity. */
+int sg_srs_check(uint64_t handle, uint64_t* bad_out);
 int sg_srs_free(uint64_t handle);
 /* ParamsKZG::commit (basis = 0, monomial g[]) / commit_lagrange (basis = 1): n <= 2^k scalars */
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]);

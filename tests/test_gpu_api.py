@@ -199,3 +199,22 @@ def test_prove_from_csv_compiled_program(tmp_path, kat):
     assert H(cd2["vk_digest"]) != H(tr["vk_digest"]) and SV.verify(bytes.fromhex(cd2["proof"][2:]), [H(v) for v in cd2["public_inputs"]], vk2)
     assert subprocess.run([exe, SRS, CSV, "16", str(K), out], capture_output=True, text=True).returncode == 1     # user index out of bounds
     assert subprocess.run([exe, SRS, CSV, "0", "12", out], capture_output=True, text=True).returncode == 1        # k is too large for the given params
+
+
+def test_params_read_rejects_points_off_the_curve(tmp_path):
+    """ParamsKZG::read with SerdeFormat::RawBytes rejects points that are not on the curve; here the check runs on the
+    device (sg_srs_check) when generate_setup_artifacts loads a file"""
+    _gpu()
+    from circuits_halo2_amd.api import MstInclusionCircuit, generate_setup_artifacts
+    from circuits_halo2_amd.params import ParamsKZG
+    raw = bytearray(open(SRS, "rb").read())
+    good = ParamsKZG.read(bytes(raw))
+    good.check()
+    good.free()
+    for offset in (4 + 64 * 100 + 3, 4 + 64 * 2048 + 64 * 777 + 40):       # one byte of g[100].x, one of g_lagrange[777].y
+        bad = bytearray(raw)
+        bad[offset] ^= 1
+        path = tmp_path / "hermez-raw-11"
+        path.write_bytes(bytes(bad))
+        with pytest.raises(ValueError, match="Failed to read params"):
+            generate_setup_artifacts(K, str(path), MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES))

@@ -82,3 +82,20 @@ def test_csv_parsing_and_currency_count():
     assert len(ents) == 16 and ents[0] == ("dxGaEAii", [11888, 41163]) and cur == [("ETH", "ETH"), ("USDT", "ETH")]
     with pytest.raises(ValueError):  # BASELINE config 1's N_CURRENCIES = 1 does not fit this file
         parse_csv_to_entries(os.path.join(GOLDEN, "entry_16.csv"), 1)
+
+
+def test_csv_balances_are_decimal_digits_only(tmp_path):
+    """utils/csv_parser.rs parses balances with BigUint::parse_bytes(.., 10): signs, blanks and digit separators are
+    "Invalid balance" (Python's int() would accept them and a negative balance would wrap mod r)"""
+    from circuits_halo2_amd.merkle_sum_tree import parse_csv_to_entries
+    good = tmp_path / "good.csv"
+    good.write_text("username,balance_ETH_ETH,balance_USDT_ETH\nalice,11888,41163\nbob,0,7\n")
+    entries, crypto = parse_csv_to_entries(str(good), 2)
+    assert entries == [("alice", [11888, 41163]), ("bob", [0, 7])] and crypto == [("ETH", "ETH"), ("USDT", "ETH")]
+    for bad in ("-5", "+3", "1_000", " 7", "7 ", "", "0x10", "١٢"):
+        f = tmp_path / "bad.csv"
+        f.write_text(f"username,balance_ETH_ETH,balance_USDT_ETH\nalice,{bad},1\n")
+        with pytest.raises(ValueError, match="Invalid balance"):
+            parse_csv_to_entries(str(f), 2)
+    with pytest.raises(ValueError):
+        parse_csv_to_entries(str(good), 1)          # column count != N_CURRENCIES (the reference panics there)
