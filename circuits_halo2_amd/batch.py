@@ -54,7 +54,7 @@ def _bcast_bytes(buf: np.ndarray | None, src: int, device: str) -> np.ndarray:
     d = _dist()
     size = torch.tensor([0 if buf is None else int(buf.size)], dtype=torch.int64, device=device)
     d.broadcast(size, src)
-    t = torch.from_numpy(np.ascontiguousarray(buf)).to(device) if buf is not None else \
+    t = torch.from_numpy(np.array(buf, dtype=np.uint8, copy=True)).to(device) if buf is not None else \
         torch.empty(int(size.item()), dtype=torch.uint8, device=device)
     if int(size.item()):
         d.broadcast(t, src)

@@ -178,3 +178,26 @@ def test_proofs_from_the_device_witness_verify():
             api.MstInclusionCircuit.init_from_tree(tree, size)
     finally:
         params.free()
+
+
+def test_bench_starts_its_own_ranks_two_rank_rehearsal():
+    """`python bench.py --gpus 2` launched bare: the parent starts the two ranks itself (torch.distributed.run child, before
+    it touches the GPU), rank 0 prints the one JSON line with n_gpus = 2.  On this one-GPU box the ranks rehearse with the
+    gloo backend and share the GPU (`--backend gloo`); everything else -- point-sharded MSM with the all_gather of partials,
+    setup broadcast, proofs dealt to ranks and kept in flight, max-over-ranks timing -- is the N > 1 code path"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--batch-proofs", "3", "--no-cpu", "--log-n", "20"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["sharding"].startswith("point-sharded") and "gloo" in line["config"]["backend"]
+    b = line["batch_k17"]
+    assert b["n_gpus"] == 2 and b["verified_sample"] is True
+    assert all(v["proofs"] == 6 and v["errors"] == 0 for v in b["by_in_flight"].values())     # 3 per rank, both ranks counted
