@@ -158,8 +158,8 @@ def _device_column(ints, n: int):
 def keygen(params: ParamsKZG, circuit: MstInclusionCircuit, vk_transcript_repr: int | None = None):
     """`keygen_vk` + `keygen_pk` [REF utils.rs:75-76]: synthesize the (empty) circuit for its fixed columns and
     permutation, commit to them (17 MSMs) and transform them into the three bases the prover reads (all on the device).
-    `vk_transcript_repr`: halo2's own digest of the verifying key where it is known (prover.verifying_key_digest
-    explains why it is not derived here); default: this build's digest."""
+    The key's digest is halo2's `transcript_repr`, derived (vk_repr.py); `vk_transcript_repr` overrides it for a key
+    whose constraint system was built elsewhere."""
     k = params.k
     asg = circuit.synthesize(k)
     n = 1 << k

@@ -185,21 +185,14 @@ class Blake2bWrite:
 
 
 def verifying_key_digest(k: int, n_currencies: int, fixed_comms, permutation_comms) -> int:
-    """The scalar `vk.hash_into` feeds the transcript (`VerifyingKey::transcript_repr`).  Upstream derives it as
-    Blake2b-512 (personalised "Halo2-Verify-Key") of  len(s) || s  with s = the `{:?}` rendering of the pinned
-    verification key, reduced from 64 bytes mod r.  The construction here is the same; the rendered string is this
-    repository's own (domain size, circuit shape, the commitments): halo2's Debug output of the whole constraint
-    system lives in the un-vendored crate and is not reproduced, so the value differs from a Rust-built key's.  For
-    the one key whose halo2 value the reference holds -- MstInclusionCircuit<4,2,8>, k = 11, its SRS: `vk_digest` of
-    contracts/src/InclusionVerifier.sol:217 -- callers inject that value (tests/golden/kat.json)."""
-    import hashlib
-    pt = lambda p: "(0x%064x, 0x%064x)" % p
-    s = ("PinnedVerificationKey { scalar_modulus: \"0x%064x\", k: %d, circuit: MstInclusion { n_currencies: %d }, "
-         "fixed_commitments: [%s], permutation: VerifyingKey { commitments: [%s] } }"
-         % (R, k, n_currencies, ", ".join(pt(p) for p in fixed_comms), ", ".join(pt(p) for p in permutation_comms)))
-    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
-    h.update(len(s).to_bytes(8, "little") + s.encode())
-    return int.from_bytes(h.digest(), "little") % R
+    """The scalar `vk.hash_into` feeds the transcript: halo2's `VerifyingKey::transcript_repr`, i.e. Blake2b-512
+    (personalised "Halo2-Verify-Key") of  len(s) || s  with s = the `{:?}` text of the pinned verification key, reduced
+    from 64 bytes mod r.  `vk_repr` rebuilds that text -- the constraint system as `MstInclusionConfig::configure`
+    leaves it, expression trees included -- so the value equals a Rust-built key's: for MstInclusionCircuit<4,2,8>,
+    k = 11 and the reference's SRS it is the `vk_digest` constant of contracts/src/InclusionVerifier.sol:217
+    (tests/test_api_cpu.py pins that)."""
+    from . import vk_repr
+    return vk_repr.transcript_repr(k, n_currencies, fixed_comms, permutation_comms)
 
 
 class ProvingKey:

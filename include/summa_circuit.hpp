@@ -466,8 +466,148 @@ struct FloorPlan {
 };
 
 // ------------------------------------------------------------------ verifying-key digest, small host helpers
-// circuits_halo2_amd/prover.py::verifying_key_digest: Blake2b-512("Halo2-Verify-Key") of len || rendering, mod r, where the
-// rendering is this repository's own (halo2's Debug output of the constraint system is not reproduced).
+// halo2's `VerifyingKey::transcript_repr`: Blake2b-512("Halo2-Verify-Key") of len || `{:?}` text of the pinned key, reduced
+// wide mod r.  The text spells the constraint system out -- every gate as an expression tree, the query lists in the order
+// `MstInclusionConfig::configure` [REF zk_prover/src/circuits/merkle_sum_tree.rs:141-207] made them -- so it is rebuilt by
+// replaying configure with halo2's operator rules (a - b = Sum(a, Negated(b)), e * scalar = Scaled).  Twin of
+// circuits_halo2_amd/vk_repr.py, which the reference's `vk_digest` (contracts/src/InclusionVerifier.sol:217) pins.
+struct PinnedText {
+  std::vector<std::pair<uint32_t, int32_t>> queries[3];   // advice, fixed, instance: (column, rotation) in first-use order
+  std::vector<std::pair<int, uint32_t>> permutation;      // (kind, column)
+  std::vector<std::string> gates;
+  enum { ADV = 0, FIX = 1, INST = 2 };
+  static const char* kind_name(int kind) { return kind == ADV ? "Advice" : kind == FIX ? "Fixed" : "Instance"; }
+  static std::string hex(const Fr& v) {
+    uint8_t be[32];
+    v.to_be_bytes(be);
+    static const char* d = "0123456789abcdef";
+    std::string s = "0x";
+    for (int i = 0; i < 32; i++) {
+      s += d[be[i] >> 4];
+      s += d[be[i] & 15];
+    }
+    return s;
+  }
+  std::string q(int kind, uint32_t col, int32_t rot = 0) {
+    auto& list = queries[kind];
+    size_t i = 0;
+    while (i < list.size() && list[i] != std::make_pair(col, rot)) i++;
+    if (i == list.size()) list.emplace_back(col, rot);
+    return std::string(kind_name(kind)) + " { query_index: " + std::to_string(i) + ", column_index: " + std::to_string(col) +
+           ", rotation: Rotation(" + std::to_string(rot) + ") }";
+  }
+  void enable_equality(int kind, uint32_t col) {
+    q(kind, col, 0);
+    for (auto& c : permutation)
+      if (c.first == kind && c.second == col) return;
+    permutation.emplace_back(kind, col);
+  }
+  static std::string neg(const std::string& a) { return "Negated(" + a + ")"; }
+  static std::string sum(const std::string& a, const std::string& b) { return "Sum(" + a + ", " + b + ")"; }
+  static std::string sub(const std::string& a, const std::string& b) { return sum(a, neg(b)); }
+  static std::string mul(const std::string& a, const std::string& b) { return "Product(" + a + ", " + b + ")"; }
+  static std::string scaled(const std::string& a, const Fr& c) { return "Scaled(" + a + ", " + hex(c) + ")"; }
+  static std::string cst(uint64_t v) { return "Constant(" + hex(Fr::from_u64(v)) + ")"; }
+  static std::string pow5(const std::string& v) {
+    const std::string v2 = mul(v, v);
+    return mul(mul(v2, v2), v);
+  }
+  static std::string sel(int i) { return "@" + std::to_string(i) + "@"; }   // replaced by compress()
+
+  // halo2_gadgets' Pow5Chip::configure, WIDTH 2 / RATE 1, on state = a0 a1, partial_sbox = a2, rc_a = f0 f1, rc_b = f2 f3
+  void pow5_chip(int s_full, int s_partial, int s_pad) {
+    const Poseidon& P = poseidon();
+    for (uint32_t c = 0; c < 2; c++) enable_equality(ADV, c);
+    for (uint32_t c = 2; c < 4; c++) enable_equality(FIX, c);
+    for (uint32_t nxt = 0; nxt < 2; nxt++) {   // "full round"
+      const std::string state_next = q(ADV, nxt, 1);
+      std::string expr;
+      for (uint32_t idx = 0; idx < 2; idx++) {
+        const std::string term = scaled(pow5(sum(q(ADV, idx), q(FIX, idx))), P.mds[nxt][idx]);
+        expr = idx ? sum(expr, term) : term;
+      }
+      gates.push_back(mul(sel(s_full), sub(expr, state_next)));
+    }
+    const std::string cur_0 = q(ADV, 0), mid_0 = q(ADV, 2), rc_a0 = q(FIX, 0), rc_b0 = q(FIX, 2);   // "partial rounds"
+    auto mid = [&](uint32_t idx) { return sum(scaled(mid_0, P.mds[idx][0]), scaled(sum(q(ADV, 1), q(FIX, 1)), P.mds[idx][1])); };
+    auto next = [&](uint32_t idx) { return sum(scaled(q(ADV, 0, 1), P.mds_inv[idx][0]), scaled(q(ADV, 1, 1), P.mds_inv[idx][1])); };
+    gates.push_back(mul(sel(s_partial), sub(pow5(sum(cur_0, rc_a0)), mid_0)));
+    gates.push_back(mul(sel(s_partial), sub(pow5(sum(mid(0), rc_b0)), next(0))));
+    {
+      const std::string rc_b1 = q(FIX, 3);
+      const std::string m = mid(1);
+      gates.push_back(mul(sel(s_partial), sub(sum(m, rc_b1), next(1))));
+    }
+    const std::string initial_rate = q(ADV, 1, -1), output_rate = q(ADV, 1, 1);                       // "pad-and-add"
+    const std::string a_prev = q(ADV, 0, -1), a_cur = q(ADV, 0), a_next = q(ADV, 0, 1);
+    gates.push_back(mul(sel(s_pad), sub(sum(a_prev, a_cur), a_next)));
+    gates.push_back(mul(sel(s_pad), sub(initial_rate, output_rate)));
+  }
+
+  // the text of PinnedConstraintSystem after keygen's selector compression
+  std::string build(uint32_t n_currencies) {
+    // selectors in creation order: 0 swap, 1 sum, 2 lookup (complex), 3-5 entry hasher, 6-8 middle hasher
+    enable_equality(FIX, 2);                                   // enable_constant(fixed[2])
+    pow5_chip(3, 4, 5);
+    pow5_chip(6, 7, 8);
+    for (uint32_t c = 0; c < 3; c++) enable_equality(ADV, c);
+    {   // MerkleSumTreeChip::configure [REF chips/merkle_sum_tree.rs:39-95]
+      const std::string swap = q(ADV, 2);
+      gates.push_back(mul(mul(sel(0), swap), sub(cst(1), swap)));
+      const std::string l = q(ADV, 0), r = q(ADV, 1), ln = q(ADV, 0, 1), rn = q(ADV, 1, 1);
+      gates.push_back(mul(sel(0), sub(sum(mul(sub(r, l), swap), l), ln)));
+      gates.push_back(mul(sel(0), sub(sum(mul(sub(l, r), swap), r), rn)));
+      for (uint32_t c = 0; c < n_currencies; c++) gates.push_back(mul(sel(1), sub(sum(q(ADV, 0), q(ADV, 1)), q(ADV, 2))));
+    }
+    // RangeCheckChip::configure [REF chips/range/range_check.rs:28-56] on advice[0], table f4
+    const std::string z_cur = q(ADV, 0), z_next = q(ADV, 0, 1), table = q(FIX, 4);
+    std::string lookup_input = mul(sel(2), sub(z_cur, mul(z_next, cst(256))));
+    enable_equality(INST, 0);
+    // compress_selectors: the complex selector gets f5; swap, sum and the two pad selectors (gate degree <= 3) share f6 as
+    // values 1..4; the four degree-6 Poseidon selectors get f7..f10 (the floor plan above writes exactly these columns)
+    std::string rep[9];
+    rep[2] = q(FIX, 5);
+    const std::string q6 = q(FIX, 6);
+    const int combo[4] = {0, 1, 5, 8};
+    for (int m = 0; m < 4; m++) {
+      std::string e = q6;
+      for (uint64_t root = 1; root <= 4; root++)
+        if (root != (uint64_t)m + 1) e = mul(e, sub(cst(root), q6));
+      rep[combo[m]] = e;
+    }
+    rep[3] = q(FIX, 7);
+    rep[4] = q(FIX, 8);
+    rep[6] = q(FIX, 9);
+    rep[7] = q(FIX, 10);
+    auto substitute = [&](std::string& t) {
+      for (int i = 0; i < 9; i++) {
+        const std::string key = sel(i);
+        for (size_t at = t.find(key); at != std::string::npos; at = t.find(key, at + rep[i].size())) t.replace(at, key.size(), rep[i]);
+      }
+    };
+    auto column = [](int kind, uint32_t i) { return "Column { index: " + std::to_string(i) + ", column_type: " + kind_name(kind) + " }"; };
+    std::string out = "PinnedConstraintSystem { num_fixed_columns: 11, num_advice_columns: 3, num_instance_columns: 1, num_selectors: 9, gates: [";
+    for (size_t i = 0; i < gates.size(); i++) {
+      substitute(gates[i]);
+      out += (i ? ", " : "") + gates[i];
+    }
+    out += "]";
+    const std::pair<const char*, int> lists[3] = {{"advice_queries", ADV}, {"instance_queries", INST}, {"fixed_queries", FIX}};
+    for (auto& l : lists) {
+      out += std::string(", ") + l.first + ": [";
+      for (size_t i = 0; i < queries[l.second].size(); i++)
+        out += std::string(i ? ", " : "") + "(" + column(l.second, queries[l.second][i].first) + ", Rotation(" + std::to_string(queries[l.second][i].second) + "))";
+      out += "]";
+    }
+    out += ", permutation: Argument { columns: [";
+    for (size_t i = 0; i < permutation.size(); i++) out += (i ? ", " : "") + column(permutation[i].first, permutation[i].second);
+    substitute(lookup_input);
+    out += "] }, lookups: [Argument { input_expressions: [" + lookup_input + "], table_expressions: [" + table + "] }]";
+    out += ", constants: [" + column(FIX, 2) + "], minimum_degree: None }";
+    return out;
+  }
+};
+
 // comms: 17 commitments as the ABI returns them (64-byte Montgomery affine), fixed first.  Returns 32 bytes big-endian.
 inline std::array<uint8_t, 32> verifying_key_digest(uint32_t k, uint32_t n_currencies, const std::vector<std::array<uint8_t, 64>>& comms) {
   auto hex_be = [](const uint8_t mont[32]) {
@@ -483,12 +623,24 @@ inline std::array<uint8_t, 32> verifying_key_digest(uint32_t k, uint32_t n_curre
   };
   auto pts = [&](size_t lo, size_t hi) {
     std::string s;
-    for (size_t i = lo; i < hi; i++) s += (i > lo ? ", (" : "(") + hex_be(comms[i].data()) + ", " + hex_be(comms[i].data() + 32) + ")";
+    for (size_t i = lo; i < hi; i++) {
+      bool zero = true;
+      for (uint8_t b : comms[i]) zero = zero && b == 0;
+      s += (i > lo ? ", " : "") + (zero ? std::string("Infinity") : "(" + hex_be(comms[i].data()) + ", " + hex_be(comms[i].data() + 32) + ")");
+    }
     return s;
   };
-  const std::string r = "PinnedVerificationKey { scalar_modulus: \"0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001\", k: " +
-                        std::to_string(k) + ", circuit: MstInclusion { n_currencies: " + std::to_string(n_currencies) +
-                        " }, fixed_commitments: [" + pts(0, NUM_FIXED) + "], permutation: VerifyingKey { commitments: [" + pts(NUM_FIXED, comms.size()) + "] } }";
+  // generator of the 2^k domain: Fr::ROOT_OF_UNITY (order 2^28) squared down (EvaluationDomain::new)
+  static const uint8_t root_2_28[32] = {0x03, 0xdd, 0xb9, 0xf5, 0x16, 0x6d, 0x18, 0xb7, 0x98, 0x86, 0x5e, 0xa9, 0x3d, 0xd3, 0x1f, 0x74,
+                                        0x32, 0x15, 0xcf, 0x6d, 0xd3, 0x93, 0x29, 0xc8, 0xd3, 0x4f, 0x1e, 0xd9, 0x60, 0xc3, 0x7c, 0x9c};
+  if (k > 28) throw std::invalid_argument("k out of range");
+  Fr omega = Fr::from_be_bytes_reduced(root_2_28);
+  for (uint32_t i = k; i < 28; i++) omega = omega * omega;
+  const std::string r = "PinnedVerificationKey { base_modulus: \"0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47\", "
+                        "scalar_modulus: \"0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001\", "
+                        "domain: PinnedEvaluationDomain { k: " + std::to_string(k) + ", extended_k: " + std::to_string(k + 3) +
+                        ", omega: " + PinnedText::hex(omega) + " }, cs: " + PinnedText().build(n_currencies) +
+                        ", fixed_commitments: [" + pts(0, NUM_FIXED) + "], permutation: VerifyingKey { commitments: [" + pts(NUM_FIXED, comms.size()) + "] } }";
   prover::Blake2b h(64, "Halo2-Verify-Key");
   const uint64_t len = r.size();
   h.update(reinterpret_cast<const uint8_t*>(&len), 8);

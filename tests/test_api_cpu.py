@@ -205,6 +205,44 @@ def test_empty_and_real_circuits_share_fixed_columns_and_permutation(kat):
     assert len(real["instances"]) == 4
 
 
+def test_vk_transcript_repr_is_the_digest_baked_into_the_reference_verifier(kat):
+    """halo2's `VerifyingKey::transcript_repr` (Blake2b of the pinned key's Debug text) rebuilt from a replay of
+    `MstInclusionConfig::configure`: for k = 11 and the reference's commitments it must be the `vk_digest` constant of
+    contracts/src/InclusionVerifier.sol:217 (kat.json)."""
+    from circuits_halo2_amd import prover as P, vk_repr as V
+    fixed = [(H(a), H(b)) for a, b in kat["fixed_comms"]]
+    perm = [(H(a), H(b)) for a, b in kat["permutation_comms"]]
+    assert P.verifying_key_digest(H(kat["k"]), 2, fixed, perm) == H(kat["vk_digest"])
+    cs, text = V.constraint_system_text(2)
+    # the query lists are the evaluation order of the reference's verifier (InclusionVerifier.sol: a_0, a_1, a_0 next,
+    # a_1 next, a_2, a_1 prev, a_0 prev; f_2, f_3, f_0, f_1, f_4 .. f_10)
+    assert cs.queries["Advice"] == [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (1, -1), (0, -1)]
+    assert [c for c, _ in cs.queries["Fixed"]] == [2, 3, 0, 1, 4, 5, 6, 7, 8, 9, 10]
+    assert cs.degree() == 6 and len(cs.gates) == 19 and cs.num_fixed == 11
+    assert text.count("Scaled(") == 2 * 20 and "Selector" not in text   # per chip: 4 (full rounds) + 5 * 2 + 2 (s-box of the mixed state, written out five times) + 4
+    # any change of the text changes the digest: one more currency = one more sum gate
+    assert P.verifying_key_digest(H(kat["k"]), 3, fixed, perm) != H(kat["vk_digest"])
+    assert len(V.constraint_system_text(3)[0].gates) == 20
+
+
+def test_selector_compression_replay_gives_the_floor_plans_selector_columns():
+    """`compress_selectors` replayed on the activations of the real floor plan assigns the same fixed columns and
+    values as the floor plan's f5 .. f10 (lookup selector alone; swap / sum / pad / pad combined as 1 .. 4; the four
+    degree-6 Poseidon selectors alone)"""
+    from circuits_halo2_amd import api, vk_repr as V
+    fixed = api.MstInclusionCircuit.init_empty(4, 2, 8).synthesize(11)["fixed"]
+    rows = lambda col, value: {r for r, v in enumerate(fixed[col]) if v == value}
+    # selector order of configure: swap, sum, lookup (complex), chip 1 full / partial / pad, chip 2 full / partial / pad
+    act = [rows(6, 1), rows(6, 2), rows(5, 1), rows(7, 1), rows(8, 1), rows(6, 3), rows(9, 1), rows(10, 1), rows(6, 4)]
+    assert all(act)
+    cs = V.configure(2)
+    cols = cs.compress_selectors(act)
+    assert sorted(cols) == [5, 6, 7, 8, 9, 10]
+    for c, values in cols.items():
+        assert values == {r: v for r, v in enumerate(fixed[c]) if v}
+    assert cs.pinned_text() == V.constraint_system_text(2)[1]
+
+
 def test_init_asserts_the_reference_lengths():
     from circuits_halo2_amd import api
     z32 = np.zeros(32, dtype=np.uint8)

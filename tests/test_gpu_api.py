@@ -117,10 +117,10 @@ def test_gen_proof_solidity_calldata_under_the_reference_srs_and_key(kat):
     from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
     from oracle import summa_verifier as SV
     want = [(H(a), H(b)) for a, b in kat["fixed_comms"] + kat["permutation_comms"]]
-    params, pk, vk = generate_setup_artifacts(K, SRS, MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES),
-                                              vk_transcript_repr=H(kat["vk_digest"]))
+    params, pk, vk = generate_setup_artifacts(K, SRS, MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES))
     try:
         assert vk.fixed_comms + vk.permutation_comms == want
+        assert pk.vk_digest == H(kat["vk_digest"])     # halo2's transcript_repr, derived (vk_repr), not passed in
         tree = MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES)
         circuit = MstInclusionCircuit.init(tree.generate_proof(0), LEVELS)
         proof, public_inputs = gen_proof_solidity_calldata(params, pk, circuit)
