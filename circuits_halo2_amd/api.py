@@ -188,6 +188,7 @@ def generate_setup_artifacts(k: int, params_path: str | None, circuit: MstInclus
     else:
         tau = int.from_bytes(os.urandom(64), "little") % R      # ParamsKZG::setup(k, OsRng)
         params = ParamsKZG.setup(k, ints_to_fr([tau]))
+    params.precompute()          # the resident SRS's window tables (fixed-base commitments; params.py)
     pk, vk = keygen(params, circuit, vk_transcript_repr)
     return params, pk, vk
 

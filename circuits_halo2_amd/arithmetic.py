@@ -254,6 +254,22 @@ def kate_division_batch(polys, points):
     return outs
 
 
+def count_noncanonical(cols):
+    """device u32 tensor (1 element) = number of elements of the equal-length device columns whose word value is >= r;
+    asynchronous on the current stream (read it at the next point where the host waits anyway)"""
+    import torch
+    m = len(cols)
+    if m > 16:
+        raise ValueError("count_noncanonical: at most 16 columns per call")
+    n = cols[0].numel() // 32 if m else 0
+    if any(c.numel() != 32 * n for c in cols):
+        raise ValueError("count_noncanonical: equal lengths expected")
+    count = torch.empty(1, dtype=torch.int32, device="cuda")
+    pc = (C.c_void_p * max(m, 1))(*[c.data_ptr() for c in cols])
+    ffi.check(ffi.lib().sg_fr_count_noncanonical_dev(pc, C.c_uint32(m), C.c_size_t(n), ffi.dev_ptr(count), ffi.current_stream_ptr()))
+    return count
+
+
 def lincomb(polys, coeffs):
     """sum_j coeffs[j] * polys[j] over equal-length device tensors; coeffs: m x 32 bytes"""
     import torch

@@ -107,6 +107,7 @@ def import_setup(setup):
     from . import prover as P
     from .params import ParamsKZG
     params = ParamsKZG(setup["k"], setup["g"], setup["g_lagrange"], bytes(setup["g2"]), bytes(setup["s_g2"]))
+    params.precompute()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     levels, nc, nb = setup["shape"]
     pk = P.ProvingKey(params, setup["k"], [dev(c) for c in setup["fixed"]], [dev(c) for c in setup["sigma"]], nc)

@@ -82,6 +82,8 @@ static constexpr size_t MAX_FUSED = 32;
 struct BatchPtrs {  // inputs of a fused batch (kernel argument)
   const fp_words* scalars[MAX_FUSED];
   const g1_affine_mem* bases[MAX_FUSED];
+  uint32_t diff_mask;  // bit m: MSM m is taken in difference form -- its digits are those of s[i] - s[i+1] (s[n] = 0) and
+                       // its bases the inclusive prefix sums of the basis (see g1_prefix_sums)
 };
 
 class MsmEngine {
@@ -109,7 +111,7 @@ class MsmEngine {
   // the same over a precomputed window table (n <= tab.n): all M MSMs use the table's bases
   hipError_t enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
                                  hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
-                                 const g1_affine_mem* const* tables = nullptr);
+                                 const g1_affine_mem* const* tables = nullptr, uint32_t diff_mask = 0);
   size_t max_fused_fixed(const FixedTable& tab, size_t n) const;
   hipError_t enqueue_back();
   hipError_t finish();
@@ -131,6 +133,7 @@ class MsmEngine {
   };
   Job job_;
   const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs
+  uint32_t diff_mask_ = 0;             // likewise
   hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
   hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;
@@ -151,6 +154,10 @@ class MsmEngine {
 hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_n, const words8& omega,
                   const words8* scale, xyzz29_mem* d_work, hipStream_t stream);
 hipError_t fixed_base_mul(const fp_words* d_scalars, size_t n, g1_affine_mem* d_out, hipStream_t stream);
+// out[i] = in[0] + ... + in[i], affine (the basis of difference-form commitments: sum_i s_i P_i = sum_i (s_i - s_{i+1}) Q_i with
+// Q the inclusive prefix sums and s_n = 0 -- a column that is constant over long runs becomes a sparse MSM).  Set-up
+// time only; allocates and frees its own work space.  d_out may not alias d_in.
+hipError_t g1_prefix_sums(const g1_affine_mem* d_in, size_t n, g1_affine_mem* d_out, hipStream_t stream);
 // *d_bad = number of points that are neither on y^2 = x^3 + 3 nor the identity
 hipError_t g1_on_curve(const g1_affine_mem* d_points, size_t n, uint32_t* d_bad, hipStream_t stream);
 

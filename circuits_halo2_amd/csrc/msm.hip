@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "host_curve.h"
 
@@ -54,7 +55,12 @@ __global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __r
     // canonical scalar = s~ * 2^-256 = s~ * 2^5 * 2^-261
     f29 k = f29_zero();
     k.l[0] = 32;
-    f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(scalars + i), k)), s.l);
+    f29 v = f29_load_r256<Fr29>(scalars + i);                  // any 256-bit word value: bound < 6
+    if ((bp.diff_mask >> blockIdx.y) & 1u) {
+      // difference form: the scalar of row i is s[i] - s[i+1] (s[n] = 0), against the prefix-summed basis
+      if (i + 1 < n) v = f29_sub<Fr29, 2>(v, f29_load_r256<Fr29>(scalars + i + 1));   // + 8r: bound < 14
+    }
+    f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(v, k)), s.l);
   }
   const uint32_t W = wp.W;
   // s += K (K < 2^254, s < 2^254: no overflow out of 256 bits)
@@ -939,6 +945,87 @@ hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ prefix sums of a basis (difference-form commits)
+// Blocked scan over points: every thread runs through PFX_CHUNK consecutive elements (inclusive running sums in place,
+// chunk total to the next level), the totals are scanned the same way recursively, then the offsets are added on the
+// way down; the last step also normalises to affine.  Once per SRS.
+static constexpr uint32_t PFX_CHUNK = 32;
+template <bool AFFINE>
+__global__ void __launch_bounds__(128) g1_prefix_chunks(const g1_affine_mem* __restrict__ in, xyzz29_mem* __restrict__ run, uint32_t n,
+                                                       xyzz29_mem* __restrict__ totals) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t first = t * PFX_CHUNK;
+  if (first >= n) return;
+  const uint32_t last = min(n, first + PFX_CHUNK);
+  xyzz29 acc = xyzz29_identity();
+  for (uint32_t i = first; i < last; i++) {
+    if (AFFINE) {
+      g1_affine_mem raw = in[i];
+      xyzz29_madd(acc, affine29_load(&raw));
+    } else {
+      xyzz29_add(acc, xyzz29_load(run + i));
+    }
+    xyzz29_store(run + i, acc);
+  }
+  if (totals) xyzz29_store(totals + t, acc);
+}
+// run[i] += upper[i / PFX_CHUNK - 1]  (upper = inclusive prefix sums of the chunk totals)
+__global__ void __launch_bounds__(128) g1_prefix_apply(xyzz29_mem* __restrict__ run, uint32_t n, const xyzz29_mem* __restrict__ upper) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i < PFX_CHUNK) return;
+  xyzz29 v = xyzz29_load(run + i);
+  xyzz29_add(v, xyzz29_load(upper + i / PFX_CHUNK - 1));
+  xyzz29_store(run + i, v);
+}
+__global__ void __launch_bounds__(128) g1_prefix_store(const xyzz29_mem* __restrict__ run, uint32_t n, const xyzz29_mem* __restrict__ upper,
+                                                      g1_affine_mem* __restrict__ out) {
+  typedef Fq29 P;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz29 p = xyzz29_load(run + i);
+  if (upper && i >= PFX_CHUNK) xyzz29_add(p, xyzz29_load(upper + i / PFX_CHUNK - 1));
+  uint32_t ow[16];
+  if (xyzz29_is_identity(p)) {
+    for (int k = 0; k < 16; k++) ow[k] = 0;
+  } else {
+    f29 iz = f29_inv<P>(p.zzz);
+    f29 t = f29_mul<P>(p.zz, iz);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(p.x, f29_sqr<P>(t)), P::r256), ow);
+    f29_to_words(f29_reduce_with<P>(f29_mul<P>(p.y, iz), P::r256), ow + 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[i].q[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
+}
+hipError_t g1_prefix_sums(const g1_affine_mem* d_in, size_t n, g1_affine_mem* d_out, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  if (n >= (1ull << 31) || d_in == d_out) return hipErrorInvalidValue;
+  // level sizes: n, ceil(n / 32), ... down to one chunk
+  std::vector<size_t> size{n};
+  while (size.back() > PFX_CHUNK) size.push_back((size.back() + PFX_CHUNK - 1) / PFX_CHUNK);
+  size_t total = 0;
+  for (size_t v : size) total += v;
+  xyzz29_mem* work = nullptr;
+  hipError_t e = hipMalloc(&work, total * sizeof(xyzz29_mem));
+  if (e != hipSuccess) return e;
+  std::vector<xyzz29_mem*> lvl(size.size());
+  lvl[0] = work;
+  for (size_t l = 1; l < size.size(); l++) lvl[l] = lvl[l - 1] + size[l - 1];
+  auto grid = [](size_t threads) { return (unsigned)((threads + 127) / 128); };
+  for (size_t l = 0; l < size.size(); l++) {   // up: running sums per chunk, totals to the next level
+    const size_t chunks = (size[l] + PFX_CHUNK - 1) / PFX_CHUNK;
+    xyzz29_mem* totals = l + 1 < size.size() ? lvl[l + 1] : nullptr;
+    if (l == 0) g1_prefix_chunks<true><<<grid(chunks), 128, 0, stream>>>(d_in, lvl[0], (uint32_t)size[0], totals);
+    else g1_prefix_chunks<false><<<grid(chunks), 128, 0, stream>>>(nullptr, lvl[l], (uint32_t)size[l], totals);
+  }
+  for (size_t l = size.size() - 1; l-- > 1;)   // down: levels size-2 .. 1 become global prefix sums
+    g1_prefix_apply<<<grid(size[l]), 128, 0, stream>>>(lvl[l], (uint32_t)size[l], lvl[l + 1]);
+  g1_prefix_store<<<grid(n), 128, 0, stream>>>(lvl[0], (uint32_t)n, size.size() > 1 ? lvl[1] : nullptr, d_out);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(work);
+  return e;
+}
+
 // ------------------------------------------------------------------ fixed-base window table
 // next[i] = 2^doublings * prev[i], affine (one inversion per point: this runs once per SRS)
 __global__ void __launch_bounds__(128) msm_table_step(const g1_affine_mem* __restrict__ prev, uint32_t n,
@@ -1141,14 +1228,17 @@ hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c
 
 hipError_t MsmEngine::enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
                                           hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
-                                          const g1_affine_mem* const* tables) {
+                                          const g1_affine_mem* const* tables, uint32_t diff_mask) {
   if (n > tab.n || !tab.table) return hipErrorInvalidValue;
+  if (diff_mask && n != tab.n) return hipErrorInvalidValue;   // s[n] = 0 closes the telescoping sum only at full length
   const g1_affine_mem* bs[MAX_FUSED];
   // `tables` (optional): one window table per MSM, all built with tab's plan (same c and n), e.g. g and g_lagrange
   for (size_t m = 0; m < M && m < MAX_FUSED; m++) bs[m] = tables ? tables[m] : tab.table;
   fixed_ = &tab;
+  diff_mask_ = diff_mask;
   hipError_t e = enqueue_front_fused(d_scalars, bs, M, n, stream, out_affine, tm);
   fixed_ = nullptr;
+  diff_mask_ = 0;
   return e;
 }
 size_t MsmEngine::max_fused_fixed(const FixedTable& tab, size_t n) const {
@@ -1183,6 +1273,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     j.bp.scalars[m] = d_scalars[m];
     j.bp.bases[m] = d_bases[m];
   }
+  j.bp.diff_mask = diff_mask_;
   // fixed-base mode: the job's windows all land in one bucket set per MSM (see msm_scatter)
   j.fixed = fixed_ != nullptr;
   j.n_tab = j.fixed ? (uint32_t)fixed_->n : 0;

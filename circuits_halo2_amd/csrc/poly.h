@@ -42,6 +42,8 @@ hipError_t poly_kate_division_batch(const fp_words* const* d_a, size_t n, const 
                                     uint8_t* h_pw, uint8_t* d_pw, fp_words* d_tmp, hipStream_t stream);
 hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,
                               fp_words* d_rem, hipStream_t stream);
+// *d_count (device u32, zeroed here) = number of elements of the m <= 16 columns (n each) whose 256-bit word value is >= r
+hipError_t poly_count_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_count, hipStream_t stream);
 // out[i] = sum_j coeffs[j] * polys[j][i], m <= LINCOMB_MAX
 static constexpr uint32_t LINCOMB_MAX = 32;
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,

@@ -321,6 +321,35 @@ __global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a
 // of ONE polynomial (it vanishes on the whole set) instead of a chain; all sets' divisions go in one batch.  The scan
 // weights live in device memory (one KatePowers per division, uploaded by the caller).
 static constexpr uint32_t KATE_BATCH_MAX = 16;
+// ---- canonical-range check of caller-supplied columns (halo2curves' Fr::from_repr refuses words >= r; the gate
+// interpreter's lazy bounds assume them) -- a streaming pass, one 32-byte load per element
+struct CanonCols {
+  const fp_words* col[16];
+};
+__global__ void __launch_bounds__(256) count_noncanonical_kernel(CanonCols cols, uint32_t n, uint32_t* __restrict__ count) {
+  // r as 8 LE words
+  const uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* src = reinterpret_cast<const uint4*>(cols.col[blockIdx.y] + i);
+  const uint4 lo = src[0], hi = src[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  bool ge = true;   // w >= r, decided from the most significant word that differs
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (w[k] != R[k]) ge = w[k] > R[k];
+  }
+  if (ge) atomicAdd(count, 1u);
+}
+hipError_t poly_count_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_count, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess || !m || !n) return e;
+  CanonCols cols{};
+  for (uint32_t j = 0; j < m; j++) cols.col[j] = d_cols[j];
+  count_noncanonical_kernel<<<dim3((unsigned)((n + 255) / 256), m), 256, 0, stream>>>(cols, (uint32_t)n, d_count);
+  return hipGetLastError();
+}
+
 struct KateBatch {
   const fp_words* a[KATE_BATCH_MAX];
   fp_words* q[KATE_BATCH_MAX];

@@ -122,7 +122,9 @@ struct Srs {
   uint32_t k;
   g1_affine_mem* g;
   g1_affine_mem* g_lagrange;
-  FixedTable tab[2];  // optional precomputed window tables (sg_srs_precompute): [0] g, [1] g_lagrange
+  FixedTable tab[3];  // optional precomputed window tables (sg_srs_precompute): [0] g, [1] g_lagrange, [2] the prefix sums
+                      // of g_lagrange (difference-form commitments of Lagrange columns)
+  g1_affine_mem* lagrange_prefix = nullptr;   // made with tab[2]
 };
 
 struct Context {
@@ -476,7 +478,7 @@ int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t ou
 // batch driver shared by sg_msm_g1_batch_dev (d_bases given) and sg_commit_batch_dev (tab given: every
 // MSM runs over the precomputed window table); caller holds the context lock
 static int msm_batch_locked(const void* const* d_scalars, const void* const* d_bases, const FixedTable* tab,
-                            const size_t* n, size_t count, void* stream, uint8_t* out_affine) {
+                            const size_t* n, size_t count, void* stream, uint8_t* out_affine, const uint8_t* diff = nullptr) {
   Context& c = *g_ctx;
   MsmEngine* eng[2] = {&c.msm, &c.msm_b};
   for (int k = 0; k < 2; k++) {
@@ -512,10 +514,13 @@ static int msm_batch_locked(const void* const* d_scalars, const void* const* d_b
       if (e != hipSuccess) break;
     }
     const Group& g = groups[gi];
-    if (tab)  // d_bases then holds one window table per MSM (all with tab's plan)
+    if (tab) {  // d_bases then holds one window table per MSM (all with tab's plan)
+      uint32_t diff_mask = 0;
+      for (size_t m = 0; diff && m < g.count; m++) diff_mask |= (diff[g.first + m] ? 1u : 0u) << m;
       e = eng[k]->enqueue_front_fixed(reinterpret_cast<const fp_words* const*>(d_scalars + g.first), *tab, g.count,
                                       n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr,
-                                      reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first));
+                                      reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), diff_mask);
+    }
     else
       e = eng[k]->enqueue_front_fused(reinterpret_cast<const fp_words* const*>(d_scalars + g.first),
                                       reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), g.count,
@@ -639,6 +644,7 @@ int sg_srs_free(uint64_t handle) {
   }
   (void)hipFree(gone.g);          // hipFree waits for the device: work in flight on these bases completes first
   (void)hipFree(gone.g_lagrange);
+  if (gone.lagrange_prefix) (void)hipFree(gone.lagrange_prefix);
   for (auto& t : gone.tab)
     if (t.table) (void)hipFree(t.table);
   return SG_OK;
@@ -646,7 +652,7 @@ int sg_srs_free(uint64_t handle) {
 // Precompute the fixed-base window table of one basis: W x 2^k points, row w = 2^(offset_w) * basis.
 // Later sg_commit* calls on this basis take the fixed-base path (same result bits).
 int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
-  if (basis != 0 && basis != 1) return fail(SG_ERR_INVALID, "sg_srs_precompute: bad basis");
+  if (basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_srs_precompute: bad basis");
   if (window_bits && (window_bits < 4 || window_bits > 16)) return fail(SG_ERR_INVALID, "sg_srs_precompute: window_bits in [4, 16]");
   LOCKED_CTX();
   Srs* srs_p = find_srs(handle);
@@ -654,11 +660,22 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
   Srs& s = (*srs_p);
   const size_t n = (size_t)1 << s.k;
   const uint32_t c = window_bits ? window_bits : fixed_window_bits_for(n);
+  hipError_t e = hipSuccess;
+  if (basis == 2 && !s.lagrange_prefix) {   // Q_i = L_0 + ... + L_i, once per SRS
+    g1_affine_mem* q = nullptr;
+    e = hipMalloc(&q, n * sizeof(g1_affine_mem));
+    if (e == hipSuccess) e = g1_prefix_sums(s.g_lagrange, n, q, g_ctx->stream);
+    if (e != hipSuccess) {
+      if (q) (void)hipFree(q);
+      return hip_fail("sg_srs_precompute: prefix sums", e);
+    }
+    s.lagrange_prefix = q;
+  }
   FixedTable t;
-  hipError_t e = build_window_table(basis ? s.g_lagrange : s.g, n, c, &t, g_ctx->stream);
+  e = build_window_table(basis == 2 ? s.lagrange_prefix : basis ? s.g_lagrange : s.g, n, c, &t, g_ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(g_ctx->stream);
   if (e != hipSuccess) return hip_fail("sg_srs_precompute", e);
-  if (s.tab[basis].table) (void)hipFree(s.tab[basis].table);
+  retire_device_memory(s.tab[basis].table);   // commitments of other lanes may still be reading the old table
   s.tab[basis] = t;
   return SG_OK;
 }
@@ -671,12 +688,17 @@ int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagra
   if (k) *k = (*srs_p).k;
   return SG_OK;
 }
+// basis 2 = a Lagrange column taken in difference form (same commitment as basis 1): possible when the prefix-sum table
+// exists and the column has the full 2^k rows
+static bool diff_form_ready(const Srs& s, size_t n) { return s.tab[2].table != nullptr && n == ((size_t)1 << s.k); }
 static hipError_t commit_run(const Srs& s, int basis, const fp_words* d_scalars, size_t n, hipStream_t stream,
                              uint8_t out_affine[64], MsmTimings* tm = nullptr) {
   MsmEngine& eng = g_ctx->msm;
+  const bool diff = basis == 2 && diff_form_ready(s, n);
+  if (basis == 2 && !diff) basis = 1;
   if (s.tab[basis].table && n) {
     const fp_words* sc[1] = {d_scalars};
-    hipError_t e = eng.enqueue_front_fixed(sc, s.tab[basis], 1, n, stream, out_affine, tm);
+    hipError_t e = eng.enqueue_front_fixed(sc, s.tab[basis], 1, n, stream, out_affine, tm, nullptr, diff ? 1u : 0u);
     if (e == hipSuccess) e = eng.enqueue_back();
     if (e == hipSuccess) e = eng.finish();
     return e;
@@ -685,7 +707,7 @@ static hipError_t commit_run(const Srs& s, int basis, const fp_words* d_scalars,
 }
 int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                         uint8_t out_affine[64], sg_msm_timings* timings) {
-  if (!out_affine || (n && !d_scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
+  if (!out_affine || (n && !d_scalars) || basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
   Srs* srs_p = find_srs(srs_handle);
   if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
@@ -710,7 +732,7 @@ int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t 
 // commitments of one proof phase); takes the fixed-base path when the table exists
 int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
                         void* stream, uint8_t* out_affine) {
-  if ((count && (!d_scalars || !out_affine)) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit_batch: bad argument");
+  if ((count && (!d_scalars || !out_affine)) || basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_commit_batch: bad argument");
   for (size_t i = 0; i < count; i++)
     if (n && !d_scalars[i]) return fail(SG_ERR_INVALID, "sg_commit_batch: null argument");
   LOCKED_CTX();
@@ -719,9 +741,12 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   const Srs& s = (*srs_p);
   std::vector<size_t> ns(count, n);
+  const bool diff = basis == 2 && diff_form_ready(s, n);
+  if (basis == 2 && !diff) basis = 1;
   const bool fixed = s.tab[basis].table != nullptr;
   std::vector<const void*> bases(count, fixed ? (const void*)s.tab[basis].table : (const void*)(basis ? s.g_lagrange : s.g));
-  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[basis] : nullptr, ns.data(), count, stream, out_affine);
+  std::vector<uint8_t> flags(count, diff ? 1 : 0);
+  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[basis] : nullptr, ns.data(), count, stream, out_affine, flags.data());
 }
 // the same with one basis per polynomial (0 = g, 1 = g_lagrange): e.g. the grand-product commitments (Lagrange)
 // and the random polynomial (coefficients) of one prover phase as ONE fused job
@@ -729,7 +754,7 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
                               void* stream, uint8_t* out_affine) {
   if (count && (!d_scalars || !out_affine || !basis)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   for (size_t i = 0; i < count; i++)
-    if ((n && !d_scalars[i]) || (basis[i] != 0 && basis[i] != 1)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
+    if ((n && !d_scalars[i]) || basis[i] < 0 || basis[i] > 2) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   LOCKED_CTX();
   Srs* srs_p = find_srs(srs_handle);
   if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
@@ -737,14 +762,20 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
   const Srs& s = (*srs_p);
   // fixed-base only when both tables exist with one plan; otherwise the generic fused path over g / g_lagrange
   const bool fixed = s.tab[0].table && s.tab[1].table && s.tab[0].c == s.tab[1].c && s.tab[0].n == s.tab[1].n;
+  // difference form (basis 2) needs the prefix-sum table on the same plan; otherwise such a column is an ordinary Lagrange one
+  const bool diff_ok = fixed && diff_form_ready(s, n) && s.tab[2].c == s.tab[0].c && s.tab[2].n == s.tab[0].n;
   std::vector<size_t> ns(count, n);
   std::vector<const void*> bases(count);
-  for (size_t i = 0; i < count; i++)
-    bases[i] = fixed ? (const void*)s.tab[basis[i]].table : (const void*)(basis[i] ? s.g_lagrange : s.g);
-  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[0] : nullptr, ns.data(), count, stream, out_affine);
+  std::vector<uint8_t> flags(count, 0);
+  for (size_t i = 0; i < count; i++) {
+    const int b = basis[i] == 2 ? (diff_ok ? 2 : 1) : basis[i];
+    flags[i] = b == 2;
+    bases[i] = fixed ? (const void*)s.tab[b].table : (const void*)(b ? s.g_lagrange : s.g);
+  }
+  return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[0] : nullptr, ns.data(), count, stream, out_affine, flags.data());
 }
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
-  if (!out_affine || (n && !scalars) || (basis != 0 && basis != 1)) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
+  if (!out_affine || (n && !scalars) || basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
   Srs* srs_p = find_srs(srs_handle);
   if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
@@ -1406,6 +1437,20 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
 }
 // m <= 16 exact divisions q_j = a_j / (X - b_j) in one launch per scan step (a_j may repeat: by partial fractions the
 // divisions of one rotation set are independent divisions of the same polynomial).  Asynchronous on `stream`.
+// how many elements of the given columns are not canonical (word value >= r)?  Asynchronous: *d_count (a u32 in device
+// memory) holds the number once the stream reaches this point.
+int sg_fr_count_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_count, void* stream) {
+  if (!d_count || (m && !d_cols)) return fail(SG_ERR_INVALID, "sg_fr_count_noncanonical: null argument");
+  if (m > 16) return fail(SG_ERR_INVALID, "sg_fr_count_noncanonical: at most 16 columns per call");
+  if (n > 0xffffffffull) return fail(SG_ERR_INVALID, "sg_fr_count_noncanonical: too many rows");
+  for (uint32_t j = 0; j < m; j++)
+    if (n && !d_cols[j]) return fail(SG_ERR_INVALID, "sg_fr_count_noncanonical: null column");
+  LOCKED_CTX();
+  hipError_t e = poly_count_noncanonical(reinterpret_cast<const fp_words* const*>(d_cols), m, n, reinterpret_cast<uint32_t*>(d_count),
+                                         reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("count_noncanonical", e);
+  return SG_OK;
+}
 int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
                                   void* stream) {
   if (m && (!d_a || !points || !d_q)) return fail(SG_ERR_INVALID, "sg_fr_kate_division_batch: null argument");

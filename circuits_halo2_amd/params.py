@@ -110,8 +110,9 @@ class ParamsKZG:
     def precompute(self, basis: int | None = None, window_bits: int = 0) -> None:
         """build the fixed-base window table(s) of the resident SRS (sg_srs_precompute): later
         commit / commit_lagrange / commit_batch calls take the fixed-base path (same results).
-        basis: 0 = g, 1 = g_lagrange, None = both."""
-        for b in ([0, 1] if basis is None else [basis]):
+        basis: 0 = g, 1 = g_lagrange, 2 = the prefix sums of g_lagrange (difference-form commitments of piecewise-constant
+        Lagrange columns: `commit_batch(..., diff=True)`, flag 2 of `commit_batch_mixed`), None = all three."""
+        for b in ([0, 1, 2] if basis is None else [basis]):
             ffi.check(ffi.lib().sg_srs_precompute(C.c_uint64(self.handle()), C.c_int(b), C.c_uint32(window_bits)))
 
     def free(self):
@@ -137,8 +138,10 @@ class ParamsKZG:
                               ffi.ptr(out)))
         return out
 
-    def commit_batch(self, polys, lagrange: bool = False) -> np.ndarray:
-        """commitments to several equal-length device polynomials as fused jobs -> (len, 64) uint8"""
+    def commit_batch(self, polys, lagrange: bool = False, diff: bool = False) -> np.ndarray:
+        """commitments to several equal-length device polynomials as fused jobs -> (len, 64) uint8.
+        diff (Lagrange columns only): a hint that the columns are piecewise constant -- the library commits to the
+        differences against the prefix-summed basis when that table exists (sg_commit, basis 2); same commitments."""
         m = len(polys)
         out = np.zeros((m, 64), dtype=np.uint8)
         if m == 0:
@@ -150,13 +153,14 @@ class ParamsKZG:
         if n > self.n:
             raise ValueError("polynomial longer than the SRS")
         ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
-        ffi.check(ffi.lib().sg_commit_batch_dev(C.c_uint64(self.handle()), C.c_int(1 if lagrange else 0), ptrs,
+        ffi.check(ffi.lib().sg_commit_batch_dev(C.c_uint64(self.handle()), C.c_int((2 if diff else 1) if lagrange else 0), ptrs,
                                                 C.c_size_t(m), C.c_size_t(n), ffi.current_stream_ptr(), ffi.ptr(out)))
         return out
 
     def commit_batch_mixed(self, polys, lagrange_flags) -> np.ndarray:
-        """like commit_batch with one basis per polynomial (True = Lagrange form): one fused job for a phase that
-        commits to both kinds (grand products + the random polynomial)"""
+        """like commit_batch with one basis per polynomial (False / 0 = coefficients, True / 1 = Lagrange form, 2 = Lagrange
+        form with the piecewise-constant hint): one fused job for a phase that commits to both kinds (grand products +
+        the random polynomial)"""
         m = len(polys)
         out = np.zeros((m, 64), dtype=np.uint8)
         if m == 0:
@@ -170,7 +174,9 @@ class ParamsKZG:
         if n > self.n:
             raise ValueError("polynomial longer than the SRS")
         ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
-        flags = (C.c_int * m)(*[1 if f else 0 for f in lagrange_flags])
+        flags = (C.c_int * m)(*[int(f) for f in lagrange_flags])
+        if any(f not in (0, 1, 2) for f in flags):
+            raise ValueError("commit_batch_mixed: flags are 0, 1 or 2")
         ffi.check(ffi.lib().sg_commit_batch_mixed_dev(C.c_uint64(self.handle()), flags, ptrs, C.c_size_t(m), C.c_size_t(n),
                                                       ffi.current_stream_ptr(), ffi.ptr(out)))
         return out

@@ -362,12 +362,15 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
         return [_point(c) for c in params.commit_batch(cols, lagrange=True)]
 
     # -- 1: advice columns: blind the last rows, commit
+    noncanonical = A.count_noncanonical(advice) if sanity_checks else None     # read where the host waits next
     advice = [a.clone() for a in advice]
     for a in advice:
         a[32 * u:] = rand(n - u)
     instance_col = _head(list(instances), n)
     for p in commit_lagrange(advice):
         tr.write_point(p)
+    if noncanonical is not None and int(noncanonical.item()):
+        raise ValueError("create_proof: advice words >= r (not canonical Montgomery field elements)")
     theta = tr.squeeze_challenge()  # one expression per side: theta only separates the phases
     adv_coeff = to_coeff(advice + [instance_col])
     for j in range(3):
@@ -387,7 +390,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
         pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
         pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
                          for rows in (pin_rows, ptab_rows))
-    for p in commit_lagrange([pin_d, ptab_d]):
+    for p in [_point(c) for c in params.commit_batch([pin_d, ptab_d], lagrange=True, diff=True)]:   # sorted columns: long runs
         tr.write_point(p)
     beta = tr.squeeze_challenge()
     gamma = tr.squeeze_challenge_again()
@@ -414,7 +417,8 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
         raise ValueError("lookup argument not satisfied by the assignment")
     lz[32 * (u + 1):] = rand(n - u - 1)
     polys[("random", 0)] = rand(n)
-    for c in params.commit_batch_mixed(zs + [lz, polys[("random", 0)]], [True, True, True, False]):   # one fused job
+    # one fused job; the grand products are constant over the unused rows (every ratio is 1 there): difference form
+    for c in params.commit_batch_mixed(zs + [lz, polys[("random", 0)]], [2, 2, 2, 0]):
         tr.write_point(_point(c))
     y = tr.squeeze_challenge()
     b_y = _fr_bytes(y)

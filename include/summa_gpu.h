@@ -89,7 +89,12 @@ int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint6
  * y^2 = x^3 + 3 nor the identity. */
 int sg_srs_check(uint64_t handle, uint64_t* bad_out);
 int sg_srs_free(uint64_t handle);
-/* ParamsKZG::commit (basis = 0, monomial g[]) / commit_lagrange (basis = 1): n <= 2^k scalars */
+/* ParamsKZG::commit (basis = 0, monomial g[]) / commit_lagrange (basis = 1): n <= 2^k scalars.
+ * basis = 2 is commit_lagrange as well -- the same commitment -- with a hint: the column is (mostly) piecewise constant, as
+ * the permutation / lookup grand products and the sorted lookup columns of a halo2 proof are over the unused rows.  With
+ *   sum_i s_i L_i = sum_i (s_i - s_{i+1}) Q_i,   Q_i = L_0 + ... + L_i,  s_n = 0
+ * the library then runs the MSM of the DIFFERENCES against the prefix-summed basis Q (sg_srs_precompute(handle, 2, ..)), in
+ * which every constant run costs nothing (zero digits are skipped).  Without that table, or for n < 2^k, basis 2 is basis 1. */
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]);
 int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                   uint8_t out_affine[64]);
@@ -98,12 +103,14 @@ int sg_commit_dev(uint64_t srs_handle, int basis, const void* d_scalars, size_t 
  *   row w = 2^(bit offset of window w) * basis[i],   W x 2^k affine points (W = ceil(255 / window_bits)),
  * after which sg_commit / sg_commit_dev / sg_commit_batch_dev on that basis run all W digits of a scalar
  * into ONE bucket set (one bucket reduction instead of W; wider windows at small k).  Same result
- * bits.  window_bits = 0 chooses min(16, k).  Memory: W * 64 * 2^k bytes per basis. */
+ * bits.  window_bits = 0 chooses min(16, k).  Memory: W * 64 * 2^k bytes per basis.
+ * basis = 2: the prefix sums Q of g_lagrange (computed on first use, 64 * 2^k bytes) and their table, for difference-form
+ * commitments (see sg_commit); use the window_bits of bases 0 / 1 when the columns are to share fused jobs. */
 int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits);
 /* `count` commitments of n scalars each against one basis, issued as fused jobs; out_affine: count x 64 B */
 int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
                         void* stream, uint8_t* out_affine);
-/* the same with one basis per polynomial (0 = g, 1 = g_lagrange): the commitments of one prover phase that mix
+/* the same with one basis per polynomial (0 = g, 1 = g_lagrange, 2 = g_lagrange in difference form): the commitments of one prover phase that mix
  * Lagrange- and coefficient-form polynomials as ONE fused job (fixed-base when both tables were precomputed) */
 int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
                               void* stream, uint8_t* out_affine);
@@ -243,6 +250,10 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
  * instead of a chain, and all sets go in one batch.  Remainders are not returned.  Complete on return. */
 int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
                                   void* stream);
+/* Range check of caller-supplied columns: *d_count (u32 in device memory) = number of elements of the m <= 16 columns (n each)
+ * whose 32-byte word value is >= r (halo2curves never produces such words; `Fr::from_repr` refuses them [UPSTREAM]).
+ * Asynchronous on `stream`. */
+int sg_fr_count_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_count, void* stream);
 /* out[i] = sum_j coeffs[j] * polys[j][i], 1 <= m <= 32 (the random linear combinations of the multi-open) */
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
 

@@ -196,6 +196,7 @@ class ParamsKZG {
   void precompute() {
     check(sg_srs_precompute(handle(), 0, 0));
     check(sg_srs_precompute(handle(), 1, 0));
+    check(sg_srs_precompute(handle(), 2, 0));
   }
   /// commit to a polynomial in coefficient form
   G1Affine commit(const std::vector<Fr>& poly) { return commit_impl(0, poly); }

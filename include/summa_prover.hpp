@@ -414,7 +414,8 @@ struct Blake2bTranscript {   // Blake2bWrite<_, G1Affine, Challenge255<_>> (halo
 };
 
 struct Options {
-  bool sanity_checks = true;   // refuse a witness whose permutation / lookup grand product does not close (upstream's cargo feature)
+  bool sanity_checks = true;   // refuse a witness whose permutation / lookup grand product does not close (upstream's cargo
+                               // feature), or whose advice words are not canonical field elements
 };
 struct WitnessError : std::runtime_error {   // the assignment, not the machinery, is at fault
   using std::runtime_error::runtime_error;
@@ -801,6 +802,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   };
 
   // -- 1: advice
+  DevCol noncanonical(1);   // device counter of the range check, read after the commitments (where the host waits anyway)
+  if (opt.sanity_checks) {
+    const void* cols[3] = {advice[0].p, advice[1].p, advice[2].p};
+    ck(sg_fr_count_noncanonical_dev(cols, 3, n, noncanonical.p, main_stream()), "range check of the advice columns");
+  }
   for (auto& a : advice) rand_rows(a, u, n - u);
   DevCol instance_col(n);
   instance_col.zero();
@@ -809,6 +815,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   fork();
   to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);   // under the commitments
   commit_batch({advice[0].p, advice[1].p, advice[2].p}, {1, 1, 1});
+  if (opt.sanity_checks) {
+    uint32_t bad = 0;
+    d2h(&bad, noncanonical.p, 4);
+    if (bad) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
+  }
   const Fr theta = tr.squeeze();
 
   lap("1_advice");
@@ -841,7 +852,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   }
   rand_rows(pin, u, n - u);
   rand_rows(ptab, u, n - u);
-  commit_batch({pin.p, ptab.p}, {1, 1});
+  commit_batch({pin.p, ptab.p}, {2, 2});   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
   const Fr beta = tr.squeeze(), gamma = tr.squeeze_again();
 
   lap("2_lookup");
@@ -889,7 +900,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   std::vector<DevCol> co3, ex3;
   fork();
   to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
-  commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {1, 1, 1, 0});
+  // the grand products stay constant wherever the ratio is 1 -- all the unused rows: difference form
+  commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
   const Fr y = tr.squeeze();
   join();
 

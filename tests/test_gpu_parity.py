@@ -893,6 +893,69 @@ def test_fixed_base_batch(gpu, O, srs11):
     params.free()
 
 
+@pytest.mark.parametrize("window_bits", [0, 5, 16])
+def test_difference_form_commitments(gpu, O, srs11, window_bits):
+    """basis 2 of sg_commit*: sum_i s_i L_i = sum_i (s_i - s_{i+1}) Q_i with Q the prefix sums of g_lagrange (s_n = 0).  The
+    commitment must be the one of commit_lagrange for every kind of column -- random (every Q_i enters), piecewise constant
+    (the case it is for: grand products over unused rows, sorted lookup columns), constant, edge values -- single, batched
+    and mixed with the other bases in one fused job; without the table, and for short columns, it is plain commit_lagrange"""
+    params = gpu.ParamsKZG(11, srs11["g_np"], srs11["gl_np"])
+    n, r = 2048, P_R()
+    rng = np.random.default_rng(77 + window_bits)
+    steps = O.random_fr(2900, 40).reshape(40, 32)
+    runs = np.sort(rng.integers(0, n, 39))
+    piecewise = np.concatenate([np.tile(steps[j], (hi - lo, 1)) for j, (lo, hi) in enumerate(zip([0] + list(runs), list(runs) + [n]))]).reshape(-1)
+    grand = piecewise.copy()
+    grand[32 * (n - 6):] = O.random_fr(2901, 6)                        # blinding rows at the end, as in a z column
+    cols = [O.random_fr(2902 + window_bits, n), piecewise, grand, fr_np([7] * n), fr_np([0] * n), fr_np([r - 1] * n),
+            fr_np([0] * (n - 1) + [1]), fr_np([1] + [0] * (n - 1)), fr_np([r - 1, 0] * (n // 2)), fr_np(sorted(int(v) for v in rng.integers(0, 256, n)))]
+    want = np.stack([O.best_multiexp(c, srs11["gl_np"], O.ncpu()) for c in cols])
+    d = [dev(c) for c in cols]
+    assert (params.commit_batch(d, lagrange=True, diff=True) == want).all()      # no tables at all: generic path
+    params.precompute(1, window_bits=window_bits)
+    assert (params.commit_batch(d, lagrange=True, diff=True) == want).all()      # no prefix table: fixed-base Lagrange
+    params.precompute(2, window_bits=window_bits)
+    assert (params.commit_batch(d, lagrange=True, diff=True) == want).all()      # difference form
+    assert (params.commit_batch(d, lagrange=True) == want).all()
+    for j in (0, 1, 3, 6):
+        assert (params.commit_batch(d[j:j + 1], lagrange=True, diff=True) == want[j:j + 1]).all()
+    # short columns cannot telescope (s_n = 0 is needed): served as commit_lagrange
+    short = [t[:32 * 700] for t in d[:3]]
+    want_s = np.stack([O.best_multiexp(c[:32 * 700], srs11["gl_np"][:64 * 700], O.ncpu()) for c in cols[:3]])
+    assert (params.commit_batch(short, lagrange=True, diff=True) == want_s).all()
+    # mixed fused jobs: coefficients, Lagrange and difference-form columns side by side (the grand-product phase)
+    flags = [2, 0, 2, 1, 2, 0, 2]
+    want_m = np.stack([O.best_multiexp(c, srs11["g_np" if f == 0 else "gl_np"], O.ncpu()) for c, f in zip(cols[:7], flags)])
+    assert (params.commit_batch_mixed(d[:7], flags) == want_m).all()            # tables 1 and 2 only: generic mixed path
+    params.precompute(0, window_bits=window_bits)
+    assert (params.commit_batch_mixed(d[:7], flags) == want_m).all()            # all three tables, one plan
+    params.precompute(2, window_bits=9 if window_bits != 9 else 8)
+    assert (params.commit_batch_mixed(d[:7], flags) == want_m).all()            # prefix table on another plan: falls back
+    assert (params.commit_batch(d[:3], lagrange=True, diff=True) == want[:3]).all()
+    with pytest.raises(ValueError):
+        params.commit_batch_mixed(d[:1], [3])
+    params.free()
+
+
+def test_difference_form_large_known_answer(gpu, O):
+    """k = 17 with a synthetic SRS: a z-like column (a few thousand distinct rows, then one value for the other 120 000,
+    blinding rows at the end) commits to the same point in difference form as in the plain fixed-base form"""
+    k = 17
+    n = 1 << k
+    params = gpu.ParamsKZG.setup(k, O.random_fr(2950, 1))
+    col = O.random_fr(2951, n).copy().reshape(n, 32)
+    col[6000:n - 6] = col[5999]
+    col = col.reshape(-1)
+    cols = [dev(col), dev(O.random_fr(2952, n)), dev(np.tile(O.random_fr(2953, 1), n))]
+    params.precompute(1)
+    want = params.commit_batch(cols, lagrange=True)
+    params.precompute(2)
+    assert (params.commit_batch(cols, lagrange=True, diff=True) == want).all()
+    params.precompute(0)
+    assert (params.commit_batch_mixed(cols + cols[:1], [2, 2, 2, 1]) == np.concatenate([want, want[:1]])).all()
+    params.free()
+
+
 def test_fixed_base_large_known_answer(gpu, O, P):
     """2^17 points of a synthetic SRS g[i] = tau^i G: sum s_i tau^i is known in the exponent"""
     k = 17
@@ -932,6 +995,30 @@ def test_kate_division(gpu, O, n):
     zero = fr_np([0])                                    # division by X: a shift
     q0 = kate_division(dev(a), zero)
     assert (q0.cpu().numpy() == a[32:]).all()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (255, 3), (256, 2), (100003, 16)])
+def test_count_noncanonical(gpu, O, n, m):
+    """sg_fr_count_noncanonical_dev against integer comparison with r: canonical data counts 0; planted words r, r + 1,
+    2^256 - 1 and words that differ from r only in one 32-bit word are counted exactly"""
+    import torch
+    from circuits_halo2_amd.arithmetic import count_noncanonical
+    from oracle import pyref as PR
+    cols = [O.random_fr(2800 + j, n).copy() for j in range(m)]
+    assert int(count_noncanonical([dev(c) for c in cols]).item()) == 0
+    rng = np.random.default_rng(n + m)
+    planted = [PR.R, PR.R + 1, (1 << 256) - 1, PR.R - 1, PR.R + (1 << 32), PR.R - (1 << 32), PR.R + (1 << 224), PR.R - (1 << 224), 0]
+    want = 0
+    seen = set()
+    for v in planted:
+        j, i = int(rng.integers(m)), int(rng.integers(n))
+        if (j, i) in seen:
+            continue
+        seen.add((j, i))
+        cols[j][32 * i:32 * i + 32] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+        want += v >= PR.R
+    assert int(count_noncanonical([dev(c) for c in cols]).item()) == want
+    assert int(count_noncanonical([]).item()) == 0
 
 
 @pytest.mark.parametrize("n,m", [(1, 2), (7, 3), (2048, 4), (2049, 16), (1 << 13, 11), (1 << 17, 11), (300001, 5)])

@@ -436,6 +436,13 @@ def test_native_driver_matches_the_python_driver(setup):
         P.create_proof_native(s["params"], s["pk"], [s["dev"](c) for c in adv], inst)
     unchecked = P.create_proof_native(s["params"], s["pk"], [s["dev"](c) for c in adv], inst, sanity_checks=False)
     assert len(unchecked) == 2144 and not SV.verify(unchecked, inst, s["vk"])       # upstream's default build: a proof that fails
+    # advice words that are not canonical field elements (>= r) are refused by both drivers when the checks are on
+    raw = [a.clone() for a in advice]
+    raw[2][32 * 9 + 31] = 0xff
+    with pytest.raises(ValueError, match="canonical"):
+        P.create_proof_native(s["params"], s["pk"], raw, inst)
+    with pytest.raises(ValueError, match="canonical"):
+        P.create_proof(s["params"], s["pk"], raw, inst, seeded_rng(22))
     # malformed calls
     with pytest.raises(ValueError):
         P.create_proof_native(s["params"], s["pk"], advice[:2], inst)

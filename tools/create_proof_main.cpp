@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
     ck(sg_srs_upload(k, g.data(), gl.data(), &srs), "srs upload");
     ck(sg_srs_precompute(srs, 0, 0), "precompute");
     ck(sg_srs_precompute(srs, 1, 0), "precompute");
+    ck(sg_srs_precompute(srs, 2, 0), "precompute");
     std::vector<DevCol> fixed, sigma, advice;
     for (uint32_t i = 0; i < NUM_FIXED; i++) fixed.push_back(rd.column(n));
     for (uint32_t i = 0; i < NUM_SIGMA; i++) sigma.push_back(rd.column(n));

@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
   CK(sg_srs_upload(k, hg.data(), hg.data(), &srs));
   CK(sg_srs_precompute(srs, 0, 0));
   CK(sg_srs_precompute(srs, 1, 0));
+  CK(sg_srs_precompute(srs, 2, 0));
   // proving-key side (extended basis), witness columns (Lagrange basis)
   std::vector<void*> fixed_ext(11), sigma_lag(6), sigma_ext(6), advice(3);
   for (auto& p : fixed_ext) p = dev_random(ne);

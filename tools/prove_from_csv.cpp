@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
     ck(sg_srs_upload(k, g.data(), gl.data(), &srs), "srs upload");
     ck(sg_srs_precompute(srs, 0, 0), "precompute");
     ck(sg_srs_precompute(srs, 1, 0), "precompute");
+    ck(sg_srs_precompute(srs, 2, 0), "precompute");
 
     // ---- key generation: the empty circuit's floor plan -> fixed / permutation columns -> commitments (vk) -> pk forms
     t = clk::now();
