@@ -332,6 +332,26 @@ def quotient_permutation(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l
     return values
 
 
+def quotient_permutation_coset(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l_active, beta, gamma, y, k: int,
+                                ext_k: int, coset: int, last_rotation_abs: int):
+    """quotient_permutation on ONE coset of the coset-major layout (EvaluationDomain.coeff_to_cosets_batch): every array
+    is that coset's 2^k rows"""
+    ns, m = len(zs), len(cols)
+    if len(sigmas) != m:
+        raise ValueError("quotient_permutation_coset: one sigma per column")
+    for t in [values, l0, l_last, l_active, *zs, *cols, *sigmas]:
+        if t.numel() != 32 << k:
+            raise ValueError("quotient_permutation_coset: every array has 2^k rows")
+    pz = (C.c_void_p * ns)(*[z.data_ptr() for z in zs])
+    pc = (C.c_void_p * m)(*[c.data_ptr() for c in cols])
+    ps = (C.c_void_p * m)(*[s.data_ptr() for s in sigmas])
+    ffi.check(ffi.lib().sg_quotient_permutation_coset_dev(
+        ffi.dev_ptr(values), pz, C.c_uint32(ns), pc, ps, C.c_uint32(m), C.c_uint32(chunk_len), ffi.dev_ptr(l0),
+        ffi.dev_ptr(l_last), ffi.dev_ptr(l_active), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(y)),
+        C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(coset), C.c_uint32(last_rotation_abs), ffi.current_stream_ptr()))
+    return values
+
+
 def quotient_lookup(values, z, permuted_input, permuted_table, inp, table, l0, l_last, l_active, beta, gamma, y,
                     k: int, ext_k: int):
     """fold one lookup argument's five constraints into the quotient numerator (in place)"""

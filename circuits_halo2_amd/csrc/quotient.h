@@ -24,6 +24,33 @@ struct QuotLookupArgs {
   uint32_t k, ext_k;
   uint32_t beta[8], gamma[8], y[8];
 };
+// ---- the quotient on quotient-degree many cosets of the 2^k domain instead of the whole extended domain
+// deg h < d n (d = cs.degree() - 1 = 5 here), so h is determined by its values on d cosets c_b H of the 2^k domain H:
+// halo2 evaluates on the 2^(k+3) extended domain = 8 such cosets, c_b = zeta omega_ext^b; the first d of them suffice.
+// On c_b H the polynomial X^n is the constant g_b = c_b^n, therefore
+//   * the vanishing polynomial X^n - 1 is the constant g_b - 1 there, and
+//   * h restricted to the coset is P_b = h mod (X^n - g_b) = sum_t g_b^t h_t, h_t the pieces of n coefficients,
+// so the pieces follow from d inverse transforms of size n and one d x d Vandermonde solve per coefficient index:
+//   h_t[i] = sum_b M[t][b] c_b^-i iNTT_n(values_b)[i],   M = V^-1 diag(1 / (g_b - 1)),  V[b][t] = g_b^t.
+// The same h as halo2's extended_to_coeff (it is unique), from 5/8 of the rows.
+static constexpr uint32_t MAX_COSETS = 8, COSET_BATCH_MAX = 16;
+struct CosetScaleArgs {  // out[j][b * n + i] = in[j][i] * c_b^i
+  const fp_words* in[COSET_BATCH_MAX];
+  fp_words* out[COSET_BATCH_MAX];
+  const fp_words* table;   // [nc][n]: c_b^i as 2^261-domain words
+  uint32_t log_n, nc;
+};
+hipError_t coset_scale(const CosetScaleArgs& a, uint32_t count, hipStream_t stream);
+struct CosetCombineArgs {  // pieces[t][i] = sum_b m[t][b] * table_inv[b][i] * raw[b * n + i]
+  const fp_words* raw;
+  fp_words* pieces[MAX_COSETS];
+  const fp_words* table_inv;   // [nc][n]: c_b^-i as 2^261-domain words
+  uint32_t log_n, nc;
+  uint32_t m[MAX_COSETS * MAX_COSETS][8];   // Montgomery-2^256 words, row-major [t][b]
+};
+hipError_t coset_combine(const CosetCombineArgs& a, hipStream_t stream);
+// table[b * n + i] = (c[b]^i) as 2^261-domain words, b < nc, i < 2^log_n
+hipError_t coset_fill_powers(fp_words* table, const words8* c, uint32_t nc, uint32_t log_n, hipStream_t stream);
 hipError_t quotient_permutation(const QuotPermArgs& a, hipStream_t stream);
 hipError_t quotient_lookup(const QuotLookupArgs& a, hipStream_t stream);
 }  // namespace sg

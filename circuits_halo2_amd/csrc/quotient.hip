@@ -20,6 +20,8 @@
 // applies the y-fold and undoes the drift.  ~45 products per row: VALU-bound like the rest.
 #include "quotient.h"
 
+#include <cstring>
+
 namespace sg {
 
 typedef Fr29 P;
@@ -127,6 +129,71 @@ __global__ void __launch_bounds__(256) quot_lookup_kernel(QuotLookupArgs a) {
   acc = fold(acc, y_hat, f29_mul<P>(d, l0), 1);
   acc = fold(acc, y_hat, f29_mul<P>(f29_mul<P>(d, f29_sub<P, 0>(ap, ld(a.permuted_input, i_prev))), l_active), 2);
   f29_store_canonical<P>(a.values + i, acc);
+}
+
+// ------------------------------------------------------------------ cosets (see quotient.h)
+struct CosetShifts {
+  uint32_t c[MAX_COSETS][8];
+};
+__global__ void __launch_bounds__(256) coset_fill_powers_kernel(fp_words* __restrict__ table, CosetShifts c, uint32_t log_n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i >> log_n) return;
+  f29_store_canonical<P>(table + ((size_t)b << log_n) + i, f29_pow_u64<P>(f29_words_to_r261<P>(c.c[b]), i));
+}
+hipError_t coset_fill_powers(fp_words* table, const words8* c, uint32_t nc, uint32_t log_n, hipStream_t stream) {
+  if (nc == 0 || nc > MAX_COSETS) return hipErrorInvalidValue;
+  CosetShifts sh{};
+  for (uint32_t b = 0; b < nc; b++) std::memcpy(sh.c[b], c[b].l, 32);
+  const uint32_t n = 1u << log_n;
+  coset_fill_powers_kernel<<<dim3((n + 255) / 256, nc), 256, 0, stream>>>(table, sh, log_n);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) coset_scale_kernel(CosetScaleArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> a.log_n) return;
+  const f29 x = ld(a.in[blockIdx.y], i);                       // x~, bound < 6 for any 256-bit word value
+  fp_words* __restrict__ out = a.out[blockIdx.y];
+  for (uint32_t b = 0; b < a.nc; b++) {
+    const size_t at = ((size_t)b << a.log_n) + i;
+    f29_store_canonical<P>(out + at, f29_mul<P>(x, ld(a.table, at)));   // x~ * (c^i)^ * 2^-261 = (x c^i)~
+  }
+}
+hipError_t coset_scale(const CosetScaleArgs& a, uint32_t count, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  if (count > COSET_BATCH_MAX || a.nc == 0 || a.nc > MAX_COSETS) return hipErrorInvalidValue;
+  const uint32_t n = 1u << a.log_n;
+  coset_scale_kernel<<<dim3((n + 255) / 256, count), 256, 0, stream>>>(a);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) {
+  __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
+  const uint32_t tid = threadIdx.x;
+  if (tid < a.nc * a.nc) {
+    const f29 v = f29_words_to_r261<P>(a.m[(tid / a.nc) * MAX_COSETS + tid % a.nc]);
+#pragma unroll
+    for (int q = 0; q < 9; q++) sm[tid][q] = v.l[q];
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + tid;
+  if (i >> a.log_n) return;
+  f29 p[MAX_COSETS];
+  for (uint32_t b = 0; b < a.nc; b++) {
+    const size_t at = ((size_t)b << a.log_n) + i;
+    p[b] = f29_mul<P>(ld(a.raw, at), ld(a.table_inv, at));     // (raw c^-i)~, < 2
+  }
+  const f29 one_hat = f29_one<P>();
+  for (uint32_t t = 0; t < a.nc; t++) {
+    auto mt = [&](uint32_t b) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sm[t * a.nc + b][q]; return r; };
+    f29 acc = f29_mul<P>(p[0], mt(0));
+    for (uint32_t b = 1; b < a.nc; b++) acc = f29_mul2<P>(p[b], mt(b), acc, one_hat);   // + p_b m_tb, one reduction each
+    f29_store_canonical<P>(a.pieces[t] + i, acc);
+  }
+}
+hipError_t coset_combine(const CosetCombineArgs& a, hipStream_t stream) {
+  if (a.nc == 0 || a.nc > MAX_COSETS) return hipErrorInvalidValue;
+  const uint32_t n = 1u << a.log_n;
+  coset_combine_kernel<<<(n + 255) / 256, 256, 0, stream>>>(a);
+  return hipGetLastError();
 }
 
 hipError_t quotient_permutation(const QuotPermArgs& a, hipStream_t stream) {

@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "host_curve.h"
@@ -146,6 +147,13 @@ struct Context {
   // that the calls are asynchronous -- work on one stream is ordered, other streams own other buffers
   std::map<std::pair<hipStream_t, int>, DevBuf<uint8_t>> stream_scratch;
   DomainConsts* d_consts = nullptr;
+  struct CosetTables {       // sg_coeff_to_cosets / sg_cosets_to_pieces: per (k, ext_k, cosets)
+    fp_words* fwd = nullptr;  // [nc][n] c_b^i   (2^261-domain words)
+    fp_words* inv = nullptr;  // [nc][n] c_b^-i
+    words8 shift[MAX_COSETS]; // c_b = zeta omega_ext^b
+    uint32_t m[MAX_COSETS * MAX_COSETS][8];   // V^-1 diag(1 / (c_b^n - 1)), row-major [t][b]
+  };
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, CosetTables> coset_tables;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
 };
@@ -978,6 +986,162 @@ int sg_extended_to_coeff(uint8_t* ext, uint32_t k, uint32_t ext_k) {
   return download(ext, a, bytes, g_ctx->stream);
 }
 
+// ------------------------------------------------------------------ the quotient on d cosets (quotient.h)
+static int coset_tables_for(uint32_t k, uint32_t ext_k, uint32_t nc, const Context::CosetTables** out) {
+  using summa::prover::Fr;
+  Context& c = *g_ctx;
+  const auto key = std::make_tuple(k, ext_k, nc);
+  auto it = c.coset_tables.find(key);
+  if (it == c.coset_tables.end()) {
+    const DomainConsts *dk, *de;
+    TRY(get_consts(k, &dk));
+    TRY(get_consts(ext_k, &de));
+    Context::CosetTables t;
+    Fr zeta, w_ext;
+    std::memcpy(zeta.l, &dk->zeta, 32);
+    std::memcpy(w_ext.l, &de->omega, 32);
+    std::vector<Fr> shift(nc), gamma(nc);
+    words8 inv_shift[MAX_COSETS];
+    const uint64_t n_limbs[4] = {(uint64_t)1 << k, 0, 0, 0};
+    for (uint32_t b = 0; b < nc; b++) {
+      shift[b] = zeta * w_ext.pow((uint64_t)b);
+      gamma[b] = shift[b].pow(n_limbs);
+      std::memcpy(&t.shift[b], shift[b].l, 32);
+      const Fr si = shift[b].inv();
+      std::memcpy(&inv_shift[b], si.l, 32);
+    }
+    // V[b][t] = gamma_b^t; inverse by Gauss-Jordan on [V | I] (the gammas are distinct: the cosets differ)
+    std::vector<std::vector<Fr>> a(nc, std::vector<Fr>(2 * nc, Fr::zero()));
+    for (uint32_t b = 0; b < nc; b++) {
+      Fr pw = Fr::one();
+      for (uint32_t tt = 0; tt < nc; tt++) {
+        a[b][tt] = pw;
+        pw = pw * gamma[b];
+      }
+      a[b][nc + b] = Fr::one();
+    }
+    for (uint32_t col = 0; col < nc; col++) {
+      uint32_t piv = col;
+      while (piv < nc && a[piv][col] == Fr::zero()) piv++;
+      if (piv == nc) return fail(SG_ERR_INVALID, "cosets: singular Vandermonde matrix");
+      std::swap(a[piv], a[col]);
+      const Fr inv = a[col][col].inv();
+      for (auto& v : a[col]) v = v * inv;
+      for (uint32_t r = 0; r < nc; r++) {
+        if (r == col || a[r][col] == Fr::zero()) continue;
+        const Fr f = a[r][col];
+        for (uint32_t q = 0; q < 2 * nc; q++) a[r][q] = a[r][q] - f * a[col][q];
+      }
+    }
+    std::memset(t.m, 0, sizeof(t.m));
+    for (uint32_t b = 0; b < nc; b++) {
+      const Fr d = gamma[b] - Fr::one();
+      if (d == Fr::zero()) return fail(SG_ERR_INVALID, "cosets: a coset inside the domain");
+      const Fr di = d.inv();
+      for (uint32_t tt = 0; tt < nc; tt++) {
+        const Fr v = a[tt][nc + b] * di;        // V^-1[t][b] / (gamma_b - 1)
+        std::memcpy(t.m[tt * MAX_COSETS + b], v.l, 32);
+      }
+    }
+    const size_t n = (size_t)1 << k;
+    CHECK_HIP(hipMalloc(&t.fwd, sizeof(fp_words) * n * nc), "coset tables");
+    CHECK_HIP(hipMalloc(&t.inv, sizeof(fp_words) * n * nc), "coset tables");
+    hipError_t e = coset_fill_powers(t.fwd, t.shift, nc, k, c.stream);
+    if (e == hipSuccess) e = coset_fill_powers(t.inv, inv_shift, nc, k, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) return hip_fail("coset tables", e);
+    it = c.coset_tables.emplace(key, t).first;
+  }
+  *out = &it->second;
+  return SG_OK;
+}
+static bool coset_shape_ok(uint32_t k, uint32_t ext_k, uint32_t nc) {
+  return k >= 1 && ext_k > k && ext_k <= 28 && nc >= 1 && nc <= MAX_COSETS && nc <= (1u << (ext_k - k));
+}
+// size-2^k transforms of `count` vectors in place (forward: omega, no scale; inverse: omega^-1, 2^-k)
+static int coset_ntts(fp_words* const* ptrs, size_t count, uint32_t k, bool inverse, hipStream_t s) {
+  Context& c = *g_ctx;
+  const DomainConsts* dk;
+  TRY(get_consts(k, &dk));
+  const size_t n = (size_t)1 << k;
+  if (k <= 18) {
+    const bool need_scratch = k > c.ntt.config().max_single_log;
+    for (size_t first = 0; first < count; first += NTT_BATCH_MAX) {
+      const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - first);
+      uint8_t* scr = nullptr;
+      if (need_scratch) {
+        hipError_t e = scratch_for(s, 3, (size_t)NTT_BATCH_MAX * n * 32, &scr);
+        if (e != hipSuccess) return hip_fail("ntt scratch", e);
+      }
+      hipError_t e = c.ntt.transform_batch(ptrs + first, cnt, reinterpret_cast<fp_words*>(scr), k, inverse ? dk->omega_inv : dk->omega,
+                                           inverse ? &dk->n_inv : nullptr, s);
+      if (e != hipSuccess) return hip_fail("coset ntt batch", e);
+    }
+    return SG_OK;
+  }
+  for (size_t i = 0; i < count; i++)
+    TRY(ntt_dev(ptrs[i], n, ptrs[i], k, inverse ? dk->omega_inv : dk->omega, inverse ? &dk->n_inv : nullptr, nullptr, nullptr, s));
+  return SG_OK;
+}
+int sg_coeff_to_cosets_batch_dev(const void* const* d_coeffs, void* const* d_out, size_t count, uint32_t k, uint32_t ext_k,
+                                 uint32_t n_cosets, void* stream) {
+  if ((count && (!d_coeffs || !d_out)) || !coset_shape_ok(k, ext_k, n_cosets)) return fail(SG_ERR_INVALID, "sg_coeff_to_cosets_batch: bad argument");
+  for (size_t i = 0; i < count; i++)
+    if (!d_coeffs[i] || !d_out[i] || d_coeffs[i] == d_out[i]) return fail(SG_ERR_INVALID, "sg_coeff_to_cosets_batch: bad vector");
+  LOCKED_CTX();
+  const Context::CosetTables* t;
+  TRY(coset_tables_for(k, ext_k, n_cosets, &t));
+  hipStream_t s = pick_stream(stream);
+  TRY(sync_own_stream_into(s));
+  const size_t n = (size_t)1 << k;
+  std::vector<fp_words*> blocks;
+  for (size_t first = 0; first < count; first += COSET_BATCH_MAX) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(COSET_BATCH_MAX, count - first);
+    CosetScaleArgs a{};
+    for (uint32_t j = 0; j < cnt; j++) {
+      a.in[j] = static_cast<const fp_words*>(d_coeffs[first + j]);
+      a.out[j] = static_cast<fp_words*>(d_out[first + j]);
+      for (uint32_t b = 0; b < n_cosets; b++) blocks.push_back(a.out[j] + b * n);
+    }
+    a.table = t->fwd;
+    a.log_n = k;
+    a.nc = n_cosets;
+    hipError_t e = coset_scale(a, cnt, s);
+    if (e != hipSuccess) return hip_fail("coset scale", e);
+  }
+  return coset_ntts(blocks.data(), blocks.size(), k, false, s);
+}
+int sg_cosets_to_pieces_dev(void* d_values, void* const* d_pieces, uint32_t k, uint32_t ext_k, uint32_t n_cosets, void* stream) {
+  if (!d_values || !d_pieces || !coset_shape_ok(k, ext_k, n_cosets)) return fail(SG_ERR_INVALID, "sg_cosets_to_pieces: bad argument");
+  for (uint32_t t = 0; t < n_cosets; t++)
+    if (!d_pieces[t]) return fail(SG_ERR_INVALID, "sg_cosets_to_pieces: null piece");
+  LOCKED_CTX();
+  const Context::CosetTables* t;
+  TRY(coset_tables_for(k, ext_k, n_cosets, &t));
+  hipStream_t s = pick_stream(stream);
+  TRY(sync_own_stream_into(s));
+  const size_t n = (size_t)1 << k;
+  fp_words* v = static_cast<fp_words*>(d_values);
+  std::vector<fp_words*> blocks;
+  for (uint32_t b = 0; b < n_cosets; b++) blocks.push_back(v + b * n);
+  TRY(coset_ntts(blocks.data(), blocks.size(), k, true, s));
+  CosetCombineArgs a{};
+  a.raw = v;
+  for (uint32_t i = 0; i < n_cosets; i++) {
+    a.pieces[i] = static_cast<fp_words*>(d_pieces[i]);
+    const uint8_t* lo = reinterpret_cast<const uint8_t*>(a.pieces[i]);
+    const uint8_t* vb = reinterpret_cast<const uint8_t*>(v);
+    if (lo < vb + 32 * n * n_cosets && vb < lo + 32 * n) return fail(SG_ERR_INVALID, "sg_cosets_to_pieces: the pieces may not overlap the values");
+  }
+  a.table_inv = t->inv;
+  a.log_n = k;
+  a.nc = n_cosets;
+  std::memcpy(a.m, t->m, sizeof(a.m));
+  hipError_t e = coset_combine(a, s);
+  if (e != hipSuccess) return hip_fail("coset combine", e);
+  return SG_OK;
+}
+
 static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_words** out) {
   Context& c = *g_ctx;
   uint64_t key = ((uint64_t)k << 32) | ext_k;
@@ -1493,11 +1657,12 @@ int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_
 }
 
 // ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
-int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
-                                const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
-                                const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
-                                const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
-                                uint32_t last_rotation_abs, void* stream) {
+// coset < 0: the whole extended domain (row i = zeta omega_ext^i); coset = b: the 2^k rows of the coset zeta omega_ext^b H
+static int quotient_permutation_impl(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                     const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                     const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                     const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                     uint32_t last_rotation_abs, int coset, void* stream) {
   if (!d_values || !d_z || !d_cols || !d_sigma || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !y)
     return fail(SG_ERR_INVALID, "sg_quotient_permutation: null argument");
   if (k == 0 || ext_k < k || ext_k > 28 || nsets == 0 || nsets > QUOT_MAX_SETS || ncols == 0 ||
@@ -1521,21 +1686,46 @@ int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t
   a.l0 = static_cast<const fp_words*>(d_l0);
   a.l_last = static_cast<const fp_words*>(d_l_last);
   a.l_active = static_cast<const fp_words*>(d_l_active);
-  a.nsets = nsets; a.ncols = ncols; a.chunk_len = chunk_len; a.k = k; a.ext_k = ext_k;
+  a.nsets = nsets; a.ncols = ncols; a.chunk_len = chunk_len; a.k = k; a.ext_k = coset < 0 ? ext_k : k;
   a.last_rot_abs = last_rotation_abs;
   const DomainConsts *dk, *de;
   TRY(get_consts(k, &dk));
   TRY(get_consts(ext_k, &de));
   std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
   std::memcpy(a.delta, DELTA_M, 32); std::memcpy(a.zeta, &dk->zeta, 32); std::memcpy(a.omega_ext, &de->omega, 32);
+  if (coset >= 0) {   // the kernel's "extended domain" is the 2^k domain shifted by c_b = zeta omega_ext^b
+    summa::prover::Fr z, w;
+    std::memcpy(z.l, &dk->zeta, 32);
+    std::memcpy(w.l, &de->omega, 32);
+    const summa::prover::Fr shift = z * w.pow((uint64_t)coset);
+    std::memcpy(a.zeta, shift.l, 32);
+    std::memcpy(a.omega_ext, &dk->omega, 32);
+  }
   hipStream_t s = pick_stream(stream);
   fp_words* pw = nullptr;
-  hipError_t e = g_ctx->ntt.local_twiddles(de->omega, 9, s, &pw);   // omega_ext^t, t < 256
+  hipError_t e = g_ctx->ntt.local_twiddles(coset < 0 ? de->omega : dk->omega, 9, s, &pw);   // omega_ext^t, t < 256
   if (e != hipSuccess) return hip_fail("quotient twiddles", e);
   a.pow_lo = pw;
   e = quotient_permutation(a, s);
   if (e != hipSuccess) return hip_fail("quotient_permutation", e);
   return SG_OK;
+}
+int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                uint32_t last_rotation_abs, void* stream) {
+  return quotient_permutation_impl(d_values, d_z, nsets, d_cols, d_sigma, ncols, chunk_len, d_l0, d_l_last, d_l_active, beta, gamma, y, k,
+                                   ext_k, last_rotation_abs, -1, stream);
+}
+int sg_quotient_permutation_coset_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                      const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                      const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                      const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                      uint32_t coset, uint32_t last_rotation_abs, void* stream) {
+  if (ext_k <= k || ext_k > 28 || coset >= (1u << (ext_k - k))) return fail(SG_ERR_INVALID, "sg_quotient_permutation_coset: bad coset");
+  return quotient_permutation_impl(d_values, d_z, nsets, d_cols, d_sigma, ncols, chunk_len, d_l0, d_l_last, d_l_active, beta, gamma, y, k,
+                                   ext_k, last_rotation_abs, (int)coset, stream);
 }
 int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
                            const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,

@@ -99,6 +99,37 @@ class EvaluationDomain:
                                                                C.c_uint32(self.extended_k), ffi.current_stream_ptr()))
         return outs
 
+    def coeff_to_cosets_batch(self, polys, n_cosets: int | None = None):
+        """the device polynomials on the first `n_cosets` (default: quotient_poly_degree) cosets of the extended domain,
+        coset-major: out[b * n + a] = f(zeta * omega_ext^b * omega^a) = coeff_to_extended(f)[a * 2^(extended_k - k) + b]
+        (sg_coeff_to_cosets_batch_dev: the rows the quotient really needs)"""
+        import torch
+        nc = self.quotient_poly_degree if n_cosets is None else n_cosets
+        m = len(polys)
+        for p in polys:
+            if not _is_torch_cuda(p) or p.numel() != 32 << self.k:
+                raise ValueError("coeff_to_cosets_batch: device tensors of 2^k elements expected")
+        outs = [torch.empty(32 * nc * self.n, dtype=torch.uint8, device=p.device) for p in polys]
+        if m:
+            pin = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
+            pout = (C.c_void_p * m)(*[o.data_ptr() for o in outs])
+            ffi.check(ffi.lib().sg_coeff_to_cosets_batch_dev(pin, pout, C.c_size_t(m), C.c_uint32(self.k), C.c_uint32(self.extended_k),
+                                                             C.c_uint32(nc), ffi.current_stream_ptr()))
+        return outs
+
+    def cosets_to_pieces(self, values, n_cosets: int | None = None):
+        """the quotient's pieces h_0 .. h_{d-1} (d device tensors of n coefficients) from the coset-major values of its
+        NUMERATOR on d cosets (destroyed): division by X^n - 1 included (sg_cosets_to_pieces_dev)"""
+        import torch
+        nc = self.quotient_poly_degree if n_cosets is None else n_cosets
+        if not _is_torch_cuda(values) or values.numel() != 32 * nc * self.n:
+            raise ValueError("cosets_to_pieces: n_cosets * 2^k values expected")
+        pieces = [torch.empty(32 * self.n, dtype=torch.uint8, device=values.device) for _ in range(nc)]
+        pp = (C.c_void_p * nc)(*[q.data_ptr() for q in pieces])
+        ffi.check(ffi.lib().sg_cosets_to_pieces_dev(ffi.dev_ptr(values), pp, C.c_uint32(self.k), C.c_uint32(self.extended_k), C.c_uint32(nc),
+                                                    ffi.current_stream_ptr()))
+        return pieces
+
     def extended_to_coeff(self, a):
         """inverse of coeff_to_extended, truncated to n * quotient_poly_degree coefficients."""
         L = ffi.lib()

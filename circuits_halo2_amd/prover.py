@@ -17,6 +17,8 @@ same constraint system with its own fixed columns and checks the proof with the 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import arithmetic as A
@@ -199,8 +201,13 @@ class ProvingKey:
     """fixed and permutation columns in the three bases halo2's pk keeps (Lagrange, coefficients, extended coset),
     the Lagrange selector polynomials l0 / l_last / l_active, and the verifying key's commitments"""
 
-    def __init__(self, params, k: int, fixed_lagrange, sigma_lagrange, n_currencies: int = 2):
+    def __init__(self, params, k: int, fixed_lagrange, sigma_lagrange, n_currencies: int = 2, quotient_domain: str | None = None):
         import torch
+        # where the quotient is evaluated: "cosets" = the first degree - 1 cosets of the extended domain (all that h
+        # needs; include/summa_gpu.h: sg_coeff_to_cosets_batch_dev), "extended" = halo2's whole extended domain
+        self.quotient_domain = quotient_domain or os.environ.get("SUMMA_QUOTIENT_DOMAIN", "cosets")
+        if self.quotient_domain not in ("cosets", "extended"):
+            raise ValueError("quotient_domain: cosets or extended")
         self.k, self.n = k, 1 << k
         self.n_currencies = n_currencies          # one sum gate per currency in the gate program
         self.dom = EvaluationDomain(M.DEGREE, k)
@@ -214,7 +221,7 @@ class ProvingKey:
         sel = [_head([1], n), l_last, torch.cat([one.repeat(u), torch.zeros(32 * (n - u), dtype=torch.uint8, device="cuda")])]
         cols = self.fixed_lagrange + self.sigma_lagrange + sel
         coeff = A.best_fft_batch([c.clone() for c in cols], self.dom.get_omega_inv(), k, divisor=self.dom.ifft_divisor())
-        ext = self.dom.coeff_to_extended_batch(coeff)
+        ext = (self.dom.coeff_to_cosets_batch if self.quotient_domain == "cosets" else self.dom.coeff_to_extended_batch)(coeff)
         nf, ns = M.NUM_FIXED, len(sigma_lagrange)
         self.fixed_coeff, self.sigma_coeff = coeff[:nf], coeff[nf:nf + ns]
         self.fixed_ext, self.sigma_ext = ext[:nf], ext[nf:nf + ns]
@@ -375,7 +382,9 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     adv_coeff = to_coeff(advice + [instance_col])
     for j in range(3):
         polys[("a", j)] = adv_coeff[j]
-    ext1 = dom.coeff_to_extended_batch(adv_coeff)
+    on_cosets = pk.quotient_domain == "cosets"
+    to_ext = dom.coeff_to_cosets_batch if on_cosets else dom.coeff_to_extended_batch
+    ext1 = to_ext(adv_coeff)
     adv_ext, inst_ext = ext1[:3], ext1[3]
 
     lap("1_advice")
@@ -424,27 +433,47 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     b_y = _fr_bytes(y)
     co3 = to_coeff([pin_d, ptab_d] + zs + [lz])
     polys[("pin", 0)], polys[("ptab", 0)], polys[("z", 0)], polys[("z", 1)], polys[("lz", 0)] = co3
-    pin_ext, ptab_ext, z0_ext, z1_ext, lz_ext = dom.coeff_to_extended_batch(co3)
+    pin_ext, ptab_ext, z0_ext, z1_ext, lz_ext = to_ext(co3)
 
     lap("3_grand_products")
     # -- 4: quotient: evaluate_h over the extended coset, / (X^n - 1), back to coefficients, five pieces
-    values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k,
-                     ext_k)
     col_ext = {(A.ADVICE, j): adv_ext[j] for j in range(3)}
     col_ext.update({(A.FIXED, j): pk.fixed_ext[j] for j in range(M.NUM_FIXED)})
     col_ext[(A.INSTANCE, 0)] = inst_ext
-    A.quotient_permutation(values, [z0_ext, z1_ext], [col_ext[c] for c in M.PERMUTATION_COLUMNS], pk.sigma_ext,
-                           M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext, pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k,
-                           M.BLINDING_FACTORS + 1)
-    input_ext = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(input_ext, M.lookup_input_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta,
-                     b_gamma, b_theta, b_y, k, ext_k)
-    A.quotient_lookup(values, lz_ext, pin_ext, ptab_ext, input_ext, pk.fixed_ext[4], pk.l0_ext, pk.l_last_ext, pk.l_active_ext,
-                      b_beta, b_gamma, b_y, k, ext_k)
-    dom.divide_by_vanishing_poly(values)
-    h = dom.extended_to_coeff(values)
-    pieces = [h[32 * n * i:32 * n * (i + 1)].clone() for i in range(M.DEGREE - 1)]
+    perm_cols = [col_ext[c] for c in M.PERMUTATION_COLUMNS]
+    if on_cosets:
+        # deg h < 5 n: its values on 5 cosets of the 2^k domain determine it; every kernel runs coset by coset on 2^k rows
+        # (a rotation is an index shift of 1 there), and the pieces come straight out of sg_cosets_to_pieces_dev
+        d = dom.quotient_poly_degree
+        values = torch.zeros(32 * n * d, dtype=torch.uint8, device="cuda")
+        input_c = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+        for b in range(d):
+            blk = lambda t: t[32 * n * b:32 * n * (b + 1)]
+            v = blk(values)
+            fixed_b, adv_b, inst_b = [blk(t) for t in pk.fixed_ext], [blk(t) for t in adv_ext], [blk(inst_ext)]
+            A.quotient_gates(v, M.gate_graph(pk.n_currencies), fixed_b, adv_b, inst_b, M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k, k)
+            A.quotient_permutation_coset(v, [blk(z0_ext), blk(z1_ext)], [blk(t) for t in perm_cols], [blk(t) for t in pk.sigma_ext],
+                                         M.PERMUTATION_CHUNK, blk(pk.l0_ext), blk(pk.l_last_ext), blk(pk.l_active_ext), b_beta, b_gamma, b_y,
+                                         k, ext_k, b, M.BLINDING_FACTORS + 1)
+            input_c.zero_()
+            A.quotient_gates(input_c, M.lookup_input_graph(), fixed_b, adv_b, inst_b, none, b_beta, b_gamma, b_theta, b_y, k, k)
+            A.quotient_lookup(v, blk(lz_ext), blk(pin_ext), blk(ptab_ext), input_c, blk(pk.fixed_ext[4]), blk(pk.l0_ext), blk(pk.l_last_ext),
+                              blk(pk.l_active_ext), b_beta, b_gamma, b_y, k, k)
+        pieces = dom.cosets_to_pieces(values)
+    else:
+        values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+        A.quotient_gates(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta,
+                         b_y, k, ext_k)
+        A.quotient_permutation(values, [z0_ext, z1_ext], perm_cols, pk.sigma_ext, M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext,
+                               pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k, M.BLINDING_FACTORS + 1)
+        input_ext = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+        A.quotient_gates(input_ext, M.lookup_input_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta,
+                         b_gamma, b_theta, b_y, k, ext_k)
+        A.quotient_lookup(values, lz_ext, pin_ext, ptab_ext, input_ext, pk.fixed_ext[4], pk.l0_ext, pk.l_last_ext, pk.l_active_ext,
+                          b_beta, b_gamma, b_y, k, ext_k)
+        dom.divide_by_vanishing_poly(values)
+        h = dom.extended_to_coeff(values)
+        pieces = [h[32 * n * i:32 * n * (i + 1)].clone() for i in range(M.DEGREE - 1)]
     for c in params.commit_batch(pieces):
         tr.write_point(_point(c))
     x = tr.squeeze_challenge()

@@ -153,6 +153,20 @@ int sg_extended_to_coeff_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stre
 int sg_divide_by_vanishing_poly(uint8_t* ext, uint32_t k, uint32_t ext_k);
 int sg_divide_by_vanishing_poly_dev(void* d_ext, uint32_t k, uint32_t ext_k, void* stream);
 
+/* ---- the quotient on quotient-degree many cosets instead of the whole extended domain (used by the library's own prover;
+ * the halo2-layout calls above stay for callers that keep halo2's evaluate_h).  deg h < d * 2^k (d = cs.degree() - 1), so h is
+ * determined by its values on d cosets of the 2^k domain H; halo2's extended domain of 2^ext_k points is 2^(ext_k - k) such
+ * cosets, c_b H with c_b = zeta * omega_ext^b, and the first d of them are used.  Layout "coset-major":
+ *   out[b * 2^k + a] = f(c_b * omega^a)  =  element a * 2^(ext_k - k) + b of sg_coeff_to_extended's output.
+ * A rotation by omega^r is an index shift of r inside a block.  On a coset X^n is the constant c_b^n: the vanishing polynomial
+ * is a constant there, and the values are those of P_b = h mod (X^n - c_b^n) = sum_t c_b^(n t) h_t, so the d pieces h_t (n
+ * coefficients each; what the prover commits to) come from d inverse transforms of size 2^k and a d x d Vandermonde solve per
+ * coefficient.  Same h as extended_to_coeff(divide_by_vanishing_poly(.)) -- it is unique -- from d / 2^(ext_k - k) of the rows. */
+int sg_coeff_to_cosets_batch_dev(const void* const* d_coeffs, void* const* d_out, size_t count, uint32_t k, uint32_t ext_k,
+                                 uint32_t n_cosets, void* stream);
+/* d_values: n_cosets * 2^k coset-major values of the quotient's NUMERATOR (destroyed); d_pieces: n_cosets vectors of 2^k */
+int sg_cosets_to_pieces_dev(void* d_values, void* const* d_pieces, uint32_t k, uint32_t ext_k, uint32_t n_cosets, void* stream);
+
 /* ---- domain constants (EvaluationDomain::new): omega = ROOT_OF_UNITY^(2^(28-k)) etc.
  * which: 0 omega, 1 omega^-1, 2 (2^k)^-1, 3 zeta (Fr::ZETA, the extended-coset shift). */
 int sg_domain_constant(uint32_t k, int which, uint8_t out[32]);
@@ -276,6 +290,12 @@ int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t
                                 const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
                                 const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
                                 uint32_t last_rotation_abs, void* stream);
+/* the same on ONE coset of the coset-major layout: all arrays are that coset's 2^k rows (row a = c_coset * omega^a) */
+int sg_quotient_permutation_coset_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                      const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                      const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                      const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                      uint32_t coset, uint32_t last_rotation_abs, void* stream);
 /* Lookup argument (one lookup; inputs already theta-compressed by the caller):
  *   l0 (1 - z);  l_last (z^2 - z);
  *   l_active (z(omega X)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma));

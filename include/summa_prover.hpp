@@ -578,6 +578,9 @@ struct ProvingKey {
   std::vector<DevCol> fixed_lag, sigma_lag, fixed_coeff, sigma_coeff, fixed_ext, sigma_ext;
   DevCol l0_ext, l_last_ext, l_active_ext;
   uint32_t ext_k() const { return k + 3; }  // degree 6: extended domain 2^(k + 3)
+  // the quotient has degree < QUOTIENT_PIECES * n: it is evaluated on that many cosets of the 2^k domain (the first ones of
+  // the extended domain, coset-major: sg_coeff_to_cosets_batch_dev), not on all 2^(k + 3) points; "ext" columns have this size
+  size_t ext_rows() const { return n * QUOTIENT_PIECES; }
 
   // fixed / sigma: Lagrange-basis device columns (moved in); builds the coefficient and extended-coset forms
   void build(uint32_t k_, uint64_t srs_, std::vector<DevCol>&& fixed, std::vector<DevCol>&& sigma) {
@@ -587,7 +590,7 @@ struct ProvingKey {
     srs = srs_;
     fixed_lag = std::move(fixed);
     sigma_lag = std::move(sigma);
-    const size_t ne = (size_t)1 << ext_k();
+    const size_t ne = ext_rows();
     uint8_t omega_inv[32], n_inv[32];
     ck(sg_domain_constant(k, 1, omega_inv), "domain constant");
     ck(sg_domain_constant(k, 2, n_inv), "domain constant");
@@ -615,7 +618,7 @@ struct ProvingKey {
       for (size_t i = 0; i < pc.size(); i += 16) {   // batched launches hold at most 16 vectors
         const size_t m = std::min<size_t>(16, pc.size() - i);
         ck(sg_ntt_fr_batch_dev(pc.data() + i, m, omega_inv, n_inv, k, main_stream()), "iNTT batch");
-        ck(sg_coeff_to_extended_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), main_stream()), "coset NTT batch");
+        ck(sg_coeff_to_cosets_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), QUOTIENT_PIECES, main_stream()), "coset NTT batch");
       }
     };
     transform(fixed_lag, fixed_coeff, fixed_ext);
@@ -733,7 +736,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     if (a.rows != pk.n || !a.p) throw std::invalid_argument("create_proof: advice columns of 2^k rows expected");
   if (instances.size() > pk.usable) throw std::invalid_argument("create_proof: more instances than usable rows");
   const uint32_t k = pk.k, ext_k = pk.ext_k();
-  const size_t n = pk.n, u = pk.usable, ne = (size_t)1 << ext_k;
+  const size_t n = pk.n, u = pk.usable, ne = pk.ext_rows();
   auto clock = std::chrono::steady_clock::now();
   auto lap = [&](const char* name) {  // per-phase wall clock with the device drained, only when asked for
     if (!timings) return;
@@ -793,7 +796,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       pe.push_back(ext.back().p);
     }
     ck(sg_ntt_fr_batch_dev(pc.data(), pc.size(), omega_inv_b, n_inv_b, k, st), "iNTT batch");
-    ck(sg_coeff_to_extended_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, st), "coset NTT batch");
+    ck(sg_coeff_to_cosets_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, QUOTIENT_PIECES, st), "coset NTT batch");
   };
   auto commit_batch = [&](std::vector<void*> cols, std::vector<int> basis) {
     std::vector<uint8_t> out(64 * cols.size());
@@ -825,9 +828,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   lap("1_advice");
   // -- 2: lookup
   const sg_graph g_in = pk.lookup_input.view(), g_gates = pk.gates.view();
-  std::vector<void*> fixed_lag_p, fixed_ext_p, adv_lag_p = {advice[0].p, advice[1].p, advice[2].p}, inst_lag_p = {instance_col.p};
+  std::vector<void*> fixed_lag_p, adv_lag_p = {advice[0].p, advice[1].p, advice[2].p}, inst_lag_p = {instance_col.p};
   for (auto& c : pk.fixed_lag) fixed_lag_p.push_back(c.p);
-  for (auto& c : pk.fixed_ext) fixed_ext_p.push_back(c.p);
   DevCol inp(n);
   inp.zero();
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
@@ -907,30 +909,37 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
 
   lap("3_grand_products");
   // -- 4: quotient
-  DevCol values(ne), input_ext(ne);
+  // every kernel runs coset by coset on 2^k rows of the coset-major arrays (a rotation is an index shift of 1 inside a block)
+  DevCol values(ne), input_c(n);
   hk(hipMemsetAsync(values.p, 0, 32 * ne, main_stream()), "memset");
-  hk(hipMemsetAsync(input_ext.p, 0, 32 * ne, main_stream()), "memset");
-  std::vector<void*> adv_ext_p = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_ext_p = {ex1[3].p};
   // the gate program folds its second block with y^5 supplied as challenge 0 (mst_inclusion.py: GATE_BLOCKS)
   const Fr y5 = y.pow((uint64_t)5);
-  ck(sg_quotient_gates_dev(values.p, &g_gates, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
-                           y5.bytes(), 1, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, main_stream()), "gates");
-  std::vector<void*> col_ext, sig_ext, z_ext = {ex3[2].p, ex3[3].p};
-  for (uint32_t c = 0; c < NUM_SIGMA; c++) {
-    col_ext.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
-    sig_ext.push_back(pk.sigma_ext[c].p);
+  std::vector<DevCol> pieces_col;
+  for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces_col.emplace_back(n);
+  for (uint32_t b = 0; b < QUOTIENT_PIECES; b++) {
+    auto blk = [&](void* p) { return static_cast<void*>(static_cast<uint8_t*>(p) + 32 * n * b); };
+    std::vector<void*> fixed_b, adv_b = {blk(ex1[0].p), blk(ex1[1].p), blk(ex1[2].p)}, inst_b = {blk(ex1[3].p)};
+    for (auto& c : pk.fixed_ext) fixed_b.push_back(blk(c.p));
+    void* v = blk(values.p);
+    ck(sg_quotient_gates_dev(v, &g_gates, fixed_b.data(), NUM_FIXED, adv_b.data(), NUM_ADVICE, inst_b.data(), 1, y5.bytes(), 1,
+                             beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, k, main_stream()), "gates");
+    std::vector<void*> col_b, sig_b, z_b = {blk(ex3[2].p), blk(ex3[3].p)};
+    for (uint32_t c = 0; c < NUM_SIGMA; c++) {
+      col_b.push_back(blk(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p));
+      sig_b.push_back(blk(pk.sigma_ext[c].p));
+    }
+    ck(sg_quotient_permutation_coset_dev(v, z_b.data(), 2, col_b.data(), sig_b.data(), NUM_SIGMA, CHUNK, blk(pk.l0_ext.p), blk(pk.l_last_ext.p),
+                                         blk(pk.l_active_ext.p), beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, b, BLINDING + 1,
+                                         main_stream()), "permutation quotient");
+    ck(sg_quotient_gates_dev(input_c.p, &g_in, fixed_b.data(), NUM_FIXED, adv_b.data(), NUM_ADVICE, inst_b.data(), 1, nullptr, 0,
+                             beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, k, main_stream()), "lookup input (coset)");
+    ck(sg_quotient_lookup_dev(v, blk(ex3[4].p), blk(ex3[0].p), blk(ex3[1].p), input_c.p, blk(pk.fixed_ext[4].p), blk(pk.l0_ext.p),
+                              blk(pk.l_last_ext.p), blk(pk.l_active_ext.p), beta.bytes(), gamma.bytes(), y.bytes(), k, k, main_stream()),
+       "lookup quotient");
   }
-  ck(sg_quotient_permutation_dev(values.p, z_ext.data(), 2, col_ext.data(), sig_ext.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p,
-                                 pk.l_last_ext.p, pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, BLINDING + 1,
-                                 main_stream()), "permutation quotient");
-  ck(sg_quotient_gates_dev(input_ext.p, &g_in, fixed_ext_p.data(), NUM_FIXED, adv_ext_p.data(), NUM_ADVICE, inst_ext_p.data(), 1,
-                           nullptr, 0, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, main_stream()), "lookup input (ext)");
-  ck(sg_quotient_lookup_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_ext.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
-                            pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, main_stream()), "lookup quotient");
-  ck(sg_divide_by_vanishing_poly_dev(values.p, k, ext_k, main_stream()), "divide by vanishing");
-  ck(sg_extended_to_coeff_dev(values.p, k, ext_k, main_stream()), "extended_to_coeff");
   std::vector<void*> pieces;
-  for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces.push_back(values.at(n * i));
+  for (auto& c : pieces_col) pieces.push_back(c.p);
+  ck(sg_cosets_to_pieces_dev(values.p, pieces.data(), k, ext_k, QUOTIENT_PIECES, main_stream()), "cosets_to_pieces");
   commit_batch(pieces, std::vector<int>(QUOTIENT_PIECES, 0));
   const Fr x = tr.squeeze();
   const uint64_t n_limbs[4] = {n, 0, 0, 0};

@@ -1263,14 +1263,10 @@ def test_quotient_shape_errors(gpu, O):
         quotient_permutation(t()[:64], [t()], [t()], [t()], 2, t(), t(), t(), b, b, b, k, ext_k, 6)
 
 
-@pytest.mark.parametrize("k,ncols,chunk_len", [(8, 6, 2), (12, 6, 4)])
-def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
-    """whole h(X) pipeline on the device with a witness that satisfies both arguments: grand products
-    -> iNTT -> coset NTT -> numerator -> / (X^n - 1) -> coset iNTT; the quotient is a polynomial of the
-    expected degree (top coefficients vanish), identical to the oracle's, and a tampered witness is caught"""
-    import torch
+def _pipeline_inputs(O, k, ncols, chunk_len):
+    """a witness that satisfies a permutation argument, a lookup argument and one custom gate, as Lagrange columns, their
+    extended-coset evaluations on the device, and the gate's program"""
     import quotient_witness as W
-    from circuits_halo2_amd.arithmetic import quotient_lookup, quotient_permutation
     blinding, n = 5, 1 << k
     ext_k = k + 3 if chunk_len == 4 else k + 2                 # degree 6 (MstInclusion's) / degree 4
     ne = 1 << ext_k
@@ -1299,6 +1295,24 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     gate = graph.add_calculation(A.MUL, graph.query(A.FIXED, 0, 0),
                                  graph.add_calculation(A.SUB, prod, graph.query(A.ADVICE, 2, 0)))
     graph.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), (A.Y, 0, 0), [gate])
+    return locals()
+
+
+@pytest.mark.parametrize("k,ncols,chunk_len", [(8, 6, 2), (12, 6, 4)])
+def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
+    """whole h(X) pipeline on the device with a witness that satisfies both arguments: grand products
+    -> iNTT -> coset NTT -> numerator -> / (X^n - 1) -> coset iNTT; the quotient is a polynomial of the
+    expected degree (top coefficients vanish), identical to the oracle's, and a tampered witness is caught"""
+    import torch
+    import quotient_witness as W
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.arithmetic import quotient_lookup, quotient_permutation
+    ctx = _pipeline_inputs(O, k, ncols, chunk_len)
+    (blinding, n, ext_k, ne, beta, gamma, y, theta, graph, dom, l0, l_last, l_active, zs, cols, sigmas, z, ap, sp, a, s, ga, gb, gc, gq,
+     e_l0, e_ll, e_la, e_zs, e_cols, e_sig, e_z, e_ap, e_sp, e_a, e_s, e_ga, e_gb, e_gc, e_gq) = (ctx[v] for v in (
+        "blinding", "n", "ext_k", "ne", "beta", "gamma", "y", "theta", "graph", "dom", "l0", "l_last", "l_active", "zs", "cols", "sigmas",
+        "z", "ap", "sp", "a", "s", "ga", "gb", "gc", "gq", "e_l0", "e_ll", "e_la", "e_zs", "e_cols", "e_sig", "e_z", "e_ap", "e_sp",
+        "e_a", "e_s", "e_ga", "e_gb", "e_gc", "e_gq"))
     values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
     gate_args = ([e_gq], [e_ga, e_gb, e_gc], [], np.zeros(0, dtype=np.uint8), beta, gamma, theta, y, k, ext_k)
     A.quotient_gates(values, graph, *gate_args)                       # halo2's order: gates, permutation, lookups
@@ -1364,6 +1378,62 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     dom.divide_by_vanishing_poly(values)
     dom.extended_to_coeff(values)
     assert not W.top_coefficients_zero(h(values), first_zero)
+
+
+@pytest.mark.parametrize("k,ncols,chunk_len", [(6, 6, 4), (8, 6, 2), (12, 6, 4)])
+def test_quotient_on_cosets_equals_the_extended_pipeline(gpu, O, k, ncols, chunk_len):
+    """the prover's short cut (sg_coeff_to_cosets / sg_cosets_to_pieces): deg h < d n, so the quotient is computed on the first d =
+    degree - 1 cosets of the extended domain only.  (1) the coset-major transform is the de-interleaved coeff_to_extended
+    (oracle-checked elsewhere), column by column; (2) gates / permutation / lookup folded coset by coset give the extended
+    numerator's rows; (3) the pieces equal extended_to_coeff(divide_by_vanishing_poly(numerator)) coefficient for
+    coefficient."""
+    import torch
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.domain import EvaluationDomain
+    ctx = _pipeline_inputs(O, k, ncols, chunk_len)
+    n, ext_k, ne, blinding = ctx["n"], ctx["ext_k"], ctx["ne"], ctx["blinding"]
+    beta, gamma, y, theta, graph = ctx["beta"], ctx["gamma"], ctx["y"], ctx["theta"], ctx["graph"]
+    deg = max(chunk_len + 2, 4)
+    dom = EvaluationDomain(deg, k)
+    d, stride = dom.quotient_poly_degree, 1 << (ext_k - k)
+    assert dom.extended_k == ext_k and d == deg - 1
+    names = ["l0", "l_last", "l_active", "z", "ap", "sp", "a", "s", "ga", "gb", "gc", "gq"]
+    lag = [ctx[v] for v in names] + list(ctx["zs"]) + list(ctx["cols"]) + list(ctx["sigmas"])
+    ext = [ctx[v] for v in ("e_l0", "e_ll", "e_la", "e_z", "e_ap", "e_sp", "e_a", "e_s", "e_ga", "e_gb", "e_gc", "e_gq")] + \
+        list(ctx["e_zs"]) + list(ctx["e_cols"]) + list(ctx["e_sig"])
+    coeffs = [dom.lagrange_to_coeff(dev(c)) for c in lag]
+    cos = dom.coeff_to_cosets_batch(coeffs)
+    for cm, e in zip(cos, ext):                                   # (1)
+        want = e.view(n, stride, 32)[:, :d, :].permute(1, 0, 2).reshape(-1)
+        assert (cm == want).all()
+    assert dom.coeff_to_cosets_batch([]) == []
+    c = dict(zip(names, cos[:len(names)]))
+    nz = len(ctx["zs"])
+    c_zs, c_cols, c_sig = cos[len(names):len(names) + nz], cos[len(names) + nz:len(names) + nz + ncols], cos[len(names) + nz + ncols:]
+    values = torch.zeros(32 * d * n, dtype=torch.uint8, device="cuda")
+    blk = lambda t, b: t[32 * n * b:32 * n * (b + 1)]
+    for b in range(d):                                            # (2)
+        v = blk(values, b)
+        A.quotient_gates(v, graph, [blk(c["gq"], b)], [blk(c[t], b) for t in ("ga", "gb", "gc")], [], np.zeros(0, dtype=np.uint8),
+                         beta, gamma, theta, y, k, k)
+        A.quotient_permutation_coset(v, [blk(t, b) for t in c_zs], [blk(t, b) for t in c_cols], [blk(t, b) for t in c_sig], chunk_len,
+                                     blk(c["l0"], b), blk(c["l_last"], b), blk(c["l_active"], b), beta, gamma, y, k, ext_k, b, blinding + 1)
+        A.quotient_lookup(v, *[blk(c[t], b) for t in ("z", "ap", "sp", "a", "s", "l0", "l_last", "l_active")], beta, gamma, y, k, k)
+    full = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(full, graph, [ctx["e_gq"]], [ctx["e_ga"], ctx["e_gb"], ctx["e_gc"]], [], np.zeros(0, dtype=np.uint8), beta, gamma,
+                     theta, y, k, ext_k)
+    A.quotient_permutation(full, ctx["e_zs"], ctx["e_cols"], ctx["e_sig"], chunk_len, ctx["e_l0"], ctx["e_ll"], ctx["e_la"], beta, gamma,
+                           y, k, ext_k, blinding + 1)
+    A.quotient_lookup(full, ctx["e_z"], ctx["e_ap"], ctx["e_sp"], ctx["e_a"], ctx["e_s"], ctx["e_l0"], ctx["e_ll"], ctx["e_la"], beta,
+                      gamma, y, k, ext_k)
+    assert (values == full.view(n, stride, 32)[:, :d, :].permute(1, 0, 2).reshape(-1)).all()
+    ctx["dom"].divide_by_vanishing_poly(full)                     # (3)
+    want = ctx["dom"].extended_to_coeff(full)[:32 * d * n].clone()
+    pieces = dom.cosets_to_pieces(values)
+    assert len(pieces) == d and want.any()
+    assert (torch.cat(pieces) == want).all()
+    with pytest.raises(ValueError):
+        dom.cosets_to_pieces(values[:64])
 
 
 # ----------------------------------------------------------------------------- witness side (row W)

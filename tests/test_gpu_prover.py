@@ -71,6 +71,32 @@ def test_gpu_proof_is_accepted_by_the_restated_verifier(setup):
         assert not SV.verify(bytes(p), s["asg"]["instances"], s["vk"]), hex(off)
 
 
+def test_quotient_on_cosets_gives_the_same_proof_as_on_the_extended_domain(setup):
+    """the quotient h is unique, so evaluating its numerator on 5 cosets (the product's default) or on halo2's whole
+    extended domain must lead to the same pieces: with the same blinding stream the two proofs are equal byte for byte
+    (both transcript flavours), and so is a proof of a witness whose gates fail (h is then not a polynomial: garbage,
+    but the same garbage is not required -- only the valid case is compared)"""
+    from oracle import summa_verifier as SV
+    s = setup
+    P = s["prover"]
+    assert s["pk"].quotient_domain == "cosets"
+    dev = s["dev"]
+    pk_ext = P.ProvingKey(s["params"], s["k"], [dev(c) for c in s["asg"]["fixed"]], [dev(c) for c in s["asg"]["sigma"]],
+                          quotient_domain="extended")
+    assert pk_ext.vk_digest == s["pk"].vk_digest and pk_ext.fixed_ext[0].numel() == 8 * s["pk"].fixed_ext[0].numel() // 5
+    advice = [dev(c) for c in s["asg"]["advice"]]
+    inst = s["asg"]["instances"]
+    for seed in (31, 32):
+        a = P.create_proof(s["params"], s["pk"], advice, inst, seeded_rng(seed))
+        b = P.create_proof(s["params"], pk_ext, advice, inst, seeded_rng(seed))
+        assert a == b and SV.verify(a, inst, s["vk"])
+    a = P.create_proof(s["params"], s["pk"], advice, inst, seeded_rng(33), transcript=P.Blake2bWrite())
+    b = P.create_proof(s["params"], pk_ext, advice, inst, seeded_rng(33), transcript=P.Blake2bWrite())
+    assert a == b and SV.verify(a, inst, s["vk"], flavour="blake2b")
+    with pytest.raises(ValueError):
+        P.ProvingKey(s["params"], s["k"], [dev(c) for c in s["asg"]["fixed"]], [dev(c) for c in s["asg"]["sigma"]], quotient_domain="x")
+
+
 @pytest.mark.parametrize("what", ["gate", "lookup", "copy"])
 def test_gpu_prover_unsatisfied_assignments(setup, what):
     """a violated gate yields a proof the verifier rejects (the quotient is not a polynomial); violated lookup /
