@@ -183,8 +183,8 @@ def cpu_oplist_baseline(k, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=9)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip NTT / op-list extras")
@@ -192,7 +192,7 @@ def main():
                     help="collective backend for --gpus > 1: nccl (= RCCL, one GPU per rank); gloo rehearses the multi-rank logic on a "
                          "box with fewer GPUs than ranks (host-side collectives, ranks share GPUs round-robin)")
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight per GPU: host threads issuing MSMs (library lanes); 1 = strictly one after the other")
-    ap.add_argument("--batch-proofs", type=int, default=24, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
+    ap.add_argument("--batch-proofs", type=int, default=72, help="k = 17 inclusion proofs per GPU in the batch extra (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -332,23 +332,36 @@ def quotient_permutation(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l
     return values
 
 
-def quotient_permutation_coset(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l_active, beta, gamma, y, k: int,
-                                ext_k: int, coset: int, last_rotation_abs: int):
-    """quotient_permutation on ONE coset of the coset-major layout (EvaluationDomain.coeff_to_cosets_batch): every array
-    is that coset's 2^k rows"""
+def quotient_permutation_cosets(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l_active, beta, gamma, y, k: int,
+                                 ext_k: int, n_cosets: int, last_rotation_abs: int):
+    """quotient_permutation over coset-major arrays (EvaluationDomain.coeff_to_cosets_batch): n_cosets blocks of 2^k rows"""
     ns, m = len(zs), len(cols)
     if len(sigmas) != m:
-        raise ValueError("quotient_permutation_coset: one sigma per column")
+        raise ValueError("quotient_permutation_cosets: one sigma per column")
     for t in [values, l0, l_last, l_active, *zs, *cols, *sigmas]:
-        if t.numel() != 32 << k:
-            raise ValueError("quotient_permutation_coset: every array has 2^k rows")
+        if t.numel() != (32 * n_cosets) << k:
+            raise ValueError("quotient_permutation_cosets: every array has n_cosets * 2^k rows")
     pz = (C.c_void_p * ns)(*[z.data_ptr() for z in zs])
     pc = (C.c_void_p * m)(*[c.data_ptr() for c in cols])
     ps = (C.c_void_p * m)(*[s.data_ptr() for s in sigmas])
-    ffi.check(ffi.lib().sg_quotient_permutation_coset_dev(
+    ffi.check(ffi.lib().sg_quotient_permutation_cosets_dev(
         ffi.dev_ptr(values), pz, C.c_uint32(ns), pc, ps, C.c_uint32(m), C.c_uint32(chunk_len), ffi.dev_ptr(l0),
         ffi.dev_ptr(l_last), ffi.dev_ptr(l_active), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(y)),
-        C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(coset), C.c_uint32(last_rotation_abs), ffi.current_stream_ptr()))
+        C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(n_cosets), C.c_uint32(last_rotation_abs), ffi.current_stream_ptr()))
+    return values
+
+
+def quotient_lookup_cosets(values, z, permuted_input, permuted_table, inp, table, l0, l_last, l_active, beta, gamma, y,
+                           k: int, n_cosets: int):
+    """quotient_lookup over coset-major arrays of n_cosets * 2^k rows"""
+    for t in [values, z, permuted_input, permuted_table, inp, table, l0, l_last, l_active]:
+        if t.numel() != (32 * n_cosets) << k:
+            raise ValueError("quotient_lookup_cosets: every array has n_cosets * 2^k rows")
+    ffi.check(ffi.lib().sg_quotient_lookup_cosets_dev(
+        ffi.dev_ptr(values), ffi.dev_ptr(z), ffi.dev_ptr(permuted_input), ffi.dev_ptr(permuted_table),
+        ffi.dev_ptr(inp), ffi.dev_ptr(table), ffi.dev_ptr(l0), ffi.dev_ptr(l_last), ffi.dev_ptr(l_active),
+        ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(y)), C.c_uint32(k), C.c_uint32(n_cosets),
+        ffi.current_stream_ptr()))
     return values
 
 
@@ -453,6 +466,32 @@ def quotient_gates(values, graph: GraphEvaluator, fixed, advice, instance, chall
         ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(theta)), ffi.ptr(ffi.u8(y)), C.c_uint32(k),
         C.c_uint32(ext_k), ffi.current_stream_ptr()))
     return values
+
+
+def quotient_gates_cosets(values, graph: GraphEvaluator, fixed, advice, instance, challenges, beta, gamma, theta, y, k: int,
+                          n_cosets: int):
+    """quotient_gates over coset-major arrays of n_cosets * 2^k rows (a rotation stays inside its block)"""
+    for t in [values, *fixed, *advice, *instance]:
+        if t.numel() != (32 * n_cosets) << k:
+            raise ValueError("quotient_gates_cosets: every array has n_cosets * 2^k rows")
+    g, keep = graph._struct()
+    arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+    ch = np.ascontiguousarray(challenges, dtype=np.uint8) if len(challenges) else np.zeros(32, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_quotient_gates_cosets_dev(
+        ffi.dev_ptr(values), C.byref(g), arr(fixed), C.c_uint32(len(fixed)), arr(advice), C.c_uint32(len(advice)),
+        arr(instance), C.c_uint32(len(instance)), ffi.ptr(ch), C.c_uint32(len(challenges) // 32 if len(challenges) else 0),
+        ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(theta)), ffi.ptr(ffi.u8(y)), C.c_uint32(k),
+        C.c_uint32(n_cosets), ffi.current_stream_ptr()))
+    return values
+
+
+def gates_program_info(graph: GraphEvaluator, n_fixed: int, n_advice: int, n_instance: int, n_challenges: int):
+    """(instructions per row, simultaneously live values = LDS slots per row) of the interpreter's lowering; host only"""
+    g, keep = graph._struct()
+    n_ops, n_slots = C.c_uint32(0), C.c_uint32(0)
+    ffi.check(ffi.lib().sg_gates_program_info(C.byref(g), C.c_uint32(n_fixed), C.c_uint32(n_advice), C.c_uint32(n_instance),
+                                              C.c_uint32(n_challenges), C.byref(n_ops), C.byref(n_slots)))
+    return n_ops.value, n_slots.value
 
 
 def best_fft_batch(vectors, omega, log_n: int, divisor=None):

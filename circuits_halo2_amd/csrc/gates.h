@@ -34,7 +34,8 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
 
 // d_blob: [ops][column pointers][constants] as laid out by gates_blob(); values updated in place
 size_t gates_blob(const GateProgram& p, const void* const* cols, std::vector<uint8_t>* blob);
+// cosets = 0: arrays of 2^ext_k rows in halo2's extended-domain order; cosets = c: coset-major arrays of c * 2^k rows
 hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_values, uint32_t k, uint32_t ext_k,
-                     hipStream_t stream);
+                     hipStream_t stream, uint32_t cosets = 0);
 
 }  // namespace sg

@@ -36,6 +36,9 @@ struct GateArgs {
   const fp_words* const* cols;
   const uint32_t* consts;  // 8 words each
   uint32_t n_ops, n_consts, n_slots, result_kind, result_index, k, ext_k;
+  // rows of the arrays and the block inside which a rotation wraps: the halo2 layout is ONE block of 2^ext_k rows (a rotation
+  // shifts by r * 2^(ext_k - k)); the coset-major layout is `cosets` blocks of 2^k rows (ext_k = k: a rotation shifts by r)
+  uint64_t rows, blockmask;
 };
 
 template <uint32_t T>
@@ -50,9 +53,9 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
     for (int q = 0; q < 9; q++) s_const[c * 9 + q] = v.l[q];
   }
   __syncthreads();
-  const size_t n_ext = (size_t)1 << a.ext_k, mask = n_ext - 1;
+  const size_t mask = (size_t)a.blockmask;
   const size_t row = (size_t)blockIdx.x * T + tid;
-  if (row >= n_ext) return;
+  if (row >= a.rows) return;
   const uint32_t rot_shift = a.ext_k - a.k;
   auto get = [&](uint32_t kind, uint32_t idx) {
     f29 r;
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
     f29 r;
     switch (code) {
       case G_LOADCOL: {
-        const size_t i = (row + ((size_t)(int64_t)(int32_t)op.b << rot_shift)) & mask;
+        const size_t i = (row & ~mask) | ((row + ((size_t)(int64_t)(int32_t)op.b << rot_shift)) & mask);
         uint32_t w[8];
         fp_words_load(a.cols[op.a] + i, w);
         // kidx 0: memory words shifted left by 5 bits ARE the 2^261 form (bound 32), no product;
@@ -410,7 +413,7 @@ size_t gates_blob(const GateProgram& p, const void* const* cols, std::vector<uin
 }
 
 hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_values, uint32_t k, uint32_t ext_k,
-                     hipStream_t stream) {
+                     hipStream_t stream, uint32_t cosets) {
   GateArgs a;
   a.values = d_values;
   a.ops = reinterpret_cast<const GateOp*>(d_blob);
@@ -421,8 +424,10 @@ hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_va
   a.n_slots = p.n_slots;
   a.result_kind = p.result_kind;
   a.result_index = p.result_index;
-  a.k = k; a.ext_k = ext_k;
-  const size_t n_ext = (size_t)1 << ext_k;
+  a.k = k; a.ext_k = cosets ? k : ext_k;
+  const size_t n_ext = cosets ? (size_t)cosets << k : (size_t)1 << ext_k;
+  a.rows = n_ext;
+  a.blockmask = ((uint64_t)1 << a.ext_k) - 1;
   // rows per workgroup from the LDS budget: (constants + slots * T) * 36 B <= 144 KiB
   const size_t budget = 144 * 1024, cbytes = (size_t)a.n_consts * 36;
   // rows per workgroup: the largest shape that fits (measured: for programs of few slots 256 rows beat 64 rows

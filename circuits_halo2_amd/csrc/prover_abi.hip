@@ -50,10 +50,13 @@ extern "C" {
 const char* sp_last_error(void) { return g_sp_err; }
 
 int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_lagrange, const void* const* d_sigma_lagrange,
-                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input, void* stream,
-                  uint64_t* key_out) {
+                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input,
+                  const uint32_t* gate_challenge_exponents, const uint32_t* gate_challenge_counts, uint32_t n_gate_challenges,
+                  void* stream, uint64_t* key_out) {
   if (!d_fixed_lagrange || !d_sigma_lagrange || !vk_digest_be || !gates || !lookup_input || !key_out || k < 4 || k > 25)
     return sp_fail(SG_ERR_INVALID, "sp_key_create: bad argument");
+  if (n_gate_challenges > 256 || (n_gate_challenges && (!gate_challenge_exponents || !gate_challenge_counts)))
+    return sp_fail(SG_ERR_INVALID, "sp_key_create: bad challenge list");
   for (uint32_t i = 0; i < NUM_FIXED; i++)
     if (!d_fixed_lagrange[i]) return sp_fail(SG_ERR_INVALID, "sp_key_create: null fixed column");
   for (uint32_t i = 0; i < NUM_SIGMA; i++)
@@ -68,6 +71,9 @@ int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_la
     std::memcpy(pk->vk_digest_be, vk_digest_be, 32);
     pk->gates = copy_graph(*gates);
     pk->lookup_input = copy_graph(*lookup_input);
+    pk->gate_challenge_exps.clear();
+    for (uint32_t i = 0, at = 0; i < n_gate_challenges; at += gate_challenge_counts[i], i++)
+      pk->gate_challenge_exps.emplace_back(gate_challenge_exponents + at, gate_challenge_exponents + at + gate_challenge_counts[i]);
     std::vector<DevCol> fixed, sigma;
     auto clone = [&](const void* src) {
       DevCol c(n);

@@ -5,8 +5,8 @@
 #include "msm.h"
 
 namespace sg {
-static constexpr uint32_t QUOT_MAX_SETS = 8, QUOT_MAX_COLS = 16;
-struct QuotPermArgs {  // kernel argument; all arrays 2^ext_k x 32 B, memory (2^256) domain
+static constexpr uint32_t QUOT_MAX_SETS = 8, QUOT_MAX_COLS = 16, QUOT_MAX_COSETS = 8;
+struct QuotPermArgs {  // kernel argument; all arrays 2^ext_k x 32 B (cosets = 0) or cosets x 2^k x 32 B, memory (2^256) domain
   fp_words* values;
   const fp_words* z[QUOT_MAX_SETS];
   const fp_words* cols[QUOT_MAX_COLS];
@@ -17,12 +17,16 @@ struct QuotPermArgs {  // kernel argument; all arrays 2^ext_k x 32 B, memory (2^
   const fp_words* pow_lo;  // omega_ext^t, t < 256, 2^261-domain words (NttEngine local twiddles)
   uint32_t nsets, ncols, chunk_len, k, ext_k, last_rot_abs;
   uint32_t beta[8], gamma[8], y[8], delta[8], zeta[8], omega_ext[8];
+  // coset-major layout (cosets > 0): block b of 2^k rows is the coset shift[b] * H; ext_k = k, omega_ext = omega, zeta unused
+  uint32_t cosets;
+  uint32_t shift[QUOT_MAX_COSETS][8];
 };
 struct QuotLookupArgs {
   fp_words* values;
   const fp_words *z, *permuted_input, *permuted_table, *input, *table, *l0, *l_last, *l_active;
   uint32_t k, ext_k;
   uint32_t beta[8], gamma[8], y[8];
+  uint32_t cosets;   // > 0: coset-major arrays of cosets * 2^k rows (ext_k = k)
 };
 // ---- the quotient on quotient-degree many cosets of the 2^k domain instead of the whole extended domain
 // deg h < d n (d = cs.degree() - 1 = 5 here), so h is determined by its values on d cosets c_b H of the 2^k domain H:

@@ -37,15 +37,20 @@ struct QuotConsts {  // per-launch constants, converted once per workgroup
 __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
   __shared__ uint32_t sc[7][9];
   const uint32_t tid = threadIdx.x;
-  const size_t n_ext = (size_t)1 << a.ext_k;
+  const size_t n_blk = (size_t)1 << a.ext_k;                       // rows per block: the whole domain, or one coset
+  const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : n_blk;
+  const size_t first = (size_t)blockIdx.x * blockDim.x;
+  // a workgroup lies inside one block when blocks are at least a workgroup long; otherwise (tiny domains) every thread
+  // takes its own block's shift and power
+  const bool uniform = !a.cosets || n_blk >= blockDim.x;
   if (tid < 7) {
     f29 v;
     if (tid == 0) v = f29_words_to_r261<P>(a.beta);
     else if (tid == 1) v = f29_from_words<0>(a.gamma);
     else if (tid == 2) v = f29_words_to_r261<P>(a.y);
     else if (tid == 3) v = f29_words_to_r261<P>(a.delta);
-    else if (tid == 4) v = f29_mul<P>(f29_from_words<0>(a.beta), f29_words_to_r261<P>(a.zeta));   // (beta zeta)~
-    else if (tid == 5) v = f29_pow_u64<P>(f29_words_to_r261<P>(a.omega_ext), (uint64_t)blockIdx.x * blockDim.x);
+    else if (tid == 4) v = f29_mul<P>(f29_from_words<0>(a.beta), f29_words_to_r261<P>(a.cosets ? a.shift[min((size_t)QUOT_MAX_COSETS - 1, first >> a.k)] : a.zeta));   // (beta shift)~
+    else if (tid == 5) v = f29_pow_u64<P>(f29_words_to_r261<P>(a.omega_ext), (uint64_t)(first & (n_blk - 1)));
     else v = f29_const<P>(P::r256);                                                                 // 1~
 #pragma unroll
     for (int q = 0; q < 9; q++) sc[tid][q] = v.l[q];
@@ -55,10 +60,10 @@ __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
   if (i >= n_ext) return;
   auto cst = [&](int k) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sc[k][q]; return r; };
   const f29 beta_hat = cst(0), gamma_t = cst(1), y_hat = cst(2), delta_hat = cst(3), one_t = cst(6);
-  const size_t mask = n_ext - 1;
+  const size_t mask = n_blk - 1, base = i & ~mask;
   const size_t rot = (size_t)1 << (a.ext_k - a.k);
-  const size_t i_next = (i + rot) & mask;
-  const size_t i_last = (i + n_ext - (size_t)a.last_rot_abs * rot) & mask;
+  const size_t i_next = base | ((i + rot) & mask);
+  const size_t i_last = base | ((i + n_blk - (size_t)a.last_rot_abs * rot) & mask);
 
   f29 acc = ld(a.values, i);
   const f29 l0 = ld(a.l0, i);
@@ -74,7 +79,13 @@ __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
   for (uint32_t s = 1; s < a.nsets; s++)
     acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(ld(a.z[s], i), ld(a.z[s - 1], i_last)), l0), 1);
   // product terms; current_delta~ = (beta zeta)~ * omega_ext^i, times delta per column
-  f29 cd = f29_mul<P>(cst(4), f29_mul<P>(cst(5), ld(a.pow_lo, tid)));   // tilde * hat = tilde; pow_lo holds hats
+  f29 cd;
+  if (uniform) {
+    cd = f29_mul<P>(cst(4), f29_mul<P>(cst(5), ld(a.pow_lo, tid)));   // tilde * hat = tilde; pow_lo holds hats
+  } else {
+    const f29 bs = f29_mul<P>(f29_from_words<0>(a.beta), f29_words_to_r261<P>(a.shift[i >> a.k]));
+    cd = f29_mul<P>(bs, f29_pow_u64<P>(f29_words_to_r261<P>(a.omega_ext), (uint64_t)(i & mask)));
+  }
   const f29 l_active = ld(a.l_active, i);
   uint32_t col = 0;
   for (uint32_t s = 0; s < a.nsets; s++) {
@@ -96,7 +107,8 @@ __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
 __global__ void __launch_bounds__(256) quot_lookup_kernel(QuotLookupArgs a) {
   __shared__ uint32_t sc[4][9];
   const uint32_t tid = threadIdx.x;
-  const size_t n_ext = (size_t)1 << a.ext_k;
+  const size_t n_blk = (size_t)1 << a.ext_k;
+  const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : n_blk;
   if (tid < 4) {
     f29 v;
     if (tid == 0) v = f29_from_words<0>(a.beta);
@@ -111,9 +123,9 @@ __global__ void __launch_bounds__(256) quot_lookup_kernel(QuotLookupArgs a) {
   if (i >= n_ext) return;
   auto cst = [&](int k) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sc[k][q]; return r; };
   const f29 beta_t = cst(0), gamma_t = cst(1), y_hat = cst(2), one_t = cst(3);
-  const size_t mask = n_ext - 1;
+  const size_t mask = n_blk - 1, base = i & ~mask;
   const size_t rot = (size_t)1 << (a.ext_k - a.k);
-  const size_t i_next = (i + rot) & mask, i_prev = (i + n_ext - rot) & mask;
+  const size_t i_next = base | ((i + rot) & mask), i_prev = base | ((i + n_blk - rot) & mask);
 
   f29 acc = ld(a.values, i);
   const f29 l0 = ld(a.l0, i), l_active = ld(a.l_active, i);
@@ -197,12 +209,12 @@ hipError_t coset_combine(const CosetCombineArgs& a, hipStream_t stream) {
 }
 
 hipError_t quotient_permutation(const QuotPermArgs& a, hipStream_t stream) {
-  const size_t n_ext = (size_t)1 << a.ext_k;
+  const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : (size_t)1 << a.ext_k;
   quot_perm_kernel<<<(unsigned)((n_ext + 255) / 256), 256, 0, stream>>>(a);
   return hipGetLastError();
 }
 hipError_t quotient_lookup(const QuotLookupArgs& a, hipStream_t stream) {
-  const size_t n_ext = (size_t)1 << a.ext_k;
+  const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : (size_t)1 << a.ext_k;
   quot_lookup_kernel<<<(unsigned)((n_ext + 255) / 256), 256, 0, stream>>>(a);
   return hipGetLastError();
 }

@@ -154,6 +154,15 @@ struct Context {
     uint32_t m[MAX_COSETS * MAX_COSETS][8];   // V^-1 diag(1 / (c_b^n - 1)), row-major [t][b]
   };
   std::map<std::tuple<uint32_t, uint32_t, uint32_t>, CosetTables> coset_tables;
+  struct BlobSlot {   // sg_quotient_gates: program blobs in flight
+    uint8_t* host = nullptr;
+    uint8_t* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+  };
+  static constexpr uint32_t BLOB_RING = 16;
+  BlobSlot blob_ring[BLOB_RING];
+  uint32_t blob_next = 0;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
 };
@@ -211,6 +220,15 @@ int make_context(int device, Context** out) {
 
 void destroy_context(Context* c) {
   for (auto& kv : c->t_evals) (void)hipFree(kv.second);
+  for (auto& kv : c->coset_tables) {
+    (void)hipFree(kv.second.fwd);
+    (void)hipFree(kv.second.inv);
+  }
+  for (auto& slot : c->blob_ring) {
+    if (slot.ev) (void)hipEventDestroy(slot.ev);
+    if (slot.host) (void)hipHostFree(slot.host);
+    if (slot.dev) (void)hipFree(slot.dev);
+  }
   c->ntt.clear();
   c->msm.release();
   c->msm_b.release();
@@ -1657,12 +1675,13 @@ int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_
 }
 
 // ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
-// coset < 0: the whole extended domain (row i = zeta omega_ext^i); coset = b: the 2^k rows of the coset zeta omega_ext^b H
+// cosets = 0: the whole extended domain (row i = zeta omega_ext^i); cosets = c: coset-major arrays, block b = the 2^k rows
+// of the coset zeta omega_ext^b H
 static int quotient_permutation_impl(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
                                      const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
                                      const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
                                      const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
-                                     uint32_t last_rotation_abs, int coset, void* stream) {
+                                     uint32_t last_rotation_abs, uint32_t cosets, void* stream) {
   if (!d_values || !d_z || !d_cols || !d_sigma || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !y)
     return fail(SG_ERR_INVALID, "sg_quotient_permutation: null argument");
   if (k == 0 || ext_k < k || ext_k > 28 || nsets == 0 || nsets > QUOT_MAX_SETS || ncols == 0 ||
@@ -1686,24 +1705,23 @@ static int quotient_permutation_impl(void* d_values, const void* const* d_z, uin
   a.l0 = static_cast<const fp_words*>(d_l0);
   a.l_last = static_cast<const fp_words*>(d_l_last);
   a.l_active = static_cast<const fp_words*>(d_l_active);
-  a.nsets = nsets; a.ncols = ncols; a.chunk_len = chunk_len; a.k = k; a.ext_k = coset < 0 ? ext_k : k;
+  a.nsets = nsets; a.ncols = ncols; a.chunk_len = chunk_len; a.k = k; a.ext_k = cosets ? k : ext_k;
+  a.cosets = cosets;
   a.last_rot_abs = last_rotation_abs;
   const DomainConsts *dk, *de;
   TRY(get_consts(k, &dk));
   TRY(get_consts(ext_k, &de));
   std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
   std::memcpy(a.delta, DELTA_M, 32); std::memcpy(a.zeta, &dk->zeta, 32); std::memcpy(a.omega_ext, &de->omega, 32);
-  if (coset >= 0) {   // the kernel's "extended domain" is the 2^k domain shifted by c_b = zeta omega_ext^b
-    summa::prover::Fr z, w;
-    std::memcpy(z.l, &dk->zeta, 32);
-    std::memcpy(w.l, &de->omega, 32);
-    const summa::prover::Fr shift = z * w.pow((uint64_t)coset);
-    std::memcpy(a.zeta, shift.l, 32);
+  if (cosets) {   // every block is the 2^k domain shifted by c_b = zeta omega_ext^b
+    const Context::CosetTables* t;
+    TRY(coset_tables_for(k, ext_k, cosets, &t));
+    for (uint32_t b = 0; b < cosets; b++) std::memcpy(a.shift[b], &t->shift[b], 32);
     std::memcpy(a.omega_ext, &dk->omega, 32);
   }
   hipStream_t s = pick_stream(stream);
   fp_words* pw = nullptr;
-  hipError_t e = g_ctx->ntt.local_twiddles(coset < 0 ? de->omega : dk->omega, 9, s, &pw);   // omega_ext^t, t < 256
+  hipError_t e = g_ctx->ntt.local_twiddles(cosets ? dk->omega : de->omega, 9, s, &pw);   // omega_ext^t, t < 256
   if (e != hipSuccess) return hip_fail("quotient twiddles", e);
   a.pow_lo = pw;
   e = quotient_permutation(a, s);
@@ -1716,21 +1734,21 @@ int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t
                                 const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
                                 uint32_t last_rotation_abs, void* stream) {
   return quotient_permutation_impl(d_values, d_z, nsets, d_cols, d_sigma, ncols, chunk_len, d_l0, d_l_last, d_l_active, beta, gamma, y, k,
-                                   ext_k, last_rotation_abs, -1, stream);
+                                   ext_k, last_rotation_abs, 0, stream);
 }
-int sg_quotient_permutation_coset_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
-                                      const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
-                                      const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
-                                      const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
-                                      uint32_t coset, uint32_t last_rotation_abs, void* stream) {
-  if (ext_k <= k || ext_k > 28 || coset >= (1u << (ext_k - k))) return fail(SG_ERR_INVALID, "sg_quotient_permutation_coset: bad coset");
+int sg_quotient_permutation_cosets_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                       const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                       const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                       const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                       uint32_t n_cosets, uint32_t last_rotation_abs, void* stream) {
+  if (!coset_shape_ok(k, ext_k, n_cosets)) return fail(SG_ERR_INVALID, "sg_quotient_permutation_cosets: bad shape");
   return quotient_permutation_impl(d_values, d_z, nsets, d_cols, d_sigma, ncols, chunk_len, d_l0, d_l_last, d_l_active, beta, gamma, y, k,
-                                   ext_k, last_rotation_abs, (int)coset, stream);
+                                   ext_k, last_rotation_abs, n_cosets, stream);
 }
-int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
-                           const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
-                           const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
-                           uint32_t k, uint32_t ext_k, void* stream) {
+static int quotient_lookup_impl(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                                const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                                const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                                uint32_t k, uint32_t ext_k, uint32_t cosets, void* stream) {
   if (!d_values || !d_z || !d_permuted_input || !d_permuted_table || !d_input || !d_table || !d_l0 || !d_l_last ||
       !d_l_active || !beta || !gamma || !y)
     return fail(SG_ERR_INVALID, "sg_quotient_lookup: null argument");
@@ -1746,18 +1764,34 @@ int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permut
   a.l0 = static_cast<const fp_words*>(d_l0);
   a.l_last = static_cast<const fp_words*>(d_l_last);
   a.l_active = static_cast<const fp_words*>(d_l_active);
-  a.k = k; a.ext_k = ext_k;
+  a.k = k; a.ext_k = cosets ? k : ext_k;
+  a.cosets = cosets;
   std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32); std::memcpy(a.y, y, 32);
   hipError_t e = quotient_lookup(a, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("quotient_lookup", e);
   return SG_OK;
 }
+int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                           const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                           const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                           uint32_t k, uint32_t ext_k, void* stream) {
+  return quotient_lookup_impl(d_values, d_z, d_permuted_input, d_permuted_table, d_input, d_table, d_l0, d_l_last, d_l_active, beta, gamma,
+                              y, k, ext_k, 0, stream);
+}
+int sg_quotient_lookup_cosets_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                                  const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                                  const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                                  uint32_t k, uint32_t n_cosets, void* stream) {
+  if (n_cosets == 0 || n_cosets > QUOT_MAX_COSETS) return fail(SG_ERR_INVALID, "sg_quotient_lookup_cosets: bad shape");
+  return quotient_lookup_impl(d_values, d_z, d_permuted_input, d_permuted_table, d_input, d_table, d_l0, d_l_last, d_l_active, beta, gamma,
+                              y, k, k, n_cosets, stream);
+}
 
-int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
-                          const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
-                          uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
-                          const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
-                          uint32_t k, uint32_t ext_k, void* stream) {
+static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                               const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                               uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                               const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                               uint32_t k, uint32_t ext_k, uint32_t cosets, void* stream) {
   if (!d_values || !graph || !beta || !gamma || !theta || !y || (n_fixed && !d_fixed) || (n_advice && !d_advice) ||
       (n_instance && !d_instance) || (n_challenges && !challenges))
     return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
@@ -1815,15 +1849,63 @@ int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* con
   for (const void* c : cols)
     if (!c) return fail(SG_ERR_INVALID, "sg_quotient_gates: null column");
   hipStream_t s = pick_stream(stream);
-  // program + column pointers + constants: one blob per stream on the device (a call on another stream may still
-  // be running from its own); the host staging vector is free again once the small copy has completed
+  // program + column pointers + constants travel as one small blob.  Ring of page-locked host / device buffer pairs, each
+  // guarded by an event recorded after the kernel that reads it: the call is asynchronous (no host wait unless the ring
+  // has wrapped onto a launch that is still running)
   const size_t bytes = gates_blob(prog, cols.data(), &g_ctx->gate_blob_host);
-  uint8_t* d_blob = nullptr;
-  hipError_t e = scratch_for(s, 2, bytes, &d_blob);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_blob, g_ctx->gate_blob_host.data(), bytes, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e == hipSuccess) e = gates_run(prog, d_blob, static_cast<fp_words*>(d_values), k, ext_k, s);
+  Context::BlobSlot& slot = g_ctx->blob_ring[g_ctx->blob_next++ % Context::BLOB_RING];
+  hipError_t e = hipSuccess;
+  if (!slot.ev) e = hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming);
+  else e = hipEventSynchronize(slot.ev);
+  if (e == hipSuccess && slot.cap < bytes) {
+    const size_t want = bytes + bytes / 2 + 256;
+    if (slot.host) (void)hipHostFree(slot.host);
+    retire_device_memory(slot.dev);
+    slot.host = nullptr;
+    slot.dev = nullptr;
+    slot.cap = 0;
+    e = hipHostMalloc(reinterpret_cast<void**>(&slot.host), want, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&slot.dev), want);
+    if (e == hipSuccess) slot.cap = want;
+  }
+  if (e == hipSuccess) {
+    std::memcpy(slot.host, g_ctx->gate_blob_host.data(), bytes);
+    e = hipMemcpyAsync(slot.dev, slot.host, bytes, hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess) e = gates_run(prog, slot.dev, static_cast<fp_words*>(d_values), k, ext_k, s, cosets);
+  if (e == hipSuccess) e = hipEventRecord(slot.ev, s);
   if (e != hipSuccess) return hip_fail("quotient_gates", e);
+  return SG_OK;
+}
+int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                          const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                          uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                          const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                          uint32_t k, uint32_t ext_k, void* stream) {
+  return quotient_gates_impl(d_values, graph, d_fixed, n_fixed, d_advice, n_advice, d_instance, n_instance, challenges, n_challenges, beta,
+                             gamma, theta, y, k, ext_k, 0, stream);
+}
+int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                                 const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                                 uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                                 const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                                 uint32_t k, uint32_t n_cosets, void* stream) {
+  if (n_cosets == 0 || n_cosets > QUOT_MAX_COSETS) return fail(SG_ERR_INVALID, "sg_quotient_gates_cosets: bad shape");
+  return quotient_gates_impl(d_values, graph, d_fixed, n_fixed, d_advice, n_advice, d_instance, n_instance, challenges, n_challenges, beta,
+                             gamma, theta, y, k, k, n_cosets, stream);
+}
+// how the interpreter would run a program: instructions and simultaneously live values (LDS slots per row; 8 or fewer keep
+// two workgroups of 256 rows per CU).  Host-only: no device is touched.
+int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
+                          uint32_t* n_ops_out, uint32_t* n_slots_out) {
+  if (!graph || !n_ops_out || !n_slots_out) return fail(SG_ERR_INVALID, "sg_gates_program_info: null argument");
+  std::vector<uint8_t> zeros(32 * (size_t)std::max<uint32_t>(1, n_challenges), 0);
+  GateProgram prog;
+  const std::string err = compile_gates(*graph, n_fixed, n_advice, n_instance, zeros.data(), n_challenges, zeros.data(), zeros.data(),
+                                        zeros.data(), zeros.data(), &prog);
+  if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_gates_program_info: " + err).c_str());
+  *n_ops_out = (uint32_t)prog.ops.size();
+  *n_slots_out = prog.n_slots;
   return SG_OK;
 }
 

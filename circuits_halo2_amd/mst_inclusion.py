@@ -165,10 +165,15 @@ def lookup_expressions():
 GATE_BLOCKS = ((0, 7), (7, 12), (12, 19))
 
 
-def gate_challenges(y: int):
-    """the `challenges` array the gate program expects: [y^5]"""
+def gate_challenge_exponents(n_currencies: int = 2):
+    """what the gate program reads as SG_VS_CHALLENGE sources: challenge i = sum of y^e over group i"""
+    return [[GATE_BLOCKS[1][1] - GATE_BLOCKS[1][0]]]
+
+
+def gate_challenges(y: int, n_currencies: int = 2):
+    """the `challenges` array the gate program expects (gate_challenge_exponents evaluated at y)"""
     from .utils import ints_to_fr
-    return ints_to_fr([pow(y, GATE_BLOCKS[1][1] - GATE_BLOCKS[1][0], R)])
+    return ints_to_fr([sum(pow(y, e, R) for e in group) % R for group in gate_challenge_exponents(n_currencies)])
 
 
 @lru_cache(maxsize=None)

@@ -248,8 +248,12 @@ def native_key(pk: ProvingKey, params) -> int:
     sigma = (C.c_void_p * len(pk.sigma_lagrange))(*[c.data_ptr() for c in pk.sigma_lagrange])
     digest = np.frombuffer(pk.vk_digest.to_bytes(32, "big"), dtype=np.uint8).copy()
     key = C.c_uint64(0)
+    groups = M.gate_challenge_exponents(pk.n_currencies)
+    exps = (C.c_uint32 * max(1, sum(len(g) for g in groups)))(*[e for g in groups for e in g])
+    counts = (C.c_uint32 * max(1, len(groups)))(*[len(g) for g in groups])
     ffi.check_prover(ffi.prover_lib().sp_key_create(C.c_uint32(pk.k), C.c_uint64(params.handle()), fixed, sigma, ffi.ptr(digest),
-                                                    C.byref(gates), C.byref(look), ffi.current_stream_ptr(), C.byref(key)))
+                                                    C.byref(gates), C.byref(look), exps, counts, C.c_uint32(len(groups)),
+                                                    ffi.current_stream_ptr(), C.byref(key)))
     pk._native = (key.value, (params.handle(), pk.vk_digest))
     return key.value
 
@@ -365,16 +369,27 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     def to_coeff(cols):
         return A.best_fft_batch([c.clone() for c in cols], dom.get_omega_inv(), k, divisor=dom.ifft_divisor())
 
-    def commit_lagrange(cols):
-        return [_point(c) for c in params.commit_batch(cols, lagrange=True)]
-
     # -- 1: advice columns: blind the last rows, commit
     noncanonical = A.count_noncanonical(advice) if sanity_checks else None     # read where the host waits next
     advice = [a.clone() for a in advice]
     for a in advice:
         a[32 * u:] = rand(n - u)
     instance_col = _head(list(instances), n)
-    for p in commit_lagrange(advice):
+    # -- 2, computed ahead of its place in the transcript: the lookup's permuted pair.  One input and one table expression:
+    # the theta-compression is the expression itself, nothing here waits for theta, so the two permuted columns share ONE
+    # fused commitment job with the advice columns; their points are written where upstream writes them (after theta).
+    inp_d = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(inp_d, M.lookup_input_graph(), pk.fixed_lagrange, advice, [instance_col], none,
+                     _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), k, k)   # the expression row by row (stride 1)
+    on_device = A.lookup_permute_small(inp_d, pk.fixed_lagrange[4], u)   # range tables: no host round trip
+    if on_device is not None:
+        pin_d, ptab_d = (torch.cat([col, rand(n - u)]) for col in on_device)             # blinding rows random
+    else:
+        pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
+        pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
+                         for rows in (pin_rows, ptab_rows))
+    points = [_point(c) for c in params.commit_batch_mixed(advice + [pin_d, ptab_d], [1, 1, 1, 2, 2])]   # sorted columns: flag 2
+    for p in points[:3]:
         tr.write_point(p)
     if noncanonical is not None and int(noncanonical.item()):
         raise ValueError("create_proof: advice words >= r (not canonical Montgomery field elements)")
@@ -388,18 +403,7 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     adv_ext, inst_ext = ext1[:3], ext1[3]
 
     lap("1_advice")
-    # -- 2: lookup: compressed input / table over the rows, permuted pair (host sort, as upstream), commitments
-    inp_d = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
-    A.quotient_gates(inp_d, M.lookup_input_graph(), pk.fixed_lagrange, advice, [instance_col], none,
-                     _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), _fr_bytes(0), k, k)   # the expression row by row (stride 1)
-    on_device = A.lookup_permute_small(inp_d, pk.fixed_lagrange[4], u)   # range tables: no host round trip
-    if on_device is not None:
-        pin_d, ptab_d = (torch.cat([col, rand(n - u)]) for col in on_device)             # blinding rows random
-    else:
-        pin_rows, ptab_rows = permute_expression_pair(_canonical_rows(inp_d)[:u], _canonical_rows(pk.fixed_lagrange[4])[:u])
-        pin_d, ptab_d = (torch.cat([A.fr_to_montgomery(torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()), rand(n - u)])
-                         for rows in (pin_rows, ptab_rows))
-    for p in [_point(c) for c in params.commit_batch([pin_d, ptab_d], lagrange=True, diff=True)]:   # sorted columns: long runs
+    for p in points[3:]:
         tr.write_point(p)
     beta = tr.squeeze_challenge()
     gamma = tr.squeeze_challenge_again()
@@ -442,27 +446,22 @@ def create_proof(params, pk: ProvingKey, advice, instances, seed: bytes | None =
     col_ext[(A.INSTANCE, 0)] = inst_ext
     perm_cols = [col_ext[c] for c in M.PERMUTATION_COLUMNS]
     if on_cosets:
-        # deg h < 5 n: its values on 5 cosets of the 2^k domain determine it; every kernel runs coset by coset on 2^k rows
-        # (a rotation is an index shift of 1 there), and the pieces come straight out of sg_cosets_to_pieces_dev
+        # deg h < 5 n: its values on 5 cosets of the 2^k domain determine it; the kernels take the coset-major arrays whole
+        # (a rotation is an index shift of 1 inside a block), and the pieces come straight out of sg_cosets_to_pieces_dev
         d = dom.quotient_poly_degree
         values = torch.zeros(32 * n * d, dtype=torch.uint8, device="cuda")
-        input_c = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
-        for b in range(d):
-            blk = lambda t: t[32 * n * b:32 * n * (b + 1)]
-            v = blk(values)
-            fixed_b, adv_b, inst_b = [blk(t) for t in pk.fixed_ext], [blk(t) for t in adv_ext], [blk(inst_ext)]
-            A.quotient_gates(v, M.gate_graph(pk.n_currencies), fixed_b, adv_b, inst_b, M.gate_challenges(y), b_beta, b_gamma, b_theta, b_y, k, k)
-            A.quotient_permutation_coset(v, [blk(z0_ext), blk(z1_ext)], [blk(t) for t in perm_cols], [blk(t) for t in pk.sigma_ext],
-                                         M.PERMUTATION_CHUNK, blk(pk.l0_ext), blk(pk.l_last_ext), blk(pk.l_active_ext), b_beta, b_gamma, b_y,
-                                         k, ext_k, b, M.BLINDING_FACTORS + 1)
-            input_c.zero_()
-            A.quotient_gates(input_c, M.lookup_input_graph(), fixed_b, adv_b, inst_b, none, b_beta, b_gamma, b_theta, b_y, k, k)
-            A.quotient_lookup(v, blk(lz_ext), blk(pin_ext), blk(ptab_ext), input_c, blk(pk.fixed_ext[4]), blk(pk.l0_ext), blk(pk.l_last_ext),
-                              blk(pk.l_active_ext), b_beta, b_gamma, b_y, k, k)
+        A.quotient_gates_cosets(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y, pk.n_currencies),
+                                b_beta, b_gamma, b_theta, b_y, k, d)
+        A.quotient_permutation_cosets(values, [z0_ext, z1_ext], perm_cols, pk.sigma_ext, M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext,
+                                      pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k, d, M.BLINDING_FACTORS + 1)
+        input_c = torch.empty(32 * n * d, dtype=torch.uint8, device="cuda")
+        A.quotient_gates_cosets(input_c, M.lookup_input_graph(), pk.fixed_ext, adv_ext, [inst_ext], none, b_beta, b_gamma, b_theta, b_y, k, d)
+        A.quotient_lookup_cosets(values, lz_ext, pin_ext, ptab_ext, input_c, pk.fixed_ext[4], pk.l0_ext, pk.l_last_ext, pk.l_active_ext,
+                                 b_beta, b_gamma, b_y, k, d)
         pieces = dom.cosets_to_pieces(values)
     else:
         values = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
-        A.quotient_gates(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y), b_beta, b_gamma, b_theta,
+        A.quotient_gates(values, M.gate_graph(pk.n_currencies), pk.fixed_ext, adv_ext, [inst_ext], M.gate_challenges(y, pk.n_currencies), b_beta, b_gamma, b_theta,
                          b_y, k, ext_k)
         A.quotient_permutation(values, [z0_ext, z1_ext], perm_cols, pk.sigma_ext, M.PERMUTATION_CHUNK, pk.l0_ext, pk.l_last_ext,
                                pk.l_active_ext, b_beta, b_gamma, b_y, k, ext_k, M.BLINDING_FACTORS + 1)
@@ -589,10 +588,12 @@ def export_bundle(path: str, params, pk: ProvingKey, advice, instances) -> None:
         return out
     host = lambda t: t.cpu().numpy().tobytes()
     with open(path, "wb") as f:
-        f.write(b"SGPB1\0\0\0" + struct.pack("<II", pk.k, len(instances)))
+        f.write(b"SGPB2\0\0\0" + struct.pack("<II", pk.k, len(instances)))
         f.write(params.g.tobytes() + params.g_lagrange.tobytes())
         for col in pk.fixed_lagrange + pk.sigma_lagrange + list(advice):
             f.write(host(col))
         f.write(ints_to_fr(list(instances)).tobytes())
         f.write(pk.vk_digest.to_bytes(32, "big"))
         f.write(graph_bytes(M.gate_graph(pk.n_currencies)) + graph_bytes(M.lookup_input_graph()))
+        groups = M.gate_challenge_exponents(pk.n_currencies)      # the gate program's challenges: sums of powers of y
+        f.write(struct.pack("<I", len(groups)) + b"".join(struct.pack("<I%dI" % len(g), len(g), *g) for g in groups))

@@ -206,6 +206,8 @@ inline Graph gate_graph(uint32_t n_currencies) {
   g.add_calculation(SG_OP_HORNER, joined, y, &p3);
   return g.g;
 }
+// what that program reads as challenges: challenge i = sum of y^e over group i (ProvingKey::gate_challenge_exps)
+inline std::vector<std::vector<uint32_t>> gate_challenge_exponents(uint32_t) { return {{5}}; }
 // the lookup's input expression f5 * (a0 - 2^8 a0_next), one value per row
 inline Graph lookup_input_graph() {
   GraphBuilder g;

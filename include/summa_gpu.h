@@ -290,12 +290,12 @@ int sg_quotient_permutation_dev(void* d_values, const void* const* d_z, uint32_t
                                 const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
                                 const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
                                 uint32_t last_rotation_abs, void* stream);
-/* the same on ONE coset of the coset-major layout: all arrays are that coset's 2^k rows (row a = c_coset * omega^a) */
-int sg_quotient_permutation_coset_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
-                                      const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
-                                      const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
-                                      const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
-                                      uint32_t coset, uint32_t last_rotation_abs, void* stream);
+/* the same over coset-major arrays (n_cosets blocks of 2^k rows; block b = the coset zeta * omega_ext^b * H): one launch */
+int sg_quotient_permutation_cosets_dev(void* d_values, const void* const* d_z, uint32_t nsets, const void* const* d_cols,
+                                       const void* const* d_sigma, uint32_t ncols, uint32_t chunk_len, const void* d_l0,
+                                       const void* d_l_last, const void* d_l_active, const uint8_t beta[32],
+                                       const uint8_t gamma[32], const uint8_t y[32], uint32_t k, uint32_t ext_k,
+                                       uint32_t n_cosets, uint32_t last_rotation_abs, void* stream);
 /* Lookup argument (one lookup; inputs already theta-compressed by the caller):
  *   l0 (1 - z);  l_last (z^2 - z);
  *   l_active (z(omega X)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma));
@@ -304,6 +304,11 @@ int sg_quotient_lookup_dev(void* d_values, const void* d_z, const void* d_permut
                            const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
                            const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
                            uint32_t k, uint32_t ext_k, void* stream);
+
+int sg_quotient_lookup_cosets_dev(void* d_values, const void* d_z, const void* d_permuted_input, const void* d_permuted_table,
+                                  const void* d_input, const void* d_table, const void* d_l0, const void* d_l_last,
+                                  const void* d_l_active, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t y[32],
+                                  uint32_t k, uint32_t n_cosets, void* stream);
 
 /* Custom-gate block: halo2's GraphEvaluator program (plonk/evaluation.rs: `calculations`, `constants`,
  * `rotations`; value sources and calculations keep upstream's names).  calculations[i] defines
@@ -333,6 +338,17 @@ int sg_quotient_gates_dev(void* d_values, const sg_graph* graph, const void* con
                           uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
                           const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
                           uint32_t k, uint32_t ext_k, void* stream);
+
+/* the same over coset-major arrays of n_cosets * 2^k rows (a rotation r reads row + r inside its block of 2^k rows) */
+int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                                 const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                                 uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                                 const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                                 uint32_t k, uint32_t n_cosets, void* stream);
+/* what the interpreter makes of a program: instructions per row and simultaneously live values (LDS slots per row; the
+ * occupancy of the kernel is set by the latter).  Host only -- no device needed. */
+int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
+                          uint32_t* n_ops_out, uint32_t* n_slots_out);
 
 /* ---- witness side: the Merkle sum tree of
  * zk_prover/src/merkle_sum_tree (node.rs:16-84, utils/build_tree.rs:5-78) over Poseidon(t = 2,

@@ -34,11 +34,14 @@ typedef enum sp_transcript {
 
 /* Proving key for 2^k rows over the SRS `srs_handle` (sg_srs_upload): d_fixed_lagrange[11] / d_sigma_lagrange[6] are
  * device columns of 2^k Montgomery Fr (copied); gates / lookup_input are the GraphEvaluator programs of the constraint
- * system (copied); vk_digest_be = the scalar `vk.hash_into` feeds the transcript, 32 bytes big-endian.  Work is
- * enqueued on `stream` and complete on return. */
+ * system (copied); vk_digest_be = the scalar `vk.hash_into` feeds the transcript, 32 bytes big-endian.
+ * The gate program may read powers of the challenge y as SG_VS_CHALLENGE sources (a program that is free to fold its gate
+ * polynomials in any order needs them): challenge i = sum of y^e over the i-th group of gate_challenge_exponents, the groups
+ * having gate_challenge_counts[i] entries each (n_gate_challenges groups).  Work is enqueued on `stream` and complete on return. */
 int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_lagrange, const void* const* d_sigma_lagrange,
-                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input, void* stream,
-                  uint64_t* key_out);
+                  const uint8_t vk_digest_be[32], const sg_graph* gates, const sg_graph* lookup_input,
+                  const uint32_t* gate_challenge_exponents, const uint32_t* gate_challenge_counts, uint32_t n_gate_challenges,
+                  void* stream, uint64_t* key_out);
 int sp_key_destroy(uint64_t key);
 
 /* One proof.  d_advice[3]: device columns of 2^k rows, Lagrange form; their last 6 rows are OVERWRITTEN with blinding

@@ -575,6 +575,8 @@ struct ProvingKey {
   uint64_t srs = 0;
   uint8_t vk_digest_be[32] = {0};
   Graph gates, lookup_input;
+  // the challenges the gate program reads: challenge i = sum over e in gate_challenge_exps[i] of y^e
+  std::vector<std::vector<uint32_t>> gate_challenge_exps;
   std::vector<DevCol> fixed_lag, sigma_lag, fixed_coeff, sigma_coeff, fixed_ext, sigma_ext;
   DevCol l0_ext, l_last_ext, l_active_ext;
   uint32_t ext_k() const { return k + 3; }  // degree 6: extended domain 2^(k + 3)
@@ -803,6 +805,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_commit_batch_mixed_dev(pk.srs, basis.data(), cols.data(), cols.size(), n, main_stream(), out.data()), "commit");
     for (size_t i = 0; i < cols.size(); i++) tr.write_point(out.data() + 64 * i);
   };
+  auto commit_points = [&](std::vector<void*> cols, std::vector<int> basis) {   // the same, the points handed back
+    std::vector<uint8_t> out(64 * cols.size());
+    ck(sg_commit_batch_mixed_dev(pk.srs, basis.data(), cols.data(), cols.size(), n, main_stream(), out.data()), "commit");
+    return out;
+  };
 
   // -- 1: advice
   DevCol noncanonical(1);   // device counter of the range check, read after the commitments (where the host waits anyway)
@@ -817,16 +824,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   std::vector<DevCol> co1, ex1;
   fork();
   to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);   // under the commitments
-  commit_batch({advice[0].p, advice[1].p, advice[2].p}, {1, 1, 1});
-  if (opt.sanity_checks) {
-    uint32_t bad = 0;
-    d2h(&bad, noncanonical.p, 4);
-    if (bad) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
-  }
-  const Fr theta = tr.squeeze();
-
-  lap("1_advice");
-  // -- 2: lookup
+  // -- 2 (computed ahead of its place in the transcript): the lookup's permuted columns.  This circuit's lookup has ONE input
+  // and ONE table expression, so the theta-compression is the expression itself and nothing here waits for theta: the two
+  // permuted columns are committed in the SAME fused job as the advice columns (one MSM group's latency instead of two) and
+  // their points enter the transcript where upstream writes them, after theta has been squeezed.
   const sg_graph g_in = pk.lookup_input.view(), g_gates = pk.gates.view();
   std::vector<void*> fixed_lag_p, adv_lag_p = {advice[0].p, advice[1].p, advice[2].p}, inst_lag_p = {instance_col.p};
   for (auto& c : pk.fixed_lag) fixed_lag_p.push_back(c.p);
@@ -854,7 +855,18 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   }
   rand_rows(pin, u, n - u);
   rand_rows(ptab, u, n - u);
-  commit_batch({pin.p, ptab.p}, {2, 2});   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
+  // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
+  const std::vector<uint8_t> pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1, 1, 1, 2, 2});
+  if (opt.sanity_checks) {
+    uint32_t bad = 0;
+    d2h(&bad, noncanonical.p, 4);
+    if (bad) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
+  }
+  for (int i = 0; i < 3; i++) tr.write_point(pts.data() + 64 * i);
+  const Fr theta = tr.squeeze();
+
+  lap("1_advice");
+  for (int i = 3; i < 5; i++) tr.write_point(pts.data() + 64 * i);
   const Fr beta = tr.squeeze(), gamma = tr.squeeze_again();
 
   lap("2_lookup");
@@ -909,32 +921,37 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
 
   lap("3_grand_products");
   // -- 4: quotient
-  // every kernel runs coset by coset on 2^k rows of the coset-major arrays (a rotation is an index shift of 1 inside a block)
-  DevCol values(ne), input_c(n);
+  // the kernels take the coset-major arrays whole (QUOTIENT_PIECES blocks of 2^k rows; a rotation is an index shift of 1 inside
+  // a block): one launch each
+  DevCol values(ne), input_c(ne);
   hk(hipMemsetAsync(values.p, 0, 32 * ne, main_stream()), "memset");
-  // the gate program folds its second block with y^5 supplied as challenge 0 (mst_inclusion.py: GATE_BLOCKS)
-  const Fr y5 = y.pow((uint64_t)5);
+  std::vector<Fr> y_powers;   // the gate program's challenges: sums of powers of y (ProvingKey::gate_challenge_exps)
+  for (auto& group : pk.gate_challenge_exps) {
+    Fr v = Fr::zero();
+    for (uint32_t e : group) v = v + y.pow((uint64_t)e);
+    y_powers.push_back(v);
+  }
+  if (y_powers.empty()) y_powers.push_back(Fr::zero());
   std::vector<DevCol> pieces_col;
   for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces_col.emplace_back(n);
-  for (uint32_t b = 0; b < QUOTIENT_PIECES; b++) {
-    auto blk = [&](void* p) { return static_cast<void*>(static_cast<uint8_t*>(p) + 32 * n * b); };
-    std::vector<void*> fixed_b, adv_b = {blk(ex1[0].p), blk(ex1[1].p), blk(ex1[2].p)}, inst_b = {blk(ex1[3].p)};
-    for (auto& c : pk.fixed_ext) fixed_b.push_back(blk(c.p));
-    void* v = blk(values.p);
-    ck(sg_quotient_gates_dev(v, &g_gates, fixed_b.data(), NUM_FIXED, adv_b.data(), NUM_ADVICE, inst_b.data(), 1, y5.bytes(), 1,
-                             beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, k, main_stream()), "gates");
-    std::vector<void*> col_b, sig_b, z_b = {blk(ex3[2].p), blk(ex3[3].p)};
+  {
+    std::vector<void*> fixed_e, adv_e = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_e = {ex1[3].p};
+    for (auto& c : pk.fixed_ext) fixed_e.push_back(c.p);
+    ck(sg_quotient_gates_cosets_dev(values.p, &g_gates, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1,
+                                    y_powers[0].bytes(), (uint32_t)pk.gate_challenge_exps.size(), beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k,
+                                    QUOTIENT_PIECES, main_stream()), "gates");
+    std::vector<void*> col_e, sig_e, z_e = {ex3[2].p, ex3[3].p};
     for (uint32_t c = 0; c < NUM_SIGMA; c++) {
-      col_b.push_back(blk(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p));
-      sig_b.push_back(blk(pk.sigma_ext[c].p));
+      col_e.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
+      sig_e.push_back(pk.sigma_ext[c].p);
     }
-    ck(sg_quotient_permutation_coset_dev(v, z_b.data(), 2, col_b.data(), sig_b.data(), NUM_SIGMA, CHUNK, blk(pk.l0_ext.p), blk(pk.l_last_ext.p),
-                                         blk(pk.l_active_ext.p), beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, b, BLINDING + 1,
-                                         main_stream()), "permutation quotient");
-    ck(sg_quotient_gates_dev(input_c.p, &g_in, fixed_b.data(), NUM_FIXED, adv_b.data(), NUM_ADVICE, inst_b.data(), 1, nullptr, 0,
-                             beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, k, main_stream()), "lookup input (coset)");
-    ck(sg_quotient_lookup_dev(v, blk(ex3[4].p), blk(ex3[0].p), blk(ex3[1].p), input_c.p, blk(pk.fixed_ext[4].p), blk(pk.l0_ext.p),
-                              blk(pk.l_last_ext.p), blk(pk.l_active_ext.p), beta.bytes(), gamma.bytes(), y.bytes(), k, k, main_stream()),
+    ck(sg_quotient_permutation_cosets_dev(values.p, z_e.data(), 2, col_e.data(), sig_e.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p, pk.l_last_ext.p,
+                                          pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, QUOTIENT_PIECES, BLINDING + 1,
+                                          main_stream()), "permutation quotient");
+    ck(sg_quotient_gates_cosets_dev(input_c.p, &g_in, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1, nullptr, 0,
+                                    beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()), "lookup input (cosets)");
+    ck(sg_quotient_lookup_cosets_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_c.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
+                                     pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()),
        "lookup quotient");
   }
   std::vector<void*> pieces;

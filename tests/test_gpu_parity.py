@@ -1411,14 +1411,20 @@ def test_quotient_on_cosets_equals_the_extended_pipeline(gpu, O, k, ncols, chunk
     nz = len(ctx["zs"])
     c_zs, c_cols, c_sig = cos[len(names):len(names) + nz], cos[len(names) + nz:len(names) + nz + ncols], cos[len(names) + nz + ncols:]
     values = torch.zeros(32 * d * n, dtype=torch.uint8, device="cuda")
-    blk = lambda t, b: t[32 * n * b:32 * n * (b + 1)]
-    for b in range(d):                                            # (2)
-        v = blk(values, b)
-        A.quotient_gates(v, graph, [blk(c["gq"], b)], [blk(c[t], b) for t in ("ga", "gb", "gc")], [], np.zeros(0, dtype=np.uint8),
-                         beta, gamma, theta, y, k, k)
-        A.quotient_permutation_coset(v, [blk(t, b) for t in c_zs], [blk(t, b) for t in c_cols], [blk(t, b) for t in c_sig], chunk_len,
-                                     blk(c["l0"], b), blk(c["l_last"], b), blk(c["l_active"], b), beta, gamma, y, k, ext_k, b, blinding + 1)
-        A.quotient_lookup(v, *[blk(c[t], b) for t in ("z", "ap", "sp", "a", "s", "l0", "l_last", "l_active")], beta, gamma, y, k, k)
+    none = np.zeros(0, dtype=np.uint8)
+    A.quotient_gates_cosets(values, graph, [c["gq"]], [c[t] for t in ("ga", "gb", "gc")], [], none, beta, gamma, theta, y, k, d)   # (2)
+    A.quotient_permutation_cosets(values, c_zs, c_cols, c_sig, chunk_len, c["l0"], c["l_last"], c["l_active"], beta, gamma, y, k, ext_k, d,
+                                  blinding + 1)
+    A.quotient_lookup_cosets(values, *[c[t] for t in ("z", "ap", "sp", "a", "s", "l0", "l_last", "l_active")], beta, gamma, y, k, d)
+    # a single block through the per-domain entry points (2^k rows, ext_k = k) gives the same rows: gates and lookup do not see the coset
+    blk = lambda t, b: t[32 * n * b:32 * n * (b + 1)].clone()
+    one = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    A.quotient_gates(one, graph, [blk(c["gq"], 1)], [blk(c[t], 1) for t in ("ga", "gb", "gc")], [], none, beta, gamma, theta, y, k, k)
+    chk = torch.zeros(32 * d * n, dtype=torch.uint8, device="cuda")
+    A.quotient_gates_cosets(chk, graph, [c["gq"]], [c[t] for t in ("ga", "gb", "gc")], [], none, beta, gamma, theta, y, k, d)
+    assert (one == blk(chk, 1)).all()
+    with pytest.raises(ValueError):
+        A.quotient_gates_cosets(values[:64], graph, [c["gq"]], [c[t] for t in ("ga", "gb", "gc")], [], none, beta, gamma, theta, y, k, d)
     full = torch.zeros(32 * ne, dtype=torch.uint8, device="cuda")
     A.quotient_gates(full, graph, [ctx["e_gq"]], [ctx["e_ga"], ctx["e_gb"], ctx["e_gc"]], [], np.zeros(0, dtype=np.uint8), beta, gamma,
                      theta, y, k, ext_k)

@@ -229,6 +229,8 @@ def test_cpp_circuit_equals_the_python_twin(k, levels, nc, nb, tmp_path):
     want = struct.pack("<4I", n_items, n_abs, rows, len(inst)) + struct.pack(f"<{len(inst)}I", *inst) + prog.tobytes()
     want += b"".join(ints_to_fr(c).tobytes() for c in asg["fixed"]) + b"".join(ints_to_fr(c).tobytes() for c in asg["sigma"])
     want += graph_bytes(M.gate_graph(nc)) + graph_bytes(M.lookup_input_graph())
+    groups = M.gate_challenge_exponents(nc)
+    want += struct.pack("<I", len(groups)) + b"".join(struct.pack("<I%dI" % len(g), len(g), *g) for g in groups)
     rinv = pow(1 << 256, -1, PR.Q)
     pts = [((2 * i + 1) * rinv % PR.Q, (2 * i + 2) * rinv % PR.Q) for i in range(17)]
     want += P.verifying_key_digest(k, nc, pts[:11], pts[11:]).to_bytes(32, "big")

@@ -48,6 +48,14 @@ int main(int argc, char** argv) {
     for (auto& col : sigma) f.write(reinterpret_cast<const char*>(col.data()), (std::streamsize)(32 * col.size()));
     put_graph(f, gate_graph(nc));
     put_graph(f, lookup_input_graph());
+    {   // the gate program's challenge list
+      const auto groups = gate_challenge_exponents(nc);
+      put_u32(f, (uint32_t)groups.size());
+      for (auto& g : groups) {
+        put_u32(f, (uint32_t)g.size());
+        for (uint32_t e : g) put_u32(f, e);
+      }
+    }
     // the verifying-key digest of 17 stand-in commitments (Montgomery bytes = 1, 2, ..), compared with the Python formula
     std::vector<std::array<uint8_t, 64>> comms(NUM_FIXED + NUM_PERM);
     for (size_t i = 0; i < comms.size(); i++) {

@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     Reader rd(argv[1]);
     char magic[8];
     rd.read(magic, 8);
-    if (std::memcmp(magic, "SGPB1\0\0\0", 8)) throw std::runtime_error("not a prover bundle");
+    if (std::memcmp(magic, "SGPB2\0\0\0", 8)) throw std::runtime_error("not a prover bundle");
     const uint32_t k = rd.u32(), n_inst = rd.u32();
     const size_t n = (size_t)1 << k;
     std::vector<uint8_t> g(64 * n), gl(64 * n);
@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
     rd.read(pk.vk_digest_be, 32);
     pk.gates = rd.graph();
     pk.lookup_input = rd.graph();
+    pk.gate_challenge_exps.resize(rd.u32());
+    for (auto& group : pk.gate_challenge_exps) {
+      group.resize(rd.u32());
+      for (auto& e : group) e = rd.u32();
+    }
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     pk.build(k, srs, std::move(fixed), std::move(sigma));

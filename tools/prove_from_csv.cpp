@@ -139,6 +139,7 @@ int main(int argc, char** argv) {
       std::memcpy(pk.vk_digest_be, d.data(), 32);
     }
     pk.gates = gate_graph(nc);
+    pk.gate_challenge_exps = gate_challenge_exponents(nc);
     pk.lookup_input = lookup_input_graph();
     pk.build(k, srs, std::move(fixed), std::move(sigma));
     const double keygen_ms = ms_since(t);
