@@ -219,14 +219,14 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
   for (uint32_t i = 0; i < g.n_constants; i++) push_const(g.constants + 32 * (size_t)i);
   for (uint32_t i = 0; i < n_challenges; i++) push_const(challenges + 32 * (size_t)i);
   push_const(beta); push_const(gamma); push_const(theta); push_const(y);
-  // (column, rotation) -> (value, instruction index of its latest use): a loaded value is reused only
-  // while the previous use is at most RELOAD_DISTANCE instructions back; beyond that a fresh load
-  // (32-byte read + one product) is cheaper than pinning an LDS slot
-  constexpr size_t RELOAD_DISTANCE = 48;
-  // column words (canonical, < p) can enter as x~ << 5 = x^ with bound 32 for free; the bound tracker then
-  // inserts a reduction only if a consumer needs one (a product with a bound-2 value does not).  A query
-  // that is referenced more than once is converted at the load instead (one product, bound 2), so that the
-  // reduction is not repeated in every expression it feeds.
+  // (column, rotation) -> (value, instruction index of its latest use): a loaded value is reused only while the previous use
+  // is at most RELOAD_DISTANCE instructions back; beyond that a fresh load (a 32-byte read, L2-resident: the row's cache
+  // lines were touched a moment ago) is cheaper than pinning an LDS slot -- the slot count sets the kernel's occupancy.
+  size_t RELOAD_DISTANCE = 12;
+  if (const char* v = std::getenv("SG_GATES_RELOAD")) RELOAD_DISTANCE = (size_t)std::atoi(v);   // development aid
+  // column words (canonical, < p) enter as x~ << 5 = x^ with bound 32 for free; the bound tracker inserts a reduction only
+  // where a consumer needs one (a product with a bound-2 value does not), and once a value has been reduced its later
+  // uses see the reduced copy (Compiler::redirect), so nothing is gained by converting at the load.
   constexpr uint32_t LOAD_BOUND = 32;
   std::map<std::pair<uint32_t, int32_t>, uint32_t> refs;
   {
@@ -265,7 +265,8 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
           it->second.second = c.ir.size();
           return it->second.first;
         }
-        const bool convert = refs[key] > 1;
+        bool convert = false;
+        if (const char* v = std::getenv("SG_GATES_CONVERT")) convert = refs[key] > (uint32_t)std::atoi(v);   // development aid
         uint32_t d = c.new_value(convert ? 2 : LOAD_BOUND);
         IrOp op{G_LOADCOL, convert ? 1u : 0u, d, Val{GK_CONST, 0}, Val{GK_CONST, 0}};
         op.col = key.first; op.rot = key.second;
@@ -390,6 +391,13 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
       free_slots.pop_back();
     }
     slot[op.dst] = d;
+    if (std::getenv("SG_GATES_DUMP")) {   // development aid: the lowered program with its slot pressure
+      static const char* names[] = {"loadcol", "loadprev", "add", "sub", "mul", "sqr", "dbl", "neg", "red"};
+      std::fprintf(stderr, "%3u %-8s dst s%-2u", i, names[op.code], d);
+      if (!reads) std::fprintf(stderr, " col %u rot %d", op.col, op.rot);
+      else std::fprintf(stderr, " %c%u %c%u", op.a.kind == GK_SLOT ? 's' : 'c', a_idx, op.b.kind == GK_SLOT ? 's' : 'c', b_idx);
+      std::fprintf(stderr, "   live %u (last use of dst: %u)\n", n_slots - (uint32_t)free_slots.size(), last[op.dst]);
+    }
     o.w0 = op.code | (op.kidx << 8) | (op.a.kind << 16) | (op.b.kind << 24);
     o.dst = d; o.a = a_idx; o.b = b_idx;
     prog.ops.push_back(o);
@@ -430,12 +438,23 @@ hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_va
   a.blockmask = ((uint64_t)1 << a.ext_k) - 1;
   // rows per workgroup from the LDS budget: (constants + slots * T) * 36 B <= 144 KiB
   const size_t budget = 144 * 1024, cbytes = (size_t)a.n_consts * 36;
-  // rows per workgroup: the largest shape that fits (measured: for programs of few slots 256 rows beat 64 rows
-  // although the latter keeps one more wave per CU; what limits the interpreter is waves per SIMD, i.e. the slot
-  // count: 7 slots -> 8 waves per CU, 67 % VALU busy; the reference circuit's 17 slots -> 4 waves, 38 %)
-  uint32_t T = 256;
-  while (T > 64 && cbytes + (size_t)p.n_slots * T * 36 > budget) T >>= 1;
-  const uint32_t best_waves = (uint32_t)(160 * 1024 / (cbytes + (size_t)p.n_slots * T * 36)) * (T / 64);
+  // rows per workgroup: what limits the interpreter is waves per SIMD, i.e. LDS per row (the slot count).  Take the shape
+  // that keeps the most waves per CU; among shapes within one wave of each other the larger workgroup (measured: for
+  // programs of few slots 256 rows beat 64 rows although the latter keeps one more wave)
+  uint32_t T = 256, best_waves = 0;
+  for (uint32_t t : {256u, 128u, 64u}) {
+    const size_t need = cbytes + (size_t)p.n_slots * t * 36;
+    if (need > budget) continue;
+    const uint32_t waves = std::min<uint32_t>(32, (uint32_t)(160 * 1024 / need) * (t / 64));
+    if (waves > best_waves + 1 || best_waves == 0) {
+      best_waves = waves;
+      T = t;
+    }
+  }
+  if (const char* v = std::getenv("SG_GATES_ROWS")) {   // development aid
+    const uint32_t t = (uint32_t)std::atoi(v);
+    if (t == 64 || t == 128 || t == 256) T = t;
+  }
   const size_t lds = cbytes + (size_t)p.n_slots * T * 36;
   if (lds > budget) return hipErrorInvalidValue;
   if (std::getenv("SG_GATES_DEBUG"))

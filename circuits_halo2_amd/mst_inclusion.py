@@ -155,40 +155,100 @@ def lookup_expressions():
     return Expr.query(A.FIXED, 5, 0) * (a0 - a0n * 256), Expr.query(A.FIXED, 4, 0)
 
 
-# The two Poseidon chips share columns, so gates 0-4 and 7-11 share their expensive subexpressions (the s-boxes, the
-# partial-round sums).  Folded strictly in order, those values stay live across gates 5-6 and the program needs 17
-# LDS slots per row (4 waves per CU, 38 % VALU busy on MI355X).  The same polynomial
-#     values * y^19 + sum_i G_i y^(18 - i)
-# is therefore evaluated as  ((Horner(values; G0..G6) * y^5 + Horner(G7; G8..G11)) folded on with G12..G18,  with the
-# second chip's block lowered first and y^5 supplied as challenge 0 (gate_challenges): one more product per row, the
-# shared values die after twelve gates.
-GATE_BLOCKS = ((0, 7), (7, 12), (12, 19))
+# The gate block of evaluate_h is   values * y^Ng + sum_i G_i y^(Ng - 1 - i)   over the Ng = 17 + n_currencies gate polynomials
+# of `gates()`.  halo2's GraphEvaluator spells that as one Horner fold over the G_i; the value is what matters, and this
+# circuit's structure allows a much cheaper program for the same value:
+#   * the two Poseidon chips sit on the same columns: gates 7..13 are gates 0..6 with another selector, i.e. the same
+#     expressions E_k shifted by y^-7.  With J = sum_k E_k y^(Ng - 8 - k) both chips' gates of a selector pair (s, s') are
+#     J * (s y^7 + s'): every E_k is evaluated once and multiplied once.
+#   * the four simple selectors packed into f6 are q prod_{j != i} (j - q); since (j + 1 - q) = (j - q) + 1,
+#     sel3 = sel4 + q u1 u2 and sel1 = sel2 + q u3 u4 (u_j = j - q): 6 products instead of 12.
+#   * no fold is in gate order any more, so the needed powers of y come in as challenges (gate_challenge_exponents);
+#     every term is added to the running value as soon as it is complete and its operands die.
+# 53 products per row instead of 73, and 8 simultaneously live values instead of 13 under the interpreter's allocator
+# (csrc/gates.hip; `arithmetic.gates_program_info`): the kernel's occupancy is set by that number (LDS slots per row).
+# tests: the value against `gates()` folded with y on the CPU (test_verifier_cpu.py) and row by row on the GPU
+# (test_gpu_parity.py), the proofs against the verifier.
+@lru_cache(maxsize=None)
+def _gate_program(n_currencies: int = 2):
+    from .utils import ints_to_fr
+    _, mds, mds_inv = _poseidon()
+    g = A.GraphEvaluator()
+    ng = 17 + n_currencies
+    e = lambda i: ng - 1 - i                  # exponent of y on gate i
+    groups = []                               # challenge i = sum of y^x over groups[i]
+
+    def chal(exps):
+        exps = list(exps)
+        if exps not in groups:
+            groups.append(exps)
+        return (A.CHALLENGE, groups.index(exps), 0)
+
+    const = lambda v: g.add_constant(ints_to_fr([v % R]).tobytes())
+    a = lambda c, r=0: g.query(A.ADVICE, c, r)
+    f = lambda c: g.query(A.FIXED, c, 0)
+    add = lambda x, y: g.add_calculation(A.ADD, x, y)
+    sub = lambda x, y: g.add_calculation(A.SUB, x, y)
+    mul = lambda x, y: g.add_calculation(A.MUL, x, y)
+    sqr = lambda x: g.add_calculation(A.SQUARE, x)
+
+    def pow5(v):
+        return mul(sqr(sqr(v)), v)
+
+    y7 = chal([7])
+    acc = mul((A.PREVIOUS_VALUE, 0, 0), chal([ng]))
+    # -- pad-and-add, swap and sum gates first: their columns die before the Poseidon rounds need the slots
+    q = f(6)
+    u1, u2, u3, u4 = (sub(const(v), q) for v in (1, 2, 3, 4))
+    lo = mul(mul(q, u1), u2)
+    sel4 = mul(lo, u3)
+    sel3 = add(sel4, lo)
+    pad0 = sub(add(a(0, -1), a(0)), a(0, 1))
+    pad1 = sub(a(1, -1), a(1, 1))
+    j_pad = add(mul(pad0, chal([e(12)])), mul(pad1, chal([e(13)])))
+    acc = add(acc, mul(j_pad, add(mul(sel3, y7), sel4)))
+    hi = mul(mul(q, u3), u4)
+    sel2 = mul(hi, u1)
+    sel1 = add(sel2, hi)
+    swap_bool = mul(a(2), sub(const(1), a(2)))
+    d = mul(sub(a(1), a(0)), a(2))
+    swap_l = sub(add(d, a(0)), a(0, 1))
+    swap_r = sub(sub(a(1), d), a(1, 1))                   # (a0 - a1) a2 + a1 - a1_next
+    inner = add(add(mul(swap_bool, chal([e(14)])), mul(swap_l, chal([e(15)]))), mul(swap_r, chal([e(16)])))
+    acc = add(acc, mul(inner, sel1))
+    total = sub(add(a(0), a(1)), a(2))
+    acc = add(acc, mul(mul(total, chal([e(17 + j) for j in range(n_currencies)])), sel2))
+    # -- the Poseidon rounds, both chips at once
+    v1 = add(a(1), f(1))
+    s1 = pow5(v1)
+    s0 = pow5(add(a(0), f(0)))
+    full0 = sub(add(mul(s0, const(int(mds[0][0]))), mul(s1, const(int(mds[0][1])))), a(0, 1))
+    full1 = sub(add(mul(s0, const(int(mds[1][0]))), mul(s1, const(int(mds[1][1])))), a(1, 1))
+    j_full = add(mul(full0, chal([e(7)])), mul(full1, chal([e(8)])))
+    acc = add(acc, mul(j_full, add(mul(f(7), y7), f(9))))
+    j_part = mul(sub(s0, a(2)), chal([e(9)]))
+    mid = [add(mul(a(2), const(int(mds[i][0]))), mul(v1, const(int(mds[i][1])))) for i in range(2)]
+    nxt = [add(mul(a(0, 1), const(int(mds_inv[i][0]))), mul(a(1, 1), const(int(mds_inv[i][1])))) for i in range(2)]
+    j_part = add(j_part, mul(sub(add(mid[1], f(3)), nxt[1]), chal([e(11)])))
+    j_part = add(j_part, mul(sub(pow5(add(mid[0], f(2))), nxt[0]), chal([e(10)])))
+    add(acc, mul(j_part, add(mul(f(8), y7), f(10))))      # the last calculation is the row's new value
+    return g, tuple(tuple(x) for x in groups)
+
+
+def gate_graph(n_currencies: int = 2) -> A.GraphEvaluator:
+    """the custom-gate part of evaluate_h as a GraphEvaluator program: values <- values * y^Ng + sum_i G_i y^(Ng - 1 - i)"""
+    return _gate_program(n_currencies)[0]
 
 
 def gate_challenge_exponents(n_currencies: int = 2):
     """what the gate program reads as SG_VS_CHALLENGE sources: challenge i = sum of y^e over group i"""
-    return [[GATE_BLOCKS[1][1] - GATE_BLOCKS[1][0]]]
+    return [list(x) for x in _gate_program(n_currencies)[1]]
 
 
 def gate_challenges(y: int, n_currencies: int = 2):
     """the `challenges` array the gate program expects (gate_challenge_exponents evaluated at y)"""
     from .utils import ints_to_fr
-    return ints_to_fr([sum(pow(y, e, R) for e in group) % R for group in gate_challenge_exponents(n_currencies)])
-
-
-@lru_cache(maxsize=None)
-def gate_graph(n_currencies: int = 2) -> A.GraphEvaluator:
-    """the custom-gate part of evaluate_h: values = Horner(previous value, gate polynomials, y), see GATE_BLOCKS"""
-    g = A.GraphEvaluator()
-    parts = [e.lower(g) for e in gates(n_currencies)]
-    y = (A.Y, 0, 0)
-    (a0, a1), (b0, b1), (c0, c1) = GATE_BLOCKS[0], GATE_BLOCKS[1], (GATE_BLOCKS[2][0], len(parts))
-    second = g.add_calculation(A.HORNER, parts[b0], y, parts[b0 + 1:b1])
-    first = g.add_calculation(A.HORNER, (A.PREVIOUS_VALUE, 0, 0), y, parts[a0:a1])
-    shifted = g.add_calculation(A.MUL, first, (A.CHALLENGE, 0, 0))
-    joined = g.add_calculation(A.ADD, second, shifted)          # operand order = lowering order: second chip first
-    g.add_calculation(A.HORNER, joined, y, parts[c0:c1])
-    return g
+    return ints_to_fr([sum(pow(y, x, R) for x in group) % R for group in gate_challenge_exponents(n_currencies)])
 
 
 @lru_cache(maxsize=None)

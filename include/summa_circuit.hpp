@@ -189,25 +189,174 @@ inline std::vector<E> gates(uint32_t n_currencies) {
   for (uint32_t c = 0; c < n_currencies; c++) out.push_back(s * (a(0) + a(1) - a(2)));
   return out;
 }
-// evaluate_h's custom-gate block: values = Horner(previous value, gate polynomials, y), folded in the three blocks of
-// mst_inclusion.GATE_BLOCKS (the second Poseidon chip's block first, joined with y^5 passed as challenge 0)
-inline Graph gate_graph(uint32_t n_currencies) {
+// evaluate_h's custom-gate block, values <- values * y^Ng + sum_i G_i y^(Ng - 1 - i) over the Ng = 17 + n_currencies polynomials of
+// gates(), as the program of mst_inclusion._gate_program (same calculations in the same order; the comment there explains the
+// factoring: both Poseidon chips at once, the packed selectors by differences, powers of y as challenges)
+struct GateProgramSpec {
+  Graph graph;
+  std::vector<std::vector<uint32_t>> challenge_exponents;   // challenge i = sum of y^e over group i
+};
+inline GateProgramSpec gate_program(uint32_t n_currencies) {
+  const Poseidon& P = poseidon();
   GraphBuilder g;
-  std::vector<sg_value_source> parts;
-  for (const E& e : gates(n_currencies)) parts.push_back(e->lower(g));
-  const sg_value_source y{SG_VS_Y, 0, 0};
-  const size_t b0 = 7, b1 = 12;
-  std::vector<sg_value_source> p2(parts.begin() + b0 + 1, parts.begin() + b1), p1(parts.begin(), parts.begin() + b0),
-      p3(parts.begin() + b1, parts.end());
-  const sg_value_source second = g.add_calculation(SG_OP_HORNER, parts[b0], y, &p2);
-  const sg_value_source first = g.add_calculation(SG_OP_HORNER, sg_value_source{SG_VS_PREVIOUS_VALUE, 0, 0}, y, &p1);
-  const sg_value_source shifted = g.add_calculation(SG_OP_MUL, first, sg_value_source{SG_VS_CHALLENGE, 0, 0});
-  const sg_value_source joined = g.add_calculation(SG_OP_ADD, second, shifted);
-  g.add_calculation(SG_OP_HORNER, joined, y, &p3);
-  return g.g;
+  GateProgramSpec out;
+  auto& groups = out.challenge_exponents;
+  const uint32_t ng = 17 + n_currencies;
+  auto e = [&](uint32_t i) { return ng - 1 - i; };
+  auto chal = [&](std::vector<uint32_t> exps) {
+    for (size_t i = 0; i < groups.size(); i++)
+      if (groups[i] == exps) return sg_value_source{SG_VS_CHALLENGE, (uint32_t)i, 0};
+    groups.push_back(exps);
+    return sg_value_source{SG_VS_CHALLENGE, (uint32_t)groups.size() - 1, 0};
+  };
+  auto cst = [&](const Fr& v) { return g.add_constant(v); };
+  auto a = [&](uint32_t c, int32_t r = 0) { return g.query(SG_VS_ADVICE, c, r); };
+  auto f = [&](uint32_t c) { return g.query(SG_VS_FIXED, c, 0); };
+  auto add = [&](sg_value_source x, sg_value_source y) { return g.add_calculation(SG_OP_ADD, x, y); };
+  auto sub = [&](sg_value_source x, sg_value_source y) { return g.add_calculation(SG_OP_SUB, x, y); };
+  auto mul = [&](sg_value_source x, sg_value_source y) { return g.add_calculation(SG_OP_MUL, x, y); };
+  auto sqr = [&](sg_value_source x) { return g.add_calculation(SG_OP_SQUARE, x); };
+  auto pow5 = [&](sg_value_source v) { return mul(sqr(sqr(v)), v); };
+  // NB: C++ leaves the evaluation order of function arguments open; every step below is its own statement so that constants,
+  // rotations and calculations are numbered exactly as in the Python twin (which evaluates left to right)
+  using V = sg_value_source;
+  const V y7 = chal({7});
+  const V c_ng = chal({ng});
+  V acc = mul(V{SG_VS_PREVIOUS_VALUE, 0, 0}, c_ng);
+  // pad-and-add, swap and sum gates
+  const V q = f(6);
+  const V k1 = cst(Fr::from_u64(1));
+  const V u1 = sub(k1, q);
+  const V k2 = cst(Fr::from_u64(2));
+  const V u2 = sub(k2, q);
+  const V k3 = cst(Fr::from_u64(3));
+  const V u3 = sub(k3, q);
+  const V k4 = cst(Fr::from_u64(4));
+  const V u4 = sub(k4, q);
+  const V qu1 = mul(q, u1);
+  const V lo = mul(qu1, u2);
+  const V sel4 = mul(lo, u3);
+  const V sel3 = add(sel4, lo);
+  const V a0p = a(0, -1);
+  const V a0c = a(0);
+  const V p0s = add(a0p, a0c);
+  const V a0n = a(0, 1);
+  const V pad0 = sub(p0s, a0n);
+  const V a1p = a(1, -1);
+  const V a1n = a(1, 1);
+  const V pad1 = sub(a1p, a1n);
+  const V c12 = chal({e(12)});
+  const V jp0 = mul(pad0, c12);
+  const V c13 = chal({e(13)});
+  const V jp1 = mul(pad1, c13);
+  const V j_pad = add(jp0, jp1);
+  const V s3y = mul(sel3, y7);
+  const V cpad = add(s3y, sel4);
+  const V tpad = mul(j_pad, cpad);
+  acc = add(acc, tpad);
+  const V qu3 = mul(q, u3);
+  const V hi = mul(qu3, u4);
+  const V sel2 = mul(hi, u1);
+  const V sel1 = add(sel2, hi);
+  const V a2c = a(2);
+  const V one_m = sub(k1, a2c);
+  const V swap_bool = mul(a2c, one_m);
+  const V a1c = a(1);
+  const V dd = sub(a1c, a0c);
+  const V d = mul(dd, a2c);
+  const V sl0 = add(d, a0c);
+  const V swap_l = sub(sl0, a0n);
+  const V sr0 = sub(a1c, d);
+  const V swap_r = sub(sr0, a1n);
+  const V c14 = chal({e(14)});
+  const V i0 = mul(swap_bool, c14);
+  const V c15 = chal({e(15)});
+  const V i1 = mul(swap_l, c15);
+  const V i01 = add(i0, i1);
+  const V c16 = chal({e(16)});
+  const V i2 = mul(swap_r, c16);
+  const V inner = add(i01, i2);
+  const V tswap = mul(inner, sel1);
+  acc = add(acc, tswap);
+  const V t01 = add(a0c, a1c);
+  const V total = sub(t01, a2c);
+  std::vector<uint32_t> sum_exps;
+  for (uint32_t j = 0; j < n_currencies; j++) sum_exps.push_back(e(17 + j));
+  const V csum = chal(sum_exps);
+  const V ts0 = mul(total, csum);
+  const V tsum = mul(ts0, sel2);
+  acc = add(acc, tsum);
+  // the Poseidon rounds, both chips at once
+  const V f1c = f(1);
+  const V v1 = add(a1c, f1c);
+  const V s1 = pow5(v1);
+  const V f0c = f(0);
+  const V v0 = add(a0c, f0c);
+  const V s0 = pow5(v0);
+  auto full = [&](int i, const V& nx) {
+    const V m0 = cst(P.mds[i][0]);
+    const V x0 = mul(s0, m0);
+    const V m1 = cst(P.mds[i][1]);
+    const V x1 = mul(s1, m1);
+    const V x = add(x0, x1);
+    return sub(x, nx);
+  };
+  const V full0 = full(0, a0n);
+  const V full1 = full(1, a1n);
+  const V c7 = chal({e(7)});
+  const V jf0 = mul(full0, c7);
+  const V c8 = chal({e(8)});
+  const V jf1 = mul(full1, c8);
+  const V j_full = add(jf0, jf1);
+  const V f7c = f(7);
+  const V f7y = mul(f7c, y7);
+  const V f9c = f(9);
+  const V cfull = add(f7y, f9c);
+  const V tfull = mul(j_full, cfull);
+  acc = add(acc, tfull);
+  const V e2 = sub(s0, a2c);
+  const V c9 = chal({e(9)});
+  V j_part = mul(e2, c9);
+  V mid[2], nxt[2];
+  for (int i = 0; i < 2; i++) {
+    const V m0 = cst(P.mds[i][0]);
+    const V x0 = mul(a2c, m0);
+    const V m1 = cst(P.mds[i][1]);
+    const V x1 = mul(v1, m1);
+    mid[i] = add(x0, x1);
+  }
+  for (int i = 0; i < 2; i++) {
+    const V m0 = cst(P.mds_inv[i][0]);
+    const V x0 = mul(a0n, m0);
+    const V m1 = cst(P.mds_inv[i][1]);
+    const V x1 = mul(a1n, m1);
+    nxt[i] = add(x0, x1);
+  }
+  const V f3c = f(3);
+  const V e4a = add(mid[1], f3c);
+  const V e4 = sub(e4a, nxt[1]);
+  const V c11 = chal({e(11)});
+  const V jp4 = mul(e4, c11);
+  j_part = add(j_part, jp4);
+  const V f2c = f(2);
+  const V e3a = add(mid[0], f2c);
+  const V e3b = pow5(e3a);
+  const V e3 = sub(e3b, nxt[0]);
+  const V c10 = chal({e(10)});
+  const V jp3 = mul(e3, c10);
+  j_part = add(j_part, jp3);
+  const V f8c = f(8);
+  const V f8y = mul(f8c, y7);
+  const V f10c = f(10);
+  const V cpart = add(f8y, f10c);
+  const V tpart = mul(j_part, cpart);
+  add(acc, tpart);   // the last calculation is the row's new value
+  out.graph = g.g;
+  return out;
 }
+inline Graph gate_graph(uint32_t n_currencies) { return gate_program(n_currencies).graph; }
 // what that program reads as challenges: challenge i = sum of y^e over group i (ProvingKey::gate_challenge_exps)
-inline std::vector<std::vector<uint32_t>> gate_challenge_exponents(uint32_t) { return {{5}}; }
+inline std::vector<std::vector<uint32_t>> gate_challenge_exponents(uint32_t n_currencies) { return gate_program(n_currencies).challenge_exponents; }
 // the lookup's input expression f5 * (a0 - 2^8 a0_next), one value per row
 inline Graph lookup_input_graph() {
   GraphBuilder g;

@@ -1556,7 +1556,7 @@ def test_mst_inclusion_constraint_system_on_device(gpu, O, k, ext_k, sample):
     start = O.random_fr(5310, ne)
     none = np.zeros(0, dtype=np.uint8)
     g = M.gate_graph()
-    chal = M.gate_challenges(PR.fr_from_bytes(bytes(y)))     # the program folds its middle block with y^5 (GATE_BLOCKS)
+    chal = M.gate_challenges(PR.fr_from_bytes(bytes(y)))     # the powers of y the factored program reads
     want = O.quotient_gates(start, g.as_dict(), fixed, advice, [], chal, beta, gamma, theta, y, k, ext_k)
     got = A.quotient_gates(dev(start), g, [dev(c) for c in fixed], [dev(c) for c in advice], [], chal, beta, gamma, theta, y,
                            k, ext_k).cpu().numpy()

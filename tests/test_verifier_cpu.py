@@ -126,22 +126,38 @@ def test_product_constraint_system_equals_the_restatement():
     assert (inp.evaluate(q), tab.evaluate(q)) == SV.lookup_input_table(q_oracle)
     assert max(e.degree() for e in M.gates()) == M.DEGREE
     assert [("f" if k == A.FIXED else "a" if k == A.ADVICE else "i", c) for k, c in M.PERMUTATION_COLUMNS] == SV.PERMUTATION_COLUMNS
-    g = M.gate_graph()
-    horners = [c for c in g.calculations if c[0] == A.HORNER]
-    assert g.calculations[-1][0] == A.HORNER and sum(len(c[3]) for c in horners) + 1 == 19   # one gate starts a block
-    assert sorted(g.rotations) == [-1, 0, 1]
-    # the blocked fold is the plain one: values * y^19 + sum_i G_i y^(18 - i), checked with integers
-    y, prev = 0x1234567, 0x7654321
-    parts = [e.evaluate(q) for e in M.gates()]
-    plain = prev
-    for t in parts:
-        plain = (plain * y + t) % PR.R
-    (a0, a1), (b0, b1), (c0, c1) = M.GATE_BLOCKS
-    fold = lambda start, ps: (lambda acc: [acc := (acc * y + t) % PR.R for t in ps][-1] if ps else acc)(start)
-    first, second = fold(prev, parts[a0:a1]), fold(parts[b0], parts[b0 + 1:b1])
-    y5 = PR.fr_from_bytes(bytes(M.gate_challenges(y)))
-    assert y5 == pow(y, 5, PR.R)
-    assert fold((second + first * y5) % PR.R, parts[c0:c1]) == plain
+    assert sorted(M.gate_graph().rotations) == [-1, 0, 1]
+
+
+@pytest.mark.parametrize("nc", [1, 2, 3])
+def test_gate_program_value_is_the_plain_fold_of_the_gate_polynomials(nc):
+    """`mst_inclusion.gate_graph` is a factored program (both Poseidon chips at once, packed selectors by differences, powers of
+    y as challenges); its VALUE must be halo2's  prev * y^Ng + sum_i G_i y^(Ng - 1 - i)  over `gates()`, the polynomials the
+    restated verifier folds.  Run by the oracle's graph interpreter on every row of a 2^4-row domain with random columns."""
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd import mst_inclusion as M
+    from oracle import oracle as O
+    from oracle import pyref as PR
+    k, n = 4, 16
+    g = M.gate_graph(nc)
+    groups = M.gate_challenge_exponents(nc)
+    assert len(groups) == 12 and [17 + nc] in groups and [7] in groups and sorted(g.rotations) == [-1, 0, 1]
+    n_ops, n_slots = A.gates_program_info(g, M.NUM_FIXED, M.NUM_ADVICE, 1, len(groups))
+    assert n_slots <= 8 and n_ops < 140            # what the kernel's occupancy hangs on (csrc/gates.hip)
+    fixed = [O.random_fr(6100 + i, n) for i in range(M.NUM_FIXED)]
+    advice = [O.random_fr(6200 + i, n) for i in range(M.NUM_ADVICE)]
+    beta, gamma, theta, y = (O.random_fr(6300 + i, 1) for i in range(4))
+    prev = O.random_fr(6310, n)
+    yi = PR.fr_from_bytes(bytes(y))
+    chal = M.gate_challenges(yi, nc)
+    got = O.quotient_gates(prev, g.as_dict(), fixed, advice, [], chal, beta, gamma, theta, y, k, k)
+    cell = lambda arr, row: PR.fr_from_bytes(bytes(arr[32 * row:32 * row + 32]))
+    for row in range(n):
+        q = lambda kind, c, rot: cell((fixed if kind == A.FIXED else advice)[c], (row + rot) % n)
+        acc = cell(prev, row)
+        for e in M.gates(nc):
+            acc = (acc * yi + e.evaluate(q)) % PR.R
+        assert cell(got, row) == acc, row
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/contracts/src/InclusionVerifier.sol"),

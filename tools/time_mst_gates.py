@@ -10,7 +10,8 @@ from circuits_halo2_amd.arithmetic import fr_to_montgomery
 
 ffi.check(ffi.lib().sg_init(0))
 g = M.gate_graph()
-print(f"program: {len(g.calculations)} calculations, {len(g.constants)} constants, rotations {g.rotations}", flush=True)
+print(f"program: {len(g.calculations)} calculations, {len(g.constants)} constants, rotations {g.rotations}, "
+      f"lowered: {A.gates_program_info(g, M.NUM_FIXED, M.NUM_ADVICE, 0, len(M.gate_challenge_exponents()))} (instructions, LDS slots)", flush=True)
 for k in [int(x) for x in os.environ.get("KS", "11,13,15,17").split(",")]:
     ext_k = k + 3
     ne = 1 << ext_k
@@ -20,10 +21,11 @@ for k in [int(x) for x in os.environ.get("KS", "11,13,15,17").split(",")]:
     values = col(300)
     b = np.frombuffer(bytes(range(1, 33)), dtype=np.uint8).copy(); b[31] = 0
     none = np.zeros(0, dtype=np.uint8)
+    chal = M.gate_challenges(0x1234567)
     best = 1e9
     for _ in range(6):
         torch.cuda.synchronize(); t = time.perf_counter()
-        A.quotient_gates(values, g, fixed, advice, [], b, b, b, b, b, k, ext_k)   # one challenge (y^5 in a proof)
+        A.quotient_gates(values, g, fixed, advice, [], chal, b, b, b, b, k, ext_k)   # the challenges: powers of y
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
     print(f"k={k} (2^{ext_k} rows, 14 columns): {best * 1e3:.3f} ms, {ne / best / 1e9:.2f} G rows/s, "
           f"{14 * 32 * ne / best / 1e9:.0f} GB/s of column reads", flush=True)
