@@ -611,10 +611,12 @@ def main():
                     from full_flow import run as run_full_flow
                     torch.cuda.empty_cache()
                     line["full_flow_levels20_k13"] = dict(run_full_flow(20, 13, cpp=not profiled17, nc=1),
-                                                          note="the reference bench's configuration (LEVELS = 20, N_CURRENCIES = 1, N_BYTES = 8, k = 13): 2^20-user "
-                                                               "Merkle sum tree on the device, inclusion witness in the reference circuit's floor plan "
-                                                               "(host, Python integers), proving-key construction "
-                                                               "from Lagrange columns, create_proof (Python driver / C++ driver)")
+                                                          note="the reference's criterion bench (benches/full_solvency_flow.rs: LEVELS = 20, N_CURRENCIES = 1, "
+                                                               "N_BYTES = 8, k = 13), its six entries on the device: mst_build_ms / mst_build_sorted_ms (2^20 "
+                                                               "synthetic users), keygen_vk_ms (17 commitments) / keygen_pk_ms (coefficient and coset forms), "
+                                                               "full_prover_ms / full_verifier_ms (Blake2b flavour, Python driver, product verifier); plus the "
+                                                               "inclusion witness in the reference circuit's floor plan (host, Python integers) and the "
+                                                               "Keccak-flavour create_proof (Python driver / C++ driver)")
                 except Exception as ex:
                     line["full_flow_levels20_k13"] = {"error": repr(ex)}
             except Exception as ex:

@@ -1,7 +1,8 @@
-"""The shape of the reference's criterion bench (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13): a
-Merkle sum tree of 2^LEVELS synthetic users on the device, the inclusion witness of one user in the reference circuit's
-own floor plan (mst_inclusion.reference_assignment, N_CURRENCIES = 2), key generation from the Lagrange columns,
-create_proof.
+"""The shape of the reference's criterion bench (zk_prover/benches/full_solvency_flow.rs: LEVELS = 20, k = 13), its six
+entries on the device: build the Merkle sum tree of 2^LEVELS synthetic users (:18-33), build it sorted by username (:35-50),
+generate the verifying key (:52-68: the 17 commitments) and the proving key (:70-86: the coefficient / coset forms), generate
+the proof (:88-116: `full_prover`, Blake2b transcript) and verify it (:118-150: `full_verifier`); plus the inclusion witness of
+one user in the reference circuit's own floor plan (mst_inclusion.reference_assignment) and the Keccak-flavour create_proof.
 `build(levels, k)` returns everything a caller needs (tests/test_gpu_prover.py verifies the proof); run as a script
 it prints the timings."""
 import os, sys, time
@@ -30,6 +31,28 @@ def build(levels=20, k=13, user=123457, nc=2, timings=None):
     run_build(); torch.cuda.synchronize()
     t0 = time.perf_counter(); run_build(); torch.cuda.synchronize()
     t["mst_build_ms"] = (time.perf_counter() - t0) * 1e3
+    # `from_csv_sorted` [REF merkle_sum_tree/mst.rs: entries sorted by username before the tree is built]: order the 256-bit
+    # usernames on the device (four stable 64-bit sorts, least significant limb first), gather the entries, build
+    def run_sorted():
+        canon = A.fr_from_montgomery(d_users).view(torch.int64).reshape(size, 4)
+        order = torch.arange(size, device="cuda")
+        for limb in range(4):
+            key = canon[order, limb] ^ (-(1 << 63))                    # unsigned order on signed 64-bit keys
+            order = order[torch.sort(key, stable=True).indices]
+        su = d_users.view(size, 32)[order].reshape(-1)
+        sb = d_bals.view(size, 32 * nc)[order].reshape(-1)
+        ffi.check(ffi.lib().sg_mst_build_dev(ffi.dev_ptr(su), ffi.dev_ptr(sb), C.c_uint32(levels), C.c_uint32(nc),
+                                             ffi.dev_ptr(d_hs), ffi.dev_ptr(d_bs), ffi.current_stream_ptr()))
+        return su
+    d_hs, d_bs = torch.empty_like(d_h), torch.empty_like(d_b)
+    run_sorted(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); su = run_sorted(); torch.cuda.synchronize()
+    t["mst_build_sorted_ms"] = (time.perf_counter() - t0) * 1e3
+    if size <= (1 << 20):   # the order is the integers' order, and the root's balances do not depend on it
+        first = A.fr_from_montgomery(su[:32 * 4096]).cpu().numpy().reshape(-1, 32)
+        as_int = [int.from_bytes(bytes(r), "little") for r in first]
+        assert as_int == sorted(as_int)
+        assert (d_bs[-32 * nc:] == d_b[-32 * nc:]).all()
     # the user's path: sibling (hash, balances) per level, bottom-up (level-major node arrays)
     t0 = time.perf_counter()
     rinv = pow(1 << 256, -1, R)
@@ -67,6 +90,11 @@ def keygen_and_prove(asg, k, params, reps=3, timings=None, nc=2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pk = prover.ProvingKey(params, k, fixed, sigma, nc)
     t["keygen_ms"] = (time.perf_counter() - t0) * 1e3
+    # the two halves as the reference benches them: keygen_vk = the 17 commitments, keygen_pk = the transforms
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    params.commit_batch(fixed + sigma, lagrange=True)
+    t["keygen_vk_ms"] = (time.perf_counter() - t0) * 1e3
+    t["keygen_pk_ms"] = max(0.0, t["keygen_ms"] - t["keygen_vk_ms"])
     proof = prover.create_proof(params, pk, advice, asg["instances"])
     best = 1e9
     for _ in range(reps):
@@ -74,6 +102,19 @@ def keygen_and_prove(asg, k, params, reps=3, timings=None, nc=2):
         proof = prover.create_proof(params, pk, advice, asg["instances"])
         best = min(best, (time.perf_counter() - t0) * 1e3)
     t["create_proof_ms"] = best
+    # full_prover / full_verifier: the Blake2b flavour, the product's verifier (GPU MSM + host pairing)
+    from circuits_halo2_amd import api, verifier
+    vk = api.VerifyingKey(k, nc, pk.fixed_comms, pk.permutation_comms, pk.vk_digest)
+    best_p, best_v = 1e9, 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        blake = prover.create_proof(params, pk, advice, asg["instances"], transcript=prover.Blake2bWrite())
+        best_p = min(best_p, (time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        ok = verifier.verify_proof(params, vk, blake, asg["instances"], flavour="blake2b")
+        best_v = min(best_v, (time.perf_counter() - t0) * 1e3)
+        assert ok
+    t["full_prover_ms"], t["full_verifier_ms"], t["verified"] = best_p, best_v, True
     return pk, advice, proof
 
 
