@@ -18,6 +18,8 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass, field
 
+import ctypes as C
+
 import numpy as np
 
 from . import mst_inclusion as M
@@ -160,10 +162,18 @@ def keygen(params: ParamsKZG, circuit: MstInclusionCircuit, vk_transcript_repr: 
     permutation, commit to them (17 MSMs) and transform them into the three bases the prover reads (all on the device).
     The key's digest is halo2's `transcript_repr`, derived (vk_repr.py); `vk_transcript_repr` overrides it for a key
     whose constraint system was built elsewhere."""
+    import torch
+    from . import ffi
     k = params.k
-    asg = circuit.synthesize(k)
     n = 1 << k
-    pk = P.ProvingKey(params, k, [_device_column(c, n) for c in asg["fixed"]], [_device_column(c, n) for c in asg["sigma"]],
+    # the floor plan (fixed columns, permutation) by the library's compiled replay of `synthesize` (include/summa_circuit.hpp;
+    # mst_inclusion.reference_assignment is its Python twin, compared column by column in tests/test_host_logic.py)
+    fixed_np = np.empty((M.NUM_FIXED, 32 * n), dtype=np.uint8)
+    sigma_np = np.empty((len(M.PERMUTATION_COLUMNS), 32 * n), dtype=np.uint8)
+    rows = C.c_uint32(0)
+    ffi.check(ffi.lib().sg_mst_inclusion_keygen_columns(C.c_uint32(k), C.c_uint32(circuit.levels), C.c_uint32(circuit.n_currencies),
+                                                        C.c_uint32(circuit.n_bytes), ffi.ptr(fixed_np), ffi.ptr(sigma_np), C.byref(rows)))
+    pk = P.ProvingKey(params, k, [torch.from_numpy(c).cuda() for c in fixed_np], [torch.from_numpy(c).cuda() for c in sigma_np],
                       circuit.n_currencies)
     pk.circuit_shape = circuit.shape()
     if vk_transcript_repr is not None:

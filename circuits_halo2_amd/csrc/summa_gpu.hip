@@ -18,6 +18,7 @@
 #include "host_curve.h"
 #include "host_pairing.h"
 #include "../../include/summa_prover.hpp"
+#include "../../include/summa_circuit.hpp"
 #include "msm.h"
 #include "ntt.h"
 #include "quotient.h"
@@ -1908,6 +1909,35 @@ int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_ad
   if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_gates_program_info: " + err).c_str());
   *n_ops_out = (uint32_t)prog.ops.size();
   *n_slots_out = prog.n_slots;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------ keygen's circuit side
+// What `keygen_vk` / `keygen_pk` need of `MstInclusionCircuit::synthesize` over 2^k rows [REF zk_prover/src/circuits/
+// merkle_sum_tree.rs:228-520 replayed over halo2's SimpleFloorPlanner: include/summa_circuit.hpp]: the 11 fixed columns (round
+// constants, range table, compressed selectors, constants) and the 6 permutation columns sigma_c[row] = the label delta^c' omega^row'
+// of the cell (c, row) is copy-constrained to.  Host only (no device needed); Montgomery words, column-major.
+int sg_mst_inclusion_keygen_columns(uint32_t k, uint32_t levels, uint32_t n_currencies, uint32_t n_bytes, uint8_t* fixed_out,
+                                    uint8_t* sigma_out, uint32_t* rows_used_out) {
+  if (!fixed_out || !sigma_out || k < 4 || k > 25 || levels == 0 || levels > 48 || n_currencies == 0 || n_currencies > 16 || n_bytes == 0 ||
+      n_bytes > 31)
+    return fail(SG_ERR_INVALID, "sg_mst_inclusion_keygen_columns: bad argument");
+  try {
+    using summa::prover::Fr;
+    const summa::circuit::FloorPlan fp(k, levels, n_currencies, n_bytes);
+    const size_t n = (size_t)1 << k;
+    if (fp.rows_used + summa::circuit::BLINDING_FACTORS + 1 > n) return fail(SG_ERR_INVALID, "sg_mst_inclusion_keygen_columns: not enough rows");
+    static const uint8_t root_2_28[32] = {0x03, 0xdd, 0xb9, 0xf5, 0x16, 0x6d, 0x18, 0xb7, 0x98, 0x86, 0x5e, 0xa9, 0x3d, 0xd3, 0x1f, 0x74,
+                                          0x32, 0x15, 0xcf, 0x6d, 0xd3, 0x93, 0x29, 0xc8, 0xd3, 0x4f, 0x1e, 0xd9, 0x60, 0xc3, 0x7c, 0x9c};
+    Fr omega = Fr::from_be_bytes_reduced(root_2_28);
+    for (uint32_t i = k; i < 28; i++) omega = omega * omega;
+    for (uint32_t c = 0; c < summa::circuit::NUM_FIXED; c++) std::memcpy(fixed_out + 32 * n * c, fp.fixed[c].data(), 32 * n);
+    const auto sigma = fp.sigma(omega);
+    for (uint32_t c = 0; c < summa::circuit::NUM_PERM; c++) std::memcpy(sigma_out + 32 * n * c, sigma[c].data(), 32 * n);
+    if (rows_used_out) *rows_used_out = fp.rows_used;
+  } catch (const std::exception& ex) {
+    return fail(SG_ERR_INVALID, (std::string("sg_mst_inclusion_keygen_columns: ") + ex.what()).c_str());
+  }
   return SG_OK;
 }
 

@@ -350,6 +350,12 @@ int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const vo
 int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
                           uint32_t* n_ops_out, uint32_t* n_slots_out);
 
+/* ---- keygen's circuit side: what keygen_vk / keygen_pk need of MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>::synthesize over
+ * 2^k rows in the reference's own floor plan (include/summa_circuit.hpp): fixed_out = 11 columns x 2^k x 32 B, sigma_out = 6
+ * columns x 2^k x 32 B (Montgomery Fr, column-major).  Host only -- no device is touched. */
+int sg_mst_inclusion_keygen_columns(uint32_t k, uint32_t levels, uint32_t n_currencies, uint32_t n_bytes, uint8_t* fixed_out,
+                                    uint8_t* sigma_out, uint32_t* rows_used_out);
+
 /* ---- witness side: the Merkle sum tree of
  * zk_prover/src/merkle_sum_tree (node.rs:16-84, utils/build_tree.rs:5-78) over Poseidon(t = 2,
  * rate 1, R_F = 8, R_P = 56, x^5; chips/poseidon/poseidon_spec.rs:14-37).  All values 32-B Fr

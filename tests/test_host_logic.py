@@ -237,3 +237,27 @@ def test_cpp_circuit_equals_the_python_twin(k, levels, nc, nb, tmp_path):
     want += ints_to_fr([int.from_bytes(PR.keccak256(b"dxGaEAii"), "big"), 11888]).tobytes()
     assert len(raw) == len(want)
     assert raw == want
+
+
+@pytest.mark.parametrize("k,levels,nc", [(11, 4, 2), (13, 20, 1)])
+def test_library_keygen_columns_equal_the_python_floor_plan(k, levels, nc):
+    """sg_mst_inclusion_keygen_columns (host only; what api.keygen uploads) against mst_inclusion.reference_assignment of the
+    empty circuit: the 11 fixed and the 6 permutation columns, row by row; bad shapes are refused"""
+    import ctypes as C
+    from circuits_halo2_amd import api, ffi
+    from circuits_halo2_amd.utils import ints_to_fr
+    n = 1 << k
+    f = np.empty((11, 32 * n), dtype=np.uint8)
+    s = np.empty((6, 32 * n), dtype=np.uint8)
+    rows = C.c_uint32(0)
+    L = ffi.lib()
+    ffi.check(L.sg_mst_inclusion_keygen_columns(C.c_uint32(k), C.c_uint32(levels), C.c_uint32(nc), C.c_uint32(8), ffi.ptr(f), ffi.ptr(s),
+                                                C.byref(rows)))
+    asg = api.MstInclusionCircuit.init_empty(levels, nc, 8).synthesize(k)
+    assert rows.value == asg["rows_used"]
+    for j in range(11):
+        assert (f[j] == ints_to_fr(asg["fixed"][j])).all(), j
+    for j in range(6):
+        assert (s[j] == ints_to_fr(asg["sigma"][j])).all(), j
+    assert L.sg_mst_inclusion_keygen_columns(C.c_uint32(3), C.c_uint32(levels), C.c_uint32(nc), C.c_uint32(8), ffi.ptr(f), ffi.ptr(s), None) != 0
+    assert L.sg_mst_inclusion_keygen_columns(C.c_uint32(8), C.c_uint32(20), C.c_uint32(2), C.c_uint32(8), ffi.ptr(f), ffi.ptr(s), None) != 0   # rows
