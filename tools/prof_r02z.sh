@@ -1,0 +1,14 @@
+set -e
+mkdir -p gpurun_out/r02y
+./tools/microbench3 > gpurun_out/r02y/fp64_vs_f29.txt 2>&1 || true
+cat gpurun_out/r02y/fp64_vs_f29.txt
+python bench.py --steps 20 --warmup 5 > gpurun_out/r02y/bench.json 2> gpurun_out/r02y/bench.err; echo "bench rc=$?"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r02z -- python3 bench.py --steps 20 --warmup 5 --no-cpu > gpurun_out/r02y/bench_under_rocprof.json 2> gpurun_out/r02y/rocprof.err; echo "rocprof rc=$?"
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_r02z_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r02y/rocprof.err; echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_r02z_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r02y/rocprof.err; echo "write rc=$?"
+rocprofv3 --pmc VALUBusy VALUUtilization -d gpurun_out/prof_r02z_valu -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r02y/rocprof.err; echo "valu rc=$?"
+python tools/summarize_prof.py r02z; python tools/summarize_valu.py r02z || true
+ls profiles | grep r02
+du -sh gpurun_out/prof_r02z* | tail -5
+rm -rf gpurun_out/prof_r02z/*/*_kernel_trace.csv.bak
