@@ -10,7 +10,8 @@ hipError_t poly_eval(const fp_words* d_coeffs, size_t n, const words8& x, fp_wor
                      fp_words* d_out, hipStream_t stream);
 size_t poly_eval_tmp_elems(size_t n);
 // out[j] = polys[j](xs[j]) for m <= EVAL_BATCH_MAX polynomials of n <= 2^26 coefficients each, two launches;
-// d_partial: m * ceil(n / 8192) elements
+// d_partial: m * poly_eval_batch_blocks(n) elements
+size_t poly_eval_batch_blocks(size_t n);
 static constexpr uint32_t EVAL_BATCH_MAX = 40;
 hipError_t poly_eval_batch(const fp_words* const* d_polys, const words8* xs, uint32_t m, size_t n, fp_words* d_partial,
                            fp_words* d_out, hipStream_t stream);

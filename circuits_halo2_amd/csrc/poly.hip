@@ -25,7 +25,12 @@ __device__ __forceinline__ void store_hat(fp_words* p, const f29& x_hat) {  // x
 // ---- eval_polynomial: sum_i c[i] x^i ------------------------------------------------------
 // thread: Horner over CH consecutive coefficients; workgroup: pairwise fold with x^(CH*2^l);
 // one partial per workgroup, folded again by the same kernel until one value is left.
-static constexpr uint32_t EV_CH = 32, EV_THREADS = 256;
+// Coefficients and the running value stay in the memory (2^256) domain, only x is in the 2^261 domain: acc~ * x^ * 2^-261 =
+// (acc x)~, so no coefficient is converted.  8 coefficients per thread: a short dependent chain, 64 workgroups per 2^17-term
+// polynomial (the 40 evaluations of a proof fill the chip).
+// Longer polynomials (> 2^22 terms, where two levels of 2^11 no longer reach) take 32 per thread.
+static constexpr uint32_t EV_THREADS = 256;
+template <uint32_t EV_CH>
 __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, uint32_t n, const words8& xw,
                                                 uint32_t log_stride, fp_words* __restrict__ out,
                                                 uint32_t (*sh)[9]) {
@@ -37,10 +42,10 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
   f29 acc = f29_zero();
   if (first < n) {
     uint32_t last = min(n, first + EV_CH);
-    acc = load_hat(c + last - 1);
+    acc = f29_load_r256<P>(c + last - 1);               // any 256-bit word value: bound < 6
     for (uint32_t i = last - 1; i-- > first;) {
-      acc = f29_mul<P>(acc, x);                         // bound 2*2 (mul out <2, x<2)
-      acc = f29_add(acc, load_hat(c + i));              // < 4
+      acc = f29_mul<P>(acc, x);                         // bound 8 * 2
+      acc = f29_add(acc, f29_load_r256<P>(c + i));      // < 2 + 6
     }
     acc = f29_mul<P>(acc, f29_one<P>());                // back below 2p
   }
@@ -65,13 +70,14 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
     f29 r;
 #pragma unroll
     for (int q = 0; q < 9; q++) r.l[q] = sh[0][q];
-    store_hat(out + blockIdx.x, r);
+    f29_store_canonical<P>(out + blockIdx.x, r);
   }
 }
+static constexpr uint32_t EV_CH = 32, EV_LOG = 13;   // the single-polynomial path (any length): log2(EV_CH * EV_THREADS)
 __global__ void __launch_bounds__(256) eval_poly_kernel(const fp_words* __restrict__ c, uint32_t n, words8 xw,
                                                         uint32_t log_stride, fp_words* __restrict__ out) {
   __shared__ uint32_t sh[EV_THREADS][9];
-  eval_poly_block(c, n, xw, log_stride, out, sh);
+  eval_poly_block<EV_CH>(c, n, xw, log_stride, out, sh);
 }
 // m polynomials of one length, each at its own point: grid (blocks, m); level 0 reads the polynomials, level
 // 1 folds the per-block partials (partials[j * stride ..]) into out[j]
@@ -79,13 +85,15 @@ struct EvalBatchArgs {
   const fp_words* polys[EVAL_BATCH_MAX];
   words8 x[EVAL_BATCH_MAX];
 };
+template <uint32_t CH>
 __global__ void __launch_bounds__(256) eval_poly_batch_kernel(EvalBatchArgs a, uint32_t n, uint32_t level,
                                                               uint32_t stride, fp_words* __restrict__ partial,
                                                               fp_words* __restrict__ out) {
   __shared__ uint32_t sh[EV_THREADS][9];
   const uint32_t j = blockIdx.y;
-  if (level == 0) eval_poly_block(a.polys[j], n, a.x[j], 0, partial + (size_t)j * stride, sh);
-  else eval_poly_block(partial + (size_t)j * stride, n, a.x[j], 13, out + j, sh);
+  constexpr uint32_t LOG = CH == 8 ? 11 : 13;   // log2(CH * EV_THREADS)
+  if (level == 0) eval_poly_block<CH>(a.polys[j], n, a.x[j], 0, partial + (size_t)j * stride, sh);
+  else eval_poly_block<CH>(partial + (size_t)j * stride, n, a.x[j], LOG, out + j, sh);
 }
 
 // ---- batch inversion (zeros stay zero, like ff::BatchInvert) --------------------------------
@@ -466,7 +474,7 @@ hipError_t poly_eval(const fp_words* d_coeffs, size_t n, const words8& x, fp_wor
     if (blocks == 1) break;
     cur = dst;
     m = blocks;
-    log_stride += 13;  // log2(EV_CH * EV_THREADS)
+    log_stride += EV_LOG;
     which ^= 1;
   }
   return hipGetLastError();
@@ -560,18 +568,28 @@ hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t
   return hipGetLastError();
 }
 
+size_t poly_eval_batch_blocks(size_t n) {   // partials per polynomial (what d_partial holds m times)
+  const size_t per = (size_t)(n <= ((size_t)1 << 22) ? 8 : 32) * EV_THREADS;
+  return (n + per - 1) / per;
+}
 hipError_t poly_eval_batch(const fp_words* const* d_polys, const words8* xs, uint32_t m, size_t n, fp_words* d_partial,
                            fp_words* d_out, hipStream_t stream) {
   if (m == 0 || m > EVAL_BATCH_MAX) return hipErrorInvalidValue;
-  const uint32_t blocks = (uint32_t)((n + (size_t)EV_CH * EV_THREADS - 1) / ((size_t)EV_CH * EV_THREADS));
-  if (n == 0 || blocks > EV_CH * EV_THREADS) return hipErrorInvalidValue;
+  const bool small = n <= ((size_t)1 << 22);
+  const uint32_t blocks = (uint32_t)poly_eval_batch_blocks(n);
+  if (n == 0 || blocks > (small ? 8u : 32u) * EV_THREADS) return hipErrorInvalidValue;
   EvalBatchArgs a;
   for (uint32_t j = 0; j < m; j++) {
     a.polys[j] = d_polys[j];
     a.x[j] = xs[j];
   }
-  eval_poly_batch_kernel<<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
-  eval_poly_batch_kernel<<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
+  if (small) {
+    eval_poly_batch_kernel<8><<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
+    eval_poly_batch_kernel<8><<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
+  } else {
+    eval_poly_batch_kernel<32><<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
+    eval_poly_batch_kernel<32><<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
+  }
   return hipGetLastError();
 }
 hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp_words* d_tmp, fp_words* d_q,

@@ -1466,7 +1466,7 @@ int sg_fr_eval_poly_batch_dev(const void* const* d_polys, size_t n, const uint8_
   for (uint32_t j = 0; j < m; j++)
     if (!d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_eval_poly_batch: null polynomial");
   LOCKED_CTX();
-  const size_t blocks = (n + 8191) / 8192;
+  const size_t blocks = poly_eval_batch_blocks(n);
   hipError_t e = g_ctx->scratch.reserve((EVAL_BATCH_MAX * (blocks + 1)) * 32);
   if (e != hipSuccess) return hip_fail("eval_poly work space", e);
   fp_words* partial = reinterpret_cast<fp_words*>(g_ctx->scratch.p);

@@ -112,8 +112,10 @@ struct Fr {
   bool operator!=(const Fr& o) const { return !(*this == o); }
   bool is_zero() const { return !(l[0] | l[1] | l[2] | l[3]); }
   Fr pow(const uint64_t e[4]) const {
+    int top = 255;   // square-and-multiply from the highest set bit (most exponents here are rotations and small powers)
+    while (top >= 0 && !((e[top / 64] >> (top % 64)) & 1)) top--;
     Fr r = one();
-    for (int i = 255; i >= 0; i--) {
+    for (int i = top; i >= 0; i--) {
       r = r * r;
       if ((e[i / 64] >> (i % 64)) & 1) r = r * *this;
     }
@@ -747,6 +749,23 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     timings->ms[name] += std::chrono::duration<double, std::milli>(now - clock).count();
     clock = now;
   };
+  // SG_PROVER_TRACE=1: the host's own timeline (no synchronisation added): when each step of the driver was reached
+  const bool trace = std::getenv("SG_PROVER_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double>> marks;
+  auto mark = [&](const char* what) {
+    if (trace) marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  };
+  struct TraceDump {
+    const std::vector<std::pair<const char*, double>>& m;
+    ~TraceDump() {
+      double prev = 0;
+      for (auto& kv : m) {
+        std::fprintf(stderr, "  %9.1f us (+%7.1f)  %s\n", kv.second, kv.second - prev, kv.first);
+        prev = kv.second;
+      }
+    }
+  } trace_dump{marks};
   const Fr zero = Fr::zero();
   uint8_t omega_inv_b[32], n_inv_b[32], omega_b[32];
   ck(sg_domain_constant(k, 0, omega_b), "domain constant");
@@ -856,12 +875,14 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   rand_rows(pin, u, n - u);
   rand_rows(ptab, u, n - u);
   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
+  mark("1: lookup columns ready, commit [a0 a1 a2 a' s'] issued");
   const std::vector<uint8_t> pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1, 1, 1, 2, 2});
   if (opt.sanity_checks) {
     uint32_t bad = 0;
     d2h(&bad, noncanonical.p, 4);
     if (bad) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
   }
+  mark("1: commitments back");
   for (int i = 0; i < 3; i++) tr.write_point(pts.data() + 64 * i);
   const Fr theta = tr.squeeze();
 
@@ -895,6 +916,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_permutation_product_dev(vals[1].data(), sig[1].data(), (uint32_t)vals[1].size(), beta.bytes(), gamma.bytes(),
                                   delta_chunk.bytes(), k, nullptr, zs[1].p, side[0]), "permutation product");
     ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, side[1]), "lookup product");
+    mark("3: grand products enqueued");
     Fr z0_last, last;
     hk(hipMemcpyAsync(z0_last.l, zs[0].at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
     hk(hipStreamSynchronize(main_stream()), "sync");   // z0 only; the other two keep running
@@ -906,6 +928,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     d2h(last.l, lz.at(u), 32);
     if (opt.sanity_checks && last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
   }
+  mark("3: grand products closed (sanity reads)");
   rand_rows(zs[0], u + 1, n - u - 1);
   rand_rows(zs[1], u + 1, n - u - 1);
   rand_rows(lz, u + 1, n - u - 1);
@@ -915,7 +938,9 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   fork();
   to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
   // the grand products stay constant wherever the ratio is 1 -- all the unused rows: difference form
+  mark("3: commit [z0 z1 lz random] issued");
   commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
+  mark("3: commitments back");
   const Fr y = tr.squeeze();
   join();
 
@@ -932,8 +957,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     y_powers.push_back(v);
   }
   if (y_powers.empty()) y_powers.push_back(Fr::zero());
+  mark("4: challenges of the gate program ready");
   std::vector<DevCol> pieces_col;
   for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces_col.emplace_back(n);
+  mark("4: buffers ready");
   {
     std::vector<void*> fixed_e, adv_e = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_e = {ex1[3].p};
     for (auto& c : pk.fixed_ext) fixed_e.push_back(c.p);
@@ -954,10 +981,13 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
                                      pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()),
        "lookup quotient");
   }
+  mark("4: numerator enqueued");
   std::vector<void*> pieces;
   for (auto& c : pieces_col) pieces.push_back(c.p);
   ck(sg_cosets_to_pieces_dev(values.p, pieces.data(), k, ext_k, QUOTIENT_PIECES, main_stream()), "cosets_to_pieces");
+  mark("4: pieces enqueued, commit issued");
   commit_batch(pieces, std::vector<int>(QUOTIENT_PIECES, 0));
+  mark("4: commitments back");
   const Fr x = tr.squeeze();
   const uint64_t n_limbs[4] = {n, 0, 0, 0};
   const Fr x_n = x.pow(n_limbs);
@@ -986,9 +1016,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ev_polys.push_back(pieces[i]);
     ev_points.push_back(x);
   }
+  mark("5: evaluation list built");
   std::vector<Fr> ev(ev_polys.size());
   ck(sg_fr_eval_poly_batch_dev(ev_polys.data(), n, ev_points[0].bytes(), (uint32_t)ev_polys.size(), main_stream(),
                                reinterpret_cast<uint8_t*>(ev.data())), "evaluations");
+  mark("5: evaluations back");
   std::map<std::pair<Key, int>, Fr> evals;
   for (size_t i = 0; i < order.size(); i++) {
     evals[{order[i].key, order[i].rot}] = ev[i];
@@ -1116,7 +1148,9 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_fr_lincomb_dev(div_out.data(), weights[0].bytes(), (uint32_t)div_out.size(), n, f_all.p, main_stream()), "f lincomb");
     hk(hipStreamSynchronize(main_stream()), "sync");   // the quotient columns go back to the pool with this scope
   }
+  mark("6: f(X) enqueued, commit issued");
   commit_batch({f_all.p}, {0});
+  mark("6: W back");
   const Fr mu = tr.squeeze();
   std::vector<int> all_rots = {ROT_LAST, -1, 0, 1};
   std::map<int, Fr> mu_minus;
@@ -1156,7 +1190,9 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   Fr rem;
   ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), main_stream()), "final division");
   if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");
+  mark("6: final quotient enqueued, commit issued");
   commit_batch({w2.p}, {0});
+  mark("6: W' back");
   lap("6_multiopen");
   return tr.proof;
 }
