@@ -30,7 +30,7 @@ struct PermCols {  // one chunk of the permutation argument (kernel argument)
 // delta^c omega^i beta + gamma + v_c[i])
 hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8& beta, const words8& gamma,
                               const words8& delta_start, const words8& delta, const words8& omega, size_t n,
-                              int numer, fp_words* d_io, hipStream_t stream, const fp_words* d_pow_lo = nullptr);
+                              int numer, fp_words* d_io, hipStream_t stream, const fp_words* d_pow_tab = nullptr);
 // numer = 0: io[i] = (x[i] + beta)(y[i] + gamma);  numer = 1: io[i] *= (x[i] + beta)(y[i] + gamma)
 hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,
                                 size_t n, int numer, fp_words* d_io, hipStream_t stream);

@@ -503,31 +503,18 @@ hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, f
 // ---- grand-product fractions (halo2 permutation::prover::commit / lookup::prover::commit_product)
 // permutation chunk: den[i] = prod_c (beta * sigma_c[i] + gamma + v_c[i])
 //                    num[i] = prod_c (delta^(j0+c) * omega^i * beta + gamma + v_c[i])
-// pow_lo (optional): omega^t for t < 256 as 2^261-domain words; with it omega^i = omega^(block start) * pow_lo[lane] costs one
-// exponentiation per workgroup instead of one per row
+// pow_tab (optional): omega^i for i < n as 2^261-domain words (NttEngine::local_twiddles(omega, k + 1), cached per domain):
+// one product instead of an exponentiation per row
 __global__ void __launch_bounds__(256) perm_fraction_kernel(PermCols cols, uint32_t ncols, words8 beta_w, words8 gamma_w, words8 dstart_w,
                                                             words8 delta_w, words8 omega_w, uint32_t n, uint32_t numer,
-                                                            const fp_words* __restrict__ pow_lo, fp_words* __restrict__ io) {
-  __shared__ uint32_t s_base[9];
-  if (numer && pow_lo) {
-    if (threadIdx.x == 0) {
-      const f29 v = f29_mul<P>(f29_words_to_r261<P>(dstart_w.l), f29_pow_u64<P>(f29_words_to_r261<P>(omega_w.l), (uint64_t)blockIdx.x * blockDim.x));
-#pragma unroll
-      for (int q = 0; q < 9; q++) s_base[q] = v.l[q];
-    }
-    __syncthreads();
-  }
+                                                            const fp_words* __restrict__ pow_tab, fp_words* __restrict__ io) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
   f29 acc = numer ? load_hat(io + i) : f29_one<P>();          // numerators multiply the inverted denominators
   f29 dw = f29_one<P>();
-  if (numer && pow_lo) {
-    f29 base;
-#pragma unroll
-    for (int q = 0; q < 9; q++) base.l[q] = s_base[q];
-    dw = f29_mul<P>(base, f29_load_r256<P>(pow_lo + threadIdx.x));   // hat * hat * 2^-261 = hat
-  } else if (numer) dw = f29_mul<P>(f29_words_to_r261<P>(dstart_w.l), f29_pow_u64<P>(f29_words_to_r261<P>(omega_w.l), i));
+  if (numer && pow_tab) dw = f29_mul<P>(f29_words_to_r261<P>(dstart_w.l), f29_load_r256<P>(pow_tab + i));   // hat * hat * 2^-261 = hat
+  else if (numer) dw = f29_mul<P>(f29_words_to_r261<P>(dstart_w.l), f29_pow_u64<P>(f29_words_to_r261<P>(omega_w.l), i));
   const f29 delta = f29_words_to_r261<P>(delta_w.l);
   for (uint32_t c = 0; c < ncols; c++) {
     f29 v = load_hat(cols.values[c] + i);                      // < 2
@@ -550,9 +537,9 @@ __global__ void lookup_fraction_kernel(const fp_words* __restrict__ x, const fp_
 }
 hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8& beta, const words8& gamma,
                               const words8& delta_start, const words8& delta, const words8& omega, size_t n,
-                              int numer, fp_words* d_io, hipStream_t stream, const fp_words* d_pow_lo) {
+                              int numer, fp_words* d_io, hipStream_t stream, const fp_words* d_pow_tab) {
   perm_fraction_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(cols, ncols, beta, gamma, delta_start, delta,
-                                                                        omega, (uint32_t)n, (uint32_t)numer, d_pow_lo, d_io);
+                                                                        omega, (uint32_t)n, (uint32_t)numer, d_pow_tab, d_io);
   return hipGetLastError();
 }
 hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,

@@ -1551,8 +1551,8 @@ int sg_permutation_product_dev(const void* const* d_values, const void* const* d
   std::memcpy(&dl, DELTA_M, 32);
   e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 0, mod, s);
   if (e == hipSuccess) e = poly_batch_invert(mod, n, s);
-  fp_words* pw = nullptr;   // omega^t, t < 256: one exponentiation per workgroup instead of one per row
-  if (e == hipSuccess) e = g_ctx->ntt.local_twiddles(dc->omega, 9, s, &pw);
+  fp_words* pw = nullptr;   // omega^i, i < n (cached per domain): one product instead of one exponentiation per row
+  if (e == hipSuccess && n == ((size_t)1 << k)) e = g_ctx->ntt.local_twiddles(dc->omega, k + 1, s, &pw);
   if (e == hipSuccess) e = poly_perm_fraction(cols, ncols, b, g, ds, dl, dc->omega, n, 1, mod, s, pw);
   if (e != hipSuccess) return hip_fail("permutation product", e);
   return grand_product_tail(mod, n, z0, d_z, s);
