@@ -100,9 +100,9 @@ def batch_extra(args, rank, world):
     out = {"k": k, "levels": levels, "n_currencies": nc, "proofs_per_gpu": args.batch_proofs, "n_gpus": world,
            "setup_artifacts_s": setup_s, "by_in_flight": {}}
     users = [(7919 * i + 13) % (1 << levels) for i in range(args.batch_proofs * world)]
-    B.prove_batch(tree, users[:6 * world], params, pk, levels, in_flight=3)                 # warm-up: every lane's plans, pools, streams
+    B.prove_batch(tree, users[:12 * world], params, pk, levels, in_flight=4)                # warm-up: every lane's plans, pools, streams
     best = None
-    for in_flight in (1, 2, 3):
+    for in_flight in (1, 2, 3, 4):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
