@@ -100,7 +100,8 @@ def batch_extra(args, rank, world):
     out = {"k": k, "levels": levels, "n_currencies": nc, "proofs_per_gpu": args.batch_proofs, "n_gpus": world,
            "setup_artifacts_s": setup_s, "by_in_flight": {}}
     users = [(7919 * i + 13) % (1 << levels) for i in range(args.batch_proofs * world)]
-    B.prove_batch(tree, users[:12 * world], params, pk, levels, in_flight=4)                # warm-up: every lane's plans, pools, streams
+    for warm in (1, 2, 3, 4):   # warm-up: every lane's plans, every worker thread's session (streams, buffer pool)
+        B.prove_batch(tree, users[:3 * warm * world], params, pk, levels, in_flight=warm)
     best = None
     for in_flight in (1, 2, 3, 4):
         if world > 1:
@@ -210,7 +211,8 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.run(cmd, env=env).returncode)
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # lanes and proofs in flight use many streams; HIP's default is 4 hardware queues
+    # HIP's default of 4 hardware queues is kept: more of them did not help the MSM lanes and made the proof batch slower and
+    # erratic (profiles/r02_sweeps/hw_queues.txt)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

@@ -132,6 +132,18 @@ def setup_on_all_ranks(k: int, params_path, levels: int, n_currencies: int = 2, 
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+_WORKERS = {}            # in_flight -> ThreadPoolExecutor, kept: a worker thread's session in the library (streams, buffer pool,
+_WORKERS_LOCK = threading.Lock()   # events; include/summa_prover.hpp) lives as long as the thread does, so the threads are reused
+
+
+def _workers(in_flight: int) -> ThreadPoolExecutor:
+    with _WORKERS_LOCK:
+        pool = _WORKERS.get(in_flight)
+        if pool is None:
+            pool = _WORKERS[in_flight] = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix=f"prove{in_flight}")
+        return pool
+
+
 class BatchResult:
     def __init__(self):
         self.proofs = {}          # user index -> (proof bytes, public inputs)
@@ -194,8 +206,7 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         for i in mine:
             work(i)
     else:
-        with ThreadPoolExecutor(max_workers=in_flight) as pool:
-            list(pool.map(work, mine))
+        list(_workers(in_flight).map(work, mine))
     res.seconds = time.perf_counter() - t0
     return res
 

@@ -17,7 +17,7 @@ prover.export_bundle("gpurun_out/r02g/bundle17.bin", params, pk, adv, c.instance
 print("bundle written")
 PY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=8
+# (HIP default number of hardware queues)
 rm -rf gpurun_out/prof_r02g
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r02g -- ./tools/create_proof_cpp gpurun_out/r02g/bundle17.bin gpurun_out/r02g/proof.bin 8 > gpurun_out/r02g/cpp.json 2> gpurun_out/r02g/rocprof.err
 cat gpurun_out/r02g/cpp.json
