@@ -1380,6 +1380,35 @@ def test_quotient_pipeline_satisfying_witness(gpu, O, k, ncols, chunk_len):
     assert not W.top_coefficients_zero(h(values), first_zero)
 
 
+@pytest.mark.parametrize("k", [10, 19])
+def test_cosets_round_trip_from_known_pieces(gpu, O, k):
+    """pieces h_0..h_4 (random) -> the numerator h (X^n - 1) on the five cosets, built block by block from the coset transforms of
+    the pieces (on c_b H: X^n = g_b, so numerator_b = (g_b - 1) sum_t g_b^t h_t) -> sg_cosets_to_pieces gives the pieces back.
+    k = 10 runs the batched transforms that the oracle-based tests cover; k = 19 the one-by-one path of long transforms, and
+    the de-interleaving identity against coeff_to_extended there too."""
+    import torch
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.domain import EvaluationDomain
+    from oracle import pyref as PR
+    dom = EvaluationDomain(6, k)
+    n, d, ext_k = 1 << k, dom.quotient_poly_degree, dom.extended_k
+    pieces = [dev(O.random_fr(3100 + t, n)) for t in range(d)]
+    cos = dom.coeff_to_cosets_batch(pieces)
+    w_ext = PR.omega_for(ext_k)
+    gam = [pow(PR.ZETA * pow(w_ext, b, PR.R) % PR.R, n, PR.R) for b in range(d)]
+    assert len(set(gam)) == d and 1 not in gam
+    blocks = []
+    for b in range(d):
+        coeffs = fr_np([(gam[b] - 1) * pow(gam[b], t, PR.R) % PR.R for t in range(d)])
+        blocks.append(A.lincomb([c[32 * n * b:32 * n * (b + 1)] for c in cos], coeffs))
+    back = dom.cosets_to_pieces(torch.cat(blocks))
+    for t in range(d):
+        assert (back[t] == pieces[t]).all(), t
+    ext = dom.coeff_to_extended(pieces[0].clone())
+    stride = 1 << (ext_k - k)
+    assert (cos[0] == ext.view(n, stride, 32)[:, :d, :].permute(1, 0, 2).reshape(-1)).all()
+
+
 @pytest.mark.parametrize("k,ncols,chunk_len", [(6, 6, 4), (8, 6, 2), (12, 6, 4)])
 def test_quotient_on_cosets_equals_the_extended_pipeline(gpu, O, k, ncols, chunk_len):
     """the prover's short cut (sg_coeff_to_cosets / sg_cosets_to_pieces): deg h < d n, so the quotient is computed on the first d =
