@@ -26,9 +26,9 @@ __device__ __forceinline__ void store_hat(fp_words* p, const f29& x_hat) {  // x
 // thread: Horner over CH consecutive coefficients; workgroup: pairwise fold with x^(CH*2^l);
 // one partial per workgroup, folded again by the same kernel until one value is left.
 // Coefficients and the running value stay in the memory (2^256) domain, only x is in the 2^261 domain: acc~ * x^ * 2^-261 =
-// (acc x)~, so no coefficient is converted.  8 coefficients per thread: a short dependent chain, 64 workgroups per 2^17-term
-// polynomial (the 40 evaluations of a proof fill the chip).
-// Longer polynomials (> 2^22 terms, where two levels of 2^11 no longer reach) take 32 per thread.
+// (acc x)~, so no coefficient is converted.  16 coefficients per thread in the batched path (32 workgroups per 2^17-term
+// polynomial: the 40 evaluations of a proof fill the chip); longer polynomials (> 2^24 terms, where two levels of 2^12 no longer
+// reach) and the single-polynomial path take 32 per thread.
 static constexpr uint32_t EV_THREADS = 256;
 template <uint32_t EV_CH>
 __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, uint32_t n, const words8& xw,
@@ -52,25 +52,35 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
 #pragma unroll
   for (int q = 0; q < 9; q++) sh[tid][q] = acc.l[q];
   __syncthreads();
-  f29 xp = x;                                            // x^(CH * 2^l) per level
-  for (uint32_t k = 1; k < EV_CH; k <<= 1) xp = f29_sqr<P>(xp);
-  for (uint32_t s = 1; s < EV_THREADS; s <<= 1) {
-    if ((tid & (2 * s - 1)) == 0) {
-      f29 lo, hi;
+  // pairwise fold with x^(CH * 2^l) at level l.  The eight powers are computed once per workgroup (lane l squares its way up:
+  // every lane doing all eight squarings was more work than the fold itself) and the sums stay lazy: the bound grows by 2 per
+  // level (<= 18 after eight), well inside what the next product takes, so only the last value is reduced.
+  __shared__ uint32_t s_xp[8][9];
+  if (tid < 8) {
+    f29 xp = x;
+    for (uint32_t k = 1; k < EV_CH; k <<= 1) xp = f29_sqr<P>(xp);
+    for (uint32_t l = 0; l < tid; l++) xp = f29_sqr<P>(xp);
 #pragma unroll
-      for (int q = 0; q < 9; q++) { lo.l[q] = sh[tid][q]; hi.l[q] = sh[tid + s][q]; }
-      lo = f29_mul<P>(f29_add(lo, f29_mul<P>(hi, xp)), f29_one<P>());   // (<2 + <2) -> <2
+    for (int q = 0; q < 9; q++) s_xp[tid][q] = xp.l[q];
+  }
+  __syncthreads();
+  uint32_t level = 0;
+  for (uint32_t s = 1; s < EV_THREADS; s <<= 1, level++) {
+    if ((tid & (2 * s - 1)) == 0) {
+      f29 lo, hi, xp;
+#pragma unroll
+      for (int q = 0; q < 9; q++) { lo.l[q] = sh[tid][q]; hi.l[q] = sh[tid + s][q]; xp.l[q] = s_xp[level][q]; }
+      lo = f29_add(lo, f29_mul<P>(hi, xp));            // bound + 2 per level; hi's bound (<= 16) * 2 stays below 170
 #pragma unroll
       for (int q = 0; q < 9; q++) sh[tid][q] = lo.l[q];
     }
-    xp = f29_sqr<P>(xp);
     __syncthreads();
   }
   if (tid == 0) {
     f29 r;
 #pragma unroll
     for (int q = 0; q < 9; q++) r.l[q] = sh[0][q];
-    f29_store_canonical<P>(out + blockIdx.x, r);
+    f29_store_canonical<P>(out + blockIdx.x, f29_mul<P>(r, f29_one<P>()));   // the lazy sums back below 2p
   }
 }
 static constexpr uint32_t EV_CH = 32, EV_LOG = 13;   // the single-polynomial path (any length): log2(EV_CH * EV_THREADS)
@@ -91,7 +101,7 @@ __global__ void __launch_bounds__(256) eval_poly_batch_kernel(EvalBatchArgs a, u
                                                               fp_words* __restrict__ out) {
   __shared__ uint32_t sh[EV_THREADS][9];
   const uint32_t j = blockIdx.y;
-  constexpr uint32_t LOG = CH == 8 ? 11 : 13;   // log2(CH * EV_THREADS)
+  constexpr uint32_t LOG = CH == 16 ? 12 : 13;   // log2(CH * EV_THREADS)
   if (level == 0) eval_poly_block<CH>(a.polys[j], n, a.x[j], 0, partial + (size_t)j * stride, sh);
   else eval_poly_block<CH>(partial + (size_t)j * stride, n, a.x[j], LOG, out + j, sh);
 }
@@ -556,23 +566,23 @@ hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t
 }
 
 size_t poly_eval_batch_blocks(size_t n) {   // partials per polynomial (what d_partial holds m times)
-  const size_t per = (size_t)(n <= ((size_t)1 << 22) ? 8 : 32) * EV_THREADS;
+  const size_t per = (size_t)(n <= ((size_t)1 << 24) ? 16 : 32) * EV_THREADS;
   return (n + per - 1) / per;
 }
 hipError_t poly_eval_batch(const fp_words* const* d_polys, const words8* xs, uint32_t m, size_t n, fp_words* d_partial,
                            fp_words* d_out, hipStream_t stream) {
   if (m == 0 || m > EVAL_BATCH_MAX) return hipErrorInvalidValue;
-  const bool small = n <= ((size_t)1 << 22);
+  const bool small = n <= ((size_t)1 << 24);
   const uint32_t blocks = (uint32_t)poly_eval_batch_blocks(n);
-  if (n == 0 || blocks > (small ? 8u : 32u) * EV_THREADS) return hipErrorInvalidValue;
+  if (n == 0 || blocks > (small ? 16u : 32u) * EV_THREADS) return hipErrorInvalidValue;
   EvalBatchArgs a;
   for (uint32_t j = 0; j < m; j++) {
     a.polys[j] = d_polys[j];
     a.x[j] = xs[j];
   }
   if (small) {
-    eval_poly_batch_kernel<8><<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
-    eval_poly_batch_kernel<8><<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
+    eval_poly_batch_kernel<16><<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
+    eval_poly_batch_kernel<16><<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);
   } else {
     eval_poly_batch_kernel<32><<<dim3(blocks, m), EV_THREADS, 0, stream>>>(a, (uint32_t)n, 0, blocks, d_partial, d_out);
     eval_poly_batch_kernel<32><<<dim3(1, m), EV_THREADS, 0, stream>>>(a, blocks, 1, blocks, d_partial, d_out);

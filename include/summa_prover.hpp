@@ -842,7 +842,9 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   if (!instances.empty()) instance_col.upload(instances.data(), 0, instances.size());
   std::vector<DevCol> co1, ex1;
   fork();
-  to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);   // under the commitments
+  // under the commitments; issued FIRST: started later (after the lookup's kernels) these transforms ran into the commitment
+  // job's latency-bound kernels and cost it more (0.70 -> 0.82 ms) than the earlier start of the lookup kernels gained (50 us)
+  to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);
   // -- 2 (computed ahead of its place in the transcript): the lookup's permuted columns.  This circuit's lookup has ONE input
   // and ONE table expression, so the theta-compression is the expression itself and nothing here waits for theta: the two
   // permuted columns are committed in the SAME fused job as the advice columns (one MSM group's latency instead of two) and

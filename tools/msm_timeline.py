@@ -17,7 +17,8 @@ import sys
 def rocpd_rows(directory, view):
     """rows of a view of rocprofv3's SQLite output (ROCm 7: `<dir>/<host>/<pid>_results.db`), as dicts"""
     out = []
-    for path in glob.glob(os.path.join(directory, "*", "*_results.db")):
+    # gpurun merges every run's database into the same directory: only the newest one is the run being summarised
+    for path in sorted(glob.glob(os.path.join(directory, "*", "*_results.db")), key=os.path.getmtime)[-1:]:
         db = sqlite3.connect(path)
         cur = db.cursor()
         cur.execute(f"select * from {view}")
