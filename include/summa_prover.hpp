@@ -793,7 +793,15 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   hipEvent_t(&ev_join)[2] = session().ev_join;
   const hipStream_t ms = main_stream();
   if (!side[0]) {
-    for (auto& st : side) hk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+    {
+      // the side streams carry work that is needed a phase later (transforms under a commitment job): lowest priority, so
+      // that the commitment job's latency-bound kernels on the other streams are dispatched first (SG_SIDE_PRIORITY=0: normal)
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const char* v = std::getenv("SG_SIDE_PRIORITY");
+      const int prio = (v && v[0] == '0') ? 0 : least;
+      for (auto& st : side) hk(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio), "stream");
+    }
     hk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "event");
     for (auto& e : ev_join) hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
   }
