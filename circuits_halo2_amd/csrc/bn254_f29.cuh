@@ -171,6 +171,172 @@ SG_HD f29 f29_sub(const f29& a, const f29& b) {
 }
 SG_HD f29 f29_dbl(const f29& a) { return f29_add(a, a); }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SG_F29_ROW_SCAN)
+// ---- device: column scanning, one chain of v_mad_u64_u32 per column ------------------------------------------------
+// Column k of a Montgomery product is (carry of column k-1) + sum a_i b_(k-i) + sum m_i p_(k-i).  v_mad_u64_u32 has a
+// 64-bit addend, so the carry can enter as the addend of the column's first multiply-add and the whole column is ONE
+// chain: 163 multiply-adds + 9 mul_lo + 17 and + 16 shifts = 205 VALU instructions.  Written as C++ (either row- or
+// column-wise) the compiler re-associates every column into "sum of products" + carry and spends a v_lshl_add_u64 per
+// column on joining them (229 instructions, and 18 live 64-bit accumulators in the row-wise form), so the chains are
+// spelled in inline asm, one block per run of products; the integer result is the same, limb for limb
+// (tools/microbench4.hip measures both and compares their outputs).  A block is opaque to the scheduler: the latency of a
+// dependent chain is covered by the other waves of the SIMD (>= 2), which every kernel here has.
+#define SG_CH_T(i) "v_mad_u64_u32 %[t], vcc, %[x" #i "], %[y" #i "], %[t]\n"
+#define SG_CH_V(i) [x##i] "v"(x[i]), [y##i] "v"(y[i])
+#define SG_CH_S(i) [x##i] "v"(x[i]), [y##i] "s"(y[i])
+// t += sum_{i < N} x[i] * y[i]; y in VGPRs
+template <int N>
+__device__ __forceinline__ void f29_chain_vv(uint64_t& t, const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+  static_assert(N >= 1 && N <= 9, "");
+  if constexpr (N == 1) asm(SG_CH_T(0) : [t] "+v"(t) : SG_CH_V(0) : "vcc");
+  if constexpr (N == 2) asm(SG_CH_T(0) SG_CH_T(1) : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1) : "vcc");
+  if constexpr (N == 3) asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2) : "vcc");
+  if constexpr (N == 4)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3) : "vcc");
+  if constexpr (N == 5)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4)
+        : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3), SG_CH_V(4) : "vcc");
+  if constexpr (N == 6)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5)
+        : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3), SG_CH_V(4), SG_CH_V(5) : "vcc");
+  if constexpr (N == 7)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5) SG_CH_T(6)
+        : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3), SG_CH_V(4), SG_CH_V(5), SG_CH_V(6) : "vcc");
+  if constexpr (N == 8)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5) SG_CH_T(6) SG_CH_T(7)
+        : [t] "+v"(t) : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3), SG_CH_V(4), SG_CH_V(5), SG_CH_V(6), SG_CH_V(7) : "vcc");
+  if constexpr (N == 9)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5) SG_CH_T(6) SG_CH_T(7) SG_CH_T(8)
+        : [t] "+v"(t)
+        : SG_CH_V(0), SG_CH_V(1), SG_CH_V(2), SG_CH_V(3), SG_CH_V(4), SG_CH_V(5), SG_CH_V(6), SG_CH_V(7), SG_CH_V(8) : "vcc");
+}
+// the same with y in SGPRs (limbs of the modulus: compile-time constants)
+template <int N>
+__device__ __forceinline__ void f29_chain_vs(uint64_t& t, const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+  static_assert(N >= 1 && N <= 8, "");
+  if constexpr (N == 1) asm(SG_CH_T(0) : [t] "+v"(t) : SG_CH_S(0) : "vcc");
+  if constexpr (N == 2) asm(SG_CH_T(0) SG_CH_T(1) : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1) : "vcc");
+  if constexpr (N == 3) asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2) : "vcc");
+  if constexpr (N == 4)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2), SG_CH_S(3) : "vcc");
+  if constexpr (N == 5)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4)
+        : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2), SG_CH_S(3), SG_CH_S(4) : "vcc");
+  if constexpr (N == 6)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5)
+        : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2), SG_CH_S(3), SG_CH_S(4), SG_CH_S(5) : "vcc");
+  if constexpr (N == 7)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5) SG_CH_T(6)
+        : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2), SG_CH_S(3), SG_CH_S(4), SG_CH_S(5), SG_CH_S(6) : "vcc");
+  if constexpr (N == 8)
+    asm(SG_CH_T(0) SG_CH_T(1) SG_CH_T(2) SG_CH_T(3) SG_CH_T(4) SG_CH_T(5) SG_CH_T(6) SG_CH_T(7)
+        : [t] "+v"(t) : SG_CH_S(0), SG_CH_S(1), SG_CH_S(2), SG_CH_S(3), SG_CH_S(4), SG_CH_S(5), SG_CH_S(6), SG_CH_S(7) : "vcc");
+}
+#undef SG_CH_T
+#undef SG_CH_V
+#undef SG_CH_S
+// t += sum over i + j = K of a_i b_j
+template <int K>
+__device__ __forceinline__ void f29_column_ab(uint64_t& t, const uint32_t (&a)[9], const uint32_t (&b)[9]) {
+  constexpr int LO = K < 9 ? 0 : K - 8, N = (K < 9 ? K : 8) - LO + 1;
+  uint32_t x[N], y[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { x[i] = a[LO + i]; y[i] = b[K - LO - i]; }
+  f29_chain_vv<N>(t, x, y);
+}
+// t += sum over i + j = K, i < min(K, 9), of m_i p_j  (for K < 9 the term m_K p_0 follows once m_K is known)
+template <class P, int K>
+__device__ __forceinline__ void f29_column_mp(uint64_t& t, const uint32_t (&m)[9]) {
+  constexpr int LO = K < 9 ? 0 : K - 8, HI = K < 9 ? K - 1 : 8, N = HI - LO + 1;
+  if constexpr (N >= 1) {
+    uint32_t x[N], y[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { x[i] = m[LO + i]; y[i] = P::p[K - LO - i]; }
+    f29_chain_vs<N>(t, x, y);
+  }
+}
+// closes column K < 9: the Montgomery digit m_K, its product with p_0, the carry into column K + 1
+template <class P, int K>
+__device__ __forceinline__ void f29_column_close_lo(uint64_t& t, uint32_t (&m)[9]) {
+  m[K] = ((uint32_t)t * P::inv) & M29;
+  t += (uint64_t)m[K] * P::p[0];
+  t >>= 29;
+}
+template <class P, int K, class AB>
+__device__ __forceinline__ void f29_columns(uint64_t& t, uint32_t (&m)[9], f29& r, const AB& ab) {
+  ab.template column<K>(t);
+  f29_column_mp<P, K>(t, m);
+  if constexpr (K < 9) {
+    f29_column_close_lo<P, K>(t, m);
+  } else {
+    r.l[K - 9] = (uint32_t)t & M29;
+    t >>= 29;
+  }
+  if constexpr (K < 16) f29_columns<P, K + 1, AB>(t, m, r, ab);
+}
+struct f29_ab_mul {
+  const f29 &a, &b;
+  template <int K> __device__ __forceinline__ void column(uint64_t& t) const { f29_column_ab<K>(t, a.l, b.l); }
+};
+struct f29_ab_mul2 {
+  const f29 &a, &b, &c, &d;
+  template <int K> __device__ __forceinline__ void column(uint64_t& t) const {
+    f29_column_ab<K>(t, a.l, b.l);
+    f29_column_ab<K>(t, c.l, d.l);
+  }
+};
+struct f29_ab_sqr {
+  const f29& a;
+  const uint32_t (&a2)[9];   // the doubled limbs
+  // pairs i < j, i + j = K against the doubled operand, the square a_(K/2)^2 on even columns
+  template <int K> __device__ __forceinline__ void column(uint64_t& t) const {
+    constexpr int LO = K < 9 ? 0 : K - 8, PAIRS = (K + 1) / 2 - LO, N = PAIRS + (K % 2 == 0 ? 1 : 0);
+    uint32_t x[N], y[N];
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) { x[i] = a2[LO + i]; y[i] = a.l[K - LO - i]; }
+    if constexpr (K % 2 == 0) { x[N - 1] = a.l[K / 2]; y[N - 1] = a.l[K / 2]; }
+    f29_chain_vv<N>(t, x, y);
+  }
+};
+
+// Montgomery product a*b*2^-261 mod p.  Requires normalised limbs and Ba*Bb <= 170;
+// returns exactly normalised limbs, value < (Ba*Bb/170.7 + 1) p < 2p.
+template <class P>
+SG_HD f29 f29_mul(const f29& a, const f29& b) {
+  uint32_t m[9];
+  uint64_t t = 0;
+  f29 r;
+  f29_columns<P, 0>(t, m, r, f29_ab_mul{a, b});
+  r.l[8] = (uint32_t)t;
+  return r;
+}
+// a^2 * 2^-261: the off-diagonal products are taken once against the doubled operand
+// (45 multiply-adds instead of 81 in front of the reduction).  Same contract as f29_mul.
+template <class P>
+SG_HD f29 f29_sqr(const f29& a) {
+  uint32_t a2[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) a2[k] = a.l[k] << 1;
+  uint32_t m[9];
+  uint64_t t = 0;
+  f29 r;
+  f29_columns<P, 0>(t, m, r, f29_ab_sqr{a, a2});
+  r.l[8] = (uint32_t)t;
+  return r;
+}
+// (a*b + c*d) * 2^-261 with ONE reduction.  Requires Ba*Bb + Bc*Bd <= 170; 27 products of
+// < 2^58 per column still fit the 64-bit accumulator.
+template <class P>
+SG_HD f29 f29_mul2(const f29& a, const f29& b, const f29& c, const f29& d) {
+  uint32_t m[9];
+  uint64_t t = 0;
+  f29 r;
+  f29_columns<P, 0>(t, m, r, f29_ab_mul2{a, b, c, d});
+  r.l[8] = (uint32_t)t;
+  return r;
+}
+#else
+// ---- host (and -DSG_F29_ROW_SCAN): row scanning in plain C++, the definition the device code is checked against ----
 // Montgomery product a*b*2^-261 mod p.  Requires normalised limbs and Ba*Bb <= 170;
 // returns exactly normalised limbs, value < (Ba*Bb/170.7 + 1) p < 2p.
 template <class P>
@@ -253,6 +419,8 @@ SG_HD f29 f29_mul2(const f29& a, const f29& b, const f29& c, const f29& d) {
   r.l[8] = (uint32_t)acc[17];
   return r;
 }
+
+#endif
 
 // ONE Montgomery limb step: a * 2^-29 mod p.  a normalised with bound <= 170; returns exactly normalised limbs,
 // value < (170 / 2^29 + 1) p < 2p.  9 multiply-adds instead of the 162 of a product: the closing reduction of an NTT

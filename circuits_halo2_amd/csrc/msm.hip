@@ -644,7 +644,9 @@ __global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __re
     const uint32_t wbase = blockIdx.y * nbw;
     auto fetch = [&](uint32_t k) {
       const uint32_t b = first + k;
-      return (b < nbw && ntask[wbase + b]) ? xyzz29_load(partial + toff[wbase + b]) : xyzz29_identity();
+      xyzz29 v = xyzz29_identity();   // (not "c ? load : identity": two temporaries behind a pointer phi stay in scratch)
+      if (b < nbw && ntask[wbase + b]) v = xyzz29_load(partial + toff[wbase + b]);
+      return v;
     };
     xyzz29 nxt = fetch(G - 1);
     for (uint32_t k = G; k-- > 0;) {
@@ -743,7 +745,9 @@ __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __re
   const uint32_t n = is_row ? cols : rows;
   auto get = [&](uint32_t e) {
     const uint32_t b = base + (is_row ? (L << sh.log_cols) + e : (e << sh.log_cols) + (L - rows));
-    return ntask[b] ? xyzz29_load(partial + toff[b]) : xyzz29_identity();
+    xyzz29 v = xyzz29_identity();
+    if (ntask[b]) v = xyzz29_load(partial + toff[b]);
+    return v;
   };
   xyzz29 sum = wg_sum<Q>(n, get, lds);
   if (threadIdx.x == 0) xyzz29_store(lines + (size_t)set * (rows + cols) + L, sum);
@@ -759,10 +763,18 @@ __global__ void __launch_bounds__(256) msm_reduce2d_bits(const xyzz29_mem* __res
   const xyzz29_mem* ln = lines + (size_t)set * (rows + cols);
   xyzz29 sum;
   if (j < sh.log_cols) {
-    sum = wg_sum<Q>(cols, [&](uint32_t e) { return ((e >> j) & 1) ? xyzz29_load(ln + rows + e) : xyzz29_identity(); }, lds);
+    sum = wg_sum<Q>(cols, [&](uint32_t e) {
+      xyzz29 v = xyzz29_identity();
+      if ((e >> j) & 1) v = xyzz29_load(ln + rows + e);
+      return v;
+    }, lds);
   } else if (j < bits) {
     const uint32_t jr = j - sh.log_cols;
-    sum = wg_sum<Q>(rows, [&](uint32_t e) { return ((e >> jr) & 1) ? xyzz29_load(ln + e) : xyzz29_identity(); }, lds);
+    sum = wg_sum<Q>(rows, [&](uint32_t e) {
+      xyzz29 v = xyzz29_identity();
+      if ((e >> jr) & 1) v = xyzz29_load(ln + e);
+      return v;
+    }, lds);
   } else {
     sum = wg_sum<Q>(cols, [&](uint32_t e) { return xyzz29_load(ln + rows + e); }, lds);
   }

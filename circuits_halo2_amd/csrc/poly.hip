@@ -112,28 +112,40 @@ __global__ void __launch_bounds__(256) batch_invert_kernel(fp_words* __restrict_
   const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * BI_CH;
   if (first >= n) return;
   const uint32_t cnt = min(BI_CH, n - first);
+  // straight-line (selects, no branches around the products) and small enough for the compiler to unroll both loops
+  // in full, so pre[] stays in registers; a zero or out-of-range element leaves the running product as it is.  The
+  // elements are read again on the way back (L2) rather than held: 8 more field elements per thread would halve the
+  // occupancy.
   f29 pre[BI_CH];           // prefix products over the non-zero elements
+  uint32_t live = 0;        // bit i: element i is in range and non-zero
   f29 acc = f29_one<P>();
 #pragma unroll
-  for (uint32_t i = 0; i < BI_CH; i++) {
+  for (int i = 0; i < (int)BI_CH; i++) {
     pre[i] = acc;
-    if (i < cnt) {
-      f29 v = load_hat(a + first + i);
-      if (!f29_is_zero_mod_p<P>(v)) acc = f29_mul<P>(acc, v);
-    }
+    const f29 v = load_hat(a + min(first + i, n - 1));
+    const bool on = (uint32_t)i < cnt && !f29_is_zero_mod_p<P>(v);
+    live |= (uint32_t)on << i;
+    const f29 next = f29_mul<P>(acc, v);
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc.l[q] = on ? next.l[q] : acc.l[q];
   }
   f29 inv = f29_inv<P>(acc);
+  // two loops of 4: one loop of 8 x (2 products + the store's domain change) is past the compiler's size limit for
+  // "#pragma unroll" (-pragma-unroll-threshold) and would be unrolled by 4 only -- pre[] indexed at run time, in scratch
+  auto back = [&](const int i) {
+    const bool on = (live >> i) & 1;
+    const f29 v = load_hat(a + min(first + i, n - 1));
+    const f29 out = f29_mul<P>(inv, pre[i]);
+    const f29 next = f29_mul<P>(inv, v);
+    if (on) store_hat(a + first + i, out);
 #pragma unroll
-  for (uint32_t k = 0; k < BI_CH; k++) {
-    const uint32_t i = BI_CH - 1 - k;
-    if (i < cnt) {
-      f29 v = load_hat(a + first + i);
-      if (!f29_is_zero_mod_p<P>(v)) {
-        store_hat(a + first + i, f29_mul<P>(inv, pre[i]));
-        inv = f29_mul<P>(inv, v);
-      }
-    }
-  }
+    for (int q = 0; q < 9; q++) inv.l[q] = on ? next.l[q] : inv.l[q];
+  };
+#pragma unroll
+  for (int k = 0; k < 4; k++) back(7 - k);
+#pragma unroll
+  for (int k = 0; k < 4; k++) back(3 - k);
+  static_assert(BI_CH == 8, "");
 }
 
 // ---- exclusive prefix product: out[0] = 1, out[i] = a[0] * ... * a[i-1] ------------------------

@@ -177,34 +177,67 @@ hipError_t coset_scale(const CosetScaleArgs& a, uint32_t count, hipStream_t stre
   coset_scale_kernel<<<dim3((n + 255) / 256, count), 256, 0, stream>>>(a);
   return hipGetLastError();
 }
-__global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) {
-  __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
+// the 5 x 5 (or nc x nc) solve per coefficient: stages the matrix in LDS, p_b = raw_b c_b^-i
+__device__ __forceinline__ void coset_matrix_to_lds(const CosetCombineArgs& a, uint32_t nc, uint32_t (*sm)[9]) {
   const uint32_t tid = threadIdx.x;
-  if (tid < a.nc * a.nc) {
-    const f29 v = f29_words_to_r261<P>(a.m[(tid / a.nc) * MAX_COSETS + tid % a.nc]);
+  if (tid < nc * nc) {
+    const f29 v = f29_words_to_r261<P>(a.m[(tid / nc) * MAX_COSETS + tid % nc]);
 #pragma unroll
     for (int q = 0; q < 9; q++) sm[tid][q] = v.l[q];
   }
   __syncthreads();
-  const uint32_t i = blockIdx.x * blockDim.x + tid;
+}
+__device__ __forceinline__ f29 coset_matrix_entry(const uint32_t (*sm)[9], uint32_t at) {
+  f29 r;
+#pragma unroll
+  for (int q = 0; q < 9; q++) r.l[q] = sm[at][q];
+  return r;
+}
+// NC cosets, known at compile time: the loops unroll and p[] stays in registers
+template <uint32_t NC>
+__global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) {
+  __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
+  coset_matrix_to_lds(a, NC, sm);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> a.log_n) return;
-  f29 p[MAX_COSETS];
-  for (uint32_t b = 0; b < a.nc; b++) {
+  f29 p[NC];
+#pragma unroll
+  for (uint32_t b = 0; b < NC; b++) {
     const size_t at = ((size_t)b << a.log_n) + i;
     p[b] = f29_mul<P>(ld(a.raw, at), ld(a.table_inv, at));     // (raw c^-i)~, < 2
   }
   const f29 one_hat = f29_one<P>();
+  for (uint32_t t = 0; t < NC; t++) {   // (not unrolled: p[] is indexed by b only)
+    f29 acc = f29_mul<P>(p[0], coset_matrix_entry(sm, t * NC));
+#pragma unroll
+    for (uint32_t b = 1; b < NC; b++)
+      acc = f29_mul2<P>(p[b], coset_matrix_entry(sm, t * NC + b), acc, one_hat);   // + p_b m_tb, one reduction each
+    f29_store_canonical<P>(a.pieces[t] + i, acc);
+  }
+}
+// any a.nc <= MAX_COSETS (p[] indexed at run time)
+__global__ void __launch_bounds__(256) coset_combine_any_kernel(CosetCombineArgs a) {
+  __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
+  coset_matrix_to_lds(a, a.nc, sm);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> a.log_n) return;
+  f29 p[MAX_COSETS];
+  for (uint32_t b = 0; b < a.nc; b++) {
+    const size_t at = ((size_t)b << a.log_n) + i;
+    p[b] = f29_mul<P>(ld(a.raw, at), ld(a.table_inv, at));
+  }
+  const f29 one_hat = f29_one<P>();
   for (uint32_t t = 0; t < a.nc; t++) {
-    auto mt = [&](uint32_t b) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sm[t * a.nc + b][q]; return r; };
-    f29 acc = f29_mul<P>(p[0], mt(0));
-    for (uint32_t b = 1; b < a.nc; b++) acc = f29_mul2<P>(p[b], mt(b), acc, one_hat);   // + p_b m_tb, one reduction each
+    f29 acc = f29_mul<P>(p[0], coset_matrix_entry(sm, t * a.nc));
+    for (uint32_t b = 1; b < a.nc; b++) acc = f29_mul2<P>(p[b], coset_matrix_entry(sm, t * a.nc + b), acc, one_hat);
     f29_store_canonical<P>(a.pieces[t] + i, acc);
   }
 }
 hipError_t coset_combine(const CosetCombineArgs& a, hipStream_t stream) {
   if (a.nc == 0 || a.nc > MAX_COSETS) return hipErrorInvalidValue;
   const uint32_t n = 1u << a.log_n;
-  coset_combine_kernel<<<(n + 255) / 256, 256, 0, stream>>>(a);
+  if (a.nc == 5) coset_combine_kernel<5><<<(n + 255) / 256, 256, 0, stream>>>(a);   // the reference circuit's degree
+  else coset_combine_any_kernel<<<(n + 255) / 256, 256, 0, stream>>>(a);
   return hipGetLastError();
 }
 

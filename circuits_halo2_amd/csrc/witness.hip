@@ -60,7 +60,7 @@ __device__ __forceinline__ void mix(f29& s0, f29& s1, const LdsTable* t) {
   s0 = a;
   s1 = b;
 }
-__device__ void poseidon_permute(f29& s0, f29& s1, const LdsTable* t) {
+__device__ __forceinline__ void poseidon_permute(f29& s0, f29& s1, const LdsTable* t) {
   uint32_t r = 0;
   for (int k = 0; k < 4; k++, r++) {
     s0 = pow5(f29_add(s0, lds_f29(t->rc, 2 * r)));      // (<4 + <2)^5

@@ -1,0 +1,99 @@
+// Rate of the field products of bn254_f29.cuh as the device sees them, dependent chains per lane at several occupancies.
+// Built twice -- as is (column chains in inline asm) and with -DSG_F29_ROW_SCAN (the plain C++ definition, what the
+// compiler makes of it) -- the two binaries print the same checksums: the two forms agree limb for limb.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench4.hip -o tools/microbench4
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSG_F29_ROW_SCAN tools/microbench4.hip -o tools/microbench4_rows
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../circuits_halo2_amd/csrc/bn254_f29.cuh"
+using namespace sg;
+
+__device__ __forceinline__ void seed(f29& x, f29& y, f29& z) {
+  for (int i = 0; i < 9; i++) {
+    x.l[i] = (threadIdx.x * 2654435761u + i * 40503u) & M29;
+    y.l[i] = (blockIdx.x * 97u + i * 7919u + 5) & M29;
+    z.l[i] = (threadIdx.x * 40503u + blockIdx.x * 31u + i * 2654435761u + 11) & M29;
+  }
+  x.l[8] &= 0xfffff; y.l[8] &= 0xfffff; z.l[8] &= 0xfffff;
+}
+__device__ __forceinline__ uint32_t fold(const f29& x) { uint32_t s = 0; for (int i = 0; i < 9; i++) s = s * 31 + x.l[i]; return s; }
+
+template <class P> __global__ void k_mul(uint32_t* out, int iters) {
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters; it++) x = f29_mul<P>(x, y);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+template <class P> __global__ void k_sqr(uint32_t* out, int iters) {
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters; it++) x = f29_sqr<P>(x);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+template <class P> __global__ void k_mul2(uint32_t* out, int iters) {   // (x y + z x): bounds 2*2 + 2*2
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters; it++) x = f29_mul2<P>(x, y, z, x);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+// two independent chains of products per lane (iters / 2 rounds: the same number of products)
+template <class P> __global__ void k_mul_x2(uint32_t* out, int iters) {
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters / 2; it++) { x = f29_mul<P>(x, y); z = f29_mul<P>(z, y); }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x) ^ (fold(z) * 7);
+}
+// lazy sums between the products, as the curve formulas have them: x = (x + z) * (y + x), z = z * y
+template <class P> __global__ void k_mixed(uint32_t* out, int iters) {
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters / 2; it++) { f29 s = f29_add(x, z), u = f29_add(y, x); x = f29_mul<P>(s, u); z = f29_mul<P>(z, y); }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x) ^ (fold(z) * 7);
+}
+
+template <class K>
+static void bench(const char* name, K kernel, uint32_t* d_out, int cus) {
+  const int iters = 512;
+  uint64_t sum = 0;
+  for (int waves_per_cu : {4, 8, 12, 16, 20, 32}) {
+    const int blocks = cus * waves_per_cu / 4;   // 256 threads = 4 waves
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    kernel<<<blocks, 256>>>(d_out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    kernel<<<blocks, 256>>>(d_out, iters);
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    const double products = (double)blocks * 256 * iters;
+    const double clk = ms * 1e-3 * 2.4e9 / (products / 64 / (cus * 4.0));
+    printf("time      %-22s waves/CU %2d  %8.3f ms  %8.1f G products/s  %7.0f clk per wave-product per SIMD (@2.4 GHz)\n", name,
+           waves_per_cu, ms, products / ms * 1e-6, clk);
+    if (waves_per_cu == 4) {
+      uint32_t* h = (uint32_t*)malloc((size_t)blocks * 256 * 4);
+      (void)hipMemcpy(h, d_out, (size_t)blocks * 256 * 4, hipMemcpyDeviceToHost);
+      for (int i = 0; i < blocks * 256; i++) sum = sum * 1000003 + h[i];
+      free(h);
+    }
+  }
+  printf("checksum  %-22s %016llx\n", name, (unsigned long long)sum);
+}
+int main() {
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount;
+  uint32_t* d_out;
+  (void)hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4 * 2);
+#if defined(SG_F29_ROW_SCAN)
+  printf("device  CUs %d   products: plain C++ (row scanning)\n", cus);
+#else
+  printf("device  CUs %d   products: column chains\n", cus);
+#endif
+  bench("f29_mul<Fq>", k_mul<Fq29>, d_out, cus);
+  bench("f29_mul<Fr>", k_mul<Fr29>, d_out, cus);
+  bench("f29_sqr<Fq>", k_sqr<Fq29>, d_out, cus);
+  bench("f29_mul2<Fr>", k_mul2<Fr29>, d_out, cus);
+  bench("f29_mul<Fq> x 2", k_mul_x2<Fq29>, d_out, cus);
+  bench("add, add, mul, mul <Fq>", k_mixed<Fq29>, d_out, cus);
+  return 0;
+}
