@@ -11,11 +11,12 @@
 namespace sg {
 
 struct GateOp {  // one instruction of the compiled program (4 words, read with scalar loads)
-  uint32_t w0;   // opcode | kidx << 8 | a_kind << 16 | b_kind << 24
-  uint32_t dst;  // LDS slot
+  uint32_t w0;   // opcode | kidx << 8 | a_kind << 16 | b_kind << 24   (MULADD: the kidx byte holds the kind of c)
+  uint32_t dst;  // LDS slot (low 16 bits); MULADD: the third operand c in the high 16 bits
   uint32_t a, b; // slot / constant index / (LOADCOL: column index, rotation)
 };
-enum GateOpcode : uint32_t { G_LOADCOL, G_LOADPREV, G_ADD, G_SUB, G_MUL, G_SQR, G_DBL, G_NEG, G_RED };
+// G_RED: the same residue below 2p (f29_reduce_small); G_MULADD: a * b + c under one reduction (f29_mul_add)
+enum GateOpcode : uint32_t { G_LOADCOL, G_LOADPREV, G_ADD, G_SUB, G_MUL, G_SQR, G_DBL, G_NEG, G_RED, G_MULADD };
 enum GateOperandKind : uint32_t { GK_SLOT = 0, GK_CONST = 1 };
 
 struct GateProgram {

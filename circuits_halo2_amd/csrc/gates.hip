@@ -8,14 +8,17 @@
 // Host side (compile_gates): the graph is lowered to a straight-line program over LDS slots --
 //   * every value lives in the 2^261 (hat) limb form; column words are shifted left by 5 bits on load
 //     (which is that form, with bound 32, at no cost), constants are converted once per workgroup;
-//   * additions / subtractions are lazy (bound tracking as in the curve code); a reduction (product
-//     with 1^) is inserted only where the next product would exceed bound_a * bound_b <= 170;
-//   * Store is an alias, Horner expands to product + sum per part, loads are emitted at first use;
+//   * additions / subtractions are lazy (bound tracking as in the curve code); a reduction (f29_reduce_small: the
+//     quotient from the top limb, ~45 instructions, no product) is inserted only where the next product would exceed
+//     bound_a * bound_b <= 170;
+//   * a product that only an addition reads is fused into it (G_MULADD = f29_mul_add: the addend joins the high columns
+//     of the product, one instruction stream entry and one LDS round trip less); Horner is a chain of those;
+//   * Store is an alias, loads are emitted at first use;
 //   * slots are allocated by liveness (last use), so the LDS footprint is the maximum number of
 //     simultaneously live values, not the number of intermediates.
 // Device side (gates_kernel): one thread per row, T rows per workgroup, slots in LDS as [slot][limb][row]
 // (conflict-free), the instruction stream is uniform (scalar loads, no divergence).  Cost per
-// product-type instruction ~300 VALU instructions (229 of them the product): ALU-bound like the rest.
+// product-type instruction ~260 VALU instructions (206 of them the product): ALU-bound like the rest.
 #include "gates.h"
 
 #include <algorithm>
@@ -81,6 +84,7 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
   for (uint32_t pc = 0; pc < a.n_ops; pc++) {
     const GateOp op = a.ops[pc];
     const uint32_t code = op.w0 & 0xff, kidx = (op.w0 >> 8) & 0xff, ak = (op.w0 >> 16) & 0xff, bk = op.w0 >> 24;
+    const uint32_t dst = op.dst & 0xffff;
     f29 r;
     switch (code) {
       case G_LOADCOL: {
@@ -104,10 +108,11 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
       case G_SQR: r = f29_sqr<P>(get(ak, op.a)); break;
       case G_DBL: { f29 x = get(ak, op.a); r = f29_add(x, x); break; }
       case G_NEG: r = sub_k(kidx, f29_zero(), get(ak, op.a)); break;
-      default: r = f29_mul<P>(get(ak, op.a), f29_one<P>()); break;  // G_RED
+      case G_MULADD: r = f29_mul_add<P>(get(ak, op.a), get(bk, op.b), get(kidx, op.dst >> 16)); break;
+      default: r = f29_reduce_small<P>(get(ak, op.a)); break;  // G_RED
     }
 #pragma unroll
-    for (int q = 0; q < 9; q++) s_slot[(op.dst * 9 + q) * T + tid] = r.l[q];
+    for (int q = 0; q < 9; q++) s_slot[(dst * 9 + q) * T + tid] = r.l[q];
   }
   f29 res = get(a.result_kind, a.result_index);
   // hat -> memory domain: x^ * 2^256 * 2^-261 = x~, then canonical
@@ -126,6 +131,7 @@ struct IrOp {
   Val a, b;
   uint32_t col = 0;
   int32_t rot = 0;
+  Val c{GK_CONST, 0};   // MULADD: the addend
 };
 struct Compiler {
   std::vector<IrOp> ir;
@@ -142,7 +148,7 @@ struct Compiler {
     return v;
   }
   uint32_t bnd(const Val& v) const { return v.kind == GK_CONST ? 2u : bound[v.index]; }
-  Val reduce(Val v) {  // product with 1^: bound 2
+  Val reduce(Val v) {  // f29_reduce_small: bound 2
     v = resolve(v);
     if (v.kind == GK_CONST || bound[v.index] <= 2) return v;
     uint32_t d = new_value(2);
@@ -196,6 +202,18 @@ struct Compiler {
     a = resolve(a);
     if (bnd(a) * bnd(a) > 170) a = reduce(a);
     return emit2(G_SQR, 0, a, a, 2);
+  }
+  Val muladd(Val a, Val b, Val z) {   // a b + z under one reduction: bound 2 + bound(z)
+    a = resolve(a); b = resolve(b); z = resolve(z);
+    while (bnd(a) * bnd(b) > 170) {
+      if (bnd(a) >= bnd(b)) a = reduce(a); else b = reduce(b);
+    }
+    if (bnd(z) + 2 > 80) z = reduce(z);
+    uint32_t d = new_value(bnd(z) + 2);
+    IrOp op{G_MULADD, 0, d, a, b};
+    op.c = z;
+    ir.push_back(op);
+    return Val{GK_SLOT, d};
   }
 };
 }  // namespace
@@ -320,12 +338,43 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
       if (depth[q] > 4096) return "dependency chain deeper than 4096 calculations";
     }
   }
+  // how often each intermediate is read: a product that is read once, by an addition, is fused into it (G_MULADD)
+  std::vector<uint32_t> uses(g.n_calculations, 0);
+  {
+    auto use = [&](const sg_value_source& s) { if (s.kind == SG_VS_INTERMEDIATE) uses[s.index]++; };
+    for (uint32_t q = 0; q < g.n_calculations; q++) {
+      const sg_calculation& cal = g.calculations[q];
+      use(cal.a);
+      if (cal.op <= SG_OP_MUL || cal.op == SG_OP_HORNER) use(cal.b);
+      if (cal.op == SG_OP_HORNER)
+        for (uint32_t t = 0; t < cal.parts_len; t++) use(g.horner_parts[cal.parts_offset + t]);
+    }
+    uses[g.n_calculations - 1]++;   // the result
+  }
   std::vector<uint8_t> done(g.n_calculations, 0);
   std::function<Val(const sg_value_source&)> need;
   std::function<void(uint32_t)> lower = [&](uint32_t q) {
     if (done[q] || !err.empty()) return;
     done[q] = 1;
     const sg_calculation& cal = g.calculations[q];
+    if (cal.op == SG_OP_ADD) {
+      // x * y + z: one operand a product (or a square) that nothing else reads and that has not been lowered yet
+      auto fusable = [&](const sg_value_source& s) {
+        return s.kind == SG_VS_INTERMEDIATE && uses[s.index] == 1 && !done[s.index] &&
+               (g.calculations[s.index].op == SG_OP_MUL || g.calculations[s.index].op == SG_OP_SQUARE);
+      };
+      const bool fa = fusable(cal.a), fb = !fa && fusable(cal.b);
+      if (fa || fb) {
+        const sg_value_source& prod = fa ? cal.a : cal.b;
+        const sg_calculation& m = g.calculations[prod.index];
+        done[prod.index] = 1;
+        const Val z = need(fa ? cal.b : cal.a);          // the addend first: one live value while the factors are computed
+        const Val x = need(m.a);
+        const Val y = m.op == SG_OP_SQUARE ? x : need(m.b);
+        inter[q] = c.muladd(x, y, z);
+        return;
+      }
+    }
     Val a = need(cal.a);
     switch (cal.op) {
       case SG_OP_ADD: inter[q] = c.add(a, need(cal.b)); break;
@@ -336,8 +385,10 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
       case SG_OP_NEGATE: inter[q] = c.neg(a); break;
       case SG_OP_HORNER: {
         Val f = need(cal.b), acc = a;
-        for (uint32_t t = 0; t < cal.parts_len && err.empty(); t++)
-          acc = c.add(c.mul(acc, f), need(g.horner_parts[cal.parts_offset + t]));
+        for (uint32_t t = 0; t < cal.parts_len && err.empty(); t++) {
+          const Val part = need(g.horner_parts[cal.parts_offset + t]);
+          acc = c.muladd(acc, f, part);
+        }
         inter[q] = acc;
         break;
       }
@@ -360,6 +411,7 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
     if (op.code == G_LOADCOL || op.code == G_LOADPREV) continue;
     if (op.a.kind == GK_SLOT) last[op.a.index] = i;
     if (op.b.kind == GK_SLOT) last[op.b.index] = i;
+    if (op.code == G_MULADD && op.c.kind == GK_SLOT) last[op.c.index] = i;
   }
   if (result.kind == GK_SLOT) last[result.index] = END;
   std::vector<uint32_t> slot(nv, END), free_slots;
@@ -367,15 +419,18 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
   for (uint32_t i = 0; i < c.ir.size(); i++) {
     const IrOp& op = c.ir[i];
     GateOp o{};
-    uint32_t a_idx = 0, b_idx = 0;
-    const bool reads = !(op.code == G_LOADCOL || op.code == G_LOADPREV);
+    uint32_t a_idx = 0, b_idx = 0, c_idx = 0;
+    const bool reads = !(op.code == G_LOADCOL || op.code == G_LOADPREV), three = op.code == G_MULADD;
     if (reads) {
       a_idx = op.a.kind == GK_SLOT ? slot[op.a.index] : op.a.index;
       b_idx = op.b.kind == GK_SLOT ? slot[op.b.index] : op.b.index;
+      if (three) c_idx = op.c.kind == GK_SLOT ? slot[op.c.index] : op.c.index;
       // operands dying here free their slots before the destination is chosen (in-place update)
+      auto same = [](const Val& u, const Val& v) { return u.kind == GK_SLOT && v.kind == GK_SLOT && u.index == v.index; };
       if (op.a.kind == GK_SLOT && last[op.a.index] == i) free_slots.push_back(slot[op.a.index]);
-      if (op.b.kind == GK_SLOT && last[op.b.index] == i && !(op.a.kind == GK_SLOT && op.a.index == op.b.index))
-        free_slots.push_back(slot[op.b.index]);
+      if (op.b.kind == GK_SLOT && last[op.b.index] == i && !same(op.a, op.b)) free_slots.push_back(slot[op.b.index]);
+      if (three && op.c.kind == GK_SLOT && last[op.c.index] == i && !same(op.a, op.c) && !same(op.b, op.c))
+        free_slots.push_back(slot[op.c.index]);
     } else {
       a_idx = op.col;
       b_idx = (uint32_t)op.rot;
@@ -392,14 +447,16 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
     }
     slot[op.dst] = d;
     if (std::getenv("SG_GATES_DUMP")) {   // development aid: the lowered program with its slot pressure
-      static const char* names[] = {"loadcol", "loadprev", "add", "sub", "mul", "sqr", "dbl", "neg", "red"};
+      static const char* names[] = {"loadcol", "loadprev", "add", "sub", "mul", "sqr", "dbl", "neg", "red", "muladd"};
       std::fprintf(stderr, "%3u %-8s dst s%-2u", i, names[op.code], d);
       if (!reads) std::fprintf(stderr, " col %u rot %d", op.col, op.rot);
       else std::fprintf(stderr, " %c%u %c%u", op.a.kind == GK_SLOT ? 's' : 'c', a_idx, op.b.kind == GK_SLOT ? 's' : 'c', b_idx);
+      if (three) std::fprintf(stderr, " %c%u", op.c.kind == GK_SLOT ? 's' : 'c', c_idx);
       std::fprintf(stderr, "   live %u (last use of dst: %u)\n", n_slots - (uint32_t)free_slots.size(), last[op.dst]);
     }
-    o.w0 = op.code | (op.kidx << 8) | (op.a.kind << 16) | (op.b.kind << 24);
-    o.dst = d; o.a = a_idx; o.b = b_idx;
+    o.w0 = op.code | ((three ? op.c.kind : op.kidx) << 8) | (op.a.kind << 16) | (op.b.kind << 24);
+    o.dst = d | (c_idx << 16); o.a = a_idx; o.b = b_idx;
+    if (d > 0xffff || c_idx > 0xffff) return "program too large (slot or constant index above 65535)";
     prog.ops.push_back(o);
   }
   prog.n_slots = std::max<uint32_t>(1, n_slots);

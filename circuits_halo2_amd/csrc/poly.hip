@@ -43,18 +43,15 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
   if (first < n) {
     uint32_t last = min(n, first + EV_CH);
     acc = f29_load_r256<P>(c + last - 1);               // any 256-bit word value: bound < 6
-    for (uint32_t i = last - 1; i-- > first;) {
-      acc = f29_mul<P>(acc, x);                         // bound 8 * 2
-      acc = f29_add(acc, f29_load_r256<P>(c + i));      // < 2 + 6
-    }
-    acc = f29_mul<P>(acc, f29_one<P>());                // back below 2p
+    for (uint32_t i = last - 1; i-- > first;)
+      acc = f29_mul_add<P>(acc, x, f29_load_r256<P>(c + i));   // acc x + c_i in one chain: < 8 * 2 / 170 + 1 + 6 < 8
   }
 #pragma unroll
   for (int q = 0; q < 9; q++) sh[tid][q] = acc.l[q];
   __syncthreads();
   // pairwise fold with x^(CH * 2^l) at level l.  The eight powers are computed once per workgroup (lane l squares its way up:
   // every lane doing all eight squarings was more work than the fold itself) and the sums stay lazy: the bound grows by 2 per
-  // level (<= 18 after eight), well inside what the next product takes, so only the last value is reduced.
+  // level (< 8 + 16 after eight), well inside what the next product takes, so only the last value is reduced.
   __shared__ uint32_t s_xp[8][9];
   if (tid < 8) {
     f29 xp = x;
@@ -70,7 +67,7 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
       f29 lo, hi, xp;
 #pragma unroll
       for (int q = 0; q < 9; q++) { lo.l[q] = sh[tid][q]; hi.l[q] = sh[tid + s][q]; xp.l[q] = s_xp[level][q]; }
-      lo = f29_add(lo, f29_mul<P>(hi, xp));            // bound + 2 per level; hi's bound (<= 16) * 2 stays below 170
+      lo = f29_mul_add<P>(hi, xp, lo);                 // lo + hi x^(..): bound + 2 per level; hi's bound (< 24) * 2 stays below 170
 #pragma unroll
       for (int q = 0; q < 9; q++) sh[tid][q] = lo.l[q];
     }
@@ -242,7 +239,7 @@ __device__ __forceinline__ f29 block_suffix_geometric(f29 mine, const f29* w_pow
 #pragma unroll
   for (int q = 0; q < 9; q++) sh[tid][q] = mine.l[q];
   __syncthreads();
-  f29 v = mine;                                              // < 2p between steps
+  f29 v = mine;                                              // lazy between steps: `mine` may come with a bound up to 8
   uint32_t j = 0;
   for (uint32_t d = 1; d < nthr; d <<= 1, j++) {
     f29 o = f29_zero();
@@ -251,7 +248,7 @@ __device__ __forceinline__ f29 block_suffix_geometric(f29 mine, const f29* w_pow
       for (int q = 0; q < 9; q++) o.l[q] = sh[tid + d][q];
     }
     __syncthreads();
-    v = f29_mul2<P>(v, f29_one<P>(), o, w_pow[j]);           // v + w^d * o, one reduction
+    v = f29_mul_add<P>(o, w_pow[j], v);                      // v + w^d * o: the bound grows by < 2 per step (< 2 + 16 after eight)
 #pragma unroll
     for (int q = 0; q < 9; q++) sh[tid][q] = v.l[q];
     __syncthreads();
@@ -264,7 +261,7 @@ __device__ __forceinline__ f29 kd_local(const fp_words* __restrict__ a, uint32_t
 #pragma unroll
   for (uint32_t k = KD_CH; k-- > 0;) {
     vals[k] = (first + k < n) ? load_hat(a + first + k) : f29_zero();
-    acc = f29_mul2<P>(acc, b_hat, vals[k], f29_one<P>());    // acc * b + a_k
+    acc = f29_mul_add<P>(acc, b_hat, vals[k]);               // acc * b + a_k: < 4 * 2 / 170 + 1 + 2 < 4
   }
   return acc;
 }
@@ -325,7 +322,7 @@ __global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a
   f29 local = kd_local(a, n, first, b_hat, vals);
   // the top thread's chunk sees the block carry: s(lo) = local + b^KD_CH * carry
   // (a single-block division has no carries: carry == nullptr)
-  if (carry && tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), w[0]);
+  if (carry && tid == KD_THREADS - 1) local = f29_mul_add<P>(load_hat(carry + blockIdx.x), w[0], local);
   block_suffix_geometric(local, w, sh, tid, KD_THREADS);      // sh[t] = s at the bottom of thread t's chunk
   f29 run = f29_zero();                                        // s just above this thread's chunk
   if (tid + 1 < KD_THREADS) {
@@ -337,7 +334,7 @@ __global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a
 #pragma unroll
   for (uint32_t k = KD_CH; k-- > 0;) {
     const uint32_t i = first + k;
-    run = f29_mul2<P>(run, b_hat, vals[k], f29_one<P>());      // s_i
+    run = f29_mul_add<P>(run, b_hat, vals[k]);                 // s_i = s_(i+1) b + a_i: < 20 * 2 / 170 + 1 + 2
     if (i < n) {
       if (i >= 1) store_hat(q_out + i - 1, run);
       else if (rem_out) store_hat(rem_out, run);
@@ -430,7 +427,7 @@ __global__ void __launch_bounds__(256) kate_write_batch(KateBatch bt, uint32_t n
   f29 vals[KD_CH];
   const f29 b_hat = pw.b_hat;
   f29 local = kd_local(a, n, first, b_hat, vals);
-  if (carry && tid == KD_THREADS - 1) local = f29_mul2<P>(local, f29_one<P>(), load_hat(carry + blockIdx.x), pw.chunk[0]);
+  if (carry && tid == KD_THREADS - 1) local = f29_mul_add<P>(load_hat(carry + blockIdx.x), pw.chunk[0], local);
   block_suffix_geometric(local, pw.chunk, sh, tid, KD_THREADS);
   f29 run = f29_zero();
   if (tid + 1 < KD_THREADS) {
@@ -442,7 +439,7 @@ __global__ void __launch_bounds__(256) kate_write_batch(KateBatch bt, uint32_t n
 #pragma unroll
   for (uint32_t k = KD_CH; k-- > 0;) {
     const uint32_t i = first + k;
-    run = f29_mul2<P>(run, b_hat, vals[k], f29_one<P>());      // s_i; s_0 = a(b) is the remainder, dropped (exact divisions)
+    run = f29_mul_add<P>(run, b_hat, vals[k]);                 // s_i = s_(i+1) b + a_i: < 20 * 2 / 170 + 1 + 2; s_0 = a(b) is the remainder, dropped (exact divisions)
     if (i < n && i >= 1) store_hat(q_out + i - 1, run);
   }
   if (first <= n - 1 && n - 1 < first + KD_CH) store_hat(q_out + n - 1, f29_zero());   // padding slot

@@ -193,7 +193,7 @@ __device__ __forceinline__ f29 coset_matrix_entry(const uint32_t (*sm)[9], uint3
   for (int q = 0; q < 9; q++) r.l[q] = sm[at][q];
   return r;
 }
-// NC cosets, known at compile time: the loops unroll and p[] stays in registers
+// NC <= 5 cosets, known at compile time: the loops unroll and p[] stays in registers
 template <uint32_t NC>
 __global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) {
   __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
@@ -206,13 +206,11 @@ __global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) 
     const size_t at = ((size_t)b << a.log_n) + i;
     p[b] = f29_mul<P>(ld(a.raw, at), ld(a.table_inv, at));     // (raw c^-i)~, < 2
   }
-  const f29 one_hat = f29_one<P>();
   for (uint32_t t = 0; t < NC; t++) {   // (not unrolled: p[] is indexed by b only)
-    f29 acc = f29_mul<P>(p[0], coset_matrix_entry(sm, t * NC));
+    f29 row[NC];
 #pragma unroll
-    for (uint32_t b = 1; b < NC; b++)
-      acc = f29_mul2<P>(p[b], coset_matrix_entry(sm, t * NC + b), acc, one_hat);   // + p_b m_tb, one reduction each
-    f29_store_canonical<P>(a.pieces[t] + i, acc);
+    for (uint32_t b = 0; b < NC; b++) row[b] = coset_matrix_entry(sm, t * NC + b);
+    f29_store_canonical<P>(a.pieces[t] + i, f29_dot<P, NC>(p, row));   // sum_b p_b m_tb under ONE reduction (bound NC * 2 * 2)
   }
 }
 // any a.nc <= MAX_COSETS (p[] indexed at run time)

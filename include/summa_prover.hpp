@@ -788,11 +788,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // two side streams: independent latency chains (the transforms of a phase under its commitments, the three grand
   // products, the rotation sets of the multi-open) run next to the main (null) stream; the library keeps its work
   // space per stream.  fork: the side streams wait for everything enqueued on the main stream; join: the reverse
-  hipStream_t(&side)[2] = session().side;
+  hipStream_t(&side_streams)[2] = session().side;
   hipEvent_t& ev_fork = session().ev_fork;
   hipEvent_t(&ev_join)[2] = session().ev_join;
   const hipStream_t ms = main_stream();
-  if (!side[0]) {
+  if (!side_streams[0]) {
     {
       // the side streams carry work that is needed a phase later (transforms under a commitment job): lowest priority, so
       // that the commitment job's latency-bound kernels on the other streams are dispatched first (SG_SIDE_PRIORITY=0: normal)
@@ -800,11 +800,14 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const char* v = std::getenv("SG_SIDE_PRIORITY");
       const int prio = (v && v[0] == '0') ? 0 : least;
-      for (auto& st : side) hk(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio), "stream");
+      for (auto& st : side_streams) hk(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio), "stream");
     }
     hk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "event");
     for (auto& e : ev_join) hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
   }
+  // SG_PROVER_SERIAL (development aid): everything on the main stream, so that a kernel trace shows every kernel alone
+  const bool serial = std::getenv("SG_PROVER_SERIAL") != nullptr;
+  const hipStream_t side[2] = {serial ? ms : side_streams[0], serial ? ms : side_streams[1]};
   auto fork = [&]() {
     hk(hipEventRecord(ev_fork, ms), "event");
     for (auto& st : side) hk(hipStreamWaitEvent(st, ev_fork, 0), "wait");
@@ -1086,19 +1089,16 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       inv = inv * v;
     }
   }
-  fork();
-  for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
+  // r_i(X) through the set's (points, values) for every set first: host arithmetic on the evaluations alone.  The
+  // coefficients are staged in page-locked memory (4 rows per set), so the uploads below need no host synchronisation and
+  // the three streams are fed back to back
+  uint64_t* r_stage = pinned_rows(4 * sets.size());
+  std::vector<std::vector<Fr>> zps(sets.size());
+  for (size_t si = 0; si < sets.size(); si++) {
     const auto& set = sets[si];
-    hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
-    DevCol& r_poly = r_polys[si];
-    std::vector<void*> ps;
-    std::vector<Fr> zp(set.polys.size());
-    for (size_t j = 0; j < set.polys.size(); j++) {
-      ps.push_back(poly.at(set.polys[j]));
-      zp[j] = j ? zp[j - 1] * zeta : Fr::one();
-    }
-    qs.emplace_back(n);
-    ck(sg_fr_lincomb_dev(ps.data(), zp[0].bytes(), (uint32_t)ps.size(), n, qs.back().p, st), "set lincomb");
+    std::vector<Fr>& zp = zps[si];
+    zp.resize(set.polys.size());
+    for (size_t j = 0; j < set.polys.size(); j++) zp[j] = j ? zp[j - 1] * zeta : Fr::one();
     std::vector<Fr> pts, vals;
     for (int r : set.rots) {
       pts.push_back(point(r));
@@ -1106,7 +1106,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       for (size_t j = 0; j < set.polys.size(); j++) v = v + zp[j] * eval_of(set.polys[j], r);
       vals.push_back(v);
     }
-    // r(X) through (pts, vals)
+    if (pts.size() > 4) throw std::runtime_error("rotation set of more than four points");
     std::vector<Fr> rc(pts.size(), Fr::zero());
     for (size_t i = 0; i < pts.size(); i++) {
       std::vector<Fr> basis = {Fr::one()};
@@ -1122,15 +1122,25 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       const Fr scale = vals[i] * denom_inv[si][i];
       for (size_t t = 0; t < basis.size(); t++) rc[t] = rc[t] + scale * basis[t];
     }
-    hk(hipMemcpyAsync(r_poly.p, rc.data(), 32 * rc.size(), hipMemcpyHostToDevice, st), "H2D");
-    hk(hipStreamSynchronize(st), "sync");   // rc is a local: the copy must have left the host buffer
+    std::memcpy(r_stage + 16 * si, rc.data(), 32 * rc.size());
+    rs.push_back(rc);
+  }
+  fork();
+  for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
+    const auto& set = sets[si];
+    hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
+    DevCol& r_poly = r_polys[si];
+    std::vector<void*> ps;
+    for (size_t j = 0; j < set.polys.size(); j++) ps.push_back(poly.at(set.polys[j]));
+    qs.emplace_back(n);
+    ck(sg_fr_lincomb_dev(ps.data(), zps[si][0].bytes(), (uint32_t)ps.size(), n, qs.back().p, st), "set lincomb");
+    hk(hipMemcpyAsync(r_poly.p, r_stage + 16 * si, 32 * rs[si].size(), hipMemcpyHostToDevice, st), "H2D");
     fs.emplace_back(n);
     {
       void* two[2] = {qs.back().p, r_poly.p};
       const Fr cf[2] = {Fr::one(), -Fr::one()};
       ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, st), "q - r");
     }
-    rs.push_back(rc);
   }
   join();
   // f_i / Z_{S_i}: q_i - r_i vanishes on the whole set, and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with
@@ -1138,10 +1148,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // set is an independent exact Kate division: ONE batch (three launches for all eleven), and
   // f = sum_i nu^i f_i / Z_{S_i} is one linear combination of the eleven quotients
   DevCol f_all(n);
+  std::vector<DevCol> quotients;   // (alive until the proof is done: returning them to the pool here would need a host sync)
   {
     std::vector<void*> div_in, div_out;
     std::vector<Fr> div_pts, weights;
-    std::vector<DevCol> quotients;
     Fr nu_pow = Fr::one();
     for (size_t si = 0; si < sets.size(); si++) {
       for (size_t j = 0; j < sets[si].rots.size(); j++) {
@@ -1156,7 +1166,6 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_fr_kate_division_batch_dev(div_in.data(), n, div_pts[0].bytes(), (uint32_t)div_in.size(), div_out.data(), main_stream()),
        "kate division batch");
     ck(sg_fr_lincomb_dev(div_out.data(), weights[0].bytes(), (uint32_t)div_out.size(), n, f_all.p, main_stream()), "f lincomb");
-    hk(hipStreamSynchronize(main_stream()), "sync");   // the quotient columns go back to the pool with this scope
   }
   mark("6: f(X) enqueued, commit issued");
   commit_batch({f_all.p}, {0});

@@ -12,12 +12,16 @@ template <class P> void run(const std::string& op, const f29& a, const f29& b) {
   if (op == "mul") r = f29_mul<P>(a, b);
   else if (op == "sqr") r = f29_sqr<P>(a);
   else if (op == "mul2") r = f29_mul2<P>(a, b, b, a);
+  else if (op == "muladd") r = f29_mul_add<P>(a, b, b);        // a b 2^-261 + b
+  else if (op == "dot3") { const f29 x[3] = {a, b, a}, y[3] = {b, b, a}; r = f29_dot<P, 3>(x, y); }   // (ab + bb + aa) 2^-261
+  else if (op == "dot5") { const f29 x[5] = {a, b, a, a, b}, y[5] = {b, b, a, b, a}; r = f29_dot<P, 5>(x, y); }   // (3ab + bb + aa) 2^-261
   else if (op == "add") r = f29_add(a, b);
   else if (op == "sub2") r = f29_sub<P, 0>(a, b);
   else if (op == "sub8") r = f29_sub<P, 2>(a, b);
   else if (op == "sub64") r = f29_sub<P, 5>(a, b);
   else if (op == "canon") r = f29_canonical<P>(a);
   else if (op == "step") r = f29_mont_step<P>(a);
+  else if (op == "redsmall") r = f29_reduce_small<P>(a);
   else if (op == "inv") r = f29_canonical<P>(f29_inv_safegcd<P>(a));
   else if (op == "iszero") { r.l[0] = f29_is_zero_mod_p<P>(a); }
   else if (op == "norm") r = f29_normalize(a);

@@ -17,6 +17,15 @@ def lazy(x, rnd):
         if l[i + 1] >= 1 and l[i] + (1 << 29) * 0 + d * 0 >= 0:
             pass
     return l
+def lazy_limbs(x, rnd):
+    """the same value with limbs up to 2^29 + 3 where the limb above can lend (what a carry step leaves)"""
+    l = limbs(x)
+    for i in range(8):
+        d = rnd.randrange(0, 4)
+        if l[i + 1] >= 1 and l[i] < d and rnd.random() < 0.5:   # borrow 2^29 from the limb above: l[i] + 2^29 <= 2^29 + 3
+            l[i] += 1 << 29
+            l[i + 1] -= 1
+    return l
 rnd = random.Random(1)
 cases = []
 for fld, p in (("q", P.Q), ("r", P.R)):
@@ -31,6 +40,11 @@ for fld, p in (("q", P.Q), ("r", P.R)):
             cases.append(("sqr", fld, limbs(a), limbs(0), ("mul", p, a, a)))
         if 2 * ba * bb <= 170:
             cases.append(("mul2", fld, limbs(a), limbs(b), ("mul2", p, a, b)))
+        cases.append(("muladd", fld, limbs(a), limbs(b), ("muladd", p, a, b, ba * bb, bb)))
+        if ba * bb + bb * bb + ba * ba <= 170:
+            cases.append(("dot3", fld, limbs(a), limbs(b), ("dot", p, a * b + b * b + a * a)))
+        if 3 * ba * bb + bb * bb + ba * ba <= 170:
+            cases.append(("dot5", fld, limbs(a), limbs(b), ("dot", p, 3 * a * b + b * b + a * a)))
         a8, b8 = rnd.randrange(8 * p), rnd.randrange(8 * p)
         cases.append(("sub8", fld, limbs(a8), limbs(b8), ("sub", p, a8, b8, 8)))
         b2 = rnd.randrange(2 * p)
@@ -40,6 +54,8 @@ for fld, p in (("q", P.Q), ("r", P.R)):
         cases.append(("canon", fld, limbs(a), limbs(0), ("canon", p, a)))
         st = rnd.choice([0, p, 170 * p - 1, p - 1]) if rnd.random() < 0.1 else rnd.randrange(rnd.choice([1, 2, 25, 170]) * p)
         cases.append(("step", fld, limbs(st), limbs(0), ("step", p, st)))
+        rs = rnd.choice([0, p - 1, p, p + 1, 2 * p - 1, 2 * p, 169 * p, 170 * p - 1, 64 * p - 1, 64 * p]) if rnd.random() < 0.3 else rnd.randrange(rnd.choice([1, 2, 3, 32, 170]) * p)
+        cases.append(("redsmall", fld, lazy_limbs(rs, rnd), limbs(0), ("redsmall", p, rs)))
         ai = rnd.choice([0, 1, 2, p - 1, p, p + 1, 3 * p, (1 << 261) % p]) if rnd.random() < 0.2 else rnd.randrange(rnd.choice([1, 2, 64, 170]) * p)
         cases.append(("inv", fld, limbs(ai), limbs(0), ("inv", p, ai)))
         z = rnd.choice([k * p for k in range(0, 65)] + [rnd.randrange(64 * p) for _ in range(8)] + [k * p + 1 for k in range(3)])
@@ -64,6 +80,14 @@ for (op, f, a, b, exp), line in zip(cases, out):
         _, p, x, y = exp
         v = val(l)
         ok = v % p == (2 * x * y * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "muladd":   # x y 2^-261 + y: the EXACT integer (x y + m p) / 2^261 + y, limbs 0..7 exactly normalised
+        _, p, x, y, bxy, bz = exp
+        v = val(l)
+        ok = (v - y) % p == (x * y * pow(1 << 261, -1, p)) % p and y <= v < 2 * p + y and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "dot":
+        _, p, sxy = exp
+        v = val(l)
+        ok = v % p == (sxy * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
     elif exp[0] == "add":
         _, p, x, y = exp
         ok = val(l) == x + y and all(t < (1 << 29) + 4 for t in l[:8])
@@ -77,6 +101,10 @@ for (op, f, a, b, exp), line in zip(cases, out):
         _, p, x = exp
         v = val(l)
         ok = v % p == x * pow(1 << 29, -1, p) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "redsmall":   # same residue, < 2p, exactly normalised, no change of domain
+        _, p, x = exp
+        v = val(l)
+        ok = v % p == x % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
     elif exp[0] == "inv":     # (x^)^-1 in the 2^261 domain: A -> A^-1 * 2^522 (0 -> 0), canonical
         _, p, x = exp
         want = 0 if x % p == 0 else pow(x, -1, p) * pow(2, 522, p) % p

@@ -827,6 +827,21 @@ def test_quad_cooperative_add_selftest(gpu):
     assert "mismatching lanes: 0 of" in out.stdout
 
 
+def test_field_products_device_selftest(gpu):
+    """the device spelling of the field products (column chains of v_mad_u64_u32 in inline asm: f29_mul, f29_sqr,
+    f29_mul2, f29_mul_add, f29_dot<2..5>) against the plain C++ definition on the host, limb for limb: random
+    operands, operands at the top of their lazy bounds, edge values, both fields (tools/test_f29_device.hip, built by
+    __graft_entry__.build())"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "test_f29_device")
+    if not os.path.exists(exe):
+        pytest.skip("tools/test_f29_device not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all products agree" in out.stdout
+
+
 # ----------------------------------------------------------------------------- fixed-base commits (precomputed SRS)
 def test_fixed_base_goldens(gpu, O, P, srs11, kat):
     """the reference-derived known answers again, through the precomputed-window path"""
