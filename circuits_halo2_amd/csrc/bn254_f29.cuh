@@ -582,10 +582,10 @@ SG_HD f29 f29_reduce_with(const f29& a, const uint32_t (&c)[9]) {
   for (int i = 0; i < 9; i++) k.l[i] = c[i];
   return f29_cond_sub_p<P>(f29_mul<P>(a, k));
 }
-// canonical representative of a (same Montgomery domain): a * (2^261 mod p) * 2^-261
+// canonical representative of a (same Montgomery domain); a normalised, bound <= 170
 template <class P>
 SG_HD f29 f29_canonical(const f29& a) {
-  return f29_reduce_with<P>(a, P::one);
+  return f29_cond_sub_p<P>(f29_reduce_small<P>(a));
 }
 // is a == 0 (mod p)?  a normalised (l[0] < 2^29 exactly), bound <= 64.
 // If a = k*p then (a.l[0] * p^-1) mod 2^29 == k; anything else passes the filter with

@@ -172,8 +172,8 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
     __syncthreads();
   }
 
-  // write back: one closing product per element, then canonical 32-byte store
-  const f29 one = f29_one<P>();
+  // write back: one closing product per element (or, with nothing to multiply by, a product-free reduction), then the
+  // canonical 32-byte store
   if (p.kind == 0) {
     for (uint32_t e = tid; e < E; e += nthr) {
       uint32_t t = e & (T - 1), r = e >> p.log_t;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       } else if (p.post3) {
         v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
       } else {
-        v = p.fold29 ? f29_mont_step<P>(v) : f29_mul<P>(v, one);
+        v = p.fold29 ? f29_mont_step<P>(v) : f29_reduce_small<P>(v);
       }
       f29_store_canonical<P>(p_out + go, v);
     }
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
       } else if (p.post3) {
         v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
       } else {
-        v = p.fold29 ? f29_mont_step<P>(v) : f29_mul<P>(v, one);
+        v = p.fold29 ? f29_mont_step<P>(v) : f29_reduce_small<P>(v);
       }
       f29_store_canonical<P>(p_out + go, v);
     }

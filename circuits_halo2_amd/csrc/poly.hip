@@ -77,7 +77,7 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
     f29 r;
 #pragma unroll
     for (int q = 0; q < 9; q++) r.l[q] = sh[0][q];
-    f29_store_canonical<P>(out + blockIdx.x, f29_mul<P>(r, f29_one<P>()));   // the lazy sums back below 2p
+    f29_store_canonical<P>(out + blockIdx.x, f29_reduce_small<P>(r));   // the lazy sums back below 2p
   }
 }
 static constexpr uint32_t EV_CH = 32, EV_LOG = 13;   // the single-polynomial path (any length): log2(EV_CH * EV_THREADS)

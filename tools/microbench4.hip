@@ -31,9 +31,36 @@ template <class P> __global__ void k_sqr(uint32_t* out, int iters) {
   for (int it = 0; it < iters; it++) x = f29_sqr<P>(x);
   out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
 }
-template <class P> __global__ void k_mul2(uint32_t* out, int iters) {   // (x y + z x): bounds 2*2 + 2*2
+// operands that the compiler cannot relate to each other (with a shared operand the plain C++ form factors a sum of products)
+__device__ __forceinline__ f29 other(const f29& s, int k) {
+  f29 r;
+  for (int i = 0; i < 9; i++) r.l[i] = (s.l[(i + k) % 9] * 2654435761u + k) & (i == 8 ? 0xfffffu : M29);
+  return r;
+}
+template <class P> __global__ void k_mul2(uint32_t* out, int iters) {   // x y + z w
   f29 x, y, z; seed(x, y, z);
-  for (int it = 0; it < iters; it++) x = f29_mul2<P>(x, y, z, x);
+  const f29 w = other(z, 3);
+  for (int it = 0; it < iters; it++) x = f29_mul2<P>(x, y, z, w);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+template <class P> __global__ void k_mul_add(uint32_t* out, int iters) {   // Horner: x = x y + z
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters; it++) x = f29_mul_add<P>(x, y, z);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+template <class P> __global__ void k_dot5(uint32_t* out, int iters) {      // iters / 5 dot products of five terms
+  f29 x, y, z; seed(x, y, z);
+  const f29 a1 = other(x, 1), a2 = other(y, 2), a3 = other(z, 3), a4 = other(x, 4);
+  const f29 b1 = other(y, 5), b2 = other(z, 6), b3 = other(x, 7), b4 = other(y, 8);
+  for (int it = 0; it < iters / 5; it++) {
+    const f29 a[5] = {x, a1, a2, a3, a4}, b[5] = {z, b1, b2, b3, b4};
+    x = f29_dot<P, 5>(a, b);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
+}
+template <class P> __global__ void k_red(uint32_t* out, int iters) {       // lazy sum, then the product-free reduction
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters; it++) x = f29_reduce_small<P>(f29_add(f29_add(x, y), z));
   out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
 }
 // two independent chains of products per lane (iters / 2 rounds: the same number of products)
@@ -84,6 +111,8 @@ int main() {
   const int cus = prop.multiProcessorCount;
   uint32_t* d_out;
   (void)hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4 * 2);
+  for (int i = 0; i < 200; i++) k_mul<Fq29><<<cus * 8, 256>>>(d_out, 512);   // clocks up before anything is timed
+  (void)hipDeviceSynchronize();
 #if defined(SG_F29_ROW_SCAN)
   printf("device  CUs %d   products: plain C++ (row scanning)\n", cus);
 #else
@@ -93,6 +122,9 @@ int main() {
   bench("f29_mul<Fr>", k_mul<Fr29>, d_out, cus);
   bench("f29_sqr<Fq>", k_sqr<Fq29>, d_out, cus);
   bench("f29_mul2<Fr>", k_mul2<Fr29>, d_out, cus);
+  bench("f29_mul_add<Fr>", k_mul_add<Fr29>, d_out, cus);
+  bench("f29_dot<Fr, 5> (per term)", k_dot5<Fr29>, d_out, cus);
+  bench("f29_reduce_small<Fr>", k_red<Fr29>, d_out, cus);
   bench("f29_mul<Fq> x 2", k_mul_x2<Fq29>, d_out, cus);
   bench("add, add, mul, mul <Fq>", k_mixed<Fq29>, d_out, cus);
   return 0;
