@@ -494,6 +494,18 @@ def gates_program_info(graph: GraphEvaluator, n_fixed: int, n_advice: int, n_ins
     return n_ops.value, n_slots.value
 
 
+def gates_program_words(graph: GraphEvaluator, n_fixed: int, n_advice: int, n_instance: int, n_challenges: int):
+    """the interpreter's lowering of a program as words: [n_slots, result_kind, result_index, n_ops, (w0, dst, a, b) per
+    instruction]; host only (tools/gen_gates_programs.py, tests)"""
+    g, keep = graph._struct()
+    need = C.c_uint32(0)
+    args = (C.byref(g), C.c_uint32(n_fixed), C.c_uint32(n_advice), C.c_uint32(n_instance), C.c_uint32(n_challenges))
+    ffi.check(ffi.lib().sg_gates_program_words(*args, None, C.c_uint32(0), C.byref(need)))
+    buf = (C.c_uint32 * need.value)()
+    ffi.check(ffi.lib().sg_gates_program_words(*args, buf, C.c_uint32(need.value), C.byref(need)))
+    return list(buf)
+
+
 def best_fft_batch(vectors, omega, log_n: int, divisor=None):
     """in-place best_fft (or ifft when `divisor` is given) of several device tensors of one size"""
     m = len(vectors)

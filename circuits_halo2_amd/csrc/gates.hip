@@ -119,6 +119,85 @@ __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
   f29_store_canonical<P>(a.values + row, f29_mul<P>(res, f29_const<P>(P::r256)));
 }
 
+// ---- the same, for a program known at compile time (gates_mst_programs.inc: the reference circuit's own gate programs as
+// lowered by compile_gates below; tools/gen_gates_programs.py).  Every instruction is a template instantiation: the
+// operands are registers (slot[] is indexed by constants only), there is no instruction fetch or decode and no LDS round
+// trip per instruction -- what remains of the interpreter's ~50 instructions of overhead per op is the constants' LDS
+// reads.  gates_run uses it when the program it is given is word for word one of the tables; SG_GATES_GENERIC=1 keeps
+// the interpreter (tests compare the two).
+#include "gates_mst_programs.inc"
+
+template <uint32_t KIND, uint32_t IDX, uint32_t NS>
+__device__ __forceinline__ f29 fixed_operand(const f29 (&slot)[NS], const uint32_t* s_const) {
+  if constexpr (KIND == GK_CONST) {
+    f29 r;
+#pragma unroll
+    for (int q = 0; q < 9; q++) r.l[q] = s_const[IDX * 9 + q];
+    return r;
+  } else {
+    return slot[IDX];
+  }
+}
+template <class PROG, uint32_t PC>
+__device__ __forceinline__ void fixed_step(f29 (&slot)[PROG::n_slots], const uint32_t* s_const, const GateArgs& a, size_t row,
+                                           size_t mask, uint32_t rot_shift) {
+  if constexpr (PC < PROG::n_ops) {
+    constexpr GateOp op = PROG::ops[PC];
+    constexpr uint32_t code = op.w0 & 0xff, kidx = (op.w0 >> 8) & 0xff, ak = (op.w0 >> 16) & 0xff, bk = op.w0 >> 24;
+    constexpr uint32_t dst = op.dst & 0xffff, ci = op.dst >> 16, NS = PROG::n_slots;
+    static_assert(dst < NS, "");
+    f29 r;
+    if constexpr (code == G_LOADCOL) {
+      const size_t i = (row & ~mask) | ((row + ((size_t)(int64_t)(int32_t)op.b << rot_shift)) & mask);
+      uint32_t w[8];
+      fp_words_load(a.cols[op.a] + i, w);
+      if constexpr (kidx != 0) r = f29_mul<P>(f29_from_words<0>(w), f29_const<P>(P::r266));
+      else r = f29_from_words<5>(w);
+    } else if constexpr (code == G_LOADPREV) {
+      uint32_t w[8];
+      fp_words_load(a.values + row, w);
+      r = f29_from_words<5>(w);
+    } else {
+      const f29 x = fixed_operand<ak, op.a, NS>(slot, s_const);
+      if constexpr (code == G_ADD) r = f29_add(x, fixed_operand<bk, op.b, NS>(slot, s_const));
+      else if constexpr (code == G_SUB) r = f29_sub<P, (kidx < 5 ? kidx : 5)>(x, fixed_operand<bk, op.b, NS>(slot, s_const));
+      else if constexpr (code == G_MUL) r = f29_mul<P>(x, fixed_operand<bk, op.b, NS>(slot, s_const));
+      else if constexpr (code == G_SQR) r = f29_sqr<P>(x);
+      else if constexpr (code == G_DBL) r = f29_add(x, x);
+      else if constexpr (code == G_NEG) r = f29_sub<P, (kidx < 5 ? kidx : 5)>(f29_zero(), x);
+      else if constexpr (code == G_MULADD)
+        r = f29_mul_add<P>(x, fixed_operand<bk, op.b, NS>(slot, s_const), fixed_operand<kidx, ci, NS>(slot, s_const));
+      else r = f29_reduce_small<P>(x);   // G_RED
+    }
+    slot[dst] = r;
+    fixed_step<PROG, PC + 1>(slot, s_const, a, row, mask, rot_shift);
+  }
+}
+template <class PROG>
+__global__ void __launch_bounds__(256) gates_fixed_kernel(GateArgs a) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* s_const = lds;                       // [n_consts][9]
+  for (uint32_t c = threadIdx.x; c < a.n_consts; c += blockDim.x) {
+    f29 v = f29_words_to_r261<P>(a.consts + 8 * c);
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_const[c * 9 + q] = v.l[q];
+  }
+  __syncthreads();
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.rows) return;
+  f29 slot[PROG::n_slots];
+#pragma unroll
+  for (uint32_t i = 0; i < PROG::n_slots; i++) slot[i] = f29_zero();
+  fixed_step<PROG, 0>(slot, s_const, a, row, (size_t)a.blockmask, a.ext_k - a.k);
+  const f29 res = fixed_operand<PROG::result_kind, PROG::result_index, PROG::n_slots>(slot, s_const);
+  f29_store_canonical<P>(a.values + row, f29_mul<P>(res, f29_const<P>(P::r256)));
+}
+template <class PROG>
+static bool is_program(const GateProgram& p) {
+  return p.ops.size() == PROG::n_ops && p.n_slots == PROG::n_slots && p.result_kind == PROG::result_kind &&
+         p.result_index == PROG::result_index && std::memcmp(p.ops.data(), PROG::ops, sizeof(GateOp) * PROG::n_ops) == 0;
+}
+
 // ------------------------------------------------------------------ host: compiler
 namespace {
 struct Val {         // a virtual value of the lowered program
@@ -493,6 +572,20 @@ hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_va
   const size_t n_ext = cosets ? (size_t)cosets << k : (size_t)1 << ext_k;
   a.rows = n_ext;
   a.blockmask = ((uint64_t)1 << a.ext_k) - 1;
+  if (!std::getenv("SG_GATES_GENERIC")) {   // a program known ahead of time: the straight-line kernel
+    const unsigned blocks = (unsigned)((n_ext + 255) / 256);
+    const size_t lds = (size_t)a.n_consts * 36;
+    const bool nc2 = is_program<MstGatesNc2>(p), nc1 = !nc2 && is_program<MstGatesNc1>(p);
+    if ((nc1 || nc2) && std::getenv("SG_GATES_DEBUG")) std::fprintf(stderr, "gates: ahead-of-time program MstGatesNc%d, %u blocks\n", nc2 ? 2 : 1, blocks);
+    if (nc2) {
+      gates_fixed_kernel<MstGatesNc2><<<blocks, 256, lds, stream>>>(a);
+      return hipGetLastError();
+    }
+    if (nc1) {
+      gates_fixed_kernel<MstGatesNc1><<<blocks, 256, lds, stream>>>(a);
+      return hipGetLastError();
+    }
+  }
   // rows per workgroup from the LDS budget: (constants + slots * T) * 36 B <= 144 KiB
   const size_t budget = 144 * 1024, cbytes = (size_t)a.n_consts * 36;
   // rows per workgroup: what limits the interpreter is waves per SIMD, i.e. LDS per row (the slot count).  Take the shape

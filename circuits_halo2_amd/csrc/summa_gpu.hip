@@ -1912,6 +1912,24 @@ int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_ad
   return SG_OK;
 }
 
+// the lowered program itself, for tooling (tools/gen_gates_programs.py writes the ahead-of-time instantiations of the reference
+// circuit's programs from it) and tests: words_out = [n_slots, result_kind, result_index, n_ops, then (w0, dst, a, b) per
+// instruction].  *n_words_out is the size needed; nothing is written beyond cap_words.  Host only.
+int sg_gates_program_words(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
+                           uint32_t* words_out, uint32_t cap_words, uint32_t* n_words_out) {
+  if (!graph || !n_words_out || (cap_words && !words_out)) return fail(SG_ERR_INVALID, "sg_gates_program_words: null argument");
+  std::vector<uint8_t> zeros(32 * (size_t)std::max<uint32_t>(1, n_challenges), 0);
+  GateProgram prog;
+  const std::string err = compile_gates(*graph, n_fixed, n_advice, n_instance, zeros.data(), n_challenges, zeros.data(), zeros.data(),
+                                        zeros.data(), zeros.data(), &prog);
+  if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_gates_program_words: " + err).c_str());
+  std::vector<uint32_t> w = {prog.n_slots, prog.result_kind, prog.result_index, (uint32_t)prog.ops.size()};
+  for (const GateOp& o : prog.ops) { w.push_back(o.w0); w.push_back(o.dst); w.push_back(o.a); w.push_back(o.b); }
+  *n_words_out = (uint32_t)w.size();
+  if (cap_words >= w.size()) std::memcpy(words_out, w.data(), 4 * w.size());
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------ keygen's circuit side
 // What `keygen_vk` / `keygen_pk` need of `MstInclusionCircuit::synthesize` over 2^k rows [REF zk_prover/src/circuits/
 // merkle_sum_tree.rs:228-520 replayed over halo2's SimpleFloorPlanner: include/summa_circuit.hpp]: the 11 fixed columns (round

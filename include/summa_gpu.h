@@ -349,6 +349,10 @@ int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const vo
  * occupancy of the kernel is set by the latter).  Host only -- no device needed. */
 int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
                           uint32_t* n_ops_out, uint32_t* n_slots_out);
+/* the lowered program itself (tooling, tests): words_out = [n_slots, result_kind, result_index, n_ops, then 4 words per
+ * instruction]; *n_words_out = the size needed, nothing is written when cap_words is smaller.  Host only. */
+int sg_gates_program_words(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
+                           uint32_t* words_out, uint32_t cap_words, uint32_t* n_words_out);
 
 /* ---- keygen's circuit side: what keygen_vk / keygen_pk need of MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>::synthesize over
  * 2^k rows in the reference's own floor plan (include/summa_circuit.hpp): fixed_out = 11 columns x 2^k x 32 B, sigma_out = 6

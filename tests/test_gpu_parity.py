@@ -827,6 +827,47 @@ def test_quad_cooperative_add_selftest(gpu):
     assert "mismatching lanes: 0 of" in out.stdout
 
 
+@pytest.mark.parametrize("nc", [1, 2])
+def test_ahead_of_time_gate_program_equals_the_interpreter(gpu, capfd, nc):
+    """the reference circuit's gate programs are also compiled ahead of time (gates_mst_programs.inc: every instruction a
+    template instantiation, values in registers); sg_quotient_gates* picks that kernel when the program it is given lowers
+    to exactly the table.  Same rows as the interpreter (SG_GATES_GENERIC=1), on the extended domain and on cosets, and the
+    ahead-of-time kernel is the one that ran"""
+    import os
+    import torch
+    from circuits_halo2_amd import arithmetic as A, mst_inclusion as M
+    from circuits_halo2_amd.utils import random_fr_canonical
+    k, ext_k, d = 7, 10, 5
+    graph = M.gate_graph(nc)
+    chal = M.gate_challenges(0x1234567 + nc, nc)
+    b = np.frombuffer(bytes(range(1, 33)), dtype=np.uint8).copy(); b[31] = 0
+    for rows, kw in ((1 << ext_k, None), (d << k, d)):
+        col = lambda s: A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(s, rows)).cuda())
+        fixed = [col(100 + i) for i in range(M.NUM_FIXED)]
+        advice = [col(200 + i) for i in range(M.NUM_ADVICE)]
+        start = col(300)
+        outs = []
+        for generic in (False, True):
+            if generic:
+                os.environ["SG_GATES_GENERIC"] = "1"
+            os.environ["SG_GATES_DEBUG"] = "1"
+            try:
+                v = start.clone()
+                if kw is None:
+                    A.quotient_gates(v, graph, fixed, advice, [], chal, b, b, b, b, k, ext_k)
+                else:
+                    A.quotient_gates_cosets(v, graph, fixed, advice, [], chal, b, b, b, b, k, kw)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("SG_GATES_GENERIC", None)
+                os.environ.pop("SG_GATES_DEBUG", None)
+            err = capfd.readouterr().err
+            assert ("ahead-of-time program MstGatesNc%d" % nc in err) == (not generic), err
+            outs.append(v)
+        assert (outs[0] == outs[1]).all()
+        assert not (outs[0] == start).all()
+
+
 def test_field_products_device_selftest(gpu):
     """the device spelling of the field products (column chains of v_mad_u64_u32 in inline asm: f29_mul, f29_sqr,
     f29_mul2, f29_mul_add, f29_dot<2..5>) against the plain C++ definition on the host, limb for limb: random

@@ -261,3 +261,15 @@ def test_library_keygen_columns_equal_the_python_floor_plan(k, levels, nc):
         assert (s[j] == ints_to_fr(asg["sigma"][j])).all(), j
     assert L.sg_mst_inclusion_keygen_columns(C.c_uint32(3), C.c_uint32(levels), C.c_uint32(nc), C.c_uint32(8), ffi.ptr(f), ffi.ptr(s), None) != 0
     assert L.sg_mst_inclusion_keygen_columns(C.c_uint32(8), C.c_uint32(20), C.c_uint32(2), C.c_uint32(8), ffi.ptr(f), ffi.ptr(s), None) != 0   # rows
+
+
+def test_ahead_of_time_gate_tables_are_current():
+    """circuits_halo2_amd/csrc/gates_mst_programs.inc (the reference circuit's gate programs as compile-time tables) is what
+    tools/gen_gates_programs.py makes of the CURRENT lowering: a change to compile_gates or to the gate program needs the tables
+    regenerated (and the library rebuilt), otherwise the ahead-of-time kernels are silently not used any more"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gates_programs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "gates_mst_programs.inc is stale: run tools/gen_gates_programs.py and rebuild\n" + r.stdout + r.stderr

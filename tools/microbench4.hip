@@ -63,6 +63,78 @@ template <class P> __global__ void k_red(uint32_t* out, int iters) {       // la
   for (int it = 0; it < iters; it++) x = f29_reduce_small<P>(f29_add(f29_add(x, y), z));
   out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
 }
+#if !defined(SG_F29_ROW_SCAN)
+// ---- experiment: TWO independent products as chains that alternate instruction by instruction inside one asm block (the
+// second chain fills the first one's dependency gaps within the wave instead of leaving that to the other waves)
+#define DT(i) "v_mad_u64_u32 %[t], vcc, %[x" #i "], %[y" #i "], %[t]\nv_mad_u64_u32 %[u], vcc, %[p" #i "], %[q" #i "], %[u]\n"
+#define DV(i) [x##i] "v"(x[i]), [y##i] "v"(y[i]), [p##i] "v"(pp[i]), [q##i] "v"(q[i])
+#define DS(i) [x##i] "v"(x[i]), [y##i] "s"(y[i]), [p##i] "v"(pp[i]), [q##i] "s"(y[i])
+template <int N>
+__device__ __forceinline__ void dual_vv(uint64_t& t, uint64_t& u, const uint32_t* x, const uint32_t* y, const uint32_t* pp, const uint32_t* q) {
+  if constexpr (N == 1) asm(DT(0) : [t] "+v"(t), [u] "+v"(u) : DV(0) : "vcc");
+  if constexpr (N == 2) asm(DT(0) DT(1) : [t] "+v"(t), [u] "+v"(u) : DV(0), DV(1) : "vcc");
+  if constexpr (N == 3) asm(DT(0) DT(1) DT(2) : [t] "+v"(t), [u] "+v"(u) : DV(0), DV(1), DV(2) : "vcc");
+  if constexpr (N == 4) asm(DT(0) DT(1) DT(2) DT(3) : [t] "+v"(t), [u] "+v"(u) : DV(0), DV(1), DV(2), DV(3) : "vcc");
+  if constexpr (N > 4) { dual_vv<4>(t, u, x, y, pp, q); dual_vv<N - 4>(t, u, x + 4, y + 4, pp + 4, q + 4); }
+}
+#define DTS(i) "v_mad_u64_u32 %[t], vcc, %[x" #i "], %[y" #i "], %[t]\nv_mad_u64_u32 %[u], vcc, %[p" #i "], %[y" #i "], %[u]\n"
+#define DSS(i) [x##i] "v"(x[i]), [y##i] "s"(y[i]), [p##i] "v"(pp[i])
+template <int N>
+__device__ __forceinline__ void dual_vs(uint64_t& t, uint64_t& u, const uint32_t* x, const uint32_t* pp, const uint32_t* y) {
+  if constexpr (N == 1) asm(DTS(0) : [t] "+v"(t), [u] "+v"(u) : DSS(0) : "vcc");
+  if constexpr (N == 2) asm(DTS(0) DTS(1) : [t] "+v"(t), [u] "+v"(u) : DSS(0), DSS(1) : "vcc");
+  if constexpr (N == 3) asm(DTS(0) DTS(1) DTS(2) : [t] "+v"(t), [u] "+v"(u) : DSS(0), DSS(1), DSS(2) : "vcc");
+  if constexpr (N == 4) asm(DTS(0) DTS(1) DTS(2) DTS(3) : [t] "+v"(t), [u] "+v"(u) : DSS(0), DSS(1), DSS(2), DSS(3) : "vcc");
+  if constexpr (N > 4) { dual_vs<4>(t, u, x, pp, y); dual_vs<N - 4>(t, u, x + 4, pp + 4, y + 4); }
+}
+template <class P, int K>
+__device__ __forceinline__ void pair_columns(uint64_t& t, uint64_t& u, uint32_t (&m)[9], uint32_t (&n)[9], f29& r, f29& s,
+                                             const f29& a, const f29& b, const f29& c, const f29& d) {
+  {
+    constexpr int LO = K < 9 ? 0 : K - 8, N = (K < 9 ? K : 8) - LO + 1;
+    uint32_t x[N], y[N], pp[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { x[i] = a.l[LO + i]; y[i] = b.l[K - LO - i]; pp[i] = c.l[LO + i]; q[i] = d.l[K - LO - i]; }
+    dual_vv<N>(t, u, x, y, pp, q);
+  }
+  {
+    constexpr int LO = K < 9 ? 0 : K - 8, HI = K < 9 ? K - 1 : 8, N = HI - LO + 1;
+    if constexpr (N >= 1) {
+      uint32_t x[N], pp[N], y[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) { x[i] = m[LO + i]; pp[i] = n[LO + i]; y[i] = P::p[K - LO - i]; }
+      dual_vs<N>(t, u, x, pp, y);
+    }
+  }
+  if constexpr (K < 9) {
+    m[K] = ((uint32_t)t * P::inv) & M29;
+    n[K] = ((uint32_t)u * P::inv) & M29;
+    t += (uint64_t)m[K] * P::p[0];
+    u += (uint64_t)n[K] * P::p[0];
+    t >>= 29;
+    u >>= 29;
+  } else {
+    r.l[K - 9] = (uint32_t)t & M29;
+    s.l[K - 9] = (uint32_t)u & M29;
+    t >>= 29;
+    u >>= 29;
+  }
+  if constexpr (K < 16) pair_columns<P, K + 1>(t, u, m, n, r, s, a, b, c, d);
+}
+template <class P>
+__device__ __forceinline__ void f29_mul_pair(const f29& a, const f29& b, const f29& c, const f29& d, f29& r, f29& s) {
+  uint32_t m[9], n[9];
+  uint64_t t = 0, u = 0;
+  pair_columns<P, 0>(t, u, m, n, r, s, a, b, c, d);
+  r.l[8] = (uint32_t)t;
+  s.l[8] = (uint32_t)u;
+}
+template <class P> __global__ void k_mul_pair(uint32_t* out, int iters) {
+  f29 x, y, z; seed(x, y, z);
+  for (int it = 0; it < iters / 2; it++) { f29 r, s; f29_mul_pair<P>(x, y, z, y, r, s); x = r; z = s; }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x) ^ (fold(z) * 7);
+}
+#endif
 // two independent chains of products per lane (iters / 2 rounds: the same number of products)
 template <class P> __global__ void k_mul_x2(uint32_t* out, int iters) {
   f29 x, y, z; seed(x, y, z);
@@ -127,5 +199,8 @@ int main() {
   bench("f29_reduce_small<Fr>", k_red<Fr29>, d_out, cus);
   bench("f29_mul<Fq> x 2", k_mul_x2<Fq29>, d_out, cus);
   bench("add, add, mul, mul <Fq>", k_mixed<Fq29>, d_out, cus);
+#if !defined(SG_F29_ROW_SCAN)
+  bench("f29_mul<Fq> x 2, one block", k_mul_pair<Fq29>, d_out, cus);   // same checksum as "f29_mul<Fq> x 2"
+#endif
   return 0;
 }
