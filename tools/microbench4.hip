@@ -37,10 +37,14 @@ __device__ __forceinline__ f29 other(const f29& s, int k) {
   for (int i = 0; i < 9; i++) r.l[i] = (s.l[(i + k) % 9] * 2654435761u + k) & (i == 8 ? 0xfffffu : M29);
   return r;
 }
+// (every operand changes from one iteration to the next: the plain C++ form hoists a product of two loop invariants)
 template <class P> __global__ void k_mul2(uint32_t* out, int iters) {   // x y + z w
   f29 x, y, z; seed(x, y, z);
-  const f29 w = other(z, 3);
-  for (int it = 0; it < iters; it++) x = f29_mul2<P>(x, y, z, w);
+  f29 w = other(z, 3);
+  for (int it = 0; it < iters; it++) {
+    const f29 t = f29_mul2<P>(x, y, z, w);
+    w = z; z = y; y = x; x = t;
+  }
   out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
 }
 template <class P> __global__ void k_mul_add(uint32_t* out, int iters) {   // Horner: x = x y + z
@@ -50,11 +54,12 @@ template <class P> __global__ void k_mul_add(uint32_t* out, int iters) {   // Ho
 }
 template <class P> __global__ void k_dot5(uint32_t* out, int iters) {      // iters / 5 dot products of five terms
   f29 x, y, z; seed(x, y, z);
-  const f29 a1 = other(x, 1), a2 = other(y, 2), a3 = other(z, 3), a4 = other(x, 4);
-  const f29 b1 = other(y, 5), b2 = other(z, 6), b3 = other(x, 7), b4 = other(y, 8);
+  f29 a[5] = {x, other(x, 1), other(y, 2), other(z, 3), other(x, 4)}, b[5] = {z, other(y, 5), other(z, 6), other(x, 7), other(y, 8)};
   for (int it = 0; it < iters / 5; it++) {
-    const f29 a[5] = {x, a1, a2, a3, a4}, b[5] = {z, b1, b2, b3, b4};
-    x = f29_dot<P, 5>(a, b);
+    const f29 t = f29_dot<P, 5>(a, b);
+    b[4] = b[3]; b[3] = b[2]; b[2] = b[1]; b[1] = b[0]; b[0] = a[4];
+    a[4] = a[3]; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t;
+    x = t;
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = fold(x);
 }
