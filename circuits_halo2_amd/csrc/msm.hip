@@ -1454,7 +1454,7 @@ hipError_t MsmEngine::enqueue_back() {
     const uint32_t nt2 = std::min(NB, items_ub) + (items_ub >> log_L);
     items_ub = nt2;
     SG_TRY(partial_[1 - pbuf].reserve(nt2));
-    if (quad)
+    if (quad && nt2 <= cfg_.merge_quad_tasks)
       msm_merge<4><<<(nt2 + 63) / 64, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, toff_[nxt].p, NB, log_L, meta_.p,
                                                         partial_[1 - pbuf].p);
     else
