@@ -124,12 +124,17 @@ SG_HD void xyzz29_madd(xyzz29& acc, const affine29& q) {
   f29 ppp = f29_mul<P>(p, pp);                                 // 20
   f29 qq = f29_mul<P>(acc.x, pp);                              // 16
   f29 rr = f29_sqr<P>(r);                                      // 36
-  f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // (<4) - (<4) + 4p => < 8
-  f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
+  // x3 = rr - ppp - 2 qq: (<4) - (<4) + 4p => < 8.  rr, ppp, qq come out of products (limbs < 2^29 exactly), so the two
+  // differences and the doubling share ONE carry step: limbs stay in [2^29, 2^29 + 2^30.6 + 2^30.5) < 2^32 on the way, and the
+  // value stays above p (ppp and qq are products of bounds <= 20: below 1.12 p each), so the carried top limb is the true one
+  f29 x3 = f29_carry(f29_sub_nc<P, 1>(f29_sub_nc<P, 0>(rr, ppp), f29_add_nc(qq, qq)));
+  // t = qq + 8p - x3 (< 10; above 0.75 p because x3 < rr + 6p < 7.25 p) goes straight into the product t r as its first operand:
+  // limbs < 2^29 + 2^30.5, only the top limb carried
+  f29 t = f29_carry_top(f29_sub_nc<P, 2>(qq, x3));
 #if SG_FUSED_Y3
-  f29 y3 = f29_mul2<P>(r, t, f29_sub<P, 1>(f29_zero(), acc.y), ppp);  // r t + (4p - Y1) ppp: 60 + 8 -> < 2
+  f29 y3 = f29_mul2<P>(t, r, f29_sub<P, 1>(f29_zero(), acc.y), ppp);  // t r + (4p - Y1) ppp: 60 + 8 -> < 2
 #else
-  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(acc.y, ppp));   // 60, 8 => < 4
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(t, r), f29_mul<P>(acc.y, ppp));   // 60, 8 => < 4
 #endif
   acc.zz = f29_mul<P>(acc.zz, pp);                             // 4
   acc.zzz = f29_mul<P>(acc.zzz, ppp);                          // 4
@@ -160,12 +165,13 @@ SG_HD void xyzz29_add(xyzz29& acc, const xyzz29& q) {
   f29 ppp = f29_mul<P>(p, pp);                                 // 8
   f29 qq = f29_mul<P>(u1, pp);                                 // 4
   f29 rr = f29_sqr<P>(r);                                      // 16
-  f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq)); // < 8
-  f29 t = f29_sub<P, 2>(qq, x3);                               // < 10
+  // one carry step for rr - ppp - 2 qq (< 8), none but the top limb's for t = qq - x3 (< 10): see xyzz29_madd
+  f29 x3 = f29_carry(f29_sub_nc<P, 1>(f29_sub_nc<P, 0>(rr, ppp), f29_add_nc(qq, qq)));
+  f29 t = f29_carry_top(f29_sub_nc<P, 2>(qq, x3));
 #if SG_FUSED_Y3
-  f29 y3 = f29_mul2<P>(r, t, f29_sub<P, 0>(f29_zero(), s1), ppp);  // r t + (2p - S1) ppp: 40 + 4 -> < 2
+  f29 y3 = f29_mul2<P>(t, r, f29_sub<P, 0>(f29_zero(), s1), ppp);  // t r + (2p - S1) ppp: 40 + 4 -> < 2
 #else
-  f29 y3 = f29_sub<P, 0>(f29_mul<P>(r, t), f29_mul<P>(s1, ppp));   // 40, 4 => < 4
+  f29 y3 = f29_sub<P, 0>(f29_mul<P>(t, r), f29_mul<P>(s1, ppp));   // 40, 4 => < 4
 #endif
   acc.zz = f29_mul<P>(f29_mul<P>(acc.zz, q.zz), pp);           // 4, 4
   acc.zzz = f29_mul<P>(f29_mul<P>(acc.zzz, q.zzz), ppp);       // 4, 4
@@ -326,10 +332,10 @@ __device__ __forceinline__ void xyzz29_add_quad(xyzz29& acc, const xyzz29& q, ui
   // round 3: PPP = P PP | Q = U1 PP | ZZ3 = ZZ12 PP | V = ZZZ12 P      (lanes 2, 3 reuse their own m)
   m = f29_mul<P>(quad_sel(role, p, u1, m, m), quad_sel(role, pp, pp, pp, p));                  // 8, 4, 4, 8
   const f29 ppp = quad_bcast<0>(m), qq = quad_bcast<1>(m), zz3 = quad_bcast<2>(m);
-  const f29 x3 = f29_sub<P, 1>(f29_sub<P, 0>(rr, ppp), f29_dbl(qq));                           // < 8
-  const f29 t = f29_sub<P, 2>(qq, x3);                                                         // < 10
-  // round 4: R T | S1 PPP | (idle: repeats lane 1) | ZZZ3 = V PP
-  m = f29_mul<P>(quad_sel(role, r, s1, s1, m), quad_sel(role, t, ppp, ppp, pp));               // 40, 4, 4, 4
+  const f29 x3 = f29_carry(f29_sub_nc<P, 1>(f29_sub_nc<P, 0>(rr, ppp), f29_add_nc(qq, qq)));   // < 8, one carry step (xyzz29_madd)
+  const f29 t = f29_carry_top(f29_sub_nc<P, 2>(qq, x3));                                       // < 10, a product's first operand
+  // round 4: T R | S1 PPP | (idle: repeats lane 1) | ZZZ3 = V PP
+  m = f29_mul<P>(quad_sel(role, t, s1, s1, m), quad_sel(role, r, ppp, ppp, pp));               // 40, 4, 4, 4
   acc.y = f29_sub<P, 0>(quad_bcast<0>(m), quad_bcast<1>(m));                                   // < 4
   acc.zzz = quad_bcast<3>(m);
   acc.zz = zz3;

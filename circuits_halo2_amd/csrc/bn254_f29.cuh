@@ -170,6 +170,34 @@ SG_HD f29 f29_sub(const f29& a, const f29& b) {
   return f29_carry(r);
 }
 SG_HD f29 f29_dbl(const f29& a) { return f29_add(a, a); }
+// ---- the same sums WITHOUT their carry step, for chains of sums that end in ONE carry step and for values that go straight
+// into a product as its FIRST operand.  Limbs are plain 32-bit sums here: every limb of an intermediate must stay below 2^32
+// and, limb by limb, non-negative (the constants of f29_sub_nc have their limbs 0..7 raised by 2^30, so a subtrahend with
+// limbs < 2^30 is fine: a normalised value, or the double of an exactly normalised one); the TOP limb may wrap below zero
+// (it is short by the two units the limb below borrowed) until a carry step or f29_carry_top has added them back.
+// f29_mul(a, b) takes an `a` with limbs up to 2^31 when b is exactly normalised (nine products of < 2^60 and nine of < 2^58
+// per column) -- but its top limb must be the true one: f29_carry_top.
+SG_HD f29 f29_add_nc(const f29& a, const f29& b) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <class P, int KIDX>
+SG_HD f29 f29_sub_nc(const f29& a, const f29& b) {
+  f29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P::subc[KIDX][i] - b.l[i];
+  return r;
+}
+// the carry of limb 7 into the top limb only (3 instructions instead of 24): the top limb is then what a full carry step
+// would leave, limbs 0..6 stay as they are
+SG_HD f29 f29_carry_top(const f29& a) {
+  f29 r = a;
+  r.l[8] = a.l[8] + (a.l[7] >> 29);
+  r.l[7] = a.l[7] & M29;
+  return r;
+}
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SG_F29_ROW_SCAN)
 // ---- device: column scanning, one chain of v_mad_u64_u32 per column ------------------------------------------------

@@ -15,6 +15,8 @@ template <class P> void run(const std::string& op, const f29& a, const f29& b) {
   else if (op == "muladd") r = f29_mul_add<P>(a, b, b);        // a b 2^-261 + b
   else if (op == "dot3") { const f29 x[3] = {a, b, a}, y[3] = {b, b, a}; r = f29_dot<P, 3>(x, y); }   // (ab + bb + aa) 2^-261
   else if (op == "dot5") { const f29 x[5] = {a, b, a, a, b}, y[5] = {b, b, a, b, a}; r = f29_dot<P, 5>(x, y); }   // (3ab + bb + aa) 2^-261
+  else if (op == "x3nc") r = f29_carry(f29_sub_nc<P, 1>(f29_sub_nc<P, 0>(a, b), f29_add_nc(b, b)));   // a + 2p - b + 4p - 2b, one carry step
+  else if (op == "tnc") r = f29_carry_top(f29_sub_nc<P, 2>(a, b));                                    // a + 8p - b, top limb carried only
   else if (op == "add") r = f29_add(a, b);
   else if (op == "sub2") r = f29_sub<P, 0>(a, b);
   else if (op == "sub8") r = f29_sub<P, 2>(a, b);

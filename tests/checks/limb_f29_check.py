@@ -45,6 +45,13 @@ for fld, p in (("q", P.Q), ("r", P.R)):
             cases.append(("dot3", fld, limbs(a), limbs(b), ("dot", p, a * b + b * b + a * a)))
         if 3 * ba * bb + bb * bb + ba * ba <= 170:
             cases.append(("dot5", fld, limbs(a), limbs(b), ("dot", p, 3 * a * b + b * b + a * a)))
+        # the lazily carried sums of the point additions: operands as products leave them (exactly normalised; rr < 2p; ppp and qq are
+        # products of bounds <= 20, i.e. below (20 / 170.7 + 1) p < 9p/8 -- what keeps rr + 6p - ppp - 2qq above p and its top limb true)
+        pa = rnd.choice([0, 1, p - 1, p, 2 * p - 1]) if rnd.random() < 0.3 else rnd.randrange(2 * p)
+        pb = rnd.choice([0, 1, p - 1, p, 9 * p // 8 - 1]) if rnd.random() < 0.3 else rnd.randrange(9 * p // 8)
+        cases.append(("x3nc", fld, limbs(pa), limbs(pb), ("x3nc", p, pa, pb)))
+        x8 = rnd.choice([0, 29 * p // 4 - 1, p]) if rnd.random() < 0.2 else rnd.randrange(29 * p // 4)   # x3 < rr + 6p < 7.25 p
+        cases.append(("tnc", fld, limbs(pa), lazy_limbs(x8, rnd), ("tnc", p, pa, x8)))
         a8, b8 = rnd.randrange(8 * p), rnd.randrange(8 * p)
         cases.append(("sub8", fld, limbs(a8), limbs(b8), ("sub", p, a8, b8, 8)))
         b2 = rnd.randrange(2 * p)
@@ -88,6 +95,12 @@ for (op, f, a, b, exp), line in zip(cases, out):
         _, p, sxy = exp
         v = val(l)
         ok = v % p == (sxy * pow(1 << 261, -1, p)) % p and v < 2 * p and all(t < (1 << 29) for t in l[:8])
+    elif exp[0] == "x3nc":   # the exact integer, limbs 0..7 below 2^29 + 8 after the one carry step, top limb the true one
+        _, p, x, y = exp
+        ok = val(l) == x + 6 * p - 3 * y and all(t < (1 << 29) + 8 for t in l[:8]) and l[8] < (1 << 31)
+    elif exp[0] == "tnc":    # the exact integer; limbs 0..6 uncarried but below 2^31, limb 7 below 2^29, top limb the true one
+        _, p, x, y = exp
+        ok = val(l) == x + 8 * p - y and all(t < (1 << 31) for t in l[:7]) and l[7] < (1 << 29) and l[8] < (1 << 31)
     elif exp[0] == "add":
         _, p, x, y = exp
         ok = val(l) == x + y and all(t < (1 << 29) + 4 for t in l[:8])
