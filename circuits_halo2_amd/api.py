@@ -214,8 +214,11 @@ def synthesize_on_device(pk, tree, user_indices):
         raise ValueError("the proving key was generated for a circuit of other dimensions")
     cached = getattr(pk, "_witness_program", None)
     if cached is None:
-        prog, n_items, n_absorbs, _, rows_used = M.witness_program(pk.k, levels, nc, nb)
-        cached = pk._witness_program = (torch.from_numpy(prog.view(np.int32).copy()).cuda(), n_items, n_absorbs)
+        with getattr(pk, "_lock", P._KEY_LOCK):      # proofs in flight start together on a fresh key: built once
+            cached = getattr(pk, "_witness_program", None)
+            if cached is None:
+                prog, n_items, n_absorbs, _, rows_used = M.witness_program(pk.k, levels, nc, nb)
+                cached = pk._witness_program = (torch.from_numpy(prog.view(np.int32).copy()).cuda(), n_items, n_absorbs)
     d_prog, n_items, n_absorbs = cached
     idx = torch.tensor([int(i) for i in user_indices], dtype=torch.int32, device="cuda")
     advice = torch.empty((len(user_indices), 3, 32 * pk.n), dtype=torch.uint8, device="cuda")

@@ -7,7 +7,8 @@ batch (BASELINE configs[4]; SURVEY.md §8e level 1, "proof-level"):
 * one process per GPU (`torch.distributed`; backend nccl = RCCL on the GPUs, gloo in the CPU tests);
 * the setup artifacts exist once: rank 0 loads / generates the SRS and the proving key's Lagrange columns and
   broadcasts them (`broadcast_setup`: one `dist.broadcast` per buffer -- 2 * 64 * 2^k bytes of SRS, 17 * 32 * 2^k
-  bytes of key columns); every rank derives the key's coefficient / extended forms on its own device;
+  bytes of key columns; with nccl from device tensors into device tensors, no host copy on either side); every rank
+  derives the key's coefficient / extended forms on its own device;
 * users are dealt round-robin to ranks (`deal`): proofs are independent, so there is no data-path collective at
   all -- the only other communication is the optional gather of the finished proofs (`gather_proofs`, host bytes);
 * per GPU several proofs are in flight: worker threads, each on its own HIP stream, so that one proof's host work
@@ -48,67 +49,93 @@ def owner_of(position: int, world: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def _bcast_bytes(buf: np.ndarray | None, src: int, device: str) -> np.ndarray:
-    """broadcast a uint8 buffer whose length the other ranks do not know yet"""
+_HEAD_BYTES = 64 + 128 + 128 + 32      # 8 x int64 (k, levels, nc, nb, #fixed, #sigma) | g2 | s_g2 | vk digest (little-endian)
+
+
+def _as_bytes_tensor(buf, device: str):
+    """a uint8 tensor on `device` holding `buf` (numpy / bytes / torch tensor); a tensor already there is used as it is"""
     import torch
-    d = _dist()
-    size = torch.tensor([0 if buf is None else int(buf.size)], dtype=torch.int64, device=device)
-    d.broadcast(size, src)
-    t = torch.from_numpy(np.array(buf, dtype=np.uint8, copy=True)).to(device) if buf is not None else \
-        torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-    if int(size.item()):
-        d.broadcast(t, src)
-    return t.cpu().numpy()
+    if isinstance(buf, torch.Tensor):
+        t = buf.reshape(-1).view(torch.uint8) if buf.dtype != torch.uint8 else buf.reshape(-1)
+        return t if t.device.type == device else t.to(device)
+    return torch.from_numpy(np.array(np.frombuffer(bytes(buf), dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf,
+                                     dtype=np.uint8, copy=True).reshape(-1)).to(device)
 
 
 def broadcast_setup(setup, src: int = 0):
-    """`setup`: on rank `src` a dict {k, shape (levels, n_currencies, n_bytes), g, g_lagrange, g2, s_g2 (bytes),
-    fixed [11], sigma [6] (Lagrange columns as uint8 buffers), vk_digest}; None elsewhere.  Returns the same dict on
-    every rank.  One broadcast per buffer; with the nccl backend the buffers travel GPU to GPU over xGMI."""
+    """`setup`: on rank `src` a dict {k, shape (levels, n_currencies, n_bytes), g, g_lagrange (2^k x 64 B), g2, s_g2 (128 B),
+    fixed [11], sigma [6] (Lagrange columns, 2^k x 32 B), vk_digest}; None elsewhere.  Returns the same dict on every rank.
+    One small header broadcast, then one `dist.broadcast` per buffer (their sizes follow from k).
+
+    With the nccl backend the buffers are DEVICE tensors on both sides and stay there: rank `src` sends straight from the
+    tensors its proving key keeps (`export_setup(..., on_device=True)`), the other ranks receive into the tensors theirs
+    will keep (`import_setup` hands them to the library device to device) -- the artifacts travel GPU to GPU over xGMI
+    and never visit a host.  With gloo (CPU tests, rehearsals) they are host arrays."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return setup
     import torch
-    device = "cuda" if d.get_backend() == "nccl" else "cpu"
+    on_device = d.get_backend() == "nccl"
+    device = "cuda" if on_device else "cpu"
     rank = d.get_rank()
-    head = torch.zeros(8, dtype=torch.int64, device=device)
+    head = torch.zeros(_HEAD_BYTES, dtype=torch.uint8, device="cpu")
     if rank == src:
         levels, nc, nb = setup["shape"]
-        head[:6] = torch.tensor([setup["k"], levels, nc, nb, len(setup["fixed"]), len(setup["sigma"])], dtype=torch.int64)
+        ints = np.array([setup["k"], levels, nc, nb, len(setup["fixed"]), len(setup["sigma"]), 0, 0], dtype="<i8")
+        raw = ints.tobytes() + bytes(setup["g2"]).ljust(128, b"\0")[:128] + bytes(setup["s_g2"]).ljust(128, b"\0")[:128] + \
+            int(setup["vk_digest"]).to_bytes(32, "little")
+        head = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy())
+    head = head.to(device)
     d.broadcast(head, src)
-    k, levels, nc, nb, n_fixed, n_sigma = (int(v) for v in head[:6].tolist())
+    raw = bytes(head.cpu().numpy())
+    k, levels, nc, nb, n_fixed, n_sigma = (int(v) for v in np.frombuffer(raw[:48], dtype="<i8"))
+    out = {"k": k, "shape": (levels, nc, nb), "g2": raw[64:192], "s_g2": raw[192:320],
+           "vk_digest": int.from_bytes(raw[320:352], "little")}
+
+    def one(buf, nbytes):
+        if rank == src:
+            t = _as_bytes_tensor(buf, device)
+            if t.numel() != nbytes:
+                raise ValueError("broadcast_setup: a buffer's size does not follow from k")
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        d.broadcast(t, src)
+        return t if on_device else t.numpy()
+
     mine = setup if rank == src else None
-    pick = lambda name: np.frombuffer(bytes(mine[name]), dtype=np.uint8) if mine is not None else None
-    out = {"k": k, "shape": (levels, nc, nb)}
-    for name in ("g", "g_lagrange", "g2", "s_g2"):
-        out[name] = _bcast_bytes(pick(name), src, device)
-    out["fixed"] = [_bcast_bytes(np.asarray(mine["fixed"][j], dtype=np.uint8) if mine is not None else None, src, device)
-                    for j in range(n_fixed)]
-    out["sigma"] = [_bcast_bytes(np.asarray(mine["sigma"][j], dtype=np.uint8) if mine is not None else None, src, device)
-                    for j in range(n_sigma)]
-    digest = _bcast_bytes(np.frombuffer(int(mine["vk_digest"]).to_bytes(32, "little"), dtype=np.uint8) if mine is not None else None,
-                          src, device)
-    out["vk_digest"] = int.from_bytes(bytes(digest), "little")
+    for name in ("g", "g_lagrange"):
+        out[name] = one(mine[name] if mine else None, 64 << k)
+    out["fixed"] = [one(mine["fixed"][j] if mine else None, 32 << k) for j in range(n_fixed)]
+    out["sigma"] = [one(mine["sigma"][j] if mine else None, 32 << k) for j in range(n_sigma)]
     return out
 
 
-def export_setup(params, pk) -> dict:
-    """the broadcastable form of (params, pk): host buffers"""
-    host = lambda t: t.cpu().numpy()
-    return {"k": pk.k, "shape": tuple(pk.circuit_shape), "g": params.g, "g_lagrange": params.g_lagrange,
-            "g2": np.frombuffer(bytes(params.g2), dtype=np.uint8), "s_g2": np.frombuffer(bytes(params.s_g2), dtype=np.uint8),
-            "fixed": [host(c) for c in pk.fixed_lagrange], "sigma": [host(c) for c in pk.sigma_lagrange],
-            "vk_digest": pk.vk_digest}
+def export_setup(params, pk, on_device: bool = False) -> dict:
+    """the broadcastable form of (params, pk).  on_device: the buffers as device tensors -- the key columns are the very
+    tensors `pk` keeps, the bases are device copies of the library's resident SRS -- for a broadcast that stays on the
+    GPUs; otherwise host arrays"""
+    if on_device:
+        d_g, d_gl = params.device_bases()
+        cols = lambda cs: list(cs)
+    else:
+        d_g, d_gl = params.g, params.g_lagrange
+        cols = lambda cs: [c.cpu().numpy() for c in cs]
+    return {"k": pk.k, "shape": tuple(pk.circuit_shape), "g": d_g, "g_lagrange": d_gl,
+            "g2": bytes(params.g2), "s_g2": bytes(params.s_g2),
+            "fixed": cols(pk.fixed_lagrange), "sigma": cols(pk.sigma_lagrange), "vk_digest": pk.vk_digest}
 
 
 def import_setup(setup):
-    """(params, pk, vk) on this rank's device from a broadcast setup dict"""
+    """(params, pk, vk) on this rank's device from a broadcast setup dict; device tensors in it are used where they are"""
     import torch
     from . import prover as P
     from .params import ParamsKZG
-    params = ParamsKZG(setup["k"], setup["g"], setup["g_lagrange"], bytes(setup["g2"]), bytes(setup["s_g2"]))
+    if isinstance(setup["g"], torch.Tensor) and setup["g"].is_cuda:
+        params = ParamsKZG.from_device(setup["k"], setup["g"], setup["g_lagrange"], bytes(setup["g2"]), bytes(setup["s_g2"]))
+    else:
+        params = ParamsKZG(setup["k"], np.asarray(setup["g"]), np.asarray(setup["g_lagrange"]), bytes(setup["g2"]), bytes(setup["s_g2"]))
     params.precompute()
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dev = lambda a: a if (isinstance(a, torch.Tensor) and a.is_cuda) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
     levels, nc, nb = setup["shape"]
     pk = P.ProvingKey(params, setup["k"], [dev(c) for c in setup["fixed"]], [dev(c) for c in setup["sigma"]], nc)
     pk.circuit_shape = (levels, nc, nb)
@@ -123,10 +150,23 @@ def setup_on_all_ranks(k: int, params_path, levels: int, n_currencies: int = 2, 
     if world == 1:
         return api.generate_setup_artifacts(k, params_path, api.MstInclusionCircuit.init_empty(levels, n_currencies, n_bytes),
                                             vk_transcript_repr)
+    import torch
+    d = _dist()
+    on_device = d.get_backend() == "nccl"
+    # rank 0's outcome first: if key generation fails there, every rank raises instead of waiting in a broadcast
+    made, failure = None, None
     if rank == 0:
-        made = api.generate_setup_artifacts(k, params_path, api.MstInclusionCircuit.init_empty(levels, n_currencies, n_bytes),
-                                            vk_transcript_repr)
-        broadcast_setup(export_setup(made[0], made[1]), 0)
+        try:
+            made = api.generate_setup_artifacts(k, params_path, api.MstInclusionCircuit.init_empty(levels, n_currencies, n_bytes),
+                                                vk_transcript_repr)
+        except Exception as ex:
+            failure = ex
+    status = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device="cuda" if on_device else "cpu")
+    d.broadcast(status, 0)
+    if int(status.item()):
+        raise RuntimeError("generate_setup_artifacts failed on rank 0") from failure
+    if rank == 0:
+        broadcast_setup(export_setup(made[0], made[1], on_device=on_device), 0)
         return made
     return import_setup(broadcast_setup(None, 0))
 

@@ -178,7 +178,7 @@ struct Shared {
   std::vector<std::pair<std::string, int>> params;  // sg_set_param history, replayed on every new lane
 };
 
-// Concurrency model.  The library keeps kLanes independent contexts ("lanes"), each with its own streams, MSM
+// Concurrency model.  The library keeps g_lane_count (default 4, at most kLanes) independent contexts ("lanes"), each with its own streams, MSM
 // engines, NTT plans, staging and scratch buffers.  A call takes ONE lane for its whole duration (lane 0 when it is
 // free, so a single-threaded caller always works in the same warm work space) and touches nothing of the others:
 // calls from different host threads -- halo2 reaches best_multiexp / best_fft from rayon iterators; the batch driver
@@ -187,7 +187,8 @@ struct Shared {
 // as the call returns.  The lock is per lane and re-entrant for the owning thread (entry points that stage host
 // buffers and then call their `_dev` form keep the lane in between).
 Shared g_sh;
-static constexpr int kLanes = 4;
+static constexpr int kLanes = 8;          // upper bound; g_lane_count of them are handed out (sg_set_param "lanes")
+std::atomic<int> g_lane_count{4};
 struct Lane {
   std::mutex mu;
   Context* ctx = nullptr;
@@ -267,10 +268,11 @@ int acquire_lane() {
     params = g_sh.params;
   }
   Lane* lane = nullptr;
-  for (int i = 0; i < kLanes && !lane; i++)
+  const int lanes = g_lane_count.load();
+  for (int i = 0; i < lanes && !lane; i++)
     if (g_lanes[i].mu.try_lock()) lane = &g_lanes[i];
-  if (!lane) {
-    lane = &g_lanes[g_rr.fetch_add(1) % kLanes];
+  if (!lane) {   // more concurrent callers than lanes: wait for one (round-robin), for the whole of its current call
+    lane = &g_lanes[g_rr.fetch_add(1) % (unsigned)lanes];
     lane->mu.lock();
   }
   if (!lane->ctx) {
@@ -313,11 +315,15 @@ struct LaneHold {
   LaneHold& operator=(const LaneHold&) = delete;
 };
 
-// the SRS behind a handle; entries live until sg_srs_free / sg_shutdown (std::map nodes are stable)
-Srs* find_srs(uint64_t handle) {
+// the SRS behind a handle: a COPY of the entry (device pointers, window tables' descriptors), taken under the lock, so
+// that a concurrent sg_srs_precompute / sg_srs_free on another lane never changes it under a reader.  The device
+// memory it names stays valid while the handle does (retired tables are kept until sg_collect_retired / sg_shutdown).
+bool find_srs(uint64_t handle, Srs* out) {
   std::lock_guard<std::mutex> lk(g_sh.mu);
   auto it = g_sh.srs.find(handle);
-  return it == g_sh.srs.end() ? nullptr : &it->second;
+  if (it == g_sh.srs.end()) return false;
+  *out = it->second;
+  return true;
 }
 
 int get_consts(uint32_t k, const DomainConsts** out) {
@@ -456,6 +462,7 @@ void sg_shutdown(void) {
     for (auto& kv : g_sh.srs) {
       (void)hipFree(kv.second.g);
       (void)hipFree(kv.second.g_lagrange);
+      if (kv.second.lagrange_prefix) (void)hipFree(kv.second.lagrange_prefix);
       for (auto& t : kv.second.tab)
         if (t.table) (void)hipFree(t.table);
     }
@@ -465,6 +472,25 @@ void sg_shutdown(void) {
     retired_device_memory_collect();
   }
   for (auto& l : g_lanes) l.mu.unlock();
+}
+
+// Returns the device memory the library has outgrown since it started (work spaces that were reallocated larger, window
+// tables replaced by sg_srs_precompute).  It waits for the device: call it when no other call is in flight.
+int sg_collect_retired(void) {
+  if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_collect_retired: not from inside a call");
+  int device;
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    device = g_sh.device;
+  }
+  if (device < 0) return SG_OK;
+  for (auto& l : g_lanes) l.mu.lock();       // index order, no lane of our own held: no call is in flight meanwhile
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) retired_device_memory_collect();
+  for (auto& l : g_lanes) l.mu.unlock();
+  if (e != hipSuccess) return hip_fail("sg_collect_retired", e);
+  return SG_OK;
 }
 
 // ------------------------------------------------------------------ MSM
@@ -639,13 +665,50 @@ int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint6
   }
   return SG_OK;
 }
+// the same from device memory (e.g. the receive buffers of an RCCL broadcast): device-to-device copies on `stream`
+int sg_srs_upload_dev(uint32_t k, const void* d_g, const void* d_g_lagrange, void* stream, uint64_t* handle_out) {
+  if (!d_g || !d_g_lagrange || !handle_out || k > 28) return fail(SG_ERR_INVALID, "sg_srs_upload_dev: bad argument");
+  LOCKED_CTX();
+  const size_t bytes = (size_t)64 << k;
+  hipStream_t st = pick_stream(stream);
+  Srs s{k, nullptr, nullptr, {}};
+  hipError_t e = hipMalloc(&s.g, bytes);
+  if (e == hipSuccess) e = hipMalloc(&s.g_lagrange, bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(s.g, d_g, bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(s.g_lagrange, d_g_lagrange, bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);   // the bases are read from other streams afterwards
+  if (e != hipSuccess) {
+    if (s.g) (void)hipFree(s.g);
+    if (s.g_lagrange) (void)hipFree(s.g_lagrange);
+    return hip_fail("sg_srs_upload_dev", e);
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    const uint64_t h = g_sh.next_handle++;
+    g_sh.srs[h] = s;
+    *handle_out = h;
+  }
+  return SG_OK;
+}
+// copies of the resident bases into caller-owned device buffers (2^k x 64 B each; either may be NULL)
+int sg_srs_copy_dev(uint64_t handle, void* d_g_out, void* d_g_lagrange_out, void* stream) {
+  LOCKED_CTX();
+  Srs srs_v;
+  if (!find_srs(handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  const size_t bytes = (size_t)64 << srs_v.k;
+  hipStream_t st = pick_stream(stream);
+  if (d_g_out) CHECK_HIP(hipMemcpyAsync(d_g_out, srs_v.g, bytes, hipMemcpyDeviceToDevice, st), "sg_srs_copy_dev");
+  if (d_g_lagrange_out) CHECK_HIP(hipMemcpyAsync(d_g_lagrange_out, srs_v.g_lagrange, bytes, hipMemcpyDeviceToDevice, st), "sg_srs_copy_dev");
+  return SG_OK;
+}
 // `SerdeFormat::RawBytes` validation of ParamsKZG::read (halo2: from_raw_bytes rejects points off the curve; the
 // `RawBytesUnchecked` format skips this): *bad_out = number of points of the resident SRS that fail y^2 = x^3 + 3
 int sg_srs_check(uint64_t handle, uint64_t* bad_out) {
   if (!bad_out) return fail(SG_ERR_INVALID, "sg_srs_check: null argument");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   uint8_t* cnt = nullptr;
   hipStream_t s = g_ctx->stream;
   hipError_t e = scratch_for(s, 7, 64, &cnt);
@@ -683,12 +746,14 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
   if (basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_srs_precompute: bad basis");
   if (window_bits && (window_bits < 4 || window_bits > 16)) return fail(SG_ERR_INVALID, "sg_srs_precompute: window_bits in [4, 16]");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
-  Srs& s = (*srs_p);
+  Srs srs_v;
+  if (!find_srs(handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
+  Srs& s = (*srs_p);   // a copy: the entry itself is updated under the lock once the table exists
   const size_t n = (size_t)1 << s.k;
   const uint32_t c = window_bits ? window_bits : fixed_window_bits_for(n);
   hipError_t e = hipSuccess;
+  g1_affine_mem* new_prefix = nullptr;
   if (basis == 2 && !s.lagrange_prefix) {   // Q_i = L_0 + ... + L_i, once per SRS
     g1_affine_mem* q = nullptr;
     e = hipMalloc(&q, n * sizeof(g1_affine_mem));
@@ -697,20 +762,37 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
       if (q) (void)hipFree(q);
       return hip_fail("sg_srs_precompute: prefix sums", e);
     }
-    s.lagrange_prefix = q;
+    s.lagrange_prefix = new_prefix = q;
   }
   FixedTable t;
   e = build_window_table(basis == 2 ? s.lagrange_prefix : basis ? s.g_lagrange : s.g, n, c, &t, g_ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(g_ctx->stream);
-  if (e != hipSuccess) return hip_fail("sg_srs_precompute", e);
-  retire_device_memory(s.tab[basis].table);   // commitments of other lanes may still be reading the old table
-  s.tab[basis] = t;
+  if (e != hipSuccess) {
+    if (new_prefix) (void)hipFree(new_prefix);
+    return hip_fail("sg_srs_precompute", e);
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    auto it = g_sh.srs.find(handle);
+    if (it == g_sh.srs.end()) {   // freed by another thread meanwhile
+      retire_device_memory(t.table);
+      retire_device_memory(new_prefix);
+      return fail(SG_ERR_INVALID, "sg_srs_precompute: the handle was freed during the call");
+    }
+    if (new_prefix) {
+      if (it->second.lagrange_prefix) retire_device_memory(new_prefix);   // two concurrent precomputes: keep the first
+      else it->second.lagrange_prefix = new_prefix;
+    }
+    retire_device_memory(it->second.tab[basis].table);   // commitments of other lanes may still be reading the old table
+    it->second.tab[basis] = t;
+  }
   return SG_OK;
 }
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k) {
   LOCKED_CTX();
-  Srs* srs_p = find_srs(handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   if (d_g) *d_g = (*srs_p).g;
   if (d_g_lagrange) *d_g_lagrange = (*srs_p).g_lagrange;
   if (k) *k = (*srs_p).k;
@@ -737,8 +819,9 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
                         uint8_t out_affine[64], sg_msm_timings* timings) {
   if (!out_affine || (n && !d_scalars) || basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(srs_handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   MsmTimings tm;
   hipError_t e = commit_run((*srs_p), basis, static_cast<const fp_words*>(d_scalars), n, pick_stream(stream), out_affine,
@@ -764,8 +847,9 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
   for (size_t i = 0; i < count; i++)
     if (n && !d_scalars[i]) return fail(SG_ERR_INVALID, "sg_commit_batch: null argument");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(srs_handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   const Srs& s = (*srs_p);
   std::vector<size_t> ns(count, n);
@@ -784,8 +868,9 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
   for (size_t i = 0; i < count; i++)
     if ((n && !d_scalars[i]) || basis[i] < 0 || basis[i] > 2) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(srs_handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   const Srs& s = (*srs_p);
   // fixed-base only when both tables exist with one plan; otherwise the generic fused path over g / g_lagrange
@@ -805,8 +890,9 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && !scalars) || basis < 0 || basis > 2) return fail(SG_ERR_INVALID, "sg_commit: bad argument");
   LOCKED_CTX();
-  Srs* srs_p = find_srs(srs_handle);
-  if (!srs_p) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs srs_v;
+  if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
+  Srs* srs_p = &srs_v;
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
   hipError_t e = commit_run((*srs_p), basis, reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, g_ctx->stream,
@@ -2039,17 +2125,22 @@ int sg_mst_inclusion_witness_dev(const void* d_program, uint32_t n_items, uint32
 int sg_set_param(const char* name, int value) {
   if (!name || value < 0) return fail(SG_ERR_INVALID, "sg_set_param: bad argument");
   if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_set_param: not from inside a call");
-  LOCKED_CTX();   // makes sure a context exists to validate the name against
   const std::string s(name);
-  int rc = apply_param(*g_ctx, s, value);
-  if (rc != SG_OK) return rc;
+  if (s == "lanes") {   // how many concurrent calls get a context of their own (1 .. 8); further callers wait for a lane
+    if (value < 1 || value > kLanes) return fail(SG_ERR_INVALID, "sg_set_param: lanes in [1, 8]");
+    g_lane_count.store(value);
+    return SG_OK;
+  }
   {
+    LOCKED_CTX();   // makes sure a context exists to validate the name against
+    int rc = apply_param(*g_ctx, s, value);
+    if (rc != SG_OK) return rc;
     std::lock_guard<std::mutex> lk(g_sh.mu);
     g_sh.params.emplace_back(s, value);   // lanes created later replay it
   }
-  Lane* mine = g_held;
-  for (auto& l : g_lanes) {               // lanes that exist already: when they are idle
-    if (&l == mine) continue;
+  // the lanes that exist already, one at a time and with none held (two threads setting parameters at once cannot
+  // wait for each other's lane): each when it is idle
+  for (auto& l : g_lanes) {
     std::lock_guard<std::mutex> lk(l.mu);
     if (l.ctx) (void)apply_param(*l.ctx, s, value);
   }

@@ -582,27 +582,45 @@ class _PermutationAssembly:
 class _ReferenceFloorPlan:
     """cells are (column key, row) with the keys of PERMUTATION_COLUMNS; values are tracked next to the layout"""
 
-    def __init__(self, k: int):
+    def __init__(self, k: int, lenient: bool = False, instances=None):
+        """lenient (the mock prover's view, mock_prover.py): the witness is laid out as given even where it violates a
+        copy or range constraint -- halo2's synthesize does not check values either -- and the instance column holds
+        `instances` instead of the exposed cells' values"""
         self.k, self.n = k, 1 << k
+        self.lenient = lenient
         self.next_free = {}
         self.fixed = [[0] * self.n for _ in range(NUM_FIXED)]
         self.adv = [[0] * self.n for _ in range(NUM_ADVICE)]
-        self.instances = {}
+        self.instances = dict(enumerate(int(v) % R for v in instances)) if instances is not None else {}
+        self.given_instances = instances is not None
         self.asm = _PermutationAssembly(self.n, len(PERMUTATION_COLUMNS))
         self.rcs, self.mds, _ = _poseidon()
+        # regions in `assign_region` order with the cells assigned inside them (what halo2's MockProver records:
+        # name, assigned columns, first / last assigned row); constants and instance cells lie outside every region
+        self.regions = []
+        self._cur = None
 
     # -- floor planner
-    def region(self, columns, rows: int) -> int:
+    def region(self, columns, rows: int, name: str = "") -> int:
         start = max([self.next_free.get(c, 0) for c in columns] + [0])
         for c in columns:
             self.next_free[c] = start + rows
         if start + rows > self.n - (BLINDING_FACTORS + 1):
             raise ValueError("the circuit does not fit 2^k rows")
+        self._cur = {"name": name, "columns": set(), "lo": None, "hi": None}
+        self.regions.append(self._cur)
         return start
+
+    def _touch(self, column, row: int):
+        r = self._cur
+        if r is not None:
+            r["columns"].add(column)
+            r["lo"] = row if r["lo"] is None else min(r["lo"], row)
+            r["hi"] = row if r["hi"] is None else max(r["hi"], row)
 
     def copy(self, left, right):
         lv, rv = self.value(left), self.value(right)
-        if lv != rv:
+        if lv != rv and not self.lenient:
             raise AssertionError(("copy constraint between unequal cells", left, right))
         self.asm.copy((PERMUTATION_COLUMNS.index(left[0]), left[1]), (PERMUTATION_COLUMNS.index(right[0]), right[1]))
 
@@ -616,6 +634,7 @@ class _ReferenceFloorPlan:
 
     def constants(self, items):
         col = (FIXED, 2)
+        self._cur = None          # the floor planner assigns a region's constants after it has left the region
         for v, cell in items:
             row = self.next_free.get(col, 0)
             self.next_free[col] = row + 1
@@ -625,22 +644,23 @@ class _ReferenceFloorPlan:
     def set(self, cell, v):
         (kind, idx), row = cell
         self.adv[idx][row] = v % R
+        self._touch(cell[0], row)
         return cell
 
     # -- chips
-    def witness(self, column: int, v: int):
-        return self.set(((ADVICE, column), self.region([(ADVICE, column)], 1)), v)
+    def witness(self, column: int, v: int, label: str = "value"):
+        return self.set(((ADVICE, column), self.region([(ADVICE, column)], 1, "assign " + label)), v)
 
     def hash(self, chip: int, inputs):
         s_full, s_partial, pad = (7, 8, 3) if chip == 1 else (9, 10, 4)
         a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
-        st = self.region([a0, a1], 1)
+        st = self.region([a0, a1], 1, "initial state for domain ConstantLength")
         vals = [0, (len(inputs) << 64) % R]
         state = [self.set((a0, st), vals[0]), self.set((a1, st), vals[1])]
         self.constants([(vals[0], state[0]), (vals[1], state[1])])
         mix = lambda s: [(self.mds[i][0] * s[0] + self.mds[i][1] * s[1]) % R for i in range(2)]
         for cell in inputs:
-            st = self.region([a0, a1, ("selector", "pad", chip)], 3)
+            st = self.region([a0, a1, ("selector", "pad", chip)], 3, "add input for domain ConstantLength")
             self.fixed[6][st + 1] = pad
             self.set((a0, st), vals[0]); self.set((a1, st), vals[1])
             self.copy((a0, st), state[0])
@@ -649,7 +669,8 @@ class _ReferenceFloorPlan:
             self.copy((a0, st + 1), cell)
             vals = [(vals[0] + self.value(cell)) % R, vals[1]]
             state = [self.set((a0, st + 2), vals[0]), self.set((a1, st + 2), vals[1])]
-            st = self.region([a0, a1, a2] + [(FIXED, j) for j in range(4)] + [("selector", "full", chip), ("selector", "partial", chip)], 37)
+            st = self.region([a0, a1, a2] + [(FIXED, j) for j in range(4)] + [("selector", "full", chip), ("selector", "partial", chip)], 37,
+                             "permute state")
             self.set((a0, st), vals[0]); self.set((a1, st), vals[1])
             self.copy((a0, st), state[0])
             self.copy((a1, st), state[1])
@@ -661,51 +682,56 @@ class _ReferenceFloorPlan:
                         self.fixed[s_partial][row] = 1
                         self.fixed[0][row], self.fixed[1][row] = rc_a
                         self.fixed[2][row], self.fixed[3][row] = rc_b
+                        for j in range(4):
+                            self._touch((FIXED, j), row)
                         sbox = pow((vals[0] + rc_a[0]) % R, 5, R)
-                        self.adv[2][row] = sbox
+                        self.set((a2, row), sbox)
                         mid = mix([sbox, (vals[1] + rc_a[1]) % R])
                         vals = mix([pow((mid[0] + rc_b[0]) % R, 5, R), (mid[1] + rc_b[1]) % R])
                         row += 1
-                        self.adv[0][row], self.adv[1][row] = vals
+                        self.set((a0, row), vals[0]); self.set((a1, row), vals[1])
                 else:
                     for r in half:
                         self.fixed[s_full][row] = 1
                         self.fixed[0][row], self.fixed[1][row] = self.rcs[r]
+                        self._touch((FIXED, 0), row); self._touch((FIXED, 1), row)
                         vals = mix([pow((vals[j] + self.rcs[r][j]) % R, 5, R) for j in range(2)])
                         row += 1
-                        self.adv[0][row], self.adv[1][row] = vals
+                        self.set((a0, row), vals[0]); self.set((a1, row), vals[1])
             state = [(a0, st + 36), (a1, st + 36)]
         return state[0]
 
     def range_check(self, cell, n_bytes: int):
         a0 = (ADVICE, 0)
-        st = self.region([a0, ("selector", "lookup")], n_bytes + 1)
+        st = self.region([a0, ("selector", "lookup")], n_bytes + 1, "assign value to perform range check")
         v = self.value(cell)
         for i in range(n_bytes):
             self.fixed[5][st + i] = 1
-            self.adv[0][st + i] = v
+            self.set((a0, st + i), v)
             v >>= 8
-        if v:
+        if v and not self.lenient:
             raise ValueError("balance out of range")
-        self.adv[0][st + n_bytes] = 0
+        # the last running sum: 0 for a value of n_bytes bytes; what is left of a larger one (the chip decomposes the value's
+        # low bytes only, chips/range/utils.rs:12-33, so the running sum does not close and the copy to the constant 0 breaks)
+        self.set((a0, st + n_bytes), v)
         self.copy((a0, st), cell)
         self.constants([(0, (a0, st + n_bytes))])
 
     def swap(self, cur, sibling, bit):
         a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
-        st = self.region([a0, a1, a2, ("selector", "swap")], 2)
+        st = self.region([a0, a1, a2, ("selector", "swap")], 2, "assign nodes hashes per merkle tree level")
         self.fixed[6][st] = 1
         for col, cell in ((a0, cur), (a1, sibling), (a2, bit)):
             self.set((col, st), self.value(cell))
             self.copy((col, st), cell)
         l, r = self.value(cur), self.value(sibling)
-        if self.value(bit):
+        if self.value(bit):       # chips/merkle_sum_tree.rs:150-158: any non-zero bit swaps
             l, r = r, l
         return self.set((a0, st + 1), l), self.set((a1, st + 1), r)
 
     def add(self, cur, sibling):
         a0, a1, a2 = (ADVICE, 0), (ADVICE, 1), (ADVICE, 2)
-        st = self.region([a0, a1, a2, ("selector", "sum")], 1)
+        st = self.region([a0, a1, a2, ("selector", "sum")], 1, "sum nodes balances per currency")
         self.fixed[6][st] = 2
         for col, cell in ((a0, cur), (a1, sibling)):
             self.set((col, st), self.value(cell))
@@ -713,7 +739,8 @@ class _ReferenceFloorPlan:
         return self.set((a2, st), self.value(cur) + self.value(sibling))
 
     def expose(self, cell, row: int):
-        self.instances[row] = self.value(cell)
+        if not self.given_instances:
+            self.instances[row] = self.value(cell)
         self.copy(cell, ((INSTANCE, 0), row))
 
     def finish(self):
@@ -729,42 +756,45 @@ class _ReferenceFloorPlan:
         sigma = [[labels[m[0]][m[1]] for m in col] for col in self.asm.mapping]
         inst = [self.instances[i] for i in range(len(self.instances))]
         return {"fixed": self.fixed, "advice": self.adv, "instances": inst, "sigma": sigma,
-                "usable_rows": self.n - (BLINDING_FACTORS + 1), "rows_used": max(self.next_free.values())}
+                "usable_rows": self.n - (BLINDING_FACTORS + 1), "rows_used": max(self.next_free.values()),
+                "regions": [(r["name"], r["lo"], r["hi"], frozenset(r["columns"])) for r in self.regions],
+                "mapping": self.asm.mapping}
 
 
 def reference_assignment(k: int, username: int, balances, path_bits, sibling_leaf_preimage, sibling_middle_preimages,
-                         n_bytes: int = 8):
+                         n_bytes: int = 8, lenient: bool = False, instances=None):
     """`MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>::synthesize` replayed over the reference's own floor plan
     (see above): fixed columns, permutation and advice assignment exactly as halo2's keygen / prover would hold them.
     Inputs as in the reference's MerkleProof [REF merkle_sum_tree/tree.rs, circuits/merkle_sum_tree.rs:30-60]:
     sibling_leaf_preimage = [username, balances..], sibling_middle_preimages[level - 1] = [balances.., left hash,
     right hash]; integers.  Empty inputs (zeros) give the key-generation view (`init_empty`)."""
-    fp = _ReferenceFloorPlan(k)
+    fp = _ReferenceFloorPlan(k, lenient, instances)
     nc = len(balances)
-    user = fp.witness(0, username)
-    cur_bal = [fp.witness(1, b) for b in balances]
+    user = fp.witness(0, username, "entry username")
+    cur_bal = [fp.witness(1, b, "entry balance") for b in balances]
     cur_hash = fp.hash(1, [user] + cur_bal)
     fp.expose(cur_hash, 0)
-    st = fp.region([(FIXED, 4)], 256)
+    st = fp.region([(FIXED, 4)], 256, "load range check table of 8 bits")
     for i in range(256):
         fp.fixed[4][st + i] = i
+        fp._touch((FIXED, 4), st + i)
     for level, bit_value in enumerate(path_bits):
         if level == 0:
-            sib_user = fp.witness(0, sibling_leaf_preimage[0])
-            sib_bal = [fp.witness(1, b) for b in sibling_leaf_preimage[1:1 + nc]]
+            sib_user = fp.witness(0, sibling_leaf_preimage[0], "sibling leaf node username")
+            sib_bal = [fp.witness(1, b, "sibling leaf balance") for b in sibling_leaf_preimage[1:1 + nc]]
             sib_hash = fp.hash(1, [sib_user] + sib_bal)
             for c in range(nc):
                 fp.range_check(cur_bal[c], n_bytes)
                 fp.range_check(sib_bal[c], n_bytes)
         else:
             pre = sibling_middle_preimages[level - 1]
-            sib_bal = [fp.witness(1, b) for b in pre[:nc]]
-            left = fp.witness(2, pre[nc])
-            right = fp.witness(2, pre[nc + 1])
+            sib_bal = [fp.witness(1, b, "sibling node balance") for b in pre[:nc]]
+            left = fp.witness(2, pre[nc], "sibling left hash")
+            right = fp.witness(2, pre[nc + 1], "sibling right hash")
             sib_hash = fp.hash(2, sib_bal + [left, right])
             for c in range(nc):
                 fp.range_check(sib_bal[c], n_bytes)
-        bit = fp.witness(0, bit_value)
+        bit = fp.witness(0, bit_value, "swap bit")
         left, right = fp.swap(cur_hash, sib_hash, bit)
         cur_bal = [fp.add(cur_bal[c], sib_bal[c]) for c in range(nc)]
         cur_hash = fp.hash(2, cur_bal + [left, right])

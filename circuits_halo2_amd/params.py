@@ -21,12 +21,52 @@ class ParamsKZG:
     def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2: bytes = b"", s_g2: bytes = b""):
         self.k = k
         self.n = 1 << k
-        self.g = ffi.u8(g)
-        self.g_lagrange = ffi.u8(g_lagrange)
-        if self.g.size != 64 * self.n or self.g_lagrange.size != 64 * self.n:
+        self._g = ffi.u8(g)
+        self._g_lagrange = ffi.u8(g_lagrange)
+        if self._g.size != 64 * self.n or self._g_lagrange.size != 64 * self.n:
             raise ValueError("ParamsKZG: basis length != 2^k")
         self.g2, self.s_g2 = g2, s_g2
         self._handle = None
+
+    @classmethod
+    def from_device(cls, k: int, d_g, d_g_lagrange, g2: bytes = b"", s_g2: bytes = b"") -> "ParamsKZG":
+        """params whose bases arrive in device memory (the receive side of the setup broadcast, batch.py): they go into the
+        library's SRS cache device to device (sg_srs_upload_dev) and visit the host only if `g` / `g_lagrange` / `write`
+        are asked for"""
+        if not (_is_torch_cuda(d_g) and _is_torch_cuda(d_g_lagrange)) or d_g.numel() != 64 << k or d_g_lagrange.numel() != 64 << k:
+            raise ValueError("ParamsKZG.from_device: two device buffers of 2^k x 64 bytes expected")
+        self = cls.__new__(cls)
+        self.k, self.n = k, 1 << k
+        self._g = self._g_lagrange = None
+        self.g2, self.s_g2 = g2, s_g2
+        h = C.c_uint64(0)
+        ffi.check(ffi.lib().sg_srs_upload_dev(C.c_uint32(k), ffi.dev_ptr(d_g), ffi.dev_ptr(d_g_lagrange), ffi.current_stream_ptr(),
+                                              C.byref(h)))
+        self._handle = h.value
+        return self
+
+    def device_bases(self):
+        """copies of the resident g / g_lagrange as two device tensors (the send side of the setup broadcast)"""
+        import torch
+        d_g = torch.empty(64 * self.n, dtype=torch.uint8, device="cuda")
+        d_gl = torch.empty(64 * self.n, dtype=torch.uint8, device="cuda")
+        ffi.check(ffi.lib().sg_srs_copy_dev(C.c_uint64(self.handle()), ffi.dev_ptr(d_g), ffi.dev_ptr(d_gl), ffi.current_stream_ptr()))
+        return d_g, d_gl
+
+    def _fetch_host(self):
+        if self._g is None:
+            d_g, d_gl = self.device_bases()
+            self._g, self._g_lagrange = d_g.cpu().numpy(), d_gl.cpu().numpy()
+
+    @property
+    def g(self) -> np.ndarray:
+        self._fetch_host()
+        return self._g
+
+    @property
+    def g_lagrange(self) -> np.ndarray:
+        self._fetch_host()
+        return self._g_lagrange
 
     # --- construction -------------------------------------------------------------------
     @classmethod
@@ -82,12 +122,13 @@ class ParamsKZG:
             raise ValueError("k is too large for the given params")  # utils.rs:58-60
         if k == self.k:
             return
+        g_all = self.g          # (fetched from the device first when the params came from there)
         self.free()
         n = 1 << k
-        g = np.ascontiguousarray(self.g[:64 * n])
+        g = np.ascontiguousarray(g_all[:64 * n])
         gl = np.zeros(64 * n, dtype=np.uint8)
         ffi.check(ffi.lib().sg_g1_to_lagrange(ffi.ptr(g), C.c_uint32(k), ffi.ptr(gl)))
-        self.k, self.n, self.g, self.g_lagrange = k, n, g, gl
+        self.k, self.n, self._g, self._g_lagrange = k, n, g, gl
 
     # --- device cache -------------------------------------------------------------------
     def handle(self) -> int:
@@ -117,6 +158,7 @@ class ParamsKZG:
 
     def free(self):
         if self._handle is not None:
+            self._fetch_host()    # the host copy is what a later handle() uploads again
             ffi.check(ffi.lib().sg_srs_free(C.c_uint64(self._handle)))
             self._handle = None
 

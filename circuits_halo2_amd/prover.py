@@ -18,6 +18,7 @@ same constraint system with its own fixed columns and checks the proof with the 
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 
@@ -209,6 +210,7 @@ class ProvingKey:
         if self.quotient_domain not in ("cosets", "extended"):
             raise ValueError("quotient_domain: cosets or extended")
         self.k, self.n = k, 1 << k
+        self._lock = threading.Lock()             # guards the caches made on first use (native key, witness program)
         self.n_currencies = n_currencies          # one sum gate per currency in the gate program
         self.dom = EvaluationDomain(M.DEGREE, k)
         n, u = self.n, self.n - (M.BLINDING_FACTORS + 1)
@@ -233,8 +235,21 @@ class ProvingKey:
         torch.cuda.synchronize()
 
 
+_KEY_LOCK = threading.Lock()      # for key objects that carry no lock of their own
+
+
 def native_key(pk: ProvingKey, params) -> int:
-    """the proving key inside the library's compiled prover (sp_key_create), made on first use and kept on `pk`"""
+    """the proving key inside the library's compiled prover (sp_key_create), made on first use and kept on `pk`.
+    Several proofs may start on a fresh key at once (batch.prove_batch's worker threads): the key is made once, under
+    the key's lock, and the others wait for it."""
+    made = getattr(pk, "_native", None)
+    if made is not None and made[1] == (params.handle(), pk.vk_digest):
+        return made[0]
+    with getattr(pk, "_lock", _KEY_LOCK):
+        return _native_key_locked(pk, params)
+
+
+def _native_key_locked(pk: ProvingKey, params) -> int:
     import ctypes as C
     from . import ffi
     made = getattr(pk, "_native", None)

@@ -154,9 +154,24 @@ def _expected_h_eval(evals, ch, lag, n_currencies: int) -> int:
 
 def verify_proof(params, vk, proof: bytes, instances, flavour: str = "evm") -> bool:
     """params: ParamsKZG with g2 / s_g2 (the verifier params); vk: api.VerifyingKey; instances: the instance column's
-    values (integers < r).  True iff the proof is accepted."""
+    values (integers < r).  True iff the proof is accepted.  A proof that cannot be checked -- malformed bytes, a point
+    off the curve, a challenge that lands on the domain so that a denominator vanishes -- is a rejected proof, not an
+    exception (upstream's `verify_proof` returns Err for all of these); a missing library or GPU still raises."""
     if any(not 0 <= int(v) < R for v in instances) or len(params.g2) != 128 or len(params.s_g2) != 128:
         return False
+    if len(instances) > (1 << vk.k) - (M.BLINDING_FACTORS + 1):      # halo2: Error::InstanceTooLarge
+        return False
+    try:
+        return _verify(params, vk, proof, instances, flavour)
+    except (ValueError, ZeroDivisionError):
+        return False
+    except ffi.SummaGpuError as ex:
+        if ex.code == -1:          # SG_ERR_INVALID: the data (an unreduced coordinate, a point off the curve), not the device
+            return False
+        raise
+
+
+def _verify(params, vk, proof: bytes, instances, flavour: str) -> bool:
     k = vk.k
     try:
         rd = _Reader(bytes(proof), flavour)

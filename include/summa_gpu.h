@@ -22,8 +22,13 @@
  * bit-comparable with the CPU prover's.
  *
  * Conventions: every function returns SG_OK (0) or a negative sg_status; nothing throws or
- * aborts; pointers are borrowed for the duration of the call; the library is thread-safe
- * (calls from several host threads are serialised per device context).  "_dev" entry points are
+ * aborts; pointers are borrowed for the duration of the call; the library is thread-safe and
+ * re-entrant: it keeps a small number of independent contexts ("lanes": own streams, MSM engines,
+ * NTT plans, staging buffers), a call owns one lane for its whole duration, and calls from different
+ * host threads run side by side on the device.  There are FOUR lanes by default
+ * (sg_set_param("lanes", 1..8)); a caller that arrives while all of them are taken WAITS for one,
+ * for as long as that lane's current call lasts -- a thread pool wider than the lane count (rayon's
+ * default is one thread per core) gains nothing beyond it.  "_dev" entry points are
  * asynchronous unless they return a value to the host: the work is ordered on the given stream and the
  * library's work space is kept per stream, so independent ops may be issued on several streams.  "host" entry points
  * take host pointers and move data themselves; "_dev" entry points take HIP device pointers
@@ -55,6 +60,11 @@ typedef enum {
  * under torch.distributed pass LOCAL_RANK).  Idempotent for the same device. */
 int sg_init(int device);
 void sg_shutdown(void);
+/* Device memory the library has outgrown while running (work spaces reallocated larger, window tables replaced by
+ * sg_srs_precompute) is retired, not freed -- hipFree waits for the whole device, which would stall every other lane.
+ * It is bounded by the final sizes (work spaces grow geometrically) and is returned here and by sg_shutdown.  The call
+ * waits for the device to go idle: use it between workloads (e.g. after switching k), with no other call in flight. */
+int sg_collect_retired(void);
 /* Message of the last failure on the calling thread (static storage, never NULL). */
 const char* sg_last_error(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
@@ -84,6 +94,11 @@ int sg_g1_sum_affine(const uint8_t* points, size_t n, uint8_t out_affine[64]);
 /* SRS cache: keeps ParamsKZG's g[] / g_lagrange[] resident in HBM across proofs
  * (the reference re-reads the file per Snapshot: backend/src/apis/round.rs:136-145). */
 int sg_srs_upload(uint32_t k, const uint8_t* g, const uint8_t* g_lagrange, uint64_t* handle_out);
+/* The same from device buffers (2^k x 64 B each, e.g. the receive side of an RCCL broadcast of the setup artifacts: the
+ * bases never visit the host), and the reverse: copies of the resident bases into caller-owned device buffers (the send
+ * side; either output may be NULL).  Copies are ordered on `stream`; sg_srs_upload_dev returns after they completed. */
+int sg_srs_upload_dev(uint32_t k, const void* d_g, const void* d_g_lagrange, void* stream, uint64_t* handle_out);
+int sg_srs_copy_dev(uint64_t handle, void* d_g_out, void* d_g_lagrange_out, void* stream);
 /* The validation `ParamsKZG::read` performs with SerdeFormat::RawBytes (points off the curve are rejected; the
  * RawBytesUnchecked format skips it): *bad_out = number of points of the resident SRS (g and g_lagrange) that are neither on
  * y^2 = x^3 + 3 nor the identity. */
@@ -398,7 +413,8 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
                         sg_msm_timings* timings);
 int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                         uint8_t out_affine[64], sg_msm_timings* timings);
-/* name: "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
+/* name: "lanes" (1..8, default 4: concurrent calls that get a context of their own, see the conventions at the top),
+ * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
  * "ntt.max_single_log", "ntt.max_multi_log" */
 int sg_set_param(const char* name, int value);
 /* Time `reps` back-to-back launches of the operation with HIP events on the library's

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <chrono>
 #include <functional>
+#include <exception>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -808,6 +809,17 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // SG_PROVER_SERIAL (development aid): everything on the main stream, so that a kernel trace shows every kernel alone
   const bool serial = std::getenv("SG_PROVER_SERIAL") != nullptr;
   const hipStream_t side[2] = {serial ? ms : side_streams[0], serial ? ms : side_streams[1]};
+  // A proof that ends in an exception (WitnessError, a failed call) may leave kernels behind on the side streams, and its
+  // device columns go back to this thread's pool as the stack unwinds -- the next proof would take them while those
+  // kernels still write to them.  On the way out by exception the three streams are drained first.
+  struct DrainOnUnwind {
+    hipStream_t s[3];
+    int depth = std::uncaught_exceptions();
+    ~DrainOnUnwind() {
+      if (std::uncaught_exceptions() > depth)
+        for (hipStream_t st : s) (void)hipStreamSynchronize(st);
+    }
+  } drain_on_unwind{{side[0], side[1], ms}};
   auto fork = [&]() {
     hk(hipEventRecord(ev_fork, ms), "event");
     for (auto& st : side) hk(hipStreamWaitEvent(st, ev_fork, 0), "wait");

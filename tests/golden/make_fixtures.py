@@ -11,6 +11,8 @@ Fixtures are DATA:
                      big-integer twin oracle/pyref.py (NTT 2^4, coeff_to_extended 2^4->2^7,
                      MSM answers as f(tau)*G).
   ntt_k11_{in,out}.bin, msm_tau_k10_{scalars,bases}.bin   pyref-generated vectors.
+  entry_*.csv        byte copies of the reference's CSV data fixtures csv/*.csv (the inputs of its Merkle-sum-tree and
+                     circuit tests: 13 / 16 / 17 entries, switched order, one modified entry, big integers, an overflowing balance).
 """
 import json
 import os
@@ -23,6 +25,18 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from oracle import pyref as P  # noqa: E402
 
 REF = "/root/reference"
+
+
+CSVS = ["entry_16.csv", "entry_13.csv", "entry_17.csv", "entry_16_switched_order.csv", "entry_16_modified.csv",
+        "entry_16_bigints.csv", "entry_16_overflow.csv"]
+
+
+def copy_csvs():
+    """the reference's CSV data fixtures (csv/*.csv: the inputs of zk_prover/src/merkle_sum_tree/tests.rs and
+    zk_prover/src/circuits/tests.rs), byte copies"""
+    for name in CSVS:
+        shutil.copyfile(os.path.join(REF, "csv", name), os.path.join(HERE, name))
+        os.chmod(os.path.join(HERE, name), 0o644)
 
 
 def main():
@@ -75,9 +89,8 @@ def main():
     f_tau = sum(s * pow(tau, i, P.R) for i, s in enumerate(sp)) % P.R
     ans = P.g1_mul(P.G1_GEN, f_tau)
     kat["msm_tau_k10_sparse"] = {"scalars": [hex(x) for x in sp], "answer": [hex(ans[0]), hex(ans[1])] if ans else None}
-    # --- witness side (K5): the reference's own data file and the constants its tests pin
-    shutil.copyfile(os.path.join(REF, "csv/entry_16.csv"), os.path.join(HERE, "entry_16.csv"))
-    os.chmod(os.path.join(HERE, "entry_16.csv"), 0o644)
+    # --- witness side (K5): the reference's own data files and the constants its tests pin
+    copy_csvs()
     tests_rs = open(os.path.join(REF, "zk_prover/src/circuits/tests.rs")).read()
     backend_rs = open(os.path.join(REF, "backend/src/tests.rs")).read()
     leafs = re.findall(r'"(0x[0-9a-f]{64})"', tests_rs)

@@ -180,24 +180,103 @@ def test_proofs_from_the_device_witness_verify():
         params.free()
 
 
-def test_bench_starts_its_own_ranks_two_rank_rehearsal():
-    """`python bench.py --gpus 2` launched bare: the parent starts the two ranks itself (torch.distributed.run child, before
-    it touches the GPU), rank 0 prints the one JSON line with n_gpus = 2.  On this one-GPU box the ranks rehearse with the
-    gloo backend and share the GPU (`--backend gloo`); everything else -- point-sharded MSM with the all_gather of partials,
-    setup broadcast, proofs dealt to ranks and kept in flight, max-over-ranks timing -- is the N > 1 code path"""
+def _run_bench(extra, timeout=1100):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
-                        "--batch-proofs", "3", "--no-cpu", "--log-n", "20"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_two_rank_line(line, backend_word):
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
-    assert line["config"]["sharding"].startswith("point-sharded") and "gloo" in line["config"]["backend"]
+    assert line["config"]["sharding"].startswith("point-sharded") and backend_word in line["config"]["backend"]
     b = line["batch_k17"]
-    assert b["n_gpus"] == 2 and b["verified_sample"] is True
-    assert all(v["proofs"] == 6 and v["errors"] == 0 for v in b["by_in_flight"].values())     # 3 per rank, both ranks counted
+    assert b["n_gpus"] == 2 and b["verified_sample"] is True and b["proofs_total"] == 6 and b["errors"] == 0
+    assert all(r["proofs"] == 6 and r["errors"] == 0 for r in b["repeats"])          # dealt 3 + 3, both ranks counted
+    assert all(v["errors"] == 0 for v in b["pre_sweep_by_in_flight"].values())
+    st = line["msm_strong_scaling_2^23"]
+    assert st["n_gpus"] == 2 and st["scaling"] == "strong" and st["points_per_gpu"] == 1 << 22
+    assert st["every_rank_partial_equals_inner_product_times_G"] is True
+    return st["result_x"]
+
+
+def test_bench_starts_its_own_ranks_two_rank_rehearsal():
+    """`python bench.py --gpus 2` launched bare: the parent starts the two ranks itself (torch.distributed.run child, before
+    it touches the GPU), rank 0 prints the one JSON line with n_gpus = 2.  On this one-GPU box the ranks rehearse with the
+    gloo backend and share the GPU (`--backend gloo`); everything else -- point-sharded MSM with the all_gather of partials
+    (weak: 2^20 per rank; strong: one 2^23-point MSM cut in two), setup broadcast, the batch's users dealt to the ranks and
+    kept in flight, max-over-ranks timing -- is the N > 1 code path.  The strong-scaling MSM's result must be the point the
+    same extra finds on ONE rank (same 2^23 inputs at every N)."""
+    two = _run_bench(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch-proofs", "6", "--batch-repeats", "1",
+                      "--no-cpu", "--log-n", "20"])
+    x2 = _check_two_rank_line(two, "gloo")
+    one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch-proofs", "0", "--no-cpu", "--log-n", "20", "--strong-only"])
+    assert one["msm_strong_scaling_2^23"]["result_x"] == x2 and one["msm_strong_scaling_2^23"]["points_per_gpu"] == 1 << 23
+
+
+def test_two_rank_nccl():
+    """the same bare launch with the nccl (= RCCL) backend, one GPU per rank: the first box with two GPUs exercises the
+    collectives over xGMI -- the all_gather of partials, the device-to-device setup broadcast, the timing all_reduces --
+    without anyone editing code.  One-GPU boxes skip it (the gloo rehearsal above covers the logic there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL between ranks)")
+    line = _run_bench(["--gpus", "2", "--backend", "nccl", "--steps", "3", "--warmup", "1", "--batch-proofs", "6", "--batch-repeats", "1",
+                       "--no-cpu", "--log-n", "20"])
+    _check_two_rank_line(line, "nccl")
+
+
+def test_batch_of_1024_users_at_k17():
+    """BASELINE configs[4] at its stated size on one GPU: inclusion proofs for 1024 users of a 2^20-user snapshot,
+    MstInclusionCircuit<20,2,8> at k = 17, through the batch driver (what the reference's backend serves one call at a
+    time, backend/src/apis/round.rs:132-174).  Every proof is verified by the product's verifier inside
+    gen_proof_solidity_calldata (create_proof_checked, utils.rs:162-196); here additionally: none failed, every user
+    got a proof of 2144 bytes whose public inputs are the tree's leaf / root / root balances for THAT user, all leaf
+    hashes differ, and the oracle's verifier accepts a sample."""
+    _gpu()
+    import sys
+    import time
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import oracle_vk, snapshot_tree
+    from circuits_halo2_amd import batch as B
+    from oracle import summa_verifier as SV
+    levels, nc, k = 20, 2, 17
+    params, pk, vk = B.setup_on_all_ranks(k, None, levels, nc)
+    try:
+        tree = snapshot_tree(levels, nc)
+        users = [(7919 * i + 13) % (1 << levels) for i in range(1024)]
+        assert len(set(users)) == 1024
+        B.prove_batch(tree, users[:8], params, pk, levels, in_flight=4)          # warm: lanes, sessions
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = B.prove_batch(tree, users, params, pk, levels, flavour="evm", in_flight=4)
+        dt = time.perf_counter() - t0
+        assert not res.errors and sorted(res.proofs) == sorted(users)
+        root_inputs = None
+        leaves = set()
+        for u, (proof, inst) in res.proofs.items():
+            assert len(proof) == 2144 and len(inst) == 2 + nc
+            assert inst == tree.public_inputs(u)
+            root_inputs = root_inputs or inst[1:]
+            assert inst[1:] == root_inputs
+            leaves.add(inst[0])
+        assert len(leaves) == 1024
+        ovk = oracle_vk(params, vk)
+        for u in users[::256]:
+            assert SV.verify(res.proofs[u][0], res.proofs[u][1], ovk), u
+        # a proof does not verify for another user's public inputs
+        a, b = users[0], users[1]
+        from circuits_halo2_amd import verifier as V
+        assert V.verify_proof(params, vk, res.proofs[a][0], res.proofs[a][1], "evm")
+        assert not V.verify_proof(params, vk, res.proofs[a][0], res.proofs[b][1], "evm")
+        print(f"1024 proofs at k = 17 in {dt:.2f} s = {1024 / dt:.1f} proofs/s (4 in flight, every proof re-verified)")
+    finally:
+        params.free()
