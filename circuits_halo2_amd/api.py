@@ -128,7 +128,10 @@ class MstInclusionCircuit:
     # --- Circuit::synthesize, through halo2's floor planner [REF merkle_sum_tree.rs:228-520]
     def synthesize(self, k: int):
         """the assignment of this circuit over 2^k rows in the reference's own floor plan: fixed columns, permutation,
-        advice columns, the values exposed as public inputs (mst_inclusion.reference_assignment)"""
+        advice columns, the values exposed as public inputs (mst_inclusion.reference_assignment).  As halo2's `synthesize`,
+        it lays out whatever witness it is given: a tampered entry, path index or an out-of-range balance yields advice
+        columns that violate the constraints, and a proof made from them is one the verifier rejects [REF
+        circuits/tests.rs:125-152, and the MockProver cases :158-433, restated in tests/test_mock_prover_cpu.py]"""
         if self._device is not None and self.entry is None:   # host view of a device-side circuit: fetch the Merkle proof
             mp = MstInclusionCircuit.init(self._device[0].generate_proof(self._device[1]), self.levels, self.n_currencies, self.n_bytes)
             self.entry, self.root = mp.entry, mp.root
@@ -138,7 +141,7 @@ class MstInclusionCircuit:
             self._assignment[k] = M.reference_assignment(k, self.entry[0], list(self.entry[1]), self.path_indices,
                                                           self.sibling_leaf_node_hash_preimage,
                                                           self.sibling_middle_node_hash_preimages[:max(0, self.levels - 1)],
-                                                          self.n_bytes)
+                                                          self.n_bytes, lenient=True)
         return self._assignment[k]
 
     def shape(self):

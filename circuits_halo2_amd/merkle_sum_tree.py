@@ -77,7 +77,14 @@ def parse_csv_to_entries(path: str, n_currencies: int):
     header, body = rows[0], rows[1:]
     if len(header) - 1 != n_currencies:
         raise ValueError(f"csv has {len(header) - 1} balance columns, N_CURRENCIES = {n_currencies}")
-    cryptocurrencies = [tuple(h.split("_")[1:3]) for h in header[1:]]
+    cryptocurrencies = []
+    for h in header[1:]:            # csv_parser.rs:17-31: `balance_<name>_<chain>`, anything else is an error
+        parts = h.split("_")
+        if len(parts) != 3 or parts[0] != "balance":
+            raise ValueError(f"Invalid header: {h}")
+        cryptocurrencies.append((parts[1], parts[2]))
+    if header[0] != "username":
+        raise ValueError("Username not found")
     def balance(text: str) -> int:
         # BigUint::parse_bytes(.., 10): decimal digits only -- no sign, blanks or underscores (csv_parser.rs:45-50)
         if not text or not text.isascii() or not text.isdigit():
@@ -147,8 +154,10 @@ class MerkleSumTree:
         for _, bal in entries:
             if len(bal) != n_currencies:
                 raise ValueError("entry with a wrong number of balances")
-            if any(b < 0 or b >= (1 << (8 * n_bytes)) for b in bal):
-                raise ValueError("balance does not fit N_BYTES")  # range the circuit can prove (mst.rs)
+            # mst.rs:103-134 builds the tree from any BigUint balances: one that does not fit N_BYTES only fails later, in
+            # the circuit's range check (circuits/tests.rs:268-299 builds its tree from entry_16_overflow.csv)
+            if any(b < 0 for b in bal):
+                raise ValueError("Invalid balance")
         depth = max(0, (n - 1).bit_length())
         size = 1 << depth
         users = bytearray(32 * size)      # zero entries: username 0, balances 0 (entry.rs:30-38)
@@ -234,6 +243,41 @@ class MerkleSumTree:
             self._set_node(level, parent, h, bsum)
             cur = parent
         return self.root()
+
+    def get_entry(self, index: int):
+        return self.entries[index]
+
+    def get_middle_node_hash_preimage(self, level: int, index: int) -> np.ndarray:
+        """tree.rs:22-56: [left.balances + right.balances ..., left.hash, right.hash] of the middle node (level, index) as
+        Montgomery bytes; "Invalid depth" for the leaf level or above the root, "Node not found" beyond the level's width"""
+        if level == 0 or level > self.depth:
+            raise ValueError("Invalid depth")
+        if not 0 <= index < (1 << (self.depth - level)):
+            raise IndexError("Node not found")
+        lh, _ = self.node(level - 1, 2 * index)
+        rh, _ = self.node(level - 1, 2 * index + 1)
+        return np.concatenate([self.node(level, index)[1], lh, rh])
+
+    def get_leaf_node_hash_preimage(self, index: int) -> np.ndarray:
+        """tree.rs:59-81: [username, balances ...] of entry `index` as Montgomery bytes"""
+        name, bal = self.get_entry(index)
+        u, b = self._entry_fields(name, bal)
+        return np.frombuffer(u + b, dtype=np.uint8).copy()
+
+    @staticmethod
+    def middle_node_from_preimage(preimage, n_currencies: int):
+        """node.rs:73-84 `Node::middle_node_from_preimage`: (hash, balances) with hash = H(preimage) on the device"""
+        pre = np.asarray(preimage, dtype=np.uint8)
+        bal = pre[:32 * n_currencies]
+        zeros = np.zeros(32 * n_currencies, dtype=np.uint8)
+        h, _ = _hash_batch("middle", pre[32 * n_currencies:], np.concatenate([bal, zeros]), n=1, nc=n_currencies)
+        return h, bal.copy()
+
+    @staticmethod
+    def leaf_node_from_preimage(preimage, n_currencies: int):
+        """node.rs:57-68 `Node::leaf_node_from_preimage`"""
+        pre = np.asarray(preimage, dtype=np.uint8)
+        return _hash_batch("leaf", pre[:32], pre[32:], n=1, nc=n_currencies), pre[32:].copy()
 
     def generate_proof(self, index: int):
         """tree.rs:85-137.  Besides the sibling nodes (hash, balances) the proof carries what the reference's

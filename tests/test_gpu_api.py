@@ -219,3 +219,83 @@ def test_params_read_rejects_points_off_the_curve(tmp_path):
         path.write_bytes(bytes(bad))
         with pytest.raises(ValueError, match="Failed to read params"):
             generate_setup_artifacts(K, str(path), MstInclusionCircuit.init_empty(LEVELS, N_CURRENCIES, N_BYTES))
+
+
+# --- the reference's MockProver cases [REF zk_prover/src/circuits/tests.rs:158-433] on the real prover: the same tampered
+# circuits, in the reference's floor plan, go through `full_prover` -- which, like upstream's create_proof, lays out and proves
+# whatever witness it is given -- and the verifier must reject the proof.  Beside each: halo2's constraint checker restated
+# (circuits_halo2_amd/mock_prover.py) on the product's own device-hashed tree reports exactly the failures the reference's
+# test expects (tests/test_mock_prover_cpu.py checks the same lists on the oracle's tree).
+def _tampered_case(artifacts, csv_name, tamper, expected_failures):
+    from circuits_halo2_amd.api import MstInclusionCircuit, full_prover, full_verifier
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    from circuits_halo2_amd.mock_prover import MockProver
+    from oracle import summa_verifier as SV
+    params, pk, vk = artifacts
+    tree = MerkleSumTree.from_csv(os.path.join(GOLDEN, csv_name), N_CURRENCIES, N_BYTES)
+    circuit = MstInclusionCircuit.init(tree.generate_proof(0), LEVELS)
+    instances = circuit.instances()
+    tamper(circuit, instances)
+    assert MockProver.run(K, circuit, instances).verify() == expected_failures
+    proof = full_prover(params, pk, circuit, instances)                     # "prover should not fail" (utils.rs:102)
+    assert len(proof) == 1632
+    assert not full_verifier(params, vk, proof, instances)
+    assert not SV.verify(proof, instances[0], oracle_vk(params, vk), flavour="blake2b")
+    # the untampered circuit of the same user, same keys: accepted (the rejection above is the witness's doing)
+    if csv_name == "entry_16.csv":
+        good = MstInclusionCircuit.init(tree.generate_proof(0), LEVELS)
+        assert MockProver.run(K, good, good.instances()).verify() == []
+        assert full_verifier(params, vk, full_prover(params, pk, good, good.instances()), good.instances())
+
+
+_SWAP = ("InRegion", (26, "assign nodes hashes per merkle tree level"), 0)
+_ROOT_HASH = ("InRegion", (121, "permute state"), 36)
+_LEAF0 = "0x167505f45c4ef4a0b051c30e881d2e8f881f26f5edb231396198a2cc1712f5ad"
+_LEAF1 = "0x2c688f624d2bca741a1c2ad1ad2880721fbfd1613bbc5fe3d2ba66eb672e3aab"
+
+
+def test_invalid_entry_balance_as_witness(artifacts):
+    """:158-229"""
+    def tamper(circuit, instances):
+        circuit.entry = (circuit.entry[0], [1000, 1000])
+    _tampered_case(artifacts, "entry_16.csv", tamper, [
+        ("Permutation", ("advice", 0), _SWAP), ("Permutation", ("advice", 0), _ROOT_HASH),
+        ("Permutation", ("advice", 2), ("InRegion", (111, "sum nodes balances per currency"), 0)),
+        ("Permutation", ("advice", 2), ("InRegion", (112, "sum nodes balances per currency"), 0)),
+    ] + [("Permutation", ("instance", 0), ("OutsideRegion", row)) for row in range(4)])
+
+
+def test_invalid_leaf_hash_as_instance(artifacts):
+    """:232-266"""
+    def tamper(circuit, instances):
+        instances[0][0] = 1000
+    _tampered_case(artifacts, "entry_16.csv", tamper, [("Permutation", ("advice", 0), _SWAP),
+                                                       ("Permutation", ("instance", 0), ("OutsideRegion", 0))])
+
+
+def test_balance_not_in_range(artifacts):
+    """:268-299: csv/entry_16_overflow.csv; the tree is built (mst.rs does not range-check), the circuit's range check fails"""
+    _tampered_case(artifacts, "entry_16_overflow.csv", lambda circuit, instances: None, [
+        ("Permutation", ("fixed", 2), ("OutsideRegion", 246)),
+        ("Permutation", ("advice", 0), ("InRegion", (21, "assign value to perform range check"), 8))])
+
+
+def test_non_binary_index(artifacts):
+    """:302-395"""
+    def tamper(circuit, instances):
+        circuit.path_indices[0] = 2
+    _tampered_case(artifacts, "entry_16.csv", tamper, [
+        ("ConstraintNotSatisfied", (6, "bool constraint"), 0, _SWAP, [(("advice", 2), 0, "0x2")]),
+        ("ConstraintNotSatisfied", (7, "swap constraint"), 0, _SWAP,
+         [(("advice", 0), 0, _LEAF0), (("advice", 0), 1, _LEAF1), (("advice", 1), 0, _LEAF1), (("advice", 2), 0, "0x2")]),
+        ("ConstraintNotSatisfied", (7, "swap constraint"), 1, _SWAP,
+         [(("advice", 0), 0, _LEAF0), (("advice", 1), 0, _LEAF1), (("advice", 1), 1, _LEAF0), (("advice", 2), 0, "0x2")]),
+        ("Permutation", ("advice", 0), _ROOT_HASH), ("Permutation", ("instance", 0), ("OutsideRegion", 1))])
+
+
+def test_swapping_index(artifacts):
+    """:398-433"""
+    def tamper(circuit, instances):
+        circuit.path_indices[0] = 1
+    _tampered_case(artifacts, "entry_16.csv", tamper, [("Permutation", ("advice", 0), _ROOT_HASH),
+                                                       ("Permutation", ("instance", 0), ("OutsideRegion", 1))])

@@ -99,3 +99,48 @@ def test_csv_balances_are_decimal_digits_only(tmp_path):
             parse_csv_to_entries(str(f), 2)
     with pytest.raises(ValueError):
         parse_csv_to_entries(str(good), 1)          # column count != N_CURRENCIES (the reference panics there)
+
+
+def _csv_tree(name, sort=False):
+    import csv
+    rows = [r for r in list(csv.reader(open(os.path.join(GOLDEN, name))))[1:] if r]
+    if sort:
+        rows.sort(key=lambda r: r[0].encode())
+    return rows, P.mst_build([P.mst_entry(r[0], [int(v) for v in r[1:]]) for r in rows])
+
+
+def test_oracle_tree_on_the_rest_of_the_references_mst_vectors():
+    """more reference-held pins of the oracle's tree [REF zk_prover/src/merkle_sum_tree/tests.rs]: entry_13.csv -> depth 4,
+    root balances 385969 / 459661 (:202-232); entry_17.csv -> depth 5, 556863 / 556863 (:234-263); the switched-order file has
+    the same totals under another root hash (:36-43); entry_16_modified.csv differs in one entry and, with that entry set
+    back to (2087, 79731), gives entry_16.csv's root (:69-95); the sorted tree keeps the totals (:112-131)"""
+    _, (r16, l16) = _csv_tree("entry_16.csv")
+    _, (r13, l13) = _csv_tree("entry_13.csv")
+    assert len(l13) - 1 == 4 and r13[1] == [385969, 459661] and r13[0] != 0
+    assert [n[1] for n in l13[0][13:]] == [[0, 0]] * 3 and len({n[0] for n in l13[0][13:]}) == 1        # three zero entries
+    _, (r17, l17) = _csv_tree("entry_17.csv")
+    assert len(l17) - 1 == 5 and r17[1] == [556863, 556863] and len(l17[0]) == 32
+    _, (rs, _) = _csv_tree("entry_16_switched_order.csv")
+    assert rs[1] == r16[1] and rs[0] != r16[0]
+    rows, (rm, _) = _csv_tree("entry_16_modified.csv")
+    assert rm[0] != r16[0]
+    rows = [[r[0], "2087", "79731"] if r[0] == "RkLzkDun" else r for r in rows]
+    assert P.mst_build([P.mst_entry(r[0], [int(v) for v in r[1:]]) for r in rows])[0] == r16
+    _, (rsorted, _) = _csv_tree("entry_16.csv", sort=True)
+    assert rsorted[1] == r16[1] and rsorted[0] != r16[0]
+
+
+def test_csv_header_rules(tmp_path):
+    """csv_parser.rs:17-31: a balance column is `balance_<name>_<chain>`"""
+    from circuits_halo2_amd.merkle_sum_tree import parse_csv_to_entries
+    f = tmp_path / "h.csv"
+    f.write_text("username,balance_ETH,balance_USDT_ETH\nalice,1,2\n")
+    with pytest.raises(ValueError, match="Invalid header: balance_ETH"):
+        parse_csv_to_entries(str(f), 2)
+    f.write_text("username,amount_ETH_ETH,balance_USDT_ETH\nalice,1,2\n")
+    with pytest.raises(ValueError, match="Invalid header"):
+        parse_csv_to_entries(str(f), 2)
+    for name in ("entry_13.csv", "entry_17.csv", "entry_16_bigints.csv", "entry_16_overflow.csv"):   # no final newline / a blank last line
+        entries, crypto = parse_csv_to_entries(os.path.join(GOLDEN, name), 2)
+        assert len(entries) == int(name.split("_")[1].split(".")[0]) and crypto == [("ETH", "ETH"), ("USDT", "ETH")]
+    assert parse_csv_to_entries(os.path.join(GOLDEN, "entry_16_overflow.csv"), 2)[0][0][1][0] == 5192296858534827628530496329220096
