@@ -354,6 +354,9 @@ class DeviceMerkleSumTree:
         ffi.check(ffi.lib().sg_mst_build_dev(ffi.dev_ptr(d_usernames), ffi.dev_ptr(d_balances), C.c_uint32(depth),
                                              C.c_uint32(n_currencies), ffi.dev_ptr(self.d_h), ffi.dev_ptr(self.d_b),
                                              ffi.current_stream_ptr()))
+        # the snapshot is read from other streams afterwards (proofs in flight run one stream per worker thread, and the
+        # first reader caches the root): the build -- one-off, tens of milliseconds -- is complete when the constructor returns
+        torch.cuda.current_stream().synchronize()
         self.offsets = [0]
         for level in range(depth):
             self.offsets.append(self.offsets[-1] + (size >> level))
