@@ -1617,8 +1617,12 @@ def test_merkle_sum_tree_vs_oracle(gpu, O, n, nc):
         assert (tree._b[32 * off * nc:32 * (off + m) * nc] == b).all()
         off += m
         m >>= 1
+    # the tree takes any BigUint balance (mst.rs:103-134; only the circuit's range check objects to one beyond N_BYTES:
+    # circuits/tests.rs:268-299); a negative one cannot exist
+    big = MerkleSumTree.from_entries([("x", [1 << 64] * nc)], nc, n_bytes=8)
+    assert bytes(big.node(0, 0)[1]) == fr_np([1 << 64] * nc).tobytes()
     with pytest.raises(ValueError):
-        MerkleSumTree.from_entries([("x", [1 << 64] * nc)], nc, n_bytes=8)
+        MerkleSumTree.from_entries([("x", [-1] * nc)], nc, n_bytes=8)
 
 
 # ---------------------------------------------------------------- the reference circuit's own constraint system
