@@ -16,6 +16,7 @@ back to.  Proofs differ run to run (the blinding factors come from the OS entrop
 from __future__ import annotations
 
 import os
+import threading
 from dataclasses import dataclass, field
 
 import ctypes as C
@@ -243,6 +244,14 @@ def _advice_columns(pk, circuit: MstInclusionCircuit):
 
 
 DRIVER = os.environ.get("SUMMA_PROVER_DRIVER", "native")    # "native": the library's compiled host driver; "python": prover.create_proof
+_tls = threading.local()      # .combine: this thread's proofs may share fused commitment jobs with other threads' (batch.py sets it)
+
+
+def set_commit_combining(on: bool) -> None:
+    """for the calling thread: let its proofs' commitment jobs be fused with those of proofs in flight on other threads
+    (the library's commit combiner; off by default -- a lone proof gains nothing from the bounded wait it implies)"""
+    _tls.combine = bool(on)
+
 
 
 def _create_proof(params, pk, circuit, instances, flavour: str) -> bytes:
@@ -252,7 +261,8 @@ def _create_proof(params, pk, circuit, instances, flavour: str) -> bytes:
     advice = _advice_columns(pk, circuit)
     if DRIVER == "native":
         # device-synthesized columns are fresh per proof: the prover may write its blinding rows into them
-        return P.create_proof_native(params, pk, advice, inst, flavour, sanity_checks=False, in_place=circuit._device is not None)
+        return P.create_proof_native(params, pk, advice, inst, flavour, sanity_checks=False, in_place=circuit._device is not None,
+                                     combine=getattr(_tls, "combine", False))
     transcript = P.EvmTranscriptWriter() if flavour == "evm" else P.Blake2bWrite()
     return P.create_proof(params, pk, advice, inst, transcript=transcript, sanity_checks=False)
 

@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -470,6 +473,7 @@ void sg_shutdown(void) {
     g_sh.params.clear();
     g_sh.device = -1;
     retired_device_memory_collect();
+    summa::prover::release_orphans();   // what the prover sessions of ended threads left behind
   }
   for (auto& l : g_lanes) l.mu.unlock();
 }
@@ -487,7 +491,10 @@ int sg_collect_retired(void) {
   for (auto& l : g_lanes) l.mu.lock();       // index order, no lane of our own held: no call is in flight meanwhile
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) retired_device_memory_collect();
+  if (e == hipSuccess) {
+    retired_device_memory_collect();
+    summa::prover::release_orphans();
+  }
   for (auto& l : g_lanes) l.mu.unlock();
   if (e != hipSuccess) return hip_fail("sg_collect_retired", e);
   return SG_OK;
@@ -862,11 +869,152 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
 }
 // the same with one basis per polynomial (0 = g, 1 = g_lagrange): e.g. the grand-product commitments (Lagrange)
 // and the random polynomial (coefficients) of one prover phase as ONE fused job
+// ---- commit combiner.  Proofs in flight on several host threads (circuits_halo2_amd/batch.py) each issue five commitment
+// jobs; alone, every job pays its own sort front-end, bucket reduction and host tail, and the jobs of different threads
+// compete for the chip.  A thread that has declared itself (sg_commit_combine_begin) hands its sg_commit_batch*_dev calls
+// to the combiner instead: the first caller to find no job running becomes the runner, waits a bounded time for the
+// other declared threads to arrive (they do: after one fused job all of them get their points at the same moment and
+// reach their next commitment together), takes EVERYTHING pending with the same SRS and length and runs it as ONE
+// fused job on a lane of its own; callers that arrive while a job runs form the next one.  No caller ever waits for a
+// thread that might not come -- only for a deadline -- so a failed or finished proof cannot block the others.
+struct CommitReq {
+  uint64_t srs;
+  size_t n, count;
+  const int* basis;
+  const void* const* scalars;
+  uint8_t* out;
+  hipEvent_t ready;      // recorded on the caller's stream after its inputs were enqueued
+  int rc = SG_OK;
+  bool done = false;
+  char err[256] = "";
+};
+struct Combiner {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<CommitReq*> pending;
+  bool running = false;
+  int members = 0;                       // threads between sg_commit_combine_begin and _end
+  std::atomic<int> wait_us{300};         // how long a runner waits for the other members (sg_set_param "commit.combine_wait_us")
+  std::atomic<uint64_t> jobs{0}, requests{0};   // statistics: fused jobs run, requests served
+};
+Combiner g_comb;
+thread_local bool t_combine = false;
+thread_local hipEvent_t t_ready = nullptr;
+
+static int commit_batch_mixed_core(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
+                                   void* stream, uint8_t* out_affine);
+
+// runs on the runner's thread: one fused job for all requests of `batch` (same SRS, same n)
+static void combiner_run(const std::vector<CommitReq*>& batch) {
+  std::vector<int> basis;
+  std::vector<const void*> scalars;
+  size_t total = 0;
+  for (CommitReq* r : batch) total += r->count;
+  basis.reserve(total);
+  scalars.reserve(total);
+  for (CommitReq* r : batch)
+    for (size_t i = 0; i < r->count; i++) {
+      basis.push_back(r->basis[i]);
+      scalars.push_back(r->scalars[i]);
+    }
+  std::vector<uint8_t> out(64 * total);
+  int rc;
+  {
+    LaneHold hold;     // the job's own lane: its stream waits for every member's inputs
+    rc = hold.rc;
+    if (rc == SG_OK) {
+      for (CommitReq* r : batch) {
+        hipError_t e = hipStreamWaitEvent(g_ctx->stream, r->ready, 0);
+        if (e != hipSuccess) { rc = hip_fail("commit combiner: stream wait", e); break; }
+      }
+    }
+    if (rc == SG_OK) rc = commit_batch_mixed_core(batch[0]->srs, basis.data(), scalars.data(), total, batch[0]->n, g_ctx->stream, out.data());
+  }
+  size_t at = 0;
+  for (CommitReq* r : batch) {
+    r->rc = rc;
+    if (rc == SG_OK) std::memcpy(r->out, out.data() + 64 * at, 64 * r->count);
+    else std::snprintf(r->err, sizeof r->err, "%s", g_err);
+    at += r->count;
+  }
+  g_comb.jobs.fetch_add(1);
+  g_comb.requests.fetch_add(batch.size());
+}
+
+static int commit_combined(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
+                           void* stream, uint8_t* out_affine) {
+  if (!t_ready) CHECK_HIP(hipEventCreateWithFlags(&t_ready, hipEventDisableTiming), "event");
+  CHECK_HIP(hipEventRecord(t_ready, pick_stream(stream)), "event");
+  CommitReq req{srs_handle, n, count, basis, d_scalars, out_affine, t_ready};
+  std::unique_lock<std::mutex> lk(g_comb.mu);
+  g_comb.pending.push_back(&req);
+  g_comb.cv.notify_all();                         // a runner waiting for stragglers counts again
+  while (!req.done) {
+    if (g_comb.running) {
+      g_comb.cv.wait(lk);
+      continue;
+    }
+    g_comb.running = true;                        // this thread runs the next job
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(g_comb.wait_us.load());
+    while ((int)g_comb.pending.size() < g_comb.members)
+      if (g_comb.cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    // everything pending with the first request's SRS and length, up to MAX_FUSED polynomials
+    std::vector<CommitReq*> batch;
+    size_t polys = 0;
+    CommitReq* first = g_comb.pending.front();
+    for (auto it = g_comb.pending.begin(); it != g_comb.pending.end();) {
+      CommitReq* r = *it;
+      if (r->srs == first->srs && r->n == first->n && polys + r->count <= MAX_FUSED) {
+        batch.push_back(r);
+        polys += r->count;
+        it = g_comb.pending.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    combiner_run(batch);
+    lk.lock();
+    for (CommitReq* r : batch) r->done = true;
+    g_comb.running = false;
+    g_comb.cv.notify_all();
+  }
+  if (req.rc != SG_OK) std::snprintf(g_err, sizeof g_err, "%s", req.err);
+  return req.rc;
+}
+
+int sg_commit_combine_begin(void) {
+  if (t_combine) return SG_OK;
+  t_combine = true;
+  std::lock_guard<std::mutex> lk(g_comb.mu);
+  g_comb.members++;
+  return SG_OK;
+}
+int sg_commit_combine_end(void) {
+  if (!t_combine) return SG_OK;
+  t_combine = false;
+  std::lock_guard<std::mutex> lk(g_comb.mu);
+  g_comb.members--;
+  g_comb.cv.notify_all();          // a runner waiting for this thread stops counting it
+  return SG_OK;
+}
+int sg_commit_combine_stats(uint64_t* jobs, uint64_t* requests) {
+  if (jobs) *jobs = g_comb.jobs.load();
+  if (requests) *requests = g_comb.requests.load();
+  return SG_OK;
+}
+
 int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
                               void* stream, uint8_t* out_affine) {
   if (count && (!d_scalars || !out_affine || !basis)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   for (size_t i = 0; i < count; i++)
     if ((n && !d_scalars[i]) || basis[i] < 0 || basis[i] > 2) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
+  if (t_combine && count && n && count <= MAX_FUSED && g_depth == 0)
+    return commit_combined(srs_handle, basis, d_scalars, count, n, stream, out_affine);
+  return commit_batch_mixed_core(srs_handle, basis, d_scalars, count, n, stream, out_affine);
+}
+static int commit_batch_mixed_core(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
+                                   void* stream, uint8_t* out_affine) {
   LOCKED_CTX();
   Srs srs_v;
   if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
@@ -2126,6 +2274,10 @@ int sg_set_param(const char* name, int value) {
   if (!name || value < 0) return fail(SG_ERR_INVALID, "sg_set_param: bad argument");
   if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_set_param: not from inside a call");
   const std::string s(name);
+  if (s == "commit.combine_wait_us") {   // how long the combiner's runner waits for the other declared threads
+    g_comb.wait_us.store(std::min(value, 100000));
+    return SG_OK;
+  }
   if (s == "lanes") {   // how many concurrent calls get a context of their own (1 .. 8); further callers wait for a lane
     if (value < 1 || value > kLanes) return fail(SG_ERR_INVALID, "sg_set_param: lanes in [1, 8]");
     g_lane_count.store(value);

@@ -274,7 +274,7 @@ def _native_key_locked(pk: ProvingKey, params) -> int:
 
 
 def create_proof_native(params, pk: ProvingKey, advice, instances, flavour: str = "evm", sanity_checks: bool = True,
-                        in_place: bool = False) -> bytes:
+                        in_place: bool = False, combine: bool = False) -> bytes:
     """`create_proof` by the library's compiled host driver (include/summa_prover.hpp behind the C ABI of
     include/summa_prover.h): same steps, same transcripts, same proofs as create_proof below, without the interpreter
     between the kernels -- and with the GIL released for the whole proof, so several can be in flight from Python
@@ -293,9 +293,17 @@ def create_proof_native(params, pk: ProvingKey, advice, instances, flavour: str 
     inst = ints_to_fr(list(instances)) if instances else np.zeros(0, dtype=np.uint8)
     out = np.zeros(2144, dtype=np.uint8)
     size = C.c_size_t(0)
-    rc = ffi.prover_lib().sp_create_proof(C.c_uint64(key), ptrs, ffi.ptr(inst) if len(instances) else None, C.c_uint32(len(instances)),
-                                          C.c_int(0 if flavour == "evm" else 1), C.c_int(1 if sanity_checks else 0),
-                                          ffi.current_stream_ptr(), ffi.ptr(out), C.c_size_t(out.size), C.byref(size))
+    # combine: this proof is one of several in flight on other threads (batch.prove_batch) -- its commitment jobs may be
+    # fused with theirs by the library's commit combiner (include/summa_gpu.h: sg_commit_combine_begin)
+    if combine:
+        ffi.check(ffi.lib().sg_commit_combine_begin())
+    try:
+        rc = ffi.prover_lib().sp_create_proof(C.c_uint64(key), ptrs, ffi.ptr(inst) if len(instances) else None, C.c_uint32(len(instances)),
+                                              C.c_int(0 if flavour == "evm" else 1), C.c_int(1 if sanity_checks else 0),
+                                              ffi.current_stream_ptr(), ffi.ptr(out), C.c_size_t(out.size), C.byref(size))
+    finally:
+        if combine:
+            ffi.check(ffi.lib().sg_commit_combine_end())
     if rc == -6:      # SG_ERR_WITNESS
         raise ValueError(ffi.prover_lib().sp_last_error().decode())
     ffi.check_prover(rc)

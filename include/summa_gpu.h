@@ -129,6 +129,16 @@ int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_sca
  * Lagrange- and coefficient-form polynomials as ONE fused job (fixed-base when both tables were precomputed) */
 int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
                               void* stream, uint8_t* out_affine);
+/* Commit combiner, for provers that keep several proofs in flight from several host threads (one proof per thread).  Between
+ * sg_commit_combine_begin() and sg_commit_combine_end() the calling thread's sg_commit_batch_mixed_dev calls may be FUSED with
+ * those of the other threads that declared themselves: whichever caller finds no job running waits a bounded time (parameter
+ * "commit.combine_wait_us", default 300) for the others to arrive, then everything pending with the same SRS and length
+ * runs as one job -- one sort front-end, one bucket reduction, one host tail for all of them.  Same commitments, same
+ * return values; a caller never waits for a thread that may not come, only for that deadline or for the running job.
+ * sg_commit_combine_stats: fused jobs run / requests served so far (requests / jobs = average fusion). */
+int sg_commit_combine_begin(void);
+int sg_commit_combine_end(void);
+int sg_commit_combine_stats(uint64_t* jobs, uint64_t* requests);
 /* Device pointers of a cached SRS (for callers that drive the *_dev entry points). */
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k);
 
@@ -414,6 +424,7 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
 int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                         uint8_t out_affine[64], sg_msm_timings* timings);
 /* name: "lanes" (1..8, default 4: concurrent calls that get a context of their own, see the conventions at the top),
+ * "commit.combine_wait_us" (see sg_commit_combine_begin),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
  * "ntt.max_single_log", "ntt.max_multi_log" */
 int sg_set_param(const char* name, int value);

@@ -19,6 +19,7 @@
 #include <functional>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -450,6 +451,34 @@ inline bool& session_gone() {   // trivially destructible, so still readable aft
   static thread_local bool gone = false;
   return gone;
 }
+// What a host thread's session leaves behind when the thread ends.  A thread-local destructor must not call into HIP: worker
+// threads are joined while the process shuts down, and hipFree from a thread's destructor then runs into the runtime's own
+// teardown (seen as a crash in amd::Context::svmFree with more worker threads than lanes).  So a dying session hands its
+// device columns, streams, events and pinned staging to this process-wide store; the next session on another thread takes
+// them from here before asking the runtime, and release_orphans() (sg_shutdown, with the device idle) returns them.
+struct Orphans {
+  std::mutex mu;
+  std::multimap<size_t, void*> pool;
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> events;
+  std::vector<std::pair<uint64_t*, size_t>> pinned;
+};
+inline Orphans& orphans() {
+  static Orphans* o = new Orphans();   // never destroyed: sessions may end after static destruction has begun
+  return *o;
+}
+inline void release_orphans() {
+  Orphans& o = orphans();
+  std::lock_guard<std::mutex> lk(o.mu);
+  for (auto& kv : o.pool) (void)hipFree(kv.second);
+  for (auto& p : o.pinned) (void)hipHostFree(p.first);
+  for (auto& st : o.streams) (void)hipStreamDestroy(st);
+  for (auto& e : o.events) (void)hipEventDestroy(e);
+  o.pool.clear();
+  o.pinned.clear();
+  o.streams.clear();
+  o.events.clear();
+}
 struct Session {
   hipStream_t main = nullptr;                 // NULL: HIP's default stream (single-threaded callers)
   hipStream_t side[2] = {nullptr, nullptr};
@@ -457,20 +486,51 @@ struct Session {
   std::multimap<size_t, void*> pool;          // freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device)
   uint64_t* pinned = nullptr;
   size_t pinned_cap = 0;
-  ~Session() {
-    for (auto& kv : pool) (void)hipFree(kv.second);
-    if (pinned) (void)hipHostFree(pinned);
+  ~Session() {   // no HIP calls here (see Orphans)
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    for (auto& kv : pool) o.pool.emplace(kv.first, kv.second);
+    if (pinned) o.pinned.emplace_back(pinned, pinned_cap);
     for (auto& st : side)
-      if (st) (void)hipStreamDestroy(st);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
+      if (st) o.streams.push_back(st);
+    if (ev_fork) o.events.push_back(ev_fork);
     for (auto& e : ev_join)
-      if (e) (void)hipEventDestroy(e);
+      if (e) o.events.push_back(e);
     session_gone() = true;
   }
 };
 inline Session& session() {
   static thread_local Session s;
   return s;
+}
+// a stream / an event for a new session: one an ended session left behind, else a new one
+inline hipStream_t adopt_or_create_stream(int priority) {
+  {
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (!o.streams.empty()) {
+      hipStream_t st = o.streams.back();
+      o.streams.pop_back();
+      return st;
+    }
+  }
+  hipStream_t st = nullptr;
+  hk(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority), "stream");
+  return st;
+}
+inline hipEvent_t adopt_or_create_event() {
+  {
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (!o.events.empty()) {
+      hipEvent_t e = o.events.back();
+      o.events.pop_back();
+      return e;
+    }
+  }
+  hipEvent_t e = nullptr;
+  hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+  return e;
 }
 inline hipStream_t main_stream() { return session().main; }
 struct StreamScope {   // run this thread's prover calls on `s` for the scope
@@ -509,7 +569,16 @@ struct DevCol {  // device column of Fr (Montgomery); owned unless borrowed from
       p = it->second;
       column_pool().erase(it);
     } else {
-      hk(hipMalloc(&p, 32 * r), "hipMalloc");
+      {
+        Orphans& o = orphans();
+        std::lock_guard<std::mutex> lk(o.mu);
+        auto ot = o.pool.find(r);
+        if (ot != o.pool.end()) {
+          p = ot->second;
+          o.pool.erase(ot);
+        }
+      }
+      if (!p) hk(hipMalloc(&p, 32 * r), "hipMalloc");
     }
   }
   DevCol(const DevCol&) = delete;
@@ -801,10 +870,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const char* v = std::getenv("SG_SIDE_PRIORITY");
       const int prio = (v && v[0] == '0') ? 0 : least;
-      for (auto& st : side_streams) hk(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio), "stream");
+      for (auto& st : side_streams) st = adopt_or_create_stream(prio);
     }
-    hk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "event");
-    for (auto& e : ev_join) hk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+    ev_fork = adopt_or_create_event();
+    for (auto& e : ev_join) e = adopt_or_create_event();
   }
   // SG_PROVER_SERIAL (development aid): everything on the main stream, so that a kernel trace shows every kernel alone
   const bool serial = std::getenv("SG_PROVER_SERIAL") != nullptr;
