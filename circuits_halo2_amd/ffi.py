@@ -92,7 +92,7 @@ def current_stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 # C ABI of the compiled-host prover (include/summa_prover.h), exported by the same library
-PROVER_EXPORTS = ["sp_key_create", "sp_key_destroy", "sp_create_proof", "sp_last_error"]
+PROVER_EXPORTS = ["sp_key_create", "sp_key_destroy", "sp_create_proof", "sp_last_error", "sp_verify_proof", "sp_verify_last_error"]
 
 
 def prover_lib():
@@ -101,6 +101,7 @@ def prover_lib():
         for name in PROVER_EXPORTS:
             getattr(L, name)
         L.sp_last_error.restype = C.c_char_p
+        L.sp_verify_last_error.restype = C.c_char_p
         L._sp_ready = True
     return L
 

@@ -16,6 +16,7 @@ with the same scaling by 1 / Z_{T \\ S_0}(mu) as the reference's generated verif
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -152,11 +153,49 @@ def _expected_h_eval(evals, ch, lag, n_currencies: int) -> int:
     return acc * _inv((lag["x_n"] - 1) % R) % R
 
 
-def verify_proof(params, vk, proof: bytes, instances, flavour: str = "evm") -> bool:
+DRIVER = os.environ.get("SUMMA_VERIFIER_DRIVER", "native")   # "native": sp_verify_proof, the library's compiled verifier; "python": the twin below
+
+
+def verify_proof_native(params, vk, proof: bytes, instances, flavour: str = "evm") -> bool:
+    """the same check by the library's compiled host code (include/summa_prover.h: sp_verify_proof; csrc/verifier_abi.hip):
+    no interpreter in the loop and the GIL released, so that the re-verification of every proof (`create_proof_checked`)
+    does not serialise the proofs in flight of a batch"""
+    if flavour not in ("evm", "blake2b"):
+        raise ValueError("flavour: evm or blake2b")
+    if any(not 0 <= int(v) < R for v in instances) or len(params.g2) != 128 or len(params.s_g2) != 128:
+        return False
+    cached = getattr(vk, "_native_view", None)
+    if cached is None:
+        pts = lambda comms: np.frombuffer(b"".join(_g1_bytes(tuple(c)) for c in comms), dtype=np.uint8).copy()
+        cached = (np.frombuffer(int(vk.transcript_repr).to_bytes(32, "big"), dtype=np.uint8).copy(), pts(vk.fixed_comms),
+                  pts(vk.permutation_comms))
+        try:
+            vk._native_view = cached
+        except AttributeError:
+            pass
+    digest, fixed, perm = cached
+    g2 = np.frombuffer(bytes(params.g2), dtype=np.uint8).copy()
+    s_g2 = np.frombuffer(bytes(params.s_g2), dtype=np.uint8).copy()
+    raw = np.frombuffer(bytes(proof), dtype=np.uint8).copy() if len(proof) else np.zeros(1, dtype=np.uint8)
+    inst = np.frombuffer(b"".join(_fr_bytes(int(v)) for v in instances), dtype=np.uint8).copy() if len(instances) else np.zeros(1, dtype=np.uint8)
+    ok = C.c_int(0)
+    L = ffi.prover_lib()
+    rc = L.sp_verify_proof(C.c_uint32(vk.k), C.c_uint32(vk.n_currencies), ffi.ptr(digest), ffi.ptr(fixed), ffi.ptr(perm), ffi.ptr(g2),
+                           ffi.ptr(s_g2), ffi.ptr(raw), C.c_size_t(len(proof)), ffi.ptr(inst), C.c_uint32(len(instances)),
+                           C.c_int(0 if flavour == "evm" else 1), C.byref(ok))
+    if rc != 0:
+        raise ffi.SummaGpuError(rc, L.sp_verify_last_error().decode())
+    return ok.value == 1
+
+
+def verify_proof(params, vk, proof: bytes, instances, flavour: str = "evm", driver: str | None = None) -> bool:
     """params: ParamsKZG with g2 / s_g2 (the verifier params); vk: api.VerifyingKey; instances: the instance column's
     values (integers < r).  True iff the proof is accepted.  A proof that cannot be checked -- malformed bytes, a point
     off the curve, a challenge that lands on the domain so that a denominator vanishes -- is a rejected proof, not an
-    exception (upstream's `verify_proof` returns Err for all of these); a missing library or GPU still raises."""
+    exception (upstream's `verify_proof` returns Err for all of these); a missing library or GPU still raises.
+    driver: "native" (default: the library's compiled verifier) or "python" (this file's twin of it, same steps)."""
+    if (driver or DRIVER) == "native":
+        return verify_proof_native(params, vk, proof, instances, flavour)
     if any(not 0 <= int(v) < R for v in instances) or len(params.g2) != 128 or len(params.s_g2) != 128:
         return False
     if len(instances) > (1 << vk.k) - (M.BLINDING_FACTORS + 1):      # halo2: Error::InstanceTooLarge

@@ -54,6 +54,20 @@ int sp_create_proof(uint64_t key, void* const* d_advice, const uint8_t* instance
 
 const char* sp_last_error(void);
 
+/* halo2's verify_proof::<KZG, VerifierSHPLONK, _, _, SingleStrategy> for this constraint system -- what `full_verifier`
+ * (utils.rs:110-131, Blake2b flavour) and `create_proof_checked` (utils.rs:181-193, Keccak flavour, run on EVERY proof the
+ * backend serves) do -- as compiled host code: transcript replay, Lagrange / instance evaluations, the constraint polynomials
+ * at x, SHPLONK's scalars; the group side is one 37-point sg_msm_g1 on the device and one sg_pairing_check.
+ * The verifying key is passed as data: k, N_CURRENCIES, vk.transcript_repr (32 B big-endian), the 11 fixed and 6 permutation
+ * commitments (64 B each, the ABI's point format), the parameters' g2 and s_g2 (128 B each, the SRS container's format).
+ * instances: n_instances x 32 B Montgomery Fr.  Returns SG_OK whenever the question could be answered: *accepted = 1 for a
+ * valid proof, 0 for anything else -- wrong length, a point off the curve, an unreduced scalar, a failed pairing check;
+ * other codes mean the machinery failed (no device, bad arguments), with the reason in sp_verify_last_error(). */
+int sp_verify_proof(uint32_t k, uint32_t n_currencies, const uint8_t vk_digest_be[32], const uint8_t* fixed_comms,
+                    const uint8_t* permutation_comms, const uint8_t g2[128], const uint8_t s_g2[128], const uint8_t* proof,
+                    size_t proof_len, const uint8_t* instances, uint32_t n_instances, int transcript, int* accepted);
+const char* sp_verify_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,7 @@ def oracle_msm(monkeypatch):
     from circuits_halo2_amd import verifier as V
     from oracle import oracle as O
     monkeypatch.setattr(V, "best_multiexp", lambda s, b: O.best_multiexp(np.ascontiguousarray(s), np.ascontiguousarray(b), 2))
+    monkeypatch.setattr(V, "DRIVER", "python")     # the twin of the compiled verifier (which runs its MSM on the GPU: tests/test_gpu_api.py)
     return V
 
 

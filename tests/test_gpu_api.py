@@ -299,3 +299,54 @@ def test_swapping_index(artifacts):
         circuit.path_indices[0] = 1
     _tampered_case(artifacts, "entry_16.csv", tamper, [("Permutation", ("advice", 0), _ROOT_HASH),
                                                        ("Permutation", ("instance", 0), ("OutsideRegion", 1))])
+
+
+def test_compiled_verifier_equals_its_python_twin(artifacts):
+    """sp_verify_proof (csrc/verifier_abi.hip, what `full_verifier` / `create_proof_checked` run) against verifier.py's
+    Python twin and the oracle's restated verifier: the reference's shipped proof K6 under the reference's key, GPU-made
+    proofs of both flavours, and the same rejections -- flipped bytes all over the proof, a changed public input, wrong
+    length, wrong flavour, an unreduced scalar, a point off the curve, another key"""
+    from circuits_halo2_amd import api, params as PM, verifier as V
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree
+    R = V.R
+    cases = []
+    # K6: the reference's own proof, key and SRS
+    tr = json.load(open(os.path.join(GOLDEN, "k6_verifier_trace.json")))["vk"]
+    comm = [(H(a), H(b)) for a, b in tr["commitments"]]
+    vk6 = api.VerifyingKey(11, 2, comm[:11], comm[11:], H(tr["vk_digest"]))
+    cd = json.load(open(os.path.join(GOLDEN, "k6_inclusion_proof_solidity_calldata.json")))
+    p6 = PM.ParamsKZG.read(open(SRS, "rb"))
+    cases.append((p6, vk6, bytes.fromhex(cd["proof"][2:]), [H(x) for x in cd["public_inputs"]], "evm"))
+    # proofs made here, both flavours
+    params, pk, vk = artifacts
+    circuit = api.MstInclusionCircuit.init(MerkleSumTree.from_csv(CSV, N_CURRENCIES, N_BYTES).generate_proof(3), LEVELS)
+    inst = circuit.instances()[0]
+    cases.append((params, vk, api._create_proof(params, pk, circuit, [inst], "evm"), inst, "evm"))
+    cases.append((params, vk, api.full_prover(params, pk, circuit, [inst]), inst, "blake2b"))
+    both = lambda *a: (V.verify_proof(*a, driver="native"), V.verify_proof(*a, driver="python"))
+    for prm, key, proof, pub, flavour in cases:
+        assert both(prm, key, proof, pub, flavour) == (True, True)
+        step = max(1, len(proof) // 41)
+        for off in list(range(0, len(proof), step)) + [len(proof) - 1]:
+            bad = bytearray(proof)
+            bad[off] ^= 0x04
+            assert both(prm, key, bytes(bad), pub, flavour) == (False, False), (flavour, off)
+        assert both(prm, key, proof, [pub[0], pub[1], pub[2] + 1, pub[3]], flavour) == (False, False)
+        assert both(prm, key, proof, pub[:3], flavour) == (False, False)
+        assert both(prm, key, proof[:-1], pub, flavour) == (False, False)
+        assert both(prm, key, proof + b"\0", pub, flavour) == (False, False)
+        assert both(prm, key, proof, pub, "blake2b" if flavour == "evm" else "evm") == (False, False)
+        assert both(prm, key, proof, [R] + pub[1:], flavour) == (False, False)
+        other = type(key)(key.k, key.n_currencies, key.fixed_comms, key.permutation_comms, (key.transcript_repr + 1) % R)
+        assert both(prm, other, proof, pub, flavour) == (False, False)
+        swapped = type(key)(key.k, key.n_currencies, key.fixed_comms[1:] + key.fixed_comms[:1], key.permutation_comms, key.transcript_repr)
+        assert both(prm, swapped, proof, pub, flavour) == (False, False)
+    # an unreduced evaluation (evm: scalar 0 of the proof set to r) and a first commitment off the curve
+    prm, key, proof, pub, flavour = cases[0]
+    bad = bytearray(proof)
+    bad[0x380:0x3a0] = R.to_bytes(32, "big")
+    assert both(prm, key, bytes(bad), pub, flavour) == (False, False)
+    bad = bytearray(proof)
+    bad[32:64] = (int.from_bytes(proof[32:64], "big") ^ 1).to_bytes(32, "big")
+    assert both(prm, key, bytes(bad), pub, flavour) == (False, False)
+    p6.free()
