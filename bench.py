@@ -147,8 +147,8 @@ def batch_extra(args, rank, world, coll_dev):
     # warm-up and pre-sweep (short batches): every lane's plans, every worker thread's session; the best in-flight setting
     # of the pre-sweep runs the headline batch
     sweep = {}
-    per = max(6 * world, min(48 * world, total // 8))
-    for in_flight in (1, 2, 3, 4):
+    per = max(6 * world, min(96 * world, total // 4))
+    for in_flight in (1, 2, 4, 8, 12, 16):
         timed_batch(users[:3 * in_flight * world], in_flight)
         done, errs, dt, _ = timed_batch(users[:per], in_flight)
         sweep[str(in_flight)] = {"proofs": done, "errors": errs, "seconds": dt, "proofs_per_s": done / dt if dt else 0.0}

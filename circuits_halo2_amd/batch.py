@@ -203,13 +203,19 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     in_flight: proofs in flight on this GPU, each on its own stream / worker thread.
     `prove(circuit) -> (proof, public_inputs)` and `make_circuit(user_index)` replace the default steps (the CPU tests
     of the scheduling inject stand-ins; the product path uses the API functions).
-    combine (default off; SUMMA_COMBINE_COMMITS=1): the commitment jobs of the proofs in flight are fused by the library's
-    commit combiner -- one sort front-end, bucket reduction and host tail per phase for all of them.  Measured on one
-    MI355X (profiles/r03_sweeps/commit_combiner.txt): 2.3 requests per fused job at four proofs in flight and 5 % FEWER
-    proofs per second than independent jobs, whose latency-bound phases already hide under the other proofs' kernels."""
+    combine (default: in_flight >= 6; SUMMA_COMBINE_COMMITS=0/1 overrides): the commitment jobs of the proofs in flight are
+    fused by the library's commit combiner (include/summa_gpu.h: sg_commit_combine_begin) -- one sort front-end, bucket
+    reduction and host tail per job for all of them.  It pays once enough proofs are in flight for full jobs to form
+    while one is running (profiles/r03_sweeps/commit_combiner.txt: 4 in flight 184 -> 174 proofs/s, 8: 189 -> 217,
+    16: 179 -> 227)."""
     import os
     if combine is None:
-        combine = os.environ.get("SUMMA_COMBINE_COMMITS", "0") == "1" and in_flight > 1 and prove is None
+        env = os.environ.get("SUMMA_COMBINE_COMMITS")
+        combine = (env == "1" or (env is None and in_flight >= 6)) and in_flight > 1 and prove is None
+    if combine:
+        from . import ffi
+        ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(in_flight)))
+        ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 5000))
     mine = deal(list(user_indices))
     res = BatchResult()
     if make_circuit is None:

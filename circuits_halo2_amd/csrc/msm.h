@@ -79,11 +79,11 @@ struct FixedTable {
 uint32_t fixed_window_bits_for(size_t n);
 hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c, FixedTable* out, hipStream_t stream);
 
-static constexpr size_t MAX_FUSED = 32;
+static constexpr size_t MAX_FUSED = 64;
 struct BatchPtrs {  // inputs of a fused batch (kernel argument)
   const fp_words* scalars[MAX_FUSED];
   const g1_affine_mem* bases[MAX_FUSED];
-  uint32_t diff_mask;  // bit m: MSM m is taken in difference form -- its digits are those of s[i] - s[i+1] (s[n] = 0) and
+  uint64_t diff_mask;  // bit m: MSM m is taken in difference form -- its digits are those of s[i] - s[i+1] (s[n] = 0) and
                        // its bases the inclusive prefix sums of the basis (see g1_prefix_sums)
 };
 
@@ -112,7 +112,7 @@ class MsmEngine {
   // the same over a precomputed window table (n <= tab.n): all M MSMs use the table's bases
   hipError_t enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
                                  hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
-                                 const g1_affine_mem* const* tables = nullptr, uint32_t diff_mask = 0);
+                                 const g1_affine_mem* const* tables = nullptr, uint64_t diff_mask = 0);
   size_t max_fused_fixed(const FixedTable& tab, size_t n) const;
   hipError_t enqueue_back();
   hipError_t finish();
@@ -134,7 +134,7 @@ class MsmEngine {
   };
   Job job_;
   const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs
-  uint32_t diff_mask_ = 0;             // likewise
+  uint64_t diff_mask_ = 0;             // likewise
   hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
   hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;

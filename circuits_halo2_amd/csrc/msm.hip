@@ -56,7 +56,7 @@ __global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __r
     f29 k = f29_zero();
     k.l[0] = 32;
     f29 v = f29_load_r256<Fr29>(scalars + i);                  // any 256-bit word value: bound < 6
-    if ((bp.diff_mask >> blockIdx.y) & 1u) {
+    if ((bp.diff_mask >> blockIdx.y) & 1ull) {
       // difference form: the scalar of row i is s[i] - s[i+1] (s[n] = 0), against the prefix-summed basis
       if (i + 1 < n) v = f29_sub<Fr29, 2>(v, f29_load_r256<Fr29>(scalars + i + 1));   // + 8r: bound < 14
     }
@@ -1240,7 +1240,7 @@ hipError_t build_window_table(const g1_affine_mem* d_bases, size_t n, uint32_t c
 
 hipError_t MsmEngine::enqueue_front_fixed(const fp_words* const* d_scalars, const FixedTable& tab, size_t M, size_t n,
                                           hipStream_t stream, uint8_t* out_affine, MsmTimings* tm,
-                                          const g1_affine_mem* const* tables, uint32_t diff_mask) {
+                                          const g1_affine_mem* const* tables, uint64_t diff_mask) {
   if (n > tab.n || !tab.table) return hipErrorInvalidValue;
   if (diff_mask && n != tab.n) return hipErrorInvalidValue;   // s[n] = 0 closes the telescoping sum only at full length
   const g1_affine_mem* bs[MAX_FUSED];

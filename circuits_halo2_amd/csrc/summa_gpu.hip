@@ -576,8 +576,8 @@ static int msm_batch_locked(const void* const* d_scalars, const void* const* d_b
     }
     const Group& g = groups[gi];
     if (tab) {  // d_bases then holds one window table per MSM (all with tab's plan)
-      uint32_t diff_mask = 0;
-      for (size_t m = 0; diff && m < g.count; m++) diff_mask |= (diff[g.first + m] ? 1u : 0u) << m;
+      uint64_t diff_mask = 0;
+      for (size_t m = 0; diff && m < g.count; m++) diff_mask |= (uint64_t)(diff[g.first + m] ? 1 : 0) << m;
       e = eng[k]->enqueue_front_fixed(reinterpret_cast<const fp_words* const*>(d_scalars + g.first), *tab, g.count,
                                       n[g.first], c.bstream[k], out_affine + 64 * g.first, nullptr,
                                       reinterpret_cast<const g1_affine_mem* const*>(d_bases + g.first), diff_mask);
@@ -892,9 +892,12 @@ struct Combiner {
   std::mutex mu;
   std::condition_variable cv;
   std::deque<CommitReq*> pending;
-  bool running = false;
+  int runners = 0;                       // fused jobs running now
+  int busy = 0;                          // requests inside those jobs
   int members = 0;                       // threads between sg_commit_combine_begin and _end
-  std::atomic<int> wait_us{300};         // how long a runner waits for the other members (sg_set_param "commit.combine_wait_us")
+  std::atomic<int> wait_us{300};         // how long a runner waits for requests to arrive (sg_set_param "commit.combine_wait_us")
+  std::atomic<int> target{4};            // ... or until this many are pending ("commit.combine_target")
+  std::atomic<int> max_runners{1};       // fused jobs that may run side by side, each on a lane of its own ("commit.combine_runners")
   std::atomic<uint64_t> jobs{0}, requests{0};   // statistics: fused jobs run, requests served
 };
 Combiner g_comb;
@@ -950,15 +953,23 @@ static int commit_combined(uint64_t srs_handle, const int* basis, const void* co
   g_comb.pending.push_back(&req);
   g_comb.cv.notify_all();                         // a runner waiting for stragglers counts again
   while (!req.done) {
-    if (g_comb.running) {
+    const bool mine_pending = std::find(g_comb.pending.begin(), g_comb.pending.end(), &req) != g_comb.pending.end();
+    if (!mine_pending || g_comb.runners >= g_comb.max_runners.load()) {   // my request is inside a running job, or no runner slot is free
       g_comb.cv.wait(lk);
       continue;
     }
-    g_comb.running = true;                        // this thread runs the next job
+    g_comb.runners++;                             // this thread runs the next job
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(g_comb.wait_us.load());
-    while ((int)g_comb.pending.size() < g_comb.members)
+    // wait for company: until `target` requests are pending, or every declared thread that is not inside a running job
+    // has arrived, or the deadline
+    while ((int)g_comb.pending.size() < std::min(g_comb.target.load(), g_comb.members - g_comb.busy))
       if (g_comb.cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
     // everything pending with the first request's SRS and length, up to MAX_FUSED polynomials
+    if (g_comb.pending.empty()) {   // another runner took everything meanwhile (this thread's request included)
+      g_comb.runners--;
+      g_comb.cv.notify_all();
+      continue;
+    }
     std::vector<CommitReq*> batch;
     size_t polys = 0;
     CommitReq* first = g_comb.pending.front();
@@ -972,11 +983,13 @@ static int commit_combined(uint64_t srs_handle, const int* basis, const void* co
         ++it;
       }
     }
+    g_comb.busy += (int)batch.size();
     lk.unlock();
     combiner_run(batch);
     lk.lock();
     for (CommitReq* r : batch) r->done = true;
-    g_comb.running = false;
+    g_comb.busy -= (int)batch.size();
+    g_comb.runners--;
     g_comb.cv.notify_all();
   }
   if (req.rc != SG_OK) std::snprintf(g_err, sizeof g_err, "%s", req.err);
@@ -2276,6 +2289,14 @@ int sg_set_param(const char* name, int value) {
   const std::string s(name);
   if (s == "commit.combine_wait_us") {   // how long the combiner's runner waits for the other declared threads
     g_comb.wait_us.store(std::min(value, 100000));
+    return SG_OK;
+  }
+  if (s == "commit.combine_target") {
+    g_comb.target.store(std::max(1, std::min(value, 32)));
+    return SG_OK;
+  }
+  if (s == "commit.combine_runners") {
+    g_comb.max_runners.store(std::max(1, std::min(value, 4)));
     return SG_OK;
   }
   if (s == "lanes") {   // how many concurrent calls get a context of their own (1 .. 8); further callers wait for a lane

@@ -254,10 +254,10 @@ def test_batch_of_1024_users_at_k17():
         tree = snapshot_tree(levels, nc)
         users = [(7919 * i + 13) % (1 << levels) for i in range(1024)]
         assert len(set(users)) == 1024
-        B.prove_batch(tree, users[:8], params, pk, levels, in_flight=4)          # warm: lanes, sessions
+        B.prove_batch(tree, users[:24], params, pk, levels, in_flight=12)        # warm: lanes, sessions
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = B.prove_batch(tree, users, params, pk, levels, flavour="evm", in_flight=4)
+        res = B.prove_batch(tree, users, params, pk, levels, flavour="evm", in_flight=12)   # twelve in flight: commitment jobs fused
         dt = time.perf_counter() - t0
         assert not res.errors and sorted(res.proofs) == sorted(users)
         root_inputs = None
@@ -277,6 +277,67 @@ def test_batch_of_1024_users_at_k17():
         from circuits_halo2_amd import verifier as V
         assert V.verify_proof(params, vk, res.proofs[a][0], res.proofs[a][1], "evm")
         assert not V.verify_proof(params, vk, res.proofs[a][0], res.proofs[b][1], "evm")
-        print(f"1024 proofs at k = 17 in {dt:.2f} s = {1024 / dt:.1f} proofs/s (4 in flight, every proof re-verified)")
+        print(f"1024 proofs at k = 17 in {dt:.2f} s = {1024 / dt:.1f} proofs/s (12 in flight, every proof re-verified)")
     finally:
         params.free()
+
+
+def test_commit_combiner_fuses_the_jobs_of_proofs_in_flight():
+    """sg_commit_combine_begin / _end: proofs in flight on eight threads hand their commitment jobs to the combiner; the
+    proofs are what they would be alone (each accepted by the product's verifier and the oracle's), requests outnumber
+    the fused jobs, and two keys of different sizes proving at the same time are never fused with each other (their jobs
+    differ in SRS and length) -- both batches come out right"""
+    _gpu()
+    import ctypes as C
+    import threading
+    import torch
+    from circuits_halo2_amd import api, arithmetic as A, batch as B, ffi
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.utils import random_fr_canonical
+    from oracle import summa_verifier as SV
+    from test_gpu_api import oracle_vk
+
+    def stats():
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        ffi.check(ffi.lib().sg_commit_combine_stats(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def snapshot(levels, nc, seed):
+        size = 1 << levels
+        bal = random_fr_canonical(seed, size * nc).reshape(-1, 32).copy()
+        bal[:, 4:] = 0
+        return DeviceMerkleSumTree(A.fr_random(bytes(range(32)), seed, size), A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda()), levels, nc)
+
+    setups = []
+    try:
+        for levels, k, seed in ((6, 12, 31), (5, 13, 32)):
+            params, pk, vk = api.generate_setup_artifacts(k, None, api.MstInclusionCircuit.init_empty(levels, 2))
+            setups.append((levels, params, pk, vk, snapshot(levels, 2, seed)))
+        j0, r0 = stats()
+        levels, params, pk, vk, tree = setups[0]
+        users = list(range(0, 64, 2))
+        res = B.prove_batch(tree, users, params, pk, levels, in_flight=8, combine=True)
+        j1, r1 = stats()
+        assert not res.errors and sorted(res.proofs) == users
+        assert r1 - r0 == 5 * len(users) and j1 - j0 < r1 - r0            # five commitment jobs per proof, fused
+        ovk = oracle_vk(params, vk)
+        assert all(SV.verify(p, i, ovk) for p, i in list(res.proofs.values())[::5])
+        # two keys at once, from two driver threads with four workers each
+        out = {}
+
+        def drive(idx):
+            lv, pr, key, _, tr = setups[idx]
+            out[idx] = B.prove_batch(tr, list(range(20)), pr, key, lv, in_flight=4, combine=True)
+        threads = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for idx in range(2):
+            lv, pr, key, vkey, tr = setups[idx]
+            assert not out[idx].errors and sorted(out[idx].proofs) == list(range(20))
+            ovk = oracle_vk(pr, vkey)
+            assert all(SV.verify(p, i, ovk) for p, i in list(out[idx].proofs.values())[::4])
+    finally:
+        for s_ in setups:
+            s_[1].free()
