@@ -575,14 +575,20 @@ hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_va
   if (!std::getenv("SG_GATES_GENERIC")) {   // a program known ahead of time: the straight-line kernel
     const unsigned blocks = (unsigned)((n_ext + 255) / 256);
     const size_t lds = (size_t)a.n_consts * 36;
-    const bool nc2 = is_program<MstGatesNc2>(p), nc1 = !nc2 && is_program<MstGatesNc1>(p);
-    if ((nc1 || nc2) && std::getenv("SG_GATES_DEBUG")) std::fprintf(stderr, "gates: ahead-of-time program MstGatesNc%d, %u blocks\n", nc2 ? 2 : 1, blocks);
-    if (nc2) {
-      gates_fixed_kernel<MstGatesNc2><<<blocks, 256, lds, stream>>>(a);
-      return hipGetLastError();
-    }
-    if (nc1) {
-      gates_fixed_kernel<MstGatesNc1><<<blocks, 256, lds, stream>>>(a);
+    // (tables for N_CURRENCIES = 1 .. 4: gates_mst_programs.inc; any other program runs in the interpreter below)
+    int which = 0;
+    auto launch = [&](auto tag, int nc) {
+      using PROG = decltype(tag);
+      if (which || !is_program<PROG>(p)) return;
+      which = nc;
+      gates_fixed_kernel<PROG><<<blocks, 256, lds, stream>>>(a);
+    };
+    launch(MstGatesNc2{}, 2);
+    launch(MstGatesNc1{}, 1);
+    launch(MstGatesNc3{}, 3);
+    launch(MstGatesNc4{}, 4);
+    if (which) {
+      if (std::getenv("SG_GATES_DEBUG")) std::fprintf(stderr, "gates: ahead-of-time program MstGatesNc%d, %u blocks\n", which, blocks);
       return hipGetLastError();
     }
   }

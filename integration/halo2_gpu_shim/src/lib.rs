@@ -82,6 +82,69 @@ extern "C" {
     ) -> c_int;
 }
 
+/// `sg_graph` of include/summa_gpu.h: the plain-struct image of halo2's `GraphEvaluator` (what `pk.ev` holds)
+#[repr(C)]
+pub struct SgGraph {
+    _opaque: [u8; 0], // laid out by include/summa_gpu.h; built by the code that walks `GraphEvaluator` (not part of this shim)
+}
+
+// The compiled-host prover and verifier for `MstInclusionCircuit` (include/summa_prover.h): what
+// `zk_prover/src/circuits/utils.rs` calls in place of `create_proof` / `verify_proof`
+extern "C" {
+    pub fn sp_key_create(
+        k: u32,
+        srs_handle: u64,
+        d_fixed_lagrange: *const *const c_void,
+        d_sigma_lagrange: *const *const c_void,
+        vk_digest_be: *const u8,
+        gates: *const SgGraph,
+        lookup_input: *const SgGraph,
+        gate_challenge_exponents: *const u32,
+        gate_challenge_counts: *const u32,
+        n_gate_challenges: u32,
+        stream: *mut c_void,
+        key_out: *mut u64,
+    ) -> c_int;
+    pub fn sp_key_destroy(key: u64) -> c_int;
+    pub fn sp_create_proof(
+        key: u64,
+        d_advice: *const *mut c_void,
+        instances: *const u8,
+        n_instances: u32,
+        transcript: c_int,
+        sanity_checks: c_int,
+        stream: *mut c_void,
+        proof_out: *mut u8,
+        proof_cap: size_t,
+        proof_len: *mut size_t,
+    ) -> c_int;
+    pub fn sp_last_error() -> *const c_char;
+    pub fn sp_verify_proof(
+        k: u32,
+        n_currencies: u32,
+        vk_digest_be: *const u8,
+        fixed_comms: *const u8,
+        permutation_comms: *const u8,
+        g2: *const u8,
+        s_g2: *const u8,
+        proof: *const u8,
+        proof_len: size_t,
+        instances: *const u8,
+        n_instances: u32,
+        transcript: c_int,
+        accepted: *mut c_int,
+    ) -> c_int;
+    pub fn sp_verify_last_error() -> *const c_char;
+    // a setup that arrives in device memory (RCCL broadcast), proofs in flight from several threads, memory hygiene
+    pub fn sg_srs_upload_dev(k: u32, d_g: *const c_void, d_g_lagrange: *const c_void, stream: *mut c_void, handle_out: *mut u64) -> c_int;
+    pub fn sg_srs_copy_dev(handle: u64, d_g_out: *mut c_void, d_g_lagrange_out: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn sg_commit_combine_begin() -> c_int;
+    pub fn sg_commit_combine_end() -> c_int;
+    pub fn sg_commit_combine_stats(jobs: *mut u64, requests: *mut u64) -> c_int;
+    pub fn sg_collect_retired() -> c_int;
+    pub fn sg_set_param(name: *const c_char, value: c_int) -> c_int;
+}
+
 const _: () = assert!(std::mem::size_of::<Fr>() == 32);
 const _: () = assert!(std::mem::size_of::<G1Affine>() == 64);
 

@@ -350,3 +350,48 @@ def test_compiled_verifier_equals_its_python_twin(artifacts):
     bad[32:64] = (int.from_bytes(proof[32:64], "big") ^ 1).to_bytes(32, "big")
     assert both(prm, key, bytes(bad), pub, flavour) == (False, False)
     p6.free()
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_other_currency_counts_prove_and_verify(nc, capfd):
+    """`MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>` for N_CURRENCIES other than the reference tests' 2 (its bench runs
+    1: benches/full_solvency_flow.rs:15; one sum gate and one Poseidon input per currency, so the gate program, the floor
+    plan, the verifying key's digest and the witness kernel all depend on it): key generation, a proof from the host
+    witness and one from the device witness, both flavours, accepted by the product's verifier and the oracle's; a proof
+    under another currency count's key is rejected; the gate block ran as the ahead-of-time kernel of that count"""
+    _gpu()
+    import torch
+    from circuits_halo2_amd import api, arithmetic as A
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.mock_prover import MockProver
+    from circuits_halo2_amd.utils import random_fr_canonical
+    from oracle import summa_verifier as SV
+    levels, k = 5, 12
+    size = 1 << levels
+    bal = random_fr_canonical(500 + nc, size * nc).reshape(-1, 32).copy()
+    bal[:, 4:] = 0
+    tree = DeviceMerkleSumTree(A.fr_random(bytes(range(32)), 40 + nc, size), A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda()), levels, nc)
+    params, pk, vk = api.generate_setup_artifacts(k, None, api.MstInclusionCircuit.init_empty(levels, nc))
+    try:
+        ovk = oracle_vk(params, vk)
+        host = api.MstInclusionCircuit.init(tree.generate_proof(9), levels)
+        assert host.n_currencies == nc and len(host.instances()[0]) == 2 + nc
+        assert MockProver.run(k, host, host.instances()).verify() == []
+        os.environ["SG_GATES_DEBUG"] = "1"
+        try:
+            proof, inst = api.gen_proof_solidity_calldata(params, pk, host)
+        finally:
+            os.environ.pop("SG_GATES_DEBUG", None)
+        assert f"ahead-of-time program MstGatesNc{nc}" in capfd.readouterr().err
+        assert SV.verify(proof, inst, ovk) and inst == tree.public_inputs(9)
+        dev = api.MstInclusionCircuit.init_from_tree(tree, 9)
+        blake = api.full_prover(params, pk, dev, dev.instances())
+        assert api.full_verifier(params, vk, blake, dev.instances()) and SV.verify(blake, inst, ovk, flavour="blake2b")
+        bad = list(inst)
+        bad[-1] = (bad[-1] + 1) % SV.R
+        assert not api.full_verifier(params, vk, blake, [bad])
+        other = api.VerifyingKey(vk.k, 2, vk.fixed_comms, vk.permutation_comms, vk.transcript_repr)   # the gate list of two currencies
+        from circuits_halo2_amd import verifier as V
+        assert not V.verify_proof(params, other, proof, inst, "evm") or nc == 2
+    finally:
+        params.free()

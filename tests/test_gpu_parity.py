@@ -827,7 +827,7 @@ def test_quad_cooperative_add_selftest(gpu):
     assert "mismatching lanes: 0 of" in out.stdout
 
 
-@pytest.mark.parametrize("nc", [1, 2])
+@pytest.mark.parametrize("nc", [1, 2, 3, 4])
 def test_ahead_of_time_gate_program_equals_the_interpreter(gpu, capfd, nc):
     """the reference circuit's gate programs are also compiled ahead of time (gates_mst_programs.inc: every instruction a
     template instantiation, values in registers); sg_quotient_gates* picks that kernel when the program it is given lowers

@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol():
     assert ffi.lib().sg_version().startswith(b"summa_gpu")
     # the compiled-host prover's ABI (include/summa_prover.h) lives in the same library
     prover_names = _declared_symbols("summa_prover.h", "sp_")
-    assert set(prover_names) == set(ffi.PROVER_EXPORTS) and len(prover_names) == 4
+    assert set(prover_names) == set(ffi.PROVER_EXPORTS) and len(prover_names) == 6
     for n in prover_names:
         assert hasattr(L, n), f"{n} declared in include/summa_prover.h but not exported"
     assert ffi.prover_lib().sp_last_error() == b""
