@@ -800,20 +800,23 @@ def main():
             # reported with nproc beside it); halo2's best_multiexp splits the points into one chunk per thread, so the thread
             # count changes the algorithm's window size too -- the 16-thread figure of the earlier rounds is kept beside it
             hs, hb = scal.cpu().numpy(), bases.cpu().numpy()
+            entries = []
             for cores in sorted({O.ncpu(), min(O.ncpu(), 16)}, reverse=True):
                 t1 = time.perf_counter()
                 ref = O.best_multiexp(hs, hb, cores)
                 cdt = time.perf_counter() - t1
                 ok = bool((ref == result).all()) if world == 1 else None
-                entry = {"value": n / cdt, "unit": "points/s", "cores": cores, "affinity_cores": O.ncpu(), "nproc": os.cpu_count(),
-                         "kind": "port",
-                         "sample": f"one full 2^{args.log_n} MSM on the same inputs ({cdt:.2f} s), "
-                                   f"halo2-shaped per-thread-chunked Pippenger (oracle/bn254_oracle.c)",
-                         "matches_gpu_result": ok}
-                if cores == O.ncpu():
-                    line["cpu_baseline"] = entry
-                else:
-                    line["cpu_baseline"]["with_16_threads"] = entry
+                entries.append({"value": n / cdt, "unit": "points/s", "cores": cores, "affinity_cores": O.ncpu(), "nproc": os.cpu_count(),
+                                "kind": "port",
+                                "sample": f"one full 2^{args.log_n} MSM on the same inputs ({cdt:.2f} s), "
+                                          f"halo2-shaped per-thread-chunked Pippenger (oracle/bn254_oracle.c)",
+                                "matches_gpu_result": ok})
+            # the baseline is the CPU's best showing: the faster of "one thread per core this process may use" and the 16
+            # threads of the earlier rounds (on a box whose affinity mask is wider than its CPU quota the former oversubscribes)
+            entries.sort(key=lambda e: -e["value"])
+            line["cpu_baseline"] = dict(entries[0])
+            if len(entries) > 1:
+                line["cpu_baseline"]["other_thread_count"] = entries[1]
         if strong_line is not None:
             line["msm_strong_scaling_2^23"] = strong_line
         if batch_line is not None:

@@ -16,6 +16,8 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("SUMMA_ORACLE_LIB"):        # another build of the same source (tests/test_sanitizers_cpu.py: liboracle_asan.so)
+        return os.environ["SUMMA_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "bn254_oracle.c")
     if force or not os.path.exists(so) or (

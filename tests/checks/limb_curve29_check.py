@@ -4,7 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import pyref as P
 exe = "/tmp/limb_curve29_check"
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_curve29_check.cpp")])
+# SG_CHECK_CXXFLAGS: other compiler flags for the driver (tests/test_sanitizers_cpu.py: -fsanitize=address,undefined)
+flags = os.environ.get("SG_CHECK_CXXFLAGS", "-O2").split()
+if flags != ["-O2"]:
+    exe += "_flagged"
+subprocess.check_call(["g++"] + flags + ["-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_curve29_check.cpp")])
 rnd = random.Random(7)
 def words(pt):
     b = P.g1_to_bytes(pt)

@@ -6,7 +6,11 @@ sys.path.insert(0, ROOT)
 from oracle import pyref as P
 M = (1 << 29) - 1
 exe = "/tmp/limb_f29_check"
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_f29_check.cpp")])
+# SG_CHECK_CXXFLAGS: other compiler flags for the driver (tests/test_sanitizers_cpu.py: -fsanitize=address,undefined)
+flags = os.environ.get("SG_CHECK_CXXFLAGS", "-O2").split()
+if flags != ["-O2"]:
+    exe += "_flagged"
+subprocess.check_call(["g++"] + flags + ["-std=c++17", "-o", exe, os.path.join(ROOT, "tests/checks/limb_f29_check.cpp")])
 def limbs(x): return [(x >> (29 * i)) & M if i < 8 else x >> (29 * i) for i in range(9)]
 def val(l): return sum(v << (29 * i) for i, v in enumerate(l))
 def lazy(x, rnd):
