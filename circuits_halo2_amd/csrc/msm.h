@@ -146,9 +146,11 @@ class MsmEngine {
   DevBuf<uint32_t> win_words_;
   DevBuf<uint32_t> part_entry_, ccnt_, coff_;  // two-pass sort: partitioned entries, coarse-bin counts / offsets
   DevBuf<uint16_t> part_fine_;
-  uint32_t* h_meta_ = nullptr;
+  uint32_t* h_meta_ = nullptr;   // page-locked, written by the scan kernels through d_hmeta_ (its device address)
+  uint32_t* d_hmeta_ = nullptr;
   size_t h_win_cap_ = 0;
-  uint32_t* h_win_ = nullptr;  // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window
+  uint32_t* h_win_ = nullptr;    // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window; written by the export kernels through d_hwin_
+  uint32_t* d_hwin_ = nullptr;
 };
 
 // FFT over G1 (N5): out = DFT_omega(in) [* scale], natural order; d_work: 2^log_n xyzz29_mem

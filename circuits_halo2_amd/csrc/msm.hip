@@ -177,36 +177,46 @@ __global__ void __launch_bounds__(256) msm_scan_sums(const uint32_t* __restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    bsum[2 * blockIdx.x] = s_a[0];
-    bsum[2 * blockIdx.x + 1] = s_t[0];
-    atomicMax(&meta[2], s_m[0]);
+    bsum[3 * blockIdx.x] = s_a[0];
+    bsum[3 * blockIdx.x + 1] = s_t[0];
+    bsum[3 * blockIdx.x + 2] = s_m[0];   // the largest count of the block (no atomic, nothing to zero beforehand)
   }
+  (void)meta;
 }
 // one workgroup: exclusive scan of the (<= 1024) block sums, totals into meta / the last slots
+// `host_meta` (optional): the three counters also go straight into page-locked host memory the device can write
+// (the host reads them after an event, no copy kernel in between)
 __global__ void __launch_bounds__(1024) msm_scan_blocks(uint32_t* __restrict__ bsum, uint32_t nblk, uint32_t NB,
                                                         uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
-                                                        uint32_t* __restrict__ meta) {
-  __shared__ uint32_t s_a[1024], s_t[1024];
+                                                        uint32_t* __restrict__ meta, volatile uint32_t* host_meta) {
+  __shared__ uint32_t s_a[1024], s_t[1024], s_m[1024];
   const uint32_t tid = threadIdx.x;
-  uint32_t a = tid < nblk ? bsum[2 * tid] : 0, t = tid < nblk ? bsum[2 * tid + 1] : 0;
-  s_a[tid] = a; s_t[tid] = t;
+  uint32_t a = tid < nblk ? bsum[3 * tid] : 0, t = tid < nblk ? bsum[3 * tid + 1] : 0;
+  s_a[tid] = a; s_t[tid] = t; s_m[tid] = tid < nblk ? bsum[3 * tid + 2] : 0;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t va = 0, vt = 0;
-    if (tid >= d) { va = s_a[tid - d]; vt = s_t[tid - d]; }
+    uint32_t va = 0, vt = 0, vm = 0;
+    if (tid >= d) { va = s_a[tid - d]; vt = s_t[tid - d]; vm = s_m[tid - d]; }
     __syncthreads();
-    s_a[tid] += va; s_t[tid] += vt;
+    s_a[tid] += va; s_t[tid] += vt; s_m[tid] = max(s_m[tid], vm);
     __syncthreads();
   }
   if (tid < nblk) {
-    bsum[2 * tid] = s_a[tid] - a;
-    bsum[2 * tid + 1] = s_t[tid] - t;
+    bsum[3 * tid] = s_a[tid] - a;
+    bsum[3 * tid + 1] = s_t[tid] - t;
   }
   if (tid == 1023) {
     if (off) off[NB] = s_a[tid];
     toff[NB] = s_t[tid];
     meta[0] = s_a[tid];
     meta[1] = s_t[tid];
+    meta[2] = s_m[tid];
+    if (host_meta) {
+      host_meta[0] = s_a[tid];
+      host_meta[1] = s_t[tid];
+      host_meta[2] = s_m[tid];
+      __threadfence_system();
+    }
   }
 }
 __global__ void __launch_bounds__(256) msm_scan_write(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(256) msm_scan_write(const uint32_t* __restrict
     s_a[tid] += va; s_t[tid] += vt;
     __syncthreads();
   }
-  uint32_t ra = bsum[2 * blockIdx.x] + s_a[tid] - a, rt = bsum[2 * blockIdx.x + 1] + s_t[tid] - t;
+  uint32_t ra = bsum[3 * blockIdx.x] + s_a[tid] - a, rt = bsum[3 * blockIdx.x + 1] + s_t[tid] - t;
 #pragma unroll
   for (uint32_t k = 0; k < SCAN_ITEMS; k++) {
     if (base + k < NB) {
@@ -798,12 +808,15 @@ __global__ void __launch_bounds__(32) msm_reduce2d_combine(const xyzz29_mem* __r
   if (t == 0) xyzz29_store(out + set, xyzz29_load(&lds[0]));
 }
 // canonical words of `count` XYZZ points for the host tail (32 words each)
+// (`out` is page-locked host memory mapped into the device: the words land where the host tail reads them)
 __global__ void msm_export_points(const xyzz29_mem* __restrict__ in, uint32_t count, uint32_t* __restrict__ out) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= count) return;
   uint32_t w[32];
   xyzz29_to_words(xyzz29_load(in + q), w);
-  for (int i = 0; i < 32; i++) out[32 * q + i] = w[i];
+  uint4* o = reinterpret_cast<uint4*>(out + 32 * q);
+  for (int i = 0; i < 8; i++) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  __threadfence_system();
 }
 
 // per-window (A, S, T) -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ each) for the
@@ -818,7 +831,9 @@ __global__ void msm_export_windows(ReduceOut in, uint32_t W, uint32_t has_t, uin
   } else {
     xyzz29_to_words(xyzz29_load((which == 0 ? in.a : which == 1 ? in.s : in.r) + j), w);
   }
-  for (int i = 0; i < 32; i++) out[32 * q + i] = w[i];
+  uint4* o = reinterpret_cast<uint4*>(out + 32 * q);
+  for (int i = 0; i < 8; i++) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  __threadfence_system();
 }
 
 // out[i] = scalars[i] * G  (ParamsKZG::setup's fixed-base products; also used to build
@@ -1127,7 +1142,8 @@ hipError_t MsmEngine::init() {
 static constexpr uint32_t SCAN_SMALL_PER = 4;   // x 1024 threads = 4 Ki buckets (beyond that the strided stores cost more than the launches saved)
 __global__ void __launch_bounds__(1024) msm_scan_small(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ ntask,
-                                                       uint32_t* __restrict__ toff, uint32_t* __restrict__ meta) {
+                                                       uint32_t* __restrict__ toff, uint32_t* __restrict__ meta,
+                                                       volatile uint32_t* host_meta) {
   __shared__ uint32_t s_a[1024], s_t[1024], s_m[1024];
   const uint32_t Lm1 = (1u << log_L) - 1, tid = threadIdx.x;
   const uint32_t per = (NB + 1023) / 1024, lo = min(tid * per, NB);
@@ -1168,21 +1184,26 @@ __global__ void __launch_bounds__(1024) msm_scan_small(const uint32_t* __restric
     meta[0] = s_a[tid];
     meta[1] = s_t[tid];
     meta[2] = s_m[tid];
+    if (host_meta) {
+      host_meta[0] = s_a[tid];
+      host_meta[1] = s_t[tid];
+      host_meta[2] = s_m[tid];
+      __threadfence_system();
+    }
   }
 }
 
-// exclusive scans over NB buckets (three small launches)
+// exclusive scans over NB buckets (one launch for small NB, else three); host_meta: see msm_scan_blocks
 static hipError_t launch_scan(const uint32_t* cnt, uint32_t NB, uint32_t log_L, uint32_t* off, uint32_t* ntask,
-                              uint32_t* toff, uint32_t* bsum, uint32_t* meta, hipStream_t stream) {
+                              uint32_t* toff, uint32_t* bsum, uint32_t* meta, hipStream_t stream, uint32_t* host_meta = nullptr) {
   if (NB <= SCAN_SMALL_PER * 1024) {
-    msm_scan_small<<<1, 1024, 0, stream>>>(cnt, NB, log_L, off, ntask, toff, meta);
+    msm_scan_small<<<1, 1024, 0, stream>>>(cnt, NB, log_L, off, ntask, toff, meta, host_meta);
     return hipGetLastError();
   }
   const uint32_t nblk = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   if (nblk > 1024) return hipErrorInvalidValue;
-  SG_TRY(hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), stream));
   msm_scan_sums<<<nblk, SCAN_THREADS, 0, stream>>>(cnt, NB, log_L, bsum, meta);
-  msm_scan_blocks<<<1, 1024, 0, stream>>>(bsum, nblk, NB, off, toff, meta);
+  msm_scan_blocks<<<1, 1024, 0, stream>>>(bsum, nblk, NB, off, toff, meta, host_meta);
   msm_scan_write<<<nblk, SCAN_THREADS, 0, stream>>>(cnt, NB, log_L, bsum, off, ntask, toff);
   return hipGetLastError();
 }
@@ -1353,7 +1374,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     SG_TRY(ccnt_.reserve((size_t)sets * B + 1));
     SG_TRY(coff_.reserve((size_t)sets * B + 1));
   }
-  SG_TRY(bsum_.reserve(2 * 1024));
+  SG_TRY(bsum_.reserve(3 * 1024));
   SG_TRY(counts_.reserve((size_t)NB + 1));
   SG_TRY(off_.reserve((size_t)NB + 1));
   for (int i = 0; i < 2; i++) {
@@ -1361,14 +1382,22 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     SG_TRY(toff_[i].reserve((size_t)NB + 1));
   }
   SG_TRY(meta_.reserve(16));
-  if (!h_meta_) SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t)));
-  if (h_win_cap_ < (size_t)W * 96) {
-    if (h_win_) (void)hipHostFree(h_win_);
-    h_win_ = nullptr;
-    SG_TRY(hipHostMalloc(&h_win_, (size_t)W * 96 * sizeof(uint32_t)));
-    h_win_cap_ = (size_t)W * 96;
+  // the counters and the window sums reach the host through page-locked memory the kernels write directly (mapped,
+  // coherent): no copy kernels between the producing kernel and the event the host waits for
+  if (!h_meta_) {
+    SG_TRY(hipHostMalloc(&h_meta_, 16 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    SG_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_hmeta_), h_meta_, 0));
   }
-  SG_TRY(win_words_.reserve((size_t)W * 96));
+  {
+    const size_t need = std::max<size_t>((size_t)W * 96, (size_t)W * 32 * 17);   // (A, S, T) per window, or bits + 1 points per set
+    if (h_win_cap_ < need) {
+      if (h_win_) (void)hipHostFree(h_win_);   // (the previous job has finished: finish() waited for its event)
+      h_win_ = nullptr;
+      SG_TRY(hipHostMalloc(&h_win_, need * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+      SG_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_hwin_), h_win_, 0));
+      h_win_cap_ = need;
+    }
+  }
   if (!ev_meta_) SG_TRY(hipEventCreateWithFlags(&ev_meta_, hipEventDisableTiming));
   if (!ev_done_) SG_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
   if (tm) {
@@ -1390,15 +1419,13 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
     const uint32_t F = 1u << shift, fs_threads = 512;
     msm_fine_sort<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
         part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p);
-    SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
-    SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
     SG_TRY(hipEventRecord(ev_meta_, stream));
   } else {
     msm_hist<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, 0, hist_.p);
     msm_hist_prefix<<<(NB + HP_BUCKETS - 1) / HP_BUCKETS, HP_BUCKETS * HP_GROUPS, 0, stream>>>(
         hist_.p, j.fixed ? W1 * P : P, nbw, NB, counts_.p);
-    SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream));
-    SG_TRY(hipMemcpyAsync(h_meta_, meta_.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
     SG_TRY(hipEventRecord(ev_meta_, stream));
     uint32_t log_R = std::min<uint32_t>(cfg_.log_scatter_rounds, c - 1);
     msm_scatter<<<dim3(W, P, 1u << log_R), 1024, (nbw >> log_R) * sizeof(uint32_t), stream>>>(
@@ -1434,7 +1461,8 @@ hipError_t MsmEngine::enqueue_back() {
   msm_accumulate<<<(ntasks_ub + at - 1) / at, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
                                                               toff_[0].p, order_.p, log_L, meta_.p, partial_[0].p);
   SG_TRY(hipEventSynchronize(ev_meta_));
-  const uint32_t ntasks = j.ntasks = h_meta_[1], max_cnt = j.max_cnt = h_meta_[2];
+  const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_blocks / msm_scan_small), complete with the event
+  const uint32_t ntasks = j.ntasks = hm[1], max_cnt = j.max_cnt = hm[2];
   if (!ntasks) {  // every digit was zero (the launches above found nothing to do)
     j.all_zero = true;
     return hipSuccess;
@@ -1503,8 +1531,7 @@ hipError_t MsmEngine::enqueue_back() {
       count = sets;
     }
     if (j.tm) SG_TRY(hipEventRecord(j.ev[4], stream));
-    msm_export_points<<<(count + 63) / 64, 64, 0, stream>>>(fin, count, win_words_.p);
-    SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 32 * count, hipMemcpyDeviceToHost, stream));
+    msm_export_points<<<(count + 63) / 64, 64, 0, stream>>>(fin, count, d_hwin_);
     SG_TRY(hipEventRecord(ev_done_, stream));
     return hipGetLastError();
   }
@@ -1539,15 +1566,16 @@ hipError_t MsmEngine::enqueue_back() {
   if (blocks > 1) {
     uint32_t T1 = 16;
     while (T1 < blocks) T1 <<= 1;
-    if (quad)
+    // level 1 is a handful of items per window whatever the job: always a latency chain, so its additions are
+    // quad-cooperative whenever the workgroup fits (3 * T1 * 4 lanes)
+    if (quad || T1 <= 64)
       msm_reduce_items<4><<<dim3(1, W), 3 * T1 * 4, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
     else
       msm_reduce_items<1><<<dim3(1, W), 3 * T1, (size_t)3 * T1 * sizeof(xyzz29_mem), stream>>>(lvl0, blocks, T1, lvl1);
     fin = lvl1;
   }
   if (j.tm) SG_TRY(hipEventRecord(j.ev[4], stream));
-  msm_export_windows<<<(3 * W + 63) / 64, 64, 0, stream>>>(fin, W, blocks > 1 ? 1u : 0u, win_words_.p);
-  SG_TRY(hipMemcpyAsync(h_win_, win_words_.p, sizeof(uint32_t) * 96 * W, hipMemcpyDeviceToHost, stream));
+  msm_export_windows<<<(3 * W + 63) / 64, 64, 0, stream>>>(fin, W, blocks > 1 ? 1u : 0u, d_hwin_);
   SG_TRY(hipEventRecord(ev_done_, stream));
   return hipGetLastError();
 }

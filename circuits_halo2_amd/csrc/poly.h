@@ -64,6 +64,10 @@ hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_
 // redrawn with attempt + 1 while >= r (~24 %); the accepted limbs are written as they are (a uniform value in any
 // fixed representation is uniform).  Blinding rows / the random polynomial of a proof, without host traffic.
 hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_words* d_out, hipStream_t stream);
+// `m` <= RANDOM_BATCH_MAX draws in one launch: draw d fills d_out[d] with n[d] elements of stream `first_stream_id + d`
+static constexpr uint32_t RANDOM_BATCH_MAX = 8;
+hipError_t poly_random_batch(const uint32_t key[8], uint64_t first_stream_id, uint32_t m, fp_words* const* d_out, const size_t* n,
+                             hipStream_t stream);
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,
                                 hipStream_t stream);
 }  // namespace sg

@@ -667,10 +667,19 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) 
   c += d; b ^= c; b = rotl32(b, 12); \
   a += b; d ^= a; d = rotl32(d, 8);  \
   c += d; b ^= c; b = rotl32(b, 7);
-__global__ void __launch_bounds__(256) fr_random_kernel(ChaChaKey key, uint32_t stream_lo, uint32_t stream_hi, size_t n,
-                                                        fp_words* __restrict__ out) {
+// blockIdx.y = draw d of a batch: stream id `stream + d`, its own length and output (one launch for the blinding rows of
+// several columns; a single draw is a batch of one)
+struct RandomBatch {
+  fp_words* out[RANDOM_BATCH_MAX];
+  uint32_t n[RANDOM_BATCH_MAX];
+};
+__global__ void __launch_bounds__(256) fr_random_kernel(ChaChaKey key, uint32_t stream_lo0, uint32_t stream_hi0, RandomBatch rb) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = rb.n[blockIdx.y];
   if (i >= n) return;
+  fp_words* __restrict__ out = rb.out[blockIdx.y];
+  const uint64_t stream_id = (((uint64_t)stream_hi0 << 32) | stream_lo0) + blockIdx.y;
+  const uint32_t stream_lo = (uint32_t)stream_id, stream_hi = (uint32_t)(stream_id >> 32);
   // r as 8 LE words
   const uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
   for (uint32_t attempt = 0;; attempt++) {
@@ -704,13 +713,27 @@ __global__ void __launch_bounds__(256) fr_random_kernel(ChaChaKey key, uint32_t 
   }
 }
 #undef SG_QR
-hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_words* d_out, hipStream_t stream) {
-  if (!n) return hipSuccess;
-  if (n >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // the block counter is the element index
+hipError_t poly_random_batch(const uint32_t key[8], uint64_t first_stream_id, uint32_t m, fp_words* const* d_out, const size_t* n,
+                             hipStream_t stream) {
+  if (!m) return hipSuccess;
+  if (m > RANDOM_BATCH_MAX) return hipErrorInvalidValue;
+  RandomBatch rb{};
+  size_t longest = 0;
+  for (uint32_t d = 0; d < m; d++) {
+    if (n[d] >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // the block counter is the element index
+    rb.out[d] = d_out[d];
+    rb.n[d] = (uint32_t)n[d];
+    longest = std::max(longest, n[d]);
+  }
+  if (!longest) return hipSuccess;
   ChaChaKey k;
   for (int t = 0; t < 8; t++) k.w[t] = key[t];
-  fr_random_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(k, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), n, d_out);
+  fr_random_kernel<<<dim3((unsigned)((longest + 255) / 256), m), 256, 0, stream>>>(k, (uint32_t)first_stream_id,
+                                                                                   (uint32_t)(first_stream_id >> 32), rb);
   return hipGetLastError();
+}
+hipError_t poly_random(const uint32_t key[8], uint64_t stream_id, size_t n, fp_words* d_out, hipStream_t stream) {
+  return poly_random_batch(key, stream_id, 1, &d_out, &n, stream);
 }
 
 // ------------------------------------------------------------------ lookup permutation for range tables

@@ -1135,6 +1135,39 @@ int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32],
   return SG_OK;
 }
 
+// the same out of place (d_out[i] = transform of d_in[i]; the inputs stay): what `lagrange_to_coeff` of a column that is
+// still needed in Lagrange form costs without a device-to-device copy in front of it
+int sg_ntt_fr_batch_oop_dev(const void* const* d_in, void* const* d_out, size_t count, const uint8_t omega[32], const uint8_t* divisor,
+                            uint32_t log_n, void* stream) {
+  if ((count && (!d_in || !d_out)) || !omega || log_n > 28) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: bad argument");
+  for (size_t i = 0; i < count; i++)
+    if (!d_in[i] || !d_out[i] || d_in[i] == d_out[i]) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: null or aliased vector");
+  const size_t n = (size_t)1 << log_n;
+  if (log_n < 1 || log_n > 18) {   // outside the batched plans: copy, then in place
+    for (size_t i = 0; i < count; i++)
+      CHECK_HIP(hipMemcpyAsync(d_out[i], d_in[i], n * 32, hipMemcpyDeviceToDevice, pick_stream(stream)), "D2D copy");
+    return sg_ntt_fr_batch_dev(d_out, count, omega, divisor, log_n, stream);
+  }
+  LOCKED_CTX();
+  Context& c = *g_ctx;
+  words8 w, dv;
+  std::memcpy(&w, omega, 32);
+  if (divisor) std::memcpy(&dv, divisor, 32);
+  hipStream_t s = pick_stream(stream);
+  for (size_t first = 0; first < count; first += NTT_BATCH_MAX) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - first);
+    fp_words* outs[NTT_BATCH_MAX];
+    const fp_words* ins[NTT_BATCH_MAX];
+    for (uint32_t i = 0; i < cnt; i++) {
+      outs[i] = static_cast<fp_words*>(d_out[first + i]);
+      ins[i] = static_cast<const fp_words*>(d_in[first + i]);
+    }
+    hipError_t e = c.ntt.transform_batch(outs, cnt, nullptr, log_n, w, divisor ? &dv : nullptr, s, ins, n);
+    if (e != hipSuccess) return hip_fail("ntt batch", e);
+  }
+  return SG_OK;
+}
+
 int sg_intt_fr_dev(void* d_a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n, void* stream) {
   if (!d_a || !omega_inv || !divisor) return fail(SG_ERR_INVALID, "sg_intt_fr: null argument");
   LOCKED_CTX();
@@ -1669,6 +1702,17 @@ int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, siz
   uint32_t k[8];
   std::memcpy(k, key, 32);
   hipError_t e = poly_random(k, stream_id, n, static_cast<fp_words*>(d_out), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("fr_random", e);
+  return SG_OK;
+}
+int sg_fr_random_batch_dev(const uint8_t key[32], uint64_t first_stream_id, void* const* d_out, const size_t* n, uint32_t m, void* stream) {
+  if (!key || (m && (!d_out || !n)) || m > RANDOM_BATCH_MAX) return fail(SG_ERR_INVALID, "sg_fr_random_batch: bad argument");
+  for (uint32_t d = 0; d < m; d++)
+    if (n[d] && !d_out[d]) return fail(SG_ERR_INVALID, "sg_fr_random_batch: null output");
+  LOCKED_CTX();
+  uint32_t k[8];
+  std::memcpy(k, key, 32);
+  hipError_t e = poly_random_batch(k, first_stream_id, m, reinterpret_cast<fp_words* const*>(d_out), n, pick_stream(stream));
   if (e != hipSuccess) return hip_fail("fr_random", e);
   return SG_OK;
 }

@@ -153,6 +153,11 @@ int sg_ntt_fr_dev(void* d_a, const uint8_t omega[32], uint32_t log_n, void* stre
 int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32], const uint8_t* divisor,
                         uint32_t log_n, void* stream);
 
+/* The same out of place: d_out[i] = transform of d_in[i], the inputs untouched (a column that is still needed in Lagrange
+ * form -- every advice column, every grand product -- is transformed without a device-to-device copy in front). */
+int sg_ntt_fr_batch_oop_dev(const void* const* d_in, void* const* d_out, size_t count, const uint8_t omega[32], const uint8_t* divisor,
+                            uint32_t log_n, void* stream);
+
 /* ---- N2: EvaluationDomain::ifft(a, omega_inv, log_n, divisor): best_fft with omega_inv,
  * then every element times `divisor` (n^-1 for lagrange_to_coeff). */
 int sg_intt_fr(uint8_t* a, const uint8_t omega_inv[32], const uint8_t divisor[32], uint32_t log_n);
@@ -246,6 +251,9 @@ int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t
  * on the device): element i = the first 32 bytes of block(key, counter = i, nonce = (attempt, stream_id)) with the top
  * two bits cleared, redrawn with attempt + 1 while >= r.  Deterministic in (key, stream_id, i). */
 int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream);
+/* m <= 8 draws in one launch: draw d fills d_out[d] with n[d] elements of stream `first_stream_id + d` (exactly what m calls
+ * of sg_fr_random_dev with consecutive stream ids produce: the blinding rows of a phase's columns cost one launch) */
+int sg_fr_random_batch_dev(const uint8_t key[32], uint64_t first_stream_id, void* const* d_out, const size_t* n, uint32_t m, void* stream);
 
 /* ---- first "next" row: device-resident helpers between NTTs and MSMs.
  * halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i

@@ -682,16 +682,17 @@ struct ProvingKey {
     }
     auto transform = [&](std::vector<DevCol>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext) {
       std::vector<void*> pc, pe;
+      std::vector<const void*> pl;
       for (auto& c : lag) {
         coeff.emplace_back(n);
-        hk(hipMemcpyAsync(coeff.back().p, c.p, 32 * n, hipMemcpyDeviceToDevice, main_stream()), "D2D");
         ext.emplace_back(ne);
+        pl.push_back(c.p);
         pc.push_back(coeff.back().p);
         pe.push_back(ext.back().p);
       }
       for (size_t i = 0; i < pc.size(); i += 16) {   // batched launches hold at most 16 vectors
         const size_t m = std::min<size_t>(16, pc.size() - i);
-        ck(sg_ntt_fr_batch_dev(pc.data() + i, m, omega_inv, n_inv, k, main_stream()), "iNTT batch");
+        ck(sg_ntt_fr_batch_oop_dev(pl.data() + i, pc.data() + i, m, omega_inv, n_inv, k, main_stream()), "iNTT batch");
         ck(sg_coeff_to_cosets_batch_dev(pc.data() + i, pe.data() + i, m, k, ext_k(), QUOTIENT_PIECES, main_stream()), "coset NTT batch");
       }
     };
@@ -852,8 +853,17 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   uint8_t key[32];
   os_random(key, 32);
   uint64_t draws = 0;
-  auto rand_rows = [&](DevCol& col, size_t first, size_t count) {
-    ck(sg_fr_random_dev(key, ++draws, col.at(first), count, main_stream()), "fr_random");
+  struct Rows { DevCol* col; size_t first, count; };
+  auto rand_rows = [&](std::initializer_list<Rows> list) {   // one launch; draw ids as if drawn one after the other
+    void* outs[8];
+    size_t counts[8];
+    uint32_t m = 0;
+    for (const Rows& r : list) {
+      outs[m] = r.col->at(r.first);
+      counts[m++] = r.count;
+    }
+    ck(sg_fr_random_batch_dev(key, draws + 1, outs, counts, m, main_stream()), "fr_random");
+    draws += m;
   };
   // two side streams: independent latency chains (the transforms of a phase under its commitments, the three grand
   // products, the rotation sets of the multi-open) run next to the main (null) stream; the library keeps its work
@@ -901,14 +911,13 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   };
   auto to_coeff_ext = [&](const std::vector<void*>& lag, std::vector<DevCol>& coeff, std::vector<DevCol>& ext, hipStream_t st) {
     std::vector<void*> pc, pe;
-    for (void* c : lag) {
+    for (size_t i = 0; i < lag.size(); i++) {
       coeff.emplace_back(n);
-      hk(hipMemcpyAsync(coeff.back().p, c, 32 * n, hipMemcpyDeviceToDevice, st), "D2D");
       ext.emplace_back(ne);
       pc.push_back(coeff.back().p);
       pe.push_back(ext.back().p);
     }
-    ck(sg_ntt_fr_batch_dev(pc.data(), pc.size(), omega_inv_b, n_inv_b, k, st), "iNTT batch");
+    ck(sg_ntt_fr_batch_oop_dev(lag.data(), pc.data(), pc.size(), omega_inv_b, n_inv_b, k, st), "iNTT batch");   // Lagrange columns stay
     ck(sg_coeff_to_cosets_batch_dev(pc.data(), pe.data(), pc.size(), k, ext_k, QUOTIENT_PIECES, st), "coset NTT batch");
   };
   auto commit_batch = [&](std::vector<void*> cols, std::vector<int> basis) {
@@ -928,7 +937,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     const void* cols[3] = {advice[0].p, advice[1].p, advice[2].p};
     ck(sg_fr_count_noncanonical_dev(cols, 3, n, noncanonical.p, main_stream()), "range check of the advice columns");
   }
-  for (auto& a : advice) rand_rows(a, u, n - u);
+  rand_rows({{&advice[0], u, n - u}, {&advice[1], u, n - u}, {&advice[2], u, n - u}});
   DevCol instance_col(n);
   instance_col.zero();
   if (!instances.empty()) instance_col.upload(instances.data(), 0, instances.size());
@@ -966,8 +975,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   } else {
     ck(prc, "lookup permutation");
   }
-  rand_rows(pin, u, n - u);
-  rand_rows(ptab, u, n - u);
+  rand_rows({{&pin, u, n - u}, {&ptab, u, n - u}});
   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
   mark("1: lookup columns ready, commit [a0 a1 a2 a' s'] issued");
   const std::vector<uint8_t> pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1, 1, 1, 2, 2});
@@ -1023,11 +1031,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     if (opt.sanity_checks && last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
   }
   mark("3: grand products closed (sanity reads)");
-  rand_rows(zs[0], u + 1, n - u - 1);
-  rand_rows(zs[1], u + 1, n - u - 1);
-  rand_rows(lz, u + 1, n - u - 1);
   DevCol random_poly(n);
-  rand_rows(random_poly, 0, n);
+  rand_rows({{&zs[0], u + 1, n - u - 1}, {&zs[1], u + 1, n - u - 1}, {&lz, u + 1, n - u - 1}, {&random_poly, 0, n}});
   std::vector<DevCol> co3, ex3;
   fork();
   to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
