@@ -14,9 +14,17 @@ struct NttConfig {
   // measured on MI355X (profiles/r01_sweeps/ntt_sweep*.txt): small tiles (several workgroups per CU
   // hide the barrier and load latency) beat fewer, longer passes: the kernel is product-bound
   uint32_t max_single_log = 11;  // largest transform done in one LDS-resident pass
-  uint32_t max_multi_log = 8;    // largest per-pass DFT length in multi-pass plans
+  uint32_t max_multi_log = 9;    // largest per-pass DFT length in multi-pass plans (2^17 = 2^9 x 2^8: two passes)
   uint32_t tile_log = 9;         // log2(elements per workgroup tile)  (2^9 * 36 B = 18 KiB LDS)
   uint32_t threads = 256;        // one butterfly per thread per stage at tile_log = 9
+  // throughput shape, for launches that fill the chip anyway (batches of >= batch_min vectors, transforms of >= 2^big_log):
+  // re-swept in round 3 with the round-2 closings in place (profiles/r03_sweeps/ntt_plans.txt) -- a lone 2^17 transform is
+  // three or two launches at their latency floor and wants many small workgroups; 16 of them, or 2^22 points, want
+  // wider tiles (two columns per 2^9-point DFT, coalesced 64-byte runs) on 512 threads
+  uint32_t big_tile_log = 10;
+  uint32_t big_threads = 512;
+  uint32_t batch_min = 4;
+  uint32_t big_log = 20;
 };
 
 #ifndef SG_WORDS8

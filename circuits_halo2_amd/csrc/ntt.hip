@@ -419,13 +419,15 @@ static uint32_t skippable_stages(const PassArgs& a, uint32_t log_n) {
 static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n, hipStream_t stream) {
   a.skip = skippable_stages(a, log_n);
   // tile width: as many contiguous columns as the LDS budget allows
-  uint32_t log_e = std::min<uint32_t>(cfg.tile_log, log_n);
+  const bool big = (a.nbatch >= cfg.batch_min || log_n >= cfg.big_log) && cfg.big_tile_log;
+  const uint32_t tile_log = big ? cfg.big_tile_log : cfg.tile_log, max_threads = big ? cfg.big_threads : cfg.threads;
+  uint32_t log_e = std::min<uint32_t>(tile_log, log_n);
   if (log_e < a.log_r) log_e = a.log_r;
   uint32_t log_t = std::min<uint32_t>(log_e - a.log_r, a.log_b);
   a.log_t = log_t;
   size_t E = (size_t)1 << (a.log_r + log_t);
   size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 8) * 36 + 64;
-  uint32_t threads = (uint32_t)std::min<size_t>(cfg.threads, std::max<size_t>(64, E / 2));
+  uint32_t threads = (uint32_t)std::min<size_t>(max_threads, std::max<size_t>(64, E / 2));
   uint32_t tiles = 1u << (log_n - a.log_r - log_t);
   hipLaunchKernelGGL(ntt_pass, dim3(tiles, a.nbatch ? a.nbatch : 1), dim3(threads), lds, stream, a);
   return hipGetLastError();

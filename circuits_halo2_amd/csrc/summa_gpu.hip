@@ -414,6 +414,10 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "msm.log_red_chunk") c.msm.config().log_red_chunk = c.msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
   else if (s == "ntt.tile_log") c.ntt.config().tile_log = (uint32_t)std::max(6, std::min(12, value));
   else if (s == "ntt.threads") c.ntt.config().threads = (uint32_t)std::max(64, std::min(1024, value));
+  else if (s == "ntt.big_tile_log") c.ntt.config().big_tile_log = value ? (uint32_t)std::max(6, std::min(12, value)) : 0u;   // 0: one shape for all
+  else if (s == "ntt.big_threads") c.ntt.config().big_threads = (uint32_t)std::max(64, std::min(1024, value));
+  else if (s == "ntt.batch_min") c.ntt.config().batch_min = (uint32_t)std::max(1, value);
+  else if (s == "ntt.big_log") c.ntt.config().big_log = (uint32_t)std::max(1, value);
   else if (s == "ntt.max_single_log") { c.ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); c.ntt.clear(); }
   else if (s == "ntt.max_multi_log") { c.ntt.config().max_multi_log = (uint32_t)std::max(4, std::min(12, value)); c.ntt.clear(); }
   else return fail(SG_ERR_INVALID, "sg_set_param: unknown parameter");
