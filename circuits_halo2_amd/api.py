@@ -75,6 +75,7 @@ class MstInclusionCircuit:
         self.root = root
         self._assignment = {}
         self._device = None       # (DeviceMerkleSumTree, user index): the witness is synthesized on the device
+        self._prefetched = None   # (advice columns, public inputs) laid out ahead of time with other users' (batch.py)
 
     @classmethod
     def init_empty(cls, levels: int, n_currencies: int = 2, n_bytes: int = 8) -> "MstInclusionCircuit":
@@ -122,6 +123,8 @@ class MstInclusionCircuit:
 
     def instances(self) -> list:
         """[[leaf hash, root hash, root balances..]]"""
+        if self._prefetched is not None:
+            return [list(self._prefetched[1])]
         if self._device is not None:
             return [self._device[0].public_inputs(self._device[1])]
         return [[self.leaf_hash(), self.root[0]] + list(self.root[1])]
@@ -236,6 +239,8 @@ def synthesize_on_device(pk, tree, user_indices):
 def _advice_columns(pk, circuit: MstInclusionCircuit):
     if getattr(pk, "circuit_shape", circuit.shape()) != circuit.shape():
         raise ValueError("the proving key was generated for a circuit of other dimensions")
+    if circuit._prefetched is not None:
+        return list(circuit._prefetched[0])
     if circuit._device is not None:
         adv = synthesize_on_device(pk, circuit._device[0], [circuit._device[1]])
         return [adv[0, j] for j in range(3)]

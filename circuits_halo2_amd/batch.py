@@ -184,6 +184,57 @@ def _workers(in_flight: int) -> ThreadPoolExecutor:
         return pool
 
 
+class _WitnessAhead:
+    """`Circuit::synthesize` for the batch's users a chunk at a time, ahead of the provers: one launch of the witness kernel
+    lays out the advice columns of `chunk` users of a device-resident snapshot (sg_mst_inclusion_witness_dev takes any
+    number of users; its duration is the latency of one Poseidon sponge chain, about a millisecond, whatever the count),
+    and one gather brings their public inputs.  Per proof that is 1 / chunk of a launch instead of a launch of its own.
+    A background thread keeps at most `ahead` chunks laid out beyond what the provers have taken."""
+
+    def __init__(self, tree, pk, users, chunk: int = 16, ahead: int = 3):
+        import torch
+        self.tree, self.pk, self.users = tree, pk, list(users)
+        self.chunk, self.ahead = chunk, ahead
+        self.ready, self.error = {}, None
+        self.cv = threading.Condition()
+        self.taken = 0
+        self.stream = torch.cuda.Stream()
+        self.thread = threading.Thread(target=self._run, name="witness-ahead", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        import torch
+        try:
+            with torch.cuda.stream(self.stream):
+                for first in range(0, len(self.users), self.chunk):
+                    with self.cv:
+                        self.cv.wait_for(lambda: first < self.taken + self.ahead * self.chunk)
+                    part = self.users[first:first + self.chunk]
+                    adv = api.synthesize_on_device(self.pk, self.tree, part)
+                    inst = self.tree.public_inputs_many(part)
+                    self.stream.synchronize()          # the provers read the columns on their own streams
+                    with self.cv:
+                        for j, u in enumerate(part):
+                            self.ready[u] = ([adv[j, c] for c in range(3)], inst[j])
+                        self.cv.notify_all()
+        except Exception as ex:   # handed to whoever waits
+            with self.cv:
+                self.error = ex
+                self.cv.notify_all()
+
+    def circuit(self, user: int):
+        with self.cv:
+            self.cv.wait_for(lambda: user in self.ready or self.error is not None)
+            if user not in self.ready:
+                raise self.error
+            got = self.ready.pop(user)
+            self.taken += 1
+            self.cv.notify_all()
+        c = api.MstInclusionCircuit.init_from_tree(self.tree, user)
+        c._prefetched = got
+        return c
+
+
 class BatchResult:
     def __init__(self):
         self.proofs = {}          # user index -> (proof bytes, public inputs)
@@ -220,7 +271,10 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     res = BatchResult()
     if make_circuit is None:
         if hasattr(tree, "d_h"):      # a device-resident snapshot: the witness never visits the host
-            make_circuit = lambda i: api.MstInclusionCircuit.init_from_tree(tree, i)
+            if len(mine) >= 8 and len(set(mine)) == len(mine) and hasattr(pk, "circuit_shape"):
+                make_circuit = _WitnessAhead(tree, pk, mine).circuit     # chunks of users per witness launch, ahead of the provers
+            else:
+                make_circuit = lambda i: api.MstInclusionCircuit.init_from_tree(tree, i)
         else:
             make_circuit = lambda i: api.MstInclusionCircuit.init(tree.generate_proof(i), levels)
     if prove is None:
