@@ -51,6 +51,16 @@ def main():
     print("kernels that run ALONE, by total time alone:")
     for name, t in alone.most_common(14):
         print(f"  {name:44s} {t / 1e3:9.1f} us  {100.0 * t / total:5.1f} % of the window")
+    tot = collections.Counter()
+    cnt = collections.Counter()
+    for r in rs:
+        if w0 <= r["start"] < w1:
+            name = r["name"].split("(")[0]
+            tot[name] += r["end"] - r["start"]
+            cnt[name] += 1
+    print("kernels by total duration in the window (concurrent kernels both count):")
+    for name, t in tot.most_common(24):
+        print(f"  {name:44s} {t / 1e3:10.1f} us  {cnt[name]:6d} launches  {100.0 * t / total:5.1f} % of the window")
     q = collections.Counter()
     for r in rs:
         if w0 <= r["start"] < w1:
