@@ -47,8 +47,10 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
 hipError_t poly_count_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_count, hipStream_t stream);
 // out[i] = sum_j coeffs[j] * polys[j][i], m <= LINCOMB_MAX
 static constexpr uint32_t LINCOMB_MAX = 32;
+// optionally + low[i] for i < n_low <= LINCOMB_LOW_MAX (a polynomial of a few coefficients, passed by value)
+static constexpr uint32_t LINCOMB_LOW_MAX = 8;
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
-                        hipStream_t stream);
+                        hipStream_t stream, const words8* low = nullptr, uint32_t n_low = 0);
 // halo2 lookup::prover::permute_expression_pair for range tables (every table value < 2^16), on the device:
 // A' = the input rows sorted, S' = the table rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1]
 // (first occurrences take their value from the table, the leftover table values fill the repeated rows in

@@ -449,6 +449,8 @@ __global__ void __launch_bounds__(256) kate_write_batch(KateBatch bt, uint32_t n
 struct LinCombArgs {
   const fp_words* polys[LINCOMB_MAX];
   words8 coeff[LINCOMB_MAX];
+  words8 low[LINCOMB_LOW_MAX];   // a polynomial of n_low coefficients added to the combination (memory-domain words)
+  uint32_t n_low;
 };
 __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgs a, uint32_t m, uint32_t n, fp_words* __restrict__ out) {
   __shared__ uint32_t s_c[LINCOMB_MAX][9];
@@ -474,6 +476,7 @@ __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgs a, uint32_t m,
     acc = f29_add(acc, f29_mul2<P>(p0, c0, p1, c1));          // bound grows by 2 per pair
     if ((j & 31) == 30) acc = f29_mul<P>(acc, f29_one<P>());   // keep the lazy sum far below 170 p... (tilde stays tilde)
   }
+  if (i < a.n_low) acc = f29_add(acc, f29_from_words<0>(a.low[i].l));   // the low-degree addend: a few rows only
   f29_store_canonical<P>(out + i, f29_mul<P>(acc, f29_one<P>()));
 }
 
@@ -645,14 +648,16 @@ hipError_t poly_kate_division_batch(const fp_words* const* d_a, size_t n, const 
   return hipGetLastError();
 }
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
-                        hipStream_t stream) {
-  if (m == 0 || m > LINCOMB_MAX) return hipErrorInvalidValue;
+                        hipStream_t stream, const words8* low, uint32_t n_low) {
+  if (m == 0 || m > LINCOMB_MAX || n_low > LINCOMB_LOW_MAX || n_low > n) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   LinCombArgs a;
   for (uint32_t j = 0; j < m; j++) {
     a.polys[j] = d_polys[j];
     a.coeff[j] = coeffs[j];
   }
+  a.n_low = n_low;
+  for (uint32_t t = 0; t < n_low; t++) a.low[t] = low[t];
   lincomb_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, m, (uint32_t)n, d_out);
   return hipGetLastError();
 }

@@ -1973,6 +1973,23 @@ int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_
   return SG_OK;
 }
 
+int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, const uint8_t* low, uint32_t n_low,
+                          void* d_out, void* stream) {
+  if (!d_polys || !coeffs || (n && !d_out) || (n_low && !low)) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: null argument");
+  if (m == 0 || m > LINCOMB_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: between 1 and 32 polynomials");
+  if (n >= (1ull << 32) || n_low > LINCOMB_LOW_MAX || n_low > n) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: bad length");
+  for (uint32_t j = 0; j < m; j++)
+    if (n && !d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: null polynomial");
+  LOCKED_CTX();
+  words8 cw[LINCOMB_MAX], lw[LINCOMB_LOW_MAX];
+  std::memcpy(cw, coeffs, 32 * (size_t)m);
+  if (n_low) std::memcpy(lw, low, 32 * (size_t)n_low);
+  hipError_t e = poly_lincomb(reinterpret_cast<const fp_words* const*>(d_polys), cw, m, n, static_cast<fp_words*>(d_out),
+                              pick_stream(stream), lw, n_low);
+  if (e != hipSuccess) return hip_fail("lincomb", e);
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
 // cosets = 0: the whole extended domain (row i = zeta omega_ext^i); cosets = c: coset-major arrays, block b = the 2^k rows
 // of the coset zeta omega_ext^b H

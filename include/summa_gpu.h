@@ -303,6 +303,11 @@ int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_
 int sg_fr_count_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_count, void* stream);
 /* out[i] = sum_j coeffs[j] * polys[j][i], 1 <= m <= 32 (the random linear combinations of the multi-open) */
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
+/* the same plus a polynomial of n_low <= 8 coefficients given by value (32 B Montgomery each): out[i] += low[i] for i < n_low.
+ * What SHPLONK's q_i(X) - r_i(X) needs -- r_i interpolates a rotation set's evaluations, at most four coefficients -- without
+ * a zeroed column, an upload and a second pass for it. */
+int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, const uint8_t* low, uint32_t n_low,
+                          void* d_out, void* stream);
 
 /* ---- the generic (circuit-independent) parts of halo2's `evaluate_h`
  * (halo2_proofs plonk/evaluation.rs, Evaluator::evaluate_h; the same terms, in the same

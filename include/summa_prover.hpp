@@ -1141,13 +1141,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // -- 6: SHPLONK
   const Fr zeta = tr.squeeze(), nu = tr.squeeze_again();
   const auto sets = rotation_sets();
-  std::vector<DevCol> qs, fs;
+  std::vector<DevCol> fs;
   std::vector<std::vector<Fr>> rs;
-  std::vector<DevCol> r_polys;
-  for (size_t i = 0; i < sets.size(); i++) {
-    r_polys.emplace_back(n);
-    r_polys.back().zero();
-  }
   // the Lagrange denominators prod_{j != i} (p_i - p_j) of every set depend only on x: one host inversion for all
   // of them (Montgomery's trick) instead of one 254-step exponentiation each
   std::vector<std::vector<Fr>> denom_inv(sets.size());
@@ -1175,10 +1170,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       inv = inv * v;
     }
   }
-  // r_i(X) through the set's (points, values) for every set first: host arithmetic on the evaluations alone.  The
-  // coefficients are staged in page-locked memory (4 rows per set), so the uploads below need no host synchronisation and
-  // the three streams are fed back to back
-  uint64_t* r_stage = pinned_rows(4 * sets.size());
+  // r_i(X) through the set's (points, values) for every set first: host arithmetic on the evaluations alone.  r_i has at most
+  // four coefficients: it enters the kernels BY VALUE (sg_fr_lincomb_low_dev), never as a column
   std::vector<std::vector<Fr>> zps(sets.size());
   for (size_t si = 0; si < sets.size(); si++) {
     const auto& set = sets[si];
@@ -1208,25 +1201,20 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       const Fr scale = vals[i] * denom_inv[si][i];
       for (size_t t = 0; t < basis.size(); t++) rc[t] = rc[t] + scale * basis[t];
     }
-    std::memcpy(r_stage + 16 * si, rc.data(), 32 * rc.size());
     rs.push_back(rc);
   }
   fork();
   for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
     const auto& set = sets[si];
     hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
-    DevCol& r_poly = r_polys[si];
     std::vector<void*> ps;
     for (size_t j = 0; j < set.polys.size(); j++) ps.push_back(poly.at(set.polys[j]));
-    qs.emplace_back(n);
-    ck(sg_fr_lincomb_dev(ps.data(), zps[si][0].bytes(), (uint32_t)ps.size(), n, qs.back().p, st), "set lincomb");
-    hk(hipMemcpyAsync(r_poly.p, r_stage + 16 * si, 32 * rs[si].size(), hipMemcpyHostToDevice, st), "H2D");
+    std::vector<Fr> minus_r;
+    for (const Fr& c : rs[si]) minus_r.push_back(-c);
+    // f_i = q_i - r_i in one pass: q_i = the zeta-combination of the set's polynomials, r_i by value
     fs.emplace_back(n);
-    {
-      void* two[2] = {qs.back().p, r_poly.p};
-      const Fr cf[2] = {Fr::one(), -Fr::one()};
-      ck(sg_fr_lincomb_dev(two, cf[0].bytes(), 2, n, fs.back().p, st), "q - r");
-    }
+    ck(sg_fr_lincomb_low_dev(ps.data(), zps[si][0].bytes(), (uint32_t)ps.size(), n, minus_r[0].bytes(), (uint32_t)minus_r.size(),
+                             fs.back().p, st), "set lincomb");
   }
   join();
   // f_i / Z_{S_i}: q_i - r_i vanishes on the whole set, and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with
@@ -1270,28 +1258,27 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   const Fr d0_inv = diffs[0].inv();
   Fr z_s0 = Fr::one();
   for (int r : sets[0].rots) z_s0 = z_s0 * mu_minus[r];
+  // L(X) = sum_i scale_i (q_i(X) - r_i(mu)) - Z_{S_0}(mu) f(X), with q_i = f_i + r_i:
+  //      = sum_i scale_i f_i(X) - Z_{S_0}(mu) f(X) + [ sum_i scale_i (r_i(X) - r_i(mu)) ]      (the bracket: at most four coefficients)
   std::vector<Fr> coeffs;
-  Fr konst = Fr::zero(), nu_pow = Fr::one();
+  std::vector<Fr> low(4, Fr::zero());
+  Fr nu_pow = Fr::one();
   for (size_t i = 0; i < sets.size(); i++) {
     const Fr scale = nu_pow * diffs[i] * d0_inv;
     coeffs.push_back(scale);
     Fr r_at_mu = Fr::zero();
     for (size_t t = rs[i].size(); t-- > 0;) r_at_mu = r_at_mu * mu + rs[i][t];
-    konst = konst + scale * r_at_mu;
+    for (size_t t = 0; t < rs[i].size(); t++) low[t] = low[t] + scale * rs[i][t];
+    low[0] = low[0] - scale * r_at_mu;
     nu_pow = nu_pow * nu;
   }
-  const Fr one = Fr::one();
-  DevCol& r_poly = r_polys[0];
-  hk(hipMemsetAsync(r_poly.p, 0, 32 * 4, main_stream()), "memset");
-  r_poly.upload(one.l, 0, 1);  // the constant polynomial 1
   std::vector<void*> lp;
-  for (auto& q : qs) lp.push_back(q.p);
+  for (auto& f : fs) lp.push_back(f.p);
   lp.push_back(f_all.p);
-  lp.push_back(r_poly.p);
   coeffs.push_back(-z_s0);
-  coeffs.push_back(-konst);
   DevCol l_poly(n), w2(n);
-  ck(sg_fr_lincomb_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, l_poly.p, main_stream()), "L lincomb");
+  ck(sg_fr_lincomb_low_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, low[0].bytes(), (uint32_t)low.size(), l_poly.p,
+                           main_stream()), "L lincomb");
   Fr rem;
   ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), main_stream()), "final division");
   if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Per-proof kernel totals from a rocprofv3 --kernel-trace directory of tools/create_proof_cpp (tools/prof_proof.sh):
-a proof = the kernels between the first blinding draws of two consecutive proofs (three 256-thread fr_random launches in
-a row open phase 1)."""
+a proof = the kernels between the first blinding draws of two consecutive proofs."""
 import collections, sys
 from msm_timeline import rocpd_rows
 
@@ -11,8 +10,11 @@ name = lambda r: r["name"].split("(")[0]
 grid = lambda r: int(r["grid_x"]) * int(r["grid_y"]) * int(r["grid_z"])
 starts = []
 for i in range(len(rows) - 3):
-    if all(name(rows[i + d]) == "sg::fr_random_kernel" for d in range(4)) and grid(rows[i + 3]) > 4096 and (i == 0 or name(rows[i - 1]) != "sg::fr_random_kernel"):
+    # round 3: the blinding rows of the three advice columns are ONE launch with grid.y = 3 (sg_fr_random_batch_dev)
+    if name(rows[i]) == "sg::fr_random_kernel" and int(rows[i]["grid_y"]) == 3:
         starts.append(i)
+    elif all(name(rows[i + d]) == "sg::fr_random_kernel" for d in range(4)) and grid(rows[i + 3]) > 4096 and (i == 0 or name(rows[i - 1]) != "sg::fr_random_kernel"):
+        starts.append(i)   # (traces of earlier rounds: three single launches open phase 1)
 print(f"# {len(starts)} proof starts found")
 for pi in range(max(0, len(starts) - 4), len(starts) - 1):
     seg = rows[starts[pi]:starts[pi + 1]]
