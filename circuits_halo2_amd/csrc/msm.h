@@ -26,6 +26,7 @@ struct MsmConfig {
   uint32_t merge_quad_tasks = 0xffffffffu;  // merge rounds with more tasks than this use one lane per addition even when `quad` holds
   uint32_t red2d_max_sets = 5; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh)
   uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
+  uint32_t red2d_fold = 8;     // ... whose line sums add up to this many partial sums per bucket themselves (no merge round below that)
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
 

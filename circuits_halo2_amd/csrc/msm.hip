@@ -742,6 +742,18 @@ __device__ __forceinline__ xyzz29 wg_sum(uint32_t n, F get, xyzz29_mem* lds) {
   tree_sum<Q>(lds, NL, lt, role, true);
   return xyzz29_load(&lds[0]);
 }
+// the same with `get(e, acc, role)` adding element e -- possibly several terms -- into the running sum itself
+template <int Q, typename F>
+__device__ __forceinline__ xyzz29 wg_sum_into(uint32_t n, F get, xyzz29_mem* lds) {
+  constexpr uint32_t NL = 256 / Q;  // logical threads
+  const uint32_t lt = threadIdx.x / Q, role = threadIdx.x % Q;
+  xyzz29 acc = xyzz29_identity();
+  for (uint32_t e = lt; e < n; e += NL) get(e, acc, role);
+  if (role == 0) xyzz29_store(&lds[lt], acc);
+  __syncthreads();
+  tree_sum<Q>(lds, NL, lt, role, true);
+  return xyzz29_load(&lds[0]);
+}
 // grid (rows + cols, sets): line sums.  lines[set * (rows + cols) + L]
 template <int Q>
 __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __restrict__ partial,
@@ -753,13 +765,14 @@ __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __re
   const uint32_t base = set << (sh.log_rows + sh.log_cols);
   const bool is_row = L < rows;
   const uint32_t n = is_row ? cols : rows;
-  auto get = [&](uint32_t e) {
+  // a bucket owns ntask[b] partial sums (one per accumulation task; several when the heavy-bucket merge was folded in
+  // here: the line sums add them on the way, which costs the few extra additions of a merge round without its launches)
+  auto get = [&](uint32_t e, xyzz29& acc, uint32_t role) {
     const uint32_t b = base + (is_row ? (L << sh.log_cols) + e : (e << sh.log_cols) + (L - rows));
-    xyzz29 v = xyzz29_identity();
-    if (ntask[b]) v = xyzz29_load(partial + toff[b]);
-    return v;
+    const uint32_t nt = ntask[b], t0 = toff[b];
+    for (uint32_t t = 0; t < nt; t++) add_q<Q>(acc, xyzz29_load(partial + t0 + t), role);
   };
-  xyzz29 sum = wg_sum<Q>(n, get, lds);
+  xyzz29 sum = wg_sum_into<Q>(n, get, lds);
   if (threadIdx.x == 0) xyzz29_store(lines + (size_t)set * (rows + cols) + L, sum);
 }
 // grid (log_rows + log_cols + 1, sets): WG j < log_cols: columns with bit j of lo set; next log_rows: rows with
@@ -1473,8 +1486,13 @@ hipError_t MsmEngine::enqueue_back() {
   const bool quad = cfg_.quad == 2 || (cfg_.quad == 1 && NB <= (1u << 18));  // measured crossover: tools/small_batches2.sh
   int lvl = 0, pbuf = 0;
   uint32_t items_ub = ntasks;  // upper bound of the number of partial sums alive at this level
-  // heavy buckets: fold their partial sums until every bucket owns at most one
-  for (uint32_t max_items = (max_cnt + (1u << log_L) - 1) >> log_L; max_items > 1;
+  // 2-D reduction (below) or the scan-based one?  Decided here because the 2-D line sums can add a bucket's few partial sums
+  // themselves: up to `fold` of them per bucket need no merge round (its launches -- three scans and the merge -- cost more
+  // than the extra additions inside a launch that runs anyway)
+  j.red2d = (cfg_.red2d && j.c >= 5) ? ((W <= cfg_.red2d_max_sets && Wm <= 4) ? 1u : (cfg_.red2d >= 2 ? 2u : 0u)) : 0u;
+  const uint32_t fold = j.red2d ? cfg_.red2d_fold : 1u;
+  // heavy buckets: fold their partial sums until every bucket owns at most `fold`
+  for (uint32_t max_items = (max_cnt + (1u << log_L) - 1) >> log_L; max_items > fold;
        max_items = (max_items + (1u << log_L) - 1) >> log_L) {
     const int nxt = 1 - lvl;
     SG_TRY(launch_scan(ntask_[lvl].p, NB, log_L, nullptr, ntask_[nxt].p, toff_[nxt].p, bsum_.p, meta_.p, stream));
@@ -1508,7 +1526,6 @@ hipError_t MsmEngine::enqueue_back() {
   // Measured (profiles/r01_sweeps): a clear win for up to 4 sets (k = 17 single commit: reduction 190 -> 90 us); with
   // many sets the tree sums waste lanes and the scan-based path below is faster, so the device-weights variant only
   // runs when forced (msm.red2d = 2).
-  j.red2d = (cfg_.red2d && j.c >= 5) ? ((W <= cfg_.red2d_max_sets && Wm <= 4) ? 1u : (cfg_.red2d >= 2 ? 2u : 0u)) : 0u;
   if (j.red2d) {
     const uint32_t bits = j.c - 1, sets = W;
     Reduce2dShape sh{(bits + 1) / 2, bits / 2};

@@ -409,6 +409,7 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "msm.acc_threads") c.msm.config().acc_threads = c.msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
   else if (s == "msm.merge_quad_tasks") c.msm.config().merge_quad_tasks = c.msm_b.config().merge_quad_tasks = (uint32_t)std::max(0, value);
   else if (s == "msm.red2d_max_sets") c.msm.config().red2d_max_sets = c.msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));
+  else if (s == "msm.red2d_fold") c.msm.config().red2d_fold = c.msm_b.config().red2d_fold = (uint32_t)std::min(256, std::max(1, value));
   else if (s == "msm.red2d") c.msm.config().red2d = c.msm_b.config().red2d = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.quad") c.msm.config().quad = c.msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.log_red_chunk") c.msm.config().log_red_chunk = c.msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);

@@ -1,0 +1,23 @@
+# whole-proof A/B of library tunables with the compiled prover (k = 17, best of 30 per run, baseline repeated between the others)
+set -e
+mkdir -p gpurun_out/r03g
+python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import torch
+from bench import snapshot_tree
+from circuits_halo2_amd import api, ffi, prover
+ffi.check(ffi.lib().sg_init(0))
+tree = snapshot_tree(20, 2)
+params, pk, vk = api.generate_setup_artifacts(17, None, api.MstInclusionCircuit.init_empty(20, 2, 8))
+c = api.MstInclusionCircuit.init_from_tree(tree, 5)
+adv = api._advice_columns(pk, c)
+prover.export_bundle("gpurun_out/r03g/bundle17.bin", params, pk, adv, c.instances()[0])
+PY
+run() { echo -n "$1 | "; env $1 ./tools/create_proof_cpp gpurun_out/r03g/bundle17.bin gpurun_out/r03g/proof.bin 30 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['create_proof_ms'])"; }
+for knob in "SG_PARAMS=msm.red2d_fold=1" "SG_PARAMS=msm.red2d_fold=2" "SG_PARAMS=msm.red2d_fold=4" "SG_PARAMS=msm.red2d_fold=1" "SG_PARAMS=msm.red2d_fold=4" "SG_PARAMS=ntt.batch_min=64" "SG_PARAMS=ntt.big_tile_log=11"; do
+  run "X=0"
+  run "$knob"
+done
+rm -f gpurun_out/r03g/bundle17.bin
+

@@ -18,8 +18,8 @@ for i in range(3):
     zlike.append(z.reshape(-1).contiguous())
 jobs = {"1 dense": (dense[:1], [0]), "5 dense": (dense, [0] * 5), "3 z-like + 1 dense": (zlike + dense[:1], [2, 2, 2, 0])}
 ref = {}
-for seg in (0, 4, 5, 6, 7, 8):
-    ffi.check(ffi.lib().sg_set_param(b"msm.log_seg", seg))
+for seg in (1, 2, 4, 8, 16, 1, 8):
+    ffi.check(ffi.lib().sg_set_param(b"msm.red2d_fold", seg))
     row = []
     for name, (cols, flags) in jobs.items():
         out = params.commit_batch_mixed(cols, flags)
@@ -28,4 +28,4 @@ for seg in (0, 4, 5, 6, 7, 8):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): params.commit_batch_mixed(cols, flags)
         torch.cuda.synchronize(); row.append(f"{name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
-    print(f"log_seg {seg} (0 = the rule) | " + " | ".join(row), flush=True)
+    print(f"red2d_fold {seg} | " + " | ".join(row), flush=True)
