@@ -198,6 +198,7 @@ class _WitnessAhead:
         self.ready, self.error = {}, None
         self.cv = threading.Condition()
         self.taken = 0
+        self.closed = False
         self.stream = torch.cuda.Stream()
         self.thread = threading.Thread(target=self._run, name="witness-ahead", daemon=True)
         self.thread.start()
@@ -208,7 +209,9 @@ class _WitnessAhead:
             with torch.cuda.stream(self.stream):
                 for first in range(0, len(self.users), self.chunk):
                     with self.cv:
-                        self.cv.wait_for(lambda: first < self.taken + self.ahead * self.chunk)
+                        self.cv.wait_for(lambda: self.closed or first < self.taken + self.ahead * self.chunk)
+                        if self.closed:
+                            return
                     part = self.users[first:first + self.chunk]
                     adv = api.synthesize_on_device(self.pk, self.tree, part)
                     inst = self.tree.public_inputs_many(part)
@@ -221,6 +224,13 @@ class _WitnessAhead:
             with self.cv:
                 self.error = ex
                 self.cv.notify_all()
+
+    def close(self):
+        """the batch is over (or failed): the producer stops, what it had laid out is dropped"""
+        with self.cv:
+            self.closed = True
+            self.ready.clear()
+            self.cv.notify_all()
 
     def circuit(self, user: int):
         with self.cv:
@@ -269,10 +279,12 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 5000))
     mine = deal(list(user_indices))
     res = BatchResult()
+    ahead = None
     if make_circuit is None:
         if hasattr(tree, "d_h"):      # a device-resident snapshot: the witness never visits the host
             if len(mine) >= 8 and len(set(mine)) == len(mine) and hasattr(pk, "circuit_shape"):
-                make_circuit = _WitnessAhead(tree, pk, mine).circuit     # chunks of users per witness launch, ahead of the provers
+                ahead = _WitnessAhead(tree, pk, mine)       # chunks of users per witness launch, ahead of the provers
+                make_circuit = ahead.circuit
             else:
                 make_circuit = lambda i: api.MstInclusionCircuit.init_from_tree(tree, i)
         else:
@@ -310,11 +322,15 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
                 res.errors[i] = repr(ex)
 
     t0 = time.perf_counter()
-    if in_flight <= 1:
-        for i in mine:
-            work(i)
-    else:
-        list(_workers(in_flight).map(work, mine))
+    try:
+        if in_flight <= 1:
+            for i in mine:
+                work(i)
+        else:
+            list(_workers(in_flight).map(work, mine))
+    finally:
+        if ahead is not None:
+            ahead.close()
     res.seconds = time.perf_counter() - t0
     return res
 

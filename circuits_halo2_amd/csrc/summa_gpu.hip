@@ -913,7 +913,18 @@ static int commit_batch_mixed_core(uint64_t srs_handle, const int* basis, const 
                                    void* stream, uint8_t* out_affine);
 
 // runs on the runner's thread: one fused job for all requests of `batch` (same SRS, same n)
+static void combiner_run_unguarded(const std::vector<CommitReq*>& batch);
 static void combiner_run(const std::vector<CommitReq*>& batch) {
+  try {
+    combiner_run_unguarded(batch);
+  } catch (const std::exception& e) {   // (allocation failures of the host vectors: every member learns of it)
+    for (CommitReq* r : batch) {
+      r->rc = SG_ERR_NOMEM;
+      std::snprintf(r->err, sizeof r->err, "commit combiner: %s", e.what());
+    }
+  }
+}
+static void combiner_run_unguarded(const std::vector<CommitReq*>& batch) {
   std::vector<int> basis;
   std::vector<const void*> scalars;
   size_t total = 0;

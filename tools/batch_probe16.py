@@ -1,5 +1,7 @@
+"""1024 inclusion proofs at k = 17 with 8 / 12 / 16 / 24 proofs in flight (default batch path: combiner, witnesses ahead),
+two repeats each; the last batch is checked by the oracle's verifier."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import snapshot_tree, oracle_vk
 from circuits_halo2_amd import api, batch as B

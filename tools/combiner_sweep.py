@@ -1,5 +1,7 @@
+"""Commit combiner sweep: 384 inclusion proofs at k = 17 (LEVELS = 20) with many proofs in flight, the combiner's target batch size,
+deadline and fused-job capacity varied (profiles/r03_sweeps/commit_combiner.txt); run on the GPU box."""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import snapshot_tree
 from circuits_halo2_amd import api, batch as B, ffi

@@ -1,6 +1,6 @@
 """fixed-base commitment jobs of a k = 17 proof (1 dense, 5 dense, 3 diff + 1 dense) under task lengths L = 2^log_seg"""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import circuits_halo2_amd as sg
 from circuits_halo2_amd import ffi

@@ -1,5 +1,7 @@
+"""Batch throughput against proofs in flight and library lanes, with and without the re-verification of every proof
+(profiles/r03_sweeps/commit_combiner.txt, second table); run on the GPU box."""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import snapshot_tree
 from circuits_halo2_amd import api, batch as B, ffi

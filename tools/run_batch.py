@@ -1,5 +1,7 @@
+"""One batch of inclusion proofs at k = 17 for traces: run_batch.py <in flight> <proofs> <combine 0|1>
+(rocprofv3 --kernel-trace -- python3 tools/run_batch.py 16 256 1, then tools/batch_concurrency.py)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import snapshot_tree
 from circuits_halo2_amd import batch as B
