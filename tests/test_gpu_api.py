@@ -180,6 +180,7 @@ def test_prove_from_csv_compiled_program(tmp_path, kat):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     print(info)
     assert (info["k"], info["levels"], info["n_currencies"], info["users"], info["rows_used"]) == (11, 4, 2, 16, 1489)
+    assert info["verified"] is True and info["verify_ms"] > 0          # create_proof_checked: verified by sp_verify_proof inside the program
     cd = json.load(open(out))
     want = [(H(a), H(b)) for a, b in kat["fixed_comms"] + kat["permutation_comms"]]
     assert [(H(a), H(b)) for a, b in cd["commitments"]] == want                  # the reference's verifying key

@@ -4,7 +4,8 @@
 // Steps: parse the CSV, hash the usernames (Keccak), build the Merkle sum tree on the device (sg_mst_build_dev), read /
 // downsize the parameters, lay out MstInclusionCircuit<LEVELS, N_CURRENCIES, 8> with the reference's floor plan
 // (include/summa_circuit.hpp), commit to its fixed and permutation columns (the verifying key), build the proving key's forms,
-// synthesize the user's witness on the device (sg_mst_inclusion_witness_dev), create_proof (Keccak transcript, SHPLONK).
+// synthesize the user's witness on the device (sg_mst_inclusion_witness_dev), create_proof (Keccak transcript, SHPLONK), and --
+// as create_proof_checked does [REF utils.rs:181-193] -- verify the proof right away (sp_verify_proof, the file's g2 / s_g2).
 //   build: hipcc -O2 -std=c++17 -Iinclude tools/prove_from_csv.cpp -o tools/prove_from_csv -Lcircuits_halo2_amd -lsumma_gpu
 //   usage: prove_from_csv <srs file> <csv> <user index> <k> <out.json> [vk digest as 0x.. (default: this build's digest)] [reps]
 #include <chrono>
@@ -14,6 +15,7 @@
 #include <sstream>
 
 #include "summa_circuit.hpp"
+#include "summa_prover.h"
 
 using namespace summa::prover;
 using namespace summa::circuit;
@@ -98,6 +100,10 @@ int main(int argc, char** argv) {
     sf.read(reinterpret_cast<char*>(g.data()), (std::streamsize)g.size());
     sf.read(reinterpret_cast<char*>(gl.data()), (std::streamsize)gl.size());
     if (!sf) throw std::runtime_error("Failed to read params");
+    uint8_t g2[128], s_g2[128];   // the verifier's side of the parameters: the container's last 256 bytes
+    sf.read(reinterpret_cast<char*>(g2), 128);
+    sf.read(reinterpret_cast<char*>(s_g2), 128);
+    if (!sf) throw std::runtime_error("Failed to read params");
     if (k_file > k) {
       g.resize(64 * n);
       gl.resize(64 * n);
@@ -155,7 +161,7 @@ int main(int argc, char** argv) {
     hk(hipMemcpy(instances[2].l, d_b.at((2 * size - 2) * nc), 32 * nc, hipMemcpyDeviceToHost), "D2H");
 
     std::vector<uint8_t> proof;
-    double best = 1e30, witness_ms = 0;
+    double best = 1e30, witness_ms = 0, verify_ms = 0;
     for (int r = 0; r < reps + 1; r++) {
       hk(hipDeviceSynchronize(), "sync");
       auto t0 = clk::now();
@@ -170,6 +176,16 @@ int main(int argc, char** argv) {
       if (r) best = std::min(best, ms_since(t0));
     }
 
+    // ---- create_proof_checked: the proof is verified before it is handed out
+    int accepted = 0;
+    {
+      const auto t0 = clk::now();
+      if (sp_verify_proof(k, nc, pk.vk_digest_be, comms[0].data(), comms[summa::prover::NUM_FIXED].data(), g2, s_g2, proof.data(), proof.size(),
+                          reinterpret_cast<const uint8_t*>(instances.data()), (uint32_t)instances.size(), SP_TRANSCRIPT_EVM, &accepted) != SG_OK)
+        throw std::runtime_error(std::string("verify_proof: ") + sp_verify_last_error());
+      verify_ms = ms_since(t0);
+      if (!accepted) throw std::runtime_error("the proof just made does not verify");
+    }
     // ---- calldata JSON (what gen_proof_solidity_calldata hands back) + the verifying key for whoever checks it
     std::ofstream out(out_path);
     out << "{\"proof\": \"0x";
@@ -190,8 +206,8 @@ int main(int argc, char** argv) {
     }
     out << "]}\n";
     std::printf("{\"k\": %u, \"levels\": %u, \"n_currencies\": %u, \"users\": %zu, \"rows_used\": %u, \"tree_ms\": %.3f, \"keygen_ms\": %.3f, "
-                "\"witness_ms\": %.3f, \"create_proof_ms\": %.3f, \"proof_bytes\": %zu, \"total_ms\": %.1f}\n",
-                k, depth, nc, users.size(), fp.rows_used, tree_ms, keygen_ms, witness_ms, best, proof.size(), ms_since(t_all));
+                "\"witness_ms\": %.3f, \"create_proof_ms\": %.3f, \"verify_ms\": %.3f, \"verified\": true, \"proof_bytes\": %zu, \"total_ms\": %.1f}\n",
+                k, depth, nc, users.size(), fp.rows_used, tree_ms, keygen_ms, witness_ms, best, verify_ms, proof.size(), ms_since(t_all));
     sg_srs_free(srs);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "prove_from_csv: %s\n", e.what());
