@@ -382,7 +382,7 @@ def main():
         return dt, results
 
     in_flight = max(1, args.in_flight)
-    pool = ThreadPoolExecutor(max_workers=in_flight)
+    pool = ThreadPoolExecutor(max_workers=in_flight, initializer=ffi.bind_thread)   # a new thread's current device is 0
     run_steps(2 * in_flight, in_flight)      # set-up, not a step: every lane allocates its work space (first call per lane)
     run_steps(args.warmup, in_flight)
     dt, results = timed(args.steps, in_flight)
@@ -562,7 +562,7 @@ def main():
                             tls.stream = torch.cuda.Stream()
                         with torch.cuda.stream(tls.stream):
                             return p20.commit(scal)
-                    with ThreadPoolExecutor(max_workers=3) as tp:
+                    with ThreadPoolExecutor(max_workers=3, initializer=ffi.bind_thread) as tp:
                         list(tp.map(one_commit, range(6)))
                         torch.cuda.synchronize()
                         t1 = time.perf_counter()

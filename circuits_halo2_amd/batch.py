@@ -22,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import api
+from . import api, ffi
 
 
 def _dist():
@@ -180,7 +180,8 @@ def _workers(in_flight: int) -> ThreadPoolExecutor:
     with _WORKERS_LOCK:
         pool = _WORKERS.get(in_flight)
         if pool is None:
-            pool = _WORKERS[in_flight] = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix=f"prove{in_flight}")
+            pool = _WORKERS[in_flight] = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix=f"prove{in_flight}",
+                                                             initializer=ffi.bind_thread)   # rank r's threads on device r
         return pool
 
 
@@ -206,6 +207,7 @@ class _WitnessAhead:
     def _run(self):
         import torch
         try:
+            ffi.bind_thread()
             with torch.cuda.stream(self.stream):
                 for first in range(0, len(self.users), self.chunk):
                     with self.cv:

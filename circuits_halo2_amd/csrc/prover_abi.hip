@@ -65,6 +65,7 @@ int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_la
       (lookup_input->n_calculations && !lookup_input->calculations))
     return sp_fail(SG_ERR_INVALID, "sp_key_create: malformed program");
   return guarded([&]() {
+    if (sg_bind_thread() != SG_OK) throw std::runtime_error(sg_last_error());   // this thread's own HIP calls: the library's device
     StreamScope scope(static_cast<hipStream_t>(stream));
     const size_t n = (size_t)1 << k;
     auto pk = std::make_shared<ProvingKey>();
@@ -120,6 +121,7 @@ int sp_create_proof(uint64_t key, void* const* d_advice, const uint8_t* instance
     pk = it->second;
   }
   return guarded([&]() {
+    if (sg_bind_thread() != SG_OK) throw std::runtime_error(sg_last_error());   // this thread's own HIP calls: the library's device
     StreamScope scope(static_cast<hipStream_t>(stream));
     std::vector<DevCol> advice;
     for (uint32_t i = 0; i < NUM_ADVICE; i++) {

@@ -435,6 +435,17 @@ int sg_device_count(void) {
   return n;
 }
 const char* sg_version(void) { return "summa_gpu 0.1.0 gfx950"; }
+int sg_device(void) {
+  std::lock_guard<std::mutex> lk(g_sh.mu);
+  return g_sh.device;
+}
+int sg_bind_thread(void) {
+  const int device = sg_device();
+  if (device < 0) return SG_OK;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail("sg_bind_thread", e);
+  return SG_OK;
+}
 const char* sg_last_error(void) { return g_err; }
 
 int sg_init(int device) {

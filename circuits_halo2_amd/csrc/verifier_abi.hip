@@ -384,6 +384,7 @@ int sp_verify_proof(uint32_t k, uint32_t n_currencies, const uint8_t vk_digest_b
     return SG_ERR_INVALID;
   }
   *accepted = 0;
+  (void)sg_bind_thread();
   try {
     std::vector<Fr> inst(n_instances);
     for (uint32_t i = 0; i < n_instances; i++) {

@@ -16,7 +16,7 @@ _LIB = None
 
 SG_OK = 0
 EXPORTS = [
-    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_last_error", "sg_device_count", "sg_version",
+    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
     "sg_msm_g1", "sg_msm_g1_dev", "sg_msm_g1_batch", "sg_msm_g1_batch_dev", "sg_g1_sum_affine", "sg_srs_upload", "sg_srs_upload_dev", "sg_srs_copy_dev", "sg_srs_free", "sg_srs_check", "sg_commit", "sg_commit_dev",
     "sg_srs_device_ptrs", "sg_srs_precompute", "sg_commit_batch_dev", "sg_commit_batch_mixed_dev", "sg_commit_combine_begin", "sg_commit_combine_end", "sg_commit_combine_stats", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_ntt_fr_batch_dev", "sg_ntt_fr_batch_oop_dev", "sg_intt_fr", "sg_intt_fr_dev",
     "sg_lagrange_to_coeff", "sg_lagrange_to_coeff_dev", "sg_coeff_to_extended", "sg_coeff_to_extended_dev", "sg_coeff_to_extended_batch_dev",
@@ -70,6 +70,26 @@ def check(rc: int):
         raise SummaGpuError(rc, lib().sg_last_error().decode())
 
 
+def bind_thread():
+    """Make the library's device the calling thread's current device, for HIP and for torch.  The current device is a
+    property of the host thread and starts at 0 in every new thread: on a multi-GPU host (one process per GPU, rank r on
+    device r) a worker thread's `device="cuda"` allocations and `torch.cuda.Stream()`s would land on device 0.  Every
+    thread pool of this package starts its threads with this; callers with threads of their own do the same.  No-op
+    before the library is bound to a device (sg_init or its first call)."""
+    dev = lib().sg_device()
+    if dev >= 0:
+        import torch
+        torch.cuda.set_device(dev)          # hipSetDevice on this thread + torch's notion of the current device
+    return dev
+
+
+def cuda_device():
+    """torch.device of the GPU this process is bound to (what a bare "cuda" means on the thread that called sg_init)"""
+    import torch
+    dev = lib().sg_device()
+    return torch.device("cuda", dev if dev >= 0 else torch.cuda.current_device())
+
+
 def u8(a) -> np.ndarray:
     a = np.ascontiguousarray(a)
     if a.dtype != np.uint8:
@@ -82,8 +102,13 @@ def ptr(a: np.ndarray):
 
 
 def dev_ptr(t):
-    """torch CUDA tensor -> raw device pointer"""
+    """torch CUDA tensor -> raw device pointer.  A tensor on another GPU than the library's is refused here: handed to a
+    kernel it would be a fault on the device, not an error code (see bind_thread)."""
     assert t.is_cuda and t.is_contiguous()
+    bound = lib().sg_device()
+    if bound >= 0 and t.device.index != bound:
+        raise SummaGpuError(-2, f"tensor on cuda:{t.device.index}, library bound to device {bound}: "
+                                "call ffi.bind_thread() in the thread that allocates")
     return C.c_void_p(t.data_ptr())
 
 

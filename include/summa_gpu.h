@@ -69,6 +69,14 @@ int sg_collect_retired(void);
 const char* sg_last_error(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int sg_device_count(void);
+/* The device this process is bound to (sg_init, or 0 after the first lazily initialised call); -1 before either. */
+int sg_device(void);
+/* HIP's current device is a property of the host thread and starts at 0 in every new thread.  The library selects its
+ * device itself on every call; a caller's OWN HIP calls on a worker thread -- the allocations and streams whose pointers
+ * it then hands over -- do not.  sg_bind_thread() makes the bound device current on the calling thread (no-op before
+ * the library is bound); sp_key_create / sp_create_proof / sp_verify_proof call it on entry.  Matters on a multi-GPU
+ * host only: one process per GPU, rank r on device r, worker threads that would otherwise allocate on device 0. */
+int sg_bind_thread(void);
 /* "summa_gpu <version> gfx950" */
 const char* sg_version(void);
 

@@ -18,6 +18,8 @@ extern "C" {
     pub fn sg_shutdown();
     pub fn sg_last_error() -> *const c_char;
     pub fn sg_device_count() -> c_int;
+    pub fn sg_device() -> c_int;
+    pub fn sg_bind_thread() -> c_int;
     pub fn sg_msm_g1(scalars: *const u8, bases: *const u8, n: size_t, out_affine: *mut u8) -> c_int;
     pub fn sg_msm_g1_batch(
         scalars: *const *const u8,

@@ -143,3 +143,24 @@ def test_collect_retired_and_lane_count():
         assert not errs and len(got) == 30 and set(got) == {bytes(want)}
     finally:
         ffi.check(L.sg_set_param(b"lanes", 4))
+
+
+def test_thread_binding_reports_the_bound_device():
+    """sg_device / sg_bind_thread (one process per GPU: a worker thread's own HIP calls must land on the library's device);
+    a tensor from another device is refused at the pointer hand-over (only checkable in full on a multi-GPU host)"""
+    import torch
+    from circuits_halo2_amd import ffi
+    L = ffi.lib()
+    ffi.check(L.sg_init(torch.cuda.current_device()))
+    assert L.sg_device() == torch.cuda.current_device()
+    got = []
+    th = threading.Thread(target=lambda: got.append((ffi.bind_thread(), torch.cuda.current_device(), ffi.cuda_device())))
+    th.start()
+    th.join()
+    assert got == [(L.sg_device(), L.sg_device(), torch.device("cuda", L.sg_device()))]
+    t = torch.zeros(32, dtype=torch.uint8, device=ffi.cuda_device())
+    assert ffi.dev_ptr(t).value == t.data_ptr()
+    if torch.cuda.device_count() > 1:
+        other = torch.zeros(32, dtype=torch.uint8, device=torch.device("cuda", (L.sg_device() + 1) % torch.cuda.device_count()))
+        with pytest.raises(ffi.SummaGpuError):
+            ffi.dev_ptr(other)

@@ -273,3 +273,22 @@ def test_ahead_of_time_gate_tables_are_current():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gates_programs.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, "gates_mst_programs.inc is stale: run tools/gen_gates_programs.py and rebuild\n" + r.stdout + r.stderr
+
+
+def test_worker_threads_are_bound_to_the_library_device(monkeypatch):
+    """A host thread's current HIP device starts at 0: on rank r of a multi-GPU host a worker's bare "cuda" allocations and
+    streams would land on another rank's GPU.  Every pool of the package starts its threads with ffi.bind_thread; before
+    the library is bound (no device here) it is a no-op that reports -1."""
+    from circuits_halo2_amd import batch, ffi
+    assert ffi.lib().sg_device() == -1 and ffi.bind_thread() == -1 and ffi.lib().sg_bind_thread() == 0
+    seen = []
+    monkeypatch.setattr(ffi, "bind_thread", lambda: seen.append(__import__("threading").current_thread().name))
+    pool = batch._workers(7)                       # a size no other test uses: the pool is created here, with the patched hook
+    try:
+        assert list(pool.map(lambda i: i * i, range(20))) == [i * i for i in range(20)]
+        assert seen and all(name.startswith("prove7") for name in seen) and len(set(seen)) == len(seen) <= 7
+    finally:
+        pool.shutdown()
+        batch._WORKERS.pop(7, None)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("ThreadPoolExecutor(") == src.count("initializer=ffi.bind_thread")
