@@ -23,6 +23,8 @@ struct MsmConfig {
   uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^19 entries), 2 always
   uint32_t log_scatter_rounds = 0;  // the counting sort's scatter runs in 2^x bucket-range rounds
   uint32_t acc_threads = 0;    // workgroup size of msm_accumulate (0: 128)
+  uint32_t acc_waves = 0;      // waves per SIMD of the persistent msm_accumulate launch: 0 = 3 (a full register file); >= 8: grid = tasks, one ticket per wave
+  uint32_t acc_waves_fixed = 0; // ... of fixed-base jobs (the commitments of a proof, which run beside that proof's transforms on other streams): 0 = 2
   uint32_t merge_quad_tasks = 0xffffffffu;  // merge rounds with more tasks than this use one lane per addition even when `quad` holds
   uint32_t red2d_max_sets = 5; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh)
   uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
@@ -119,6 +121,7 @@ class MsmEngine {
   hipError_t finish();
 
  private:
+  uint32_t cus_ = 256;
   struct Job {
     BatchPtrs bp{};
     uint32_t M = 1;

@@ -13,8 +13,9 @@
 //   3 msm_scan_*      exclusive scans: bucket offsets and task offsets (a task = <= L
 //                     consecutive entries of one bucket, so heavy buckets are split)
 //     msm_scatter     counting sort of the point indices by (window, bucket); slots are handed
-//                     out by LDS atomics on per-workgroup cursors (no global atomics anywhere)
-//   4 msm_accumulate  one thread per task: XYZZ accumulator += affine points (8M+2S each)
+//                     out by LDS atomics on per-workgroup cursors (no global atomics in the sort)
+//   4 msm_accumulate  one lane per task: XYZZ accumulator += affine points (8M+2S each); persistent waves that
+//                     take tickets of 64 tasks from one global counter
 //     msm_merge       (only when a bucket had > L entries) same over partial sums
 //   5 msm_reduce_*    sum_b b*B_b per window: per-thread running sums over G buckets, then a
 //                     workgroup-wide suffix scan + tree reduction in LDS; repeated per level
@@ -437,6 +438,7 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff
 // ---- task ordering: longest tasks first, equal lengths side by side, so the 64 lanes of a
 // wave run the same number of additions (bucket sizes are Poisson-distributed: without this
 // a wave waits for its largest bucket, ~30 % of the lanes' time idle).
+static constexpr uint32_t ACC_TICKET = 8;          // word of meta_ that holds msm_accumulate's task counter
 static constexpr uint32_t TASK_BINS = 257;        // task length clamped to 256
 // buckets per workgroup in the ordering passes: ~128 workgroups, 256 .. 8192 buckets each
 static inline uint32_t task_block_for(uint32_t NB, uint32_t nbins) {
@@ -470,8 +472,10 @@ __global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict_
 // nbins = L + 1 bins in use; total = nbins * nblk <= TASK_SCAN_MAX entries, a fixed number per
 // thread so that all loads of a thread are in flight together
 static constexpr uint32_t TASK_SCAN_PER = 32;  // x 1024 threads = 32 Ki entries at most
-__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk, uint32_t nbins) {
+__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk, uint32_t nbins,
+                                                      uint32_t* __restrict__ ticket) {
   __shared__ uint32_t s_sum[1024];
+  if (threadIdx.x == 0) *ticket = 0;   // msm_accumulate's task counter (next launch on this stream)
   const uint32_t total = nbins * nblk, tid = threadIdx.x;
   const uint32_t per = (total + 1023) / 1024;  // <= TASK_SCAN_PER
   const uint32_t lo = min(tid * per, total);
@@ -531,39 +535,53 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
   }
 }
 
+// Persistent: the grid is a fixed number of waves per SIMD (MsmConfig::acc_waves; three fill the register file at 161
+// registers), and every wave takes tickets of 64 consecutive tasks from a counter until the task list (longest first, so
+// the 64 lanes of a ticket have equal work) is used up: the end of the launch is balanced by construction instead of by
+// the order in which the hardware happens to retire workgroups (2^20: 1.16 -> 1.12 ms; profiles/r03_sweeps/persistent_accumulate.txt).
+// Sizing the launch to leave room for the kernels of other streams (two waves per SIMD) was measured too and does not pay:
+// the kernels beside it still crawl (same file), and the accumulation alone loses 4 %.
 __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict__ sorted, BatchPtrs bp,
                                                       uint32_t buckets_per_msm,
                                                       const uint32_t* __restrict__ off,
                                                       const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ toff,
                                                       const uint2* __restrict__ order, uint32_t log_L,
-                                                      const uint32_t* __restrict__ meta, xyzz29_mem* __restrict__ partial) {
-  // the grid covers a host-side upper bound (launched before the host has read the counters back, so that the read
-  // overlaps this kernel instead of leaving the queue empty); the exact task count is meta[1]
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= meta[1]) return;
-  const uint2 o = order[t];
-  const uint32_t b = o.x, seg = o.y;
-  const g1_affine_mem* __restrict__ bases = bp.bases[b / buckets_per_msm];
-  uint32_t start = off[b] + (seg << log_L);
-  uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
-  xyzz29 acc = xyzz29_identity();
-  uint32_t e = sorted[start];
-  g1_affine_mem raw = bases[e & 0x7fffffffu];
-  for (uint32_t k = start; k < end; k++) {
-    uint32_t e_next = 0;
-    g1_affine_mem raw_next = raw;
-    if (k + 1 < end) {  // prefetch the next point while this one is being added
-      e_next = sorted[k + 1];
-      raw_next = bases[e_next & 0x7fffffffu];
+                                                      const uint32_t* __restrict__ meta, uint32_t* __restrict__ ticket,
+                                                      xyzz29_mem* __restrict__ partial) {
+  // launched before the host has read the counters back (the read overlaps this kernel); the exact task count is meta[1]
+  const uint32_t ntasks = meta[1], lane = threadIdx.x & 63u;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(ticket, 64u);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= ntasks) break;          // every wave gets here: the counter only grows
+    const uint32_t t = base + lane;
+    if (t < ntasks) {
+      const uint2 o = order[t];
+      const uint32_t b = o.x, seg = o.y;
+      const g1_affine_mem* __restrict__ bases = bp.bases[b / buckets_per_msm];
+      uint32_t start = off[b] + (seg << log_L);
+      uint32_t end = min(off[b] + cnt[b], start + (1u << log_L));
+      xyzz29 acc = xyzz29_identity();
+      uint32_t e = sorted[start];
+      g1_affine_mem raw = bases[e & 0x7fffffffu];
+      for (uint32_t k = start; k < end; k++) {
+        uint32_t e_next = 0;
+        g1_affine_mem raw_next = raw;
+        if (k + 1 < end) {  // prefetch the next point while this one is being added
+          e_next = sorted[k + 1];
+          raw_next = bases[e_next & 0x7fffffffu];
+        }
+        affine29 p = affine29_load(&raw);
+        if (e >> 31) affine29_negate(p);
+        xyzz29_madd(acc, p);
+        e = e_next;
+        raw = raw_next;
+      }
+      xyzz29_store(partial + toff[b] + seg, acc);
     }
-    affine29 p = affine29_load(&raw);
-    if (e >> 31) affine29_negate(p);
-    xyzz29_madd(acc, p);
-    e = e_next;
-    raw = raw_next;
   }
-  xyzz29_store(partial + toff[b] + seg, acc);
 }
 
 // Every kernel below is written for LOGICAL threads of Q lanes: Q = 1 is one lane per point
@@ -1134,6 +1152,12 @@ uint32_t MsmEngine::window_bits_for(size_t n, bool fused) const {
 }
 
 hipError_t MsmEngine::init() {
+  {
+    int dev = 0, cus = 0;
+    SG_TRY(hipGetDevice(&dev));
+    SG_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus_ = cus > 0 ? (uint32_t)cus : 256u;
+  }
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets<1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items<1>),
@@ -1466,13 +1490,17 @@ hipError_t MsmEngine::enqueue_back() {
     SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
     SG_TRY(order_.reserve(ntasks_ub));
     msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
-    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins);
+    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins, meta_.p + ACC_TICKET);
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
   }
   const uint32_t at = cfg_.acc_threads ? cfg_.acc_threads : 128;  // measured: 128 beats 256 by 5 % at 2^20 (finer-grained tail), 64 loses in fixed mode
-  j.acc_threads = (ntasks_ub + at - 1) / at * at;
-  msm_accumulate<<<(ntasks_ub + at - 1) / at, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p,
-                                                              toff_[0].p, order_.p, log_L, meta_.p, partial_[0].p);
+  // persistent launch: `waves` per SIMD on every CU (3 fill the register file)
+  const uint32_t waves = j.fixed ? (cfg_.acc_waves_fixed ? cfg_.acc_waves_fixed : 2) : (cfg_.acc_waves ? cfg_.acc_waves : 3);
+  const uint32_t wg_all = (ntasks_ub + at - 1) / at;
+  const uint32_t wg = waves >= 8 ? wg_all : std::min<uint32_t>(wg_all, cus_ * (waves * 4 * 64 / at));
+  j.acc_threads = wg * at;
+  msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
+                                        meta_.p + ACC_TICKET, partial_[0].p);
   SG_TRY(hipEventSynchronize(ev_meta_));
   const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_blocks / msm_scan_small), complete with the event
   const uint32_t ntasks = j.ntasks = hm[1], max_cnt = j.max_cnt = hm[2];

@@ -406,6 +406,8 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; c.msm.config().red_threads = c.msm_b.config().red_threads = v; }
   else if (s == "msm.log_scatter_rounds") c.msm.config().log_scatter_rounds = c.msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));
   else if (s == "msm.two_pass") c.msm.config().two_pass = c.msm_b.config().two_pass = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "msm.acc_waves_fixed") c.msm.config().acc_waves_fixed = c.msm_b.config().acc_waves_fixed = (uint32_t)std::max(0, std::min(8, value));
+  else if (s == "msm.acc_waves") c.msm.config().acc_waves = c.msm_b.config().acc_waves = (uint32_t)std::max(0, std::min(8, value));
   else if (s == "msm.acc_threads") c.msm.config().acc_threads = c.msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
   else if (s == "msm.merge_quad_tasks") c.msm.config().merge_quad_tasks = c.msm_b.config().merge_quad_tasks = (uint32_t)std::max(0, value);
   else if (s == "msm.red2d_max_sets") c.msm.config().red2d_max_sets = c.msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));

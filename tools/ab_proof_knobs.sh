@@ -1,6 +1,7 @@
 # whole-proof A/B of library tunables with the compiled prover (k = 17, best of 30 per run, baseline repeated between the others)
+# usage: ab_proof_knobs.sh "SG_PARAMS=a=1" "SG_PARAMS=b=2" ...
 set -e
-mkdir -p gpurun_out/r02g
+mkdir -p gpurun_out/r03g
 python - <<'PY'
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
@@ -12,13 +13,11 @@ tree = snapshot_tree(20, 2)
 params, pk, vk = api.generate_setup_artifacts(17, None, api.MstInclusionCircuit.init_empty(20, 2, 8))
 c = api.MstInclusionCircuit.init_from_tree(tree, 5)
 adv = api._advice_columns(pk, c)
-prover.export_bundle("gpurun_out/r02g/bundle17.bin", params, pk, adv, c.instances()[0])
+prover.export_bundle("gpurun_out/r03g/bundle17.bin", params, pk, adv, c.instances()[0])
 PY
-run() { echo -n "$1 | "; env $1 ./tools/create_proof_cpp gpurun_out/r02g/bundle17.bin gpurun_out/r02g/proof.bin 30 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['create_proof_ms'])"; }
-for knob in "SG_PARAMS=msm.log_seg=3" "SG_PARAMS=msm.log_seg=5" "SG_PARAMS=msm.two_pass=0" "SG_PARAMS=msm.two_pass=2" "SG_PARAMS=msm.red2d_max_sets=3" \
-            "SG_PARAMS=msm.quad=0" "SG_PARAMS=msm.quad=2" "SG_PARAMS=msm.acc_threads=64" "SG_PARAMS=msm.acc_threads=256" "SG_PARAMS=ntt.tile_log=8" "SG_PARAMS=ntt.tile_log=10" \
-            "SG_PARAMS=ntt.threads=128" "SG_PARAMS=ntt.threads=512" "SG_GATES_RELOAD=8" "SG_GATES_ROWS=128" "GPU_MAX_HW_QUEUES=8" "GPU_MAX_HW_QUEUES=2"; do
+run() { echo -n "$1 | "; env $1 ./tools/create_proof_cpp gpurun_out/r03g/bundle17.bin gpurun_out/r03g/proof.bin 30 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['create_proof_ms'])"; }
+for knob in "$@"; do
   run "X=0"
   run "$knob"
 done
-rm -f gpurun_out/r02g/bundle17.bin
+rm -f gpurun_out/r03g/bundle17.bin

@@ -9,6 +9,11 @@ levels, nc, k = 20, 2, 17
 infl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 comb = len(sys.argv) > 3 and sys.argv[3] == "1"
+from circuits_halo2_amd import ffi
+ffi.check(ffi.lib().sg_init(0))
+for kv in filter(None, os.environ.get("SG_PARAMS", "").split(",")):   # tuning sweeps, as bench.py takes them
+    name, val = kv.split("=")
+    ffi.check(ffi.lib().sg_set_param(name.encode(), int(val)))
 params, pk, vk = B.setup_on_all_ranks(k, None, levels, nc)
 tree = snapshot_tree(levels, nc)
 users = [(7919 * i + 13) % (1 << levels) for i in range(count)]
