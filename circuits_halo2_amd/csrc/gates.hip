@@ -20,6 +20,7 @@
 // (conflict-free), the instruction stream is uniform (scalar loads, no divergence).  Cost per
 // product-type instruction ~260 VALU instructions (206 of them the product): ALU-bound like the rest.
 #include "gates.h"
+#include "side_prio.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -29,6 +30,7 @@
 #include <map>
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(gates_set_side_prio)
 
 typedef Fr29 P;
 
@@ -46,6 +48,7 @@ struct GateArgs {
 
 template <uint32_t T>
 __global__ void __launch_bounds__(T) gates_kernel(GateArgs a) {
+  side_kernel_prio();
   extern __shared__ uint32_t lds[];
   uint32_t* s_const = lds;                       // [n_consts][9]
   uint32_t* s_slot = lds + a.n_consts * 9;       // [n_slots][9][T]
@@ -175,6 +178,7 @@ __device__ __forceinline__ void fixed_step(f29 (&slot)[PROG::n_slots], const uin
 }
 template <class PROG>
 __global__ void __launch_bounds__(256) gates_fixed_kernel(GateArgs a) {
+  side_kernel_prio();
   extern __shared__ uint32_t lds[];
   uint32_t* s_const = lds;                       // [n_consts][9]
   for (uint32_t c = threadIdx.x; c < a.n_consts; c += blockDim.x) {

@@ -29,6 +29,8 @@ struct MsmConfig {
   uint32_t red2d_max_sets = 5; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh)
   uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
   uint32_t red2d_fold = 8;     // ... whose line sums add up to this many partial sums per bucket themselves (no merge round below that)
+  uint32_t acc_chain = 1;      // accumulations of different jobs run one after the other (each waits for the previous launch's event)
+  uint32_t red_lean = 1;       // level-0 bucket reduction within 168 registers (fits beside a polite accumulation): 0 never, 1 when other jobs are in flight, 2 always
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
 
@@ -121,6 +123,15 @@ class MsmEngine {
   hipError_t finish();
 
  private:
+  hipError_t enqueue_back_impl();
+  hipError_t finish_impl();
+  void mark_in_flight(bool on);
+  bool others_in_flight() const;   // another engine of this process has a job between its accumulation launch and its host tail
+  bool counted_ = false;
+  hipError_t chain_accumulate_before(hipStream_t stream);
+  hipError_t chain_accumulate_after(hipStream_t stream);
+  hipEvent_t ev_chain_[2] = {nullptr, nullptr};
+  int chain_slot_ = 0;
   uint32_t cus_ = 256;
   struct Job {
     BatchPtrs bp{};

@@ -25,8 +25,11 @@
 // is negated on the fly when d < 0.  The group law is commutative, so the order in which a
 // bucket's points are added (LDS atomics make it non-deterministic) never changes the result bits.
 #include "msm.h"
+#include "side_prio.cuh"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -34,6 +37,7 @@
 #include "host_curve.h"
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(msm_set_side_prio)
 
 
 // ------------------------------------------------------------------ 1: signed digits
@@ -47,6 +51,7 @@ namespace sg {
 // blockIdx.y = m selects the scalar vector of a fused batch (BatchPtrs); its digit rows are
 // dig[(m*W + j)*n + i].
 __global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __restrict__ dig) {
+  side_kernel_prio();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const fp_words* __restrict__ scalars = bp.scalars[blockIdx.y];
@@ -104,6 +109,7 @@ __global__ void msm_digits(BatchPtrs bp, uint32_t n, WindowPlan wp, int16_t* __r
 // `shift` > 0 histograms coarse bins (bucket >> shift) for the two-pass sort; nbw = bins per row.
 __global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig, uint32_t n, uint32_t chunk,
                                                  uint32_t nbw, uint32_t shift, uint32_t* __restrict__ hist) {
+  side_kernel_prio();
   extern __shared__ uint32_t s_cnt[];
   const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
   for (uint32_t b = threadIdx.x; b < nbw; b += blockDim.x) s_cnt[b] = 0;
@@ -125,6 +131,7 @@ __global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig
 static constexpr uint32_t HP_BUCKETS = 32, HP_GROUPS = 8;
 __global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hist, uint32_t P, uint32_t nbw, uint32_t NB,
                                                        uint32_t* __restrict__ counts) {
+  side_kernel_prio();
   __shared__ uint32_t s_sum[HP_GROUPS][HP_BUCKETS];
   const uint32_t bx = threadIdx.x % HP_BUCKETS, gy = threadIdx.x / HP_BUCKETS;
   const uint32_t g = blockIdx.x * HP_BUCKETS + bx;  // global bucket id = j*nbw + b
@@ -156,6 +163,7 @@ static constexpr uint32_t SCAN_ITEMS = 8, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_
 
 __global__ void __launch_bounds__(256) msm_scan_sums(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
                                                      uint32_t* __restrict__ bsum, uint32_t* __restrict__ meta) {
+  side_kernel_prio();
   __shared__ uint32_t s_a[SCAN_THREADS], s_t[SCAN_THREADS], s_m[SCAN_THREADS];
   const uint32_t Lm1 = (1u << log_L) - 1;
   uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -190,6 +198,7 @@ __global__ void __launch_bounds__(256) msm_scan_sums(const uint32_t* __restrict_
 __global__ void __launch_bounds__(1024) msm_scan_blocks(uint32_t* __restrict__ bsum, uint32_t nblk, uint32_t NB,
                                                         uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
                                                         uint32_t* __restrict__ meta, volatile uint32_t* host_meta) {
+  side_kernel_prio();
   __shared__ uint32_t s_a[1024], s_t[1024], s_m[1024];
   const uint32_t tid = threadIdx.x;
   uint32_t a = tid < nblk ? bsum[3 * tid] : 0, t = tid < nblk ? bsum[3 * tid + 1] : 0;
@@ -223,6 +232,7 @@ __global__ void __launch_bounds__(1024) msm_scan_blocks(uint32_t* __restrict__ b
 __global__ void __launch_bounds__(256) msm_scan_write(const uint32_t* __restrict__ cnt, uint32_t NB, uint32_t log_L,
                                                       const uint32_t* __restrict__ bsum, uint32_t* __restrict__ off,
                                                       uint32_t* __restrict__ ntask, uint32_t* __restrict__ toff) {
+  side_kernel_prio();
   __shared__ uint32_t s_a[SCAN_THREADS], s_t[SCAN_THREADS];
   const uint32_t Lm1 = (1u << log_L) - 1, tid = threadIdx.x;
   uint32_t base = blockIdx.x * SCAN_BLOCK + tid * SCAN_ITEMS;
@@ -264,6 +274,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
                                                     uint32_t nbw, const uint32_t* __restrict__ hist,
                                                     const uint32_t* __restrict__ off, uint32_t collapse_W,
                                                     uint32_t n_tab, uint32_t* __restrict__ sorted) {
+  side_kernel_prio();
   extern __shared__ uint32_t s_cur[];
   const uint32_t j = blockIdx.x, p = blockIdx.y, P = gridDim.y;
   // blockIdx.z = round r of R: only the buckets [r, r+1) * nbw / R are placed.  Every round re-reads
@@ -305,6 +316,7 @@ __global__ void __launch_bounds__(1024) msm_partition(const int16_t* __restrict_
                                                       const uint32_t* __restrict__ coff, uint32_t collapse_W,
                                                       uint32_t n_tab, uint32_t* __restrict__ part_entry,
                                                       uint16_t* __restrict__ part_fine) {
+  side_kernel_prio();
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_cnt = s_mem;                 // [B] tile counts, then tile bases
   uint32_t* s_base = s_cnt + B;            // [B]
@@ -375,6 +387,7 @@ __global__ void __launch_bounds__(512) msm_fine_sort(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ ccnt, uint32_t B, uint32_t shift,
                                                      uint32_t nbw, uint32_t* __restrict__ counts,
                                                      uint32_t* __restrict__ sorted) {
+  side_kernel_prio();
   extern __shared__ uint32_t s_mem[];
   const uint32_t F = 1u << shift, tid = threadIdx.x, nthr = blockDim.x;
   uint32_t* s_cnt = s_mem;        // [F] counts, then cursors
@@ -452,6 +465,7 @@ static inline uint32_t task_block_for(uint32_t NB, uint32_t nbins) {
 __global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t NB,
                                                      uint32_t log_L, uint32_t task_block,
                                                      uint32_t* __restrict__ thist) {
+  side_kernel_prio();
   __shared__ uint32_t s_h[TASK_BINS];
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_h[k] = 0;
   __syncthreads();
@@ -468,46 +482,47 @@ __global__ void __launch_bounds__(256) msm_task_hist(const uint32_t* __restrict_
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) thist[k * gridDim.x + blockIdx.x] = s_h[k];
 }
-// one workgroup: exclusive scan of thist in DESCENDING bin order (bin-major, block-minor) over the
-// nbins = L + 1 bins in use; total = nbins * nblk <= TASK_SCAN_MAX entries, a fixed number per
-// thread so that all loads of a thread are in flight together
-static constexpr uint32_t TASK_SCAN_PER = 32;  // x 1024 threads = 32 Ki entries at most
-__global__ void __launch_bounds__(1024) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk, uint32_t nbins,
-                                                      uint32_t* __restrict__ ticket) {
-  __shared__ uint32_t s_sum[1024];
+// one workgroup: exclusive scan of thist in DESCENDING bin order (bin-major, block-minor) over the nbins = L + 1 bins in
+// use; total = nbins * nblk <= 32 Ki entries.  256 lanes with a handful of registers, two passes over the entries (the
+// second one hits L2): the former 1024 lanes x 98 registers needed a whole CU's register file at once and, beside a
+// running accumulation, waited for that accumulation to END -- a millisecond on the path of the next job.
+__global__ void __launch_bounds__(256) msm_task_scan(uint32_t* __restrict__ thist, uint32_t nblk, uint32_t nbins,
+                                                     uint32_t* __restrict__ ticket) {
+  side_kernel_prio();
+  __shared__ uint32_t s_sum[256];
   if (threadIdx.x == 0) *ticket = 0;   // msm_accumulate's task counter (next launch on this stream)
   const uint32_t total = nbins * nblk, tid = threadIdx.x;
-  const uint32_t per = (total + 1023) / 1024;  // <= TASK_SCAN_PER
-  const uint32_t lo = min(tid * per, total);
+  const uint32_t per = (total + 255) / 256;
+  const uint32_t lo = min(tid * per, total), hi = min(lo + per, total);
   // position q in scan order <-> entry (nbins-1 - q / nblk) * nblk + q % nblk
-  uint32_t v[TASK_SCAN_PER], idx[TASK_SCAN_PER];
+  const uint32_t row0 = lo / nblk, col0 = lo - row0 * nblk;
+  uint32_t a = 0;
   {
-    uint32_t row = lo / nblk, col = lo - row * nblk;
-#pragma unroll
-    for (uint32_t k = 0; k < TASK_SCAN_PER; k++) {
-      const bool live = k < per && lo + k < total;
-      idx[k] = live ? (nbins - 1 - row) * nblk + col : 0xffffffffu;
+    uint32_t row = row0, col = col0;
+#pragma unroll 8
+    for (uint32_t q = lo; q < hi; q++) {
+      a += thist[(nbins - 1 - row) * nblk + col];
       if (++col == nblk) { col = 0; row++; }
     }
   }
-  uint32_t a = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) v[k] = idx[k] != 0xffffffffu ? thist[idx[k]] : 0u;
-#pragma unroll
-  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) a += v[k];
   s_sum[tid] = a;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
+  for (uint32_t d = 1; d < 256; d <<= 1) {
     uint32_t u = tid >= d ? s_sum[tid - d] : 0;
     __syncthreads();
     s_sum[tid] += u;
     __syncthreads();
   }
   uint32_t run = s_sum[tid] - a;
-#pragma unroll
-  for (uint32_t k = 0; k < TASK_SCAN_PER; k++) {
-    if (idx[k] != 0xffffffffu) thist[idx[k]] = run;
-    run += v[k];
+  {
+    uint32_t row = row0, col = col0;
+    for (uint32_t q = lo; q < hi; q++) {
+      const uint32_t idx = (nbins - 1 - row) * nblk + col;
+      const uint32_t v = thist[idx];
+      thist[idx] = run;
+      run += v;
+      if (++col == nblk) { col = 0; row++; }
+    }
   }
 }
 // order[pos] = (bucket, segment) of the task that runs as thread `pos`
@@ -515,6 +530,7 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
                                                         uint32_t log_L, uint32_t task_block,
                                                         const uint32_t* __restrict__ thist,
                                                         uint2* __restrict__ order) {
+  side_kernel_prio();
   __shared__ uint32_t s_c[TASK_BINS];
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = thist[k * gridDim.x + blockIdx.x];
   __syncthreads();
@@ -587,16 +603,26 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
 // Every kernel below is written for LOGICAL threads of Q lanes: Q = 1 is one lane per point
 // operation, Q = 4 the quad-cooperative addition (xyzz29_add_quad; all 4 lanes hold the same
 // values).  lt = logical thread, role = lane within the quad.
+#ifndef SG_ADD_CALL
+#define SG_ADD_CALL 0
+#endif
+// ONE copy of the general addition per kernel instead of one per call site
+__device__ __attribute__((noinline)) void xyzz29_add_call(xyzz29& acc, const xyzz29& q) { xyzz29_add(acc, q); }
 template <int Q>
 __device__ __forceinline__ void add_q(xyzz29& acc, const xyzz29& q, uint32_t role) {
   if (Q == 4) xyzz29_add_quad(acc, q, role);
+#if SG_ADD_CALL
+  else xyzz29_add_call(acc, q);
+#else
   else xyzz29_add(acc, q);
+#endif
 }
 template <int Q>
 __global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ in, const uint32_t* __restrict__ off,
                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
                                                  uint32_t NB, uint32_t log_L, const uint32_t* __restrict__ meta,
                                                  xyzz29_mem* __restrict__ out) {
+  side_kernel_prio();
   // the grid covers a host-side upper bound; the exact task count of this level is meta[1]
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Q, role = threadIdx.x % Q;
   if (t >= meta[1]) return;
@@ -656,10 +682,10 @@ __device__ __forceinline__ xyzz29 suffix_scan(xyzz29_mem* arr, xyzz29 mine, uint
 
 // level 0: grid (blocks, W), N = blockDim.x / Q logical threads (power of two >= 16)
 template <int Q>
-__global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __restrict__ partial,
-                                                          const uint32_t* __restrict__ toff,
-                                                          const uint32_t* __restrict__ ntask, uint32_t nbw,
-                                                          uint32_t log_G, ReduceOut out) {
+__device__ __forceinline__ void reduce_buckets_body(const xyzz29_mem* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                    const uint32_t* __restrict__ ntask, uint32_t nbw, uint32_t log_G,
+                                                    ReduceOut out) {
+  side_kernel_prio();
   extern __shared__ uint4 smem[];
   const uint32_t N = blockDim.x / Q, lt = threadIdx.x / Q, role = threadIdx.x % Q;
   xyzz29_mem* sA = reinterpret_cast<xyzz29_mem*>(smem);
@@ -699,10 +725,26 @@ __global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __re
   if (threadIdx.x == 0) xyzz29_store(out.a + o, xyzz29_load(&sA[0]));
   if (lt == halfN && role == 0) xyzz29_store(out.s + o, xyzz29_load(&sR[0]));
 }
+template <int Q>
+__global__ void __launch_bounds__(256) msm_reduce_buckets(const xyzz29_mem* __restrict__ partial,
+                                                          const uint32_t* __restrict__ toff,
+                                                          const uint32_t* __restrict__ ntask, uint32_t nbw,
+                                                          uint32_t log_G, ReduceOut out) {
+  reduce_buckets_body<Q>(partial, toff, ntask, nbw, log_G, out);
+}
+// the same within 168 registers (60 values live in scratch, +5 %): a wave of it fits beside two waves of msm_accumulate on
+// a SIMD, so the reduction of one job runs under the accumulation of the next instead of after it
+template <int Q>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+msm_reduce_buckets_lean(const xyzz29_mem* __restrict__ partial, const uint32_t* __restrict__ toff,
+                        const uint32_t* __restrict__ ntask, uint32_t nbw, uint32_t log_G, ReduceOut out) {
+  reduce_buckets_body<Q>(partial, toff, ntask, nbw, log_G, out);
+}
 // level 1: grid (1, W), blockDim = 3 * T1 * Q (T1 a power of two >= count): group 0 scans/folds
 // the R items, group 1 folds A, group 2 folds S
 template <int Q>
 __global__ void __launch_bounds__(768) msm_reduce_items(ReduceOut in, uint32_t count, uint32_t T1, ReduceOut out) {
+  side_kernel_prio();
   extern __shared__ uint4 smem[];
   xyzz29_mem* sR = reinterpret_cast<xyzz29_mem*>(smem);
   xyzz29_mem* sA = sR + T1;
@@ -778,6 +820,7 @@ __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __re
                                                           const uint32_t* __restrict__ toff,
                                                           const uint32_t* __restrict__ ntask, Reduce2dShape sh,
                                                           xyzz29_mem* __restrict__ lines) {
+  side_kernel_prio();
   __shared__ xyzz29_mem lds[256 / Q];
   const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols, L = blockIdx.x, set = blockIdx.y;
   const uint32_t base = set << (sh.log_rows + sh.log_cols);
@@ -798,6 +841,7 @@ __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __re
 template <int Q>
 __global__ void __launch_bounds__(256) msm_reduce2d_bits(const xyzz29_mem* __restrict__ lines, Reduce2dShape sh,
                                                          xyzz29_mem* __restrict__ out) {
+  side_kernel_prio();
   __shared__ xyzz29_mem lds[256 / Q];
   const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols, j = blockIdx.x, set = blockIdx.y;
   const uint32_t bits = sh.log_rows + sh.log_cols;
@@ -825,6 +869,7 @@ __global__ void __launch_bounds__(256) msm_reduce2d_bits(const xyzz29_mem* __res
 // a tree sum: one point per set.  grid (sets), 32 threads
 __global__ void __launch_bounds__(32) msm_reduce2d_combine(const xyzz29_mem* __restrict__ terms, uint32_t bits,
                                                            xyzz29_mem* __restrict__ out) {
+  side_kernel_prio();
   __shared__ xyzz29_mem lds[32];
   const uint32_t t = threadIdx.x, set = blockIdx.x;
   xyzz29 p = xyzz29_identity();
@@ -841,6 +886,7 @@ __global__ void __launch_bounds__(32) msm_reduce2d_combine(const xyzz29_mem* __r
 // canonical words of `count` XYZZ points for the host tail (32 words each)
 // (`out` is page-locked host memory mapped into the device: the words land where the host tail reads them)
 __global__ void msm_export_points(const xyzz29_mem* __restrict__ in, uint32_t count, uint32_t* __restrict__ out) {
+  side_kernel_prio();
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= count) return;
   uint32_t w[32];
@@ -853,6 +899,7 @@ __global__ void msm_export_points(const xyzz29_mem* __restrict__ in, uint32_t co
 // per-window (A, S, T) -> canonical 8 x u32 Montgomery-2^256 words (X, Y, ZZ, ZZZ each) for the
 // host tail; out[(3*j + which)*32 ..]
 __global__ void msm_export_windows(ReduceOut in, uint32_t W, uint32_t has_t, uint32_t* __restrict__ out) {
+  side_kernel_prio();
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= 3 * W) return;
   uint32_t j = q / 3, which = q - 3 * j;
@@ -1124,7 +1171,35 @@ __global__ void __launch_bounds__(128) msm_table_step(const g1_affine_mem* __res
 
 MsmEngine::~MsmEngine() { release(); }
 
+// Accumulations of different jobs never share the device: each one alone keeps the vector ALUs busy, and two polite ones
+// side by side fill the register file that politeness leaves to the other kernels.  Every accumulation launch waits for
+// the event recorded after the previous one (whichever engine / stream launched it).
+static std::mutex g_acc_chain_mu;
+static hipEvent_t g_acc_chain_last = nullptr;   // recorded after the most recent accumulation launch of the process
+hipError_t MsmEngine::chain_accumulate_before(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
+  if (g_acc_chain_last) SG_TRY(hipStreamWaitEvent(stream, g_acc_chain_last, 0));
+  return hipSuccess;
+}
+hipError_t MsmEngine::chain_accumulate_after(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
+  // two events per engine, alternating: the previous record of this engine may still be the one another stream waits on
+  chain_slot_ ^= 1;
+  if (!ev_chain_[chain_slot_]) SG_TRY(hipEventCreateWithFlags(&ev_chain_[chain_slot_], hipEventDisableTiming));
+  SG_TRY(hipEventRecord(ev_chain_[chain_slot_], stream));
+  g_acc_chain_last = ev_chain_[chain_slot_];
+  return hipSuccess;
+}
 void MsmEngine::release() {
+  mark_in_flight(false);
+  {
+    std::lock_guard<std::mutex> lk(g_acc_chain_mu);
+    for (auto& e : ev_chain_) {
+      if (e && g_acc_chain_last == e) g_acc_chain_last = nullptr;
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  }
   win_words_.release(); part_entry_.release(); part_fine_.release(); ccnt_.release(); coff_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_a_[i].release(); red_s_[i].release(); red_r_[i].release();
@@ -1160,6 +1235,8 @@ hipError_t MsmEngine::init() {
   }
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets<1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_buckets_lean<1>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_reduce_items<1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
   SG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1181,6 +1258,7 @@ __global__ void __launch_bounds__(1024) msm_scan_small(const uint32_t* __restric
                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ ntask,
                                                        uint32_t* __restrict__ toff, uint32_t* __restrict__ meta,
                                                        volatile uint32_t* host_meta) {
+  side_kernel_prio();
   __shared__ uint32_t s_a[1024], s_t[1024], s_m[1024];
   const uint32_t Lm1 = (1u << log_L) - 1, tid = threadIdx.x;
   const uint32_t per = (NB + 1023) / 1024, lo = min(tid * per, NB);
@@ -1473,7 +1551,26 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
 }
 
 // ---- phase 2: needs the task count on the host; enqueues accumulate .. export + result copy
+// jobs of this process between their accumulation launch and the end of their host tail (all engines, all lanes)
+static std::atomic<int> g_jobs_in_flight{0};
+void MsmEngine::mark_in_flight(bool on) {
+  if (on == counted_) return;
+  counted_ = on;
+  g_jobs_in_flight.fetch_add(on ? 1 : -1);
+}
+bool MsmEngine::others_in_flight() const { return g_jobs_in_flight.load() > (counted_ ? 1 : 0); }
 hipError_t MsmEngine::enqueue_back() {
+  mark_in_flight(true);
+  const hipError_t e = enqueue_back_impl();
+  if (e != hipSuccess) mark_in_flight(false);
+  return e;
+}
+hipError_t MsmEngine::finish() {
+  const hipError_t e = finish_impl();
+  mark_in_flight(false);
+  return e;
+}
+hipError_t MsmEngine::enqueue_back_impl() {
   Job& j = job_;
   if (j.trivial) return hipSuccess;
   hipStream_t stream = j.stream;
@@ -1490,17 +1587,22 @@ hipError_t MsmEngine::enqueue_back() {
     SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
     SG_TRY(order_.reserve(ntasks_ub));
     msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
-    msm_task_scan<<<1, 1024, 0, stream>>>(thist_.p, tblk, nbins, meta_.p + ACC_TICKET);
+    msm_task_scan<<<1, 256, 0, stream>>>(thist_.p, tblk, nbins, meta_.p + ACC_TICKET);
     msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
   }
   const uint32_t at = cfg_.acc_threads ? cfg_.acc_threads : 128;  // measured: 128 beats 256 by 5 % at 2^20 (finer-grained tail), 64 loses in fixed mode
   // persistent launch: `waves` per SIMD on every CU (3 fill the register file)
-  const uint32_t waves = j.fixed ? (cfg_.acc_waves_fixed ? cfg_.acc_waves_fixed : 2) : (cfg_.acc_waves ? cfg_.acc_waves : 3);
+  // ... three fill the register file (a job that has the device to itself); two leave a third of it to the kernels of other
+  // streams, which run at wave priority 3 (side_kernel_prio): the other jobs in flight, a proof's transforms under its commitments
+  const uint32_t waves = j.fixed ? (cfg_.acc_waves_fixed ? cfg_.acc_waves_fixed : 2)
+                                 : (cfg_.acc_waves ? cfg_.acc_waves : (others_in_flight() ? 2 : 3));
   const uint32_t wg_all = (ntasks_ub + at - 1) / at;
   const uint32_t wg = waves >= 8 ? wg_all : std::min<uint32_t>(wg_all, cus_ * (waves * 4 * 64 / at));
   j.acc_threads = wg * at;
+  if (cfg_.acc_chain) SG_TRY(chain_accumulate_before(stream));
   msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
                                         meta_.p + ACC_TICKET, partial_[0].p);
+  if (cfg_.acc_chain) SG_TRY(chain_accumulate_after(stream));
   SG_TRY(hipEventSynchronize(ev_meta_));
   const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_blocks / msm_scan_small), complete with the event
   const uint32_t ntasks = j.ntasks = hm[1], max_cnt = j.max_cnt = hm[2];
@@ -1604,6 +1706,9 @@ hipError_t MsmEngine::enqueue_back() {
   if (quad)
     msm_reduce_buckets<4><<<dim3(blocks, W), threads * 4, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
         cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
+  else if (cfg_.red_lean == 2 || (cfg_.red_lean == 1 && others_in_flight()))
+    msm_reduce_buckets_lean<1><<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
+        cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
   else
     msm_reduce_buckets<1><<<dim3(blocks, W), threads, (size_t)threads * 2 * sizeof(xyzz29_mem), stream>>>(
         cur, toff_[lvl].p, ntask_[lvl].p, nbw, j.log_G, lvl0);
@@ -1626,7 +1731,7 @@ hipError_t MsmEngine::enqueue_back() {
 }
 
 // ---- phase 3: wait for the window sums; host tail
-hipError_t MsmEngine::finish() {
+hipError_t MsmEngine::finish_impl() {
   Job& j = job_;
   auto drop_events = [&]() {
     if (j.tm) {

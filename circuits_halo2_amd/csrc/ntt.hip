@@ -15,11 +15,13 @@
 // HBM traffic per pass: 32 B read + 32 B write per element (+32 B twiddle on twiddled
 // passes).  Arithmetic: (n/2) log2 n Montgomery products + one per element per twiddled pass.
 #include "ntt.h"
+#include "side_prio.cuh"
 
 #include <algorithm>
 #include <cstring>
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(ntt_set_side_prio)
 
 // ------------------------------------------------------------------ device kernels
 // Arithmetic: 9 x 29-bit limbs (bn254_f29.cuh).  Data stays in the Montgomery-2^256 domain it
@@ -76,6 +78,7 @@ __device__ __forceinline__ f29 lds_get(const LdsTile& t, uint32_t i) {
 // One pass.  grid.x = number of tiles = (2^log_b / T) * A  where A = n / (B*R).
 // Dynamic LDS: (T*R + R/2 + 8) * 36 bytes.
 __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
+  side_kernel_prio();
   extern __shared__ uint4 lds[];
   typedef Fr29 P;
   const fp_words* __restrict__ p_in = p.nbatch ? p.in_b[blockIdx.y] : p.in;
@@ -211,6 +214,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
 
 // tw[k] = (w^k)^ for k < count; w given as Montgomery-2^256 words
 __global__ void fill_powers(fp_words* tw, words8 w, uint32_t count) {
+  side_kernel_prio();
   typedef Fr29 P;
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < count) f29_store_canonical<P>(tw + k, f29_pow_u64<P>(f29_words_to_r261<P>(w.l), k));
@@ -223,6 +227,7 @@ __global__ void fill_powers(fp_words* tw, words8 w, uint32_t count) {
 //  times29: the table additionally carries the factor 2^29 that the last pass removes with f29_mont_step
 __global__ void fill_pass_twiddles(fp_words* tw, words8 w, words8 scale, uint32_t has_scale, uint32_t mode,
                                    uint32_t l1, uint32_t l2, uint32_t l3, uint32_t log_n, uint32_t times29) {
+  side_kernel_prio();
   typedef Fr29 P;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >> log_n) return;
@@ -249,6 +254,7 @@ __global__ void fill_pass_twiddles(fp_words* tw, words8 w, words8 scale, uint32_
 }
 // out = w^e as Montgomery-2^256 words (host-visible domain constants)
 __global__ void pow_single(fp_words* out, words8 w, uint64_t e) {
+  side_kernel_prio();
   typedef Fr29 P;
   f29 v = f29_pow_u64<P>(f29_words_to_r261<P>(w.l), e);
   uint32_t o[8];
@@ -257,6 +263,7 @@ __global__ void pow_single(fp_words* out, words8 w, uint64_t e) {
 }
 
 __global__ void scale_kernel(fp_words* a, words8 s, size_t n) {
+  side_kernel_prio();
   typedef Fr29 P;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) f29_store_canonical<P>(a + i, f29_mul<P>(f29_load_r256<P>(a + i), f29_words_to_r261<P>(s.l)));
@@ -264,6 +271,7 @@ __global__ void scale_kernel(fp_words* a, words8 s, size_t n) {
 // a[i] *= tab[i & (period-1)]   (divide_by_vanishing_poly; period = 2^(ext_k-k)); tab in the
 // 2^256 domain like the data
 __global__ void scale_periodic_kernel(fp_words* a, const fp_words* tab, uint32_t period, size_t n) {
+  side_kernel_prio();
   typedef Fr29 P;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -275,6 +283,7 @@ __global__ void scale_periodic_kernel(fp_words* a, const fp_words* tab, uint32_t
 // dir = 1: canonical integers -> Montgomery-2^256 (x * 2^517 * 2^-261); dir = 0: the inverse
 // (x~ * 2^5 * 2^-261)
 __global__ void to_mont_kernel(const fp_words* in, fp_words* out, size_t n, int dir) {
+  side_kernel_prio();
   typedef Fr29 P;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {

@@ -7,8 +7,10 @@
 // All vectors: n x 32 B Fr, Montgomery-2^256 words (halo2curves layout); arithmetic on
 // 9 x 29-bit limbs (bn254_f29.cuh) in the 2^261 domain.
 #include "poly.h"
+#include "side_prio.cuh"
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(poly_set_side_prio)
 
 typedef Fr29 P;
 __device__ __forceinline__ f29 load_hat(const fp_words* p) {  // x~ words -> x^ (< 2p)
@@ -83,6 +85,7 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
 static constexpr uint32_t EV_CH = 32, EV_LOG = 13;   // the single-polynomial path (any length): log2(EV_CH * EV_THREADS)
 __global__ void __launch_bounds__(256) eval_poly_kernel(const fp_words* __restrict__ c, uint32_t n, words8 xw,
                                                         uint32_t log_stride, fp_words* __restrict__ out) {
+  side_kernel_prio();
   __shared__ uint32_t sh[EV_THREADS][9];
   eval_poly_block<EV_CH>(c, n, xw, log_stride, out, sh);
 }
@@ -96,6 +99,7 @@ template <uint32_t CH>
 __global__ void __launch_bounds__(256) eval_poly_batch_kernel(EvalBatchArgs a, uint32_t n, uint32_t level,
                                                               uint32_t stride, fp_words* __restrict__ partial,
                                                               fp_words* __restrict__ out) {
+  side_kernel_prio();
   __shared__ uint32_t sh[EV_THREADS][9];
   const uint32_t j = blockIdx.y;
   constexpr uint32_t LOG = CH == 16 ? 12 : 13;   // log2(CH * EV_THREADS)
@@ -106,6 +110,7 @@ __global__ void __launch_bounds__(256) eval_poly_batch_kernel(EvalBatchArgs a, u
 // ---- batch inversion (zeros stay zero, like ff::BatchInvert) --------------------------------
 static constexpr uint32_t BI_CH = 8;
 __global__ void __launch_bounds__(256) batch_invert_kernel(fp_words* __restrict__ a, uint32_t n) {
+  side_kernel_prio();
   const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * BI_CH;
   if (first >= n) return;
   const uint32_t cnt = min(BI_CH, n - first);
@@ -181,6 +186,7 @@ __device__ __forceinline__ f29 block_exclusive_scan_mul(f29 mine, uint32_t (*sh)
 }
 __global__ void __launch_bounds__(256) prefix_product_blocks(const fp_words* __restrict__ a, uint32_t n,
                                                              fp_words* __restrict__ bprod) {
+  side_kernel_prio();
   __shared__ uint32_t sh[PP_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * PP_THREADS + tid) * PP_CH;
   f29 acc = f29_one<P>();
@@ -191,6 +197,7 @@ __global__ void __launch_bounds__(256) prefix_product_blocks(const fp_words* __r
   if (tid == 0) store_hat(bprod + blockIdx.x, total);
 }
 __global__ void __launch_bounds__(1024) prefix_product_scan_blocks(fp_words* __restrict__ bprod, uint32_t nblk) {
+  side_kernel_prio();
   __shared__ uint32_t sh[1024][9];
   const uint32_t tid = threadIdx.x;
   f29 mine = tid < nblk ? load_hat(bprod + tid) : f29_one<P>();
@@ -201,6 +208,7 @@ __global__ void __launch_bounds__(256) prefix_product_write(const fp_words* __re
                                                             const fp_words* __restrict__ bprod, words8 init,
                                                             uint32_t has_init, uint32_t count_out,
                                                             fp_words* __restrict__ out) {
+  side_kernel_prio();
   __shared__ uint32_t sh[PP_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * PP_THREADS + tid) * PP_CH;
   f29 v[PP_CH];
@@ -222,6 +230,7 @@ __global__ void __launch_bounds__(256) prefix_product_write(const fp_words* __re
 // ---- element-wise: out = a * b ------------------------------------------------------------------
 __global__ void mul_elementwise_kernel(const fp_words* __restrict__ a, const fp_words* __restrict__ b, uint32_t n,
                                        fp_words* __restrict__ out) {
+  side_kernel_prio();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // a~ * b^ * 2^-261 = (ab)~
@@ -290,6 +299,7 @@ static KatePowers kate_powers(const words8& b) {
 }
 __global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ a, uint32_t n, KatePowers pw,
                                                    fp_words* __restrict__ bval) {
+  side_kernel_prio();
   __shared__ uint32_t sh[KD_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
   f29 vals[KD_CH];
@@ -299,6 +309,7 @@ __global__ void __launch_bounds__(256) kate_blocks(const fp_words* __restrict__ 
 }
 // carry[k] = sum_{u > k} bval[u] * (b^KD_BLOCK)^(u - k - 1): the value of s just above block k
 __global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ bval, uint32_t nblk, KatePowers pw) {
+  side_kernel_prio();
   __shared__ uint32_t sh[1024][9];
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;        // nthr = power of two >= nblk: log2(nthr) scan steps
   f29 mine = tid < nblk ? load_hat(bval + tid) : f29_zero();
@@ -314,6 +325,7 @@ __global__ void __launch_bounds__(1024) kate_scan_blocks(fp_words* __restrict__ 
 __global__ void __launch_bounds__(256) kate_write(const fp_words* __restrict__ a, uint32_t n, KatePowers pw,
                                                   const fp_words* __restrict__ carry, fp_words* __restrict__ q_out,
                                                   fp_words* __restrict__ rem_out) {
+  side_kernel_prio();
   __shared__ uint32_t sh[KD_THREADS][9];
   const uint32_t tid = threadIdx.x, first = (blockIdx.x * KD_THREADS + tid) * KD_CH;
   f29 vals[KD_CH];
@@ -354,6 +366,7 @@ struct CanonCols {
   const fp_words* col[16];
 };
 __global__ void __launch_bounds__(256) count_noncanonical_kernel(CanonCols cols, uint32_t n, uint32_t* __restrict__ count) {
+  side_kernel_prio();
   // r as 8 LE words
   const uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,6 +396,7 @@ struct KateBatch {
 };
 __global__ void __launch_bounds__(256) kate_blocks_batch(KateBatch bt, uint32_t n, const KatePowers* __restrict__ pws,
                                                          fp_words* __restrict__ bval, uint32_t nblk) {
+  side_kernel_prio();
   __shared__ uint32_t sh[KD_THREADS][9];
   __shared__ KatePowers pw;
   for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
@@ -396,6 +410,7 @@ __global__ void __launch_bounds__(256) kate_blocks_batch(KateBatch bt, uint32_t 
 }
 __global__ void __launch_bounds__(1024) kate_scan_blocks_batch(fp_words* __restrict__ bval, uint32_t nblk,
                                                                const KatePowers* __restrict__ pws) {
+  side_kernel_prio();
   __shared__ uint32_t sh[1024][9];
   __shared__ KatePowers pw;
   for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
@@ -415,6 +430,7 @@ __global__ void __launch_bounds__(1024) kate_scan_blocks_batch(fp_words* __restr
 }
 __global__ void __launch_bounds__(256) kate_write_batch(KateBatch bt, uint32_t n, const KatePowers* __restrict__ pws,
                                                         const fp_words* __restrict__ carry_all, uint32_t nblk) {
+  side_kernel_prio();
   __shared__ uint32_t sh[KD_THREADS][9];
   __shared__ KatePowers pw;
   for (uint32_t i = threadIdx.x; i < sizeof(KatePowers) / 4; i += blockDim.x)
@@ -453,6 +469,7 @@ struct LinCombArgs {
   uint32_t n_low;
 };
 __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgs a, uint32_t m, uint32_t n, fp_words* __restrict__ out) {
+  side_kernel_prio();
   __shared__ uint32_t s_c[LINCOMB_MAX][9];
   if (threadIdx.x < m) {
     f29 c = f29_words_to_r261<P>(a.coeff[threadIdx.x].l);
@@ -530,6 +547,7 @@ hipError_t poly_prefix_product(const fp_words* d_a, size_t n, fp_words* d_tmp, f
 __global__ void __launch_bounds__(256) perm_fraction_kernel(PermCols cols, uint32_t ncols, words8 beta_w, words8 gamma_w, words8 dstart_w,
                                                             words8 delta_w, words8 omega_w, uint32_t n, uint32_t numer,
                                                             const fp_words* __restrict__ pow_tab, fp_words* __restrict__ io) {
+  side_kernel_prio();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
@@ -550,6 +568,7 @@ __global__ void __launch_bounds__(256) perm_fraction_kernel(PermCols cols, uint3
 // lookup: den[i] = (a'[i] + beta)(s'[i] + gamma);  num[i] = (a[i] + beta)(s[i] + gamma)
 __global__ void lookup_fraction_kernel(const fp_words* __restrict__ x, const fp_words* __restrict__ y, words8 beta_w,
                                        words8 gamma_w, uint32_t n, uint32_t numer, fp_words* __restrict__ io) {
+  side_kernel_prio();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
@@ -679,6 +698,7 @@ struct RandomBatch {
   uint32_t n[RANDOM_BATCH_MAX];
 };
 __global__ void __launch_bounds__(256) fr_random_kernel(ChaChaKey key, uint32_t stream_lo0, uint32_t stream_hi0, RandomBatch rb) {
+  side_kernel_prio();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = rb.n[blockIdx.y];
   if (i >= n) return;
@@ -753,6 +773,7 @@ __device__ __forceinline__ bool small_canonical(const fp_words* p, uint32_t* v) 
 }
 __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __restrict__ input, const fp_words* __restrict__ table,
                                                            size_t rows, uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
+  side_kernel_prio();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   uint32_t a, t;
@@ -783,6 +804,7 @@ __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __res
 }
 // one workgroup: three exclusive prefix sums over the bins (input counts, repeated rows, leftover table values)
 __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag, uint32_t rows) {
+  side_kernel_prio();
   __shared__ uint32_t s_sum[3][1024];
   const uint32_t bound = min(flag[1] + 1, LOOKUP_BINS), PER = (bound + 1023) / 1024;
   const uint32_t tid = threadIdx.x;
@@ -845,6 +867,7 @@ __device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, con
 __global__ void __launch_bounds__(256) lookup_permute_write(size_t rows, const uint32_t* __restrict__ work,
                                                             const uint32_t* __restrict__ flag, fp_words* __restrict__ out_a,
                                                             fp_words* __restrict__ out_s) {
+  side_kernel_prio();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows || flag[0]) return;   // flagged inputs: the caller discards the outputs
   const uint32_t bound = min(flag[1] + 1, LOOKUP_BINS);

@@ -19,10 +19,12 @@
 // ONE fused two-product reduction  values * y^ + raw_term * 2^(261+5j)  (f29_mul2), which both
 // applies the y-fold and undoes the drift.  ~45 products per row: VALU-bound like the rest.
 #include "quotient.h"
+#include "side_prio.cuh"
 
 #include <cstring>
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(quotient_set_side_prio)
 
 typedef Fr29 P;
 __device__ __forceinline__ f29 ld(const fp_words* p, size_t i) { return f29_load_r256<P>(p + i); }
@@ -35,6 +37,7 @@ struct QuotConsts {  // per-launch constants, converted once per workgroup
 };
 
 __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
+  side_kernel_prio();
   __shared__ uint32_t sc[7][9];
   const uint32_t tid = threadIdx.x;
   const size_t n_blk = (size_t)1 << a.ext_k;                       // rows per block: the whole domain, or one coset
@@ -105,6 +108,7 @@ __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
 }
 
 __global__ void __launch_bounds__(256) quot_lookup_kernel(QuotLookupArgs a) {
+  side_kernel_prio();
   __shared__ uint32_t sc[4][9];
   const uint32_t tid = threadIdx.x;
   const size_t n_blk = (size_t)1 << a.ext_k;
@@ -148,6 +152,7 @@ struct CosetShifts {
   uint32_t c[MAX_COSETS][8];
 };
 __global__ void __launch_bounds__(256) coset_fill_powers_kernel(fp_words* __restrict__ table, CosetShifts c, uint32_t log_n) {
+  side_kernel_prio();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (i >> log_n) return;
   f29_store_canonical<P>(table + ((size_t)b << log_n) + i, f29_pow_u64<P>(f29_words_to_r261<P>(c.c[b]), i));
@@ -161,6 +166,7 @@ hipError_t coset_fill_powers(fp_words* table, const words8* c, uint32_t nc, uint
   return hipGetLastError();
 }
 __global__ void __launch_bounds__(256) coset_scale_kernel(CosetScaleArgs a) {
+  side_kernel_prio();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> a.log_n) return;
   const f29 x = ld(a.in[blockIdx.y], i);                       // x~, bound < 6 for any 256-bit word value
@@ -196,6 +202,7 @@ __device__ __forceinline__ f29 coset_matrix_entry(const uint32_t (*sm)[9], uint3
 // NC <= 5 cosets, known at compile time: the loops unroll and p[] stays in registers
 template <uint32_t NC>
 __global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) {
+  side_kernel_prio();
   __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
   coset_matrix_to_lds(a, NC, sm);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,6 +222,7 @@ __global__ void __launch_bounds__(256) coset_combine_kernel(CosetCombineArgs a) 
 }
 // any a.nc <= MAX_COSETS (p[] indexed at run time)
 __global__ void __launch_bounds__(256) coset_combine_any_kernel(CosetCombineArgs a) {
+  side_kernel_prio();
   __shared__ uint32_t sm[MAX_COSETS * MAX_COSETS][9];
   coset_matrix_to_lds(a, a.nc, sm);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -28,8 +28,12 @@
 #include "gates.h"
 #include "poly.h"
 #include "witness.h"
+#include "side_prio.cuh"
 
 using namespace sg;
+namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(abi_set_side_prio)
+}
 
 namespace {
 
@@ -63,6 +67,7 @@ __device__ void put_words(words8* dst, const f29& v_r261) {
 }
 // EvaluationDomain::new constants for 2^k (computed in the 2^261 domain, exported as words)
 __global__ void domain_kernel(uint32_t k, DomainConsts* out) {
+  side_kernel_prio();
   typedef Fr29 P;
   uint32_t rw[8], zw[8];
   for (int i = 0; i < 8; i++) { rw[i] = ROOT_OF_UNITY_M[i]; zw[i] = ZETA_M[i]; }
@@ -84,6 +89,7 @@ __global__ void domain_kernel(uint32_t k, DomainConsts* out) {
 }
 // t_evaluations[i] = 1 / ((zeta * omega_ext^i)^(2^k) - 1), i < 2^(ext_k - k)
 __global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, words8 omega_ext, fp_words* out) {
+  side_kernel_prio();
   typedef Fr29 P;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> (ext_k - k)) return;
@@ -100,6 +106,7 @@ __global__ void t_eval_kernel(uint32_t k, uint32_t ext_k, words8 omega_ext, fp_w
 // ParamsKZG::setup scalars: pw[i] = tau^i, lg[i] = L_i(tau) = omega^i (tau^n - 1) / (n (tau - omega^i))
 // (Montgomery-2^256 words); the group part is g1_fixed_base_mul over them.
 __global__ void kzg_setup_scalars(uint32_t k, words8 tau_w, fp_words* pw, fp_words* lg) {
+  side_kernel_prio();
   typedef Fr29 P;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> k) return;
@@ -204,10 +211,30 @@ thread_local int g_depth = 0;
 
 int apply_param(Context& c, const std::string& s, int value);
 
-int make_context(int device, Context** out) {
+// The lanes' main streams are created together, before any of the library's other streams: HIP gives a new stream the
+// least used of its hardware queues (four by default), so streams created back to back land on different queues, and two
+// streams on ONE hardware queue run their kernels one after the other whatever the priorities -- the next MSM's sort then
+// sits behind the current accumulation instead of under it (profiles/r03_sweeps/persistent_accumulate.txt).  Raising the number
+// of hardware queues (GPU_MAX_HW_QUEUES) is not an option: a batch of proofs in flight collapses with 8 or 16 of them.
+hipStream_t g_lane_main[kLanes] = {};
+bool g_lane_main_made = false;   // guarded by g_sh.mu
+hipError_t make_lane_streams() {
+  if (g_lane_main_made) return hipSuccess;
+  for (auto& st : g_lane_main) {
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  g_lane_main_made = true;
+  return hipSuccess;
+}
+int make_context(int device, int lane_index, Context** out) {
   Context* c = new Context();
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    e = make_lane_streams();
+    if (e == hipSuccess) c->stream = g_lane_main[lane_index];
+  }
   if (e == hipSuccess) e = c->ntt.init();
   if (e == hipSuccess) e = c->msm.init();
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->bstream[0], hipStreamNonBlocking);
@@ -251,7 +278,7 @@ void destroy_context(Context* c) {
   for (auto& kv : c->ntt_scratch) kv.second.release();
   for (auto& kv : c->stream_scratch) kv.second.release();
   if (c->d_consts) (void)hipFree(c->d_consts);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = nullptr;   // one of g_lane_main: destroyed with the others at sg_shutdown
   delete c;
 }
 
@@ -279,7 +306,7 @@ int acquire_lane() {
     lane->mu.lock();
   }
   if (!lane->ctx) {
-    int rc = make_context(device, &lane->ctx);
+    int rc = make_context(device, (int)(lane - g_lanes), &lane->ctx);
     if (rc != SG_OK) {
       lane->mu.unlock();
       return rc;
@@ -406,6 +433,19 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; c.msm.config().red_threads = c.msm_b.config().red_threads = v; }
   else if (s == "msm.log_scatter_rounds") c.msm.config().log_scatter_rounds = c.msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));
   else if (s == "msm.two_pass") c.msm.config().two_pass = c.msm_b.config().two_pass = (uint32_t)std::min(2, std::max(0, value));
+  else if (s == "side_prio") {   // device-wide, not per lane: wave priority 3 for every kernel but msm_accumulate (side_prio.cuh)
+    const uint32_t on = value ? 1u : 0u;
+    hipError_t e = msm_set_side_prio(on);
+    if (e == hipSuccess) e = ntt_set_side_prio(on);
+    if (e == hipSuccess) e = poly_set_side_prio(on);
+    if (e == hipSuccess) e = quotient_set_side_prio(on);
+    if (e == hipSuccess) e = gates_set_side_prio(on);
+    if (e == hipSuccess) e = witness_set_side_prio(on);
+    if (e == hipSuccess) e = abi_set_side_prio(on);
+    if (e != hipSuccess) return hip_fail("side_prio", e);
+  }
+  else if (s == "msm.acc_chain") c.msm.config().acc_chain = c.msm_b.config().acc_chain = value ? 1u : 0u;
+  else if (s == "msm.red_lean") c.msm.config().red_lean = c.msm_b.config().red_lean = (uint32_t)std::max(0, std::min(2, value));
   else if (s == "msm.acc_waves_fixed") c.msm.config().acc_waves_fixed = c.msm_b.config().acc_waves_fixed = (uint32_t)std::max(0, std::min(8, value));
   else if (s == "msm.acc_waves") c.msm.config().acc_waves = c.msm_b.config().acc_waves = (uint32_t)std::max(0, std::min(8, value));
   else if (s == "msm.acc_threads") c.msm.config().acc_threads = c.msm_b.config().acc_threads = (value == 64 || value == 128 || value == 256) ? (uint32_t)value : 0u;
@@ -479,6 +519,14 @@ void sg_shutdown(void) {
       if (l.ctx) destroy_context(l.ctx);
       l.ctx = nullptr;
     }
+    {
+      std::lock_guard<std::mutex> lk(g_sh.mu);
+      for (auto& st : g_lane_main) {
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+      }
+      g_lane_main_made = false;
+    }
     std::lock_guard<std::mutex> lk(g_sh.mu);
     for (auto& kv : g_sh.srs) {
       (void)hipFree(kv.second.g);
@@ -524,8 +572,21 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
   if (!out_affine || (n && (!d_scalars || !d_bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
   LOCKED_CTX();
   MsmTimings tm;
+  // on the lane's own stream, after everything the caller has enqueued on his: the call returns the point, so nothing of
+  // it is left on any stream afterwards, and the lanes' streams sit on different hardware queues (make_lane_streams) --
+  // which the streams of callers on different threads may or may not
+  hipStream_t st = pick_stream(stream);
+  if (st != g_ctx->stream) {
+    // (an idle caller stream needs no edge -- and a marker on it would queue behind whatever shares ITS hardware queue,
+    // another lane's accumulation for instance)
+    if (hipStreamQuery(st) != hipSuccess) {
+      CHECK_HIP(hipEventRecord(g_ctx->ev_in, st), "event");
+      CHECK_HIP(hipStreamWaitEvent(g_ctx->stream, g_ctx->ev_in, 0), "wait");
+    }
+    st = g_ctx->stream;
+  }
   hipError_t e = g_ctx->msm.run(static_cast<const fp_words*>(d_scalars), static_cast<const g1_affine_mem*>(d_bases), n,
-                                pick_stream(stream), out_affine, timings ? &tm : nullptr);
+                                st, out_affine, timings ? &tm : nullptr);
   if (e != hipSuccess) return hip_fail("msm", e);
   if (timings) {
     timings->digits_ms = tm.digits_ms; timings->sort_ms = tm.sort_ms; timings->accumulate_ms = tm.accumulate_ms;

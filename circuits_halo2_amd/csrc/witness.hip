@@ -7,10 +7,12 @@
 // added to state[0] and followed by one permutation; the output is state[0].
 // One thread per hash; 472-ish Fr products per permutation, so the kernels are VALU-bound.
 #include "witness.h"
+#include "side_prio.cuh"
 
 #include "poseidon_constants.inc"
 
 namespace sg {
+SG_DEFINE_SIDE_PRIO_SETTER(witness_set_side_prio)
 
 typedef Fr29 P;
 struct PoseidonTable {  // 2^261-domain limbs, built once per context
@@ -20,6 +22,7 @@ struct PoseidonTable {  // 2^261-domain limbs, built once per context
 
 __global__ void poseidon_table_kernel(const uint32_t* __restrict__ rc_words, const uint32_t* __restrict__ mds_words,
                                       PoseidonTable* out) {
+  side_kernel_prio();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 128) {
     uint32_t w[8];
@@ -103,6 +106,7 @@ __global__ void __launch_bounds__(128) mst_leaves_kernel(const fp_words* __restr
                                                          const fp_words* __restrict__ balances, uint32_t n,
                                                          uint32_t nc, const PoseidonTable* __restrict__ table,
                                                          fp_words* __restrict__ hashes) {
+  side_kernel_prio();
   __shared__ LdsTable tab;
   stage_table(table, &tab);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,6 +125,7 @@ __global__ void __launch_bounds__(128) mst_level_kernel(const fp_words* __restri
                                                         const fp_words* __restrict__ child_bal, uint32_t m,
                                                         uint32_t nc, const PoseidonTable* __restrict__ table,
                                                         fp_words* __restrict__ hashes, fp_words* __restrict__ bal) {
+  side_kernel_prio();
   __shared__ LdsTable tab;
   stage_table(table, &tab);
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +207,7 @@ __global__ void __launch_bounds__(64) mst_inclusion_witness_kernel(const Witness
                                                                   const uint32_t* __restrict__ user_index, uint32_t n_users,
                                                                   const PoseidonTable* __restrict__ table, fp_words* advice,
                                                                   size_t rows, size_t user_stride) {
+  side_kernel_prio();
   __shared__ LdsTable tab;
   stage_table(table, &tab);
   // hash items first in the program: whole waves of sponges, then the cheap cell copies
