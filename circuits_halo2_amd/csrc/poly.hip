@@ -668,7 +668,7 @@ hipError_t poly_kate_division_batch(const fp_words* const* d_a, size_t n, const 
 }
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
                         hipStream_t stream, const words8* low, uint32_t n_low) {
-  if (m == 0 || m > LINCOMB_MAX || n_low > LINCOMB_LOW_MAX || n_low > n) return hipErrorInvalidValue;
+  if (m > LINCOMB_MAX || n_low > LINCOMB_LOW_MAX || n_low > n) return hipErrorInvalidValue;   // m = 0: the low polynomial alone
   if (n == 0) return hipSuccess;
   LinCombArgs a;
   for (uint32_t j = 0; j < m; j++) {

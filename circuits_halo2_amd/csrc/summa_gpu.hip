@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <deque>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -151,6 +152,8 @@ struct Context {
   DevBuf<uint8_t> stage_a, stage_b, scratch;
   std::vector<uint8_t> gate_blob_host;
   std::map<uint64_t, GateProgram> gate_cache;  // lowered gate programs by structure hash
+  uint64_t gate_recent[4] = {0, 0, 0, 0};      // keys of the programs used last (tried first, by comparison)
+  uint32_t gate_recent_next = 0;
   // in-place multi-pass transforms need a scratch vector; one per caller stream, so that transforms
   // enqueued on a side stream never share it with work in flight on another stream
   std::map<hipStream_t, DevBuf<uint8_t>> ntt_scratch;
@@ -211,20 +214,19 @@ thread_local int g_depth = 0;
 
 int apply_param(Context& c, const std::string& s, int value);
 
-// The lanes' main streams are created together, before any of the library's other streams: HIP gives a new stream the
-// least used of its hardware queues (four by default), so streams created back to back land on different queues, and two
-// streams on ONE hardware queue run their kernels one after the other whatever the priorities -- the next MSM's sort then
-// sits behind the current accumulation instead of under it (profiles/r03_sweeps/persistent_accumulate.txt).  Raising the number
-// of hardware queues (GPU_MAX_HW_QUEUES) is not an option: a batch of proofs in flight collapses with 8 or 16 of them.
-hipStream_t g_lane_main[kLanes] = {};
-bool g_lane_main_made = false;   // guarded by g_sh.mu
-hipError_t make_lane_streams() {
-  if (g_lane_main_made) return hipSuccess;
-  for (auto& st : g_lane_main) {
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+// The main streams of the lanes in use are created together, before any of the library's other streams, so that they land
+// on different hardware queues: two streams on ONE queue run their kernels one after the other whatever the priorities,
+// and the next MSM's sort then sits behind the current accumulation instead of under it
+// (profiles/r03_sweeps/persistent_accumulate.txt).  No more of them than lanes: every stream is a queue the firmware has
+// to schedule, and idle ones cost too (a k = 17 proof: 5.83 ms with four, 6.27 ms with eight; raising HIP's number of
+// hardware queues, GPU_MAX_HW_QUEUES = 8 / 16, takes a batch of sixteen proofs in flight from 237 to 140 / 52 proofs/s).
+hipStream_t g_lane_main[kLanes] = {};   // guarded by g_sh.mu
+hipError_t make_lane_streams(int count) {
+  for (int i = 0; i < count && i < kLanes; i++) {
+    if (g_lane_main[i]) continue;
+    hipError_t e = hipStreamCreateWithFlags(&g_lane_main[i], hipStreamNonBlocking);
     if (e != hipSuccess) return e;
   }
-  g_lane_main_made = true;
   return hipSuccess;
 }
 int make_context(int device, int lane_index, Context** out) {
@@ -232,7 +234,7 @@ int make_context(int device, int lane_index, Context** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> lk(g_sh.mu);
-    e = make_lane_streams();
+    e = make_lane_streams(std::max(g_lane_count.load(), lane_index + 1));
     if (e == hipSuccess) c->stream = g_lane_main[lane_index];
   }
   if (e == hipSuccess) e = c->ntt.init();
@@ -525,7 +527,6 @@ void sg_shutdown(void) {
         if (st) (void)hipStreamDestroy(st);
         st = nullptr;
       }
-      g_lane_main_made = false;
     }
     std::lock_guard<std::mutex> lk(g_sh.mu);
     for (auto& kv : g_sh.srs) {
@@ -2061,14 +2062,14 @@ int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_
 
 int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, const uint8_t* low, uint32_t n_low,
                           void* d_out, void* stream) {
-  if (!d_polys || !coeffs || (n && !d_out) || (n_low && !low)) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: null argument");
-  if (m == 0 || m > LINCOMB_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: between 1 and 32 polynomials");
+  if ((m && (!d_polys || !coeffs)) || (n && !d_out) || (n_low && !low)) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: null argument");
+  if (m > LINCOMB_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: at most 32 polynomials");
   if (n >= (1ull << 32) || n_low > LINCOMB_LOW_MAX || n_low > n) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: bad length");
   for (uint32_t j = 0; j < m; j++)
     if (n && !d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_lincomb_low: null polynomial");
   LOCKED_CTX();
   words8 cw[LINCOMB_MAX], lw[LINCOMB_LOW_MAX];
-  std::memcpy(cw, coeffs, 32 * (size_t)m);
+  if (m) std::memcpy(cw, coeffs, 32 * (size_t)m);
   if (n_low) std::memcpy(lw, low, 32 * (size_t)n_low);
   hipError_t e = poly_lincomb(reinterpret_cast<const fp_words* const*>(d_polys), cw, m, n, static_cast<fp_words*>(d_out),
                               pick_stream(stream), lw, n_low);
@@ -2199,36 +2200,61 @@ static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void
     return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
   if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_gates: bad shape");
   LOCKED_CTX();
-  // the lowered program depends on the graph's structure only (constants / challenges are a table refreshed per
-  // call): cache it under a hash of the structure
-  uint64_t key = 1469598103934665603ull;
-  std::vector<uint8_t> sig;  // the exact structure: a cache hit is confirmed byte for byte
-  auto mix = [&](const void* p, size_t len) {
-    const uint8_t* b = static_cast<const uint8_t*>(p);
-    for (size_t i = 0; i < len; i++) key = (key ^ b[i]) * 1099511628211ull;
-    sig.insert(sig.end(), b, b + len);
-  };
+  // the lowered program depends on the graph's structure only (constants / challenges are a table refreshed per call):
+  // cached under the structure itself.  A prover sends the same two programs proof after proof, so the lane's most recent
+  // hits are tried first with one memcmp each (the structure of the reference circuit's gate program is 100+ KB: hashing
+  // it byte by byte cost 0.3 ms of host time per proof, with the device idle behind it)
+  std::vector<uint8_t> sig;
   {
     const uint32_t hdr[8] = {graph->n_constants, graph->n_rotations, graph->n_calculations, graph->n_horner_parts, n_fixed,
                              n_advice, n_instance, n_challenges};
-    mix(hdr, sizeof hdr);
-    if (graph->rotations) mix(graph->rotations, sizeof(int32_t) * graph->n_rotations);
-    if (graph->calculations) mix(graph->calculations, sizeof(sg_calculation) * graph->n_calculations);
-    if (graph->horner_parts) mix(graph->horner_parts, sizeof(sg_value_source) * graph->n_horner_parts);
+    const size_t parts[4] = {sizeof hdr, graph->rotations ? sizeof(int32_t) * graph->n_rotations : 0,
+                             graph->calculations ? sizeof(sg_calculation) * graph->n_calculations : 0,
+                             graph->horner_parts ? sizeof(sg_value_source) * graph->n_horner_parts : 0};
+    const void* src[4] = {hdr, graph->rotations, graph->calculations, graph->horner_parts};
+    sig.resize(parts[0] + parts[1] + parts[2] + parts[3]);
+    size_t at = 0;
+    for (int i = 0; i < 4; i++) {
+      if (parts[i]) std::memcpy(sig.data() + at, src[i], parts[i]);
+      at += parts[i];
+    }
   }
-  GateProgram fresh;
-  std::string err = "";
-  auto hit = g_ctx->gate_cache.find(key);
-  if (hit != g_ctx->gate_cache.end() && hit->second.signature != sig) {  // 64-bit collision: recompile
-    g_ctx->gate_cache.erase(hit);
-    hit = g_ctx->gate_cache.end();
+  auto hit = g_ctx->gate_cache.end();
+  for (uint64_t recent : g_ctx->gate_recent) {
+    auto it = g_ctx->gate_cache.find(recent);
+    if (it != g_ctx->gate_cache.end() && it->second.signature == sig) {
+      hit = it;
+      break;
+    }
   }
+  uint64_t key = 1469598103934665603ull;
   if (hit == g_ctx->gate_cache.end()) {
+    size_t i = 0;
+    for (; i + 8 <= sig.size(); i += 8) {
+      uint64_t w;
+      std::memcpy(&w, sig.data() + i, 8);
+      key = (key ^ w) * 1099511628211ull;
+    }
+    for (; i < sig.size(); i++) key = (key ^ sig[i]) * 1099511628211ull;
+    hit = g_ctx->gate_cache.find(key);
+    if (hit != g_ctx->gate_cache.end() && hit->second.signature != sig) {  // 64-bit collision: recompile
+      g_ctx->gate_cache.erase(hit);
+      hit = g_ctx->gate_cache.end();
+    }
+  }
+  std::string err = "";
+  if (hit == g_ctx->gate_cache.end()) {
+    GateProgram fresh;
     err = compile_gates(*graph, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y, &fresh);
     if (!err.empty()) return fail(SG_ERR_INVALID, ("sg_quotient_gates: " + err).c_str());
     fresh.signature = std::move(sig);
     if (g_ctx->gate_cache.size() >= 64) g_ctx->gate_cache.clear();
     hit = g_ctx->gate_cache.emplace(key, std::move(fresh)).first;
+  }
+  {
+    bool listed = false;
+    for (uint64_t recent : g_ctx->gate_recent) listed = listed || recent == hit->first;
+    if (!listed) g_ctx->gate_recent[g_ctx->gate_recent_next++ % 4] = hit->first;
   }
   GateProgram& prog = hit->second;
   if ((graph->n_constants && !graph->constants)) return fail(SG_ERR_INVALID, "sg_quotient_gates: null constants");
@@ -2258,9 +2284,12 @@ static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void
   Context::BlobSlot& slot = g_ctx->blob_ring[g_ctx->blob_next++ % Context::BLOB_RING];
   hipError_t e = hipSuccess;
   if (!slot.ev) e = hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming);
-  else e = hipEventSynchronize(slot.ev);
+  else if (hipEventQuery(slot.ev) != hipSuccess) e = hipEventSynchronize(slot.ev);   // (a query first: waiting on an event that
+                                                                                     // has long completed still costs a wake-up, 0.3 ms)
   if (e == hipSuccess && slot.cap < bytes) {
-    const size_t want = bytes + bytes / 2 + 256;
+    // (never small: the ring rotates, and a slot sized by a small program would be re-allocated -- two allocations, 0.25 ms
+    // with the device idle -- the first time the big program of the same prover comes round to it)
+    const size_t want = std::max<size_t>(bytes + bytes / 2 + 256, (size_t)256 << 10);
     if (slot.host) (void)hipHostFree(slot.host);
     retire_device_memory(slot.dev);
     slot.host = nullptr;

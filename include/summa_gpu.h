@@ -313,7 +313,8 @@ int sg_fr_count_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
 /* the same plus a polynomial of n_low <= 8 coefficients given by value (32 B Montgomery each): out[i] += low[i] for i < n_low.
  * What SHPLONK's q_i(X) - r_i(X) needs -- r_i interpolates a rotation set's evaluations, at most four coefficients -- without
- * a zeroed column, an upload and a second pass for it. */
+ * a zeroed column, an upload and a second pass for it.  m = 0 (d_polys, coeffs may be NULL): out = the low polynomial itself,
+ * zeros from row n_low on -- an instance column from its few values in one launch. */
 int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, const uint8_t* low, uint32_t n_low,
                           void* d_out, void* stream);
 

@@ -939,8 +939,13 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   }
   rand_rows({{&advice[0], u, n - u}, {&advice[1], u, n - u}, {&advice[2], u, n - u}});
   DevCol instance_col(n);
-  instance_col.zero();
-  if (!instances.empty()) instance_col.upload(instances.data(), 0, instances.size());
+  if (instances.size() <= 8) {   // the column = its few values then zeros: one launch, the values travel as kernel arguments
+    ck(sg_fr_lincomb_low_dev(nullptr, nullptr, 0, n, instances.empty() ? nullptr : instances[0].bytes(), (uint32_t)instances.size(),
+                             instance_col.p, main_stream()), "instance column");
+  } else {
+    instance_col.zero();
+    instance_col.upload(instances.data(), 0, instances.size());
+  }
   std::vector<DevCol> co1, ex1;
   fork();
   // under the commitments; issued FIRST: started later (after the lookup's kernels) these transforms ran into the commitment
@@ -1025,10 +1030,12 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     join();
     void* z1p[1] = {zs[1].p};
     ck(sg_fr_lincomb_dev(z1p, z0_last.bytes(), 1, n, zs[1].p, main_stream()), "z1 *= z0[u]");
-    d2h(last.l, zs[1].at(u), 32);
-    if (opt.sanity_checks && last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
-    d2h(last.l, lz.at(u), 32);
-    if (opt.sanity_checks && last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
+    if (opt.sanity_checks) {   // (two blocking reads: only when asked for)
+      d2h(last.l, zs[1].at(u), 32);
+      if (last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
+      d2h(last.l, lz.at(u), 32);
+      if (last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
+    }
   }
   mark("3: grand products closed (sanity reads)");
   DevCol random_poly(n);
@@ -1050,10 +1057,21 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   DevCol values(ne), input_c(ne);
   hk(hipMemsetAsync(values.p, 0, 32 * ne, main_stream()), "memset");
   std::vector<Fr> y_powers;   // the gate program's challenges: sums of powers of y (ProvingKey::gate_challenge_exps)
-  for (auto& group : pk.gate_challenge_exps) {
-    Fr v = Fr::zero();
-    for (uint32_t e : group) v = v + y.pow((uint64_t)e);
-    y_powers.push_back(v);
+  {
+    uint32_t top = 0;
+    for (auto& group : pk.gate_challenge_exps)
+      for (uint32_t e : group) top = std::max(top, e);
+    std::vector<Fr> pw;   // y^0 .. y^top by one product each (an exponentiation per term was 60 us of host time with the device idle)
+    if (top < (1u << 16)) {
+      pw.resize((size_t)top + 1);
+      pw[0] = Fr::one();
+      for (uint32_t e = 1; e <= top; e++) pw[e] = pw[e - 1] * y;
+    }
+    for (auto& group : pk.gate_challenge_exps) {
+      Fr v = Fr::zero();
+      for (uint32_t e : group) v = v + (pw.empty() ? y.pow((uint64_t)e) : pw[e]);
+      y_powers.push_back(v);
+    }
   }
   if (y_powers.empty()) y_powers.push_back(Fr::zero());
   mark("4: challenges of the gate program ready");
@@ -1066,6 +1084,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_quotient_gates_cosets_dev(values.p, &g_gates, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1,
                                     y_powers[0].bytes(), (uint32_t)pk.gate_challenge_exps.size(), beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k,
                                     QUOTIENT_PIECES, main_stream()), "gates");
+    mark("4: gate block enqueued");
     std::vector<void*> col_e, sig_e, z_e = {ex3[2].p, ex3[3].p};
     for (uint32_t c = 0; c < NUM_SIGMA; c++) {
       col_e.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
@@ -1074,8 +1093,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_quotient_permutation_cosets_dev(values.p, z_e.data(), 2, col_e.data(), sig_e.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p, pk.l_last_ext.p,
                                           pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, QUOTIENT_PIECES, BLINDING + 1,
                                           main_stream()), "permutation quotient");
+    mark("4: permutation block enqueued");
     ck(sg_quotient_gates_cosets_dev(input_c.p, &g_in, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1, nullptr, 0,
                                     beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()), "lookup input (cosets)");
+    mark("4: lookup input enqueued");
     ck(sg_quotient_lookup_cosets_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_c.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
                                      pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()),
        "lookup quotient");
