@@ -448,7 +448,15 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
 /* name: "lanes" (1..8, default 4: concurrent calls that get a context of their own, see the conventions at the top),
  * "commit.combine_wait_us" (see sg_commit_combine_begin),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
- * "ntt.max_single_log", "ntt.max_multi_log" */
+ * "ntt.max_single_log", "ntt.max_multi_log";
+ * how calls in flight share the device (the defaults are what the measurements chose):
+ *   "side_prio" (1 | 0): every kernel but the MSM's accumulation runs at wave priority 3, so that a kernel of another call that
+ *     lands beside an accumulation is not starved of issue slots by it (device-wide, not per lane);
+ *   "msm.acc_waves" / "msm.acc_waves_fixed" (0 = default, 2, 3, 8): waves per SIMD of the persistent accumulation launch of
+ *     generic / fixed-base jobs -- default: 3 (a full register file) for a generic job that has the device to itself, 2 (a
+ *     third of the file left to other kernels) when other jobs are in flight and for fixed-base jobs; 8: one ticket per wave;
+ *   "msm.acc_chain" (1 | 0): accumulations of different calls run one after the other;
+ *   "msm.red_lean" (0 | 1 | 2): the bucket reduction's 168-register twin never / when other jobs are in flight / always. */
 int sg_set_param(const char* name, int value);
 /* Time `reps` back-to-back launches of the operation with HIP events on the library's
  * stream; returns average milliseconds per launch in *ms_out (used by bench.py for the

@@ -164,3 +164,59 @@ def test_thread_binding_reports_the_bound_device():
         other = torch.zeros(32, dtype=torch.uint8, device=torch.device("cuda", (L.sg_device() + 1) % torch.cuda.device_count()))
         with pytest.raises(ffi.SummaGpuError):
             ffi.dev_ptr(other)
+
+
+def test_calls_in_flight_are_bit_exact_under_every_sharing_setting():
+    """persistent accumulation (2 / 3 waves per SIMD, one ticket per wave), wave priorities, chained accumulations,
+    the lean bucket reduction -- none of it may change a result bit, alone or with three calls in flight"""
+    import torch
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import arithmetic as A, ffi
+    from circuits_halo2_amd.utils import random_fr_canonical
+    _gpu()
+    L = ffi.lib()
+    n = 1 << 17
+    scal = [A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(900 + i, n)).cuda()) for i in range(3)]
+    bases = A.g1_fixed_base_mul(A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(77, n)).cuda()))
+    torch.cuda.synchronize()
+    want = [bytes(sg.best_multiexp(s, bases)) for s in scal]
+    assert len(set(want)) == 3
+    settings = [{"msm.acc_waves": 2, "msm.red_lean": 2}, {"msm.acc_waves": 8, "side_prio": 0, "msm.acc_chain": 0},
+                {"msm.acc_waves": 3, "msm.red_lean": 0, "side_prio": 1}, {}]
+    defaults = {"msm.acc_waves": 0, "msm.red_lean": 1, "side_prio": 1, "msm.acc_chain": 1}
+    try:
+        for setting in settings:
+            for name, value in {**defaults, **setting}.items():
+                ffi.check(L.sg_set_param(name.encode(), int(value)))
+            got = [[] for _ in range(3)]
+
+            def run(i):
+                ffi.bind_thread()
+                for _ in range(6):
+                    got[i].append(bytes(sg.best_multiexp(scal[i], bases)))
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert all(g == [want[i]] * 6 for i, g in enumerate(got)), setting
+    finally:
+        for name, value in defaults.items():
+            ffi.check(L.sg_set_param(name.encode(), int(value)))
+
+
+def test_low_polynomial_alone_is_a_column():
+    """sg_fr_lincomb_low_dev with no polynomials: the instance column of a proof from its few values, in one launch"""
+    import torch
+    from circuits_halo2_amd import ffi
+    _gpu()
+    n = 1 << 10
+    low = np.arange(1, 6 * 8 + 1, dtype=np.uint32).view(np.uint8).copy()            # six 32-byte values (any words < r)
+    out = torch.full((32 * n,), 0xAB, dtype=torch.uint8, device="cuda")
+    ffi.check(ffi.lib().sg_fr_lincomb_low_dev(None, None, C.c_uint32(0), C.c_size_t(n), ffi.ptr(low), C.c_uint32(6), ffi.dev_ptr(out),
+                                              ffi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:32 * 6] == low).all() and not got[32 * 6:].any()
+    assert ffi.lib().sg_fr_lincomb_low_dev(None, None, C.c_uint32(0), C.c_size_t(n), ffi.ptr(low), C.c_uint32(9), ffi.dev_ptr(out),
+                                           ffi.current_stream_ptr()) != 0
