@@ -123,10 +123,12 @@ class MsmEngine {
   hipError_t finish();
 
  private:
+  hipError_t enqueue_front_fused_impl(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases, size_t M, size_t n,
+                                      hipStream_t stream, uint8_t* out_affine, MsmTimings* tm);
   hipError_t enqueue_back_impl();
   hipError_t finish_impl();
   void mark_in_flight(bool on);
-  bool others_in_flight() const;   // another engine of this process has a job between its accumulation launch and its host tail
+  bool others_in_flight() const;   // another engine of this process has a job between its first kernel and its host tail
   bool counted_ = false;
   hipError_t chain_accumulate_before(hipStream_t stream);
   hipError_t chain_accumulate_after(hipStream_t stream);

@@ -1408,6 +1408,17 @@ hipError_t MsmEngine::enqueue_front(const fp_words* d_scalars, const g1_affine_m
 hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases,
                                           size_t M, size_t n, hipStream_t stream, uint8_t* out_affine,
                                           MsmTimings* tm) {
+  // in flight from its first kernel on: an accumulation launched while ANOTHER job is still sorting must already leave
+  // room for that sort (counted from the accumulation launch only, the first accumulation after a pause took the whole
+  // register file and the other callers' front-ends waited a millisecond behind it)
+  mark_in_flight(true);
+  const hipError_t e = enqueue_front_fused_impl(d_scalars, d_bases, M, n, stream, out_affine, tm);
+  if (e != hipSuccess) mark_in_flight(false);
+  return e;
+}
+hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars, const g1_affine_mem* const* d_bases,
+                                               size_t M, size_t n, hipStream_t stream, uint8_t* out_affine,
+                                               MsmTimings* tm) {
   Job& j = job_;
   j = Job{};
   j.M = (uint32_t)M; j.n = n; j.stream = stream; j.out = out_affine; j.tm = tm;
@@ -1551,7 +1562,7 @@ hipError_t MsmEngine::enqueue_front_fused(const fp_words* const* d_scalars, cons
 }
 
 // ---- phase 2: needs the task count on the host; enqueues accumulate .. export + result copy
-// jobs of this process between their accumulation launch and the end of their host tail (all engines, all lanes)
+// jobs of this process between their first kernel and the end of their host tail (all engines, all lanes)
 static std::atomic<int> g_jobs_in_flight{0};
 void MsmEngine::mark_in_flight(bool on) {
   if (on == counted_) return;
