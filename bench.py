@@ -364,8 +364,37 @@ def main():
         collective -- stays on this thread, in step order on every rank"""
         if in_flight <= 1:
             return [exchange_partials(partial()) for _ in range(count)]
-        futures = [pool.submit(partial) for _ in range(count)]
-        return [exchange_partials(f.result()) for f in futures]
+        # the threads take step numbers from one counter (three submissions, not `count`: the main thread holds the interpreter
+        # lock while it submits, and the pool's threads start only when it lets go)
+        import itertools
+        ticket, results, failure = itertools.count(), [None] * count, []
+        ready = [threading.Event() for _ in range(count)]
+
+        def issue():
+            while not failure:
+                i = next(ticket)
+                if i >= count:
+                    return
+                try:
+                    results[i] = partial()
+                except BaseException as ex:      # noqa: BLE001 -- handed to the main thread, which raises it
+                    failure.append(ex)
+                    for ev in ready:
+                        ev.set()
+                    return
+                ready[i].set()
+        futures = [pool.submit(issue) for _ in range(in_flight)]
+        out = []
+        for i in range(count):
+            ready[i].wait()
+            if failure:
+                break
+            out.append(exchange_partials(results[i]))
+        for f in futures:
+            f.result()
+        if failure:
+            raise failure[0]
+        return out
 
     def timed(count, in_flight):
         if world > 1:

@@ -603,19 +603,10 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
 // Every kernel below is written for LOGICAL threads of Q lanes: Q = 1 is one lane per point
 // operation, Q = 4 the quad-cooperative addition (xyzz29_add_quad; all 4 lanes hold the same
 // values).  lt = logical thread, role = lane within the quad.
-#ifndef SG_ADD_CALL
-#define SG_ADD_CALL 0
-#endif
-// ONE copy of the general addition per kernel instead of one per call site
-__device__ __attribute__((noinline)) void xyzz29_add_call(xyzz29& acc, const xyzz29& q) { xyzz29_add(acc, q); }
 template <int Q>
 __device__ __forceinline__ void add_q(xyzz29& acc, const xyzz29& q, uint32_t role) {
   if (Q == 4) xyzz29_add_quad(acc, q, role);
-#if SG_ADD_CALL
-  else xyzz29_add_call(acc, q);
-#else
-  else xyzz29_add(acc, q);
-#endif
+  else xyzz29_add(acc, q);   // (inlined at every call site: one out-of-line copy per kernel was measured and is slower)
 }
 template <int Q>
 __global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ in, const uint32_t* __restrict__ off,
