@@ -82,7 +82,10 @@ const char* sg_version(void);
 
 /* ---- M1: halo2_proofs::arithmetic::best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1
  * (reached via ParamsKZG::commit / commit_lagrange).  upstream asserts
- * coeffs.len() == bases.len(); here a single n covers both.  n = 0 yields the identity. */
+ * coeffs.len() == bases.len(); here a single n covers both.  n = 0 yields the identity.
+ * sg_msm_g1_dev returns the point, i.e. it is complete on return: its kernels run on the calling lane's own stream, ordered
+ * after whatever `stream` holds at the time of the call (the lanes' streams are on distinct hardware queues, so calls from
+ * several threads overlap whatever streams the callers use: DESIGN.md section 4.11). */
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]);
 int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]);
 
