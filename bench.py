@@ -148,9 +148,9 @@ def batch_extra(args, rank, world, coll_dev):
     # of the pre-sweep runs the headline batch
     sweep = {}
     per = max(6 * world, min(96 * world, total // 4))
-    for in_flight in (1, 2, 4, 8, 12, 16):
+    for in_flight in (1, 2, 4, 8, 12, 16, 24):
         timed_batch(users[:3 * in_flight * world], in_flight)
-        done, errs, dt, _ = timed_batch(users[:per], in_flight)
+        done, errs, dt, _ = timed_batch(users[:min(total, max(per, 6 * in_flight * world))], in_flight)
         sweep[str(in_flight)] = {"proofs": done, "errors": errs, "seconds": dt, "proofs_per_s": done / dt if dt else 0.0}
     best_in_flight = int(max(sweep, key=lambda f: sweep[f]["proofs_per_s"]))
     out["pre_sweep_by_in_flight"] = sweep
