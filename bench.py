@@ -344,8 +344,6 @@ def main():
     base_scal = fr_to_montgomery(torch.from_numpy(random_fr_canonical(0x7A55 + rank, n)).cuda())
     bases = g1_fixed_base_mul(base_scal)  # s_i * G: valid, distinct curve points
     torch.cuda.synchronize()
-    if os.environ.get("SG_BENCH_SETTLE_MS"):
-        time.sleep(float(os.environ["SG_BENCH_SETTLE_MS"]) * 1e-3)
 
     from concurrent.futures import ThreadPoolExecutor
     import threading
