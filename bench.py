@@ -495,7 +495,7 @@ def main():
                        "frac_of_mad_peak": mads / (acc_ms * 1e-3) / MAD_PEAK,
                        "note": "integer-VALU view: a mixed add is 6 products + 2 squarings + 1 fused two-product "
                                "reduction on 9x29-bit limbs = 1467 v_mad_u64_u32 of 2 170 VALU instructions per addition "
-                               "(SQ_INSTS_VALU of the launch / additions, profiles/r02z_insts.json; 2 383 before the products "
+                               "(SQ_INSTS_VALU of the launch / additions, profiles/r03z_insts.json: the same for the persistent launch of round 3 as for the grid of round 2; 2 383 before the products "
                                "became one multiply-add chain per column and the sums between them shared their carry steps); peak = "
                                "measured v_mad_u64_u32 issue rate (profiles/r01_microbench_instr_rates.txt)"}
 
