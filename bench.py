@@ -82,12 +82,165 @@ def oracle_vk(params, vk):
             "neg_s_g2": (s_g2[0], ((-s_g2[1][0]) % PR.Q, (-s_g2[1][1]) % PR.Q))}
 
 
+class FailSafe:
+    """ONE JSON line on stdout whatever happens to this run (rank 0 prints; every rank leaves).
+
+    * `beat(label, allow_s)`: the main thread announces a step that may block (a collective, a barrier, a batch) and how
+      long it may take; a watchdog thread fires when the step overstays, or when the whole run passes `limit_s`.  The
+      allowances are shorter than the process group's own timeout (90 s): with the nccl backend that timeout ends the
+      process from a C++ thread, with no chance to print anything.
+    * SIGTERM / SIGINT (what torch.distributed.run sends the surviving ranks when one rank has died) reach the watchdog
+      through the signal module's wake-up descriptor, which is written at C level even while the main thread sits in a
+      collective.
+    * On any of these -- and on an exception out of main() -- rank 0 prints {"metric", "value": null, "error", "partial"}
+      with whatever had been measured, and the process leaves with os._exit (no destructors: a hung collective would hang
+      them too)."""
+
+    def __init__(self, rank, args, limit_s):
+        import threading
+        self.rank, self.args, self.limit_s = rank, args, limit_s
+        self.partial = {}
+        self.lock = threading.Lock()
+        self.printed = False
+        self.t0 = time.monotonic()
+        self.step_label, self.step_deadline = "start", self.t0 + limit_s
+        self.rfd, self.wfd = os.pipe()
+        os.set_blocking(self.wfd, False)
+        self.thread = None
+
+    def arm(self):
+        import signal
+        import threading
+        try:   # (only possible in the main thread of the main interpreter; a test harness importing main() elsewhere goes without)
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                signal.signal(sig, lambda *_: None)
+            signal.set_wakeup_fd(self.wfd, warn_on_full_buffer=False)
+        except ValueError:
+            pass
+        self.thread = threading.Thread(target=self._watch, name="bench-failsafe", daemon=True)
+        self.thread.start()
+
+    def beat(self, label, allow_s):
+        self.step_label, self.step_deadline = label, time.monotonic() + allow_s
+
+    def _watch(self):
+        import select
+        while True:
+            now = time.monotonic()
+            wait = max(0.05, min(self.step_deadline, self.t0 + self.limit_s) - now)
+            ready, _, _ = select.select([self.rfd], [], [], min(wait, 1.0))
+            if ready:
+                sig = os.read(self.rfd, 16)
+                self.fail(f"signal {list(sig)} while in step '{self.step_label}' (another rank failed, or the launcher gave up)", 143)
+            now = time.monotonic()
+            if now > self.t0 + self.limit_s:
+                self.fail(f"wall-clock limit of {self.limit_s:.0f} s reached in step '{self.step_label}'", 124)
+            if now > self.step_deadline:
+                self.fail(f"step '{self.step_label}' overstayed its allowance (a rank is missing from a collective?)", 124)
+
+    def error_line(self, reason):
+        a = self.args
+        return {"metric": "msm_points_per_sec", "value": None, "unit": "points/s", "n_gpus": a.gpus, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u32", "data": "synthetic", "error": reason, "elapsed_s": round(time.monotonic() - self.t0, 1),
+                "partial": self.partial}
+
+    def emit(self, line):
+        """the run's one line (rank 0); False if the watchdog got there first"""
+        with self.lock:
+            if self.printed:
+                return False
+            self.printed = True
+            print(json.dumps(line), flush=True)
+            return True
+
+    def fail(self, reason, code):
+        if self.rank == 0:
+            self.emit(self.error_line(reason))
+        else:
+            print(f"bench.py rank {self.rank}: {reason}", file=sys.stderr, flush=True)
+        os._exit(code)
+
+
+_FS = None      # the run's FailSafe (set by main)
+
+
+def _beat(label, allow_s=75.0):
+    if _FS is not None:
+        _FS.beat(label, allow_s)
+
+
+def run_ranks_and_relay(args, argv):
+    """`python bench.py --gpus N` launched bare: start the N ranks (one torch.distributed.run child, its own process
+    group), relay rank 0's JSON line, and keep the promise of FailSafe from the outside too: when the child fails,
+    prints nothing, or outlives `--wall-limit` + 30 s, its whole process group is killed (by the group id this parent
+    created -- never by pattern) and the parent prints the error line itself.  Returns the exit code."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.monotonic()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+
+    def pump():
+        for ln in child.stdout:
+            if ln.startswith("{"):
+                lines.append(ln.strip())
+            else:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    reason = None
+    try:
+        rc = child.wait(timeout=args.wall_limit + 30)
+    except subprocess.TimeoutExpired:
+        reason, rc = f"the ranks outlived --wall-limit {args.wall_limit:.0f} s + 30 s", 124
+    if rc != 0 and reason is None:
+        reason = f"torch.distributed.run exited with code {rc} (a rank died or failed)"
+    if reason is not None:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)     # child.pid is the id of the session / group created above
+        except ProcessLookupError:
+            pass
+        child.wait()
+    th.join(timeout=5)
+    if lines and reason is None:
+        print(lines[-1], flush=True)
+        return 0
+    rank0 = None
+    if lines:
+        try:
+            rank0 = json.loads(lines[-1])
+        except ValueError:
+            rank0 = {"unparsed": lines[-1][:400]}
+    if rank0 is not None and rank0.get("error"):
+        print(json.dumps(rank0), flush=True)          # rank 0 already said what happened, with its partial results
+        return rc or 1
+    fs = FailSafe(0, args, args.wall_limit)
+    fs.t0 = t0
+    line = fs.error_line(reason or "the ranks printed no JSON line")
+    if rank0 is not None:
+        line["rank0_line"] = rank0
+    print(json.dumps(line), flush=True)
+    return rc or 1
+
+
 def _all_max(x, world, coll_dev):
     """max over ranks of a float (every rank calls it)"""
     import torch
     import torch.distributed as dist
     if world == 1:
         return float(x)
+    _beat("all_reduce(max)")
     t = torch.tensor([float(x)], device=coll_dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -98,9 +251,68 @@ def _all_sum(xs, world, coll_dev):
     import torch.distributed as dist
     if world == 1:
         return [float(v) for v in xs]
+    _beat("all_reduce(sum)")
     t = torch.tensor([float(v) for v in xs], device=coll_dev, dtype=torch.float64)
     dist.all_reduce(t)
     return [float(v) for v in t.tolist()]
+
+
+# algorithmic bytes of ONE k = 17 proof's op list: 16 MSMs of 2^17 pairs at 96 B, 11 665 408
+# element-transforms (9 iNTT 2^17 + 9 NTT 2^20 + 1 iNTT 2^20, halo2's extended-domain layout) at 64 B, and the quotient's
+# numerator reading about 29 extended columns of 2^20 rows at 32 B
+PROOF_ALG_BYTES = 16 * (1 << 17) * MSM_BYTES_PER_PAIR + 11_665_408 * NTT_BYTES_PER_ELEM + 29 * (1 << 20) * 32
+
+
+def proof_roofline(ms, what):
+    achieved = PROOF_ALG_BYTES / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes": PROOF_ALG_BYTES, "ms": ms, "traffic": None,
+            "note": what + "; algorithmic bytes of halo2's op list for this proof (16 x 2^17 x 96 B + 11 665 408 x 64 B + 29 x 2^20 x 32 B); "
+                           "the kernels behind it are integer-VALU-bound (see `alu`), the fraction says how far the whole proof is from a pure stream"}
+
+
+def host_cpu_info():
+    """what the process may use of the host: the affinity mask, and the CPU quota of its control group when one is set
+    (cgroup v2 `cpu.max`, v1 `cfs_quota_us`): on the boxes of this pool the mask is the whole machine, the quota is not"""
+    info = {"affinity_cores": len(os.sched_getaffinity(0)), "nproc": os.cpu_count(), "cgroup_cpu_quota_cores": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            info["cgroup_cpu_quota_cores"] = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                info["cgroup_cpu_quota_cores"] = q / per
+        except (OSError, ValueError):
+            pass
+    return info
+
+
+def cpu_share_rehearsal(args, in_flight, busy_cores):
+    """The 1024-proof batch again with this process confined to a fraction of the host's cores (`--cpu-share`, one child
+    process per setting: the affinity has to be in place before the HIP runtime starts its threads): what ONE rank gets
+    when 8 / 4 / 2 ranks share the host.  The shares are fractions of what this process can actually use -- the control
+    group's CPU quota when there is one, else the affinity mask.  Each child picks its own in-flight setting among
+    {in_flight / 2, in_flight} and runs the whole batch once."""
+    import subprocess
+    info = host_cpu_info()
+    usable = info["cgroup_cpu_quota_cores"] or info["affinity_cores"]
+    out = {"usable_cores": usable, "full_share_cores_busy": busy_cores, "by_share": {}}
+    for div in (8, 4, 2):
+        cores = max(1, int(usable // div))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--batch-only", "--cpu-share", str(cores), "--batch-proofs",
+               str(args.batch_proofs), "--batch-repeats", "1", "--no-cpu", "--batch-in-flight", str(in_flight), "--wall-limit", "150"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["by_share"][f"1/{div}"] = {"cores": cores, "proofs_per_s": got.get("proofs_per_s"), "host_cpu_ms_per_proof": got.get("host_cpu_ms_per_proof"),
+                                           "host_cores_busy": got.get("host_cores_busy_per_gpu"), "in_flight": got.get("in_flight"),
+                                           "errors": got.get("errors"), "error": got.get("error")}
+        except Exception as ex:      # an extra: never costs the line
+            out["by_share"][f"1/{div}"] = {"cores": cores, "error": repr(ex)}
+    return out
 
 
 def batch_extra(args, rank, world, coll_dev):
@@ -116,8 +328,10 @@ def batch_extra(args, rank, world, coll_dev):
     levels, k, nc = 20, 17, 2
     total = args.batch_proofs
     t0 = time.perf_counter()
+    _beat("setup artifacts: keygen on rank 0 + broadcast", 150.0)
     params, pk, vk = B.setup_on_all_ranks(k, None, levels, nc)
     setup_s = time.perf_counter() - t0
+    _beat("snapshot tree", 120.0)
     params.precompute()
     tree = snapshot_tree(levels, nc)
     torch.cuda.synchronize()
@@ -125,12 +339,28 @@ def batch_extra(args, rank, world, coll_dev):
            "setup_artifacts_s": setup_s}
     users = [(7919 * i + 13) % (1 << levels) for i in range(total)]
 
-    def timed_batch(subset, in_flight):
-        """one timed batch over `subset` (dealt over the ranks): (proofs, errors, seconds max-over-ranks, this rank's result)"""
+    import resource
+
+    def cpu_seconds():
+        """user + system CPU time of this process so far, all threads (the host side of the proofs: witness hand-over,
+        transcripts, Fiat-Shamir scalars, five MSM tails and the pairing check of the re-verification per proof)"""
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        return ru.ru_utime + ru.ru_stime
+
+    fault = os.environ.get("SUMMA_BENCH_FAULT", "")      # "rank:batch:seconds" -- tests/test_gpu_batch.py kills one rank mid-batch
+
+    def timed_batch(subset, in_flight, headline=False):
+        """one timed batch over `subset` (dealt over the ranks): (proofs, errors, seconds max-over-ranks, this rank's
+        result, CPU seconds of all ranks)"""
+        _beat("proof batch", 75.0 + 0.05 * len(subset))
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        if headline and fault.startswith(f"{rank}:batch:"):
+            import signal
+            import threading
+            threading.Timer(float(fault.split(":")[2]), lambda: os.kill(os.getpid(), signal.SIGKILL)).start()
+        t1, c1 = time.perf_counter(), cpu_seconds()
         res, failure = None, 0
         try:
             res = B.prove_batch(tree, subset, params, pk, levels, flavour="evm", in_flight=in_flight)
@@ -138,27 +368,31 @@ def batch_extra(args, rank, world, coll_dev):
             failure, res = 1, B.BatchResult()
             res.errors[-1] = repr(ex)
         torch.cuda.synchronize()
+        cpu = cpu_seconds() - c1
         if world > 1:
+            _beat("barrier after the batch")
             dist.barrier()
         dt = _all_max(time.perf_counter() - t1, world, coll_dev)
-        done, errs = _all_sum([len(res.proofs), len(res.errors) + failure], world, coll_dev)
-        return int(done), int(errs), dt, res
+        done, errs, cpu_all = _all_sum([len(res.proofs), len(res.errors) + failure, cpu], world, coll_dev)
+        return int(done), int(errs), dt, res, cpu_all
 
     # warm-up and pre-sweep (short batches): every lane's plans, every worker thread's session; the best in-flight setting
     # of the pre-sweep runs the headline batch
     sweep = {}
     per = max(6 * world, min(96 * world, total // 4))
-    for in_flight in (1, 2, 4, 8, 12, 16, 24):
+    candidates = sorted({max(1, args.batch_in_flight // 2), args.batch_in_flight}) if args.batch_in_flight > 0 else (1, 2, 4, 8, 12, 16, 24, 32)
+    for in_flight in candidates:
         timed_batch(users[:3 * in_flight * world], in_flight)
-        done, errs, dt, _ = timed_batch(users[:min(total, max(per, 6 * in_flight * world))], in_flight)
+        done, errs, dt, _, _ = timed_batch(users[:min(total, max(per, 6 * in_flight * world))], in_flight)
         sweep[str(in_flight)] = {"proofs": done, "errors": errs, "seconds": dt, "proofs_per_s": done / dt if dt else 0.0}
     best_in_flight = int(max(sweep, key=lambda f: sweep[f]["proofs_per_s"]))
     out["pre_sweep_by_in_flight"] = sweep
     out["in_flight"] = best_in_flight
     reps, last = [], None
     for _ in range(max(1, args.batch_repeats)):
-        done, errs, dt, res = timed_batch(users, best_in_flight)
-        reps.append({"proofs": done, "errors": errs, "seconds": dt, "proofs_per_s": done / dt if dt else 0.0})
+        done, errs, dt, res, cpu = timed_batch(users, best_in_flight, headline=True)
+        reps.append({"proofs": done, "errors": errs, "seconds": dt, "proofs_per_s": done / dt if dt else 0.0,
+                     "host_cpu_ms_per_proof": cpu / max(1, done) * 1e3, "host_cores_busy": cpu / dt / world if dt else 0.0})
         last = res
     rates = sorted(r["proofs_per_s"] for r in reps)
     out["repeats"] = reps
@@ -166,6 +400,9 @@ def batch_extra(args, rank, world, coll_dev):
     out["proofs_per_s_min_median_max"] = [rates[0], rates[len(rates) // 2], rates[-1]]
     out["proofs_per_s"] = rates[len(rates) // 2]
     out["seconds"] = sorted(r["seconds"] for r in reps)[len(reps) // 2]
+    out["host_cpu_ms_per_proof"] = sorted(r["host_cpu_ms_per_proof"] for r in reps)[len(reps) // 2]
+    out["host_cores_busy_per_gpu"] = sorted(r["host_cores_busy"] for r in reps)[len(reps) // 2]
+    out["host"] = host_cpu_info()
     assert out["errors"] == 0 and all(r["proofs"] == total for r in reps), out
     if rank == 0:   # checker leg, outside every timed region: the oracle's verifier on a sample of the proofs made
         from oracle import summa_verifier as SV
@@ -206,6 +443,7 @@ def strong_scaling_extra(args, rank, world, coll_dev):
     want = A.g1_fixed_base_mul(inner)
     ok_local = bool((part == want).all())
     del bs
+    _beat("strong-scaling MSM", 120.0)
     sharded_msm(sc, bases)
     steps = max(3, min(args.steps, 10))
     if world > 1:
@@ -273,7 +511,7 @@ def cpu_oplist_baseline(k, cores):
                                      "evaluations and the multi-open's polynomial arithmetic not included)"}
 
 
-def main():
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -289,22 +527,25 @@ def main():
                                                                   "(BASELINE configs[4]: 1024 users; 0 = skip)")
     ap.add_argument("--strong-only", action="store_true", help="of the extras, run only the strong-scaling MSM (tests)")
     ap.add_argument("--batch-repeats", type=int, default=3, help="timed repeats of the whole batch (min / median / max reported)")
+    ap.add_argument("--wall-limit", type=float, default=540.0,
+                    help="seconds after which the run gives up and prints a JSON line with `error` and what it had (below the driver's own limit)")
+    ap.add_argument("--cpu-share", type=int, default=0,
+                    help="run on the first N of the CPUs this process may use (os.sched_setaffinity, set before anything touches the GPU, so "
+                         "every thread of the HIP runtime and of the library inherits it): what one rank of N_total / N ranks sharing the host gets")
+    ap.add_argument("--batch-only", action="store_true", help="only the proof batch (the child runs of the --cpu-share rehearsal): prints the batch extra's dict")
+    ap.add_argument("--batch-in-flight", type=int, default=0, help="proofs in flight for the batch (0 = pre-sweep picks)")
+    ap.add_argument("--no-cpu-share-sweep", action="store_true", help="skip the CPU-share rehearsal of the batch (three child runs)")
     args = ap.parse_args()
+
+    if args.cpu_share > 0:
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, allowed[:max(1, min(args.cpu_share, len(allowed)))])
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, BEFORE anything
         # in this process touches the GPU (a child process, never an exec of a process that has initialised HIP);
-        # rank 0 of the children prints the JSON line, which passes through
-        import socket
-        import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.run(cmd, env=env).returncode)
+        # rank 0 of the children prints the JSON line, which passes through -- or the parent says what went wrong
+        sys.exit(run_ranks_and_relay(args, sys.argv[1:]))
 
     # HIP's default of 4 hardware queues is kept: more of them did not help the MSM lanes and made the proof batch slower and
     # erratic (profiles/r02_sweeps/hw_queues.txt)
@@ -321,22 +562,37 @@ def main():
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the small tensors of the timing collectives live
+    global _FS
+    fs = _FS = FailSafe(rank, args, args.wall_limit)
+    fs.arm()
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        _beat("init_process_group", 100.0)
+        # a rank that never arrives must not cost the others the driver's whole time limit (the default is ten minutes)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=90))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
+    _beat("set-up", 300.0)
 
     import circuits_halo2_amd as sg
     from circuits_halo2_amd import ffi
     from circuits_halo2_amd.arithmetic import fr_to_montgomery, g1_fixed_base_mul
-    from circuits_halo2_amd.distributed import exchange_partials
+    from circuits_halo2_amd.distributed import exchange_partials_many
     from circuits_halo2_amd.utils import DEFAULT_SEED, random_fr_canonical
     ffi.check(sg.lib().sg_init(local_rank))
     for kv in filter(None, os.environ.get("SG_PARAMS", "").split(",")):  # e.g. SG_PARAMS=msm.log_seg=6
         name, val = kv.split("=")
         ffi.check(sg.lib().sg_set_param(name.encode(), int(val)))
+
+    if args.batch_only:      # a child run of the CPU-share rehearsal: the batch extra alone, its dict as the line
+        got, _ = batch_extra(args, rank, world, coll_dev)
+        if rank == 0:
+            got["cpu_share"] = args.cpu_share
+            fs.emit(got)
+        sys.stdout.flush()
+        os._exit(0)          # (no teardown: the line is out, the library's worker threads need no farewell)
 
     n = 1 << args.log_n
     # synthetic inputs, generated per rank from rank-dependent seeds, resident in HBM
@@ -358,10 +614,12 @@ def main():
 
     def run_steps(count, in_flight):
         """`count` steps; with in_flight > 1 the MSMs of consecutive steps are issued from that many host threads (each call
-        takes its own lane of the library: streams, engines, work space), while the exchange step of every MSM -- the
-        collective -- stays on this thread, in step order on every rank"""
+        takes its own lane of the library: streams, engines, work space); the exchange step of the `count` MSMs is ONE
+        collective on this thread after the last partial has arrived (distributed.exchange_partials_many: the partials
+        are 64 bytes each and already on the host; RCCL's kernels cannot raise their wave priority and would crawl beside
+        the chained accumulations, so no collective runs while the device is saturated)"""
         if in_flight <= 1:
-            return [exchange_partials(partial()) for _ in range(count)]
+            return exchange_partials_many([partial() for _ in range(count)])
         # the threads take step numbers from one counter (three submissions, not `count`: the main thread holds the interpreter
         # lock while it submits, and the pool's threads start only when it lets go)
         import itertools
@@ -382,19 +640,18 @@ def main():
                     return
                 ready[i].set()
         futures = [pool.submit(issue) for _ in range(in_flight)]
-        out = []
         for i in range(count):
             ready[i].wait()
             if failure:
                 break
-            out.append(exchange_partials(results[i]))
         for f in futures:
             f.result()
         if failure:
             raise failure[0]
-        return out
+        return exchange_partials_many(results)
 
     def timed(count, in_flight):
+        _beat("timed steps", 75.0 + 0.05 * count)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -404,11 +661,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, results
+        return _all_max(dt, world, coll_dev), results
 
     in_flight = max(1, args.in_flight)
     pool = ThreadPoolExecutor(max_workers=in_flight, initializer=ffi.bind_thread)   # a new thread's current device is 0
@@ -417,10 +670,13 @@ def main():
     dt, results = timed(args.steps, in_flight)
     result = results[-1]
     assert all((r == result).all() for r in results), "steps of one input must agree"
+    fs.partial.update({"value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": world})
     # the same steps strictly one after the other (the latency of one MSM, round 1's headline)
     run_steps(2, 1)
     dt_seq, _ = timed(args.steps, 1)
+    fs.partial["sequential_ms_per_step"] = dt_seq / args.steps * 1e3
     pool.shutdown()
+    _beat("extras", args.wall_limit)
     phase_reps = None
     if rank == 0:   # per-phase HIP-event timings of the same MSM, taken here (the extras below fill HBM and caches with other data)
         sg.best_multiexp(scal, bases, timings=True)
@@ -455,6 +711,15 @@ def main():
             batch_line = {"error": "another rank failed in the batch extra"}
         if any_failed:
             k17 = None
+        if rank == 0 and isinstance(batch_line, dict):
+            fs.partial["batch_k17"] = {k_: batch_line.get(k_) for k_ in ("proofs_per_s", "proofs_total", "errors", "error", "in_flight") if k_ in batch_line}
+    if world > 1:
+        # the last collective of the run: what follows is rank 0's own (the line, the local extras); the other ranks leave
+        # without waiting for it, so no rank sits in a barrier while rank 0 times a CPU baseline
+        _beat("final barrier")
+        dist.barrier()
+        dist.destroy_process_group()
+    _beat("rank 0: local extras and the line", args.wall_limit)
 
     line = None
     if rank == 0:
@@ -467,7 +732,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"standalone BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x synthetic-SRS "
                                    f"affine points per GPU (BASELINE configs[1])",
-                       "points_per_gpu": n, "sharding": "point-sharded, all_gather of 64-B partials" if world > 1 else "none",
+                       "points_per_gpu": n, "sharding": "point-sharded; exchange = ONE all_gather of steps x 64-B partials per timed region + host sums" if world > 1 else "none",
                        "backend": ("nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal: ranks share GPUs)") if world > 1 else None,
                        "steps_in_flight": in_flight,
                        "step": "one whole MSM per GPU (digits, sort, accumulate, reduce, host tail; result = the 64-byte point); "
@@ -485,7 +750,7 @@ def main():
                             "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
         line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, reps[0]["accumulate_threads"], n))
         line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
-                                 ("digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}
+                                 ("digits_ms", "sort_ms", "order_ms", "accumulate_ms", "reduce_ms", "total_ms")}
         line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket", "accumulate_threads")})
         # integer-ALU view (MSM is VALU-bound): mixed adds * 10 products * ~560 VALU instr
         adds = reps[0]["windows"] * n
@@ -852,11 +1117,40 @@ def main():
             line["batch_k17"] = batch_line
             if "proofs_per_s" in batch_line:
                 line["proofs_per_s"] = batch_line["proofs_per_s"]
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+                batch_line["roofline"] = proof_roofline(1e3 / batch_line["proofs_per_s"] * world,
+                                                        "per proof of the batch: GPU-time per proof = n_gpus / proofs_per_s")
+                if world == 1 and not args.no_cpu_share_sweep and not args.no_extras and batch_line.get("proofs_total", 0) >= 64:
+                    # what one of 8 / 4 / 2 ranks sharing this host's CPUs would get (child runs under --cpu-share)
+                    batch_line["cpu_share_rehearsal"] = cpu_share_rehearsal(args, batch_line["in_flight"], batch_line.get("host_cores_busy_per_gpu"))
+        # BASELINE's metric is "proof-gen wall-clock + MSM-points/sec": the proof half where a reader of `config` / `roofline`
+        # finds it without opening the extras
+        cp = line.get("create_proof_k17") or {}
+        proof_ms = cp.get("ms_cpp_driver") or cp.get("ms")
+        if proof_ms:
+            cp["roofline"] = proof_roofline(proof_ms, "one k = 17 proof, wall clock of the compiled driver")
+            line["roofline"]["create_proof_k17"] = cp["roofline"]
+        line["config"]["proof_gen_k17_ms"] = proof_ms
+        line["config"]["proof_gen_k17_verified"] = cp.get("verified")
+        line["config"]["proofs_per_s_1024"] = (batch_line or {}).get("proofs_per_s")
+        line["config"]["proofs_per_s_1024_errors"] = (batch_line or {}).get("errors")
+        line["config"]["sequential_ms_per_step"] = line["sequential"]["ms_per_step"]
+        if batch_line and "roofline" in batch_line:
+            line["roofline"]["batch_k17_per_proof"] = batch_line["roofline"]
+        fs.emit(line)
     return line
+
+
+def main():
+    try:
+        return _main()
+    except SystemExit:
+        raise
+    except BaseException as ex:     # noqa: BLE001 -- whatever it was, the run still owes its one JSON line
+        import traceback
+        traceback.print_exc()
+        if _FS is not None:
+            _FS.fail(f"{type(ex).__name__}: {ex}", 1)
+        raise
 
 
 if __name__ == "__main__":

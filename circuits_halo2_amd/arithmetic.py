@@ -312,6 +312,32 @@ def lookup_product(inp, table, permuted_input, permuted_table, beta, gamma):
     return z
 
 
+def grand_products(perm_chunks, lookups, beta, gamma, k: int, usable_rows: int):
+    """ALL grand products of one proof in batched launches (sg_grand_products_dev): `perm_chunks` = [(values, sigmas), ...]
+    in order (chunk j's z continues from chunk j-1's value at row `usable_rows`), `lookups` = [(input, table, permuted
+    input, permuted table), ...]; returns ([z per chunk], [z per lookup]), 2^k rows each"""
+    import torch
+    vals = [v for ch in perm_chunks for v in ch[0]]
+    sigs = [s_ for ch in perm_chunks for s_ in ch[1]]
+    if len(vals) != len(sigs):
+        raise ValueError("grand_products: one sigma per column")
+    cols = (C.c_uint32 * max(1, len(perm_chunks)))(*[len(ch[0]) for ch in perm_chunks])
+    pv = (C.c_void_p * max(1, len(vals)))(*[ffi.dev_ptr(v).value for v in vals])
+    ps = (C.c_void_p * max(1, len(sigs)))(*[ffi.dev_ptr(v).value for v in sigs])
+    lk = [t for lu in lookups for t in lu]
+    if len(lk) != 4 * len(lookups):
+        raise ValueError("grand_products: four columns per lookup")
+    pl = (C.c_void_p * max(1, len(lk)))(*[ffi.dev_ptr(t).value for t in lk])
+    total = len(perm_chunks) + len(lookups)
+    dev_ = (vals + lk)[0].device if total else None
+    zs = [torch.empty(32 << k, dtype=torch.uint8, device=dev_) for _ in range(total)]
+    pz = (C.c_void_p * max(1, total))(*[z.data_ptr() for z in zs])
+    ffi.check(ffi.lib().sg_grand_products_dev(pv, ps, cols, C.c_uint32(len(perm_chunks)), pl, C.c_uint32(len(lookups)),
+                                              ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), C.c_uint32(k), C.c_size_t(usable_rows), pz,
+                                              ffi.current_stream_ptr()))
+    return zs[:len(perm_chunks)], zs[len(perm_chunks):]
+
+
 def quotient_permutation(values, zs, cols, sigmas, chunk_len: int, l0, l_last, l_active, beta, gamma, y, k: int,
                          ext_k: int, last_rotation_abs: int):
     """fold the permutation argument's constraints into the quotient numerator `values` (device

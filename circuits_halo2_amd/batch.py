@@ -79,34 +79,50 @@ def broadcast_setup(setup, src: int = 0):
     device = "cuda" if on_device else "cpu"
     rank = d.get_rank()
     head = torch.zeros(_HEAD_BYTES, dtype=torch.uint8, device="cpu")
+    staged, failure = {}, None
     if rank == src:
-        levels, nc, nb = setup["shape"]
-        ints = np.array([setup["k"], levels, nc, nb, len(setup["fixed"]), len(setup["sigma"]), 0, 0], dtype="<i8")
-        raw = ints.tobytes() + bytes(setup["g2"]).ljust(128, b"\0")[:128] + bytes(setup["s_g2"]).ljust(128, b"\0")[:128] + \
-            int(setup["vk_digest"]).to_bytes(32, "little")
-        head = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy())
+        # everything that can be wrong with the source's data is found HERE, before the first collective: the header
+        # carries a status word, and a source that cannot send says so in the one broadcast every rank takes part in
+        # (a source that raised between two broadcasts would leave the other ranks waiting in the next one)
+        try:
+            levels, nc, nb = setup["shape"]
+            k = int(setup["k"])
+            if not 1 <= k <= 28:
+                raise ValueError(f"broadcast_setup: k = {k}")
+            sizes = [("g", setup["g"], 64 << k), ("g_lagrange", setup["g_lagrange"], 64 << k)]
+            sizes += [(f"fixed[{j}]", c, 32 << k) for j, c in enumerate(setup["fixed"])]
+            sizes += [(f"sigma[{j}]", c, 32 << k) for j, c in enumerate(setup["sigma"])]
+            for name, buf, nbytes in sizes:
+                t = _as_bytes_tensor(buf, device)
+                if t.numel() != nbytes:
+                    raise ValueError(f"broadcast_setup: {name} has {t.numel()} bytes, k = {k} needs {nbytes}")
+                staged[name] = t
+            ints = np.array([k, levels, nc, nb, len(setup["fixed"]), len(setup["sigma"]), 0, 0], dtype="<i8")
+            raw = ints.tobytes() + bytes(setup["g2"]).ljust(128, b"\0")[:128] + bytes(setup["s_g2"]).ljust(128, b"\0")[:128] + \
+                int(setup["vk_digest"]).to_bytes(32, "little")
+            head = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy())
+        except Exception as ex:   # noqa: BLE001 -- carried to every rank as the status word
+            failure = ex
+            ints = np.array([0, 0, 0, 0, 0, 0, 1, 0], dtype="<i8")                    # word 6: status (0 = ok)
+            head = torch.from_numpy(np.frombuffer(ints.tobytes().ljust(_HEAD_BYTES, b"\0"), dtype=np.uint8).copy())
     head = head.to(device)
     d.broadcast(head, src)
     raw = bytes(head.cpu().numpy())
-    k, levels, nc, nb, n_fixed, n_sigma = (int(v) for v in np.frombuffer(raw[:48], dtype="<i8"))
+    k, levels, nc, nb, n_fixed, n_sigma, status = (int(v) for v in np.frombuffer(raw[:56], dtype="<i8"))
+    if status:
+        raise RuntimeError(f"broadcast_setup: rank {src} has nothing valid to send") from failure
     out = {"k": k, "shape": (levels, nc, nb), "g2": raw[64:192], "s_g2": raw[192:320],
            "vk_digest": int.from_bytes(raw[320:352], "little")}
 
-    def one(buf, nbytes):
-        if rank == src:
-            t = _as_bytes_tensor(buf, device)
-            if t.numel() != nbytes:
-                raise ValueError("broadcast_setup: a buffer's size does not follow from k")
-        else:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    def one(name, nbytes):
+        t = staged[name] if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
         d.broadcast(t, src)
         return t if on_device else t.numpy()
 
-    mine = setup if rank == src else None
     for name in ("g", "g_lagrange"):
-        out[name] = one(mine[name] if mine else None, 64 << k)
-    out["fixed"] = [one(mine["fixed"][j] if mine else None, 32 << k) for j in range(n_fixed)]
-    out["sigma"] = [one(mine["sigma"][j] if mine else None, 32 << k) for j in range(n_sigma)]
+        out[name] = one(name, 64 << k)
+    out["fixed"] = [one(f"fixed[{j}]", 32 << k) for j in range(n_fixed)]
+    out["sigma"] = [one(f"sigma[{j}]", 32 << k) for j in range(n_sigma)]
     return out
 
 
@@ -236,9 +252,11 @@ class _WitnessAhead:
 
     def circuit(self, user: int):
         with self.cv:
-            self.cv.wait_for(lambda: user in self.ready or self.error is not None)
+            self.cv.wait_for(lambda: user in self.ready or self.error is not None or self.closed)
             if user not in self.ready:
-                raise self.error
+                self.taken += 1          # the producer's look-ahead window moves on past a user nobody will get
+                self.cv.notify_all()
+                raise self.error if self.error is not None else RuntimeError("witness producer closed (the batch was abandoned)")
             got = self.ready.pop(user)
             self.taken += 1
             self.cv.notify_all()
@@ -276,7 +294,7 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         env = os.environ.get("SUMMA_COMBINE_COMMITS")
         combine = (env == "1" or (env is None and in_flight >= 6)) and in_flight > 1 and prove is None
     if combine:
-        from . import ffi
+        # process-wide tunables of the combiner, for the length of this batch (restored to the library's defaults below)
         ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(in_flight)))
         ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 5000))
     mine = deal(list(user_indices))
@@ -333,6 +351,9 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     finally:
         if ahead is not None:
             ahead.close()
+        if combine:     # the library's defaults (include/summa_gpu.h, sg_set_param): a later caller's lone proofs do not wait 5 ms for company
+            ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", 4))
+            ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 300))
     res.seconds = time.perf_counter() - t0
     return res
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include "bn254_curve29.cuh"
 #include "devmem.h"
 
@@ -29,6 +31,8 @@ struct MsmConfig {
   uint32_t red2d_max_sets = 5; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh)
   uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
   uint32_t red2d_fold = 8;     // ... whose line sums add up to this many partial sums per bucket themselves (no merge round below that)
+  uint32_t red2d_prefold = 1;  // ... after a pass that adds every bucket's partial sums once (msm_fold_buckets); 0: the line sums add them on the way (twice)
+  uint32_t prefold_quad_buckets = 1u << 15;  // ... with a quad per bucket up to this many buckets in the job, one lane per bucket beyond
   uint32_t acc_chain = 1;      // accumulations of different jobs run one after the other (each waits for the previous launch's event)
   uint32_t red_lean = 1;       // level-0 bucket reduction within 168 registers (fits beside a polite accumulation): 0 never, 1 when other jobs are in flight, 2 always
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
@@ -37,6 +41,7 @@ struct MsmConfig {
 struct MsmTimings {
   float digits_ms = 0, sort_ms = 0, accumulate_ms = 0, reduce_ms = 0, total_ms = 0;
   uint32_t window_bits = 0, windows = 0, tasks = 0, max_bucket = 0, accumulate_threads = 0;
+  float order_ms = 0;   // between the sort and the accumulation: task ordering, and the wait behind other jobs' accumulations
 };
 
 template <typename T>
@@ -130,8 +135,7 @@ class MsmEngine {
   void mark_in_flight(bool on);
   bool others_in_flight() const;   // another engine of this process has a job between its first kernel and its host tail
   bool counted_ = false;
-  hipError_t chain_accumulate_before(hipStream_t stream);
-  hipError_t chain_accumulate_after(hipStream_t stream);
+  hipError_t chained_accumulate(hipStream_t stream, hipEvent_t after_wait, const std::function<void()>& launch);
   hipEvent_t ev_chain_[2] = {nullptr, nullptr};
   int chain_slot_ = 0;
   uint32_t cus_ = 256;
@@ -147,7 +151,7 @@ class MsmEngine {
     uint32_t n_tab = 0;
     uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0, acc_threads = 0;
     WindowPlan wp{};
-    hipEvent_t ev[5];
+    hipEvent_t ev[6];
   };
   Job job_;
   const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <cstdio>
 #include <cstring>
@@ -805,6 +806,49 @@ __device__ __forceinline__ xyzz29 wg_sum_into(uint32_t n, F get, xyzz29_mem* lds
   tree_sum<Q>(lds, NL, lt, role, true);
   return xyzz29_load(&lds[0]);
 }
+// A bucket of a fixed-base job owns several partial sums (one per accumulation task: ~64 entries in tasks of 16).  The
+// line sums below used to add them on the way -- twice, once in the row pass and once in the column pass, and with
+// quad-cooperative additions (2.5 lanes' worth of issue slots each): 2 x 4.5 quad-additions per bucket where the sums
+// themselves need 2.  This pass adds them ONCE, one logical thread per bucket, and leaves one value per bucket in
+// bucket order, so the line sums read plain coalesced arrays.  Q = 4 (a quad per bucket) while the job is small enough
+// for every bucket to get its quad at once (one bucket set: 2^15 quads), Q = 1 beyond.  grid: NB logical threads.
+template <int Q>
+__global__ void __launch_bounds__(256) msm_fold_buckets(const xyzz29_mem* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                        const uint32_t* __restrict__ ntask, uint32_t NB,
+                                                        xyzz29_mem* __restrict__ folded) {
+  side_kernel_prio();
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / Q, role = threadIdx.x % Q;
+  if (b >= NB) return;
+  const uint32_t nt = ntask[b], t0 = toff[b];
+  xyzz29 acc = xyzz29_identity();
+  if (nt) {
+    acc = xyzz29_load(partial + t0);
+    xyzz29 nxt = acc;
+    if (nt > 1) nxt = xyzz29_load(partial + t0 + 1);
+    for (uint32_t t = 1; t < nt; t++) {
+      const xyzz29 cur = nxt;
+      if (t + 1 < nt) nxt = xyzz29_load(partial + t0 + t + 1);   // in flight while the addition below runs
+      add_q<Q>(acc, cur, role);
+    }
+  }
+  if (role == 0) xyzz29_store(folded + b, acc);
+}
+// grid (rows + cols, sets): line sums over folded buckets (one value per bucket, bucket order).  lines[set * (rows + cols) + L]
+template <int Q>
+__global__ void __launch_bounds__(256) msm_reduce2d_lines_folded(const xyzz29_mem* __restrict__ folded, Reduce2dShape sh,
+                                                                 xyzz29_mem* __restrict__ lines) {
+  side_kernel_prio();
+  __shared__ xyzz29_mem lds[256 / Q];
+  const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols, L = blockIdx.x, set = blockIdx.y;
+  const xyzz29_mem* src = folded + ((size_t)set << (sh.log_rows + sh.log_cols));
+  const bool is_row = L < rows;
+  const uint32_t n = is_row ? cols : rows;
+  xyzz29 sum = wg_sum<Q>(n, [&](uint32_t e) {
+    return xyzz29_load(src + (is_row ? (L << sh.log_cols) + e : (e << sh.log_cols) + (L - rows)));
+  }, lds);
+  if (threadIdx.x == 0) xyzz29_store(lines + (size_t)set * (rows + cols) + L, sum);
+}
+// (the one-launch form: line sums that add a bucket's partial sums themselves; msm.red2d_prefold = 0)
 // grid (rows + cols, sets): line sums.  lines[set * (rows + cols) + L]
 template <int Q>
 __global__ void __launch_bounds__(256) msm_reduce2d_lines(const xyzz29_mem* __restrict__ partial,
@@ -1165,20 +1209,28 @@ MsmEngine::~MsmEngine() { release(); }
 // Accumulations of different jobs never share the device: each one alone keeps the vector ALUs busy, and two polite ones
 // side by side fill the register file that politeness leaves to the other kernels.  Every accumulation launch waits for
 // the event recorded after the previous one (whichever engine / stream launched it).
+// (process-wide state: the library serves ONE device per process -- sg_init binds it, one process per GPU -- so "of the
+// process" is "of the device")
 static std::mutex g_acc_chain_mu;
 static hipEvent_t g_acc_chain_last = nullptr;   // recorded after the most recent accumulation launch of the process
-hipError_t MsmEngine::chain_accumulate_before(hipStream_t stream) {
-  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
-  if (g_acc_chain_last) SG_TRY(hipStreamWaitEvent(stream, g_acc_chain_last, 0));
-  return hipSuccess;
-}
-hipError_t MsmEngine::chain_accumulate_after(hipStream_t stream) {
-  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
-  // two events per engine, alternating: the previous record of this engine may still be the one another stream waits on
-  chain_slot_ ^= 1;
-  if (!ev_chain_[chain_slot_]) SG_TRY(hipEventCreateWithFlags(&ev_chain_[chain_slot_], hipEventDisableTiming));
-  SG_TRY(hipEventRecord(ev_chain_[chain_slot_], stream));
-  g_acc_chain_last = ev_chain_[chain_slot_];
+// wait for the previous accumulation, launch, record -- under ONE hold of the mutex: taken separately around the launch, two
+// lanes could both wait on the same predecessor and then run their accumulations side by side, which is what the chain is for
+hipError_t MsmEngine::chained_accumulate(hipStream_t stream, hipEvent_t after_wait, const std::function<void()>& launch) {
+  std::unique_lock<std::mutex> lk(g_acc_chain_mu, std::defer_lock);
+  if (cfg_.acc_chain) {
+    lk.lock();
+    if (g_acc_chain_last) SG_TRY(hipStreamWaitEvent(stream, g_acc_chain_last, 0));
+  }
+  if (after_wait) SG_TRY(hipEventRecord(after_wait, stream));   // timing mode: the accumulation's own start, behind the chain wait
+  launch();
+  SG_TRY(hipGetLastError());
+  if (cfg_.acc_chain) {
+    // two events per engine, alternating: the previous record of this engine may still be the one another stream waits on
+    chain_slot_ ^= 1;
+    if (!ev_chain_[chain_slot_]) SG_TRY(hipEventCreateWithFlags(&ev_chain_[chain_slot_], hipEventDisableTiming));
+    SG_TRY(hipEventRecord(ev_chain_[chain_slot_], stream));
+    g_acc_chain_last = ev_chain_[chain_slot_];
+  }
   return hipSuccess;
 }
 void MsmEngine::release() {
@@ -1601,10 +1653,10 @@ hipError_t MsmEngine::enqueue_back_impl() {
   const uint32_t wg_all = (ntasks_ub + at - 1) / at;
   const uint32_t wg = waves >= 8 ? wg_all : std::min<uint32_t>(wg_all, cus_ * (waves * 4 * 64 / at));
   j.acc_threads = wg * at;
-  if (cfg_.acc_chain) SG_TRY(chain_accumulate_before(stream));
-  msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
-                                        meta_.p + ACC_TICKET, partial_[0].p);
-  if (cfg_.acc_chain) SG_TRY(chain_accumulate_after(stream));
+  SG_TRY(chained_accumulate(stream, j.tm ? j.ev[5] : nullptr, [&]() {
+    msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
+                                          meta_.p + ACC_TICKET, partial_[0].p);
+  }));
   SG_TRY(hipEventSynchronize(ev_meta_));
   const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_blocks / msm_scan_small), complete with the event
   const uint32_t ntasks = j.ntasks = hm[1], max_cnt = j.max_cnt = hm[2];
@@ -1664,13 +1716,22 @@ hipError_t MsmEngine::enqueue_back_impl() {
     const uint32_t rows = 1u << sh.log_rows, cols = 1u << sh.log_cols;
     SG_TRY(red_a_[0].reserve((size_t)sets * (rows + cols)));
     SG_TRY(red_a_[1].reserve((size_t)sets * (bits + 1)));
-    if (quad) {
+    if (cfg_.red2d_prefold) {
+      // partial sums -> one value per bucket (once), then line sums over plain arrays
+      SG_TRY(red_r_[0].reserve(NB));
+      if (quad && NB <= cfg_.prefold_quad_buckets)
+        msm_fold_buckets<4><<<(NB + 63) / 64, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, NB, red_r_[0].p);
+      else
+        msm_fold_buckets<1><<<(NB + 255) / 256, 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, NB, red_r_[0].p);
+      if (quad) msm_reduce2d_lines_folded<4><<<dim3(rows + cols, sets), 256, 0, stream>>>(red_r_[0].p, sh, red_a_[0].p);
+      else msm_reduce2d_lines_folded<1><<<dim3(rows + cols, sets), 256, 0, stream>>>(red_r_[0].p, sh, red_a_[0].p);
+    } else if (quad) {
       msm_reduce2d_lines<4><<<dim3(rows + cols, sets), 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, sh, red_a_[0].p);
-      msm_reduce2d_bits<4><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
     } else {
       msm_reduce2d_lines<1><<<dim3(rows + cols, sets), 256, 0, stream>>>(cur, toff_[lvl].p, ntask_[lvl].p, sh, red_a_[0].p);
-      msm_reduce2d_bits<1><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
     }
+    if (quad) msm_reduce2d_bits<4><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
+    else msm_reduce2d_bits<1><<<dim3(bits + 1, sets), 256, 0, stream>>>(red_a_[0].p, sh, red_a_[1].p);
     const xyzz29_mem* fin = red_a_[1].p;
     uint32_t count = sets * (bits + 1);
     if (j.red2d == 2) {
@@ -1833,7 +1894,8 @@ hipError_t MsmEngine::finish_impl() {
     float ms;
     (void)hipEventElapsedTime(&ms, j.ev[0], j.ev[1]); tm->digits_ms = ms;
     (void)hipEventElapsedTime(&ms, j.ev[1], j.ev[2]); tm->sort_ms = ms;
-    (void)hipEventElapsedTime(&ms, j.ev[2], j.ev[3]); tm->accumulate_ms = ms;
+    (void)hipEventElapsedTime(&ms, j.ev[5], j.ev[3]); tm->accumulate_ms = ms;   // the accumulation (and merge rounds) alone
+    (void)hipEventElapsedTime(&ms, j.ev[2], j.ev[5]); tm->order_ms = ms;        // task ordering + time queued behind other jobs' accumulations
     (void)hipEventElapsedTime(&ms, j.ev[3], j.ev[4]); tm->reduce_ms = ms;
     (void)hipEventElapsedTime(&ms, j.ev[0], j.ev[4]); tm->total_ms = ms;
     tm->window_bits = j.c;

@@ -35,6 +35,25 @@ hipError_t poly_perm_fraction(const PermCols& cols, uint32_t ncols, const words8
 hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const words8& beta, const words8& gamma,
                                 size_t n, int numer, fp_words* d_io, hipStream_t stream);
 size_t prefix_product_tmp_elems(size_t n);
+// all grand products of one proof in batched launches (poly.hip): products 0 .. n_perm-1 are the chunks of the permutation
+// argument in order (chunk j's z continues from chunk j-1's value at row `usable`), then n_lookup lookup products
+static constexpr uint32_t GRAND_MAX = 8;
+struct GrandProducts {   // kernel argument
+  uint32_t n_perm, n_lookup;
+  uint32_t ncols[GRAND_MAX];             // columns of permutation chunk p
+  PermCols perm[GRAND_MAX];
+  words8 delta_start[GRAND_MAX];         // delta^(index of the chunk's first column)
+  const fp_words* lookup[GRAND_MAX][4];  // input, table, permuted input, permuted table (compressed expressions, Lagrange)
+};
+struct GrandOut {
+  fp_words* z[GRAND_MAX];
+};
+size_t grand_products_mod_elems(size_t n, uint32_t products);
+size_t grand_products_tmp_elems(size_t n, uint32_t products);
+// d_pow_tab: omega^i, i < n, as 2^261-domain words (NttEngine::local_twiddles); d_mod / d_tmp: work space of the sizes above
+hipError_t poly_grand_products(const GrandProducts& g, const words8& beta, const words8& gamma, const words8& delta, size_t n,
+                               size_t usable, const fp_words* d_pow_tab, fp_words* d_mod, fp_words* d_tmp, const GrandOut& outs,
+                               hipStream_t stream);
 // Kate division a(X) = q(X)(X - b) + a(b): q_out gets n slots (q_0..q_{n-2}, then a zero) and must not alias a,
 // rem_out (optional) a(b); n <= 2^21; d_tmp: 1024 elements
 size_t kate_batch_powers_bytes(uint32_t m);

@@ -589,6 +589,117 @@ hipError_t poly_lookup_fraction(const fp_words* d_x, const fp_words* d_y, const 
                                                                           (uint32_t)numer, d_io);
   return hipGetLastError();
 }
+// ---- all grand products of a proof in batched launches ------------------------------------------------------
+// halo2 builds the permutation argument's z per chunk and each lookup's z one after the other; every one of them is
+// "denominators -> batch inversion -> numerators -> running product", and the inversion is ONE division-step chain per
+// lane (~65 us) whatever the size.  Here the P products of a proof share the launches: blockIdx.y = product, one
+// inversion pass over P * n elements, one three-launch running product with grid.y = P; a chunk's z continues from the
+// previous chunk's last usable value through a device-side scalar (no host round trip).
+__global__ void __launch_bounds__(256) grand_fraction_kernel(GrandProducts g, words8 beta_w, words8 gamma_w, words8 delta_w,
+                                                             uint32_t n, uint32_t numer, const fp_words* __restrict__ pow_tab,
+                                                             fp_words* __restrict__ io) {
+  side_kernel_prio();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (i >= n) return;
+  io += (size_t)y * n;
+  const f29 beta = f29_words_to_r261<P>(beta_w.l), gamma = f29_words_to_r261<P>(gamma_w.l);
+  if (y < g.n_perm) {
+    f29 acc = numer ? load_hat(io + i) : f29_one<P>();
+    f29 dw = f29_one<P>();
+    if (numer) dw = f29_mul<P>(f29_words_to_r261<P>(g.delta_start[y].l), f29_load_r256<P>(pow_tab + i));   // hat * hat * 2^-261 = hat
+    const f29 delta = f29_words_to_r261<P>(delta_w.l);
+    const uint32_t ncols = g.ncols[y];
+    for (uint32_t c = 0; c < ncols; c++) {
+      f29 v = load_hat(g.perm[y].values[c] + i);                 // < 2
+      f29 t = numer ? f29_mul<P>(dw, beta) : f29_mul<P>(load_hat(g.perm[y].sigma[c] + i), beta);
+      t = f29_add(f29_add(t, gamma), v);                         // < 6
+      acc = f29_mul<P>(acc, t);                                  // 12
+      if (numer) dw = f29_mul<P>(dw, delta);
+    }
+    store_hat(io + i, acc);
+  } else {
+    const uint32_t l = y - g.n_perm;
+    const fp_words* x = g.lookup[l][numer ? 0 : 2];
+    const fp_words* t_ = g.lookup[l][numer ? 1 : 3];
+    f29 t = f29_mul<P>(f29_add(load_hat(x + i), beta), f29_add(load_hat(t_ + i), gamma));   // 4 * 4
+    if (numer) t = f29_mul<P>(t, load_hat(io + i));
+    store_hat(io + i, t);
+  }
+}
+__global__ void __launch_bounds__(256) prefix_product_blocks_batch(const fp_words* __restrict__ a, uint32_t n, uint32_t nblk,
+                                                                   fp_words* __restrict__ bprod) {
+  side_kernel_prio();
+  __shared__ uint32_t sh[PP_THREADS][9];
+  a += (size_t)blockIdx.y * n;
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * PP_THREADS + tid) * PP_CH;
+  f29 acc = f29_one<P>();
+  for (uint32_t i = 0; i < PP_CH; i++)
+    if (first + i < n) acc = f29_mul<P>(acc, load_hat(a + first + i));
+  f29 total;
+  block_exclusive_scan_mul(acc, sh, tid, PP_THREADS, &total);
+  if (tid == 0) store_hat(bprod + (size_t)blockIdx.y * nblk + blockIdx.x, total);
+}
+__global__ void __launch_bounds__(1024) prefix_product_scan_blocks_batch(fp_words* __restrict__ bprod, uint32_t nblk) {
+  side_kernel_prio();
+  __shared__ uint32_t sh[1024][9];
+  bprod += (size_t)blockIdx.y * nblk;
+  const uint32_t tid = threadIdx.x;
+  f29 mine = tid < nblk ? load_hat(bprod + tid) : f29_one<P>();
+  f29 ex = block_exclusive_scan_mul(mine, sh, tid, 1024, nullptr);
+  if (tid < nblk) store_hat(bprod + tid, ex);
+}
+__global__ void __launch_bounds__(256) prefix_product_write_batch(const fp_words* __restrict__ a, uint32_t n, uint32_t nblk,
+                                                                  const fp_words* __restrict__ bprod, uint32_t count_out,
+                                                                  GrandOut outs) {
+  side_kernel_prio();
+  __shared__ uint32_t sh[PP_THREADS][9];
+  a += (size_t)blockIdx.y * n;
+  fp_words* __restrict__ out = outs.z[blockIdx.y];
+  const uint32_t tid = threadIdx.x, first = (blockIdx.x * PP_THREADS + tid) * PP_CH;
+  f29 v[PP_CH];
+  f29 acc = f29_one<P>();
+#pragma unroll
+  for (uint32_t i = 0; i < PP_CH; i++) {
+    v[i] = (first + i < n) ? load_hat(a + first + i) : f29_one<P>();
+    acc = f29_mul<P>(acc, v[i]);
+  }
+  f29 run = f29_mul<P>(block_exclusive_scan_mul(acc, sh, tid, PP_THREADS, nullptr), load_hat(bprod + (size_t)blockIdx.y * nblk + blockIdx.x));
+#pragma unroll
+  for (uint32_t i = 0; i < PP_CH; i++) {
+    if (first + i < count_out) store_hat(out + first + i, run);
+    run = f29_mul<P>(run, v[i]);
+  }
+}
+// z[i] *= *scalar (a value another kernel of the stream has just written: the previous chunk's z at its last usable row)
+__global__ void __launch_bounds__(256) scale_by_device_scalar_kernel(fp_words* __restrict__ z, uint32_t n, const fp_words* __restrict__ scalar) {
+  side_kernel_prio();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_hat(z + i, f29_mul<P>(load_hat(z + i), load_hat(scalar)));
+}
+size_t grand_products_mod_elems(size_t n, uint32_t products) { return (size_t)products * n; }
+size_t grand_products_tmp_elems(size_t n, uint32_t products) { return (size_t)products * ((n + 1 + PP_BLOCK - 1) / PP_BLOCK) + 1; }
+hipError_t poly_grand_products(const GrandProducts& g, const words8& beta, const words8& gamma, const words8& delta, size_t n,
+                               size_t usable, const fp_words* d_pow_tab, fp_words* d_mod, fp_words* d_tmp, const GrandOut& outs,
+                               hipStream_t stream) {
+  const uint32_t Pn = g.n_perm + g.n_lookup;
+  if (Pn == 0) return hipSuccess;
+  if (Pn > GRAND_MAX || n == 0 || usable >= n || (g.n_perm && !d_pow_tab)) return hipErrorInvalidValue;
+  const uint32_t nblk = (uint32_t)((n + 1 + PP_BLOCK - 1) / PP_BLOCK);   // covers out[0..n]
+  if (nblk > 1024) return hipErrorInvalidValue;                          // n <= 2^21
+  const dim3 rows((unsigned)((n + 255) / 256), Pn);
+  grand_fraction_kernel<<<rows, 256, 0, stream>>>(g, beta, gamma, delta, (uint32_t)n, 0u, d_pow_tab, d_mod);
+  batch_invert_kernel<<<(unsigned)(((size_t)Pn * n / BI_CH + 255) / 256 + 1), 256, 0, stream>>>(d_mod, (uint32_t)(Pn * n));
+  grand_fraction_kernel<<<rows, 256, 0, stream>>>(g, beta, gamma, delta, (uint32_t)n, 1u, d_pow_tab, d_mod);
+  prefix_product_blocks_batch<<<dim3(nblk, Pn), PP_THREADS, 0, stream>>>(d_mod, (uint32_t)n, nblk, d_tmp);
+  prefix_product_scan_blocks_batch<<<dim3(1, Pn), 1024, 0, stream>>>(d_tmp, nblk);
+  prefix_product_write_batch<<<dim3(nblk, Pn), PP_THREADS, 0, stream>>>(d_mod, (uint32_t)n, nblk, d_tmp, (uint32_t)n, outs);
+  // chunk j of the permutation argument starts where chunk j - 1 ended: z_j = z_{j-1}[usable] * (its own running product)
+  for (uint32_t j = 1; j < g.n_perm; j++)
+    scale_by_device_scalar_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(outs.z[j], (uint32_t)n, outs.z[j - 1] + usable);
+  return hipGetLastError();
+}
+
 hipError_t poly_mul_elementwise(const fp_words* d_a, const fp_words* d_b, size_t n, fp_words* d_out,
                                 hipStream_t stream) {
   if (!n) return hipSuccess;

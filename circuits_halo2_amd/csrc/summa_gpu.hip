@@ -454,6 +454,8 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "msm.merge_quad_tasks") c.msm.config().merge_quad_tasks = c.msm_b.config().merge_quad_tasks = (uint32_t)std::max(0, value);
   else if (s == "msm.red2d_max_sets") c.msm.config().red2d_max_sets = c.msm_b.config().red2d_max_sets = (uint32_t)std::min(32, std::max(0, value));
   else if (s == "msm.red2d_fold") c.msm.config().red2d_fold = c.msm_b.config().red2d_fold = (uint32_t)std::min(256, std::max(1, value));
+  else if (s == "msm.red2d_prefold") c.msm.config().red2d_prefold = c.msm_b.config().red2d_prefold = value ? 1u : 0u;
+  else if (s == "msm.prefold_quad_buckets") c.msm.config().prefold_quad_buckets = c.msm_b.config().prefold_quad_buckets = (uint32_t)std::max(0, value);
   else if (s == "msm.red2d") c.msm.config().red2d = c.msm_b.config().red2d = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.quad") c.msm.config().quad = c.msm_b.config().quad = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.log_red_chunk") c.msm.config().log_red_chunk = c.msm_b.config().log_red_chunk = (uint32_t)std::min(8, value);
@@ -506,6 +508,13 @@ int sg_init(int device) {
   return SG_OK;
 }
 
+// host ranges page-locked for the library (sg_host_register, below)
+struct HostRange {
+  uintptr_t base;
+  size_t bytes;
+};
+static std::mutex g_host_mu;
+static std::vector<HostRange> g_host_ranges;
 void sg_shutdown(void) {
   if (g_depth > 0) return;   // never from inside a call
   for (auto& l : g_lanes) l.mu.lock();
@@ -528,6 +537,11 @@ void sg_shutdown(void) {
         st = nullptr;
       }
     }
+    {
+      std::lock_guard<std::mutex> lk(g_host_mu);
+      for (const HostRange& r : g_host_ranges) (void)hipHostUnregister(reinterpret_cast<void*>(r.base));
+      g_host_ranges.clear();
+    }
     std::lock_guard<std::mutex> lk(g_sh.mu);
     for (auto& kv : g_sh.srs) {
       (void)hipFree(kv.second.g);
@@ -547,6 +561,43 @@ void sg_shutdown(void) {
 
 // Returns the device memory the library has outgrown since it started (work spaces that were reallocated larger, window
 // tables replaced by sg_srs_precompute).  It waits for the device: call it when no other call is in flight.
+// ---- host memory the caller has page-locked for the library (sg_host_register): the host-pointer entry points move such
+// ranges by direct DMA at link speed, asynchronously; anything else goes through the runtime's pageable path
+[[maybe_unused]] static bool host_registered(const void* p, size_t bytes) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (const HostRange& r : g_host_ranges)
+    if (a >= r.base && a + bytes <= r.base + r.bytes) return true;
+  return false;
+}
+int sg_host_register(void* host, size_t bytes) {
+  if (!host || !bytes) return fail(SG_ERR_INVALID, "sg_host_register: null or empty range");
+  {
+    LOCKED_CTX();   // a device is bound (the registration is made for it)
+    const uintptr_t a = reinterpret_cast<uintptr_t>(host);
+    {
+      std::lock_guard<std::mutex> lk(g_host_mu);
+      for (const HostRange& r : g_host_ranges)
+        if (a < r.base + r.bytes && r.base < a + bytes) return fail(SG_ERR_INVALID, "sg_host_register: overlaps a registered range");
+    }
+    CHECK_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault), "hipHostRegister");
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_ranges.push_back({a, bytes});
+  }
+  return SG_OK;
+}
+int sg_host_unregister(void* host) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(host);
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = std::find_if(g_host_ranges.begin(), g_host_ranges.end(), [&](const HostRange& r) { return r.base == a; });
+    if (it == g_host_ranges.end()) return fail(SG_ERR_INVALID, "sg_host_unregister: not the start of a registered range");
+    g_host_ranges.erase(it);
+  }
+  CHECK_HIP(hipHostUnregister(host), "hipHostUnregister");
+  return SG_OK;
+}
+
 int sg_collect_retired(void) {
   if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_collect_retired: not from inside a call");
   int device;
@@ -594,6 +645,7 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
     timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
     timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
     timings->accumulate_threads = tm.accumulate_threads;
+    timings->order_ms = tm.order_ms;
   }
   return SG_OK;
 }
@@ -604,11 +656,32 @@ int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t ou
   if (!out_affine || (n && (!scalars || !bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
   {
     LOCKED_CTX();
-    TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
-    TRY(upload(g_ctx->stage_b, bases, n * 64, g_ctx->stream));
-    hipError_t e = g_ctx->msm.run(reinterpret_cast<const fp_words*>(g_ctx->stage_a.p),
-                                  reinterpret_cast<const g1_affine_mem*>(g_ctx->stage_b.p), n, g_ctx->stream, out_affine,
-                                  nullptr);
+    Context& c = *g_ctx;
+    // The scalars travel first and the digit / sort front-end starts behind them; the bases (twice the bytes) travel on a
+    // second stream meanwhile and only the accumulation waits for them.  From page-locked or registered memory
+    // (sg_host_register) both copies are direct DMA; from pageable memory the runtime stages them and the call blocks
+    // in the copy, with the front-end already running on the device.
+    TRY(upload(c.stage_a, scalars, n * 32, c.stream));
+    hipError_t e = c.stage_b.reserve(n ? n * 64 : 1);
+    if (e != hipSuccess) return hip_fail("staging buffer", e);
+    if (!n) {
+      e = c.msm.run(reinterpret_cast<const fp_words*>(c.stage_a.p), reinterpret_cast<const g1_affine_mem*>(c.stage_b.p), 0, c.stream,
+                    out_affine, nullptr);
+      if (e != hipSuccess) return hip_fail("msm", e);
+      return SG_OK;
+    }
+    hipStream_t side = c.bstream[0];
+    CHECK_HIP(hipEventRecord(c.ev_in, c.stream), "event");          // the staging buffer may still be read by the stream's earlier work
+    CHECK_HIP(hipStreamWaitEvent(side, c.ev_in, 0), "stream wait");
+    e = c.msm.enqueue_front(reinterpret_cast<const fp_words*>(c.stage_a.p), reinterpret_cast<const g1_affine_mem*>(c.stage_b.p), n, c.stream,
+                            out_affine, nullptr);
+    if (e != hipSuccess) return hip_fail("msm", e);
+    hipError_t ce = hipMemcpyAsync(c.stage_b.p, bases, n * 64, hipMemcpyHostToDevice, side);
+    if (ce == hipSuccess) ce = hipEventRecord(c.ev_in, side);
+    if (ce == hipSuccess) ce = hipStreamWaitEvent(c.stream, c.ev_in, 0);
+    e = c.msm.enqueue_back();                 // (always: the engine's job is closed in order, whatever the copy did)
+    if (e == hipSuccess) e = c.msm.finish();
+    if (ce != hipSuccess) return hip_fail("H2D copy", ce);
     if (e != hipSuccess) return hip_fail("msm", e);
   }
   return SG_OK;
@@ -919,6 +992,7 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
     timings->reduce_ms = tm.reduce_ms; timings->total_ms = tm.total_ms; timings->window_bits = tm.window_bits;
     timings->windows = tm.windows; timings->tasks = tm.tasks; timings->max_bucket = tm.max_bucket;
     timings->accumulate_threads = tm.accumulate_threads;
+    timings->order_ms = tm.order_ms;
   }
   return SG_OK;
 }
@@ -979,6 +1053,8 @@ struct Combiner {
   std::atomic<int> target{4};            // ... or until this many are pending ("commit.combine_target")
   std::atomic<int> max_runners{1};       // fused jobs that may run side by side, each on a lane of its own ("commit.combine_runners")
   std::atomic<uint64_t> jobs{0}, requests{0};   // statistics: fused jobs run, requests served
+  std::atomic<uint64_t> isolated{0};     // members re-run alone after their fused job failed as a whole
+  std::atomic<int> fail_next{0};         // test hook ("debug.fail_next_fused_job"): the next fused job reports SG_ERR_NOMEM unrun
 };
 Combiner g_comb;
 thread_local bool t_combine = false;
@@ -1022,7 +1098,8 @@ static void combiner_run_unguarded(const std::vector<CommitReq*>& batch) {
         if (e != hipSuccess) { rc = hip_fail("commit combiner: stream wait", e); break; }
       }
     }
-    if (rc == SG_OK) rc = commit_batch_mixed_core(batch[0]->srs, basis.data(), scalars.data(), total, batch[0]->n, g_ctx->stream, out.data());
+    if (rc == SG_OK && batch.size() > 1 && g_comb.fail_next.exchange(0)) rc = fail(SG_ERR_NOMEM, "commit combiner: injected failure of a fused job");
+    else if (rc == SG_OK) rc = commit_batch_mixed_core(batch[0]->srs, basis.data(), scalars.data(), total, batch[0]->n, g_ctx->stream, out.data());
   }
   size_t at = 0;
   for (CommitReq* r : batch) {
@@ -1030,6 +1107,24 @@ static void combiner_run_unguarded(const std::vector<CommitReq*>& batch) {
     if (rc == SG_OK) std::memcpy(r->out, out.data() + 64 * at, 64 * r->count);
     else std::snprintf(r->err, sizeof r->err, "%s", g_err);
     at += r->count;
+  }
+  if (rc != SG_OK && batch.size() > 1) {
+    // The fused job failed AS A WHOLE -- out of device memory at this size, one member's bad pointer or stale handle.  One
+    // member's fault must not cost the others their proofs: every member gets a job of its own (same lane discipline:
+    // the job's stream waits for that member's inputs) and its own return value and message.
+    for (CommitReq* r : batch) {
+      LaneHold hold;
+      int rc1 = hold.rc;
+      if (rc1 == SG_OK) {
+        const hipError_t e = hipStreamWaitEvent(g_ctx->stream, r->ready, 0);
+        if (e != hipSuccess) rc1 = hip_fail("commit combiner: stream wait", e);
+      }
+      if (rc1 == SG_OK) rc1 = commit_batch_mixed_core(r->srs, r->basis, r->scalars, r->count, r->n, g_ctx->stream, r->out);
+      r->rc = rc1;
+      if (rc1 != SG_OK) std::snprintf(r->err, sizeof r->err, "%s", g_err);
+      else r->err[0] = 0;
+      g_comb.isolated.fetch_add(1);
+    }
   }
   g_comb.jobs.fetch_add(1);
   g_comb.requests.fetch_add(batch.size());
@@ -1097,9 +1192,15 @@ int sg_commit_combine_begin(void) {
 int sg_commit_combine_end(void) {
   if (!t_combine) return SG_OK;
   t_combine = false;
-  std::lock_guard<std::mutex> lk(g_comb.mu);
-  g_comb.members--;
-  g_comb.cv.notify_all();          // a runner waiting for this thread stops counting it
+  {
+    std::lock_guard<std::mutex> lk(g_comb.mu);
+    g_comb.members--;
+    g_comb.cv.notify_all();          // a runner waiting for this thread stops counting it
+  }
+  if (t_ready) {                     // this thread's requests have all returned: nothing waits on the event any more
+    (void)hipEventDestroy(t_ready);
+    t_ready = nullptr;
+  }
   return SG_OK;
 }
 int sg_commit_combine_stats(uint64_t* jobs, uint64_t* requests) {
@@ -1231,9 +1332,22 @@ int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32],
 int sg_ntt_fr_batch_oop_dev(const void* const* d_in, void* const* d_out, size_t count, const uint8_t omega[32], const uint8_t* divisor,
                             uint32_t log_n, void* stream) {
   if ((count && (!d_in || !d_out)) || !omega || log_n > 28) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: bad argument");
-  for (size_t i = 0; i < count; i++)
-    if (!d_in[i] || !d_out[i] || d_in[i] == d_out[i]) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: null or aliased vector");
   const size_t n = (size_t)1 << log_n;
+  {
+    // the vectors of a launch are transformed side by side: an output that overlaps ANY input, or another output, would be
+    // read or written by two workgroups at once -- refused here ("the inputs untouched" is the call's promise)
+    auto overlap = [&](const void* a, const void* b) {
+      const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+      return x < y + 32 * n && y < x + 32 * n;
+    };
+    for (size_t i = 0; i < count; i++) {
+      if (!d_in[i] || !d_out[i]) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: null vector");
+      for (size_t j = 0; j < count; j++) {
+        if (overlap(d_out[i], d_in[j])) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: an output overlaps an input");
+        if (j != i && overlap(d_out[i], d_out[j])) return fail(SG_ERR_INVALID, "sg_ntt_fr_batch_oop: two outputs overlap");
+      }
+    }
+  }
   if (log_n < 1 || log_n > 18) {   // outside the batched plans: copy, then in place
     for (size_t i = 0; i < count; i++)
       CHECK_HIP(hipMemcpyAsync(d_out[i], d_in[i], n * 32, hipMemcpyDeviceToDevice, pick_stream(stream)), "D2D copy");
@@ -1964,6 +2078,64 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
   return grand_product_tail(mod, n, nullptr, d_z, s);
 }
 
+int sg_grand_products_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
+                          const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
+                          uint32_t k, size_t usable_rows, void* const* d_z, void* stream) {
+  if (!beta || !gamma || !d_z || (n_chunks && (!d_values || !d_sigma || !chunk_cols)) || (n_lookups && !d_lookup_cols))
+    return fail(SG_ERR_INVALID, "sg_grand_products: null argument");
+  if (n_chunks + n_lookups == 0) return SG_OK;
+  if (n_chunks + n_lookups > GRAND_MAX) return fail(SG_ERR_INVALID, "sg_grand_products: at most 8 products per call");
+  if (k == 0 || k > 20) return fail(SG_ERR_INVALID, "sg_grand_products: 1 <= k <= 20");
+  const size_t n = (size_t)1 << k;
+  if (usable_rows >= n) return fail(SG_ERR_INVALID, "sg_grand_products: usable_rows must be below 2^k");
+  LOCKED_CTX();
+  const DomainConsts* dc;
+  TRY(get_consts(k, &dc));
+  GrandProducts g{};
+  GrandOut outs{};
+  g.n_perm = n_chunks;
+  g.n_lookup = n_lookups;
+  // delta^(index of the chunk's first column), on the host: a handful of products in the memory domain
+  summa::prover::Fr dpow = summa::prover::Fr::one(), dlt;
+  std::memcpy(dlt.l, DELTA_M, 32);
+  uint32_t col = 0;
+  for (uint32_t j = 0; j < n_chunks; j++) {
+    if (chunk_cols[j] == 0 || chunk_cols[j] > PERM_MAX_COLS) return fail(SG_ERR_INVALID, "sg_grand_products: 1 .. 8 columns per chunk");
+    g.ncols[j] = chunk_cols[j];
+    std::memcpy(g.delta_start[j].l, dpow.l, 32);
+    for (uint32_t c = 0; c < chunk_cols[j]; c++, col++) {
+      if (!d_values[col] || !d_sigma[col]) return fail(SG_ERR_INVALID, "sg_grand_products: null column");
+      g.perm[j].values[c] = static_cast<const fp_words*>(d_values[col]);
+      g.perm[j].sigma[c] = static_cast<const fp_words*>(d_sigma[col]);
+      dpow = dpow * dlt;
+    }
+  }
+  for (uint32_t l = 0; l < n_lookups; l++)
+    for (int q = 0; q < 4; q++) {
+      if (!d_lookup_cols[4 * l + q]) return fail(SG_ERR_INVALID, "sg_grand_products: null lookup column");
+      g.lookup[l][q] = static_cast<const fp_words*>(d_lookup_cols[4 * l + q]);
+    }
+  for (uint32_t p = 0; p < n_chunks + n_lookups; p++) {
+    if (!d_z[p]) return fail(SG_ERR_INVALID, "sg_grand_products: null output");
+    outs.z[p] = static_cast<fp_words*>(d_z[p]);
+  }
+  hipStream_t s = pick_stream(stream);
+  uint8_t *modb = nullptr, *tmpb = nullptr;
+  hipError_t e = scratch_for(s, 1, grand_products_mod_elems(n, n_chunks + n_lookups) * 32 + 64, &modb);
+  if (e == hipSuccess) e = scratch_for(s, 0, grand_products_tmp_elems(n, n_chunks + n_lookups) * 32 + 64, &tmpb);
+  if (e != hipSuccess) return hip_fail("grand products work space", e);
+  fp_words* pw = nullptr;   // omega^i, i < n (cached per domain)
+  if (n_chunks) {
+    e = g_ctx->ntt.local_twiddles(dc->omega, k + 1, s, &pw);
+    if (e != hipSuccess) return hip_fail("grand products: power table", e);
+  }
+  words8 b, gm, dl;
+  std::memcpy(&b, beta, 32); std::memcpy(&gm, gamma, 32); std::memcpy(&dl, DELTA_M, 32);
+  e = poly_grand_products(g, b, gm, dl, n, usable_rows, pw, reinterpret_cast<fp_words*>(modb), reinterpret_cast<fp_words*>(tmpb), outs, s);
+  if (e != hipSuccess) return hip_fail("grand products", e);
+  return SG_OK;   // asynchronous: ordered on the caller's stream
+}
+
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream) {
   if (n && (!d_a || !d_b || !d_out)) return fail(SG_ERR_INVALID, "sg_fr_mul: null argument");
   if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_mul: vector too long");
@@ -2473,6 +2645,10 @@ int sg_set_param(const char* name, int value) {
   }
   if (s == "commit.combine_target") {
     g_comb.target.store(std::max(1, std::min(value, 32)));
+    return SG_OK;
+  }
+  if (s == "debug.fail_next_fused_job") {
+    g_comb.fail_next.store(value ? 1 : 0);
     return SG_OK;
   }
   if (s == "commit.combine_runners") {

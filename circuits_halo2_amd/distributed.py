@@ -71,6 +71,30 @@ def exchange_partials(part: np.ndarray, msm=None) -> np.ndarray:
     return combine_partials(gathered.cpu().numpy(), msm)
 
 
+def exchange_partials_many(parts, msm=None):
+    """the exchange step of SEVERAL point-sharded MSMs in ONE collective: every rank contributes the 64-byte partials of
+    its K steps (they are host-resident: the MSM's tail runs on the host), one all_gather of K * 64 bytes, K local sums
+    of world_size points.  Returns the K result points (the same on every rank).
+
+    Why a pipelined caller uses this instead of K calls of `exchange_partials`: with steps in flight, accumulations of
+    consecutive MSMs run back to back on the device, and every kernel beside them must raise its wave priority to be
+    issued at all (csrc/side_prio.cuh); RCCL's kernels cannot.  One collective after the steps
+    keeps RCCL off the device while it is saturated; the step's result is complete when this returns."""
+    parts = [np.ascontiguousarray(p_) for p_ in parts]
+    d = _dist()
+    if d is None or not parts:
+        return parts
+    import torch
+    world = d.get_world_size()
+    dev = "cuda" if d.get_backend() == "nccl" else "cpu"
+    K = len(parts)
+    mine = torch.from_numpy(np.concatenate(parts)).to(dev)
+    gathered = torch.empty(64 * K * world, dtype=torch.uint8, device=dev)
+    d.all_gather_into_tensor(gathered, mine)
+    g = gathered.cpu().numpy().reshape(world, K, 64)
+    return [combine_partials(np.ascontiguousarray(g[:, i, :]).reshape(-1), msm) for i in range(K)]
+
+
 def sharded_msm(local_scalars, local_bases, msm=None) -> np.ndarray:
     """sum over ALL ranks' shards of sum_i s_i P_i; every rank returns the same 64-byte point.
     With no process group this is plain best_multiexp."""

@@ -16,7 +16,7 @@ _LIB = None
 
 SG_OK = 0
 EXPORTS = [
-    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
+    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_host_register", "sg_host_unregister", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
     "sg_msm_g1", "sg_msm_g1_dev", "sg_msm_g1_batch", "sg_msm_g1_batch_dev", "sg_g1_sum_affine", "sg_srs_upload", "sg_srs_upload_dev", "sg_srs_copy_dev", "sg_srs_free", "sg_srs_check", "sg_commit", "sg_commit_dev",
     "sg_srs_device_ptrs", "sg_srs_precompute", "sg_commit_batch_dev", "sg_commit_batch_mixed_dev", "sg_commit_combine_begin", "sg_commit_combine_end", "sg_commit_combine_stats", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_ntt_fr_batch_dev", "sg_ntt_fr_batch_oop_dev", "sg_intt_fr", "sg_intt_fr_dev",
     "sg_lagrange_to_coeff", "sg_lagrange_to_coeff_dev", "sg_coeff_to_extended", "sg_coeff_to_extended_dev", "sg_coeff_to_extended_batch_dev",
@@ -24,7 +24,7 @@ EXPORTS = [
     "sg_divide_by_vanishing_poly_dev", "sg_domain_constant", "sg_g1_fixed_base_mul", "sg_g1_fixed_base_mul_dev", "sg_g2_generator_mul", "sg_pairing_check", "sg_pairing_check_slow", "sg_keccak256", "sg_kzg_setup", "sg_kzg_setup_dev", "sg_g1_fft_dev", "sg_g1_to_lagrange",
     "sg_fr_to_montgomery_dev", "sg_fr_from_montgomery_dev", "sg_fr_random_dev", "sg_fr_random_batch_dev", "sg_lookup_permute_small_dev", "sg_fr_eval_poly", "sg_fr_eval_poly_dev", "sg_fr_eval_poly_batch_dev",
     "sg_fr_batch_invert_dev", "sg_fr_prefix_product_dev", "sg_fr_mul_dev", "sg_fr_kate_division_dev", "sg_fr_kate_division_batch_dev", "sg_fr_count_noncanonical_dev", "sg_fr_lincomb_dev", "sg_fr_lincomb_low_dev", "sg_permutation_product_dev",
-    "sg_lookup_product_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_set_param", "sg_time_ntt_dev",
+    "sg_lookup_product_dev", "sg_grand_products_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_set_param", "sg_time_ntt_dev",
 ]
 
 
@@ -38,7 +38,7 @@ class MsmTimings(C.Structure):
     _fields_ = [("digits_ms", C.c_float), ("sort_ms", C.c_float), ("accumulate_ms", C.c_float),
                 ("reduce_ms", C.c_float), ("total_ms", C.c_float), ("window_bits", C.c_uint32),
                 ("windows", C.c_uint32), ("tasks", C.c_uint32), ("max_bucket", C.c_uint32),
-                ("accumulate_threads", C.c_uint32)]
+                ("accumulate_threads", C.c_uint32), ("order_ms", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -235,6 +235,26 @@ class ProvingKey:
         torch.cuda.synchronize()
 
 
+    def free(self) -> None:
+        """give back the key's forms inside the library's compiled prover (sp_key_create on first use: coefficient and
+        coset columns of every fixed / permutation column, on the device); the key object itself stays usable and
+        makes them again when a proof asks.  Called when the object dies: a long-lived process that proves for one
+        snapshot after another must not keep every past key's columns (tests/test_gpu_batch.py, the long-lived-process test)."""
+        made = getattr(self, "_native", None)
+        if made is None:
+            return
+        self._native = None
+        try:
+            import ctypes as C
+            from . import ffi
+            ffi.prover_lib().sp_key_destroy(C.c_uint64(made[0]))
+        except Exception:   # noqa: BLE001 -- interpreter shutdown, library gone: nothing left to give back to
+            pass
+
+    def __del__(self):
+        self.free()
+
+
 _KEY_LOCK = threading.Lock()      # for key objects that carry no lock of their own
 
 

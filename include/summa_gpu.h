@@ -65,6 +65,15 @@ void sg_shutdown(void);
  * It is bounded by the final sizes (work spaces grow geometrically) and is returned here and by sg_shutdown.  The call
  * waits for the device to go idle: use it between workloads (e.g. after switching k), with no other call in flight. */
 int sg_collect_retired(void);
+/* Host memory for the host-pointer entry points (sg_msm_g1, sg_commit, sg_ntt_fr and the other calls without `_dev`): what a
+ * [patch] of best_multiexp / best_fft hands over are ordinary vectors in pageable memory, which the runtime has to stage
+ * on every call.  A caller that keeps its vectors in place (an SRS, a column pool, an arena) page-locks them ONCE with
+ * sg_host_register(base, bytes) -- hipHostRegister underneath -- and every later call whose argument lies inside a
+ * registered range moves it by direct DMA at link speed.  Ranges may not overlap; sg_host_unregister takes the base
+ * address again (before the memory is freed); sg_shutdown drops what is left.  Not needed for memory that is already
+ * page-locked (hipHostMalloc). */
+int sg_host_register(void* host, size_t bytes);
+int sg_host_unregister(void* host);
 /* Message of the last failure on the calling thread (static storage, never NULL). */
 const char* sg_last_error(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
@@ -146,6 +155,8 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
  * "commit.combine_wait_us", default 300) for the others to arrive, then everything pending with the same SRS and length
  * runs as one job -- one sort front-end, one bucket reduction, one host tail for all of them.  Same commitments, same
  * return values; a caller never waits for a thread that may not come, only for that deadline or for the running job.
+ * A fused job that fails as a whole (device memory, a bad pointer of ONE member) does not fail its members: each of them is
+ * then run as a job of its own and gets its own return value.
  * sg_commit_combine_stats: fused jobs run / requests served so far (requests / jobs = average fusion). */
 int sg_commit_combine_begin(void);
 int sg_commit_combine_end(void);
@@ -294,6 +305,19 @@ int sg_permutation_product_dev(const void* const* d_values, const void* const* d
 int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* d_permuted_input,
                           const void* d_permuted_table, const uint8_t beta[32], const uint8_t gamma[32], size_t n,
                           void* d_z, void* stream);
+/* ALL grand products of one proof in batched launches (permutation::prover::commit over every chunk, then
+ * lookup::prover::commit_product for every lookup -- halo2 plonk/permutation/prover.rs, plonk/lookup/prover.rs; reached
+ * from the reference's create_proof call, zk_prover/src/circuits/utils.rs:94-101): the products share one denominator
+ * pass, ONE batch inversion, one numerator pass and one three-launch running product (grid.y = product), and a chunk's z
+ * continues from the previous chunk's value at row `usable_rows` through a device-side scalar -- no host round trip, nothing
+ * to synchronise.  Same values as the calls above chained by hand.
+ *   d_values / d_sigma: the permutation's columns in order, chunk after chunk (chunk j has chunk_cols[j] <= 8 of them);
+ *   d_lookup_cols: 4 per lookup -- input, table, permuted input, permuted table (theta-compressed by the caller);
+ *   d_z: n_chunks + n_lookups outputs of 2^k values each (the caller overwrites the blinding rows); k <= 20,
+ *   n_chunks + n_lookups <= 8. */
+int sg_grand_products_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
+                          const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
+                          uint32_t k, size_t usable_rows, void* const* d_z, void* stream);
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 
@@ -439,9 +463,11 @@ int sg_mst_inclusion_witness_dev(const void* d_program, uint32_t n_items, uint32
 
 /* ---- tuning / introspection (not part of the reference seam) */
 typedef struct {
-  float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream */
+  float digits_ms, sort_ms, accumulate_ms, reduce_ms, total_ms; /* HIP-event times on the stream; accumulate_ms: the accumulation launch
+                                                                  * (and merge rounds) alone, from behind its wait for other jobs' accumulations */
   uint32_t window_bits, windows, tasks, max_bucket;
   uint32_t accumulate_threads; /* threads of the msm_accumulate launch (sized by an upper bound of `tasks`) */
+  float order_ms;              /* between sort and accumulation: the task-ordering kernels + the time queued behind other jobs' accumulations */
 } sg_msm_timings;
 /* as sg_msm_g1_dev, additionally fills per-phase HIP event timings */
 int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64],
@@ -449,7 +475,11 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
 int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, size_t n, void* stream,
                         uint8_t out_affine[64], sg_msm_timings* timings);
 /* name: "lanes" (1..8, default 4: concurrent calls that get a context of their own, see the conventions at the top),
- * "commit.combine_wait_us" (see sg_commit_combine_begin),
+ * "commit.combine_wait_us" (default 300), "commit.combine_target" (default 4: a runner stops waiting once this many requests
+ *   are pending), "commit.combine_runners" (default 1: fused jobs that may run side by side, each on a lane of its own) -- see
+ *   sg_commit_combine_begin; process-wide, they stay as set until set again,
+ * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that
+ *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
  * "ntt.max_single_log", "ntt.max_multi_log";
  * how calls in flight share the device (the defaults are what the measurements chose):

@@ -486,11 +486,13 @@ struct Session {
   std::multimap<size_t, void*> pool;          // freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device)
   uint64_t* pinned = nullptr;
   size_t pinned_cap = 0;
+  uint64_t* pinned_small = nullptr;           // 8 rows of page-locked memory for values read back asynchronously (checked where the host waits anyway)
   ~Session() {   // no HIP calls here (see Orphans)
     Orphans& o = orphans();
     std::lock_guard<std::mutex> lk(o.mu);
     for (auto& kv : pool) o.pool.emplace(kv.first, kv.second);
     if (pinned) o.pinned.emplace_back(pinned, pinned_cap);
+    if (pinned_small) o.pinned.emplace_back(pinned_small, (size_t)0);   // (capacity 0: released, never handed on as row staging)
     for (auto& st : side)
       if (st) o.streams.push_back(st);
     if (ev_fork) o.events.push_back(ev_fork);
@@ -722,6 +724,11 @@ inline void os_random(uint8_t* out, size_t bytes) {
   std::fclose(f);
 }
 
+inline uint64_t* pinned_small_rows() {   // 8 rows, allocated once per session
+  uint64_t*& p = session().pinned_small;
+  if (!p) hk(hipHostMalloc(reinterpret_cast<void**>(&p), 32 * 8), "hipHostMalloc");
+  return p;
+}
 inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept (per thread)
   uint64_t*& p = session().pinned;
   size_t& cap = session().pinned_cap;
@@ -845,7 +852,6 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   Fr omega, omega_inv;
   std::memcpy(omega.l, omega_b, 32);
   std::memcpy(omega_inv.l, omega_inv_b, 32);
-  const Fr delta = Fr::from_u64(7).pow((uint64_t)1 << 28);
   tr.common_scalar(Fr::from_be_bytes_reduced(pk.vk_digest_be));   // vk.hash_into(transcript)
   for (auto& v : instances) tr.common_scalar(v);
 
@@ -864,6 +870,14 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     }
     ck(sg_fr_random_batch_dev(key, draws + 1, outs, counts, m, main_stream()), "fr_random");
     draws += m;
+  };
+  // a draw out of turn: the values of draw number `id` (1-based, in the order upstream's prover draws) on stream `st`, for a
+  // column that depends on nothing and can be filled while the device is busy with something else.  The draw numbers of
+  // the others do not move, so the proof under a fixed key is the one the in-order schedule gives.
+  auto rand_at = [&](uint64_t id, DevCol& col, size_t first, size_t count, hipStream_t st) {
+    void* outs[1] = {col.at(first)};
+    size_t counts[1] = {count};
+    ck(sg_fr_random_batch_dev(key, id, outs, counts, 1, st), "fr_random");
   };
   // two side streams: independent latency chains (the transforms of a phase under its commitments, the three grand
   // products, the rotation sets of the multi-open) run next to the main (null) stream; the library keeps its work
@@ -951,6 +965,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // under the commitments; issued FIRST: started later (after the lookup's kernels) these transforms ran into the commitment
   // job's latency-bound kernels and cost it more (0.70 -> 0.82 ms) than the earlier start of the lookup kernels gained (50 us)
   to_coeff_ext({advice[0].p, advice[1].p, advice[2].p, instance_col.p}, co1, ex1, side[0]);
+  // the random polynomial of phase 3 (draw 9: after the three advice columns, the two permuted columns and the three grand
+  // products) depends on nothing: 2^k values drawn here, under phase 1's commitment job, instead of on phase 3's critical path
+  DevCol random_poly(n);
+  rand_at(9, random_poly, 0, n, side[1]);
   // -- 2 (computed ahead of its place in the transcript): the lookup's permuted columns.  This circuit's lookup has ONE input
   // and ONE table expression, so the theta-compression is the expression itself and nothing here waits for theta: the two
   // permuted columns are committed in the SAME fused job as the advice columns (one MSM group's latency instead of two) and
@@ -1004,8 +1022,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   };
   const uint32_t perm_kind[6] = {SG_VS_FIXED, SG_VS_ADVICE, SG_VS_ADVICE, SG_VS_FIXED, SG_VS_ADVICE, SG_VS_INSTANCE};
   const uint32_t perm_idx[6] = {2, 0, 1, 3, 2, 0};
-  // the three grand products are independent up to one scalar (z1 continues from z0's last usable value): z1 is
-  // built from 1 on a side stream and scaled afterwards, the lookup product runs on the other side stream
+  // the three grand products are independent up to one scalar (z1 continues from z0's last usable value)
   std::vector<DevCol> zs;
   zs.emplace_back(n);
   zs.emplace_back(n);
@@ -1016,37 +1033,43 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       vals[c / CHUNK].push_back(lag_col(perm_kind[c], perm_idx[c]));
       sig[c / CHUNK].push_back(pk.sigma_lag[c].p);
     }
-    const Fr delta_chunk = delta.pow((uint64_t)CHUNK);
-    fork();
-    ck(sg_permutation_product_dev(vals[0].data(), sig[0].data(), (uint32_t)vals[0].size(), beta.bytes(), gamma.bytes(),
-                                  Fr::one().bytes(), k, nullptr, zs[0].p, main_stream()), "permutation product");
-    ck(sg_permutation_product_dev(vals[1].data(), sig[1].data(), (uint32_t)vals[1].size(), beta.bytes(), gamma.bytes(),
-                                  delta_chunk.bytes(), k, nullptr, zs[1].p, side[0]), "permutation product");
-    ck(sg_lookup_product_dev(inp.p, pk.fixed_lag[4].p, pin.p, ptab.p, beta.bytes(), gamma.bytes(), n, lz.p, side[1]), "lookup product");
-    mark("3: grand products enqueued");
-    Fr z0_last, last;
-    hk(hipMemcpyAsync(z0_last.l, zs[0].at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
-    hk(hipStreamSynchronize(main_stream()), "sync");   // z0 only; the other two keep running
-    join();
-    void* z1p[1] = {zs[1].p};
-    ck(sg_fr_lincomb_dev(z1p, z0_last.bytes(), 1, n, zs[1].p, main_stream()), "z1 *= z0[u]");
-    if (opt.sanity_checks) {   // (two blocking reads: only when asked for)
-      d2h(last.l, zs[1].at(u), 32);
-      if (last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
-      d2h(last.l, lz.at(u), 32);
-      if (last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
+    // one batched call (sg_grand_products_dev): the three products share their launches -- one inversion pass instead of
+    // three latency chains --, z1 continues from z0's last usable value on the device, and nothing here waits for the device
+    std::vector<void*> all_vals, all_sig;
+    uint32_t chunk_cols[2];
+    for (int c = 0; c < 2; c++) {
+      chunk_cols[c] = (uint32_t)vals[c].size();
+      all_vals.insert(all_vals.end(), vals[c].begin(), vals[c].end());
+      all_sig.insert(all_sig.end(), sig[c].begin(), sig[c].end());
     }
+    void* lookup_cols[4] = {inp.p, pk.fixed_lag[4].p, pin.p, ptab.p};
+    void* z_out[3] = {zs[0].p, zs[1].p, lz.p};
+    ck(sg_grand_products_dev(all_vals.data(), all_sig.data(), chunk_cols, 2, lookup_cols, 1, beta.bytes(), gamma.bytes(), k, u, z_out,
+                             main_stream()), "grand products");
+    mark("3: grand products enqueued");
   }
-  mark("3: grand products closed (sanity reads)");
-  DevCol random_poly(n);
-  rand_rows({{&zs[0], u + 1, n - u - 1}, {&zs[1], u + 1, n - u - 1}, {&lz, u + 1, n - u - 1}, {&random_poly, 0, n}});
+  uint64_t* closing = pinned_small_rows();   // z1[u], lz[u]: read back asynchronously, looked at when the commitments are back
+  if (opt.sanity_checks) {
+    hk(hipMemcpyAsync(closing, zs[1].at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
+    hk(hipMemcpyAsync(closing + 4, lz.at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
+  }
+  rand_rows({{&zs[0], u + 1, n - u - 1}, {&zs[1], u + 1, n - u - 1}, {&lz, u + 1, n - u - 1}});
+  draws += 1;                                // draw 9, the random polynomial, was made in phase 1
   std::vector<DevCol> co3, ex3;
+  join();                                    // (the random polynomial's stream)
   fork();
   to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
   // the grand products stay constant wherever the ratio is 1 -- all the unused rows: difference form
   mark("3: commit [z0 z1 lz random] issued");
   commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
   mark("3: commitments back");
+  if (opt.sanity_checks) {   // the copies above precede the commitment job on the main stream: complete by now
+    Fr last;
+    std::memcpy(last.l, closing, 32);
+    if (last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
+    std::memcpy(last.l, closing + 4, 32);
+    if (last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
+  }
   const Fr y = tr.squeeze();
   join();
 

@@ -32,6 +32,12 @@ assert (got == want).all(), "sharded MSM differs from the single-process result"
 got2 = sharded_msm(sc[:32 * n] if rank == 0 else sc[:0], bases[:64 * n] if rank == 0 else bases[:0], msm=msm)
 assert (got2 == want).all()
 assert sorted(sum((assign_ops(35, r, world) for r in range(world)), [])) == list(range(35))
+# the exchange of several steps in ONE collective gives what one collective per step gives
+from circuits_halo2_amd.distributed import exchange_partials, exchange_partials_many
+parts = [msm(sc[32 * (lo + j):32 * hi], bases[64 * (lo + j):64 * hi]) for j in range(3)]
+many = exchange_partials_many(parts, msm=msm)
+assert len(many) == 3 and all((many[j] == exchange_partials(parts[j], msm=msm)).all() for j in range(3))
+assert (many[0] == want).all() and exchange_partials_many([], msm=msm) == []
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -74,6 +80,16 @@ assert bytes(got["g2"]) == bytes(range(128)) and bytes(got["s_g2"]) == bytes(ran
 for col in got["fixed"] + got["sigma"]:
     assert (col == ref.integers(0, 256, 32 << k, dtype=np.uint8)).all()
 assert len(got["fixed"]) == 11 and len(got["sigma"]) == 6
+# --- a source with nothing valid to send says so in the header: EVERY rank raises, none waits in the next broadcast
+bad = dict(setup, g=setup["g"][:-1]) if rank == 0 else None
+try:
+    B.broadcast_setup(bad, 0)
+    raise SystemExit("a short buffer on the source must fail the broadcast on every rank")
+except RuntimeError as ex:
+    assert "nothing valid to send" in str(ex)
+    assert (ex.__cause__ is not None and "g has" in str(ex.__cause__)) == (rank == 0)
+again = B.broadcast_setup(setup, 0)                  # and the group is still usable
+assert again["k"] == k and (again["g"] == got["g"]).all()
 # --- users are dealt round-robin; every user is proven exactly once across the group; several proofs in flight
 users = list(range(3, 40))
 mine = B.deal(users)

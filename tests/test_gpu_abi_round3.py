@@ -70,6 +70,30 @@ def test_out_of_place_batch_transform(log_n):
     assert ffi.lib().sg_ntt_fr_batch_oop_dev(same, same, C.c_size_t(1), ffi.ptr(omega), None, C.c_uint32(log_n), None) == -1   # aliased
 
 
+def test_out_of_place_batch_refuses_vectors_that_overlap():
+    """the vectors of one launch are transformed side by side, so an output that overlaps ANY input (not only its own) or
+    another output would be corrupted silently: refused with SG_ERR_INVALID (advisor r03)"""
+    torch = _gpu()
+    from circuits_halo2_amd import ffi
+    from oracle import oracle as O
+    k = 8
+    n = 1 << k
+    buf = torch.zeros(32 * n * 4, dtype=torch.uint8, device="cuda")
+    at = lambda off: buf.data_ptr() + off
+    w = O.omega(k)
+
+    def call(ins, outs):
+        pi = (C.c_void_p * len(ins))(*ins)
+        po = (C.c_void_p * len(outs))(*outs)
+        return ffi.lib().sg_ntt_fr_batch_oop_dev(pi, po, C.c_size_t(len(ins)), ffi.ptr(ffi.u8(w)), None, C.c_uint32(k), None)
+    assert call([at(0), at(32 * n)], [at(64 * n), at(96 * n)]) == 0                         # disjoint: fine
+    assert call([at(0), at(32 * n)], [at(32 * n), at(96 * n)]) != 0                         # out[0] is in[1]
+    assert call([at(0), at(32 * n)], [at(64 * n), at(64 * n)]) != 0                         # the same output twice
+    assert call([at(0), at(32 * n)], [at(64 * n), at(64 * n + 32)]) != 0                    # outputs overlap partially
+    assert call([at(0)], [at(32)]) != 0                                                    # output inside its input
+    torch.cuda.synchronize()
+
+
 def test_srs_from_device_memory_and_device_side_setup_import():
     torch = _gpu()
     import os

@@ -220,6 +220,34 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal():
     assert one["msm_strong_scaling_2^23"]["result_x"] == x2 and one["msm_strong_scaling_2^23"]["points_per_gpu"] == 1 << 23
 
 
+def test_a_rank_killed_mid_batch_costs_an_error_line_not_the_run():
+    """the two-rank gloo rehearsal again, and rank 1 is killed (SIGKILL) one second into the headline batch
+    (SUMMA_BENCH_FAULT): the launcher ends the surviving rank, whose watchdog prints the error line with what had been
+    measured, and the parent of the bare launch returns non-zero with that ONE JSON line -- within two minutes, not after
+    the process group's (or the driver's) ten."""
+    import json
+    import subprocess
+    import sys
+    import time
+    _gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SUMMA_BENCH_FAULT"] = "1:batch:1.0"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--batch-proofs", "512", "--batch-repeats", "1", "--batch-in-flight", "8", "--no-cpu", "--log-n", "20"],
+                       capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    took = time.time() - t0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["error"] and line["n_gpus"] == 2
+    # the headline steps had been measured before the batch began: the partial results say so
+    part = line.get("partial") or (line.get("rank0_line") or {}).get("partial") or {}
+    assert part.get("value", 0) > 0 and part.get("n_gpus") == 2, line
+    assert took < 240, took          # set-up of two ranks + one second of batch + the launcher's clean-up; never the timeouts
+
+
 def test_two_rank_nccl():
     """the same bare launch with the nccl (= RCCL) backend, one GPU per rank: the first box with two GPUs exercises the
     collectives over xGMI -- the all_gather of partials, the device-to-device setup broadcast, the timing all_reduces --
@@ -341,3 +369,93 @@ def test_commit_combiner_fuses_the_jobs_of_proofs_in_flight():
     finally:
         for s_ in setups:
             s_[1].free()
+
+
+def _small_snapshot(levels, nc, seed):
+    import torch
+    from circuits_halo2_amd import arithmetic as A
+    from circuits_halo2_amd.merkle_sum_tree import DeviceMerkleSumTree
+    from circuits_halo2_amd.utils import random_fr_canonical
+    size = 1 << levels
+    bal = random_fr_canonical(seed, size * nc).reshape(-1, 32).copy()
+    bal[:, 4:] = 0
+    return DeviceMerkleSumTree(A.fr_random(bytes(range(32)), seed, size), A.fr_to_montgomery(torch.from_numpy(bal.reshape(-1)).cuda()), levels, nc)
+
+
+def test_a_failed_fused_job_does_not_fail_its_members():
+    """the commit combiner fuses the commitment jobs of up to sixteen proofs; a fused job that fails as a whole (injected:
+    `debug.fail_next_fused_job` makes the next one report SG_ERR_NOMEM without running) must cost nobody a proof: every
+    member is re-run as a job of its own -- all sixteen proofs come out and verify (batch.py: "one bad witness must not
+    lose the batch"), and the statistics show that members were isolated"""
+    _gpu()
+    import ctypes as C
+    from circuits_halo2_amd import api, batch as B, ffi
+    from oracle import summa_verifier as SV
+    from test_gpu_api import oracle_vk
+    levels, k = 6, 12
+    params, pk, vk = api.generate_setup_artifacts(k, None, api.MstInclusionCircuit.init_empty(levels, 2))
+    try:
+        tree = _small_snapshot(levels, 2, 41)
+        users = list(range(16))
+        B.prove_batch(tree, users, params, pk, levels, in_flight=16, combine=True)          # warm: sessions, lanes
+        j0, r0 = C.c_uint64(0), C.c_uint64(0)
+        ffi.check(ffi.lib().sg_commit_combine_stats(C.byref(j0), C.byref(r0)))
+        ffi.check(ffi.lib().sg_set_param(b"debug.fail_next_fused_job", 1))
+        res = B.prove_batch(tree, users, params, pk, levels, in_flight=16, combine=True)
+        ffi.check(ffi.lib().sg_set_param(b"debug.fail_next_fused_job", 0))
+        assert not res.errors, res.errors
+        assert sorted(res.proofs) == users
+        ovk = oracle_vk(params, vk)
+        assert all(SV.verify(p, i, ovk) for p, i in res.proofs.values())
+        j1, r1 = C.c_uint64(0), C.c_uint64(0)
+        ffi.check(ffi.lib().sg_commit_combine_stats(C.byref(j1), C.byref(r1)))
+        assert r1.value - r0.value == 5 * len(users) and j1.value - j0.value < r1.value - r0.value    # fused as usual around the failure
+    finally:
+        params.free()
+
+
+def test_batches_in_a_long_lived_process_do_not_grow():
+    """the reference's backend is a long-lived server that proves for one snapshot after another
+    (backend/src/apis/round.rs:132-174): three batches of 256 proofs under each of two keys of different size, and
+    afterwards -- keys freed, sg_collect_retired() -- the device has the memory it had before (within 64 MiB) and the
+    process the threads it had after the first batch (worker pools and library sessions are reused, not re-created)"""
+    _gpu()
+    import threading
+    import torch
+    from circuits_halo2_amd import api, batch as B, ffi
+
+    def free_mib():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0] / 2 ** 20
+
+    def os_threads():
+        for ln in open("/proc/self/status"):
+            if ln.startswith("Threads:"):
+                return int(ln.split()[1])
+        return -1
+
+    def one_round(levels, k, seed, batches):
+        params, pk, vk = api.generate_setup_artifacts(k, None, api.MstInclusionCircuit.init_empty(levels, 2))
+        try:
+            tree = _small_snapshot(levels, 2, seed)
+            users = [(37 * i + 5) % (1 << levels) for i in range(256)]
+            for _ in range(batches):
+                res = B.prove_batch(tree, users, params, pk, levels, in_flight=8)
+                assert not res.errors and len(res.proofs) == len(set(users))
+            del tree
+        finally:
+            params.free()
+        del pk, vk
+
+    one_round(6, 12, 51, 1)                      # warm: worker threads, sessions, lanes, plans of both sizes
+    one_round(7, 13, 52, 1)
+    ffi.check(ffi.lib().sg_collect_retired())
+    base_mem, base_py, base_os = free_mib(), threading.active_count(), os_threads()
+    for rnd in range(3):
+        one_round(6, 12, 60 + rnd, 1)
+        one_round(7, 13, 70 + rnd, 1)
+    ffi.check(ffi.lib().sg_collect_retired())
+    mem, py, osn = free_mib(), threading.active_count(), os_threads()
+    assert abs(mem - base_mem) <= 64, (base_mem, mem)
+    assert py == base_py and osn <= base_os + 2, (base_py, py, base_os, osn)

@@ -696,6 +696,51 @@ def test_permutation_grand_product(gpu, O, P, k, ncols):
         assert (got.cpu().numpy() == np.tile(one, n)).all()
 
 
+@pytest.mark.parametrize("k,shape", [(5, ((4, 2), 1)), (11, ((4, 2), 1)), (13, ((3, 3, 1), 2)), (17, ((4, 2), 1)), (9, ((), 2)), (9, ((5,), 0))])
+def test_grand_products_batched(gpu, O, P, k, shape):
+    """sg_grand_products_dev: every grand product of a proof in batched launches -- the chunks of the permutation argument
+    (chunk j continues from chunk j-1's value at the last usable row, on the device) and the lookups, through ONE batch
+    inversion -- equals the oracle's products chained by hand, bit for bit (MstInclusion's shape is ((4, 2), 1))"""
+    from circuits_halo2_amd.arithmetic import grand_products
+    chunks, n_lookups = shape
+    n = 1 << k
+    u = n - 6
+    beta, gamma = O.random_fr(2301 + k, 1), O.random_fr(2302 + k, 1)
+    perm, want_z, col, z0 = [], [], 0, None
+    for j, nc in enumerate(chunks):
+        vals = [O.random_fr(2100 + 100 * k + col + c, n) for c in range(nc)]
+        sig = [O.random_fr(2200 + 100 * k + col + c, n) for c in range(nc)]
+        dstart = fr_np([pow(P.DELTA, col, P.R)])
+        z = O.permutation_product(vals, sig, beta, gamma, dstart, k, z0)
+        want_z.append(z)
+        z0 = z[32 * u:32 * (u + 1)].copy()
+        perm.append(([dev(v) for v in vals], [dev(s_) for s_ in sig]))
+        col += nc
+    lookups, want_l = [], []
+    for l in range(n_lookups):
+        a, s_, ap, sp = (O.random_fr(2400 + 10 * l + i + k, n) for i in range(4))
+        want_l.append(O.lookup_product(a, s_, ap, sp, beta, gamma))
+        lookups.append((dev(a), dev(s_), dev(ap), dev(sp)))
+    got_z, got_l = grand_products(perm, lookups, beta, gamma, k, u)
+    assert len(got_z) == len(chunks) and len(got_l) == n_lookups
+    for got, want in zip(got_z + got_l, want_z + want_l):
+        assert (got.cpu().numpy() == want).all()
+
+
+def test_grand_products_batched_arguments(gpu, O):
+    from circuits_halo2_amd.arithmetic import grand_products
+    k = 6
+    col = lambda seed: dev(O.random_fr(seed, 1 << k))
+    beta, gamma = O.random_fr(1, 1), O.random_fr(2, 1)
+    assert grand_products([], [], beta, gamma, k, 10) == ([], [])
+    with pytest.raises(gpu.SummaGpuError):       # usable rows beyond the domain
+        grand_products([([col(3)], [col(4)])], [], beta, gamma, k, 1 << k)
+    with pytest.raises(gpu.SummaGpuError):       # more than eight products
+        grand_products([([col(3)], [col(4)])] * 9, [], beta, gamma, k, 10)
+    with pytest.raises(gpu.SummaGpuError):       # more than eight columns in a chunk
+        grand_products([([col(3)] * 9, [col(4)] * 9)], [], beta, gamma, k, 10)
+
+
 @pytest.mark.parametrize("n", [16, 2048, 1 << 13, 5000])
 def test_lookup_grand_product(gpu, O, n):
     from circuits_halo2_amd.arithmetic import lookup_product

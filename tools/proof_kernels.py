@@ -9,7 +9,12 @@ rows = sorted(rocpd_rows(src, "kernels"), key=lambda r: r["start"])
 name = lambda r: r["name"].split("(")[0]
 grid = lambda r: int(r["grid_x"]) * int(r["grid_y"]) * int(r["grid_z"])
 starts = []
-for i in range(len(rows) - 3):
+# round 4: the compiled driver runs with sanity checks, whose range check of the advice columns (count_noncanonical_kernel, grid.y = 3)
+# is the FIRST kernel of every proof -- and the blinding rows of phase 3 became a second 256 x 3 launch of fr_random_kernel
+marker = [i for i, r in enumerate(rows) if name(r) == "sg::count_noncanonical_kernel"]
+if len(marker) >= 3:
+    starts = marker
+for i in range(len(rows) - 3 if not starts else 0):
     # round 3: the blinding rows of the three advice columns are ONE launch with grid.y = 3 (sg_fr_random_batch_dev)
     if name(rows[i]) == "sg::fr_random_kernel" and int(rows[i]["grid_y"]) == 3:
         starts.append(i)

@@ -9,7 +9,9 @@ cur.execute("select * from kernels")
 names = [d[0] for d in cur.description]
 rows = sorted((dict(zip(names, r)) for r in cur.fetchall()), key=lambda r: r["start"])
 short = lambda n: n.split("(")[0].replace("void ", "").replace("sg::", "")
-starts = [i for i, r in enumerate(rows) if short(r["name"]) == "fr_random_kernel" and int(r["grid_y"]) == 3]
+starts = [i for i, r in enumerate(rows) if short(r["name"]) == "count_noncanonical_kernel"]      # first kernel of a proof (sanity checks on)
+if len(starts) < 3:
+    starts = [i for i, r in enumerate(rows) if short(r["name"]) == "fr_random_kernel" and int(r["grid_y"]) == 3]   # traces of round 3
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 seg = rows[starts[-which - 1]:starts[-which]]
 t0 = seg[0]["start"]
