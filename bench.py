@@ -271,6 +271,52 @@ def proof_roofline(ms, what):
                            "the kernels behind it are integer-VALU-bound (see `alu`), the fraction says how far the whole proof is from a pure stream"}
 
 
+def host_pointer_extra(scal, bases, want):
+    """sg_msm_g1 / sg_commit / sg_ntt_fr at 2^20 with every argument in pageable host memory (numpy), timed around the C call
+    itself: the link is inside the figure (96 MiB, 32 MiB, 32 MiB each way)"""
+    import torch
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi
+    L = sg.lib()
+    n = 1 << 20
+    hs, hb = scal[:32 * n].cpu().numpy().copy(), bases[:64 * n].cpu().numpy().copy()
+    res = np.zeros(64, dtype=np.uint8)
+    p_s, p_b, p_r = (C.c_void_p(x.ctypes.data) for x in (hs, hb, res))
+
+    def best(fn, reps=6):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts)
+    out = {"log_n": 20, "memory": "pageable (numpy)"}
+    out["sg_msm_g1_ms"] = best(lambda: ffi.check(L.sg_msm_g1(p_s, p_b, C.c_size_t(n), p_r)))
+    out["sg_msm_g1_matches"] = bool((res == want).all()) if scal.numel() == 32 * n else None
+    params = sg.ParamsKZG(20, hb, hb)
+    try:
+        h = C.c_uint64(params.handle())
+        out["sg_commit_ms"] = best(lambda: ffi.check(L.sg_commit(h, C.c_int(0), p_s, C.c_size_t(n), p_r)))
+        out["sg_commit_matches"] = bool((res == want).all()) if scal.numel() == 32 * n else None
+    finally:
+        params.free()
+    w = ffi.u8(sg.EvaluationDomain(2, 20).get_omega())
+    ha = hs.copy()
+    p_a = C.c_void_p(ha.ctypes.data)
+    out["sg_ntt_fr_ms"] = best(lambda: ffi.check(L.sg_ntt_fr(p_a, ffi.ptr(w), C.c_uint32(20))))
+    tp, dev = torch.from_numpy(hb), torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+
+    def h2d():
+        dev.copy_(tp, non_blocking=True)
+        torch.cuda.synchronize()
+    out["h2d_pageable_GBs"] = 64 * n / best(h2d) / 1e6
+    out["note"] = ("PCIe-inclusive wall clock of the C call, best of 6, inputs in pageable host memory: sg_msm_g1 moves 96 MiB (two halves on two "
+                   "streams, the first half's MSM under the second half's upload), sg_commit 32 MiB against the resident SRS, sg_ntt_fr 32 MiB each way; "
+                   "h2d_pageable_GBs is the plain copy rate of this box (page-locked memory is no faster here, so there is no staging layer to add)")
+    return out
+
+
 def host_cpu_info():
     """what the process may use of the host: the affinity mask, and the CPU quota of its control group when one is set
     (cgroup v2 `cpu.max`, v1 `cfs_quota_us`): on the boxes of this pool the mask is the whole machine, the quota is not"""
@@ -380,7 +426,7 @@ def batch_extra(args, rank, world, coll_dev):
     # of the pre-sweep runs the headline batch
     sweep = {}
     per = max(6 * world, min(96 * world, total // 4))
-    candidates = sorted({max(1, args.batch_in_flight // 2), args.batch_in_flight}) if args.batch_in_flight > 0 else (1, 2, 4, 8, 12, 16, 24, 32)
+    candidates = sorted({max(1, args.batch_in_flight // 2), args.batch_in_flight}) if args.batch_in_flight > 0 else (1, 2, 4, 8, 16, 24, 32, 48)
     for in_flight in candidates:
         timed_batch(users[:3 * in_flight * world], in_flight)
         done, errs, dt, _, _ = timed_batch(users[:min(total, max(per, 6 * in_flight * world))], in_flight)
@@ -1076,6 +1122,13 @@ def _main():
             except Exception as ex:
                 line["extras_error"] = repr(ex)
 
+        # ---- the host-pointer entry points: what a [patch] of best_multiexp / best_fft in an unmodified halo2 calls
+        # (INTEGRATION.md section 2).  PCIe-inclusive, from ordinary pageable memory, in place through ctypes; never `value`
+        if not args.no_extras and not args.strong_only and world == 1 and args.log_n >= 20:
+            try:
+                line["host_pointer_entry_points"] = host_pointer_extra(scal, bases, result)
+            except Exception as ex:
+                line["host_pointer_entry_points"] = {"error": repr(ex)}
         # ---- CPU baseline for the NTT numbers above (same oracle, same box)
         if not args.no_cpu and world == 1 and "ntt" in line:
             from oracle import oracle as O

@@ -297,6 +297,13 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         # process-wide tunables of the combiner, for the length of this batch (restored to the library's defaults below)
         ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(in_flight)))
         ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 5000))
+    # with several proofs in flight most worker threads are waiting for the device most of the time: they poll and SLEEP
+    # (sg_set_param "host.wait_sleep_us") instead of polling and yielding -- the same proofs per second on a whole host, a
+    # fifth more on a 1/8 share of it (what a rank gets when eight share a node), 13 -> 8 ms of CPU per proof
+    # (profiles/r04_sweeps/batch_wait_modes.txt).  A lone proof keeps the runtime's wait: its dozen waits are on its critical path
+    naps = prove is None and in_flight >= 4 and os.environ.get("SUMMA_WAIT_SLEEP_US", "50") != "0"
+    if naps:
+        ffi.check(ffi.lib().sg_set_param(b"host.wait_sleep_us", int(os.environ.get("SUMMA_WAIT_SLEEP_US", "50"))))
     mine = deal(list(user_indices))
     res = BatchResult()
     ahead = None
@@ -351,6 +358,8 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     finally:
         if ahead is not None:
             ahead.close()
+        if naps:
+            ffi.check(ffi.lib().sg_set_param(b"host.wait_sleep_us", 0))
         if combine:     # the library's defaults (include/summa_gpu.h, sg_set_param): a later caller's lone proofs do not wait 5 ms for company
             ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", 4))
             ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 300))

@@ -1,0 +1,50 @@
+// How a host thread waits for the device (shared by every translation unit of the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <sys/prctl.h>
+#include <time.h>
+
+#include <atomic>
+
+namespace sg {
+
+// 0 (default): the HIP runtime's own wait -- hipEventSynchronize / hipStreamSynchronize, which on ROCm poll and yield:
+// the lowest latency, and one busy CPU per waiting thread.  > 0 ("host.wait_sleep_us"): the thread polls the event /
+// stream every that many microseconds and SLEEPS in between.  A lone proof wants the first (a dozen waits per proof, each
+// on its critical path); a batch with sixteen to thirty-two proofs in flight wants the second: its threads wait most of
+// the time, thirty yielding pollers eat the process's CPU quota (on the boxes of this pool: 16 cores under a 256-CPU
+// mask, and eight ranks of one node share such a quota), and a few tens of microseconds of wake-up latency cost a proof
+// that is in flight for a hundred milliseconds nothing (bench.py --cpu-share).
+inline std::atomic<int>& host_wait_sleep_us() {
+  static std::atomic<int> v{0};
+  return v;
+}
+inline void host_wait_nap(int us) {
+  static thread_local bool slack_set = false;
+  if (!slack_set) {   // the default timer slack of 50 us would be added to every nap
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    slack_set = true;
+  }
+  struct timespec ts = {0, (long)us * 1000L};
+  (void)nanosleep(&ts, nullptr);
+}
+inline hipError_t host_wait_event(hipEvent_t e) {
+  const int us = host_wait_sleep_us().load(std::memory_order_relaxed);
+  if (us <= 0) return hipEventSynchronize(e);
+  for (;;) {
+    const hipError_t q = hipEventQuery(e);
+    if (q != hipErrorNotReady) return q;
+    host_wait_nap(us);
+  }
+}
+inline hipError_t host_wait_stream(hipStream_t s) {
+  const int us = host_wait_sleep_us().load(std::memory_order_relaxed);
+  if (us <= 0) return hipStreamSynchronize(s);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q;
+    host_wait_nap(us);
+  }
+}
+
+}  // namespace sg

@@ -26,6 +26,7 @@
 // bucket's points are added (LDS atomics make it non-deterministic) never changes the result bits.
 #include "msm.h"
 #include "side_prio.cuh"
+#include "host_wait.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1161,7 +1162,7 @@ hipError_t g1_prefix_sums(const g1_affine_mem* d_in, size_t n, g1_affine_mem* d_
     g1_prefix_apply<<<grid(size[l]), 128, 0, stream>>>(lvl[l], (uint32_t)size[l], lvl[l + 1]);
   g1_prefix_store<<<grid(n), 128, 0, stream>>>(lvl[0], (uint32_t)n, size.size() > 1 ? lvl[1] : nullptr, d_out);
   e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = host_wait_stream(stream);
   (void)hipFree(work);
   return e;
 }
@@ -1657,7 +1658,7 @@ hipError_t MsmEngine::enqueue_back_impl() {
     msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
                                           meta_.p + ACC_TICKET, partial_[0].p);
   }));
-  SG_TRY(hipEventSynchronize(ev_meta_));
+  SG_TRY(host_wait_event(ev_meta_));
   const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_blocks / msm_scan_small), complete with the event
   const uint32_t ntasks = j.ntasks = hm[1], max_cnt = j.max_cnt = hm[2];
   if (!ntasks) {  // every digit was zero (the launches above found nothing to do)
@@ -1810,7 +1811,7 @@ hipError_t MsmEngine::finish_impl() {
     drop_events();
     return hipSuccess;
   }
-  SG_TRY(hipEventSynchronize(ev_done_));
+  SG_TRY(host_wait_event(ev_done_));
   // window_j = A + 2^log_G (S + 2^log_N T); then Horner over the windows, high to low
   using namespace host;
   auto point_at = [&](uint32_t q) {

@@ -15,6 +15,7 @@
 // HBM traffic per pass: 32 B read + 32 B write per element (+32 B twiddle on twiddled
 // passes).  Arithmetic: (n/2) log2 n Montgomery products + one per element per twiddled pass.
 #include "ntt.h"
+#include "host_wait.h"
 #include "side_prio.cuh"
 
 #include <algorithm>
@@ -323,7 +324,7 @@ hipError_t NttEngine::local_twiddles(const words8& omega_r, uint32_t log_r, hipS
   if (err != hipSuccess) return err;
   fill_powers<<<(count + 255) / 256, 256, 0, stream>>>(d, omega_r, count);
   err = hipGetLastError();
-  if (err == hipSuccess) err = hipStreamSynchronize(stream);  // complete before any other stream may use the cached table
+  if (err == hipSuccess) err = host_wait_stream(stream);  // complete before any other stream may use the cached table
   if (err != hipSuccess) {
     retire_device_memory(d);
     return err;
@@ -377,7 +378,7 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8
     // fill_powers computes w^k; k = 2^times fits 32 bits (times <= 28)
     pow_single<<<1, 1, 0, stream>>>(d, omega, 1ull << times);
     e = hipMemcpyAsync(res, d, sizeof(fp_words), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = host_wait_stream(stream);
     retire_device_memory(d);   // a few bytes per plan; hipFree would wait for every other stream of the device
     return e;
   };
@@ -407,7 +408,7 @@ hipError_t NttEngine::get_plan(uint32_t log_n, const words8& omega, const words8
   err = hipGetLastError();
   if (err != hipSuccess) return err;
   // tables must be complete before any other stream may use the cached plan
-  err = hipStreamSynchronize(stream);
+  err = host_wait_stream(stream);
   if (err != hipSuccess) return err;
   plans_.push_back(pl);
   *out = &plans_.back();

@@ -29,6 +29,43 @@ Graph copy_graph(const sg_graph& g) {
   out.parts.assign(g.horner_parts, g.horner_parts + g.n_horner_parts);
   return out;
 }
+// what sp_key_create can see of the constraint-system shape from its arguments (include/summa_prover.h lists the rest):
+// every value source of a program names an existing column / constant / earlier intermediate, its rotation is one of
+// -1, 0, +1 (the multi-open's rotation sets are fixed), the instance column is read at rotation 0 only
+const char* graph_shape_error(const sg_graph& g, uint32_t n_challenges) {
+  for (uint32_t r = 0; r < g.n_rotations; r++)
+    if (g.rotations[r] < -1 || g.rotations[r] > 1) return "a rotation beyond -1 / 0 / +1";
+  auto bad = [&](const sg_value_source& v, uint32_t self) -> const char* {
+    switch (v.kind) {
+      case SG_VS_CONSTANT: return v.index < g.n_constants ? nullptr : "a constant index out of range";
+      case SG_VS_INTERMEDIATE: return v.index < self ? nullptr : "an intermediate that is not defined yet";
+      case SG_VS_FIXED: case SG_VS_ADVICE: case SG_VS_INSTANCE: {
+        const uint32_t lim = v.kind == SG_VS_FIXED ? NUM_FIXED : v.kind == SG_VS_ADVICE ? NUM_ADVICE : 1u;
+        if (v.index >= lim) return "a column index beyond this constraint system's 11 fixed / 3 advice / 1 instance columns";
+        if (v.rotation >= g.n_rotations) return "a rotation index out of range";
+        if (v.kind == SG_VS_INSTANCE && g.rotations[v.rotation] != 0) return "the instance column read at a rotation";
+        return nullptr;
+      }
+      case SG_VS_CHALLENGE: return v.index < n_challenges ? nullptr : "a challenge index out of range";
+      case SG_VS_BETA: case SG_VS_GAMMA: case SG_VS_THETA: case SG_VS_Y: case SG_VS_PREVIOUS_VALUE: return nullptr;
+      default: return "an unknown value source";
+    }
+  };
+  for (uint32_t i = 0; i < g.n_calculations; i++) {
+    const sg_calculation& c = g.calculations[i];
+    if (c.op > SG_OP_STORE) return "an unknown calculation";
+    if (const char* e = bad(c.a, i)) return e;
+    const bool binary = c.op == SG_OP_ADD || c.op == SG_OP_SUB || c.op == SG_OP_MUL || c.op == SG_OP_HORNER;
+    if (binary)
+      if (const char* e = bad(c.b, i)) return e;
+    if (c.op == SG_OP_HORNER) {
+      if ((uint64_t)c.parts_offset + c.parts_len > g.n_horner_parts || (c.parts_len && !g.horner_parts)) return "Horner parts out of range";
+      for (uint32_t q = 0; q < c.parts_len; q++)
+        if (const char* e = bad(g.horner_parts[c.parts_offset + q], i)) return e;
+    }
+  }
+  return nullptr;
+}
 template <class F>
 int guarded(F&& body) {
   try {
@@ -64,6 +101,16 @@ int sp_key_create(uint32_t k, uint64_t srs_handle, const void* const* d_fixed_la
   if ((gates->n_constants && !gates->constants) || (gates->n_calculations && !gates->calculations) ||
       (lookup_input->n_calculations && !lookup_input->calculations))
     return sp_fail(SG_ERR_INVALID, "sp_key_create: malformed program");
+  if ((gates->n_rotations && !gates->rotations) || (lookup_input->n_rotations && !lookup_input->rotations) ||
+      (lookup_input->n_constants && !lookup_input->constants))
+    return sp_fail(SG_ERR_INVALID, "sp_key_create: malformed program");
+  for (const sg_graph* g : {gates, lookup_input}) {
+    if (const char* why = graph_shape_error(*g, g == gates ? n_gate_challenges : 0u)) {
+      std::snprintf(g_sp_err, sizeof g_sp_err, "sp_key_create: the %s program does not fit this prover's constraint-system shape: %s",
+                    g == gates ? "gate" : "lookup-input", why);
+      return SG_ERR_INVALID;
+    }
+  }
   return guarded([&]() {
     if (sg_bind_thread() != SG_OK) throw std::runtime_error(sg_last_error());   // this thread's own HIP calls: the library's device
     StreamScope scope(static_cast<hipStream_t>(stream));

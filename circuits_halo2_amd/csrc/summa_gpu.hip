@@ -30,6 +30,7 @@
 #include "poly.h"
 #include "witness.h"
 #include "side_prio.cuh"
+#include "host_wait.h"
 
 using namespace sg;
 namespace sg {
@@ -365,7 +366,7 @@ int get_consts(uint32_t k, const DomainConsts** out) {
     domain_kernel<<<1, 1, 0, c.stream>>>(k, c.d_consts);
     DomainConsts h;
     CHECK_HIP(hipMemcpyAsync(&h, c.d_consts, sizeof h, hipMemcpyDeviceToHost, c.stream), "domain constants");
-    CHECK_HIP(hipStreamSynchronize(c.stream), "domain constants");
+    CHECK_HIP(host_wait_stream(c.stream), "domain constants");
     it = c.consts.emplace(k, h).first;
   }
   *out = &it->second;
@@ -379,7 +380,7 @@ hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 // order the library's own stream work (plan/twiddle generation) before a caller stream
 int sync_own_stream_into(hipStream_t s) {
   if (s == g_ctx->stream) return SG_OK;
-  CHECK_HIP(hipStreamSynchronize(g_ctx->stream), "stream sync");
+  CHECK_HIP(host_wait_stream(g_ctx->stream), "stream sync");
   return SG_OK;
 }
 
@@ -415,7 +416,7 @@ int upload(DevBuf<uint8_t>& buf, const uint8_t* host, size_t bytes, hipStream_t 
 }
 int download(uint8_t* host, const void* dev, size_t bytes, hipStream_t s) {
   CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s), "D2H copy");
-  CHECK_HIP(hipStreamSynchronize(s), "stream sync");
+  CHECK_HIP(host_wait_stream(s), "stream sync");
   return SG_OK;
 }
 
@@ -598,6 +599,12 @@ int sg_host_unregister(void* host) {
   return SG_OK;
 }
 
+int sg_stream_wait(void* stream) {
+  const hipError_t e = host_wait_stream(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("sg_stream_wait", e);
+  return SG_OK;
+}
+
 int sg_collect_retired(void) {
   if (g_depth > 0) return fail(SG_ERR_INVALID, "sg_collect_retired: not from inside a call");
   int device;
@@ -612,6 +619,14 @@ int sg_collect_retired(void) {
   if (e == hipSuccess) {
     retired_device_memory_collect();
     summa::prover::release_orphans();
+    // the lanes' own work spaces too (MSM buckets and sort buffers, NTT plans and twiddle tables, staging, scratch): which
+    // lane met the largest job of the last workload is a matter of timing, so "what the library holds" would otherwise
+    // creep up to lanes x the largest work space over a long-lived process.  They are rebuilt by the next call that
+    // needs them (milliseconds); the lanes' main streams, the SRS cache and the proving keys stay.
+    for (auto& l : g_lanes) {
+      if (l.ctx) destroy_context(l.ctx);
+      l.ctx = nullptr;
+    }
   }
   for (auto& l : g_lanes) l.mu.unlock();
   if (e != hipSuccess) return hip_fail("sg_collect_retired", e);
@@ -652,39 +667,63 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
 int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]) {
   return sg_msm_g1_dev_timed(d_scalars, d_bases, n, stream, out_affine, nullptr);
 }
+// sg_msm_g1 hands over host buffers: 96 bytes per pair have to cross the link (1.8 ms for 2^20 pairs at the 56 GB/s this
+// platform reaches from pageable memory just as from page-locked memory) before the last addition can run.  Large inputs
+// are therefore cut in two halves on two streams with the two engines of the lane: half A's MSM runs while half B is
+// still travelling, and the call costs about the upload plus ONE half's MSM instead of the upload plus the whole.
+// The copies of the second half are interleaved with the phases of the first so that the host's waits fall where the
+// device has work: [A up] front(A) [B scalars up] back(A) [B bases up] front(B) back(B) finish(A) finish(B), then A + B.
+static constexpr size_t MSM_HOST_SPLIT_MIN = (size_t)1 << 18;
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && (!scalars || !bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
   {
     LOCKED_CTX();
     Context& c = *g_ctx;
-    // The scalars travel first and the digit / sort front-end starts behind them; the bases (twice the bytes) travel on a
-    // second stream meanwhile and only the accumulation waits for them.  From page-locked or registered memory
-    // (sg_host_register) both copies are direct DMA; from pageable memory the runtime stages them and the call blocks
-    // in the copy, with the front-end already running on the device.
-    TRY(upload(c.stage_a, scalars, n * 32, c.stream));
-    hipError_t e = c.stage_b.reserve(n ? n * 64 : 1);
+    hipError_t e = c.stage_a.reserve(n ? n * 32 : 1);
+    if (e == hipSuccess) e = c.stage_b.reserve(n ? n * 64 : 1);
     if (e != hipSuccess) return hip_fail("staging buffer", e);
-    if (!n) {
-      e = c.msm.run(reinterpret_cast<const fp_words*>(c.stage_a.p), reinterpret_cast<const g1_affine_mem*>(c.stage_b.p), 0, c.stream,
-                    out_affine, nullptr);
+    const fp_words* d_s = reinterpret_cast<const fp_words*>(c.stage_a.p);
+    const g1_affine_mem* d_b = reinterpret_cast<const g1_affine_mem*>(c.stage_b.p);
+    if (n < MSM_HOST_SPLIT_MIN) {
+      if (n) {
+        CHECK_HIP(hipMemcpyAsync(c.stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream), "H2D copy");
+        CHECK_HIP(hipMemcpyAsync(c.stage_b.p, bases, n * 64, hipMemcpyHostToDevice, c.stream), "H2D copy");
+      }
+      e = c.msm.run(d_s, d_b, n, c.stream, out_affine, nullptr);
       if (e != hipSuccess) return hip_fail("msm", e);
       return SG_OK;
     }
-    hipStream_t side = c.bstream[0];
-    CHECK_HIP(hipEventRecord(c.ev_in, c.stream), "event");          // the staging buffer may still be read by the stream's earlier work
-    CHECK_HIP(hipStreamWaitEvent(side, c.ev_in, 0), "stream wait");
-    e = c.msm.enqueue_front(reinterpret_cast<const fp_words*>(c.stage_a.p), reinterpret_cast<const g1_affine_mem*>(c.stage_b.p), n, c.stream,
-                            out_affine, nullptr);
+    const size_t h = n / 2, r = n - h;
+    hipStream_t sa = c.stream, sb = c.bstream[0];
+    uint8_t part[128];
+    // the staging buffers may still be read by earlier work of the lane's stream: the second stream starts behind it
+    CHECK_HIP(hipEventRecord(c.ev_in, sa), "event");
+    CHECK_HIP(hipStreamWaitEvent(sb, c.ev_in, 0), "stream wait");
+    hipError_t ce = hipMemcpyAsync(c.stage_a.p, scalars, h * 32, hipMemcpyHostToDevice, sa);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(c.stage_b.p, bases, h * 64, hipMemcpyHostToDevice, sa);
+    if (ce != hipSuccess) return hip_fail("H2D copy", ce);
+    e = c.msm.enqueue_front(d_s, d_b, h, sa, part, nullptr);
     if (e != hipSuccess) return hip_fail("msm", e);
-    hipError_t ce = hipMemcpyAsync(c.stage_b.p, bases, n * 64, hipMemcpyHostToDevice, side);
-    if (ce == hipSuccess) ce = hipEventRecord(c.ev_in, side);
-    if (ce == hipSuccess) ce = hipStreamWaitEvent(c.stream, c.ev_in, 0);
-    e = c.msm.enqueue_back();                 // (always: the engine's job is closed in order, whatever the copy did)
+    // from here on both engines' jobs are closed in order whatever a copy does (an engine left with an open job would
+    // poison the lane's next call)
+    ce = hipMemcpyAsync(c.stage_a.p + h * 32, scalars + h * 32, r * 32, hipMemcpyHostToDevice, sb);
+    e = c.msm.enqueue_back();
+    if (ce == hipSuccess) ce = hipMemcpyAsync(c.stage_b.p + h * 64, bases + h * 64, r * 64, hipMemcpyHostToDevice, sb);
+    hipError_t e2 = hipSuccess;
+    bool b_open = false;
+    if (ce == hipSuccess && e == hipSuccess) {
+      e2 = c.msm_b.enqueue_front(d_s + h, d_b + h, r, sb, part + 64, nullptr);
+      b_open = e2 == hipSuccess;
+      if (b_open) e2 = c.msm_b.enqueue_back();
+    }
     if (e == hipSuccess) e = c.msm.finish();
+    if (b_open && e2 == hipSuccess) e2 = c.msm_b.finish();
+    else if (b_open) (void)c.msm_b.finish();
     if (ce != hipSuccess) return hip_fail("H2D copy", ce);
     if (e != hipSuccess) return hip_fail("msm", e);
+    if (e2 != hipSuccess) return hip_fail("msm", e2);
+    return sg_g1_sum_affine(part, 2, out_affine);
   }
-  return SG_OK;
 }
 
 // A batch of independent MSMs (the commitments of one prover phase): two engines on two
@@ -836,7 +875,7 @@ int sg_srs_upload_dev(uint32_t k, const void* d_g, const void* d_g_lagrange, voi
   if (e == hipSuccess) e = hipMalloc(&s.g_lagrange, bytes);
   if (e == hipSuccess) e = hipMemcpyAsync(s.g, d_g, bytes, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(s.g_lagrange, d_g_lagrange, bytes, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);   // the bases are read from other streams afterwards
+  if (e == hipSuccess) e = host_wait_stream(st);   // the bases are read from other streams afterwards
   if (e != hipSuccess) {
     if (s.g) (void)hipFree(s.g);
     if (s.g_lagrange) (void)hipFree(s.g_lagrange);
@@ -877,7 +916,7 @@ int sg_srs_check(uint64_t handle, uint64_t* bad_out) {
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
     e = g1_on_curve(b ? srs_p->g_lagrange : srs_p->g, n, reinterpret_cast<uint32_t*>(cnt), s);
     if (e == hipSuccess) e = hipMemcpyAsync(&h[b], cnt, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = host_wait_stream(s);
   }
   if (e != hipSuccess) return hip_fail("sg_srs_check", e);
   *bad_out = (uint64_t)h[0] + h[1];
@@ -926,7 +965,7 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits) {
   }
   FixedTable t;
   e = build_window_table(basis == 2 ? s.lagrange_prefix : basis ? s.g_lagrange : s.g, n, c, &t, g_ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g_ctx->stream);
+  if (e == hipSuccess) e = host_wait_stream(g_ctx->stream);
   if (e != hipSuccess) {
     if (new_prefix) (void)hipFree(new_prefix);
     return hip_fail("sg_srs_precompute", e);
@@ -1323,7 +1362,7 @@ int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32],
     hipError_t e = c.ntt.transform(a, n, a, scratch, log_n, w, divisor ? &dv : nullptr, nullptr, nullptr, c.bstream[k]);
     if (e != hipSuccess) return hip_fail("ntt batch", e);
   }
-  for (auto& bs : c.bstream) CHECK_HIP(hipStreamSynchronize(bs), "stream sync");
+  for (auto& bs : c.bstream) CHECK_HIP(host_wait_stream(bs), "stream sync");
   return SG_OK;
 }
 
@@ -1553,7 +1592,7 @@ static int coset_tables_for(uint32_t k, uint32_t ext_k, uint32_t nc, const Conte
     CHECK_HIP(hipMalloc(&t.inv, sizeof(fp_words) * n * nc), "coset tables");
     hipError_t e = coset_fill_powers(t.fwd, t.shift, nc, k, c.stream);
     if (e == hipSuccess) e = coset_fill_powers(t.inv, inv_shift, nc, k, c.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e == hipSuccess) e = host_wait_stream(c.stream);
     if (e != hipSuccess) return hip_fail("coset tables", e);
     it = c.coset_tables.emplace(key, t).first;
   }
@@ -1658,7 +1697,7 @@ static int t_eval_table(uint32_t k, uint32_t ext_k, const fp_words** out) {
     fp_words* d = nullptr;
     CHECK_HIP(hipMalloc(&d, sizeof(fp_words) * cnt), "t_evaluations");
     t_eval_kernel<<<(cnt + 63) / 64, 64, 0, c.stream>>>(k, ext_k, dc->omega, d);
-    CHECK_HIP(hipStreamSynchronize(c.stream), "t_evaluations");
+    CHECK_HIP(host_wait_stream(c.stream), "t_evaluations");
     it = c.t_evals.emplace(key, d).first;
   }
   *out = it->second;
@@ -1805,7 +1844,7 @@ int sg_kzg_setup_dev(uint32_t k, const uint8_t tau[32], void* d_g, void* d_g_lag
   kzg_setup_scalars<<<(unsigned)((n + 127) / 128), 128, 0, s>>>(k, t, pw, lg);
   e = fixed_base_mul(pw, n, static_cast<g1_affine_mem*>(d_g), s);
   if (e == hipSuccess) e = fixed_base_mul(lg, n, static_cast<g1_affine_mem*>(d_g_lagrange), s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // staging buffers are reused by later calls
+  if (e == hipSuccess) e = host_wait_stream(s);  // staging buffers are reused by later calls
   if (e != hipSuccess) return hip_fail("kzg_setup", e);
   return SG_OK;
 }
@@ -1845,7 +1884,7 @@ int sg_g1_fft_dev(const void* d_in, void* d_out, const uint8_t omega[32], const 
   if (scale) std::memcpy(&sc, scale, 32);
   e = g1_fft(static_cast<const g1_affine_mem*>(d_in), static_cast<g1_affine_mem*>(d_out), log_n, w,
              scale ? &sc : nullptr, reinterpret_cast<xyzz29_mem*>(g_ctx->scratch.p), pick_stream(stream));
-  if (e == hipSuccess) e = hipStreamSynchronize(pick_stream(stream));  // scratch is shared with the NTT engine
+  if (e == hipSuccess) e = host_wait_stream(pick_stream(stream));  // scratch is shared with the NTT engine
   if (e != hipSuccess) return hip_fail("g1 fft", e);
   return SG_OK;
 }
@@ -1863,7 +1902,7 @@ int sg_g1_to_lagrange(const uint8_t* g, uint32_t k, uint8_t* g_lagrange) {
     TRY(upload(g_ctx->stage_a, g, bytes, g_ctx->stream));
     hipError_t e = g_ctx->stage_b.reserve(bytes);
     if (e != hipSuccess) return hip_fail("staging buffer", e);
-    CHECK_HIP(hipStreamSynchronize(g_ctx->stream), "stream sync");
+    CHECK_HIP(host_wait_stream(g_ctx->stream), "stream sync");
   }
   int rc = sg_g1_fft_dev(g_ctx->stage_a.p, g_ctx->stage_b.p, reinterpret_cast<const uint8_t*>(&wi),
                          reinterpret_cast<const uint8_t*>(&ni), k, g_ctx->stream);
@@ -1895,7 +1934,7 @@ int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t
   if (e == hipSuccess) e = fr_montgomery(ps, ps, rows, 1, s);
   uint32_t h_flag = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag, sizeof h_flag, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = host_wait_stream(s);
   if (e != hipSuccess) return hip_fail("lookup permutation", e);
   if (h_flag == 2) return fail(SG_ERR_UNSUPPORTED, "sg_lookup_permute_small: a table value is not below 2^16 (use the general path)");
   if (h_flag == 1) return fail(SG_ERR_WITNESS, "sg_lookup_permute_small: an input value is not in the table");
@@ -2170,7 +2209,7 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
   // asynchronous unless the caller wants the remainder on the host
   if (e == hipSuccess && remainder_out) {
     e = hipMemcpyAsync(remainder_out, tmp + 1024, 32, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = host_wait_stream(s);
   }
   if (e != hipSuccess) return hip_fail("kate_division", e);
   return SG_OK;
@@ -2212,7 +2251,7 @@ int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_
                                h_pw.data(), d_pw, reinterpret_cast<fp_words*>(d_tmp), s);
   // h_pw is a local: the (pageable) upload has been staged by the time hipMemcpyAsync returns only if it was synchronous;
   // make sure before the buffer dies
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = host_wait_stream(s);
   if (e != hipSuccess) return hip_fail("kate_division_batch", e);
   return SG_OK;
 }
@@ -2456,7 +2495,7 @@ static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void
   Context::BlobSlot& slot = g_ctx->blob_ring[g_ctx->blob_next++ % Context::BLOB_RING];
   hipError_t e = hipSuccess;
   if (!slot.ev) e = hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming);
-  else if (hipEventQuery(slot.ev) != hipSuccess) e = hipEventSynchronize(slot.ev);   // (a query first: waiting on an event that
+  else if (hipEventQuery(slot.ev) != hipSuccess) e = host_wait_event(slot.ev);   // (a query first: waiting on an event that
                                                                                      // has long completed still costs a wake-up, 0.3 ms)
   if (e == hipSuccess && slot.cap < bytes) {
     // (never small: the ring rotates, and a slot sized by a small program would be re-allocated -- two allocations, 0.25 ms
@@ -2647,6 +2686,10 @@ int sg_set_param(const char* name, int value) {
     g_comb.target.store(std::max(1, std::min(value, 32)));
     return SG_OK;
   }
+  if (s == "host.wait_sleep_us") {   // how host threads wait for the device (csrc/host_wait.h): 0 = the runtime's wait, > 0 = poll and sleep
+    host_wait_sleep_us().store(std::min(value, 1000));
+    return SG_OK;
+  }
   if (s == "debug.fail_next_fused_job") {
     g_comb.fail_next.store(value ? 1 : 0);
     return SG_OK;
@@ -2690,7 +2733,7 @@ int sg_time_ntt_dev(void* d_a, uint32_t log_n, int reps, float* ms_out) {
   CHECK_HIP(hipEventRecord(e0, s), "event");
   for (int r = 0; r < reps; r++) TRY(ntt_dev(a, (size_t)1 << log_n, a, log_n, dc->omega, nullptr, nullptr, nullptr, s));
   CHECK_HIP(hipEventRecord(e1, s), "event");
-  CHECK_HIP(hipEventSynchronize(e1), "event");
+  CHECK_HIP(host_wait_event(e1), "event");
   float ms = 0;
   CHECK_HIP(hipEventElapsedTime(&ms, e0, e1), "event");
   (void)hipEventDestroy(e0);

@@ -7,6 +7,7 @@
 // added to state[0] and followed by one permutation; the output is state[0].
 // One thread per hash; 472-ish Fr products per permutation, so the kernels are VALU-bound.
 #include "witness.h"
+#include "host_wait.h"
 #include "side_prio.cuh"
 
 #include "poseidon_constants.inc"
@@ -287,7 +288,7 @@ hipError_t WitnessEngine::init(hipStream_t stream) {
   if (e == hipSuccess) e = hipMemcpyAsync(d_mds, POSEIDON_MDS, sizeof(POSEIDON_MDS), hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) {
     poseidon_table_kernel<<<2, 128, 0, stream>>>(d_rc, d_mds, static_cast<PoseidonTable*>(table_));
-    e = hipStreamSynchronize(stream);
+    e = host_wait_stream(stream);
   }
   retire_device_memory(d_rc);
   retire_device_memory(d_mds);

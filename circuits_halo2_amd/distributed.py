@@ -1,7 +1,9 @@
 """Multi-GPU sharding of the path: one process per GPU, torch.distributed.
 
-* op-level: independent MSMs/NTTs (the 16 + 19 of a proof, or whole proofs of a batch) are
-  dealt round-robin to ranks -- no data-path communication (`assign_ops`).
+* proof-level: whole proofs of a batch are dealt round-robin to ranks -- no data-path
+  communication (`batch.deal`).  The 16 MSMs + 19 NTTs of ONE proof are not spread over GPUs:
+  DESIGN.md section 5 counts what that would move (under 0.5 ms of a 5.7 ms proof on two GPUs,
+  against a second whole proof on the second GPU).
 * point-level: one large MSM is cut into contiguous shards; every rank reduces its shard and
   the 64-byte affine partials are exchanged with ONE all_gather (EC addition is not an RCCL
   reduction operator, so the "all-reduce" is all_gather + a local sum of world_size points,
@@ -21,16 +23,6 @@ _ONE_FR = np.frombuffer((0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac963
 def _dist():
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
-
-
-def assign_ops(num_ops: int, rank: int | None = None, world: int | None = None):
-    """indices of the independent ops this rank owns (round-robin)"""
-    d = _dist()
-    if rank is None:
-        rank = d.get_rank() if d else 0
-    if world is None:
-        world = d.get_world_size() if d else 1
-    return list(range(rank, num_ops, world))
 
 
 def shard_bounds(n: int, rank: int, world: int):

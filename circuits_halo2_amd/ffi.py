@@ -16,7 +16,7 @@ _LIB = None
 
 SG_OK = 0
 EXPORTS = [
-    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_host_register", "sg_host_unregister", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
+    "sg_init", "sg_shutdown", "sg_collect_retired", "sg_host_register", "sg_host_unregister", "sg_stream_wait", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
     "sg_msm_g1", "sg_msm_g1_dev", "sg_msm_g1_batch", "sg_msm_g1_batch_dev", "sg_g1_sum_affine", "sg_srs_upload", "sg_srs_upload_dev", "sg_srs_copy_dev", "sg_srs_free", "sg_srs_check", "sg_commit", "sg_commit_dev",
     "sg_srs_device_ptrs", "sg_srs_precompute", "sg_commit_batch_dev", "sg_commit_batch_mixed_dev", "sg_commit_combine_begin", "sg_commit_combine_end", "sg_commit_combine_stats", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_ntt_fr_batch_dev", "sg_ntt_fr_batch_oop_dev", "sg_intt_fr", "sg_intt_fr_dev",
     "sg_lagrange_to_coeff", "sg_lagrange_to_coeff_dev", "sg_coeff_to_extended", "sg_coeff_to_extended_dev", "sg_coeff_to_extended_batch_dev",

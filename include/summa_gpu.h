@@ -63,7 +63,9 @@ void sg_shutdown(void);
 /* Device memory the library has outgrown while running (work spaces reallocated larger, window tables replaced by
  * sg_srs_precompute) is retired, not freed -- hipFree waits for the whole device, which would stall every other lane.
  * It is bounded by the final sizes (work spaces grow geometrically) and is returned here and by sg_shutdown.  The call
- * waits for the device to go idle: use it between workloads (e.g. after switching k), with no other call in flight. */
+ * also gives back the lanes' own work spaces (MSM / NTT work space, plans, staging: rebuilt by the next call that needs
+ * them), so that afterwards the library holds what it held after sg_init plus the live SRS handles and proving keys.
+ * It waits for the device to go idle: use it between workloads (e.g. after switching k), with no other call in flight. */
 int sg_collect_retired(void);
 /* Host memory for the host-pointer entry points (sg_msm_g1, sg_commit, sg_ntt_fr and the other calls without `_dev`): what a
  * [patch] of best_multiexp / best_fft hands over are ordinary vectors in pageable memory, which the runtime has to stage
@@ -74,6 +76,10 @@ int sg_collect_retired(void);
  * page-locked (hipHostMalloc). */
 int sg_host_register(void* host, size_t bytes);
 int sg_host_unregister(void* host);
+/* Wait until everything enqueued on `stream` (NULL: the default stream) has finished -- hipStreamSynchronize, in the way the
+ * library itself waits: parameter "host.wait_sleep_us" (sg_set_param; 0 = the runtime's polling wait, the default; N > 0 =
+ * poll every N microseconds and sleep in between, for processes that keep many proofs in flight on few CPU cores). */
+int sg_stream_wait(void* stream);
 /* Message of the last failure on the calling thread (static storage, never NULL). */
 const char* sg_last_error(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
@@ -478,6 +484,7 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  * "commit.combine_wait_us" (default 300), "commit.combine_target" (default 4: a runner stops waiting once this many requests
  *   are pending), "commit.combine_runners" (default 1: fused jobs that may run side by side, each on a lane of its own) -- see
  *   sg_commit_combine_begin; process-wide, they stay as set until set again,
+ * "host.wait_sleep_us" (0 | 1..1000: see sg_stream_wait; process-wide, takes effect at once),
  * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that
  *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",

@@ -23,6 +23,22 @@
 extern "C" {
 #endif
 
+/* The constraint-system shape this prover is built for -- that of `MstInclusionConfig::configure`
+ * [REF zk_prover/src/circuits/merkle_sum_tree.rs:141-207] after halo2's selector compression:
+ *   3 advice columns, 1 instance column, 11 fixed columns (5 of the circuit's + 6 from its 9 selectors), one permutation
+ *   argument over 6 columns in chunks of 4 (two grand products), ONE lookup with one input and one table expression
+ *   (the 8-bit range check: theta-compression is the identity), constraint degree 6 (five quotient pieces on five cosets of
+ *   the extended domain), 5 blinding rows + 1, rotations -1 / 0 / +1 only, instance queried at rotation 0.
+ * What may vary without touching the library, because it arrives as DATA: k; the contents of every fixed / permutation column
+ * (LEVELS, N_BYTES, the floor plan); the gate program and the lookup's input expression (N_CURRENCIES changes the number of sum
+ * gates: any program over these columns with rotations in {-1, 0, 1} is accepted); the verifying key's digest.
+ * What would break it (a change of `ConstraintSystem` that needs the C++ driver in include/summa_prover.hpp rebuilt, not data):
+ * another number of advice / fixed / permutation columns (SP_NUM_* below are compile-time), a second lookup or a lookup with
+ * several input expressions (theta would have to be squeezed BEFORE the permuted columns are committed: the driver commits them
+ * with the advice columns, summa_prover.hpp phase 2), a second instance column or an instance rotation, a rotation beyond +-1
+ * (the multi-open's rotation sets are {0}, {0, 1}, {-1, 0, 1, last}: fixed), a constraint degree above 6 (more quotient pieces), a
+ * permutation chunk length other than degree - 2 = 4.  sp_key_create cannot see most of these from its arguments: it checks the
+ * programs' column indices and rotations and refuses what it can (SG_ERR_INVALID); the rest is the caller's contract. */
 #define SP_NUM_FIXED 11
 #define SP_NUM_SIGMA 6
 #define SP_NUM_ADVICE 3

@@ -547,11 +547,11 @@ inline void release_column_pool() {
 }
 inline void d2h(void* host, const void* dev, size_t bytes) {   // ordered on the thread's main stream, complete on return
   hk(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, main_stream()), "D2H");
-  hk(hipStreamSynchronize(main_stream()), "sync");
+  ck(sg_stream_wait(main_stream()), "sync");
 }
 inline void h2d(void* dev, const void* host, size_t bytes) {
   hk(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, main_stream()), "H2D");
-  hk(hipStreamSynchronize(main_stream()), "sync");   // the host buffer may be a temporary
+  ck(sg_stream_wait(main_stream()), "sync");   // the host buffer may be a temporary
 }
 struct DevCol {  // device column of Fr (Montgomery); owned unless borrowed from the caller
   void* p = nullptr;
@@ -711,7 +711,7 @@ struct ProvingKey {
       ck(sg_fr_from_montgomery_dev(fixed_lag[4].p, canon.p, n, main_stream()), "from_montgomery");
       d2h(table_rows.data(), canon.p, 32 * n);
     }
-    hk(hipStreamSynchronize(main_stream()), "sync");
+    ck(sg_stream_wait(main_stream()), "sync");
   }
 };
 

@@ -20,6 +20,11 @@ extern "C" {
     pub fn sg_device_count() -> c_int;
     pub fn sg_device() -> c_int;
     pub fn sg_bind_thread() -> c_int;
+    // host memory that stays in place (an SRS, an arena of columns) can be page-locked once for the host-pointer entry points
+    pub fn sg_host_register(host: *mut c_void, bytes: size_t) -> c_int;
+    pub fn sg_host_unregister(host: *mut c_void) -> c_int;
+    pub fn sg_stream_wait(stream: *mut c_void) -> c_int;
+    pub fn sg_set_param(name: *const c_char, value: c_int) -> c_int;
     pub fn sg_msm_g1(scalars: *const u8, bases: *const u8, n: size_t, out_affine: *mut u8) -> c_int;
     pub fn sg_msm_g1_batch(
         scalars: *const *const u8,
@@ -73,6 +78,21 @@ extern "C" {
     pub fn sg_g2_generator_mul(scalar: *const u8, out128: *mut u8) -> c_int;
     // blinding factors / the random polynomial (OsRng upstream): a 32-byte OS-random key expanded by ChaCha20 on the device
     pub fn sg_fr_random_dev(key: *const u8, stream_id: u64, d_out: *mut c_void, n: size_t, stream: *mut c_void) -> c_int;
+    // permutation::prover::commit over every chunk + lookup::prover::commit_product, one batched call per proof
+    pub fn sg_grand_products_dev(
+        d_values: *const *const c_void,
+        d_sigma: *const *const c_void,
+        chunk_cols: *const u32,
+        n_chunks: u32,
+        d_lookup_cols: *const *const c_void,
+        n_lookups: u32,
+        beta: *const u8,
+        gamma: *const u8,
+        k: u32,
+        usable_rows: size_t,
+        d_z: *const *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
     // lookup::prover::permute_expression_pair for range tables (returns -5 when the table is not small integers)
     pub fn sg_lookup_permute_small_dev(
         d_input: *const c_void,

@@ -353,7 +353,7 @@ def test_compiled_verifier_equals_its_python_twin(artifacts):
     p6.free()
 
 
-@pytest.mark.parametrize("nc", [1, 3])
+@pytest.mark.parametrize("nc", [1, 3, 4])
 def test_other_currency_counts_prove_and_verify(nc, capfd):
     """`MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>` for N_CURRENCIES other than the reference tests' 2 (its bench runs
     1: benches/full_solvency_flow.rs:15; one sum gate and one Poseidon input per currency, so the gate program, the floor

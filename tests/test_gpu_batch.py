@@ -448,14 +448,15 @@ def test_batches_in_a_long_lived_process_do_not_grow():
             params.free()
         del pk, vk
 
-    one_round(6, 12, 51, 1)                      # warm: worker threads, sessions, lanes, plans of both sizes
-    one_round(7, 13, 52, 1)
-    ffi.check(ffi.lib().sg_collect_retired())
-    base_mem, base_py, base_os = free_mib(), threading.active_count(), os_threads()
-    for rnd in range(3):
+    # warm-up rounds first: worker threads and their sessions, the plans of both sizes, and the work spaces of the library's
+    # lanes -- a fused job runs on whichever lane is free, so it takes a few batches until every lane has met the largest job
+    history = []
+    for rnd in range(6):
         one_round(6, 12, 60 + rnd, 1)
         one_round(7, 13, 70 + rnd, 1)
-    ffi.check(ffi.lib().sg_collect_retired())
-    mem, py, osn = free_mib(), threading.active_count(), os_threads()
-    assert abs(mem - base_mem) <= 64, (base_mem, mem)
-    assert py == base_py and osn <= base_os + 2, (base_py, py, base_os, osn)
+        ffi.check(ffi.lib().sg_collect_retired())
+        history.append((round(free_mib()), threading.active_count(), os_threads()))
+    print("free MiB / python threads / OS threads after each round:", history)
+    (base_mem, base_py, base_os), (mem, py, osn) = history[2], history[5]
+    assert abs(mem - base_mem) <= 64, history           # three batches under each key later: what the device had
+    assert py == base_py and osn <= base_os + 2, history

@@ -82,10 +82,13 @@ def test_params_read_rawbytes(srs11):
 
 
 def test_sharding_bookkeeping():
-    from circuits_halo2_amd.distributed import assign_ops, shard_bounds
-    # 16 MSMs + 19 NTTs of one proof over 8 ranks: every op owned exactly once
-    owned = sorted(i for r in range(8) for i in assign_ops(35, r, 8))
-    assert owned == list(range(35))
+    from circuits_halo2_amd.batch import deal, owner_of
+    from circuits_halo2_amd.distributed import shard_bounds
+    # the 1024 users of a batch over 8 ranks: every proof owned exactly once, by the rank owner_of names
+    users = list(range(100, 1124))
+    shares = [deal(users, r, 8) for r in range(8)]
+    assert sorted(u for sh in shares for u in sh) == users and all(len(sh) == 128 for sh in shares)
+    assert all(owner_of(users.index(u), 8) == r for r, sh in enumerate(shares) for u in sh[:5])
     for n, w in ((1 << 20, 8), (1000, 3), (5, 8), (0, 2)):
         cover = []
         for r in range(w):
@@ -292,3 +295,62 @@ def test_worker_threads_are_bound_to_the_library_device(monkeypatch):
         batch._WORKERS.pop(7, None)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("ThreadPoolExecutor(") == src.count("initializer=ffi.bind_thread")
+
+
+def test_sp_key_create_refuses_programs_outside_the_constraint_system_shape():
+    """include/summa_prover.h says which ConstraintSystem shapes the compiled prover is built for; what of that
+    sp_key_create can see in its arguments it checks before anything reaches the device: rotations beyond -1 / 0 / +1,
+    column indices beyond 11 fixed / 3 advice / 1 instance, an instance rotation, dangling intermediates.  The reference
+    circuit's own programs (N_CURRENCIES 1 .. 4) pass that check (and then fail for want of a GPU on this box)."""
+    import ctypes as C
+    from circuits_halo2_amd import ffi, mst_inclusion as M
+    from circuits_halo2_amd.arithmetic import GraphEvaluator
+    L = ffi.prover_lib()
+
+    def create(gates_graph, nc=2):
+        gates, keep1 = gates_graph._struct()
+        look, keep2 = M.lookup_input_graph()._struct()
+        fixed, sigma = (C.c_void_p * 11)(*[8] * 11), (C.c_void_p * 6)(*[8] * 6)      # never dereferenced: the check comes first
+        digest = np.zeros(32, dtype=np.uint8)
+        groups = M.gate_challenge_exponents(nc)
+        exps = (C.c_uint32 * sum(len(g) for g in groups))(*[e for g in groups for e in g])
+        counts = (C.c_uint32 * len(groups))(*[len(g) for g in groups])
+        key = C.c_uint64(0)
+        rc = L.sp_key_create(C.c_uint32(6), C.c_uint64(1), fixed, sigma, ffi.ptr(digest), C.byref(gates), C.byref(look), exps, counts,
+                             C.c_uint32(len(groups)), None, C.byref(key))
+        return rc, L.sp_last_error().decode()
+
+    for nc in (1, 2, 3, 4):
+        rc, msg = create(M.gate_graph(nc), nc)
+        assert "does not fit" not in msg, (nc, msg)               # accepted by the shape check ...
+        assert rc != 0                                            # ... and no device to build the key on here
+
+    def tampered(edit):
+        g = M.gate_graph(2)
+        t = GraphEvaluator()
+        t.constants, t.rotations, t.calculations = list(g.constants), list(g.rotations), [tuple(c) for c in g.calculations]
+        edit(t)
+        return t
+
+    def first_column_use(t, kind):
+        for i, c in enumerate(t.calculations):
+            for slot in (1, 2):
+                if c[slot][0] == kind:
+                    return i, slot
+        raise AssertionError("program has no such source")
+
+    def set_source(t, i, slot, src):
+        c = list(t.calculations[i])
+        c[slot] = src
+        t.calculations[i] = tuple(c)
+
+    SG_VS_INTERMEDIATE, SG_VS_FIXED, SG_VS_ADVICE = 1, 2, 3
+    cases = {
+        "a rotation beyond": lambda t: t.rotations.__setitem__(0, 2),
+        "a column index beyond": lambda t: set_source(t, *first_column_use(t, SG_VS_ADVICE), (SG_VS_ADVICE, 3, 0)),
+        "a rotation index out of range": lambda t: set_source(t, *first_column_use(t, SG_VS_FIXED), (SG_VS_FIXED, 0, len(t.rotations))),
+        "not defined yet": lambda t: set_source(t, 0, 1, (SG_VS_INTERMEDIATE, 5, 0)),
+    }
+    for needle, edit in cases.items():
+        rc, msg = create(tampered(edit))
+        assert rc == -1 and "does not fit" in msg and needle in msg, (needle, rc, msg)

@@ -1,6 +1,9 @@
 # SQ_INSTS_VALU / SQ_WAVES of the 2^20 MSM's kernels for the two builds of the field products (v0 = -DSG_F29_ROW_SCAN, v1 = column chains)
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 cp circuits_halo2_amd/libsumma_gpu.so /tmp/lib_orig.so
 for v in v0 v1; do
   cp circuits_halo2_amd/libsumma_gpu_$v.so circuits_halo2_amd/libsumma_gpu.so

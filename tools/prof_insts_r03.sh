@@ -1,5 +1,8 @@
 # hardware instruction counts of the MSM kernels at the end of round 3 (persistent accumulation): SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVES
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_insts_r03
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d gpurun_out/prof_insts_r03 -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2> gpurun_out/prof_insts_r03.err; echo "rc=$?"
 python - <<'PY'

@@ -16,7 +16,10 @@ adv = api._advice_columns(pk, c)
 prover.export_bundle("gpurun_out/r03g/bundle17.bin", params, pk, adv, c.instances()[0])
 print("bundle written")
 PY
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 # (HIP default number of hardware queues)
 rm -rf gpurun_out/prof_serial
 SG_PROVER_SERIAL=1 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial -- ./tools/create_proof_cpp gpurun_out/r03g/bundle17.bin gpurun_out/r03g/proof.bin 8 > gpurun_out/r03g/cpp.json 2> gpurun_out/r03g/rocprof.err

@@ -3,7 +3,10 @@ mkdir -p gpurun_out/r02y
 ./tools/microbench3 > gpurun_out/r02y/fp64_vs_f29.txt 2>&1 || true
 cat gpurun_out/r02y/fp64_vs_f29.txt
 python bench.py --steps 20 --warmup 5 > gpurun_out/r02y/bench.json 2> gpurun_out/r02y/bench.err; echo "bench rc=$?"
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r02z -- python3 bench.py --steps 20 --warmup 5 --no-cpu > gpurun_out/r02y/bench_under_rocprof.json 2> gpurun_out/r02y/rocprof.err; echo "rocprof rc=$?"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_r02z_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r02y/rocprof.err; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_r02z_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r02y/rocprof.err; echo "write rc=$?"

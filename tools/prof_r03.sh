@@ -1,7 +1,10 @@
 set -e
 mkdir -p gpurun_out/r03y
 python bench.py --steps 20 --warmup 5 --batch-proofs 256 --batch-repeats 1 > gpurun_out/r03y/bench.json 2> gpurun_out/r03y/bench.err; echo "bench rc=$?"
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG:-r03z} -- python3 bench.py --steps 20 --warmup 5 --no-cpu --batch-proofs 96 --batch-repeats 1 > gpurun_out/r03y/bench_under_rocprof.json 2> gpurun_out/r03y/rocprof.err; echo "rocprof rc=$?"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_${TAG:-r03z}_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r03y/rocprof.err; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_${TAG:-r03z}_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras > /dev/null 2>> gpurun_out/r03y/rocprof.err; echo "write rc=$?"

@@ -15,7 +15,10 @@ c = api.MstInclusionCircuit.init_from_tree(tree, 5)
 adv = api._advice_columns(pk, c)
 prover.export_bundle("gpurun_out/r03g/bundle17.bin", params, pk, adv, c.instances()[0])
 PY
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (relative paths below are removed and written under the repo copy)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 for kv in "$@"; do export "$kv"; done
 rm -rf gpurun_out/pq_$tag
 rocprofv3 --kernel-trace -d gpurun_out/pq_$tag -- ./tools/create_proof_cpp gpurun_out/r03g/bundle17.bin gpurun_out/r03g/proof.bin 6 > gpurun_out/pq_$tag.json 2> gpurun_out/pq_$tag.err
