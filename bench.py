@@ -50,10 +50,19 @@ def pmc_traffic(kernel, log_n, grid_threads=None, job_threads=None):
             # the same kernel also runs at other sizes (fused batches): take the launch shape of the timed MSM
             _, v = min(cands, key=lambda gv: abs(gv[0] - grid_threads)) if grid_threads else max(cands)
             raw = (v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024
-            return {"traffic": raw, "traffic_source": os.path.basename(path),
-                    "traffic_note": "FETCH_SIZE + WRITE_SIZE, uncorrected (64-B gathers are uncalibrated on gfx950; "
-                                    "the x2 streaming-read correction would give %.3g B)" %
-                                    ((2 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)}
+            # the guide's x2 correction of FETCH_SIZE holds for wide coalesced streams; this kernel's reads are 64-byte gathers
+            # at unrelated indices, calibrated on a known byte count of exactly that pattern (tools/calib_gather.hip)
+            cal, cal_src = None, None
+            for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fetch_calibration.json")), reverse=True):
+                rows = json.load(open(cpath))
+                cal = {f"table_{r['table_MiB']}MiB": round(r["fetch_over_requested"], 3) for r in rows}
+                cal_src = os.path.basename(cpath)
+                break
+            return {"traffic": raw, "traffic_source": os.path.basename(path), "fetch_size_over_requested_bytes_for_64B_gathers": cal,
+                    "traffic_note": "FETCH_SIZE + WRITE_SIZE of the launch (separate --pmc passes).  No x2 correction: for this kernel's access "
+                                    f"pattern, 64-byte gathers, FETCH_SIZE reads 0.94-1.00 x the bytes requested ({cal_src}: a 64 MiB table "
+                                    "resident in the Infinity Cache, as the MSM's base table is, and a 1 GiB table); every point is gathered once per "
+                                    "window, hence ~14 x the algorithmic bytes, served mostly on-die"}
     return {}
 
 
@@ -638,7 +647,7 @@ def _main():
             got["cpu_share"] = args.cpu_share
             fs.emit(got)
         sys.stdout.flush()
-        os._exit(0)          # (no teardown: the line is out, the library's worker threads need no farewell)
+        return got           # (a normal exit: a profiler attached to this process writes its database at exit)
 
     n = 1 << args.log_n
     # synthetic inputs, generated per rank from rank-dependent seeds, resident in HBM
@@ -710,6 +719,10 @@ def _main():
         return _all_max(dt, world, coll_dev), results
 
     in_flight = max(1, args.in_flight)
+    if world > 1 and "host.wait_sleep_us" not in os.environ.get("SG_PARAMS", ""):
+        # several ranks share the host's CPU quota: their waiting threads sleep between polls instead of yielding (neutral at
+        # N = 1: profiles/r04_sweeps/headline_wait_modes.txt)
+        ffi.check(sg.lib().sg_set_param(b"host.wait_sleep_us", 25))
     pool = ThreadPoolExecutor(max_workers=in_flight, initializer=ffi.bind_thread)   # a new thread's current device is 0
     run_steps(2 * in_flight, in_flight)      # set-up, not a step: every lane allocates its work space (first call per lane)
     run_steps(args.warmup, in_flight)

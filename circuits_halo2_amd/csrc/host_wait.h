@@ -14,7 +14,7 @@ namespace sg {
 // on its critical path); a batch with sixteen to thirty-two proofs in flight wants the second: its threads wait most of
 // the time, thirty yielding pollers eat the process's CPU quota (on the boxes of this pool: 16 cores under a 256-CPU
 // mask, and eight ranks of one node share such a quota), and a few tens of microseconds of wake-up latency cost a proof
-// that is in flight for a hundred milliseconds nothing (bench.py --cpu-share).
+// that is in flight for a hundred milliseconds nothing (DESIGN.md sections 4.4 and 5; bench.py --cpu-share).
 inline std::atomic<int>& host_wait_sleep_us() {
   static std::atomic<int> v{0};
   return v;

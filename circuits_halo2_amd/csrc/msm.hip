@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
 template <int Q>
 __device__ __forceinline__ void add_q(xyzz29& acc, const xyzz29& q, uint32_t role) {
   if (Q == 4) xyzz29_add_quad(acc, q, role);
-  else xyzz29_add(acc, q);   // (inlined at every call site: one out-of-line copy per kernel was measured and is slower)
+  else xyzz29_add(acc, q);   // (inlined at every call site: one out-of-line copy per kernel was measured and is slower, docs/history.md section 4.11)
 }
 template <int Q>
 __global__ void __launch_bounds__(256) msm_merge(const xyzz29_mem* __restrict__ in, const uint32_t* __restrict__ off,

@@ -1184,7 +1184,12 @@ static int commit_combined(uint64_t srs_handle, const int* basis, const void* co
       continue;
     }
     g_comb.runners++;                             // this thread runs the next job
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(g_comb.wait_us.load());
+    // the bounded wait shrinks with the company that can still come: a thread is a member for the whole of its proof, not
+    // only around its commitments, so at the tail of a batch the few proofs left would otherwise sit out the full wait
+    // (5 ms in batch.prove_batch) at every one of their five jobs for members that are busy elsewhere
+    const int may_come = std::max(1, g_comb.members - g_comb.busy - (int)g_comb.pending.size());
+    const int wait_us = std::min(g_comb.wait_us.load(), 400 * may_come);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
     // wait for company: until `target` requests are pending, or every declared thread that is not inside a running job
     // has arrived, or the deadline
     while ((int)g_comb.pending.size() < std::min(g_comb.target.load(), g_comb.members - g_comb.busy))

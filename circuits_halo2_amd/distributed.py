@@ -70,7 +70,7 @@ def exchange_partials_many(parts, msm=None):
 
     Why a pipelined caller uses this instead of K calls of `exchange_partials`: with steps in flight, accumulations of
     consecutive MSMs run back to back on the device, and every kernel beside them must raise its wave priority to be
-    issued at all (csrc/side_prio.cuh, DESIGN.md section 4); RCCL's kernels cannot.  One collective after the steps
+    issued at all (csrc/side_prio.cuh, DESIGN.md section 4.4); RCCL's kernels cannot.  One collective after the steps
     keeps RCCL off the device while it is saturated; the step's result is complete when this returns."""
     parts = [np.ascontiguousarray(p_) for p_ in parts]
     d = _dist()

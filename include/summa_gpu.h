@@ -100,7 +100,7 @@ const char* sg_version(void);
  * coeffs.len() == bases.len(); here a single n covers both.  n = 0 yields the identity.
  * sg_msm_g1_dev returns the point, i.e. it is complete on return: its kernels run on the calling lane's own stream, ordered
  * after whatever `stream` holds at the time of the call (the lanes' streams are on distinct hardware queues, so calls from
- * several threads overlap whatever streams the callers use: DESIGN.md section 4.11). */
+ * several threads overlap whatever streams the callers use: DESIGN.md section 4.4). */
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]);
 int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]);
 
@@ -489,7 +489,7 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
  * "ntt.max_single_log", "ntt.max_multi_log";
- * how calls in flight share the device (the defaults are what the measurements chose):
+ * how calls in flight share the device (DESIGN.md sections 4.1 and 4.4, docs/history.md section 4.11; the defaults are what the measurements chose):
  *   "side_prio" (1 | 0): every kernel but the MSM's accumulation runs at wave priority 3, so that a kernel of another call that
  *     lands beside an accumulation is not starved of issue slots by it (device-wide, not per lane);
  *   "msm.acc_waves" / "msm.acc_waves_fixed" (0 = default, 2, 3, 8): waves per SIMD of the persistent accumulation launch of

@@ -191,7 +191,7 @@ def test_thread_binding_reports_the_bound_device():
 
 
 def test_calls_in_flight_are_bit_exact_under_every_sharing_setting():
-    """persistent accumulation (2 / 3 waves per SIMD, one ticket per wave), wave priorities, chained accumulations,
+    """docs/history.md 4.11: persistent accumulation (2 / 3 waves per SIMD, one ticket per wave), wave priorities, chained accumulations,
     the lean bucket reduction -- none of it may change a result bit, alone or with three calls in flight"""
     import torch
     import circuits_halo2_amd as sg

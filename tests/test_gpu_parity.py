@@ -630,6 +630,53 @@ def test_host_pointer_entry_points_from_many_threads(gpu, O):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("n", [(1 << 18) - 1, 1 << 18, (1 << 18) + 1, (1 << 19) + 12345])
+def test_host_pointer_msm_in_two_halves(gpu, O, n):
+    """sg_msm_g1 from host memory cuts inputs of 2^18 pairs and more in two halves on two streams with the lane's two
+    engines (the first half's MSM runs under the second half's upload) and adds the two partial points on the host: the
+    same point as the device path and as <k, s> G, at the threshold, around it, for an odd length, with an all-zero first
+    half (its job finds nothing to do), from memory registered with sg_host_register, and under the sleeping host wait"""
+    import ctypes as C
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi
+    from circuits_halo2_amd.utils import random_fr_canonical
+    L = gpu.lib()
+    sc = A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(3100 + n % 97, n)).cuda())
+    bs = A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(3200 + n % 89, n)).cuda())
+    bases = A.g1_fixed_base_mul(bs)
+    one = np.frombuffer((0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb).to_bytes(32, "little"), dtype=np.uint8)
+    want = A.g1_fixed_base_mul(A.eval_polynomial(A.fr_mul(sc, bs), one)).cpu().numpy()     # <k, s> G: bases are s_i G
+    assert (gpu.best_multiexp(sc, bases) == want).all()
+    hs, hb = sc.cpu().numpy().copy(), bases.cpu().numpy().copy()
+    out = np.zeros(64, dtype=np.uint8)
+
+    def host_msm(s_, b_):
+        ffi.check(L.sg_msm_g1(ffi.ptr(s_), ffi.ptr(b_), C.c_size_t(s_.size // 32), ffi.ptr(out)))
+        return out.copy()
+    assert (host_msm(hs, hb) == want).all()
+    ffi.check(L.sg_host_register(C.c_void_p(hs.ctypes.data), C.c_size_t(hs.nbytes)))
+    try:
+        assert L.sg_host_register(C.c_void_p(hs.ctypes.data + 64), C.c_size_t(64)) != 0        # overlaps a registered range
+        assert (host_msm(hs, hb) == want).all()
+        ffi.check(L.sg_set_param(b"host.wait_sleep_us", 40))
+        try:
+            assert (host_msm(hs, hb) == want).all()
+            assert (gpu.best_multiexp(sc, bases) == want).all()
+        finally:
+            ffi.check(L.sg_set_param(b"host.wait_sleep_us", 0))
+    finally:
+        ffi.check(L.sg_host_unregister(C.c_void_p(hs.ctypes.data)))
+    assert L.sg_host_unregister(C.c_void_p(hs.ctypes.data)) != 0                                # not registered any more
+    # the first half all zero: that half's job has no entries; the result is the second half's
+    h = n // 2
+    hz = hs.copy()
+    hz[:32 * h] = 0
+    tail = gpu.best_multiexp(sc[32 * h:].contiguous(), bases[64 * h:].contiguous())
+    assert (host_msm(hz, hb) == tail).all()
+    hz[:] = 0
+    assert not host_msm(hz, hb).any()                                                            # identity = 64 zero bytes
+
+
 def test_two_host_threads_do_not_serialise(gpu, O):
     """calls from different host threads take different lanes of the library (own streams, MSM engines, work space): two
     threads issuing the same MSMs concurrently must finish well before twice the time one of them needs alone (they would
