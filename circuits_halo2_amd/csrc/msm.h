@@ -28,7 +28,7 @@ struct MsmConfig {
   uint32_t acc_waves = 0;      // waves per SIMD of the persistent msm_accumulate launch: 0 = 3 (a full register file); >= 8: grid = tasks, one ticket per wave
   uint32_t acc_waves_fixed = 0; // ... of fixed-base jobs (the commitments of a proof, which run beside that proof's transforms on other streams): 0 = 2
   uint32_t merge_quad_tasks = 0xffffffffu;  // merge rounds with more tasks than this use one lane per addition even when `quad` holds
-  uint32_t red2d_max_sets = 5; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh)
+  uint32_t red2d_max_sets = 6; // ... host-weights variant up to this many bucket sets (measured: tools/sweep_red2d.sh; 6 since the partial sums are folded first)
   uint32_t red2d = 1;          // 2-D (row / column / bit) bucket reduction: 0 never, 1 jobs of <= 4 bucket sets, 2 always
   uint32_t red2d_fold = 8;     // ... whose line sums add up to this many partial sums per bucket themselves (no merge round below that)
   uint32_t red2d_prefold = 1;  // ... after a pass that adds every bucket's partial sums once (msm_fold_buckets); 0: the line sums add them on the way (twice)

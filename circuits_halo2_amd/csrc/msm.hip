@@ -1753,7 +1753,12 @@ hipError_t MsmEngine::enqueue_back_impl() {
   const uint32_t max_threads = quad ? 64u : cfg_.red_threads;       // logical threads per workgroup
   const uint32_t max_blocks = quad ? 64u : 256u;                    // level 1 holds 3 * T1 * Q <= 768 lanes
   // G buckets per logical thread: 8 for the largest windows, 4 below (depth vs. work, measured)
-  j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : (nbw >= (1u << 14) ? 3 : 2), j.c - 1);
+  // ... and 16 when other jobs are in flight: the reduction then runs under another job's accumulation, where what counts is
+  // the instructions it issues (running sums are 2 additions per bucket, the scan and tree steps come per thread: 88 instead
+  // of 116 wave-additions per 2048 buckets), not the length of its own chain (alone: 0.29 -> 0.39 ms; three MSMs in
+  // flight: +0.7 % points/s, profiles/r04_sweeps/reduce_chunk_pipelined.txt)
+  const uint32_t auto_log_G = nbw >= (1u << 14) ? ((!quad && others_in_flight()) ? 4u : 3u) : 2u;
+  j.log_G = std::min<uint32_t>(cfg_.log_red_chunk ? cfg_.log_red_chunk : auto_log_G, j.c - 1);
   while ((nbw >> j.log_G) > max_threads * max_blocks) j.log_G++;
   const uint32_t items = nbw >> j.log_G;  // chunks per window at level 0 (a power of two)
   const uint32_t threads = std::min<uint32_t>(max_threads, std::max<uint32_t>(16, items));

@@ -1247,6 +1247,7 @@ int sg_commit_combine_end(void) {
   }
   return SG_OK;
 }
+int sg_commit_combining(void) { return t_combine ? 1 : 0; }
 int sg_commit_combine_stats(uint64_t* jobs, uint64_t* requests) {
   if (jobs) *jobs = g_comb.jobs.load();
   if (requests) *requests = g_comb.requests.load();
@@ -1257,7 +1258,7 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
                               void* stream, uint8_t* out_affine) {
   if (count && (!d_scalars || !out_affine || !basis)) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   for (size_t i = 0; i < count; i++)
-    if ((n && !d_scalars[i]) || basis[i] < 0 || basis[i] > 2) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
+    if ((n && !d_scalars[i]) || basis[i] < 0 || (basis[i] & ~SG_BASIS_SPARSE) > 2) return fail(SG_ERR_INVALID, "sg_commit_batch_mixed: bad argument");
   if (t_combine && count && n && count <= MAX_FUSED && g_depth == 0)
     return commit_combined(srs_handle, basis, d_scalars, count, n, stream, out_affine);
   return commit_batch_mixed_core(srs_handle, basis, d_scalars, count, n, stream, out_affine);
@@ -1277,11 +1278,26 @@ static int commit_batch_mixed_core(uint64_t srs_handle, const int* basis, const 
   std::vector<size_t> ns(count, n);
   std::vector<const void*> bases(count);
   std::vector<uint8_t> flags(count, 0);
+  bool all_sparse = count > 0;
   for (size_t i = 0; i < count; i++) {
-    const int b = basis[i] == 2 ? (diff_ok ? 2 : 1) : basis[i];
+    const int want = basis[i] & ~SG_BASIS_SPARSE;
+    all_sparse = all_sparse && (basis[i] & SG_BASIS_SPARSE);
+    const int b = want == 2 ? (diff_ok ? 2 : 1) : want;
     flags[i] = b == 2;
     bases[i] = fixed ? (const void*)s.tab[b].table : (const void*)(b ? s.g_lagrange : s.g);
   }
+  // A job whose columns are all witness-like (mostly zeros and small values: few entries, some of them in heavy buckets) is a
+  // latency chain of one task length whatever its size: tasks of 8 instead of 16 halve it (a proof's first commitment job
+  // 1.07 -> 1.00 ms) where dense jobs lose by them (profiles/r04_sweeps/task_length_by_phase.txt).  A hint, never semantics.
+  struct SegRestore {
+    Context& c;
+    uint32_t a, b;
+    ~SegRestore() { c.msm.config().log_seg = a; c.msm_b.config().log_seg = b; }
+  } seg_restore{*g_ctx, g_ctx->msm.config().log_seg, g_ctx->msm_b.config().log_seg};
+  // (only for jobs small enough for the 2-D reduction, which adds up to eight partial sums per bucket itself: a fused job of many
+  // proofs' columns goes through merge rounds, and shorter tasks would add one)
+  if (all_sparse && fixed && count <= 5 && g_ctx->msm.config().log_seg == 0 && n >= ((size_t)1 << 14))
+    g_ctx->msm.config().log_seg = g_ctx->msm_b.config().log_seg = 3;
   return msm_batch_locked(d_scalars, bases.data(), fixed ? &s.tab[0] : nullptr, ns.data(), count, stream, out_affine, flags.data());
 }
 int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, uint8_t out_affine[64]) {

@@ -18,7 +18,7 @@ SG_OK = 0
 EXPORTS = [
     "sg_init", "sg_shutdown", "sg_collect_retired", "sg_host_register", "sg_host_unregister", "sg_stream_wait", "sg_last_error", "sg_device_count", "sg_device", "sg_bind_thread", "sg_version",
     "sg_msm_g1", "sg_msm_g1_dev", "sg_msm_g1_batch", "sg_msm_g1_batch_dev", "sg_g1_sum_affine", "sg_srs_upload", "sg_srs_upload_dev", "sg_srs_copy_dev", "sg_srs_free", "sg_srs_check", "sg_commit", "sg_commit_dev",
-    "sg_srs_device_ptrs", "sg_srs_precompute", "sg_commit_batch_dev", "sg_commit_batch_mixed_dev", "sg_commit_combine_begin", "sg_commit_combine_end", "sg_commit_combine_stats", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_ntt_fr_batch_dev", "sg_ntt_fr_batch_oop_dev", "sg_intt_fr", "sg_intt_fr_dev",
+    "sg_srs_device_ptrs", "sg_srs_precompute", "sg_commit_batch_dev", "sg_commit_batch_mixed_dev", "sg_commit_combine_begin", "sg_commit_combine_end", "sg_commit_combining", "sg_commit_combine_stats", "sg_ntt_fr", "sg_ntt_fr_dev", "sg_ntt_fr_batch_dev", "sg_ntt_fr_batch_oop_dev", "sg_intt_fr", "sg_intt_fr_dev",
     "sg_lagrange_to_coeff", "sg_lagrange_to_coeff_dev", "sg_coeff_to_extended", "sg_coeff_to_extended_dev", "sg_coeff_to_extended_batch_dev",
     "sg_extended_to_coeff", "sg_extended_to_coeff_dev", "sg_coeff_to_cosets_batch_dev", "sg_cosets_to_pieces_dev", "sg_quotient_permutation_cosets_dev", "sg_quotient_lookup_cosets_dev", "sg_quotient_gates_cosets_dev", "sg_gates_program_info", "sg_gates_program_words", "sg_mst_inclusion_keygen_columns", "sg_divide_by_vanishing_poly",
     "sg_divide_by_vanishing_poly_dev", "sg_domain_constant", "sg_g1_fixed_base_mul", "sg_g1_fixed_base_mul_dev", "sg_g2_generator_mul", "sg_pairing_check", "sg_pairing_check_slow", "sg_keccak256", "sg_kzg_setup", "sg_kzg_setup_dev", "sg_g1_fft_dev", "sg_g1_to_lagrange",

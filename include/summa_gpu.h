@@ -152,7 +152,11 @@ int sg_srs_precompute(uint64_t handle, int basis, uint32_t window_bits);
 int sg_commit_batch_dev(uint64_t srs_handle, int basis, const void* const* d_scalars, size_t count, size_t n,
                         void* stream, uint8_t* out_affine);
 /* the same with one basis per polynomial (0 = g, 1 = g_lagrange, 2 = g_lagrange in difference form): the commitments of one prover phase that mix
- * Lagrange- and coefficient-form polynomials as ONE fused job (fixed-base when both tables were precomputed) */
+ * Lagrange- and coefficient-form polynomials as ONE fused job (fixed-base when both tables were precomputed).
+ * A basis value may carry the hint SG_BASIS_SPARSE (basis | 16): "this column is witness-like -- mostly zeros and small values".
+ * When every column of the call carries it the job is scheduled as the short latency chain it is (shorter accumulation tasks);
+ * the commitments are the same with and without the hint. */
+#define SG_BASIS_SPARSE 16
 int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void* const* d_scalars, size_t count, size_t n,
                               void* stream, uint8_t* out_affine);
 /* Commit combiner, for provers that keep several proofs in flight from several host threads (one proof per thread).  Between
@@ -166,6 +170,7 @@ int sg_commit_batch_mixed_dev(uint64_t srs_handle, const int* basis, const void*
  * sg_commit_combine_stats: fused jobs run / requests served so far (requests / jobs = average fusion). */
 int sg_commit_combine_begin(void);
 int sg_commit_combine_end(void);
+int sg_commit_combining(void);   /* 1 between _begin and _end on the calling thread, else 0 */
 int sg_commit_combine_stats(uint64_t* jobs, uint64_t* requests);
 /* Device pointers of a cached SRS (for callers that drive the *_dev entry points). */
 int sg_srs_device_ptrs(uint64_t handle, const void** d_g, const void** d_g_lagrange, uint32_t* k);

@@ -969,6 +969,13 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // products) depends on nothing: 2^k values drawn here, under phase 1's commitment job, instead of on phase 3's critical path
   DevCol random_poly(n);
   rand_at(9, random_poly, 0, n, side[1]);
+  // ... and is committed with phase 1's columns (below) instead of phase 3's: the one dense column among the commitments of phases
+  // 1-3 leaves the job that sits on the critical path behind the grand products (phase 3: 1.34 -> 1.0 ms) and joins one that
+  // is a latency chain of witness-like columns anyway (phase 1: 1.0 -> 1.24 ms); its point enters the transcript where upstream
+  // writes it.  A proof is GPU-bound by now (5.4 ms of kernel time in 5.6 ms of wall clock), so the gain is the fused job's
+  // saved front end and reduction, not the overlap: committing the column from a helper thread, concurrently with phase 1's
+  // job, was measured and is slower (profiles/r04_sweeps/random_polynomial_early.txt).  SG_PROVER_RANDOM_EARLY=0: upstream's order.
+  static const bool random_early = [] { const char* v = std::getenv("SG_PROVER_RANDOM_EARLY"); return !(v && v[0] == '0'); }();
   // -- 2 (computed ahead of its place in the transcript): the lookup's permuted columns.  This circuit's lookup has ONE input
   // and ONE table expression, so the theta-compression is the expression itself and nothing here waits for theta: the two
   // permuted columns are committed in the SAME fused job as the advice columns (one MSM group's latency instead of two) and
@@ -1001,7 +1008,17 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   rand_rows({{&pin, u, n - u}, {&ptab, u, n - u}});
   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
   mark("1: lookup columns ready, commit [a0 a1 a2 a' s'] issued");
-  const std::vector<uint8_t> pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1, 1, 1, 2, 2});
+  // (the random polynomial rides along: see where it is drawn)
+  // (advice and permuted-lookup columns of this circuit are witness-like: a few thousand used rows of small values)
+  const int SP = SG_BASIS_SPARSE;
+  std::vector<uint8_t> pts;
+  if (random_early) {
+    hk(hipEventRecord(ev_join[1], side[1]), "event");            // the draw of the random polynomial (side stream 1)
+    hk(hipStreamWaitEvent(ms, ev_join[1], 0), "wait");
+    pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p, random_poly.p}, {1 | SP, 1 | SP, 1 | SP, 2 | SP, 2 | SP, 0});
+  } else {
+    pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1 | SP, 1 | SP, 1 | SP, 2 | SP, 2 | SP});
+  }
   if (opt.sanity_checks) {
     uint32_t bad = 0;
     d2h(&bad, noncanonical.p, 4);
@@ -1061,7 +1078,12 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   to_coeff_ext({pin.p, ptab.p, zs[0].p, zs[1].p, lz.p}, co3, ex3, side[0]);   // under the commitments
   // the grand products stay constant wherever the ratio is 1 -- all the unused rows: difference form
   mark("3: commit [z0 z1 lz random] issued");
-  commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
+  if (random_early) {   // three piecewise-constant columns in difference form: a sparse job
+    commit_batch({zs[0].p, zs[1].p, lz.p}, {2 | SP, 2 | SP, 2 | SP});
+    tr.write_point(pts.data() + 64 * 5);                         // the random polynomial's commitment, made in phase 1's job
+  } else {
+    commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
+  }
   mark("3: commitments back");
   if (opt.sanity_checks) {   // the copies above precede the commitment job on the main stream: complete by now
     Fr last;

@@ -645,7 +645,7 @@ def test_host_pointer_msm_in_two_halves(gpu, O, n):
     bs = A.fr_to_montgomery(torch.from_numpy(random_fr_canonical(3200 + n % 89, n)).cuda())
     bases = A.g1_fixed_base_mul(bs)
     one = np.frombuffer((0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb).to_bytes(32, "little"), dtype=np.uint8)
-    want = A.g1_fixed_base_mul(A.eval_polynomial(A.fr_mul(sc, bs), one)).cpu().numpy()     # <k, s> G: bases are s_i G
+    want = np.asarray(A.g1_fixed_base_mul(A.eval_polynomial(A.fr_mul(sc, bs), one)))        # <k, s> G: bases are s_i G
     assert (gpu.best_multiexp(sc, bases) == want).all()
     hs, hb = sc.cpu().numpy().copy(), bases.cpu().numpy().copy()
     out = np.zeros(64, dtype=np.uint8)

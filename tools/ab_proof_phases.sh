@@ -1,6 +1,9 @@
-# whole-proof A/B of library tunables with the compiled prover (k = 17, best of 30 per run, baseline repeated between the others)
-# usage: ab_proof_knobs.sh "SG_PARAMS=a=1" "SG_PARAMS=b=2" ...
-set -e
+#!/bin/bash
+# whole proofs (compiled driver, k = 17, best of 30) under library tunables, with the per-phase times of the synchronised lap run
+# usage: ab_proof_phases.sh "SG_PARAMS=a=1" ...
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/ab_work
 python - <<'PY'
 import os, sys
@@ -15,7 +18,7 @@ c = api.MstInclusionCircuit.init_from_tree(tree, 5)
 adv = api._advice_columns(pk, c)
 prover.export_bundle("gpurun_out/ab_work/bundle17.bin", params, pk, adv, c.instances()[0])
 PY
-run() { echo -n "$1 | "; env $1 ./tools/create_proof_cpp gpurun_out/ab_work/bundle17.bin gpurun_out/ab_work/proof.bin 30 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['create_proof_ms'])"; }
+run() { echo -n "$1 | "; env $1 ./tools/create_proof_cpp gpurun_out/ab_work/bundle17.bin gpurun_out/ab_work/proof.bin 30 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['create_proof_ms'], {k: v for k, v in d.items() if k[0].isdigit()})"; }
 for knob in "$@"; do
   run "X=0"
   run "$knob"
