@@ -116,6 +116,7 @@ class FailSafe:
         self.rfd, self.wfd = os.pipe()
         os.set_blocking(self.wfd, False)
         self.thread = None
+        self.base_line = None      # the headline part of the line, whole and valid, once the timed steps are done (rank 0)
 
     def arm(self):
         import signal
@@ -143,9 +144,9 @@ class FailSafe:
                 self.fail(f"signal {list(sig)} while in step '{self.step_label}' (another rank failed, or the launcher gave up)", 143)
             now = time.monotonic()
             if now > self.t0 + self.limit_s:
-                self.fail(f"wall-clock limit of {self.limit_s:.0f} s reached in step '{self.step_label}'", 124)
+                self.out_of_time(f"wall-clock limit of {self.limit_s:.0f} s reached in step '{self.step_label}'")
             if now > self.step_deadline:
-                self.fail(f"step '{self.step_label}' overstayed its allowance (a rank is missing from a collective?)", 124)
+                self.out_of_time(f"step '{self.step_label}' overstayed its allowance (a rank is missing from a collective?)")
 
     def error_line(self, reason):
         a = self.args
@@ -162,6 +163,16 @@ class FailSafe:
             self.printed = True
             print(json.dumps(line), flush=True)
             return True
+
+    def out_of_time(self, reason):
+        """time ran out.  In a single-rank run whose timed steps are done, what overstayed is an EXTRA: the headline was
+        measured in full and is printed as the run's line, the missing extras named in `incomplete` (exit code 0).  In a
+        multi-rank run a step that overstays means a rank is gone: the measurement is void, the error line says so."""
+        if self.args.gpus == 1 and self.base_line is not None:
+            line = dict(self.base_line, incomplete=reason, partial_extras=self.partial)
+            self.emit(line)
+            os._exit(0)
+        self.fail(reason, 124)
 
     def fail(self, reason, code):
         if self.rank == 0:
@@ -741,45 +752,8 @@ def _main():
         sg.best_multiexp(scal, bases, timings=True)
         phase_reps = [sg.best_multiexp(scal, bases, timings=True)[1] for _ in range(5)]
 
-    # the extras that every rank takes part in.  An extra never costs the headline line, and a rank that fails locally
-    # still meets the others: after each extra the ranks agree on a failure flag (all_reduce), never on a bare barrier
-    # that a failed rank would not reach
-    def collective_extra(fn):
-        res, failed = None, 0.0
-        try:
-            res = fn()
-        except Exception as ex:
-            res, failed = {"error": repr(ex)}, 1.0
-        any_failed = _all_max(failed, world, coll_dev) > 0
-        return res, any_failed
-
-    strong_line = None
-    if not args.no_extras and args.log_n >= 20:
-        strong_line, _ = collective_extra(lambda: strong_scaling_extra(args, rank, world, coll_dev))
-        if rank != 0:
-            strong_line = None
-        torch.cuda.empty_cache()
-    batch_line, k17 = None, None
-    if args.batch_proofs > 0 and not args.no_extras and args.log_n >= 20:
-        got, any_failed = collective_extra(lambda: batch_extra(args, rank, world, coll_dev))
-        if isinstance(got, tuple):
-            batch_line, k17 = got
-        else:
-            batch_line = got if rank == 0 else None
-        if any_failed and rank == 0 and (batch_line is None or "error" not in batch_line):
-            batch_line = {"error": "another rank failed in the batch extra"}
-        if any_failed:
-            k17 = None
-        if rank == 0 and isinstance(batch_line, dict):
-            fs.partial["batch_k17"] = {k_: batch_line.get(k_) for k_ in ("proofs_per_s", "proofs_total", "errors", "error", "in_flight") if k_ in batch_line}
-    if world > 1:
-        # the last collective of the run: what follows is rank 0's own (the line, the local extras); the other ranks leave
-        # without waiting for it, so no rank sits in a barrier while rank 0 times a CPU baseline
-        _beat("final barrier")
-        dist.barrier()
-        dist.destroy_process_group()
-    _beat("rank 0: local extras and the line", args.wall_limit)
-
+    # ---- the line's headline part, complete BEFORE any extra runs: if an extra hangs or the wall-clock limit comes, the
+    # watchdog still has a whole, valid line to print (FailSafe.base_line)
     line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -836,6 +810,48 @@ def _main():
                                     "valu_source": os.path.basename(path)})
                 break
 
+        fs.base_line = line
+
+    # the extras that every rank takes part in.  An extra never costs the headline line, and a rank that fails locally
+    # still meets the others: after each extra the ranks agree on a failure flag (all_reduce), never on a bare barrier
+    # that a failed rank would not reach
+    def collective_extra(fn):
+        res, failed = None, 0.0
+        try:
+            res = fn()
+        except Exception as ex:
+            res, failed = {"error": repr(ex)}, 1.0
+        any_failed = _all_max(failed, world, coll_dev) > 0
+        return res, any_failed
+
+    strong_line = None
+    if not args.no_extras and args.log_n >= 20:
+        strong_line, _ = collective_extra(lambda: strong_scaling_extra(args, rank, world, coll_dev))
+        if rank != 0:
+            strong_line = None
+        torch.cuda.empty_cache()
+    batch_line, k17 = None, None
+    if args.batch_proofs > 0 and not args.no_extras and args.log_n >= 20:
+        got, any_failed = collective_extra(lambda: batch_extra(args, rank, world, coll_dev))
+        if isinstance(got, tuple):
+            batch_line, k17 = got
+        else:
+            batch_line = got if rank == 0 else None
+        if any_failed and rank == 0 and (batch_line is None or "error" not in batch_line):
+            batch_line = {"error": "another rank failed in the batch extra"}
+        if any_failed:
+            k17 = None
+        if rank == 0 and isinstance(batch_line, dict):
+            fs.partial["batch_k17"] = {k_: batch_line.get(k_) for k_ in ("proofs_per_s", "proofs_total", "errors", "error", "in_flight") if k_ in batch_line}
+    if world > 1:
+        # the last collective of the run: what follows is rank 0's own (the line, the local extras); the other ranks leave
+        # without waiting for it, so no rank sits in a barrier while rank 0 times a CPU baseline
+        _beat("final barrier")
+        dist.barrier()
+        dist.destroy_process_group()
+    _beat("rank 0: local extras and the line", args.wall_limit)
+
+    if rank == 0:
         # throughput mode: the same MSM issued as a batch of 8 (fused / pipelined jobs)
         sg.best_multiexp_batch([(scal, bases)] * 8)   # warms both engines' work spaces
         torch.cuda.synchronize()
@@ -1215,6 +1231,8 @@ def main():
         import traceback
         traceback.print_exc()
         if _FS is not None:
+            if _FS.base_line is not None and _FS.args.gpus == 1:      # the headline was measured: an extra threw
+                _FS.out_of_time(f"{type(ex).__name__} in an extra: {ex}")
             _FS.fail(f"{type(ex).__name__}: {ex}", 1)
         raise
 

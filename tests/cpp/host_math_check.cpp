@@ -74,10 +74,23 @@ int main() {
     const Fq a = random_fq(), b = random_fq(), c = random_fq();
     CHECK((a + b) * c == a * c + b * c);
     CHECK(a.is_zero() || a * a.inv() == Fq::one());
+    CHECK(a.inv() == a.inv_fermat());                               // the binary inverse against its definition x^(p-2)
     CHECK(a - a == Fq::zero() && a.dbl() == a + a && a.sqr() == a * a);
     const Fq2 x{a, b}, y{c, a};
     CHECK(x * y == y * x && x.sqr() == x * x);
     CHECK(x.is_zero() || x * x.inv() == Fq2::one());
+  }
+  {   // edge values of the binary inverse: 0 -> 0, 1, 2, p - 1, p - 2, (p + 1) / 2 and 2000 more random values
+    CHECK(Fq::zero().inv() == Fq::zero() && Fq::one().inv() == Fq::one());
+    const Fq two = Fq::one() + Fq::one(), m1 = Fq::zero() - Fq::one(), m2 = m1 - Fq::one();
+    for (const Fq& e : {two, m1, m2, two.inv_fermat()}) CHECK(e.inv() == e.inv_fermat() && e * e.inv() == Fq::one());
+    for (int i = 0; i < 2000; i++) {
+      Fq a = random_fq();
+      if (i % 7 == 0) a.v[3] = a.v[2] = 0;                          // short values
+      if (i % 11 == 0) a.v[0] &= ~(uint64_t)0xffff;                 // many trailing zero bits
+      if (Fq::geq_p(a.v)) Fq::sub_p(a.v);
+      CHECK(a.inv() == a.inv_fermat());
+    }
   }
   // ---- G1: (a + b) G = a G + b G, doubling and cancellation paths
   for (int i = 0; i < 6; i++) {

@@ -23,6 +23,9 @@ fs.partial["value"] = 123.0
 print("armed", flush=True)
 if mode == "step":
     fs.beat("a collective nobody else joins", 0.3)
+if mode == "extra":
+    fs.base_line = {"metric": "msm_points_per_sec", "value": 7.5e8, "n_gpus": 1, "roofline": {"frac": 0.0118}}
+    fs.beat("an extra that hangs", 0.3)
 if mode == "ok":
     assert fs.emit({"metric": "msm_points_per_sec", "value": 1.0})
     assert not fs.emit({"second": True})          # one line only
@@ -60,6 +63,16 @@ def test_a_step_that_overstays_its_allowance(tmp_path):
     rc, lines, _, _ = _run_worker(tmp_path, "step")
     assert rc == 124 and len(lines) == 1
     assert "a collective nobody else joins" in json.loads(lines[0])["error"]
+
+
+def test_an_extra_that_hangs_costs_the_extras_not_the_headline(tmp_path):
+    """single rank, timed steps done (FailSafe.base_line is set), then an extra overstays: the run's line is the headline,
+    whole, with `incomplete` naming what is missing -- exit code 0, no `error` key"""
+    rc, lines, out, _ = _run_worker(tmp_path, "extra")
+    assert rc == 0 and len(lines) == 1 and "NOT REACHED" not in out
+    line = json.loads(lines[0])
+    assert line["value"] == 7.5e8 and "error" not in line and "an extra that hangs" in line["incomplete"]
+    assert line["roofline"]["frac"] == 0.0118 and line["partial_extras"]["value"] == 123.0
 
 
 def test_sigterm_from_the_launcher_while_blocked(tmp_path):
