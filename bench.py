@@ -331,8 +331,8 @@ def host_pointer_extra(scal, bases, want):
         dev.copy_(tp, non_blocking=True)
         torch.cuda.synchronize()
     out["h2d_pageable_GBs"] = 64 * n / best(h2d) / 1e6
-    out["note"] = ("PCIe-inclusive wall clock of the C call, best of 6, inputs in pageable host memory: sg_msm_g1 moves 96 MiB (two halves on two "
-                   "streams, the first half's MSM under the second half's upload), sg_commit 32 MiB against the resident SRS, sg_ntt_fr 32 MiB each way; "
+    out["note"] = ("PCIe-inclusive wall clock of the C call, best of 6, inputs in pageable host memory: sg_msm_g1 moves 96 MiB and sg_commit 32 MiB "
+                   "(against the resident SRS), each as two chunk jobs on two engines with the second chunk's upload under the first chunk's MSM; sg_ntt_fr 32 MiB each way; "
                    "h2d_pageable_GBs is the plain copy rate of this box (page-locked memory is no faster here, so there is no staging layer to add)")
     return out
 

@@ -174,6 +174,8 @@ class MsmEngine {
   uint32_t* d_hwin_ = nullptr;
 };
 
+// +1 / -1 on the count of jobs in flight (MsmEngine::others_in_flight), for callers that run several jobs side by side
+void msm_hold_in_flight(bool on);
 // FFT over G1 (N5): out = DFT_omega(in) [* scale], natural order; d_work: 2^log_n xyzz29_mem
 hipError_t g1_fft(const g1_affine_mem* d_in, g1_affine_mem* d_out, uint32_t log_n, const words8& omega,
                   const words8* scale, xyzz29_mem* d_work, hipStream_t stream);

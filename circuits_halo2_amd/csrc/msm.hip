@@ -1608,6 +1608,9 @@ hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars,
 // ---- phase 2: needs the task count on the host; enqueues accumulate .. export + result copy
 // jobs of this process between their first kernel and the end of their host tail (all engines, all lanes)
 static std::atomic<int> g_jobs_in_flight{0};
+// a caller that is about to run several jobs side by side on its own engines (the chunked host-pointer MSM) declares them
+// "in flight" for the length of the call, so that the first of them already launches politely
+void msm_hold_in_flight(bool on) { g_jobs_in_flight.fetch_add(on ? 1 : -1); }
 void MsmEngine::mark_in_flight(bool on) {
   if (on == counted_) return;
   counted_ = on;

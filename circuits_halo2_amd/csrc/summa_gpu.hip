@@ -667,63 +667,121 @@ int sg_msm_g1_dev_timed(const void* d_scalars, const void* d_bases, size_t n, vo
 int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* stream, uint8_t out_affine[64]) {
   return sg_msm_g1_dev_timed(d_scalars, d_bases, n, stream, out_affine, nullptr);
 }
-// sg_msm_g1 hands over host buffers: 96 bytes per pair have to cross the link (1.8 ms for 2^20 pairs at the 56 GB/s this
-// platform reaches from pageable memory just as from page-locked memory) before the last addition can run.  Large inputs
-// are therefore cut in two halves on two streams with the two engines of the lane: half A's MSM runs while half B is
-// still travelling, and the call costs about the upload plus ONE half's MSM instead of the upload plus the whole.
-// The copies of the second half are interleaved with the phases of the first so that the host's waits fall where the
-// device has work: [A up] front(A) [B scalars up] back(A) [B bases up] front(B) back(B) finish(A) finish(B), then A + B.
+// The host-pointer MSM entry points (sg_msm_g1: scalars and bases in host memory; sg_commit: scalars in host memory, bases
+// resident) pay the link -- 96 or 32 bytes per pair at the 56 GB/s this platform reaches from pageable memory just as from
+// page-locked memory -- before the last addition can run, and a lone MSM is a third latency chains (sort front end, bucket
+// reduction, host tail) besides.  Large inputs are therefore cut into K chunks that run as K jobs on the lane's two
+// engines (two streams) while a third stream carries the copies: chunk i's job runs while chunk i + 1 is still travelling,
+// and one job's latency chains run under the other's accumulation.  The K partial points are added on the host.
+//   [S0 B0] front(0) { back(i) [S i+1 B i+1] finish(i-1) front(i+1) } ... finish, sum
+// -- chunk i + 1 crosses the link while chunk i's accumulation runs.  K: "msm.host_chunks" (0 = by size: 2 from 2^18 pairs; more
+// chunks lose: every job brings its own latency chains, and small kernels beside an accumulation run slowly).
 static constexpr size_t MSM_HOST_SPLIT_MIN = (size_t)1 << 18;
+static std::atomic<int> g_host_chunks{0};
+static int msm_host_chunked(const uint8_t* scalars, const uint8_t* bases_host, const g1_affine_mem* d_bases_resident, size_t n,
+                            uint8_t out_affine[64]) {
+  Context& c = *g_ctx;
+  hipError_t e = c.stage_a.reserve(n ? n * 32 : 1);
+  if (e == hipSuccess && bases_host) e = c.stage_b.reserve(n ? n * 64 : 1);
+  if (e != hipSuccess) return hip_fail("staging buffer", e);
+  const fp_words* d_s = reinterpret_cast<const fp_words*>(c.stage_a.p);
+  const g1_affine_mem* d_b = bases_host ? reinterpret_cast<const g1_affine_mem*>(c.stage_b.p) : d_bases_resident;
+  uint32_t K = (uint32_t)g_host_chunks.load();
+  if (K == 0) K = n < MSM_HOST_SPLIT_MIN ? 1u : 2u;   // measured at 2^20 (profiles/r04_sweeps/host_chunks.txt): 2 is the best for both entry points
+  K = std::min<uint32_t>(K, 8u);
+  if (n < 2 * (size_t)K) K = 1;
+  if (K == 1) {
+    if (n) {
+      CHECK_HIP(hipMemcpyAsync(c.stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream), "H2D copy");
+      if (bases_host) CHECK_HIP(hipMemcpyAsync(c.stage_b.p, bases_host, n * 64, hipMemcpyHostToDevice, c.stream), "H2D copy");
+    }
+    e = c.msm.run(d_s, d_b, n, c.stream, out_affine, nullptr);
+    if (e != hipSuccess) return hip_fail("msm", e);
+    return SG_OK;
+  }
+  MsmEngine* eng[2] = {&c.msm, &c.msm_b};
+  hipStream_t st[2] = {c.stream, c.bstream[0]}, copy = c.bstream[1];
+  std::vector<size_t> lo(K + 1);
+  for (uint32_t i = 0; i <= K; i++) lo[i] = n * i / K;
+  std::vector<uint8_t> part(64 * (size_t)K, 0);
+  std::vector<hipEvent_t> ev_s(K, nullptr), ev_b(K, nullptr);
+  struct Events {
+    std::vector<hipEvent_t>&a, &b;
+    ~Events() {
+      for (auto v : {&a, &b})
+        for (hipEvent_t x : *v)
+          if (x) (void)hipEventDestroy(x);
+    }
+  } events_guard{ev_s, ev_b};
+  for (uint32_t i = 0; i < K; i++) {
+    CHECK_HIP(hipEventCreateWithFlags(&ev_s[i], hipEventDisableTiming), "event");
+    if (bases_host) CHECK_HIP(hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming), "event");
+  }
+  // the staging buffers may still be read by earlier work of the lane's stream: the other two streams start behind it
+  CHECK_HIP(hipEventRecord(c.ev_in, c.stream), "event");
+  CHECK_HIP(hipStreamWaitEvent(st[1], c.ev_in, 0), "stream wait");
+  CHECK_HIP(hipStreamWaitEvent(copy, c.ev_in, 0), "stream wait");
+  hipError_t err = hipSuccess;          // the first failure; from the first front on, every open job is still closed in order
+  auto copy_scalars = [&](uint32_t i) {
+    if (err != hipSuccess) return;
+    err = hipMemcpyAsync(c.stage_a.p + lo[i] * 32, scalars + lo[i] * 32, (lo[i + 1] - lo[i]) * 32, hipMemcpyHostToDevice, copy);
+    if (err == hipSuccess) err = hipEventRecord(ev_s[i], copy);
+  };
+  auto copy_bases = [&](uint32_t i) {
+    if (err != hipSuccess || !bases_host) return;
+    err = hipMemcpyAsync(c.stage_b.p + lo[i] * 64, bases_host + lo[i] * 64, (lo[i + 1] - lo[i]) * 64, hipMemcpyHostToDevice, copy);
+    if (err == hipSuccess) err = hipEventRecord(ev_b[i], copy);
+  };
+  int state[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per chunk: 0 nothing, 1 front enqueued, 2 back enqueued, 3 finished
+  auto front = [&](uint32_t i) {
+    if (err != hipSuccess) return;
+    err = hipStreamWaitEvent(st[i & 1], ev_s[i], 0);
+    if (err == hipSuccess) err = eng[i & 1]->enqueue_front(d_s + lo[i], d_b + lo[i], lo[i + 1] - lo[i], st[i & 1], part.data() + 64 * i, nullptr);
+    if (err == hipSuccess) state[i] = 1;
+  };
+  auto back = [&](uint32_t i) {
+    if (state[i] != 1) return;
+    hipError_t e2 = bases_host ? hipStreamWaitEvent(st[i & 1], ev_b[i], 0) : hipSuccess;
+    const hipError_t e3 = eng[i & 1]->enqueue_back();    // (always: an engine left with an open job would poison the lane's next call)
+    state[i] = e3 == hipSuccess ? 2 : 3;
+    if (err == hipSuccess) err = e2 != hipSuccess ? e2 : e3;
+  };
+  auto finish = [&](uint32_t i) {
+    if (state[i] != 2) return;
+    const hipError_t e2 = eng[i & 1]->finish();
+    state[i] = 3;
+    if (err == hipSuccess) err = e2;
+  };
+  // every job of the call is "one of several in flight" from the start: a first accumulation launched at three waves per SIMD
+  // (a job that believes it has the device to itself) would leave the second job's front end no registers to run in
+  struct InFlight {
+    InFlight() { msm_hold_in_flight(true); }
+    ~InFlight() { msm_hold_in_flight(false); }
+  } in_flight_guard;
+  copy_scalars(0);
+  copy_bases(0);
+  front(0);
+  for (uint32_t i = 0; i < K; i++) {
+    back(i);                              // (waits for chunk i's sort; then its accumulation is on the device ...)
+    if (i + 1 < K) {
+      copy_scalars(i + 1);                // ... and runs while the next chunk crosses the link (a copy from pageable memory blocks the host)
+      copy_bases(i + 1);
+      if (i >= 1) finish(i - 1);          // the engine chunk i + 1 runs on
+      front(i + 1);
+    }
+  }
+  for (uint32_t i = 0; i < K; i++) {       // whatever is still open (the last two jobs; everything after a failure)
+    back(i);
+    finish(i);
+  }
+  if (err != hipSuccess) return hip_fail("msm (host chunks)", err);
+  return sg_g1_sum_affine(part.data(), K, out_affine);
+}
+
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && (!scalars || !bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
-  {
-    LOCKED_CTX();
-    Context& c = *g_ctx;
-    hipError_t e = c.stage_a.reserve(n ? n * 32 : 1);
-    if (e == hipSuccess) e = c.stage_b.reserve(n ? n * 64 : 1);
-    if (e != hipSuccess) return hip_fail("staging buffer", e);
-    const fp_words* d_s = reinterpret_cast<const fp_words*>(c.stage_a.p);
-    const g1_affine_mem* d_b = reinterpret_cast<const g1_affine_mem*>(c.stage_b.p);
-    if (n < MSM_HOST_SPLIT_MIN) {
-      if (n) {
-        CHECK_HIP(hipMemcpyAsync(c.stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream), "H2D copy");
-        CHECK_HIP(hipMemcpyAsync(c.stage_b.p, bases, n * 64, hipMemcpyHostToDevice, c.stream), "H2D copy");
-      }
-      e = c.msm.run(d_s, d_b, n, c.stream, out_affine, nullptr);
-      if (e != hipSuccess) return hip_fail("msm", e);
-      return SG_OK;
-    }
-    const size_t h = n / 2, r = n - h;
-    hipStream_t sa = c.stream, sb = c.bstream[0];
-    uint8_t part[128];
-    // the staging buffers may still be read by earlier work of the lane's stream: the second stream starts behind it
-    CHECK_HIP(hipEventRecord(c.ev_in, sa), "event");
-    CHECK_HIP(hipStreamWaitEvent(sb, c.ev_in, 0), "stream wait");
-    hipError_t ce = hipMemcpyAsync(c.stage_a.p, scalars, h * 32, hipMemcpyHostToDevice, sa);
-    if (ce == hipSuccess) ce = hipMemcpyAsync(c.stage_b.p, bases, h * 64, hipMemcpyHostToDevice, sa);
-    if (ce != hipSuccess) return hip_fail("H2D copy", ce);
-    e = c.msm.enqueue_front(d_s, d_b, h, sa, part, nullptr);
-    if (e != hipSuccess) return hip_fail("msm", e);
-    // from here on both engines' jobs are closed in order whatever a copy does (an engine left with an open job would
-    // poison the lane's next call)
-    ce = hipMemcpyAsync(c.stage_a.p + h * 32, scalars + h * 32, r * 32, hipMemcpyHostToDevice, sb);
-    e = c.msm.enqueue_back();
-    if (ce == hipSuccess) ce = hipMemcpyAsync(c.stage_b.p + h * 64, bases + h * 64, r * 64, hipMemcpyHostToDevice, sb);
-    hipError_t e2 = hipSuccess;
-    bool b_open = false;
-    if (ce == hipSuccess && e == hipSuccess) {
-      e2 = c.msm_b.enqueue_front(d_s + h, d_b + h, r, sb, part + 64, nullptr);
-      b_open = e2 == hipSuccess;
-      if (b_open) e2 = c.msm_b.enqueue_back();
-    }
-    if (e == hipSuccess) e = c.msm.finish();
-    if (b_open && e2 == hipSuccess) e2 = c.msm_b.finish();
-    else if (b_open) (void)c.msm_b.finish();
-    if (ce != hipSuccess) return hip_fail("H2D copy", ce);
-    if (e != hipSuccess) return hip_fail("msm", e);
-    if (e2 != hipSuccess) return hip_fail("msm", e2);
-    return sg_g1_sum_affine(part, 2, out_affine);
-  }
+  LOCKED_CTX();
+  return msm_host_chunked(scalars, bases, nullptr, n, out_affine);
 }
 
 // A batch of independent MSMs (the commitments of one prover phase): two engines on two
@@ -1307,6 +1365,14 @@ int sg_commit(uint64_t srs_handle, int basis, const uint8_t* scalars, size_t n, 
   if (!find_srs(srs_handle, &srs_v)) return fail(SG_ERR_INVALID, "unknown SRS handle");
   Srs* srs_p = &srs_v;
   if (n > ((size_t)1 << (*srs_p).k)) return fail(SG_ERR_INVALID, "sg_commit: polynomial longer than the SRS");
+  {
+    // no window table for this basis (sg_srs_precompute not called): the generic MSM over the resident bases, in chunks, so that
+    // the scalars' upload and one job's latency chains run under another job's accumulation (msm_host_chunked)
+    const Srs& sr = *srs_p;
+    const int b = (basis == 2 && !diff_form_ready(sr, n)) ? 1 : basis;
+    if (b != 2 && !sr.tab[b].table && n >= MSM_HOST_SPLIT_MIN)
+      return msm_host_chunked(scalars, nullptr, b ? sr.g_lagrange : sr.g, n, out_affine);
+  }
   TRY(upload(g_ctx->stage_a, scalars, n * 32, g_ctx->stream));
   hipError_t e = commit_run((*srs_p), basis, reinterpret_cast<const fp_words*>(g_ctx->stage_a.p), n, g_ctx->stream,
                             out_affine);
@@ -2705,6 +2771,10 @@ int sg_set_param(const char* name, int value) {
   }
   if (s == "commit.combine_target") {
     g_comb.target.store(std::max(1, std::min(value, 32)));
+    return SG_OK;
+  }
+  if (s == "msm.host_chunks") {   // chunks of the host-pointer MSM entry points (0 = by size)
+    g_host_chunks.store(std::min(value, 8));
     return SG_OK;
   }
   if (s == "host.wait_sleep_us") {   // how host threads wait for the device (csrc/host_wait.h): 0 = the runtime's wait, > 0 = poll and sleep

@@ -490,6 +490,8 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   are pending), "commit.combine_runners" (default 1: fused jobs that may run side by side, each on a lane of its own) -- see
  *   sg_commit_combine_begin; process-wide, they stay as set until set again,
  * "host.wait_sleep_us" (0 | 1..1000: see sg_stream_wait; process-wide, takes effect at once),
+ * "msm.host_chunks" (0 = by size | 1..8: the host-pointer entry points sg_msm_g1 / sg_commit cut inputs of 2^18 pairs and more into
+ *   that many chunks, which run as jobs on two engines while the next chunk is uploaded; default 2),
  * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that
  *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",

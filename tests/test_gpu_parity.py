@@ -632,8 +632,8 @@ def test_host_pointer_entry_points_from_many_threads(gpu, O):
 
 @pytest.mark.parametrize("n", [(1 << 18) - 1, 1 << 18, (1 << 18) + 1, (1 << 19) + 12345])
 def test_host_pointer_msm_in_two_halves(gpu, O, n):
-    """sg_msm_g1 from host memory cuts inputs of 2^18 pairs and more in two halves on two streams with the lane's two
-    engines (the first half's MSM runs under the second half's upload) and adds the two partial points on the host: the
+    """sg_msm_g1 / sg_commit from host memory cut inputs of 2^18 pairs and more into chunks that run as jobs on the lane's two
+    engines while a third stream carries the copies, and add the partial points on the host: the
     same point as the device path and as <k, s> G, at the threshold, around it, for an odd length, with an all-zero first
     half (its job finds nothing to do), from memory registered with sg_host_register, and under the sleeping host wait"""
     import ctypes as C
@@ -675,6 +675,19 @@ def test_host_pointer_msm_in_two_halves(gpu, O, n):
     assert (host_msm(hz, hb) == tail).all()
     hz[:] = 0
     assert not host_msm(hz, hb).any()                                                            # identity = 64 zero bytes
+    # every chunk count, and the resident-SRS flavour (sg_commit: scalars from the host, bases in HBM, generic path)
+    k_srs = (n - 1).bit_length()
+    pad = (1 << k_srs) - n
+    params = gpu.ParamsKZG(k_srs, np.concatenate([hb, np.zeros(64 * pad, dtype=np.uint8)]), np.concatenate([hb, np.zeros(64 * pad, dtype=np.uint8)]))
+    try:
+        for chunks in (1, 2, 3, 4, 8, 0):
+            ffi.check(L.sg_set_param(b"msm.host_chunks", chunks))
+            assert (host_msm(hs, hb) == want).all(), chunks
+            ffi.check(L.sg_commit(C.c_uint64(params.handle()), C.c_int(0), ffi.ptr(hs), C.c_size_t(n), ffi.ptr(out)))
+            assert (out == want).all(), chunks
+    finally:
+        ffi.check(L.sg_set_param(b"msm.host_chunks", 0))
+        params.free()
 
 
 def test_two_host_threads_do_not_serialise(gpu, O):
