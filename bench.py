@@ -1201,7 +1201,8 @@ def _main():
                 line["proofs_per_s"] = batch_line["proofs_per_s"]
                 batch_line["roofline"] = proof_roofline(1e3 / batch_line["proofs_per_s"] * world,
                                                         "per proof of the batch: GPU-time per proof = n_gpus / proofs_per_s")
-                if world == 1 and not args.no_cpu_share_sweep and not args.no_extras and batch_line.get("proofs_total", 0) >= 64:
+                under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ)
+                if world == 1 and not args.no_cpu_share_sweep and not args.no_extras and not under_profiler and batch_line.get("proofs_total", 0) >= 64:
                     # what one of 8 / 4 / 2 ranks sharing this host's CPUs would get (child runs under --cpu-share)
                     batch_line["cpu_share_rehearsal"] = cpu_share_rehearsal(args, batch_line["in_flight"], batch_line.get("host_cores_busy_per_gpu"))
         # BASELINE's metric is "proof-gen wall-clock + MSM-points/sec": the proof half where a reader of `config` / `roofline`
