@@ -201,8 +201,8 @@ class ParamsKZG:
 
     def commit_batch_mixed(self, polys, lagrange_flags) -> np.ndarray:
         """like commit_batch with one basis per polynomial (False / 0 = coefficients, True / 1 = Lagrange form, 2 = Lagrange
-        form with the piecewise-constant hint): one fused job for a phase that commits to both kinds (grand products +
-        the random polynomial)"""
+        form with the piecewise-constant hint; any of them | 16 = SG_BASIS_SPARSE, the "witness-like column" scheduling hint
+        of include/summa_gpu.h): one fused job for a phase that commits to both kinds"""
         m = len(polys)
         out = np.zeros((m, 64), dtype=np.uint8)
         if m == 0:
@@ -217,8 +217,8 @@ class ParamsKZG:
             raise ValueError("polynomial longer than the SRS")
         ptrs = (C.c_void_p * m)(*[p.data_ptr() for p in polys])
         flags = (C.c_int * m)(*[int(f) for f in lagrange_flags])
-        if any(f not in (0, 1, 2) for f in flags):
-            raise ValueError("commit_batch_mixed: flags are 0, 1 or 2")
+        if any((f & ~16) not in (0, 1, 2) for f in flags):
+            raise ValueError("commit_batch_mixed: flags are 0, 1 or 2, optionally | 16 (SG_BASIS_SPARSE)")
         ffi.check(ffi.lib().sg_commit_batch_mixed_dev(C.c_uint64(self.handle()), flags, ptrs, C.c_size_t(m), C.c_size_t(n),
                                                       ffi.current_stream_ptr(), ffi.ptr(out)))
         return out

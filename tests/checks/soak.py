@@ -23,6 +23,12 @@ while time.time() - t0 < budget:
     rounds += 1
     for name in ("msm.two_pass", "msm.quad", "msm.red2d"):
         ffi.check(ffi.lib().sg_set_param(name.encode(), C.c_int64(int(rng.integers(0, 3)))))
+    # round 4: the fold pass in front of the 2-D line sums (on / off; a quad or a lane per bucket), the reduction's chunk, sleeping waits
+    ffi.check(ffi.lib().sg_set_param(b"msm.red2d_prefold", C.c_int64(int(rng.integers(0, 2)))))
+    ffi.check(ffi.lib().sg_set_param(b"msm.prefold_quad_buckets", C.c_int64(int(rng.choice([0, 1 << 12, 1 << 15, 1 << 18])))))
+    ffi.check(ffi.lib().sg_set_param(b"msm.red2d_max_sets", C.c_int64(int(rng.choice([4, 6, 8])))))
+    ffi.check(ffi.lib().sg_set_param(b"msm.log_red_chunk", C.c_int64(int(rng.choice([0, 0, 2, 3, 4])))))
+    ffi.check(ffi.lib().sg_set_param(b"host.wait_sleep_us", C.c_int64(int(rng.choice([0, 0, 20])))))
     ffi.check(ffi.lib().sg_set_param(b"msm.acc_threads", C.c_int64(int(rng.choice([0, 64, 128, 256])))))
     if rounds % 3 == 1:
         params.free()
@@ -41,8 +47,9 @@ while time.time() - t0 < budget:
             sc = O.random_fr(int(rng.integers(1 << 30)), n); sc[: 32 * (n // 2)] = 0                     # half zeros
         cols.append(sc)
     flags = [bool(rng.integers(2)) for _ in range(m)]
+    sparse_hint = 16 if rng.integers(2) else 0          # SG_BASIS_SPARSE on every column: same commitments
     want = np.stack([O.best_multiexp(c, (bases_l if f else bases)[: 64 * n], O.ncpu()) for c, f in zip(cols, flags)])
-    got = params.commit_batch_mixed([dev(c) for c in cols], flags)
+    got = params.commit_batch_mixed([dev(c) for c in cols], [int(f) | sparse_hint for f in flags])
     if not (got == want).all():
         print("MISMATCH commit_batch_mixed", n, m, kind, flags); sys.exit(1)
     one = params.commit(dev(cols[0])) if not flags[0] else params.commit_lagrange(dev(cols[0]))

@@ -630,6 +630,38 @@ def test_host_pointer_entry_points_from_many_threads(gpu, O):
     assert not errors, errors
 
 
+def test_sparse_hint_changes_the_schedule_not_the_commitments(gpu, O):
+    """SG_BASIS_SPARSE (basis | 16): witness-like columns -- a few thousand small values, the rest zero, heavy buckets -- get
+    shorter accumulation tasks when every column of the job carries the hint; with it, without it and with it on some columns
+    only the commitments are the same points, for plain Lagrange columns and for difference-form ones"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A
+    k = 14
+    n = 1 << k
+    bases = O.fixed_base_mul(O.random_fr(3300, n), O.ncpu())
+    params = gpu.ParamsKZG(k, bases, bases)
+    params.precompute()
+    try:
+        rng = np.random.default_rng(33)
+        cols = []
+        for c in range(3):
+            vals = np.zeros((n, 32), dtype=np.uint8)
+            used = 3000 + 500 * c
+            vals[:used, 0] = rng.integers(0, 256, used)             # bytes of a range check
+            vals[:used:7, 1] = rng.integers(0, 4, len(vals[:used:7]))
+            cols.append(A.fr_to_montgomery(torch.from_numpy(vals.reshape(-1)).cuda()))
+        for flags in ([1, 1, 1], [2, 2, 1], [0, 1, 2]):
+            plain = params.commit_batch_mixed(cols, flags)
+            assert (params.commit_batch_mixed(cols, [f | 16 for f in flags]) == plain).all()
+            assert (params.commit_batch_mixed(cols, [flags[0] | 16] + flags[1:]) == plain).all()
+        want = np.stack([O.best_multiexp(c.cpu().numpy(), bases, O.ncpu()) for c in cols])
+        assert (params.commit_batch_mixed(cols, [17, 17, 17]) == want).all()
+        with pytest.raises(ValueError):
+            params.commit_batch_mixed(cols, [3, 1, 1])
+    finally:
+        params.free()
+
+
 @pytest.mark.parametrize("n", [(1 << 18) - 1, 1 << 18, (1 << 18) + 1, (1 << 19) + 12345])
 def test_host_pointer_msm_in_two_halves(gpu, O, n):
     """sg_msm_g1 / sg_commit from host memory cut inputs of 2^18 pairs and more into chunks that run as jobs on the lane's two
