@@ -35,6 +35,7 @@ struct MsmConfig {
   uint32_t prefold_quad_buckets = 1u << 15;  // ... with a quad per bucket up to this many buckets in the job, one lane per bucket beyond
   uint32_t acc_chain = 1;      // accumulations of different jobs run one after the other (each waits for the previous launch's event)
   uint32_t red_lean = 1;       // level-0 bucket reduction within 168 registers (fits beside a polite accumulation): 0 never, 1 when other jobs are in flight, 2 always
+  uint32_t acc_trace = 0;      // debug: msm_accumulate records when each wave starts and leaves; finish() prints the percentiles to stderr
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
 
@@ -165,6 +166,7 @@ class MsmEngine {
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
   DevBuf<xyzz29_mem> partial_[2], red_a_[2], red_s_[2], red_r_[2];
   DevBuf<uint32_t> win_words_;
+  DevBuf<uint64_t> trace_;
   DevBuf<uint32_t> part_entry_, ccnt_, coff_;  // two-pass sort: partitioned entries, coarse-bin counts / offsets
   DevBuf<uint16_t> part_fine_;
   uint32_t* h_meta_ = nullptr;   // page-locked, written by the scan kernels through d_hmeta_ (its device address)

@@ -591,9 +591,12 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ toff,
                                                       const uint2* __restrict__ order, uint32_t log_L,
                                                       const uint32_t* __restrict__ meta, uint32_t* __restrict__ ticket,
-                                                      xyzz29_mem* __restrict__ partial) {
+                                                      xyzz29_mem* __restrict__ partial, uint64_t* __restrict__ trace) {
   // launched before the host has read the counters back (the read overlaps this kernel); the exact task count is meta[1]
   const uint32_t ntasks = meta[1], lane = threadIdx.x & 63u;
+  // debug (msm.acc_trace): when every wave starts and leaves (wall_clock64 ticks)
+  const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (trace && lane == 0) trace[2 * wave_id] = wall_clock64();
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(ticket, 64u);
@@ -625,6 +628,7 @@ __global__ void __launch_bounds__(256) msm_accumulate(const uint32_t* __restrict
       xyzz29_store(partial + toff[b] + seg, acc);
     }
   }
+  if (trace && lane == 0) trace[2 * wave_id + 1] = wall_clock64();
 }
 
 // Every kernel below is written for LOGICAL threads of Q lanes: Q = 1 is one lane per point
@@ -1269,7 +1273,7 @@ void MsmEngine::release() {
       e = nullptr;
     }
   }
-  win_words_.release(); part_entry_.release(); part_fine_.release(); ccnt_.release(); coff_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
+  win_words_.release(); trace_.release(); part_entry_.release(); part_fine_.release(); ccnt_.release(); coff_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_a_[i].release(); red_s_[i].release(); red_r_[i].release();
   }
@@ -1685,9 +1689,10 @@ hipError_t MsmEngine::enqueue_back_impl() {
   const uint32_t wg_all = (ntasks_ub + at - 1) / at;
   const uint32_t wg = waves >= 8 ? wg_all : std::min<uint32_t>(wg_all, cus_ * (waves * 4 * 64 / at));
   j.acc_threads = wg * at;
+  if (cfg_.acc_trace) SG_TRY(trace_.reserve((size_t)2 * wg * at / 64));
   SG_TRY(chained_accumulate(stream, j.tm ? j.ev[5] : nullptr, [&]() {
     msm_accumulate<<<wg, at, 0, stream>>>(sorted_.p, j.bp, Wm * nbw, off_.p, counts_.p, toff_[0].p, order_.p, log_L, meta_.p,
-                                          meta_.p + ACC_TICKET, partial_[0].p);
+                                          meta_.p + ACC_TICKET, partial_[0].p, cfg_.acc_trace ? trace_.p : nullptr);
   }));
   SG_TRY(host_wait_event(ev_meta_));
   const volatile uint32_t* hm = h_meta_;   // written by the device (msm_scan_sums / msm_scan_small), complete with the event
@@ -1926,6 +1931,26 @@ hipError_t MsmEngine::finish_impl() {
     }
   }
 
+  if (cfg_.acc_trace && j.acc_threads) {
+    // debug: when the waves of the accumulation left, as a share of the launch's span (first start .. last exit)
+    const size_t waves = j.acc_threads / 64;
+    std::vector<uint64_t> t(2 * waves);
+    if (hipMemcpy(t.data(), trace_.p, t.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+      uint64_t t0 = ~0ull, t1 = 0;
+      for (size_t w = 0; w < waves; w++) { t0 = std::min(t0, t[2 * w]); t1 = std::max(t1, t[2 * w + 1]); }
+      std::vector<double> ends(waves);
+      size_t late = 0;
+      const double span = (double)(t1 - t0) / 100.0;
+      for (size_t w = 0; w < waves; w++) {
+        ends[w] = (double)(t[2 * w + 1] - t0) / span;
+        late += (double)(t[2 * w] - t0) / span > 5.0 ? 1 : 0;
+      }
+      std::sort(ends.begin(), ends.end());
+      auto pct = [&](double q) { return ends[std::min(waves - 1, (size_t)(q * (double)waves))]; };
+      std::fprintf(stderr, "[acc_trace] waves %zu (%zu started after 5 %% of the span), span %.0f ticks; 1 %% of the waves had left by %.1f %% of it, 10 %% by %.1f, 25 %% by %.1f, 50 %% by %.1f, 75 %% by %.1f, 90 %% by %.1f, 99 %% by %.1f\n",
+                   waves, late, span * 100.0, pct(0.01), pct(0.10), pct(0.25), pct(0.50), pct(0.75), pct(0.90), pct(0.99));
+    }
+  }
   if (j.tm) {
     MsmTimings* tm = j.tm;
     float ms;

@@ -447,6 +447,7 @@ int apply_param(Context& c, const std::string& s, int value) {
     if (e == hipSuccess) e = abi_set_side_prio(on);
     if (e != hipSuccess) return hip_fail("side_prio", e);
   }
+  else if (s == "msm.acc_trace") c.msm.config().acc_trace = c.msm_b.config().acc_trace = value ? 1u : 0u;
   else if (s == "msm.acc_chain") c.msm.config().acc_chain = c.msm_b.config().acc_chain = value ? 1u : 0u;
   else if (s == "msm.red_lean") c.msm.config().red_lean = c.msm_b.config().red_lean = (uint32_t)std::max(0, std::min(2, value));
   else if (s == "msm.acc_waves_fixed") c.msm.config().acc_waves_fixed = c.msm_b.config().acc_waves_fixed = (uint32_t)std::max(0, std::min(8, value));

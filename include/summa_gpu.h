@@ -492,6 +492,8 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  * "host.wait_sleep_us" (0 | 1..1000: see sg_stream_wait; process-wide, takes effect at once),
  * "msm.host_chunks" (0 = by size | 1..8: the host-pointer entry points sg_msm_g1 / sg_commit cut inputs of 2^18 pairs and more into
  *   that many chunks, which run as jobs on two engines while the next chunk is uploaded; default 2),
+ * "msm.acc_trace" (0 | 1: debug -- every wave of msm_accumulate records when it starts and leaves; the job's host tail prints the
+ *   percentiles to stderr: tools/acc_trace.sh, profiles/r04_sweeps/accumulate_tail.txt),
  * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that
  *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",
