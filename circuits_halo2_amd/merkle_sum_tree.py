@@ -65,6 +65,27 @@ def _to_fr_bytes(v: int) -> bytes:
     return ((v % R_MODULUS) << 256).__mod__(R_MODULUS).to_bytes(32, "little")
 
 
+def big_intify_username(username: str) -> int:
+    """utils/operation_helpers.rs:5-8: keccak256 of the username bytes as a big-endian integer"""
+    return int.from_bytes(keccak256(username.encode()), "big")
+
+
+def big_uint_to_fp(big_uint: int) -> bytes:
+    """utils/operation_helpers.rs:10-12 (`Fp::from_str_vartime` of the decimal string): the integer reduced modulo r, in
+    halo2curves' memory form (32 bytes, Montgomery, little-endian) -- what every `_dev` entry point takes"""
+    if big_uint < 0:
+        raise ValueError("Invalid balance")
+    return _to_fr_bytes(big_uint)
+
+
+def fp_to_big_uint(f) -> int:
+    """utils/operation_helpers.rs:15-17: the canonical integer of a field element given in memory form"""
+    v = int.from_bytes(bytes(f), "little")
+    if v >= R_MODULUS:
+        raise ValueError("not a field element")
+    return v * pow(1 << 256, -1, R_MODULUS) % R_MODULUS
+
+
 def parse_csv_to_entries(path: str, n_currencies: int):
     """utils/csv_parser.rs: header `username,balance_<name>_<chain>,...`; one balance per
     currency column; raises if the column count differs from n_currencies (the reference's
@@ -112,9 +133,9 @@ def _hash_batch(kind: str, *arrays, n: int, nc: int):
 
 
 class MerkleSumTree:
-    """MerkleSumTree<N_CURRENCIES, N_BYTES> (mst.rs): `from_csv`, `from_csv_sorted`, `from_entries`, `root`,
-    `leaves`, `entries`, `index_of_username`, `update_leaf`; Tree trait (tree.rs): `generate_proof`,
-    `verify_proof`.  All Poseidon hashing runs on the device; nodes are kept level-major on the host."""
+    """MerkleSumTree<N_CURRENCIES, N_BYTES> (mst.rs): `from_csv`, `from_csv_sorted`, `from_entries`, `from_params`, `root`,
+    `leaves`, `entries`, `index_of_username`, `update_leaf`; Tree trait (tree.rs): `depth`, `nodes`, `cryptocurrencies`,
+    `get_entry`, the two preimage getters, `generate_proof`, `verify_proof`; `Entry::compute_leaf / recompute_leaf` by index.  All Poseidon hashing runs on the device; nodes are kept level-major on the host."""
 
     def __init__(self, depth, n_currencies, entries, node_hashes, node_balances, is_sorted=False, cryptocurrencies=None):
         self.depth, self.n_currencies, self.entries = depth, n_currencies, entries
@@ -142,7 +163,7 @@ class MerkleSumTree:
     def _entry_fields(name: str, bal):
         """(username field element, balance field elements) as Montgomery bytes; the zero entry is ("0", 0...)
         with username field element 0 (entry.rs:30-38)"""
-        u = 0 if name is None else int.from_bytes(keccak256(name.encode()), "big")
+        u = 0 if name is None else big_intify_username(name)
         return _to_fr_bytes(u), b"".join(_to_fr_bytes(v) for v in bal)
 
     @classmethod
@@ -177,6 +198,42 @@ class MerkleSumTree:
         torch.cuda.synchronize()
         padded = list(entries) + [(None, [0] * n_currencies)] * (size - n)
         return cls(depth, n_currencies, padded, d_h.cpu().numpy(), d_b.cpu().numpy(), is_sorted)
+
+    @classmethod
+    def from_params(cls, root, nodes, depth: int, entries, cryptocurrencies, is_sorted: bool, n_currencies: int | None = None):
+        """mst.rs:137-159: a tree from parts computed elsewhere -- `nodes[level][index]` = (hash, balances) in memory
+        form, level 0 the leaves, `root` = (hash, balances).  The reference stores what it is given; here the shape is
+        checked as well (2^(depth - level) nodes per level, the root equal to the top node), because the level-major
+        buffers below have no room for a ragged tree."""
+        if len(nodes) != depth + 1 or any(len(nodes[l]) != 1 << (depth - l) for l in range(depth + 1)):
+            raise ValueError("nodes: expected 2^(depth - level) nodes on every level")
+        nc = n_currencies if n_currencies is not None else len(bytes(nodes[0][0][1])) // 32
+        hs = np.frombuffer(b"".join(bytes(h) for lvl in nodes for h, _ in lvl), dtype=np.uint8).copy()
+        bs = np.frombuffer(b"".join(bytes(b) for lvl in nodes for _, b in lvl), dtype=np.uint8).copy()
+        total = (2 << depth) - 1
+        if hs.size != 32 * total or bs.size != 32 * nc * total:
+            raise ValueError("nodes: every node is a 32-byte hash and n_currencies 32-byte balances")
+        if bytes(root[0]) != bytes(nodes[depth][0][0]) or bytes(root[1]) != bytes(nodes[depth][0][1]):
+            raise ValueError("root differs from the top node")
+        size = 1 << depth
+        padded = list(entries) + [(None, [0] * nc)] * (size - len(entries))
+        return cls(depth, nc, padded, hs, bs, is_sorted, list(cryptocurrencies))
+
+    def nodes(self):
+        """tree.rs:15 `nodes()`: every level, leaves first, as lists of (hash, balances) views"""
+        return [[self.node(level, i) for i in range(1 << (self.depth - level))] for level in range(self.depth + 1)]
+
+    def compute_leaf(self, index: int):
+        """entry.rs:40-47 `Entry::compute_leaf` of entry `index`: (hash, balances), hashed on the device"""
+        return self.recompute_leaf(index, self.entries[index][1])
+
+    def recompute_leaf(self, index: int, updated_balances):
+        """entry.rs:50-58 `Entry::recompute_leaf`: the leaf this entry would have with other balances (nothing is stored)"""
+        if len(updated_balances) != self.n_currencies:
+            raise ValueError("wrong number of balances")
+        u, b = self._entry_fields(self.entries[index][0], updated_balances)
+        bb = np.frombuffer(b, dtype=np.uint8)
+        return _hash_batch("leaf", np.frombuffer(u, dtype=np.uint8), bb, n=1, nc=self.n_currencies), bb.copy()
 
     def _level_offset(self, level: int) -> int:
         size = 1 << self.depth

@@ -375,3 +375,17 @@ def test_library_keccak_and_the_cross_checked_final_exponentiation():
         g2b = np.frombuffer(b"".join(PR.g2_to_bytes(q) for _, q in pairs), dtype=np.uint8).copy()
         ok = C.c_int(-1)
         assert ffi.lib().sg_pairing_check_slow(ffi.ptr(g1b), ffi.ptr(g2b), C.c_size_t(2), C.byref(ok)) == 0 and ok.value == want
+
+
+def test_operation_helpers_round_trip():
+    """utils/operation_helpers.rs:5-17: `big_uint_to_fp` / `fp_to_big_uint` are inverse on [0, r), reduce beyond it as
+    `Fp::from_str_vartime` does, and write halo2curves' memory form (Montgomery, little-endian)"""
+    from circuits_halo2_amd.merkle_sum_tree import big_uint_to_fp, fp_to_big_uint
+    for v in (0, 1, 3, 18446744073709551616, PR.R - 1):
+        b = big_uint_to_fp(v)
+        assert len(b) == 32 and int.from_bytes(b, "little") == (v << 256) % PR.R and fp_to_big_uint(b) == v
+    assert fp_to_big_uint(big_uint_to_fp(PR.R + 5)) == 5
+    with pytest.raises(ValueError):
+        big_uint_to_fp(-1)
+    with pytest.raises(ValueError):
+        fp_to_big_uint((PR.R).to_bytes(32, "little"))

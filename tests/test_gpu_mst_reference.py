@@ -195,3 +195,35 @@ def test_tree_with_zero_element_2():
     with pytest.raises(IndexError):
         merkle_tree.generate_proof(32)
     _same_as_oracle(merkle_tree)
+
+
+def test_from_params_nodes_and_entry_leaves():
+    """mst.rs:137-159 `from_params`, tree.rs:15 `nodes()`, entry.rs:40-58 `compute_leaf` / `recompute_leaf`: a tree taken
+    apart and put together again is the same tree (root, proofs, lookups); ragged parts are refused; an entry's leaf is
+    the tree's leaf, and with other balances the leaf `update_leaf` would store"""
+    from circuits_halo2_amd.merkle_sum_tree import MerkleSumTree, big_uint_to_fp, fp_to_big_uint, big_intify_username
+    tree = _tree("entry_16.csv")
+    nodes = tree.nodes()
+    assert len(nodes) == tree.depth + 1 == 5 and [len(l) for l in nodes] == [16, 8, 4, 2, 1]
+    again = MerkleSumTree.from_params(tree.root(), nodes, tree.depth, tree.entries, tree.cryptocurrencies, tree.is_sorted)
+    assert again.n_currencies == N_CURRENCIES and again.cryptocurrencies == tree.cryptocurrencies
+    assert bytes(again.root()[0]) == bytes(tree.root()[0]) and bytes(again.root()[1]) == bytes(tree.root()[1])
+    assert again.index_of_username("AtwIxZHo") == tree.index_of_username("AtwIxZHo")
+    for i in (0, 7, 15):
+        assert again.verify_proof(again.generate_proof(i)) and tree.verify_proof(again.generate_proof(i))
+    with pytest.raises(ValueError):
+        MerkleSumTree.from_params(tree.root(), nodes[:-1], tree.depth, tree.entries, [], False)
+    with pytest.raises(ValueError):
+        MerkleSumTree.from_params(tree.node(0, 0), nodes, tree.depth, tree.entries, [], False)
+    # Entry::compute_leaf == the stored leaf; recompute_leaf == what update_leaf stores
+    for i in (0, 3, 15):
+        h, b = tree.compute_leaf(i)
+        assert bytes(h) == bytes(tree.node(0, i)[0]) and bytes(b) == bytes(tree.node(0, i)[1])
+    name, _ = tree.entries[3]
+    h2, b2 = tree.recompute_leaf(3, [11, 22])
+    assert _ints(b2) == [11, 22] and bytes(h2) != bytes(tree.node(0, 3)[0])
+    tree.update_leaf(name, [11, 22])
+    assert bytes(tree.node(0, 3)[0]) == bytes(h2)
+    # operation_helpers.rs
+    assert fp_to_big_uint(big_uint_to_fp(18446744073709551616)) == 18446744073709551616
+    assert _ints(tree.get_leaf_node_hash_preimage(3))[0] == big_intify_username(name) % R
