@@ -342,6 +342,25 @@ def test_msm_skewed_buckets(gpu, O, P, srs11):
     assert (gpu.best_multiexp(bytes_like, bases) == O.best_multiexp(bytes_like, bases, O.ncpu())).all()
 
 
+def test_msm_accumulate_trace_leaves_results_alone(gpu, O, capfd):
+    """`msm.acc_trace` (debug: every wave of msm_accumulate records when it starts and leaves; the host tail prints the
+    percentiles): same bits with it on, a line on stderr per job, nothing once it is off again"""
+    from circuits_halo2_amd import ffi
+    n = 1 << 12
+    sc = O.random_fr(77, n)
+    bases = O.fixed_base_mul(O.random_fr(78, n), O.ncpu())
+    want = O.best_multiexp(sc, bases, O.ncpu())
+    ffi.check(ffi.lib().sg_set_param(b"msm.acc_trace", 1))
+    try:
+        assert (gpu.best_multiexp(sc, bases) == want).all()
+    finally:
+        ffi.check(ffi.lib().sg_set_param(b"msm.acc_trace", 0))
+    err = capfd.readouterr().err
+    assert "[acc_trace] waves" in err and "had left by" in err
+    assert (gpu.best_multiexp(sc, bases) == want).all()
+    assert "[acc_trace]" not in capfd.readouterr().err
+
+
 def test_msm_batch_pipeline(gpu, O):
     """sg_msm_g1_batch: independent MSMs of different sizes pipelined over two engines"""
     sizes = [1 << 12, 0, 3000, 1 << 14, 1, 5000, 1 << 13]
