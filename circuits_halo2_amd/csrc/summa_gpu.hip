@@ -415,8 +415,7 @@ int upload(DevBuf<uint8_t>& buf, const uint8_t* host, size_t bytes, hipStream_t 
   return SG_OK;
 }
 int download(uint8_t* host, const void* dev, size_t bytes, hipStream_t s) {
-  CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s), "D2H copy");
-  CHECK_HIP(host_wait_stream(s), "stream sync");
+  CHECK_HIP(host_copy_d2h(host, dev, bytes, s), "D2H copy");
   return SG_OK;
 }
 
@@ -974,8 +973,7 @@ int sg_srs_check(uint64_t handle, uint64_t* bad_out) {
   const size_t n = (size_t)1 << srs_p->k;
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
     e = g1_on_curve(b ? srs_p->g_lagrange : srs_p->g, n, reinterpret_cast<uint32_t*>(cnt), s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&h[b], cnt, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = host_wait_stream(s);
+    if (e == hipSuccess) e = host_copy_d2h(&h[b], cnt, 4, s);
   }
   if (e != hipSuccess) return hip_fail("sg_srs_check", e);
   *bad_out = (uint64_t)h[0] + h[1];
@@ -2021,8 +2019,7 @@ int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t
   if (e == hipSuccess) e = fr_montgomery(pa, pa, rows, 1, s);
   if (e == hipSuccess) e = fr_montgomery(ps, ps, rows, 1, s);
   uint32_t h_flag = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag, sizeof h_flag, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = host_wait_stream(s);
+  if (e == hipSuccess) e = host_copy_d2h(&h_flag, flag, sizeof h_flag, s);
   if (e != hipSuccess) return hip_fail("lookup permutation", e);
   if (h_flag == 2) return fail(SG_ERR_UNSUPPORTED, "sg_lookup_permute_small: a table value is not below 2^16 (use the general path)");
   if (h_flag == 1) return fail(SG_ERR_WITNESS, "sg_lookup_permute_small: an input value is not in the table");
@@ -2296,8 +2293,7 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
                          remainder_out ? tmp + 1024 : nullptr, s);
   // asynchronous unless the caller wants the remainder on the host
   if (e == hipSuccess && remainder_out) {
-    e = hipMemcpyAsync(remainder_out, tmp + 1024, 32, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = host_wait_stream(s);
+    e = host_copy_d2h(remainder_out, tmp + 1024, 32, s);
   }
   if (e != hipSuccess) return hip_fail("kate_division", e);
   return SG_OK;

@@ -546,6 +546,9 @@ inline void release_column_pool() {
   column_pool().clear();
 }
 inline void d2h(void* host, const void* dev, size_t bytes) {   // ordered on the thread's main stream, complete on return
+  // (the stream is drained by the library's wait FIRST -- asleep when "host.wait_sleep_us" is set: a copy into pageable memory
+  // waits for everything ahead of it inside hipMemcpyAsync, busily; csrc/host_wait.h, host_copy_d2h)
+  ck(sg_stream_wait(main_stream()), "sync");
   hk(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, main_stream()), "D2H");
   ck(sg_stream_wait(main_stream()), "sync");
 }
