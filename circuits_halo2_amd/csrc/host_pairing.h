@@ -44,8 +44,27 @@ inline Fq2 fq2_pow(const Fq2& a, const uint64_t* e, int words) {
   return acc;
 }
 
+// Fq6 = Fq2[v] / (v^3 - xi) as three Fq2 coefficients: the even (and, separately, the odd) powers of w of an Fq12 element,
+// v = w^2.  Karatsuba: 6 Fq2 products per product.
+struct Fq6 {
+  Fq2 a, b, c;   // a + b v + c v^2
+  Fq6 operator+(const Fq6& o) const { return Fq6{a + o.a, b + o.b, c + o.c}; }
+  Fq6 operator-(const Fq6& o) const { return Fq6{a - o.a, b - o.b, c - o.c}; }
+  Fq6 operator*(const Fq6& o) const {
+    const Fq2 v0 = a * o.a, v1 = b * o.b, v2 = c * o.c;
+    return Fq6{v0 + fq2_mul_xi((b + c) * (o.b + o.c) - v1 - v2), (a + b) * (o.a + o.b) - v0 - v1 + fq2_mul_xi(v2),
+               (a + c) * (o.a + o.c) - v0 - v2 + v1};
+  }
+  Fq6 mul_v() const { return Fq6{fq2_mul_xi(c), a, b}; }   // times v
+  Fq6 inv() const {
+    const Fq2 A = a.sqr() - fq2_mul_xi(b * c), B = fq2_mul_xi(c.sqr()) - a * b, C = b.sqr() - a * c;
+    const Fq2 f = (a * A + fq2_mul_xi(c * B + b * C)).inv();
+    return Fq6{A * f, B * f, C * f};
+  }
+};
+
 struct Fq12 {
-  Fq2 c[6];
+  Fq2 c[6];   // sum c[k] w^k, w^6 = xi; as a tower: (c[0], c[2], c[4]) + (c[1], c[3], c[5]) w over Fq6, w^2 = v
   static Fq12 one() {
     Fq12 r;
     for (int i = 0; i < 6; i++) r.c[i] = Fq2::zero();
@@ -58,7 +77,27 @@ struct Fq12 {
       if (!c[i].is_zero()) return false;
     return true;
   }
-  Fq12 operator*(const Fq12& o) const {
+  bool operator==(const Fq12& o) const {
+    for (int i = 0; i < 6; i++)
+      if (!(c[i] == o.c[i])) return false;
+    return true;
+  }
+  Fq6 even() const { return Fq6{c[0], c[2], c[4]}; }
+  Fq6 odd() const { return Fq6{c[1], c[3], c[5]}; }
+  static Fq12 from_halves(const Fq6& e, const Fq6& o) {
+    Fq12 r;
+    r.c[0] = e.a; r.c[2] = e.b; r.c[4] = e.c;
+    r.c[1] = o.a; r.c[3] = o.b; r.c[5] = o.c;
+    return r;
+  }
+  // (e + o w)(e' + o' w) = (e e' + v o o') + ((e + o)(e' + o') - e e' - o o') w: three Fq6 products = 18 Fq2 products
+  Fq12 operator*(const Fq12& x) const {
+    const Fq6 e = even(), o = odd(), xe = x.even(), xo = x.odd();
+    const Fq6 ee = e * xe, oo = o * xo;
+    return from_halves(ee + oo.mul_v(), (e + o) * (xe + xo) - ee - oo);
+  }
+  // the definition, coefficient by coefficient (36 Fq2 products): what the tower forms are checked against
+  Fq12 mul_schoolbook(const Fq12& o) const {
     Fq2 t[11];
     for (int i = 0; i < 11; i++) t[i] = Fq2::zero();
     for (int i = 0; i < 6; i++)
@@ -67,7 +106,33 @@ struct Fq12 {
     for (int i = 0; i < 6; i++) r.c[i] = i < 5 ? t[i] + fq2_mul_xi(t[i + 6]) : t[i];
     return r;
   }
-  Fq12 sqr() const { return *this * *this; }
+  // complex squaring over Fq6: (e + o w)^2 = ((e + o)(e + v o) - eo - v eo) + 2 eo w: two Fq6 products
+  Fq12 sqr() const {
+    const Fq6 e = even(), o = odd(), eo = e * o;
+    return from_halves((e + o) * (e + o.mul_v()) - eo - eo.mul_v(), eo + eo);
+  }
+  // squaring of an element of the cyclotomic subgroup (x^(q^6 + 1) = 1 and x^(q^4 - q^2 + 1) = 1: everything after the easy
+  // part of the final exponentiation), Granger-Scott: nine Fq2 squarings.  With g0..g5 = c[0], c[1], .. c[5]:
+  Fq12 cyclotomic_sqr() const {
+    const Fq2 &x0 = c[0], &x1 = c[2], &x2 = c[4], &x3 = c[1], &x4 = c[3], &x5 = c[5];   // (C0.B0, C0.B1, C0.B2, C1.B0, C1.B1, C1.B2)
+    Fq2 t0 = x4.sqr(), t1 = x0.sqr();
+    const Fq2 t6 = (x4 + x0).sqr() - t0 - t1;                 // 2 x4 x0
+    Fq2 t2 = x2.sqr(), t3 = x3.sqr();
+    const Fq2 t7 = (x2 + x3).sqr() - t2 - t3;                 // 2 x2 x3
+    Fq2 t4 = x5.sqr(), t5 = x1.sqr();
+    const Fq2 t8 = fq2_mul_xi((x5 + x1).sqr() - t4 - t5);     // 2 x5 x1 xi
+    t0 = fq2_mul_xi(t0) + t1;                                 // x4^2 xi + x0^2
+    t2 = fq2_mul_xi(t2) + t3;                                 // x2^2 xi + x3^2
+    t4 = fq2_mul_xi(t4) + t5;                                 // x5^2 xi + x1^2
+    Fq12 r;
+    r.c[0] = (t0 - x0).dbl() + t0;
+    r.c[2] = (t2 - x1).dbl() + t2;
+    r.c[4] = (t4 - x2).dbl() + t4;
+    r.c[1] = (t8 + x3).dbl() + t8;
+    r.c[3] = (t6 + x4).dbl() + t6;
+    r.c[5] = (t7 + x5).dbl() + t7;
+    return r;
+  }
   // multiply by the sparse line  a0 + a1 w + a3 w^3  (a0 in Fq)
   Fq12 mul_line(const Fq& a0, const Fq2& a1, const Fq2& a3) const {
     Fq2 t[9];
@@ -105,7 +170,13 @@ inline Fq12 frobenius(const Fq12& a) {
   for (int i = 0; i < 6; i++) r.c[i] = fq2_conj(a.c[i]) * k.gamma[i];
   return r;
 }
-inline Fq12 fq12_inv(const Fq12& a) {  // a^-1 = (a^q a^(q^2) .. a^(q^11)) / Norm(a), Norm(a) in Fq
+inline Fq12 fq12_inv(const Fq12& a) {  // (e - o w) / (e^2 - v o^2): one inversion in Fq6 (norm to Fq2 inside)
+  const Fq6 e = a.even(), o = a.odd();
+  const Fq6 d = (e * e - (o * o).mul_v()).inv();
+  return Fq12::from_halves(e * d, Fq6{Fq2::zero(), Fq2::zero(), Fq2::zero()} - o * d);
+}
+// the same through the Frobenius orbit: a^-1 = (a^q a^(q^2) .. a^(q^11)) / Norm(a), Norm(a) in Fq (the check of the form above)
+inline Fq12 fq12_inv_by_norm(const Fq12& a) {
   Fq12 f = frobenius(a), rest = f;
   for (int i = 2; i < 12; i++) {
     f = frobenius(f);
@@ -122,11 +193,12 @@ inline Fq12 fq12_conj(const Fq12& a) {   // a^(q^6): fixes the even powers of w 
   for (int i = 1; i < 6; i += 2) r.c[i] = Fq2::zero() - a.c[i];
   return r;
 }
-inline Fq12 fq12_pow_u(const Fq12& a) {   // a^u, u = 4965661367192848881 (the BN254 parameter), 63 bits
+// a^u, u = 4965661367192848881 (the BN254 parameter), 63 bits; `a` in the cyclotomic subgroup (the hard part's operands)
+inline Fq12 fq12_pow_u(const Fq12& a) {
   constexpr uint64_t U = 0x44e992b44a6909f1ULL;
   Fq12 acc = a;
   for (int i = 61; i >= 0; i--) {
-    acc = acc.sqr();
+    acc = acc.cyclotomic_sqr();
     if ((U >> i) & 1) acc = acc * a;
   }
   return acc;
@@ -141,11 +213,11 @@ inline Fq12 final_exponentiation(const Fq12& f) {
   Fq12 r = f6 * fq12_inv(f);
   r = frobenius(frobenius(r)) * r;
   const Fq12 y0 = fq12_conj(fq12_pow_u(r));            // r^-u
-  const Fq12 y1 = y0.sqr();
-  const Fq12 y2 = y1.sqr();
+  const Fq12 y1 = y0.cyclotomic_sqr();
+  const Fq12 y2 = y1.cyclotomic_sqr();
   Fq12 y3 = y2 * y1;
   const Fq12 y4 = fq12_conj(fq12_pow_u(y3));
-  const Fq12 y5 = y4.sqr();
+  const Fq12 y5 = y4.cyclotomic_sqr();
   Fq12 y6 = fq12_conj(fq12_pow_u(y5));
   y3 = fq12_conj(y3);
   y6 = fq12_conj(y6);

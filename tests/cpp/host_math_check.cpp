@@ -133,6 +133,44 @@ int main() {
       CHECK(fast.is_one() == plain.is_one());
     }
   }
+  // ---- Fq12 as a tower over its flat coefficients: every fast form against the coefficient-by-coefficient definition
+  {
+    auto random_fq12 = [&]() {
+      Fq12 r;
+      for (auto& c : r.c) c = Fq2{random_fq(), random_fq()};
+      return r;
+    };
+    for (int i = 0; i < 20; i++) {
+      const Fq12 a = random_fq12(), b = random_fq12();
+      CHECK(a * b == a.mul_schoolbook(b));
+      CHECK(a.sqr() == a.mul_schoolbook(a));
+      CHECK((a * fq12_inv(a)).is_one());
+      CHECK(fq12_inv(a) == fq12_inv_by_norm(a));
+      CHECK(a * Fq12::one() == a && (Fq12::one() * b) == b);
+      // the easy part of the final exponentiation lands in the cyclotomic subgroup, where the nine-squaring form holds
+      Fq12 a6 = a;
+      for (int k = 0; k < 6; k++) a6 = frobenius(a6);
+      Fq12 g = a6 * fq12_inv(a);
+      g = frobenius(frobenius(g)) * g;
+      CHECK(g.cyclotomic_sqr() == g.sqr());
+      CHECK((g * fq12_conj(g)).is_one());                   // there the inverse is the conjugate
+      Fq12 p = g;                                            // g^u by cyclotomic squarings == by plain squarings
+      constexpr uint64_t U = 0x44e992b44a6909f1ULL;
+      for (int k = 61; k >= 0; k--) {
+        p = p.sqr();
+        if ((U >> k) & 1) p = p.mul_schoolbook(g);
+      }
+      CHECK(fq12_pow_u(g) == p);
+      // a sparse line through the general product
+      const Fq a0 = random_fq();
+      const Fq2 a1{random_fq(), random_fq()}, a3{random_fq(), random_fq()};
+      Fq12 line = Fq12::one();
+      line.c[0] = Fq2{a0, Fq::zero()};
+      line.c[1] = a1;
+      line.c[3] = a3;
+      CHECK(a.mul_line(a0, a1, a3) == a.mul_schoolbook(line));
+    }
+  }
   // ---- Fr
   for (int i = 0; i < 30; i++) {
     const uint64_t c[4] = {rnd(), rnd(), rnd(), rnd() >> 4};
