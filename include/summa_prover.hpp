@@ -902,8 +902,12 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ev_fork = adopt_or_create_event();
     for (auto& e : ev_join) e = adopt_or_create_event();
   }
-  // SG_PROVER_SERIAL (development aid): everything on the main stream, so that a kernel trace shows every kernel alone
-  const bool serial = std::getenv("SG_PROVER_SERIAL") != nullptr;
+  // Everything on the main stream: (a) a proof that is one of several in flight (between sg_commit_combine_begin / _end: the
+  // batch driver) -- the other proofs are its concurrency, and every fork / join is three event records and four stream waits,
+  // each a marker the runtime's completion thread has to retire (one thread per process: 3.6 ms of CPU per proof at 25 records
+  // and 22 waits; without the side streams a batch of 1024 runs 2-7 % faster on a whole host and on a 1/8 share of it,
+  // profiles/r04_sweeps/batch_host_cpu_profile.txt); (b) SG_PROVER_SERIAL (development aid: a kernel trace shows every kernel alone)
+  const bool serial = std::getenv("SG_PROVER_SERIAL") != nullptr || sg_commit_combining() == 1;
   const hipStream_t side[2] = {serial ? ms : side_streams[0], serial ? ms : side_streams[1]};
   // A proof that ends in an exception (WitnessError, a failed call) may leave kernels behind on the side streams, and its
   // device columns go back to this thread's pool as the stack unwinds -- the next proof would take them while those
@@ -917,10 +921,12 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     }
   } drain_on_unwind{{side[0], side[1], ms}};
   auto fork = [&]() {
+    if (serial) return;                  // one stream: nothing to order (and no markers for the runtime to retire)
     hk(hipEventRecord(ev_fork, ms), "event");
     for (auto& st : side) hk(hipStreamWaitEvent(st, ev_fork, 0), "wait");
   };
   auto join = [&]() {
+    if (serial) return;
     for (int i = 0; i < 2; i++) {
       hk(hipEventRecord(ev_join[i], side[i]), "event");
       hk(hipStreamWaitEvent(ms, ev_join[i], 0), "wait");
@@ -1016,8 +1022,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   const int SP = SG_BASIS_SPARSE;
   std::vector<uint8_t> pts;
   if (random_early) {
-    hk(hipEventRecord(ev_join[1], side[1]), "event");            // the draw of the random polynomial (side stream 1)
-    hk(hipStreamWaitEvent(ms, ev_join[1], 0), "wait");
+    if (!serial) {
+      hk(hipEventRecord(ev_join[1], side[1]), "event");          // the draw of the random polynomial (side stream 1)
+      hk(hipStreamWaitEvent(ms, ev_join[1], 0), "wait");
+    }
     pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p, random_poly.p}, {1 | SP, 1 | SP, 1 | SP, 2 | SP, 2 | SP, 0});
   } else {
     pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1 | SP, 1 | SP, 1 | SP, 2 | SP, 2 | SP});
