@@ -85,6 +85,7 @@ B.prove_batch(tree, users[:96], params, pk, levels, flavour="evm", in_flight=in_
 torch.cuda.synchronize()
 sections.clear()
 before = thread_cpu()
+allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
 t0 = time.perf_counter()
 res = B.prove_batch(tree, users, params, pk, levels, flavour="evm", in_flight=in_flight)
 torch.cuda.synchronize()
@@ -111,6 +112,7 @@ for name, (d, du, ds, cnt) in groups.items():
     print(f"  {name}: {cnt} threads, {1e3 * d / n:.2f} ms per proof (user {1e3 * du / n:.2f}, system {1e3 * ds / n:.2f})")
 for d, tid, comm, g in sorted(detail, reverse=True)[:8]:
     print(f"    thread {tid} '{comm}': {1e3 * d / n:.2f} ms per proof")
+print(f"device allocations by torch's caching allocator during the batch: {torch.cuda.memory_stats().get('num_device_alloc', 0) - allocs0}")
 print("inside the workers (thread CPU / wall per call):")
 for name, (c, w, cnt) in sections.items():
     print(f"  {name}: {1e3 * c / max(cnt, 1):.2f} ms CPU, {1e3 * w / max(cnt, 1):.2f} ms wall, {cnt} calls")
