@@ -446,7 +446,7 @@ def batch_extra(args, rank, world, coll_dev):
     # of the pre-sweep runs the headline batch
     sweep = {}
     per = max(6 * world, min(96 * world, total // 4))
-    candidates = sorted({max(1, args.batch_in_flight // 2), args.batch_in_flight}) if args.batch_in_flight > 0 else (1, 2, 4, 8, 16, 24, 32, 48)
+    candidates = sorted({max(1, args.batch_in_flight // 2), args.batch_in_flight}) if args.batch_in_flight > 0 else (1, 2, 4, 8, 16, 24, 32, 48, 64, 96)
     for in_flight in candidates:
         timed_batch(users[:3 * in_flight * world], in_flight)
         done, errs, dt, _, _ = timed_batch(users[:min(total, max(per, 6 * in_flight * world))], in_flight)
