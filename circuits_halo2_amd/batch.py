@@ -294,9 +294,11 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         env = os.environ.get("SUMMA_COMBINE_COMMITS")
         combine = (env == "1" or (env is None and in_flight >= 6)) and in_flight > 1 and prove is None
     if combine:
-        # process-wide tunables of the combiner, for the length of this batch (restored to the library's defaults below)
-        ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(in_flight)))
-        ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 5000))
+        # process-wide tunables of the combiner, for the length of this batch (restored to the library's defaults below);
+        # SUMMA_COMBINE_TARGET / SUMMA_COMBINE_WAIT_US override them for sweeps (at 64 in flight: targets 16 / 32 / 64 and waits
+        # of 1 / 2 / 5 ms all land within the run-to-run spread, 249-266 proofs/s)
+        ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(os.environ.get("SUMMA_COMBINE_TARGET", in_flight))))
+        ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", int(os.environ.get("SUMMA_COMBINE_WAIT_US", 5000))))
     # with several proofs in flight most worker threads are waiting for the device most of the time: they poll and SLEEP
     # (sg_set_param "host.wait_sleep_us") instead of polling and yielding -- the same proofs per second on a whole host, a
     # fifth more on a 1/8 share of it (what a rank gets when eight share a node), 13 -> 8 ms of CPU per proof
