@@ -469,6 +469,7 @@ def batch_extra(args, rank, world, coll_dev):
     out["host_cpu_ms_per_proof"] = sorted(r["host_cpu_ms_per_proof"] for r in reps)[len(reps) // 2]
     out["host_cores_busy_per_gpu"] = sorted(r["host_cores_busy"] for r in reps)[len(reps) // 2]
     out["host"] = host_cpu_info()
+    out["wait_sleep_us"] = last.wait_sleep_us
     assert out["errors"] == 0 and all(r["proofs"] == total for r in reps), out
     if rank == 0:   # checker leg, outside every timed region: the oracle's verifier on a sample of the proofs made
         from oracle import summa_verifier as SV
@@ -601,6 +602,8 @@ def _main():
     ap.add_argument("--batch-only", action="store_true", help="only the proof batch (the child runs of the --cpu-share rehearsal): prints the batch extra's dict")
     ap.add_argument("--batch-in-flight", type=int, default=0, help="proofs in flight for the batch (0 = pre-sweep picks)")
     ap.add_argument("--no-cpu-share-sweep", action="store_true", help="skip the CPU-share rehearsal of the batch (three child runs)")
+    ap.add_argument("--acc-log", default="", help="profiling: write the library's msm_accumulate launch log (sg_msm_launch_log) to this file at the end "
+                                                  "of the headline steps / of the batch, so that a kernel trace of this run attributes every launch to its job exactly")
     args = ap.parse_args()
 
     if args.cpu_share > 0:
@@ -652,8 +655,16 @@ def _main():
         name, val = kv.split("=")
         ffi.check(sg.lib().sg_set_param(name.encode(), int(val)))
 
+    def dump_acc_log(region):
+        if args.acc_log and rank == 0:
+            with open(args.acc_log, "w") as f:
+                json.dump({"region": region, "launches": ffi.msm_launch_log()}, f)
+
+    if args.acc_log:
+        ffi.set_param("msm.acc_log", 1)
     if args.batch_only:      # a child run of the CPU-share rehearsal: the batch extra alone, its dict as the line
         got, _ = batch_extra(args, rank, world, coll_dev)
+        dump_acc_log("process start .. end of the batch")
         if rank == 0:
             got["cpu_share"] = args.cpu_share
             fs.emit(got)
@@ -671,11 +682,17 @@ def _main():
     import threading
     tls = threading.local()
 
+    pipelined_timings = None      # a list while the steps of a region record their own HIP-event timings (after the timed region)
+
     def partial():
         """this rank's shard of one step: a whole 2^log_n MSM (digits .. host tail), result = the 64-byte point"""
         if not hasattr(tls, "stream"):
             tls.stream = torch.cuda.Stream()
         with torch.cuda.stream(tls.stream):
+            if pipelined_timings is not None:
+                point, tm = sg.best_multiexp(scal, bases, timings=True)
+                pipelined_timings.append(tm)
+                return point
             return sg.best_multiexp(scal, bases)
 
     def run_steps(count, in_flight):
@@ -741,6 +758,14 @@ def _main():
     result = results[-1]
     assert all((r == result).all() for r in results), "steps of one input must agree"
     fs.partial.update({"value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": world})
+    # the SAME regime once more, untimed, with every step's own HIP events (sg_msm_timings: the chained accumulation launch from
+    # behind its wait for the previous one): the per-kernel figure of the regime `value` is quoted on, for `roofline`
+    if rank == 0 and in_flight > 1:
+        pipelined_timings = []
+        run_steps(max(args.steps, 2 * in_flight), in_flight)
+        pipelined_reps, pipelined_timings = pipelined_timings[in_flight:], None    # (the first ones start on an idle device)
+    else:
+        pipelined_reps = None
     # the same steps strictly one after the other (the latency of one MSM, round 1's headline)
     run_steps(2, 1)
     dt_seq, _ = timed(args.steps, 1)
@@ -751,6 +776,7 @@ def _main():
     if rank == 0:   # per-phase HIP-event timings of the same MSM, taken here (the extras below fill HBM and caches with other data)
         sg.best_multiexp(scal, bases, timings=True)
         phase_reps = [sg.best_multiexp(scal, bases, timings=True)[1] for _ in range(5)]
+    dump_acc_log("process start .. the five lone timed MSMs after the headline steps")
 
     # ---- the line's headline part, complete BEFORE any extra runs: if an extra hangs or the wall-clock limit comes, the
     # watchdog still has a whole, valid line to print (FailSafe.base_line)
@@ -778,10 +804,29 @@ def _main():
         acc_ms = float(np.mean([r["accumulate_ms"] for r in reps]))
         alg_bytes = MSM_BYTES_PER_PAIR * n
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
-        line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes}
-        line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, reps[0]["accumulate_threads"], n))
+        lone = {"regime": "one MSM at a time (the device to itself: three waves per SIMD)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                "launch_ms": acc_ms, "accumulate_threads": reps[0]["accumulate_threads"], "launches_timed": len(reps)}
+        lone.update(pmc_traffic("sg::msm_accumulate", args.log_n, reps[0]["accumulate_threads"], n))
+        if pipelined_reps:
+            # the regime the headline runs in: steps_in_flight MSMs in flight, accumulations chained one behind the other (two waves
+            # per SIMD, the other MSMs' sort / reduction kernels running under them at wave priority 3)
+            p_ms = float(np.mean([r["accumulate_ms"] for r in pipelined_reps]))
+            p_achieved = alg_bytes / (p_ms * 1e-3) / 1e9
+            line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": p_achieved / HBM_PEAK_GBS, "traffic": None,
+                                "launch_ms": p_ms, "algorithmic_bytes": alg_bytes,
+                                "regime": f"the headline's own: {in_flight} MSMs in flight, chained accumulation launches (two waves per SIMD) timed by "
+                                          "their own HIP events from behind the chain's wait, in an untimed repeat of the timed region",
+                                "accumulate_threads": pipelined_reps[0]["accumulate_threads"], "launches_timed": len(pipelined_reps),
+                                "launch_ms_min_max": [float(min(r["accumulate_ms"] for r in pipelined_reps)), float(max(r["accumulate_ms"] for r in pipelined_reps))],
+                                "share_of_step": p_ms / ms_per_step,
+                                "lone": lone}
+            line["roofline"].update(pmc_traffic("sg::msm_accumulate", args.log_n, pipelined_reps[0]["accumulate_threads"], n))
+        else:
+            line["roofline"] = {"kernel": "msm_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                "launch_ms": acc_ms, "algorithmic_bytes": alg_bytes, "regime": lone["regime"]}
+            line["roofline"].update({k_: v_ for k_, v_ in lone.items() if k_.startswith("traffic")})
         line["msm_phases_ms"] = {k: float(np.mean([r[k] for r in reps])) for k in
                                  ("digits_ms", "sort_ms", "order_ms", "accumulate_ms", "reduce_ms", "total_ms")}
         line["msm_phases_ms"].update({k: reps[0][k] for k in ("window_bits", "windows", "tasks", "max_bucket", "accumulate_threads")})

@@ -270,6 +270,7 @@ class BatchResult:
         self.proofs = {}          # user index -> (proof bytes, public inputs)
         self.seconds = 0.0
         self.errors = {}
+        self.wait_sleep_us = None  # how this batch's host threads waited (host.wait_sleep_us while it ran; None: not a GPU batch)
 
     def proofs_per_s(self) -> float:
         return len(self.proofs) / self.seconds if self.seconds else 0.0
@@ -293,21 +294,32 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     if combine is None:
         env = os.environ.get("SUMMA_COMBINE_COMMITS")
         combine = (env == "1" or (env is None and in_flight >= 6)) and in_flight > 1 and prove is None
+    # process-wide tunables of the library for the length of this batch.  What was found is put back when the LAST batch of the
+    # process ends (_ParamScope counts them): a caller's own settings -- SG_PARAMS, bench.py's multi-rank wait -- survive, and a
+    # batch that finishes does not switch another one, still running, back to busy polling
+    scope = {}
     if combine:
-        # process-wide tunables of the combiner, for the length of this batch (restored to the library's defaults below);
         # SUMMA_COMBINE_TARGET / SUMMA_COMBINE_WAIT_US override them for sweeps (at 64 in flight: targets 16 / 32 / 64 and waits
         # of 1 / 2 / 5 ms all land within the run-to-run spread, 249-266 proofs/s)
-        ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", int(os.environ.get("SUMMA_COMBINE_TARGET", in_flight))))
-        ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", int(os.environ.get("SUMMA_COMBINE_WAIT_US", 5000))))
+        scope["commit.combine_target"] = int(os.environ.get("SUMMA_COMBINE_TARGET", in_flight))
+        scope["commit.combine_wait_us"] = int(os.environ.get("SUMMA_COMBINE_WAIT_US", 5000))
     # with several proofs in flight most worker threads are waiting for the device most of the time: they poll and SLEEP
     # (sg_set_param "host.wait_sleep_us") instead of polling and yielding -- the same proofs per second on a whole host, a
     # fifth more on a 1/8 share of it (what a rank gets when eight share a node), 13 -> 8 ms of CPU per proof
-    # (profiles/r04_sweeps/batch_wait_modes.txt).  A lone proof keeps the runtime's wait: its dozen waits are on its critical path
-    naps = prove is None and in_flight >= 4 and os.environ.get("SUMMA_WAIT_SLEEP_US", "50") != "0"
-    if naps:
-        ffi.check(ffi.lib().sg_set_param(b"host.wait_sleep_us", int(os.environ.get("SUMMA_WAIT_SLEEP_US", "50"))))
+    # (profiles/r04_sweeps/batch_wait_modes.txt).  A lone proof keeps the runtime's wait: its dozen waits are on its critical path.
+    # SUMMA_WAIT_SLEEP_US=N overrides (0: keep polling); a wait the caller has already made sleep (SG_PARAMS, sg_set_param) is kept
+    nap_env = os.environ.get("SUMMA_WAIT_SLEEP_US")
+    if prove is None and in_flight >= 4 and nap_env != "0":
+        if nap_env is not None:
+            scope["host.wait_sleep_us"] = int(nap_env)
+        elif ffi.get_param("host.wait_sleep_us") == 0:
+            scope["host.wait_sleep_us"] = 50
+    params_scope = _ParamScope(scope)
+    params_scope.enter()
     mine = deal(list(user_indices))
     res = BatchResult()
+    if prove is None:
+        res.wait_sleep_us = ffi.get_param("host.wait_sleep_us")
     ahead = None
     if make_circuit is None:
         if hasattr(tree, "d_h"):      # a device-resident snapshot: the witness never visits the host
@@ -360,13 +372,38 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
     finally:
         if ahead is not None:
             ahead.close()
-        if naps:
-            ffi.check(ffi.lib().sg_set_param(b"host.wait_sleep_us", 0))
-        if combine:     # the library's defaults (include/summa_gpu.h, sg_set_param): a later caller's lone proofs do not wait 5 ms for company
-            ffi.check(ffi.lib().sg_set_param(b"commit.combine_target", 4))
-            ffi.check(ffi.lib().sg_set_param(b"commit.combine_wait_us", 300))
+        params_scope.leave()     # a later caller's lone proofs do not wait 5 ms for company, nor sleep between polls
     res.seconds = time.perf_counter() - t0
     return res
+
+
+class _ParamScope:
+    """Library parameters held at given values while at least one batch of this process runs.  The first batch to enter saves
+    what it finds (sg_get_param), every batch sets its own values, the last one to leave restores the saved ones."""
+    _lock = threading.Lock()
+    _active = 0
+    _saved: dict = {}
+
+    def __init__(self, values):
+        self.values = dict(values)
+
+    def enter(self):
+        cls = _ParamScope
+        with cls._lock:
+            for name, value in self.values.items():
+                if name not in cls._saved:
+                    cls._saved[name] = ffi.get_param(name)
+                ffi.set_param(name, value)
+            cls._active += 1
+
+    def leave(self):
+        cls = _ParamScope
+        with cls._lock:
+            cls._active -= 1
+            if cls._active == 0:
+                for name, value in cls._saved.items():
+                    ffi.set_param(name, value)
+                cls._saved = {}
 
 
 def gather_proofs(res: BatchResult, dst: int = 0):

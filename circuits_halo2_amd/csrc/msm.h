@@ -176,6 +176,17 @@ class MsmEngine {
   uint32_t* d_hwin_ = nullptr;
 };
 
+// one msm_accumulate launch as the engine issued it (parameter "msm.acc_log"; sg_msm_launch_log)
+struct AccLaunchRecord {
+  uint64_t entries;       // (digit, point) pairs the launch accumulates
+  uint32_t n, M;          // the job: M polynomials / MSMs of n scalars each
+  uint32_t threads;       // grid of the launch
+  uint32_t fixed;         // 1: fixed-base job (a commitment), 0: generic
+  uint32_t jobs_in_flight;  // jobs of the process in flight when it was issued (this one included)
+  uint32_t task_len;      // L: entries per accumulation task
+};
+void msm_acc_log_enable(bool on);
+size_t msm_acc_log_read(AccLaunchRecord* out, size_t cap);   // returns the number of records held
 // +1 / -1 on the count of jobs in flight (MsmEngine::others_in_flight), for callers that run several jobs side by side
 void msm_hold_in_flight(bool on);
 // FFT over G1 (N5): out = DFT_omega(in) [* scale], natural order; d_work: 2^log_n xyzz29_mem

@@ -1242,14 +1242,36 @@ MsmEngine::~MsmEngine() { release(); }
 // (process-wide state: the library serves ONE device per process -- sg_init binds it, one process per GPU -- so "of the
 // process" is "of the device")
 static std::mutex g_acc_chain_mu;
+static std::atomic<int> g_jobs_in_flight{0};   // jobs of this process between their first kernel and the end of their host tail
 static hipEvent_t g_acc_chain_last = nullptr;   // recorded after the most recent accumulation launch of the process
 // wait for the previous accumulation, launch, record -- under ONE hold of the mutex: taken separately around the launch, two
 // lanes could both wait on the same predecessor and then run their accumulations side by side, which is what the chain is for
+// Launch log (parameter "msm.acc_log", profiling only): one record per msm_accumulate launch, appended under the chain's mutex,
+// i.e. in the order in which the chained launches run on the device -- the i-th msm_accumulate of a kernel trace ordered by
+// start time IS the i-th record, so a profile attributes every launch to its job exactly (tools/proof_budget.py)
+static std::atomic<int> g_acc_log_on{0};
+static std::vector<AccLaunchRecord> g_acc_log;
+void msm_acc_log_enable(bool on) {
+  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
+  g_acc_log_on.store(on ? 1 : 0);
+  if (on) g_acc_log.clear();
+}
+size_t msm_acc_log_read(AccLaunchRecord* out, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_acc_chain_mu);
+  const size_t m = std::min(cap, g_acc_log.size());
+  if (out && m) std::memcpy(out, g_acc_log.data(), m * sizeof(AccLaunchRecord));
+  return g_acc_log.size();
+}
 hipError_t MsmEngine::chained_accumulate(hipStream_t stream, hipEvent_t after_wait, const std::function<void()>& launch) {
   std::unique_lock<std::mutex> lk(g_acc_chain_mu, std::defer_lock);
+  if (cfg_.acc_chain || g_acc_log_on.load()) lk.lock();
   if (cfg_.acc_chain) {
-    lk.lock();
     if (g_acc_chain_last) SG_TRY(hipStreamWaitEvent(stream, g_acc_chain_last, 0));
+  }
+  if (g_acc_log_on.load()) {
+    const Job& j = job_;
+    g_acc_log.push_back(AccLaunchRecord{(uint64_t)j.entries, (uint32_t)j.n, j.M, j.acc_threads, j.fixed ? 1u : 0u,
+                                        (uint32_t)g_jobs_in_flight.load(), 1u << j.log_L});
   }
   if (after_wait) SG_TRY(hipEventRecord(after_wait, stream));   // timing mode: the accumulation's own start, behind the chain wait
   launch();
@@ -1639,7 +1661,7 @@ hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars,
 
 // ---- phase 2: needs the task count on the host; enqueues accumulate .. export + result copy
 // jobs of this process between their first kernel and the end of their host tail (all engines, all lanes)
-static std::atomic<int> g_jobs_in_flight{0};
+// (g_jobs_in_flight is defined with the accumulation chain, above)
 // a caller that is about to run several jobs side by side on its own engines (the chunked host-pointer MSM) declares them
 // "in flight" for the length of the call, so that the first of them already launches politely
 void msm_hold_in_flight(bool on) { g_jobs_in_flight.fetch_add(on ? 1 : -1); }

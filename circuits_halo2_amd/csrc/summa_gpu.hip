@@ -2782,6 +2782,10 @@ int sg_set_param(const char* name, int value) {
     g_comb.fail_next.store(value ? 1 : 0);
     return SG_OK;
   }
+  if (s == "msm.acc_log") {   // profiling: record every msm_accumulate launch in issue order (sg_msm_launch_log); setting 1 clears the log
+    msm_acc_log_enable(value != 0);
+    return SG_OK;
+  }
   if (s == "commit.combine_runners") {
     g_comb.max_runners.store(std::max(1, std::min(value, 4)));
     return SG_OK;
@@ -2806,6 +2810,40 @@ int sg_set_param(const char* name, int value) {
   }
   return SG_OK;
 }
+
+int sg_get_param(const char* name, int* value) {
+  if (!name || !value) return fail(SG_ERR_INVALID, "sg_get_param: bad argument");
+  const std::string s(name);
+  if (s == "commit.combine_wait_us") *value = g_comb.wait_us.load();
+  else if (s == "commit.combine_target") *value = g_comb.target.load();
+  else if (s == "commit.combine_runners") *value = g_comb.max_runners.load();
+  else if (s == "msm.host_chunks") *value = g_host_chunks.load();
+  else if (s == "host.wait_sleep_us") *value = host_wait_sleep_us().load();
+  else if (s == "lanes") *value = g_lane_count.load();
+  else {
+    // per-lane parameters: the value most recently set through sg_set_param (0 = never set: the built-in default applies)
+    std::lock_guard<std::mutex> lk(g_sh.mu);
+    *value = 0;
+    bool known = false;
+    for (const auto& kv : g_sh.params)
+      if (kv.first == s) {
+        *value = kv.second;
+        known = true;
+      }
+    if (!known && s.rfind("msm.", 0) != 0 && s.rfind("ntt.", 0) != 0 && s != "side_prio")
+      return fail(SG_ERR_INVALID, "sg_get_param: unknown parameter");
+  }
+  return SG_OK;
+}
+
+int sg_msm_launch_log(uint32_t* out_words, size_t cap_records, size_t* n_records) {
+  if (!n_records || (cap_records && !out_words)) return fail(SG_ERR_INVALID, "sg_msm_launch_log: bad argument");
+  static_assert(sizeof(AccLaunchRecord) == 8 * sizeof(uint32_t), "record layout is part of the ABI");
+  *n_records = msm_acc_log_read(reinterpret_cast<AccLaunchRecord*>(out_words), cap_records);
+  return SG_OK;
+}
+
+int sg_abi_version(void) { return SG_ABI_VERSION; }
 
 int sg_time_ntt_dev(void* d_a, uint32_t log_n, int reps, float* ms_out) {
   if (!d_a || !ms_out || reps < 1 || log_n > 28) return fail(SG_ERR_INVALID, "sg_time_ntt_dev: bad argument");

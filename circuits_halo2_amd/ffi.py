@@ -24,7 +24,7 @@ EXPORTS = [
     "sg_divide_by_vanishing_poly_dev", "sg_domain_constant", "sg_g1_fixed_base_mul", "sg_g1_fixed_base_mul_dev", "sg_g2_generator_mul", "sg_pairing_check", "sg_pairing_check_slow", "sg_keccak256", "sg_kzg_setup", "sg_kzg_setup_dev", "sg_g1_fft_dev", "sg_g1_to_lagrange",
     "sg_fr_to_montgomery_dev", "sg_fr_from_montgomery_dev", "sg_fr_random_dev", "sg_fr_random_batch_dev", "sg_lookup_permute_small_dev", "sg_fr_eval_poly", "sg_fr_eval_poly_dev", "sg_fr_eval_poly_batch_dev",
     "sg_fr_batch_invert_dev", "sg_fr_prefix_product_dev", "sg_fr_mul_dev", "sg_fr_kate_division_dev", "sg_fr_kate_division_batch_dev", "sg_fr_count_noncanonical_dev", "sg_fr_lincomb_dev", "sg_fr_lincomb_low_dev", "sg_permutation_product_dev",
-    "sg_lookup_product_dev", "sg_grand_products_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_set_param", "sg_time_ntt_dev",
+    "sg_lookup_product_dev", "sg_grand_products_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_set_param", "sg_get_param", "sg_msm_launch_log", "sg_abi_version", "sg_time_ntt_dev",
 ]
 
 
@@ -68,6 +68,26 @@ def lib():
 def check(rc: int):
     if rc != SG_OK:
         raise SummaGpuError(rc, lib().sg_last_error().decode())
+
+
+def set_param(name: str, value: int):
+    check(lib().sg_set_param(name.encode(), int(value)))
+
+
+def get_param(name: str) -> int:
+    out = C.c_int(0)
+    check(lib().sg_get_param(name.encode(), C.byref(out)))
+    return out.value
+
+
+def msm_launch_log():
+    """records of the msm_accumulate launches since parameter "msm.acc_log" was set to 1 (include/summa_gpu.h: sg_msm_launch_log)"""
+    n = C.c_size_t(0)
+    check(lib().sg_msm_launch_log(None, 0, C.byref(n)))
+    buf = np.zeros((max(1, n.value), 8), dtype=np.uint32)
+    check(lib().sg_msm_launch_log(buf.ctypes.data_as(C.POINTER(C.c_uint32)), buf.shape[0], C.byref(n)))
+    keys = ("n", "M", "threads", "fixed", "jobs_in_flight", "task_len")
+    return [dict(entries=int(r[0]) | (int(r[1]) << 32), **{k: int(v) for k, v in zip(keys, r[2:])}) for r in buf[:min(n.value, buf.shape[0])]]
 
 
 def bind_thread():

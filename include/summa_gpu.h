@@ -507,6 +507,22 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   "msm.acc_chain" (1 | 0): accumulations of different calls run one after the other;
  *   "msm.red_lean" (0 | 1 | 2): the bucket reduction's 168-register twin never / when other jobs are in flight / always. */
 int sg_set_param(const char* name, int value);
+/* Reads a parameter back (so that a caller that changes a process-wide one for the length of a job can restore what it found):
+ * the process-wide ones ("lanes", "commit.*", "host.wait_sleep_us", "msm.host_chunks") return their live value, the per-lane
+ * ones ("msm.*", "ntt.*", "side_prio") the value most recently set through sg_set_param, 0 when none was (built-in default). */
+int sg_get_param(const char* name, int* value);
+/* Profiling aid.  With parameter "msm.acc_log" = 1 (setting it clears the log) every msm_accumulate launch of the process is
+ * recorded in the order in which the chained launches run on the device, so the i-th msm_accumulate of a kernel trace ordered by
+ * start time is record i: exact attribution of a profile's launches to jobs (tools/proof_budget.py).  A record is 8 u32 words:
+ * entries (lo, hi), n, M (polynomials of the job), threads of the launch, fixed-base (1) / generic (0), jobs in flight when it
+ * was issued, entries per task.  *n_records = records held (may exceed cap_records; only cap_records are written). */
+int sg_msm_launch_log(uint32_t* out_words, size_t cap_records, size_t* n_records);
+/* ABI revision of this header: bumped whenever a struct that a caller allocates grows or an entry point's meaning changes.
+ *   2 (round 4): sg_msm_timings gained `order_ms` (44 bytes; accumulate_ms excludes the wait in the accumulation chain)
+ *   3 (round 5): sg_get_param, sg_msm_launch_log, sg_abi_version added; nothing removed or resized
+ * A binding built against revision r must refuse a library whose sg_abi_version() < r. */
+#define SG_ABI_VERSION 3
+int sg_abi_version(void);
 /* Time `reps` back-to-back launches of the operation with HIP events on the library's
  * stream; returns average milliseconds per launch in *ms_out (used by bench.py for the
  * roofline block). op: 0 = ntt (d_a in place, forward with the domain omega of log_n). */

@@ -165,6 +165,9 @@ extern "C" {
     pub fn sg_commit_combine_stats(jobs: *mut u64, requests: *mut u64) -> c_int;
     pub fn sg_collect_retired() -> c_int;
     pub fn sg_set_param(name: *const c_char, value: c_int) -> c_int;
+    pub fn sg_get_param(name: *const c_char, value: *mut c_int) -> c_int;
+    // revision of include/summa_gpu.h the library was built from (SG_ABI_VERSION); this file is written against 3
+    pub fn sg_abi_version() -> c_int;
 }
 
 const _: () = assert!(std::mem::size_of::<Fr>() == 32);

@@ -82,6 +82,8 @@ int main(int argc, char** argv) {
         pos = end + 1;
       }
     }
+    const char* acc_log = std::getenv("SG_ACC_LOG");   // profiling: the library's msm_accumulate launch log, written at the end
+    if (acc_log) ck(sg_set_param("msm.acc_log", 1), "sg_set_param");
     Reader rd(argv[1]);
     char magic[8];
     rd.read(magic, 8);
@@ -133,6 +135,22 @@ int main(int argc, char** argv) {
                 best, keygen_ms, proof.size());
     for (auto& kv : tm.ms) std::printf(", \"%s\": %.3f", kv.first.c_str(), kv.second);
     std::printf("}\n");
+    if (acc_log) {
+      size_t held = 0;
+      ck(sg_msm_launch_log(nullptr, 0, &held), "launch log");
+      std::vector<uint32_t> words(8 * std::max<size_t>(held, 1));
+      ck(sg_msm_launch_log(words.data(), held, &held), "launch log");
+      if (FILE* f = std::fopen(acc_log, "w")) {
+        std::fprintf(f, "{\"region\": \"whole process\", \"launches\": [");
+        for (size_t i = 0; i < held; i++) {
+          const uint32_t* w = &words[8 * i];
+          std::fprintf(f, "%s{\"entries\": %llu, \"n\": %u, \"M\": %u, \"threads\": %u, \"fixed\": %u, \"jobs_in_flight\": %u, \"task_len\": %u}",
+                       i ? ", " : "", (unsigned long long)(w[0] | ((uint64_t)w[1] << 32)), w[2], w[3], w[4], w[5], w[6], w[7]);
+        }
+        std::fprintf(f, "]}\n");
+        std::fclose(f);
+      }
+    }
     sg_srs_free(srs);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "create_proof_cpp: %s\n", e.what());

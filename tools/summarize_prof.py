@@ -18,6 +18,22 @@ def rocpd_rows(directory, view):
     return out
 
 
+def acc_log_for(directory):
+    """the library's own launch log of the profiled run (bench.py --acc-log <directory>_acclog.json): record i = the i-th
+    msm_accumulate launch of the process in device order (the launches are chained), or None"""
+    path = directory.rstrip("/") + "_acclog.json"
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path))["launches"]
+
+
+def job_key(rec):
+    """the job a launch belongs to, as the old keys named it (thread count of its msm_digits launch = n for one MSM)"""
+    return rec["n"] if rec["M"] == 1 else f"{rec['M']}x{rec['n']}"
+
+
+attribution = {}
+
 tag = sys.argv[1]                      # e.g. r01b
 src = os.path.join("gpurun_out", f"prof_{tag}")
 out = "profiles"
@@ -55,30 +71,52 @@ if tr:
         if name == "sg::msm_digits":
             last_digits[r["Queue_Id"]] = grid
         elif name == "sg::msm_accumulate":
-            acc_jobs[(grid, last_digits.get(r["Queue_Id"], 0))].append(dur)
+            acc_jobs[(grid, last_digits.get(r["Queue_Id"], 0), None)].append(dur)
 elif glob.glob(os.path.join(src, "*", "*_results.db")):
     last_digits = {}
-    for r in sorted(rocpd_rows(src, "kernels"), key=lambda r: r["start"]):
+    rows = sorted(rocpd_rows(src, "kernels"), key=lambda r: r["start"])
+    log = acc_log_for(src)
+    n_acc = sum(1 for r in rows if r["name"].split("(")[0] == "sg::msm_accumulate")
+    exact = log is not None and len(log) == n_acc
+    attribution["kernel_trace"] = {"method": "library launch log (exact: record i = i-th chained launch)" if exact else "preceding msm_digits on the queue (heuristic)",
+                                   "launches_in_trace": n_acc, "records_in_log": None if log is None else len(log)}
+    seen = 0
+    for r in rows:
         name, grid = r["name"].split("(")[0], int(r["grid_x"]) * int(r["grid_y"]) * int(r["grid_z"])
         dur = r["duration"] / 1e3
         per[(name, grid, str(r["vgpr_count"]), str(r["lds_size"]), str(r["scratch_size"]))].append(dur)
         if name == "sg::msm_digits":
             last_digits[r["queue_id"]] = grid
         elif name == "sg::msm_accumulate":
-            acc_jobs[(grid, last_digits.get(r["queue_id"], 0))].append(dur)
+            if exact:
+                rec = log[seen]
+                assert rec["threads"] == grid, (seen, rec, grid)     # the log and the trace describe the same launch
+                acc_jobs[(grid, job_key(rec), rec["jobs_in_flight"])].append(dur)
+            else:
+                acc_jobs[(grid, last_digits.get(r["queue_id"], 0), None)].append(dur)
+            seen += 1
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     if not glob.glob(os.path.join(f"{src}_{kind}", "*", "*_counter_collection.csv")) and glob.glob(os.path.join(f"{src}_{kind}", "*", "*_results.db")):
         agg = collections.defaultdict(list)
         last_digits = {}
-        for r in sorted(rocpd_rows(f"{src}_{kind}", "counters_collection"), key=lambda r: r["start"]):
+        crow = sorted(rocpd_rows(f"{src}_{kind}", "counters_collection"), key=lambda r: r["start"])
+        log = acc_log_for(f"{src}_{kind}")
+        n_acc = sum(1 for r in crow if r["counter_name"] == ctr and r["kernel_name"].split("(")[0] == "sg::msm_accumulate")
+        exact = log is not None and len(log) == n_acc
+        attribution[kind] = {"method": "library launch log (exact)" if exact else "preceding msm_digits on the queue (heuristic)",
+                             "launches_in_pass": n_acc, "records_in_log": None if log is None else len(log)}
+        seen = 0
+        for r in crow:
             name, grid = r["kernel_name"].split("(")[0], int(r["grid_size"])
             if name == "sg::msm_digits":
                 last_digits[r["queue_id"]] = grid
             if r["counter_name"] == ctr:
                 agg[(name, grid)].append(float(r["value"]))
                 if name == "sg::msm_accumulate":
-                    agg[(name, f"{grid}@job{last_digits.get(r['queue_id'], 0)}")].append(float(r["value"]))
+                    job = job_key(log[seen]) if exact else last_digits.get(r['queue_id'], 0)
+                    agg[(name, f"{grid}@job{job}")].append(float(r["value"]))
+                    seen += 1
         for (k, g), v in agg.items():
             pmc.setdefault(f"{k}@grid{g}", {})[ctr + "_KB_avg"] = sum(v) / len(v)
             pmc[f"{k}@grid{g}"]["launches_" + kind] = len(v)
@@ -102,8 +140,9 @@ for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 summary = {"tag": tag, "kernels": [
     {"kernel": k, "grid_threads": g, "vgpr": vg, "lds": lds, "scratch": sc, "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
     for (k, g, vg, lds, sc), v in sorted(per.items(), key=lambda kv: -sum(kv[1]))],
-    "msm_accumulate_by_job": [{"grid_threads": g, "job_threads": j, "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
-                              for (g, j), v in sorted(acc_jobs.items(), key=lambda kv: -sum(kv[1]))],
+    "msm_accumulate_by_job": [{"grid_threads": g, "job_threads": j, "jobs_in_flight_at_issue": f, "launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+                              for (g, j, f), v in sorted(acc_jobs.items(), key=lambda kv: -sum(kv[1]))],
+    "msm_accumulate_attribution": attribution,
     "pmc": pmc,
     "note": "PMC units as reported by rocprofv3 (KB). gfx950: FETCH_SIZE under-reports wide coalesced streaming reads by 2x (MI355X_MICROARCH.md); 64-B gathers are uncalibrated. Collected in separate --pmc passes of the same bench command."}
 json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
