@@ -413,6 +413,7 @@ def batch_extra(args, rank, world, coll_dev):
         ru = resource.getrusage(resource.RUSAGE_SELF)
         return ru.ru_utime + ru.ru_stime
 
+    made = [0]      # proofs made by this run so far, warm-up and pre-sweep included (what a profile of the whole process contains)
     fault = os.environ.get("SUMMA_BENCH_FAULT", "")      # "rank:batch:seconds" -- tests/test_gpu_batch.py kills one rank mid-batch
 
     def timed_batch(subset, in_flight, headline=False):
@@ -440,6 +441,7 @@ def batch_extra(args, rank, world, coll_dev):
             dist.barrier()
         dt = _all_max(time.perf_counter() - t1, world, coll_dev)
         done, errs, cpu_all = _all_sum([len(res.proofs), len(res.errors) + failure, cpu], world, coll_dev)
+        made[0] += int(done)
         return int(done), int(errs), dt, res, cpu_all
 
     # warm-up and pre-sweep (short batches): every lane's plans, every worker thread's session; the best in-flight setting
@@ -470,6 +472,7 @@ def batch_extra(args, rank, world, coll_dev):
     out["host_cores_busy_per_gpu"] = sorted(r["host_cores_busy"] for r in reps)[len(reps) // 2]
     out["host"] = host_cpu_info()
     out["wait_sleep_us"] = last.wait_sleep_us
+    out["proofs_made_in_run"] = made[0]
     assert out["errors"] == 0 and all(r["proofs"] == total for r in reps), out
     if rank == 0:   # checker leg, outside every timed region: the oracle's verifier on a sample of the proofs made
         from oracle import summa_verifier as SV

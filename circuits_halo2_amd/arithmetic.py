@@ -511,6 +511,59 @@ def quotient_gates_cosets(values, graph: GraphEvaluator, fixed, advice, instance
     return values
 
 
+def quotient_numerator_cosets(values, gates: GraphEvaluator, lookup_input: GraphEvaluator, fixed, advice, instance, challenges, zs,
+                              perm_cols, sigmas, chunk_len: int, l0, l_last, l_active, lookup_z, permuted_input, permuted_table,
+                              table, beta, gamma, theta, y, k: int, ext_k: int, n_cosets: int, last_rotation_abs: int,
+                              input_work=None):
+    """halo2's evaluate_h over coset-major arrays in one call: values <- custom gates (previous value zero), permutation argument,
+    lookup argument with `lookup_input` evaluated on the way (C ABI: sg_quotient_numerator_cosets_dev -- one fused pass for the
+    reference circuit's programs, the separate kernels otherwise; the same words either way)"""
+    ns, m = len(zs), len(perm_cols)
+    if len(sigmas) != m:
+        raise ValueError("quotient_numerator_cosets: one sigma per column")
+    for t in [values, l0, l_last, l_active, lookup_z, permuted_input, permuted_table, table, *zs, *perm_cols, *sigmas, *fixed, *advice, *instance]:
+        if t.numel() != (32 * n_cosets) << k:
+            raise ValueError("quotient_numerator_cosets: every array has n_cosets * 2^k rows")
+    g, keep = gates._struct()
+    gi, keep_i = lookup_input._struct()
+    arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+    ch = np.ascontiguousarray(challenges, dtype=np.uint8) if len(challenges) else np.zeros(32, dtype=np.uint8)
+    ffi.check(ffi.lib().sg_quotient_numerator_cosets_dev(
+        ffi.dev_ptr(values), C.byref(g), C.byref(gi), arr(fixed), C.c_uint32(len(fixed)), arr(advice), C.c_uint32(len(advice)),
+        arr(instance), C.c_uint32(len(instance)), ffi.ptr(ch), C.c_uint32(len(challenges) // 32 if len(challenges) else 0),
+        arr(zs), C.c_uint32(ns), arr(perm_cols), arr(sigmas), C.c_uint32(m), C.c_uint32(chunk_len), ffi.dev_ptr(l0), ffi.dev_ptr(l_last),
+        ffi.dev_ptr(l_active), ffi.dev_ptr(lookup_z), ffi.dev_ptr(permuted_input), ffi.dev_ptr(permuted_table), ffi.dev_ptr(table),
+        ffi.dev_ptr(input_work) if input_work is not None else None, ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)), ffi.ptr(ffi.u8(theta)),
+        ffi.ptr(ffi.u8(y)), C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(n_cosets), C.c_uint32(last_rotation_abs), ffi.current_stream_ptr()))
+    return values
+
+
+def fr_lincomb_sets(sets, n: int, outs=None):
+    """several linear combinations of one length in ONE launch: sets = [(polys, coeffs (m x 32 B), low (<= 4 x 32 B or None)), ...];
+    returns the output tensors (C ABI: sg_fr_lincomb_sets_dev)"""
+    import torch
+    polys = [p for ps, _, _ in sets for p in ps]
+    for p in polys:
+        if p.numel() != 32 * n:
+            raise ValueError("fr_lincomb_sets: every polynomial has n coefficients")
+    coeffs = np.concatenate([ffi.u8(c).reshape(-1) for _, c, _ in sets])
+    sizes = (C.c_uint32 * len(sets))(*[len(ps) for ps, _, _ in sets])
+    lows = np.zeros((len(sets), 4, 32), dtype=np.uint8)
+    n_lows = (C.c_uint32 * len(sets))()
+    for i, (_, _, low) in enumerate(sets):
+        if low is not None and len(low):
+            lw = ffi.u8(low).reshape(-1, 32)
+            lows[i, :len(lw)] = lw
+            n_lows[i] = len(lw)
+    if outs is None:
+        outs = [torch.empty(32 * n, dtype=torch.uint8, device=polys[0].device) for _ in sets]
+    pp = (C.c_void_p * len(polys))(*[p.data_ptr() for p in polys])
+    po = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    ffi.check(ffi.lib().sg_fr_lincomb_sets_dev(pp, ffi.ptr(coeffs), sizes, C.c_uint32(len(sets)), C.c_size_t(n), ffi.ptr(lows.reshape(-1)),
+                                               n_lows, po, ffi.current_stream_ptr()))
+    return outs
+
+
 def gates_program_info(graph: GraphEvaluator, n_fixed: int, n_advice: int, n_instance: int, n_challenges: int):
     """(instructions per row, simultaneously live values = LDS slots per row) of the interpreter's lowering; host only"""
     g, keep = graph._struct()

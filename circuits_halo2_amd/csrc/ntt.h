@@ -34,7 +34,7 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 };
 #endif
 
-static constexpr uint32_t NTT_BATCH_MAX = 16;
+static constexpr uint32_t NTT_BATCH_MAX = 32;   // vectors per batched launch (the 25 coset blocks of a proof phase: one launch per pass)
 struct NttPlan {
   uint32_t log_n;
   words8 omega;
@@ -60,7 +60,9 @@ class NttEngine {
   // `count` <= NTT_BATCH_MAX in-place transforms of one size, one launch per pass (see ntt.hip)
   hipError_t transform_batch(fp_words* const* a, uint32_t count, fp_words* scratch, uint32_t log_n, const words8& omega,
                              const words8* scale, hipStream_t stream, const fp_words* const* src = nullptr,
-                             size_t src_len = 0, const words8* pre3 = nullptr);
+                             size_t src_len = 0, const words8* pre3 = nullptr, const fp_words* const* pre_tab = nullptr);
+  // (pre_tab[i]: optional table of 2^log_n 2^261-domain words; input element j of vector i is multiplied by pre_tab[i][j] on
+  //  the way into the first pass -- the coset shift c^j of coeff_to_cosets, which used to be a pass over HBM of its own)
   // cached table of omega_r^t, t < 2^(log_r - 1), as 2^261-domain words
   hipError_t local_twiddles(const words8& omega_r, uint32_t log_r, hipStream_t stream, fp_words** out);
 

@@ -55,6 +55,9 @@ struct PassArgs {
   uint32_t nbatch;
   const fp_words* in_b[NTT_BATCH_MAX];
   fp_words* out_b[NTT_BATCH_MAX];
+  // first pass of a batched launch: input element gi of vector y is multiplied by pre_tab_b[y][gi] (2^261-domain words) on load
+  uint32_t pre_tab;
+  const fp_words* pre_tab_b[NTT_BATCH_MAX];
 };
 
 struct LdsTile {
@@ -143,6 +146,7 @@ __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
         uint32_t m = (uint32_t)(gi % 3);
         if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
       }
+      if (p.pre_tab) v = f29_mul<P>(v, f29_load_r256<P>(p.pre_tab_b[blockIdx.y] + gi));   // x~ * (c^gi)^ = (x c^gi)~, bound < 2
     } else {
       v = f29_zero();
     }
@@ -446,8 +450,9 @@ static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n,
 // `count` in-place transforms of one size as ONE launch per pass.  scratch: count * 2^log_n elements (multi-pass plans)
 hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_words* scratch, uint32_t log_n,
                                       const words8& omega, const words8* scale, hipStream_t stream,
-                                      const fp_words* const* src, size_t src_len, const words8* pre3) {
+                                      const fp_words* const* src, size_t src_len, const words8* pre3, const fp_words* const* pre_tab) {
   if (count == 0) return hipSuccess;
+  if (pre_tab && (!src || src_len < ((size_t)1 << log_n))) return hipErrorInvalidValue;   // (the zero-padded load path does not take a table)
   if (count > NTT_BATCH_MAX || log_n == 0) return hipErrorInvalidValue;
   const NttPlan* pl;
   const bool fold_scale = scale && log_n > cfg_.max_single_log;
@@ -471,6 +476,11 @@ hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_wor
     if (first && pre3) {
       p.pre3 = 1;
       for (int i = 0; i < 3; i++) std::memcpy(p.pre[i], pre3[i].l, 32);
+    }
+    p.pre_tab = 0;
+    if (first && pre_tab) {
+      p.pre_tab = 1;
+      for (uint32_t i = 0; i < count; i++) p.pre_tab_b[i] = pre_tab[i];
     }
     first = false;
   };

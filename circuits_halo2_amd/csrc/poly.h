@@ -70,6 +70,12 @@ static constexpr uint32_t LINCOMB_MAX = 32;
 static constexpr uint32_t LINCOMB_LOW_MAX = 8;
 hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, uint32_t m, size_t n, fp_words* d_out,
                         hipStream_t stream, const words8* low = nullptr, uint32_t n_low = 0);
+// the same for up to LINCOMB_SETS_MAX independent combinations of one length in ONE launch (grid.y = combination): combination s
+// takes polys / coeffs [first[s], first[s + 1]) (at most LINCOMB_MAX of LINCOMB_SETS_POLYS in all) and n_low[s] <= LINCOMB_SETS_LOW
+// low coefficients -- the rotation sets of the multi-open
+static constexpr uint32_t LINCOMB_SETS_MAX = 8, LINCOMB_SETS_POLYS = 48, LINCOMB_SETS_LOW = 4;
+hipError_t poly_lincomb_sets(const fp_words* const* d_polys, const words8* coeffs, const uint32_t* first, uint32_t n_sets, size_t n,
+                             const words8* low, const uint32_t* n_low, fp_words* const* d_out, hipStream_t stream);
 // halo2 lookup::prover::permute_expression_pair for range tables (every table value < 2^16), on the device:
 // A' = the input rows sorted, S' = the table rearranged so that every row has A'[i] == S'[i] or A'[i] == A'[i-1]
 // (first occurrences take their value from the table, the leftover table values fill the repeated rows in

@@ -497,6 +497,44 @@ __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgs a, uint32_t m,
   f29_store_canonical<P>(out + i, f29_mul<P>(acc, f29_one<P>()));
 }
 
+struct LinCombSetsArgs {
+  const fp_words* polys[LINCOMB_SETS_POLYS];
+  words8 coeff[LINCOMB_SETS_POLYS];
+  words8 low[LINCOMB_SETS_MAX][LINCOMB_SETS_LOW];
+  fp_words* out[LINCOMB_SETS_MAX];
+  uint32_t first[LINCOMB_SETS_MAX + 1];
+  uint32_t n_low[LINCOMB_SETS_MAX];
+};
+__global__ void __launch_bounds__(256) lincomb_sets_kernel(LinCombSetsArgs a, uint32_t n) {
+  side_kernel_prio();
+  __shared__ uint32_t s_c[LINCOMB_MAX][9];
+  const uint32_t set = blockIdx.y, j0 = a.first[set], m = a.first[set + 1] - j0;
+  if (threadIdx.x < m) {
+    f29 c = f29_words_to_r261<P>(a.coeff[j0 + threadIdx.x].l);
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_c[threadIdx.x][q] = c.l[q];
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f29 acc = f29_zero();
+  for (uint32_t j = 0; j < m; j += 2) {                       // two terms per reduction (as lincomb_kernel)
+    f29 c0, c1 = f29_zero(), p1 = f29_zero();
+#pragma unroll
+    for (int q = 0; q < 9; q++) c0.l[q] = s_c[j][q];
+    const f29 p0 = f29_load_r256<P>(a.polys[j0 + j] + i);
+    if (j + 1 < m) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) c1.l[q] = s_c[j + 1][q];
+      p1 = f29_load_r256<P>(a.polys[j0 + j + 1] + i);
+    }
+    acc = f29_add(acc, f29_mul2<P>(p0, c0, p1, c1));
+    if ((j & 31) == 30) acc = f29_mul<P>(acc, f29_one<P>());
+  }
+  if (i < a.n_low[set]) acc = f29_add(acc, f29_from_words<0>(a.low[set][i].l));
+  f29_store_canonical<P>(a.out[set] + i, f29_mul<P>(acc, f29_one<P>()));
+}
+
 // ------------------------------------------------------------------ host side
 hipError_t poly_eval(const fp_words* d_coeffs, size_t n, const words8& x, fp_words* d_tmp_a, fp_words* d_tmp_b,
                      fp_words* d_out, hipStream_t stream) {
@@ -789,6 +827,27 @@ hipError_t poly_lincomb(const fp_words* const* d_polys, const words8* coeffs, ui
   a.n_low = n_low;
   for (uint32_t t = 0; t < n_low; t++) a.low[t] = low[t];
   lincomb_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, m, (uint32_t)n, d_out);
+  return hipGetLastError();
+}
+
+hipError_t poly_lincomb_sets(const fp_words* const* d_polys, const words8* coeffs, const uint32_t* first, uint32_t n_sets, size_t n,
+                             const words8* low, const uint32_t* n_low, fp_words* const* d_out, hipStream_t stream) {
+  if (n_sets == 0 || n_sets > LINCOMB_SETS_MAX || first[0] != 0 || first[n_sets] > LINCOMB_SETS_POLYS) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  LinCombSetsArgs a{};
+  for (uint32_t s = 0; s < n_sets; s++) {
+    if (first[s + 1] < first[s] || first[s + 1] - first[s] > LINCOMB_MAX || n_low[s] > LINCOMB_SETS_LOW || n_low[s] > n) return hipErrorInvalidValue;
+    a.first[s] = first[s];
+    a.n_low[s] = n_low[s];
+    a.out[s] = d_out[s];
+    for (uint32_t t = 0; t < n_low[s]; t++) a.low[s][t] = low[s * LINCOMB_SETS_LOW + t];
+  }
+  a.first[n_sets] = first[n_sets];
+  for (uint32_t j = 0; j < first[n_sets]; j++) {
+    a.polys[j] = d_polys[j];
+    a.coeff[j] = coeffs[j];
+  }
+  lincomb_sets_kernel<<<dim3((unsigned)((n + 255) / 256), n_sets), 256, 0, stream>>>(a, (uint32_t)n);
   return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 // ONE fused two-product reduction  values * y^ + raw_term * 2^(261+5j)  (f29_mul2), which both
 // applies the y-fold and undoes the drift.  ~45 products per row: VALU-bound like the rest.
 #include "quotient.h"
+#include "quotient_device.cuh"
 #include "side_prio.cuh"
 
 #include <cstring>
@@ -26,125 +27,28 @@
 namespace sg {
 SG_DEFINE_SIDE_PRIO_SETTER(quotient_set_side_prio)
 
-typedef Fr29 P;
-__device__ __forceinline__ f29 ld(const fp_words* p, size_t i) { return f29_load_r256<P>(p + i); }
-__device__ __forceinline__ f29 fold(const f29& acc, const f29& y_hat, const f29& raw, int j) {
-  return f29_mul2<P>(acc, y_hat, raw, f29_const<P>(P::p2[j]));
-}
-
-struct QuotConsts {  // per-launch constants, converted once per workgroup
-  f29 beta_hat, gamma_t, y_hat, delta_hat, bz_t, w_base_hat, one_t;
-};
-
 __global__ void __launch_bounds__(256) quot_perm_kernel(QuotPermArgs a) {
   side_kernel_prio();
-  __shared__ uint32_t sc[7][9];
-  const uint32_t tid = threadIdx.x;
+  __shared__ uint32_t sc[QUOT_PERM_CONSTS][9];
   const size_t n_blk = (size_t)1 << a.ext_k;                       // rows per block: the whole domain, or one coset
   const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : n_blk;
-  const size_t first = (size_t)blockIdx.x * blockDim.x;
-  // a workgroup lies inside one block when blocks are at least a workgroup long; otherwise (tiny domains) every thread
-  // takes its own block's shift and power
-  const bool uniform = !a.cosets || n_blk >= blockDim.x;
-  if (tid < 7) {
-    f29 v;
-    if (tid == 0) v = f29_words_to_r261<P>(a.beta);
-    else if (tid == 1) v = f29_from_words<0>(a.gamma);
-    else if (tid == 2) v = f29_words_to_r261<P>(a.y);
-    else if (tid == 3) v = f29_words_to_r261<P>(a.delta);
-    else if (tid == 4) v = f29_mul<P>(f29_from_words<0>(a.beta), f29_words_to_r261<P>(a.cosets ? a.shift[min((size_t)QUOT_MAX_COSETS - 1, first >> a.k)] : a.zeta));   // (beta shift)~
-    else if (tid == 5) v = f29_pow_u64<P>(f29_words_to_r261<P>(a.omega_ext), (uint64_t)(first & (n_blk - 1)));
-    else v = f29_const<P>(P::r256);                                                                 // 1~
-#pragma unroll
-    for (int q = 0; q < 9; q++) sc[tid][q] = v.l[q];
-  }
+  quot_perm_setup(a, sc, (size_t)blockIdx.x * blockDim.x);
   __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_ext) return;
-  auto cst = [&](int k) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sc[k][q]; return r; };
-  const f29 beta_hat = cst(0), gamma_t = cst(1), y_hat = cst(2), delta_hat = cst(3), one_t = cst(6);
-  const size_t mask = n_blk - 1, base = i & ~mask;
-  const size_t rot = (size_t)1 << (a.ext_k - a.k);
-  const size_t i_next = base | ((i + rot) & mask);
-  const size_t i_last = base | ((i + n_blk - (size_t)a.last_rot_abs * rot) & mask);
-
-  f29 acc = ld(a.values, i);
-  const f29 l0 = ld(a.l0, i);
-  // l0 (1 - z_0)
-  acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(one_t, ld(a.z[0], i)), l0), 1);
-  // l_last (z_l^2 - z_l) = l_last * z_l * (z_l - 1)
-  {
-    f29 zl = ld(a.z[a.nsets - 1], i);
-    f29 t = f29_mul<P>(f29_mul<P>(f29_sub<P, 0>(zl, one_t), zl), ld(a.l_last, i));
-    acc = fold(acc, y_hat, t, 2);
-  }
-  // l0 (z_s - z_{s-1}(w^last X))
-  for (uint32_t s = 1; s < a.nsets; s++)
-    acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(ld(a.z[s], i), ld(a.z[s - 1], i_last)), l0), 1);
-  // product terms; current_delta~ = (beta zeta)~ * omega_ext^i, times delta per column
-  f29 cd;
-  if (uniform) {
-    cd = f29_mul<P>(cst(4), f29_mul<P>(cst(5), ld(a.pow_lo, tid)));   // tilde * hat = tilde; pow_lo holds hats
-  } else {
-    const f29 bs = f29_mul<P>(f29_from_words<0>(a.beta), f29_words_to_r261<P>(a.shift[i >> a.k]));
-    cd = f29_mul<P>(bs, f29_pow_u64<P>(f29_words_to_r261<P>(a.omega_ext), (uint64_t)(i & mask)));
-  }
-  const f29 l_active = ld(a.l_active, i);
-  uint32_t col = 0;
-  for (uint32_t s = 0; s < a.nsets; s++) {
-    const uint32_t m = min(a.chunk_len, a.ncols - col);
-    f29 left = ld(a.z[s], i_next), right = ld(a.z[s], i);
-    for (uint32_t j = 0; j < m; j++, col++) {
-      const f29 v = ld(a.cols[col], i);
-      f29 fl = f29_add(f29_add(v, f29_mul<P>(ld(a.sigma[col], i), beta_hat)), gamma_t);    // < 4
-      f29 fr = f29_add(f29_add(v, cd), gamma_t);                                         // < 4
-      left = f29_mul<P>(left, fl);
-      right = f29_mul<P>(right, fr);
-      cd = f29_mul<P>(cd, delta_hat);
-    }
-    acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(left, right), l_active), (int)m + 1);
-  }
-  f29_store_canonical<P>(a.values + i, acc);
+  f29_store_canonical<P>(a.values + i, quot_perm_terms(a, sc, ld(a.values, i), i));
 }
 
 __global__ void __launch_bounds__(256) quot_lookup_kernel(QuotLookupArgs a) {
   side_kernel_prio();
-  __shared__ uint32_t sc[4][9];
-  const uint32_t tid = threadIdx.x;
+  __shared__ uint32_t sc[QUOT_LOOKUP_CONSTS][9];
   const size_t n_blk = (size_t)1 << a.ext_k;
   const size_t n_ext = a.cosets ? (size_t)a.cosets << a.k : n_blk;
-  if (tid < 4) {
-    f29 v;
-    if (tid == 0) v = f29_from_words<0>(a.beta);
-    else if (tid == 1) v = f29_from_words<0>(a.gamma);
-    else if (tid == 2) v = f29_words_to_r261<P>(a.y);
-    else v = f29_const<P>(P::r256);
-#pragma unroll
-    for (int q = 0; q < 9; q++) sc[tid][q] = v.l[q];
-  }
+  quot_lookup_setup(a, sc);
   __syncthreads();
-  const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_ext) return;
-  auto cst = [&](int k) { f29 r; for (int q = 0; q < 9; q++) r.l[q] = sc[k][q]; return r; };
-  const f29 beta_t = cst(0), gamma_t = cst(1), y_hat = cst(2), one_t = cst(3);
-  const size_t mask = n_blk - 1, base = i & ~mask;
-  const size_t rot = (size_t)1 << (a.ext_k - a.k);
-  const size_t i_next = base | ((i + rot) & mask), i_prev = base | ((i + n_blk - rot) & mask);
-
-  f29 acc = ld(a.values, i);
-  const f29 l0 = ld(a.l0, i), l_active = ld(a.l_active, i);
-  const f29 z = ld(a.z, i), ap = ld(a.permuted_input, i), sp = ld(a.permuted_table, i);
-  acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(one_t, z), l0), 1);
-  acc = fold(acc, y_hat, f29_mul<P>(f29_mul<P>(f29_sub<P, 0>(z, one_t), z), ld(a.l_last, i)), 2);
-  {
-    f29 lhs = f29_mul<P>(f29_mul<P>(ld(a.z, i_next), f29_add(ap, beta_t)), f29_add(sp, gamma_t));
-    f29 rhs = f29_mul<P>(f29_mul<P>(z, f29_add(ld(a.input, i), beta_t)), f29_add(ld(a.table, i), gamma_t));
-    acc = fold(acc, y_hat, f29_mul<P>(f29_sub<P, 0>(lhs, rhs), l_active), 3);
-  }
-  const f29 d = f29_sub<P, 0>(ap, sp);                                   // a' - s' (+2r), bound 3
-  acc = fold(acc, y_hat, f29_mul<P>(d, l0), 1);
-  acc = fold(acc, y_hat, f29_mul<P>(f29_mul<P>(d, f29_sub<P, 0>(ap, ld(a.permuted_input, i_prev))), l_active), 2);
-  f29_store_canonical<P>(a.values + i, acc);
+  f29_store_canonical<P>(a.values + i, quot_lookup_terms(a, sc, ld(a.values, i), ld(a.input, i), i));
 }
 
 // ------------------------------------------------------------------ cosets (see quotient.h)

@@ -27,6 +27,7 @@
 #include "ntt.h"
 #include "quotient.h"
 #include "gates.h"
+#include "numerator.h"
 #include "poly.h"
 #include "witness.h"
 #include "side_prio.cuh"
@@ -442,6 +443,7 @@ int apply_param(Context& c, const std::string& s, int value) {
     if (e == hipSuccess) e = poly_set_side_prio(on);
     if (e == hipSuccess) e = quotient_set_side_prio(on);
     if (e == hipSuccess) e = gates_set_side_prio(on);
+    if (e == hipSuccess) e = numerator_set_side_prio(on);
     if (e == hipSuccess) e = witness_set_side_prio(on);
     if (e == hipSuccess) e = abi_set_side_prio(on);
     if (e != hipSuccess) return hip_fail("side_prio", e);
@@ -1425,7 +1427,7 @@ int sg_ntt_fr_batch_dev(void* const* d_a, size_t count, const uint8_t omega[32],
       }
       uint8_t* scr = nullptr;
       if (need_scratch) {
-        hipError_t e = scratch_for(s, 3, (size_t)NTT_BATCH_MAX * n * 32, &scr);
+        hipError_t e = scratch_for(s, 3, std::min<size_t>(count, NTT_BATCH_MAX) * n * 32, &scr);
         if (e != hipSuccess) return hip_fail("ntt scratch", e);
       }
       hipError_t e = c.ntt.transform_batch(ptrs, cnt, reinterpret_cast<fp_words*>(scr), log_n, w, divisor ? &dv : nullptr, s);
@@ -1685,6 +1687,8 @@ static int coset_tables_for(uint32_t k, uint32_t ext_k, uint32_t nc, const Conte
   *out = &it->second;
   return SG_OK;
 }
+// debug / A-B: 1 = the coset shift as a pass of its own before the transforms (rounds 3-4), 0 = folded into the first NTT pass
+static std::atomic<int> g_coset_scale_pass{0};
 static bool coset_shape_ok(uint32_t k, uint32_t ext_k, uint32_t nc) {
   return k >= 1 && ext_k > k && ext_k <= 28 && nc >= 1 && nc <= MAX_COSETS && nc <= (1u << (ext_k - k));
 }
@@ -1700,7 +1704,7 @@ static int coset_ntts(fp_words* const* ptrs, size_t count, uint32_t k, bool inve
       const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, count - first);
       uint8_t* scr = nullptr;
       if (need_scratch) {
-        hipError_t e = scratch_for(s, 3, (size_t)NTT_BATCH_MAX * n * 32, &scr);
+        hipError_t e = scratch_for(s, 3, (size_t)cnt * n * 32, &scr);
         if (e != hipSuccess) return hip_fail("ntt scratch", e);
       }
       hipError_t e = c.ntt.transform_batch(ptrs + first, cnt, reinterpret_cast<fp_words*>(scr), k, inverse ? dk->omega_inv : dk->omega,
@@ -1724,6 +1728,27 @@ int sg_coeff_to_cosets_batch_dev(const void* const* d_coeffs, void* const* d_out
   hipStream_t s = pick_stream(stream);
   TRY(sync_own_stream_into(s));
   const size_t n = (size_t)1 << k;
+  if (k <= 18 && !g_coset_scale_pass.load()) {
+    // the coset shift c_b^i rides on the load of the first NTT pass (a table of 2^261-domain words per coset, indexed like the
+    // input): no pass over HBM of its own, and every block of every column is a vector of ONE batched launch per pass
+    const DomainConsts* dk;
+    TRY(get_consts(k, &dk));
+    std::vector<fp_words*> blocks;
+    std::vector<const fp_words*> srcs, tabs;
+    for (size_t j = 0; j < count; j++)
+      for (uint32_t b = 0; b < n_cosets; b++) {
+        blocks.push_back(static_cast<fp_words*>(d_out[j]) + b * n);
+        srcs.push_back(static_cast<const fp_words*>(d_coeffs[j]));
+        tabs.push_back(t->fwd + b * n);
+      }
+    for (size_t first = 0; first < blocks.size(); first += NTT_BATCH_MAX) {
+      const uint32_t cnt = (uint32_t)std::min<size_t>(NTT_BATCH_MAX, blocks.size() - first);
+      hipError_t e = g_ctx->ntt.transform_batch(blocks.data() + first, cnt, nullptr, k, dk->omega, nullptr, s, srcs.data() + first, n, nullptr,
+                                                tabs.data() + first);
+      if (e != hipSuccess) return hip_fail("coset ntt batch", e);
+    }
+    return SG_OK;
+  }
   std::vector<fp_words*> blocks;
   for (size_t first = 0; first < count; first += COSET_BATCH_MAX) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(COSET_BATCH_MAX, count - first);
@@ -2372,6 +2397,32 @@ int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uin
   return SG_OK;
 }
 
+int sg_fr_lincomb_sets_dev(const void* const* d_polys, const uint8_t* coeffs, const uint32_t* set_sizes, uint32_t n_sets, size_t n,
+                           const uint8_t* lows, const uint32_t* n_lows, void* const* d_outs, void* stream) {
+  if (!d_polys || !coeffs || !set_sizes || !d_outs || n_sets == 0 || n_sets > LINCOMB_SETS_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: bad argument");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: vector too long");
+  uint32_t first[LINCOMB_SETS_MAX + 1] = {0}, nl[LINCOMB_SETS_MAX] = {0};
+  for (uint32_t s = 0; s < n_sets; s++) {
+    if (set_sizes[s] > LINCOMB_MAX) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: at most 32 polynomials per combination");
+    first[s + 1] = first[s] + set_sizes[s];
+    nl[s] = n_lows ? n_lows[s] : 0;
+    if (nl[s] > LINCOMB_SETS_LOW || nl[s] > n || (nl[s] && !lows)) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: at most 4 low coefficients per combination");
+    if (n && !d_outs[s]) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: null output");
+  }
+  if (first[n_sets] > LINCOMB_SETS_POLYS) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: at most 48 polynomials in all");
+  for (uint32_t j = 0; j < first[n_sets]; j++)
+    if (n && !d_polys[j]) return fail(SG_ERR_INVALID, "sg_fr_lincomb_sets: null polynomial");
+  LOCKED_CTX();
+  words8 cw[LINCOMB_SETS_POLYS], lw[LINCOMB_SETS_MAX * LINCOMB_SETS_LOW];
+  std::memcpy(cw, coeffs, 32 * (size_t)first[n_sets]);
+  std::memset(lw, 0, sizeof lw);
+  if (lows) std::memcpy(lw, lows, 32 * (size_t)n_sets * LINCOMB_SETS_LOW);
+  hipError_t e = poly_lincomb_sets(reinterpret_cast<const fp_words* const*>(d_polys), cw, first, n_sets, n, lw, nl,
+                                   reinterpret_cast<fp_words* const*>(d_outs), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("lincomb sets", e);
+  return SG_OK;
+}
+
 // ------------------------------------------------------------------ quotient numerator (evaluate_h, generic parts)
 // cosets = 0: the whole extended domain (row i = zeta omega_ext^i); cosets = c: coset-major arrays, block b = the 2^k rows
 // of the coset zeta omega_ext^b H
@@ -2485,16 +2536,11 @@ int sg_quotient_lookup_cosets_dev(void* d_values, const void* d_z, const void* d
                               y, k, k, n_cosets, stream);
 }
 
-static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
-                               const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
-                               uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
-                               const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
-                               uint32_t k, uint32_t ext_k, uint32_t cosets, void* stream) {
-  if (!d_values || !graph || !beta || !gamma || !theta || !y || (n_fixed && !d_fixed) || (n_advice && !d_advice) ||
-      (n_instance && !d_instance) || (n_challenges && !challenges))
-    return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
-  if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_gates: bad shape");
-  LOCKED_CTX();
+// the lowered program of a graph, from the lane's cache (compiled on first sight), with its constant table refreshed for this
+// call: constants ++ challenges ++ beta, gamma, theta, y (compile_gates' order).  The caller holds the lane.
+static int gate_program_for(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, const uint8_t* challenges,
+                            uint32_t n_challenges, const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32],
+                            const uint8_t y[32], GateProgram** out) {
   // the lowered program depends on the graph's structure only (constants / challenges are a table refreshed per call):
   // cached under the structure itself.  A prover sends the same two programs proof after proof, so the lane's most recent
   // hits are tried first with one memcmp each (the structure of the reference circuit's gate program is 100+ KB: hashing
@@ -2564,6 +2610,22 @@ static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void
     for (uint32_t i = 0; i < n_challenges; i++) push(challenges + 32 * (size_t)i);
     push(beta); push(gamma); push(theta); push(y);
   }
+  *out = &prog;
+  return SG_OK;
+}
+static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void* const* d_fixed, uint32_t n_fixed,
+                               const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                               uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
+                               const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
+                               uint32_t k, uint32_t ext_k, uint32_t cosets, void* stream) {
+  if (!d_values || !graph || !beta || !gamma || !theta || !y || (n_fixed && !d_fixed) || (n_advice && !d_advice) ||
+      (n_instance && !d_instance) || (n_challenges && !challenges))
+    return fail(SG_ERR_INVALID, "sg_quotient_gates: null argument");
+  if (k == 0 || ext_k < k || ext_k > 28) return fail(SG_ERR_INVALID, "sg_quotient_gates: bad shape");
+  LOCKED_CTX();
+  GateProgram* prog_p = nullptr;
+  TRY(gate_program_for(graph, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y, &prog_p));
+  GateProgram& prog = *prog_p;
   if (prog.n_slots > 64) return fail(SG_ERR_INVALID, "sg_quotient_gates: more than 64 simultaneously live values");
   std::vector<const void*> cols;
   for (uint32_t i = 0; i < n_fixed; i++) cols.push_back(d_fixed[i]);
@@ -2620,6 +2682,110 @@ int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const vo
   return quotient_gates_impl(d_values, graph, d_fixed, n_fixed, d_advice, n_advice, d_instance, n_instance, challenges, n_challenges, beta,
                              gamma, theta, y, k, k, n_cosets, stream);
 }
+// halo2's evaluate_h in one call: values <- gates, then the permutation argument, then the lookup argument (input expression
+// evaluated on the way).  One fused kernel when the two programs are known ahead of time (csrc/numerator.hip), otherwise the
+// separate kernels one after the other -- the same words either way.
+static std::atomic<int> g_numerator_fused{1};   // "quotient.fused_numerator": 0 forces the separate kernels (A-B, tests)
+int sg_quotient_numerator_cosets_dev(void* d_values, const sg_graph* gates, const sg_graph* lookup_input, const void* const* d_fixed,
+                                     uint32_t n_fixed, const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                                     uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges, const void* const* d_z,
+                                     uint32_t nsets, const void* const* d_perm_cols, const void* const* d_sigma, uint32_t ncols,
+                                     uint32_t chunk_len, const void* d_l0, const void* d_l_last, const void* d_l_active,
+                                     const void* d_lookup_z, const void* d_permuted_input, const void* d_permuted_table,
+                                     const void* d_table, void* d_input_work, const uint8_t beta[32], const uint8_t gamma[32],
+                                     const uint8_t theta[32], const uint8_t y[32], uint32_t k, uint32_t ext_k, uint32_t n_cosets,
+                                     uint32_t last_rotation_abs, void* stream) {
+  if (!d_values || !gates || !lookup_input || !d_z || !d_perm_cols || !d_sigma || !d_l0 || !d_l_last || !d_l_active || !d_lookup_z ||
+      !d_permuted_input || !d_permuted_table || !d_table || !beta || !gamma || !theta || !y || (n_fixed && !d_fixed) ||
+      (n_advice && !d_advice) || (n_instance && !d_instance) || (n_challenges && !challenges))
+    return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: null argument");
+  if (!coset_shape_ok(k, ext_k, n_cosets) || n_cosets > QUOT_MAX_COSETS) return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: bad shape");
+  if (nsets == 0 || nsets > QUOT_MAX_SETS || ncols == 0 || ncols > QUOT_MAX_COLS || chunk_len == 0 || (ncols + chunk_len - 1) / chunk_len != nsets)
+    return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: bad permutation shape");
+  bool fused = false;
+  if (g_numerator_fused.load() && n_fixed + n_advice + n_instance <= NUM_MAX_COLS) {
+    LOCKED_CTX();
+    if (g_ctx->gate_cache.size() >= 62) g_ctx->gate_cache.clear();   // neither look-up below may evict the other's program
+    GateProgram *pg = nullptr, *pi = nullptr;
+    const uint8_t none[32] = {0};
+    TRY(gate_program_for(gates, n_fixed, n_advice, n_instance, challenges, n_challenges, beta, gamma, theta, y, &pg));
+    TRY(gate_program_for(lookup_input, n_fixed, n_advice, n_instance, none, 0, beta, gamma, theta, y, &pi));
+    if (numerator_fused_available(*pg, *pi)) {
+      NumeratorArgs a;
+      std::memset(&a, 0, sizeof a);
+      a.values = static_cast<fp_words*>(d_values);
+      uint32_t c = 0;
+      for (uint32_t i = 0; i < n_fixed; i++) a.cols[c++] = static_cast<const fp_words*>(d_fixed[i]);
+      for (uint32_t i = 0; i < n_advice; i++) a.cols[c++] = static_cast<const fp_words*>(d_advice[i]);
+      for (uint32_t i = 0; i < n_instance; i++) a.cols[c++] = static_cast<const fp_words*>(d_instance[i]);
+      for (uint32_t i = 0; i < c; i++)
+        if (!a.cols[i]) return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: null column");
+      QuotPermArgs& pa = a.perm;
+      for (uint32_t i = 0; i < nsets; i++) {
+        if (!d_z[i]) return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: null z");
+        pa.z[i] = static_cast<const fp_words*>(d_z[i]);
+      }
+      for (uint32_t i = 0; i < ncols; i++) {
+        if (!d_perm_cols[i] || !d_sigma[i]) return fail(SG_ERR_INVALID, "sg_quotient_numerator_cosets: null permutation column");
+        pa.cols[i] = static_cast<const fp_words*>(d_perm_cols[i]);
+        pa.sigma[i] = static_cast<const fp_words*>(d_sigma[i]);
+      }
+      pa.l0 = static_cast<const fp_words*>(d_l0);
+      pa.l_last = static_cast<const fp_words*>(d_l_last);
+      pa.l_active = static_cast<const fp_words*>(d_l_active);
+      pa.nsets = nsets; pa.ncols = ncols; pa.chunk_len = chunk_len; pa.k = k; pa.ext_k = k; pa.cosets = n_cosets;
+      pa.last_rot_abs = last_rotation_abs;
+      const DomainConsts* dk;
+      TRY(get_consts(k, &dk));
+      std::memcpy(pa.beta, beta, 32); std::memcpy(pa.gamma, gamma, 32); std::memcpy(pa.y, y, 32);
+      std::memcpy(pa.delta, DELTA_M, 32); std::memcpy(pa.zeta, &dk->zeta, 32); std::memcpy(pa.omega_ext, &dk->omega, 32);
+      const Context::CosetTables* t;
+      TRY(coset_tables_for(k, ext_k, n_cosets, &t));
+      for (uint32_t b = 0; b < n_cosets; b++) std::memcpy(pa.shift[b], &t->shift[b], 32);
+      hipStream_t s = pick_stream(stream);
+      fp_words* pw = nullptr;
+      hipError_t e = g_ctx->ntt.local_twiddles(dk->omega, 9, s, &pw);   // omega^t, t < 256
+      if (e != hipSuccess) return hip_fail("quotient twiddles", e);
+      pa.pow_lo = pw;
+      QuotLookupArgs& la = a.look;
+      la.z = static_cast<const fp_words*>(d_lookup_z);
+      la.permuted_input = static_cast<const fp_words*>(d_permuted_input);
+      la.permuted_table = static_cast<const fp_words*>(d_permuted_table);
+      la.table = static_cast<const fp_words*>(d_table);
+      la.l0 = pa.l0; la.l_last = pa.l_last; la.l_active = pa.l_active;
+      la.k = k; la.ext_k = k; la.cosets = n_cosets;
+      std::memcpy(la.beta, beta, 32); std::memcpy(la.gamma, gamma, 32); std::memcpy(la.y, y, 32);
+      e = numerator_fused(*pg, *pi, a, s);
+      if (e != hipSuccess) return hip_fail("quotient numerator", e);
+      fused = true;
+    }
+  }
+  if (fused) return SG_OK;
+  // any other pair of programs: the blocks one after the other over `values` (zeroed: a fresh numerator)
+  const size_t rows = (size_t)n_cosets << k;
+  void* input_work = d_input_work;
+  if (!input_work) {
+    LOCKED_CTX();
+    uint8_t* w = nullptr;
+    hipError_t e = scratch_for(pick_stream(stream), 8, rows * 32, &w);
+    if (e != hipSuccess) return hip_fail("numerator work space", e);
+    input_work = w;
+  }
+  {
+    LOCKED_CTX();
+    CHECK_HIP(hipMemsetAsync(d_values, 0, rows * 32, pick_stream(stream)), "memset");
+  }
+  const uint8_t none[32] = {0};
+  TRY(sg_quotient_gates_cosets_dev(d_values, gates, d_fixed, n_fixed, d_advice, n_advice, d_instance, n_instance, challenges, n_challenges, beta,
+                                   gamma, theta, y, k, n_cosets, stream));
+  TRY(sg_quotient_permutation_cosets_dev(d_values, d_z, nsets, d_perm_cols, d_sigma, ncols, chunk_len, d_l0, d_l_last, d_l_active, beta, gamma, y,
+                                         k, ext_k, n_cosets, last_rotation_abs, stream));
+  TRY(sg_quotient_gates_cosets_dev(input_work, lookup_input, d_fixed, n_fixed, d_advice, n_advice, d_instance, n_instance, none, 0, beta, gamma,
+                                   theta, y, k, n_cosets, stream));
+  return sg_quotient_lookup_cosets_dev(d_values, d_lookup_z, d_permuted_input, d_permuted_table, input_work, d_table, d_l0, d_l_last, d_l_active,
+                                       beta, gamma, y, k, n_cosets, stream);
+}
+
 // how the interpreter would run a program: instructions and simultaneously live values (LDS slots per row; 8 or fewer keep
 // two workgroups of 256 rows per CU).  Host-only: no device is touched.
 int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
@@ -2780,6 +2946,14 @@ int sg_set_param(const char* name, int value) {
   }
   if (s == "debug.fail_next_fused_job") {
     g_comb.fail_next.store(value ? 1 : 0);
+    return SG_OK;
+  }
+  if (s == "ntt.coset_scale_pass") {   // A-B: the coset shift of coeff_to_cosets as its own pass (1) or inside the first NTT pass (0, default)
+    g_coset_scale_pass.store(value ? 1 : 0);
+    return SG_OK;
+  }
+  if (s == "quotient.fused_numerator") {   // 1 (default): sg_quotient_numerator_cosets_dev may run its one-pass kernel; 0: always the separate kernels
+    g_numerator_fused.store(value ? 1 : 0);
     return SG_OK;
   }
   if (s == "msm.acc_log") {   // profiling: record every msm_accumulate launch in issue order (sg_msm_launch_log); setting 1 clears the log

@@ -355,6 +355,12 @@ int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_
  * zeros from row n_low on -- an instance column from its few values in one launch. */
 int sg_fr_lincomb_low_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, const uint8_t* low, uint32_t n_low,
                           void* d_out, void* stream);
+/* n_sets <= 8 such combinations of one length in ONE launch: combination s takes the next set_sizes[s] <= 32 entries of d_polys /
+ * coeffs (at most 48 in all), adds the n_lows[s] <= 4 coefficients lows[s * 4 ..] (32 B Montgomery each; lows is n_sets x 4 x 32
+ * bytes, n_lows / lows may be NULL) and writes d_outs[s].  The five rotation sets of SHPLONK's q_i(X) - r_i(X) are one launch
+ * instead of five (halo2 `multiopen::shplonk::prover::create_proof`: `rotation_sets.map(|set| ...)`).  Asynchronous on `stream`. */
+int sg_fr_lincomb_sets_dev(const void* const* d_polys, const uint8_t* coeffs, const uint32_t* set_sizes, uint32_t n_sets, size_t n,
+                           const uint8_t* lows, const uint32_t* n_lows, void* const* d_outs, void* stream);
 
 /* ---- the generic (circuit-independent) parts of halo2's `evaluate_h`
  * (halo2_proofs plonk/evaluation.rs, Evaluator::evaluate_h; the same terms, in the same
@@ -430,6 +436,27 @@ int sg_quotient_gates_cosets_dev(void* d_values, const sg_graph* graph, const vo
                                  uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges,
                                  const uint8_t beta[32], const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32],
                                  uint32_t k, uint32_t n_cosets, void* stream);
+
+/* halo2's `evaluate_h` for the quotient on cosets in ONE call: values <- the custom gates (program `gates`, previous value zero:
+ * d_values needs no clearing), folded with the permutation argument's terms (as sg_quotient_permutation_cosets_dev) and the lookup
+ * argument's (as sg_quotient_lookup_cosets_dev, its input column being program `lookup_input` over the same columns -- a lookup
+ * with ONE input and ONE table expression, so that theta does not enter).  When both programs are ones the library has
+ * straight-line code for (the reference circuit's, N_CURRENCIES 1 .. 4) a row's value stays in registers through all three
+ * blocks: one launch, every column read once, no memset, no blob upload (csrc/numerator.hip); any other pair runs the separate
+ * kernels one after the other (d_input_work: n_cosets * 2^k rows of work space for the input column, NULL = the library's own).
+ * The words written are the same either way.  d_perm_cols / d_sigma: the ncols permutation columns and their sigma polynomials in
+ * coset-major form; d_z: the nsets = ceil(ncols / chunk_len) grand products; parameter "quotient.fused_numerator" = 0 forces
+ * the separate kernels.  Asynchronous on `stream`.
+ * [UPSTREAM halo2_proofs::plonk::evaluation::Evaluator::evaluate_h: custom gates, permutations, lookups -- in this order] */
+int sg_quotient_numerator_cosets_dev(void* d_values, const sg_graph* gates, const sg_graph* lookup_input, const void* const* d_fixed,
+                                     uint32_t n_fixed, const void* const* d_advice, uint32_t n_advice, const void* const* d_instance,
+                                     uint32_t n_instance, const uint8_t* challenges, uint32_t n_challenges, const void* const* d_z,
+                                     uint32_t nsets, const void* const* d_perm_cols, const void* const* d_sigma, uint32_t ncols,
+                                     uint32_t chunk_len, const void* d_l0, const void* d_l_last, const void* d_l_active,
+                                     const void* d_lookup_z, const void* d_permuted_input, const void* d_permuted_table,
+                                     const void* d_table, void* d_input_work, const uint8_t beta[32], const uint8_t gamma[32],
+                                     const uint8_t theta[32], const uint8_t y[32], uint32_t k, uint32_t ext_k, uint32_t n_cosets,
+                                     uint32_t last_rotation_abs, void* stream);
 /* what the interpreter makes of a program: instructions per row and simultaneously live values (LDS slots per row; the
  * occupancy of the kernel is set by the latter).  Host only -- no device needed. */
 int sg_gates_program_info(const sg_graph* graph, uint32_t n_fixed, uint32_t n_advice, uint32_t n_instance, uint32_t n_challenges,
@@ -494,6 +521,8 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   that many chunks, which run as jobs on two engines while the next chunk is uploaded; default 2),
  * "msm.acc_trace" (0 | 1: debug -- every wave of msm_accumulate records when it starts and leaves; the job's host tail prints the
  *   percentiles to stderr: tools/acc_trace.sh, profiles/r04_sweeps/accumulate_tail.txt),
+ * "ntt.coset_scale_pass" (0 | 1: A-B aid -- sg_coeff_to_cosets_batch_dev multiplies by the coset shifts inside the first NTT pass
+ *   (0, default) or in a pass of its own before the transforms (1, rounds 3-4); same results), "msm.acc_log" (see sg_msm_launch_log),
  * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that
  *   its members fall back to jobs of their own),
  * "msm.window_bits", "msm.log_seg", "msm.log_red_chunk", "msm.quad", "ntt.tile_log", "ntt.threads",

@@ -992,8 +992,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   const sg_graph g_in = pk.lookup_input.view(), g_gates = pk.gates.view();
   std::vector<void*> fixed_lag_p, adv_lag_p = {advice[0].p, advice[1].p, advice[2].p}, inst_lag_p = {instance_col.p};
   for (auto& c : pk.fixed_lag) fixed_lag_p.push_back(c.p);
-  DevCol inp(n);
-  inp.zero();
+  DevCol inp(n);   // (not cleared: the input program writes every row and reads no previous value)
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
                            zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, main_stream()), "lookup input");
   DevCol pin(n), ptab(n);
@@ -1110,8 +1109,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   // -- 4: quotient
   // the kernels take the coset-major arrays whole (QUOTIENT_PIECES blocks of 2^k rows; a rotation is an index shift of 1 inside
   // a block): one launch each
-  DevCol values(ne), input_c(ne);
-  hk(hipMemsetAsync(values.p, 0, 32 * ne, main_stream()), "memset");
+  DevCol values(ne);
   std::vector<Fr> y_powers;   // the gate program's challenges: sums of powers of y (ProvingKey::gate_challenge_exps)
   {
     uint32_t top = 0;
@@ -1135,27 +1133,20 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   for (uint32_t i = 0; i < QUOTIENT_PIECES; i++) pieces_col.emplace_back(n);
   mark("4: buffers ready");
   {
+    // evaluate_h in one call: gates, permutation argument, lookup argument (its input expression on the way) -- one pass over
+    // the coset rows for this circuit's programs (sg_quotient_numerator_cosets_dev); `values` needs no clearing
     std::vector<void*> fixed_e, adv_e = {ex1[0].p, ex1[1].p, ex1[2].p}, inst_e = {ex1[3].p};
     for (auto& c : pk.fixed_ext) fixed_e.push_back(c.p);
-    ck(sg_quotient_gates_cosets_dev(values.p, &g_gates, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1,
-                                    y_powers[0].bytes(), (uint32_t)pk.gate_challenge_exps.size(), beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k,
-                                    QUOTIENT_PIECES, main_stream()), "gates");
-    mark("4: gate block enqueued");
     std::vector<void*> col_e, sig_e, z_e = {ex3[2].p, ex3[3].p};
     for (uint32_t c = 0; c < NUM_SIGMA; c++) {
       col_e.push_back(perm_kind[c] == SG_VS_ADVICE ? ex1[perm_idx[c]].p : perm_kind[c] == SG_VS_FIXED ? pk.fixed_ext[perm_idx[c]].p : ex1[3].p);
       sig_e.push_back(pk.sigma_ext[c].p);
     }
-    ck(sg_quotient_permutation_cosets_dev(values.p, z_e.data(), 2, col_e.data(), sig_e.data(), NUM_SIGMA, CHUNK, pk.l0_ext.p, pk.l_last_ext.p,
-                                          pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, ext_k, QUOTIENT_PIECES, BLINDING + 1,
-                                          main_stream()), "permutation quotient");
-    mark("4: permutation block enqueued");
-    ck(sg_quotient_gates_cosets_dev(input_c.p, &g_in, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1, nullptr, 0,
-                                    beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()), "lookup input (cosets)");
-    mark("4: lookup input enqueued");
-    ck(sg_quotient_lookup_cosets_dev(values.p, ex3[4].p, ex3[0].p, ex3[1].p, input_c.p, pk.fixed_ext[4].p, pk.l0_ext.p, pk.l_last_ext.p,
-                                     pk.l_active_ext.p, beta.bytes(), gamma.bytes(), y.bytes(), k, QUOTIENT_PIECES, main_stream()),
-       "lookup quotient");
+    ck(sg_quotient_numerator_cosets_dev(values.p, &g_gates, &g_in, fixed_e.data(), NUM_FIXED, adv_e.data(), NUM_ADVICE, inst_e.data(), 1,
+                                        y_powers[0].bytes(), (uint32_t)pk.gate_challenge_exps.size(), z_e.data(), 2, col_e.data(), sig_e.data(),
+                                        NUM_SIGMA, CHUNK, pk.l0_ext.p, pk.l_last_ext.p, pk.l_active_ext.p, ex3[4].p, ex3[0].p, ex3[1].p,
+                                        pk.fixed_ext[4].p, nullptr, beta.bytes(), gamma.bytes(), theta.bytes(), y.bytes(), k, ext_k, QUOTIENT_PIECES,
+                                        BLINDING + 1, main_stream()), "quotient numerator");
   }
   mark("4: numerator enqueued");
   std::vector<void*> pieces;
@@ -1202,14 +1193,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     evals[{order[i].key, order[i].rot}] = ev[i];
     tr.write_scalar(ev[i]);
   }
-  DevCol h_comb(n);
-  {
-    std::vector<Fr> pw(QUOTIENT_PIECES);
-    pw[0] = Fr::one();
-    for (uint32_t i = 1; i < QUOTIENT_PIECES; i++) pw[i] = pw[i - 1] * x_n;
-    ck(sg_fr_lincomb_dev(pieces.data(), pw[0].bytes(), QUOTIENT_PIECES, n, h_comb.p, main_stream()), "h lincomb");
-  }
-  poly[{H_, 0}] = h_comb.p;
+  // h(X) = sum_i x^(n i) h_i(X) is never formed: its one use -- a term of rotation set 1's combination -- takes the five
+  // pieces themselves with the weights zeta^j x^(n i) (below)
+  std::vector<Fr> xn_pow(QUOTIENT_PIECES);
+  xn_pow[0] = Fr::one();
+  for (uint32_t i = 1; i < QUOTIENT_PIECES; i++) xn_pow[i] = xn_pow[i - 1] * x_n;
   Fr h_eval = Fr::zero();
   for (uint32_t i = QUOTIENT_PIECES; i-- > 0;) h_eval = h_eval * x_n + ev[order.size() + i];
   auto eval_of = [&](const Key& key, int rot) { return key.kind == H_ ? h_eval : evals.at({key, rot}); };
@@ -1280,20 +1268,35 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     }
     rs.push_back(rc);
   }
-  fork();
-  for (size_t si = 0; si < sets.size(); si++) {   // the rotation sets are independent: round-robin over three streams
-    const auto& set = sets[si];
-    hipStream_t st = si % 3 == 0 ? main_stream() : side[si % 3 - 1];
-    std::vector<void*> ps;
-    for (size_t j = 0; j < set.polys.size(); j++) ps.push_back(poly.at(set.polys[j]));
-    std::vector<Fr> minus_r;
-    for (const Fr& c : rs[si]) minus_r.push_back(-c);
-    // f_i = q_i - r_i in one pass: q_i = the zeta-combination of the set's polynomials, r_i by value
-    fs.emplace_back(n);
-    ck(sg_fr_lincomb_low_dev(ps.data(), zps[si][0].bytes(), (uint32_t)ps.size(), n, minus_r[0].bytes(), (uint32_t)minus_r.size(),
-                             fs.back().p, st), "set lincomb");
+  {
+    // f_i = q_i - r_i for all five sets in ONE launch (grid.y = set): q_i = the zeta-combination of the set's polynomials, r_i by value
+    std::vector<void*> ps, outs;
+    std::vector<Fr> cs, lows(sets.size() * 4, Fr::zero());
+    std::vector<uint32_t> sizes, n_lows;
+    for (size_t si = 0; si < sets.size(); si++) {
+      const auto& set = sets[si];
+      uint32_t count = 0;
+      for (size_t j = 0; j < set.polys.size(); j++) {
+        if (set.polys[j].kind == H_) {
+          for (uint32_t i = 0; i < QUOTIENT_PIECES; i++, count++) {
+            ps.push_back(pieces[i]);
+            cs.push_back(zps[si][j] * xn_pow[i]);
+          }
+        } else {
+          ps.push_back(poly.at(set.polys[j]));
+          cs.push_back(zps[si][j]);
+          count++;
+        }
+      }
+      sizes.push_back(count);
+      for (size_t t = 0; t < rs[si].size(); t++) lows[4 * si + t] = -rs[si][t];
+      n_lows.push_back((uint32_t)rs[si].size());
+      fs.emplace_back(n);
+      outs.push_back(fs.back().p);
+    }
+    ck(sg_fr_lincomb_sets_dev(ps.data(), cs[0].bytes(), sizes.data(), (uint32_t)sets.size(), n, lows[0].bytes(), n_lows.data(), outs.data(),
+                              main_stream()), "set lincombs");
   }
-  join();
   // f_i / Z_{S_i}: q_i - r_i vanishes on the whole set, and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with
   // c_j = 1 / prod_{t != j} (p_j - p_t) -- the Lagrange denominators already inverted above.  So every division of every
   // set is an independent exact Kate division: ONE batch (three launches for all eleven), and

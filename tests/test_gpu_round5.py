@@ -1,0 +1,226 @@
+"""GPU tests of round 5's kernels, all through the C ABI: the one-pass quotient numerator against the separate kernels (which the
+oracle pins, tests/test_gpu_parity.py), the coset transform with the shift folded into the first NTT pass against the pass of
+its own, the rotation sets' linear combinations in one launch against one launch each, and the profiling / parameter entry
+points (launch log, sg_get_param, ABI revision)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import circuits_halo2_amd as sg
+    from circuits_halo2_amd import ffi
+    ffi.check(sg.lib().sg_init(0))
+    return sg
+
+
+def _rand_fr(seed, rows):
+    """`rows` canonical Montgomery field elements on the device"""
+    import torch
+    from circuits_halo2_amd.arithmetic import fr_to_montgomery
+    from circuits_halo2_amd.utils import random_fr_canonical
+    return fr_to_montgomery(torch.from_numpy(random_fr_canonical(seed, rows)).cuda())
+
+
+def _scalar(seed):
+    return _rand_fr(seed, 1).cpu().numpy()
+
+
+@pytest.mark.parametrize("nc", [1, 2, 3, 4])
+@pytest.mark.parametrize("k", [5, 9])
+def test_fused_numerator_matches_the_separate_kernels(gpu, nc, k):
+    """sg_quotient_numerator_cosets_dev with the reference circuit's own programs (the fused kernel) writes the words the separate
+    gate / permutation / lookup kernels write -- which the oracle pins -- over random columns; `values` arrives full of
+    garbage (the entry point promises that it needs no clearing); k = 5: blocks shorter than a workgroup (every thread takes
+    its own coset's shift), k = 9: the uniform path"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi, mst_inclusion as M
+    d, n = 5, 1 << k
+    ext_k = k + 3
+    rows = d * n
+    seed = iter(range(1000 * nc + 100 * k, 10 ** 6))
+    col = lambda: _rand_fr(next(seed), rows)
+    fixed = [col() for _ in range(M.NUM_FIXED)]
+    advice = [col() for _ in range(M.NUM_ADVICE)]
+    inst = [col()]
+    zs = [col(), col()]
+    sigmas = [col() for _ in range(6)]
+    perm_cols = [fixed[2], advice[0], advice[1], fixed[3], advice[2], inst[0]]
+    l0, l_last, l_active, lz, pin, ptab = col(), col(), col(), col(), col(), col()
+    beta, gamma, theta, y = (_scalar(next(seed)) for _ in range(4))
+    n_chal = len(M.gate_challenge_exponents(nc))
+    challenges = _rand_fr(next(seed), n_chal).cpu().numpy()
+    gates, look = M.gate_graph(nc), M.lookup_input_graph()
+    none = np.zeros(0, dtype=np.uint8)
+
+    def run(fused):
+        ffi.set_param("quotient.fused_numerator", 1 if fused else 0)
+        try:
+            values = _rand_fr(4242, rows)         # garbage in
+            A.quotient_numerator_cosets(values, gates, look, fixed, advice, inst, challenges, zs, perm_cols, sigmas, 4, l0, l_last, l_active,
+                                        lz, pin, ptab, fixed[4], beta, gamma, theta, y, k, ext_k, d, 6)
+            torch.cuda.synchronize()
+            return values
+        finally:
+            ffi.set_param("quotient.fused_numerator", 1)
+
+    got, want = run(True), run(False)
+    assert (got == want).all()
+    # ... and the separate kernels driven by hand (what the Python driver still does)
+    values = torch.zeros(32 * rows, dtype=torch.uint8, device="cuda")
+    A.quotient_gates_cosets(values, gates, fixed, advice, inst, challenges, beta, gamma, theta, y, k, d)
+    A.quotient_permutation_cosets(values, zs, perm_cols, sigmas, 4, l0, l_last, l_active, beta, gamma, y, k, ext_k, d, 6)
+    input_c = torch.empty(32 * rows, dtype=torch.uint8, device="cuda")
+    A.quotient_gates_cosets(input_c, look, fixed, advice, inst, none, beta, gamma, theta, y, k, d)
+    A.quotient_lookup_cosets(values, lz, pin, ptab, input_c, fixed[4], l0, l_last, l_active, beta, gamma, y, k, d)
+    assert (got == values).all() and got.any()
+
+
+def test_numerator_of_an_unknown_program_takes_the_separate_kernels(gpu):
+    """a gate program the library has no straight-line code for (here: the lookup's input expression in the gates' place) runs the
+    separate kernels behind the same entry point, fused or not"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi, mst_inclusion as M
+    k, d = 6, 5
+    rows = d << k
+    seed = iter(range(777, 10 ** 6))
+    col = lambda: _rand_fr(next(seed), rows)
+    fixed, advice, inst = [col() for _ in range(M.NUM_FIXED)], [col() for _ in range(M.NUM_ADVICE)], [col()]
+    zs, sigmas = [col(), col()], [col() for _ in range(6)]
+    perm_cols = [fixed[2], advice[0], advice[1], fixed[3], advice[2], inst[0]]
+    l0, l_last, l_active, lz, pin, ptab = col(), col(), col(), col(), col(), col()
+    beta, gamma, theta, y = (_scalar(next(seed)) for _ in range(4))
+    look = M.lookup_input_graph()
+    none = np.zeros(0, dtype=np.uint8)
+    got = _rand_fr(1, rows)
+    A.quotient_numerator_cosets(got, look, look, fixed, advice, inst, none, zs, perm_cols, sigmas, 4, l0, l_last, l_active, lz, pin, ptab,
+                                fixed[4], beta, gamma, theta, y, k, k + 3, d, 6)
+    values = torch.zeros(32 * rows, dtype=torch.uint8, device="cuda")
+    A.quotient_gates_cosets(values, look, fixed, advice, inst, none, beta, gamma, theta, y, k, d)
+    A.quotient_permutation_cosets(values, zs, perm_cols, sigmas, 4, l0, l_last, l_active, beta, gamma, y, k, k + 3, d, 6)
+    input_c = torch.empty(32 * rows, dtype=torch.uint8, device="cuda")
+    A.quotient_gates_cosets(input_c, look, fixed, advice, inst, none, beta, gamma, theta, y, k, d)
+    A.quotient_lookup_cosets(values, lz, pin, ptab, input_c, fixed[4], l0, l_last, l_active, beta, gamma, y, k, d)
+    assert (got == values).all()
+
+
+@pytest.mark.parametrize("k,count", [(4, 1), (11, 3), (12, 2), (13, 7), (17, 5)])
+def test_coset_shift_inside_the_first_ntt_pass(gpu, k, count):
+    """sg_coeff_to_cosets_batch_dev: the shift c_b^i folded into the load of the first NTT pass (default) gives the words of the
+    pass of its own (rounds 3-4, oracle-pinned through test_quotient_on_cosets_equals_the_extended_pipeline); 7 columns x 5
+    cosets = 35 blocks: more than one batched launch holds"""
+    import torch
+    from circuits_halo2_amd import ffi
+    from circuits_halo2_amd.domain import EvaluationDomain
+    dom = EvaluationDomain(6, k)
+    coeffs = [_rand_fr(31 * k + j, 1 << k) for j in range(count)]
+    keep = [c.clone() for c in coeffs]
+
+    def run(own_pass):
+        ffi.set_param("ntt.coset_scale_pass", own_pass)
+        try:
+            out = dom.coeff_to_cosets_batch(coeffs)
+            torch.cuda.synchronize()
+            return out
+        finally:
+            ffi.set_param("ntt.coset_scale_pass", 0)
+
+    folded, separate = run(0), run(1)
+    assert len(folded) == count
+    for a, b in zip(folded, separate):
+        assert (a == b).all() and a.any()
+    for c, c0 in zip(coeffs, keep):
+        assert (c == c0).all()          # the inputs are read only
+
+
+def test_lincomb_sets_is_the_single_combinations(gpu):
+    """sg_fr_lincomb_sets_dev: five combinations of different sizes (one of them of 25 terms, one with no low polynomial) in one
+    launch = sg_fr_lincomb_low_dev one at a time"""
+    import ctypes as C
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi
+    n = 1 << 10
+    sizes, lows = [2, 25, 1, 2, 1], [3, 1, 3, 0, 2]
+    seed = iter(range(9000, 10 ** 6))
+    sets = []
+    for m, nl in zip(sizes, lows):
+        polys = [_rand_fr(next(seed), n) for _ in range(m)]
+        coeffs = _rand_fr(next(seed), m).cpu().numpy()
+        low = _rand_fr(next(seed), nl).cpu().numpy() if nl else None
+        sets.append((polys, coeffs, low))
+    outs = A.fr_lincomb_sets(sets, n)
+    torch.cuda.synchronize()
+    L = ffi.lib()
+    for (polys, coeffs, low), got in zip(sets, outs):
+        want = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+        pp = (C.c_void_p * len(polys))(*[p.data_ptr() for p in polys])
+        ffi.check(L.sg_fr_lincomb_low_dev(pp, ffi.ptr(ffi.u8(coeffs)), C.c_uint32(len(polys)), C.c_size_t(n),
+                                          ffi.ptr(ffi.u8(low)) if low is not None else None, C.c_uint32(len(low) // 32 if low is not None else 0),
+                                          ffi.dev_ptr(want), ffi.current_stream_ptr()))
+        torch.cuda.synchronize()
+        assert (got == want).all() and got.any()
+    # bad shapes are refused, not launched
+    too_many = [([sets[1][0][0]] * 33, np.zeros(33 * 32, dtype=np.uint8), None)]
+    with pytest.raises(ffi.SummaGpuError):
+        A.fr_lincomb_sets(too_many, n)
+
+
+def test_launch_log_get_param_and_abi_revision(gpu):
+    """msm.acc_log: one record per msm_accumulate launch, in issue order, describing the job; sg_get_param returns what
+    sg_set_param set; the library reports the ABI revision of the header it was built from"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi
+    L = ffi.lib()
+    assert L.sg_abi_version() == 3
+    n = 1 << 12
+    scal = _rand_fr(5, n)
+    bases = A.g1_fixed_base_mul(_rand_fr(6, n))
+    ffi.set_param("msm.acc_log", 1)
+    try:
+        pts = [A.best_multiexp(scal, bases) for _ in range(3)]
+        A.best_multiexp(scal[:32 * 100], bases[:64 * 100])
+        log = ffi.msm_launch_log()
+    finally:
+        ffi.set_param("msm.acc_log", 0)
+    assert all((p == pts[0]).all() for p in pts)
+    assert [r["n"] for r in log][:3] == [n, n, n] and [r["n"] for r in log][3:] in ([], [100])
+    assert all(r["M"] == 1 and r["fixed"] == 0 and r["threads"] > 0 for r in log)
+    assert log[0]["entries"] % n == 0 and log[0]["task_len"] >= 4
+    ffi.set_param("msm.acc_log", 1)          # setting it again clears the log
+    assert ffi.msm_launch_log() == []
+    ffi.set_param("msm.acc_log", 0)
+    before = ffi.get_param("host.wait_sleep_us")
+    ffi.set_param("host.wait_sleep_us", 37)
+    assert ffi.get_param("host.wait_sleep_us") == 37
+    ffi.set_param("host.wait_sleep_us", before)
+    assert ffi.get_param("commit.combine_target") >= 1 and ffi.get_param("lanes") in range(1, 9)
+    ffi.set_param("msm.log_seg", 5)
+    assert ffi.get_param("msm.log_seg") == 5
+    ffi.set_param("msm.log_seg", 0)
+    with pytest.raises(ffi.SummaGpuError):
+        ffi.get_param("no.such.parameter")
+
+
+def test_batch_restores_the_parameters_it_found(gpu):
+    """prove_batch's process-wide settings (combiner target / wait, sleeping waits) are put back to what the caller had set, not to
+    built-in defaults (advisor, round 4)"""
+    from circuits_halo2_amd import batch as B, ffi
+    ffi.set_param("host.wait_sleep_us", 25)
+    ffi.set_param("commit.combine_wait_us", 777)
+    try:
+        scope = B._ParamScope({"host.wait_sleep_us": 50, "commit.combine_wait_us": 5000})
+        scope.enter()
+        inner = B._ParamScope({"commit.combine_wait_us": 2000})
+        inner.enter()
+        assert ffi.get_param("commit.combine_wait_us") == 2000 and ffi.get_param("host.wait_sleep_us") == 50
+        scope.leave()                       # the first batch ends while the second still runs: nothing is restored yet
+        assert ffi.get_param("host.wait_sleep_us") == 50
+        inner.leave()
+        assert ffi.get_param("host.wait_sleep_us") == 25 and ffi.get_param("commit.combine_wait_us") == 777
+    finally:
+        ffi.set_param("host.wait_sleep_us", 0)
+        ffi.set_param("commit.combine_wait_us", 300)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The batch's issue budget per proof (tools/prof_batch_r05.sh).
 
-    python tools/batch_budget.py <pmc dir A> <pmc dir B> <proofs B - proofs A> <serial proof budget json> <batch line json> <out json>
+    python tools/batch_budget.py <pmc dir A> <pmc dir B> <line of run A> <line of run B> <serial proof budget json> <batch line json> <out json>
 
 Two --pmc passes (SQ_INSTS_VALU, SQ_WAVES) of the same batch command that differ only in the number of proofs: per kernel name
 (sum over B) - (sum over A) = the instructions of that many proofs in the batch's own shape.  Each kernel's instructions are priced
@@ -25,8 +25,10 @@ def totals(directory):
 
 
 def main():
-    dir_a, dir_b, dproofs, serial_path, line_path, out_path = sys.argv[1:7]
-    dproofs = int(dproofs)
+    dir_a, dir_b, line_a, line_b, serial_path, line_path, out_path = sys.argv[1:8]
+    last_line = lambda path: json.loads(open(path).read().strip().splitlines()[-1])
+    # proofs the two profiled processes made, warm-up and pre-sweep included (`proofs_made_in_run` of their own lines)
+    dproofs = last_line(line_b)["proofs_made_in_run"] - last_line(line_a)["proofs_made_in_run"]
     (a, ca), (b, cb) = totals(dir_a), totals(dir_b)
     serial = json.load(open(serial_path))
     line = json.loads(open(line_path).read().strip().splitlines()[-1])

@@ -22,5 +22,5 @@ for total in 256 512; do
       --batch-in-flight "$IN_FLIGHT" --wall-limit 500 > "$work/batch_insts_$total.json" 2> "$work/batch_insts_$total.err" \
     && echo "pmc pass $total done" || { echo "pmc pass $total FAILED"; tail -5 "$work/batch_insts_$total.err"; }
 done
-python tools/batch_budget.py "$work/batch_insts_256" "$work/batch_insts_512" 256 "$out/${tag}_proof_budget.json" "$out/${tag}_batch_line.json" "$out/${tag}_batch_budget.json" | tee "$out/${tag}_batch_budget.txt"
+python tools/batch_budget.py "$work/batch_insts_256" "$work/batch_insts_512" "$work/batch_insts_256.json" "$work/batch_insts_512.json" "$out/${tag}_proof_budget.json" "$out/${tag}_batch_line.json" "$out/${tag}_batch_budget.json" | tee "$out/${tag}_batch_budget.txt"
 rm -rf "$work"/batch_insts_*/
