@@ -164,6 +164,13 @@ class FailSafe:
             print(json.dumps(line), flush=True)
             return True
 
+    def extra_failed(self, reason):
+        """an EXTRA threw after the headline was measured (single-rank run): the headline is printed as the run's line with the
+        failure named in `extras_failed`, and the run exits NON-ZERO -- a wrong result in an extra is not a time-out"""
+        line = dict(self.base_line, extras_failed=reason, partial_extras=self.partial)
+        self.emit(line)
+        os._exit(3)
+
     def out_of_time(self, reason):
         """time ran out.  In a single-rank run whose timed steps are done, what overstayed is an EXTRA: the headline was
         measured in full and is printed as the run's line, the missing extras named in `incomplete` (exit code 0).  In a
@@ -289,6 +296,38 @@ def proof_roofline(ms, what):
             "algorithmic_bytes": PROOF_ALG_BYTES, "ms": ms, "traffic": None,
             "note": what + "; algorithmic bytes of halo2's op list for this proof (16 x 2^17 x 96 B + 11 665 408 x 64 B + 29 x 2^20 x 32 B); "
                            "the kernels behind it are integer-VALU-bound (see `alu`), the fraction says how far the whole proof is from a pure stream"}
+
+
+def committed_proof_budget():
+    """the counter-backed budget of one k = 17 proof from the newest committed profile (profiles/*_proof_budget.json, written by
+    tools/prof_proof_r05.sh + tools/proof_budget.py on the GPU box): per kernel -- launches, microseconds, VALU wave-instructions,
+    VALU busy, counted FETCH / WRITE bytes, the bytes the launch must move, fractions of the HBM roofline and of its own issue floor --
+    and the proof's issue floor; None when no profile is committed"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_proof_budget.json")))
+    if not paths:
+        return None
+    b = json.load(open(paths[-1]))
+    keep = ("kernel", "launches", "us", "SQ_INSTS_VALU", "VALUBusy_pct", "VALUUtilization_pct", "fetch_bytes_counted", "write_bytes_counted",
+            "fetch_correction", "traffic_bytes", "min_bytes", "algorithmic_bytes", "frac_hbm_traffic", "frac_hbm_min_bytes", "issue_floor_us",
+            "wave_cycles_split_pct", "bound")
+    return {"source": os.path.basename(paths[-1]), "what": b.get("what"), "launches": b.get("launches"), "kernel_us_total": b.get("kernel_us_total"),
+            "valu_wave_instructions_total": b.get("valu_wave_instructions_total"), "issue_floor_ms": b.get("issue_floor_ms"),
+            "issue_floor_definition": b.get("issue_floor_definition"), "kernel_time_over_issue_floor": b.get("kernel_time_over_issue_floor"),
+            "kernels": [{k_: k[k_] for k_ in keep if k_ in k} for k in b.get("kernels", []) if k.get("us", 0) >= 20.0]}
+
+
+def committed_batch_budget():
+    """the batch's instruction budget per proof from the newest committed profile (profiles/*_batch_budget.json, tools/prof_batch_r05.sh)"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_batch_budget.json")))
+    if not paths:
+        return None
+    b = json.load(open(paths[-1]))
+    out = {k_: b.get(k_) for k_ in ("what", "valu_wave_instructions_per_proof", "launches_per_proof", "issue_floor_ms_per_proof", "proofs_per_s",
+                                     "ms_per_proof", "efficiency_issue_floor_over_time_per_proof")}
+    out["source"] = os.path.basename(paths[-1])
+    return out
 
 
 def host_pointer_extra(scal, bases, want):
@@ -1259,6 +1298,15 @@ def _main():
         proof_ms = cp.get("ms_cpp_driver") or cp.get("ms")
         if proof_ms:
             cp["roofline"] = proof_roofline(proof_ms, "one k = 17 proof, wall clock of the compiled driver")
+            budget = committed_proof_budget()
+            if budget:
+                # counters under the proof: what bounds each of its kernels, and how far the measured wall clock is from the time its
+                # vector ALUs need at the present instruction counts
+                cp["roofline"]["counter_budget"] = budget
+                cp["roofline"]["kernels"] = budget["kernels"]
+                if budget.get("issue_floor_ms"):
+                    cp["roofline"]["issue_floor_ms"] = budget["issue_floor_ms"]
+                    cp["roofline"]["issue_floor_over_wall_clock"] = budget["issue_floor_ms"] / proof_ms
             line["roofline"]["create_proof_k17"] = cp["roofline"]
         line["config"]["proof_gen_k17_ms"] = proof_ms
         line["config"]["proof_gen_k17_verified"] = cp.get("verified")
@@ -1266,6 +1314,11 @@ def _main():
         line["config"]["proofs_per_s_1024_errors"] = (batch_line or {}).get("errors")
         line["config"]["sequential_ms_per_step"] = line["sequential"]["ms_per_step"]
         if batch_line and "roofline" in batch_line:
+            bb = committed_batch_budget()
+            if bb and bb.get("issue_floor_ms_per_proof") and batch_line.get("proofs_per_s"):
+                # the profile's instruction count priced per proof, against THIS run's rate
+                bb["efficiency_at_this_runs_rate"] = bb["issue_floor_ms_per_proof"] * batch_line["proofs_per_s"] / 1e3
+                batch_line["roofline"]["counter_budget"] = bb
             line["roofline"]["batch_k17_per_proof"] = batch_line["roofline"]
         fs.emit(line)
     return line
@@ -1281,7 +1334,7 @@ def main():
         traceback.print_exc()
         if _FS is not None:
             if _FS.base_line is not None and _FS.args.gpus == 1:      # the headline was measured: an extra threw
-                _FS.out_of_time(f"{type(ex).__name__} in an extra: {ex}")
+                _FS.extra_failed(f"{type(ex).__name__} in an extra: {ex}")
             _FS.fail(f"{type(ex).__name__}: {ex}", 1)
         raise
 

@@ -33,6 +33,10 @@ std::string compile_gates(const sg_graph& g, uint32_t n_fixed, uint32_t n_advice
                           const uint8_t* challenges, uint32_t n_challenges, const uint8_t beta[32],
                           const uint8_t gamma[32], const uint8_t theta[32], const uint8_t y[32], GateProgram* out);
 
+// a program the library has straight-line code for (the reference circuit's gate programs and its lookup input): launched with
+// columns and constants as kernel arguments -- no blob; returns false (nothing launched) for any other program
+bool gates_run_by_value(const GateProgram& p, const void* const* cols, fp_words* d_values, uint32_t k, uint32_t ext_k, hipStream_t stream,
+                        uint32_t cosets, hipError_t* err);
 // d_blob: [ops][column pointers][constants] as laid out by gates_blob(); values updated in place
 size_t gates_blob(const GateProgram& p, const void* const* cols, std::vector<uint8_t>* blob);
 // cosets = 0: arrays of 2^ext_k rows in halo2's extended-domain order; cosets = c: coset-major arrays of c * 2^k rows

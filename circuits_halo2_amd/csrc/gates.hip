@@ -129,6 +129,32 @@ __global__ void __launch_bounds__(256) gates_fixed_kernel(GateArgs a) {
   f29_store_canonical<P>(a.values + row, f29_mul<P>(res, f29_const<P>(P::r256)));
 }
 
+// the same with the column pointers and the constant table as kernel arguments: nothing to upload, nothing to keep alive
+static constexpr uint32_t GATES_V_COLS = 24, GATES_V_CONSTS = 40;
+struct GateArgsV {
+  fp_words* values;
+  const fp_words* cols[GATES_V_COLS];
+  uint32_t consts[GATES_V_CONSTS][8];
+  uint32_t n_consts, k, ext_k;
+  uint64_t rows, blockmask;
+};
+template <class PROG>
+__global__ void __launch_bounds__(256) gates_fixed_value_kernel(GateArgsV a) {
+  side_kernel_prio();
+  __shared__ uint32_t s_const[GATES_V_CONSTS][9];
+  if (threadIdx.x < a.n_consts) {
+    const f29 v = f29_words_to_r261<P>(a.consts[threadIdx.x]);
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_const[threadIdx.x][q] = v.l[q];
+  }
+  __syncthreads();
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.rows) return;
+  const GateSrc src{a.cols, a.values};
+  const f29 res = gates_fixed_eval<PROG>(src, &s_const[0][0], row, (size_t)a.blockmask, a.ext_k - a.k);
+  f29_store_canonical<P>(a.values + row, f29_mul<P>(res, f29_const<P>(P::r256)));
+}
+
 // ------------------------------------------------------------------ host: compiler
 namespace {
 struct Val {         // a virtual value of the lowered program
@@ -485,6 +511,36 @@ size_t gates_blob(const GateProgram& p, const void* const* cols, std::vector<uin
   if (cols_b) std::memcpy(blob->data() + ops_b, cols, cols_b);
   std::memcpy(blob->data() + ops_b + cols_b, p.const_words.data(), const_b);
   return blob->size();
+}
+
+bool gates_run_by_value(const GateProgram& p, const void* const* cols, fp_words* d_values, uint32_t k, uint32_t ext_k, hipStream_t stream,
+                        uint32_t cosets, hipError_t* err) {
+  *err = hipSuccess;
+  if (std::getenv("SG_GATES_GENERIC") || p.n_columns > GATES_V_COLS || p.const_words.size() / 8 > GATES_V_CONSTS) return false;
+  GateArgsV a;
+  a.values = d_values;
+  for (uint32_t i = 0; i < p.n_columns; i++) a.cols[i] = static_cast<const fp_words*>(cols[i]);
+  a.n_consts = (uint32_t)(p.const_words.size() / 8);
+  std::memcpy(a.consts, p.const_words.data(), p.const_words.size() * sizeof(uint32_t));
+  a.k = k; a.ext_k = cosets ? k : ext_k;
+  const size_t n_ext = cosets ? (size_t)cosets << k : (size_t)1 << ext_k;
+  a.rows = n_ext;
+  a.blockmask = ((uint64_t)1 << a.ext_k) - 1;
+  const unsigned blocks = (unsigned)((n_ext + 255) / 256);
+  bool done = false;
+  auto launch = [&](auto tag) {
+    using PROG = decltype(tag);
+    if (done || !is_program<PROG>(p)) return;
+    done = true;
+    gates_fixed_value_kernel<PROG><<<blocks, 256, 0, stream>>>(a);
+  };
+  launch(MstLookupInput{});
+  launch(MstGatesNc2{});
+  launch(MstGatesNc1{});
+  launch(MstGatesNc3{});
+  launch(MstGatesNc4{});
+  if (done) *err = hipGetLastError();
+  return done;
 }
 
 hipError_t gates_run(const GateProgram& p, const uint8_t* d_blob, fp_words* d_values, uint32_t k, uint32_t ext_k,

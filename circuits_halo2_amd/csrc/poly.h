@@ -47,6 +47,10 @@ struct GrandProducts {   // kernel argument
 };
 struct GrandOut {
   fp_words* z[GRAND_MAX];
+  // optional: closing[p] <- z_p[closing_row] (the value every satisfied argument ends on, 1) for every product, written by the
+  // kernels that produce the row -- device-visible memory, e.g. page-locked host memory mapped into the device
+  fp_words* closing = nullptr;
+  uint32_t closing_row = 0;
 };
 size_t grand_products_mod_elems(size_t n, uint32_t products);
 size_t grand_products_tmp_elems(size_t n, uint32_t products);
@@ -64,6 +68,9 @@ hipError_t poly_kate_division(const fp_words* d_a, size_t n, const words8& b, fp
                               fp_words* d_rem, hipStream_t stream);
 // *d_count (device u32, zeroed here) = number of elements of the m <= 16 columns (n each) whose 256-bit word value is >= r
 hipError_t poly_count_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_count, hipStream_t stream);
+// the same without the clearing and without atomics: *d_flag = 1 when any such element exists, untouched otherwise (the caller
+// clears it; it may live in page-locked host memory mapped into the device: no memset launch, no copy back)
+hipError_t poly_flag_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_flag, hipStream_t stream);
 // out[i] = sum_j coeffs[j] * polys[j][i], m <= LINCOMB_MAX
 static constexpr uint32_t LINCOMB_MAX = 32;
 // optionally + low[i] for i < n_low <= LINCOMB_LOW_MAX (a polynomial of a few coefficients, passed by value)
@@ -86,6 +93,9 @@ static constexpr size_t LOOKUP_PERMUTE_WORK = 6 * (size_t)LOOKUP_BINS + 16;
 hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_table, size_t rows, uint32_t* d_work,
                                      fp_words* d_permuted_input, fp_words* d_permuted_table, uint32_t* d_flag,
                                      hipStream_t stream);
+hipError_t poly_lookup_permute_small_chained(const fp_words* d_input, const fp_words* d_table, size_t rows, uint32_t* d_work,
+                                             uint32_t* d_flag, uint32_t* d_next_work, uint32_t* d_next_flag, fp_words* d_permuted_input,
+                                             fp_words* d_permuted_table, uint32_t* d_status, hipStream_t stream);
 // n uniform field elements from ChaCha20 (RFC 8439 block function) keyed by `key` (8 LE words): element i takes the
 // first 32 bytes of block (counter = i, nonce = (attempt, stream_lo, stream_hi)), top two bits cleared, and is
 // redrawn with attempt + 1 while >= r (~24 %); the accepted limbs are written as they are (a uniform value in any

@@ -365,7 +365,7 @@ static constexpr uint32_t KATE_BATCH_MAX = 16;
 struct CanonCols {
   const fp_words* col[16];
 };
-__global__ void __launch_bounds__(256) count_noncanonical_kernel(CanonCols cols, uint32_t n, uint32_t* __restrict__ count) {
+__global__ void __launch_bounds__(256) count_noncanonical_kernel(CanonCols cols, uint32_t n, uint32_t* __restrict__ count, uint32_t flag_only) {
   side_kernel_prio();
   // r as 8 LE words
   const uint32_t R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
@@ -379,14 +379,28 @@ __global__ void __launch_bounds__(256) count_noncanonical_kernel(CanonCols cols,
   for (int k = 0; k < 8; k++) {
     if (w[k] != R[k]) ge = w[k] > R[k];
   }
-  if (ge) atomicAdd(count, 1u);
+  if (ge) {
+    if (flag_only) {   // a plain store of the same value from every finder: no atomic, so the word may live in mapped host memory
+      *reinterpret_cast<volatile uint32_t*>(count) = 1u;
+      __threadfence_system();
+    } else {
+      atomicAdd(count, 1u);
+    }
+  }
+}
+hipError_t poly_flag_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_flag, hipStream_t stream) {
+  if (!m || !n) return hipSuccess;
+  CanonCols cols{};
+  for (uint32_t j = 0; j < m; j++) cols.col[j] = d_cols[j];
+  count_noncanonical_kernel<<<dim3((unsigned)((n + 255) / 256), m), 256, 0, stream>>>(cols, (uint32_t)n, d_flag, 1u);
+  return hipGetLastError();
 }
 hipError_t poly_count_noncanonical(const fp_words* const* d_cols, uint32_t m, size_t n, uint32_t* d_count, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess || !m || !n) return e;
   CanonCols cols{};
   for (uint32_t j = 0; j < m; j++) cols.col[j] = d_cols[j];
-  count_noncanonical_kernel<<<dim3((unsigned)((n + 255) / 256), m), 256, 0, stream>>>(cols, (uint32_t)n, d_count);
+  count_noncanonical_kernel<<<dim3((unsigned)((n + 255) / 256), m), 256, 0, stream>>>(cols, (uint32_t)n, d_count, 0u);
   return hipGetLastError();
 }
 
@@ -705,15 +719,19 @@ __global__ void __launch_bounds__(256) prefix_product_write_batch(const fp_words
 #pragma unroll
   for (uint32_t i = 0; i < PP_CH; i++) {
     if (first + i < count_out) store_hat(out + first + i, run);
+    if (outs.closing && first + i == outs.closing_row) store_hat(outs.closing + blockIdx.y, run);
     run = f29_mul<P>(run, v[i]);
   }
 }
 // z[i] *= *scalar (a value another kernel of the stream has just written: the previous chunk's z at its last usable row)
-__global__ void __launch_bounds__(256) scale_by_device_scalar_kernel(fp_words* __restrict__ z, uint32_t n, const fp_words* __restrict__ scalar) {
+__global__ void __launch_bounds__(256) scale_by_device_scalar_kernel(fp_words* __restrict__ z, uint32_t n, const fp_words* __restrict__ scalar,
+                                                                     fp_words* __restrict__ closing, uint32_t closing_row) {
   side_kernel_prio();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  store_hat(z + i, f29_mul<P>(load_hat(z + i), load_hat(scalar)));
+  const f29 v = f29_mul<P>(load_hat(z + i), load_hat(scalar));
+  store_hat(z + i, v);
+  if (closing && i == closing_row) store_hat(closing, v);   // (the unscaled value prefix_product_write_batch left there is replaced)
 }
 size_t grand_products_mod_elems(size_t n, uint32_t products) { return (size_t)products * n; }
 size_t grand_products_tmp_elems(size_t n, uint32_t products) { return (size_t)products * ((n + 1 + PP_BLOCK - 1) / PP_BLOCK) + 1; }
@@ -734,7 +752,8 @@ hipError_t poly_grand_products(const GrandProducts& g, const words8& beta, const
   prefix_product_write_batch<<<dim3(nblk, Pn), PP_THREADS, 0, stream>>>(d_mod, (uint32_t)n, nblk, d_tmp, (uint32_t)n, outs);
   // chunk j of the permutation argument starts where chunk j - 1 ended: z_j = z_{j-1}[usable] * (its own running product)
   for (uint32_t j = 1; j < g.n_perm; j++)
-    scale_by_device_scalar_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(outs.z[j], (uint32_t)n, outs.z[j - 1] + usable);
+    scale_by_device_scalar_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(outs.z[j], (uint32_t)n, outs.z[j - 1] + usable,
+                                                                                   outs.closing ? outs.closing + j : nullptr, outs.closing_row);
   return hipGetLastError();
 }
 
@@ -1034,12 +1053,32 @@ __device__ __forceinline__ uint32_t bin_of(const uint32_t* __restrict__ pre, con
   while (count[lo] == 0 && lo > 0) lo--;   // empty bins share their prefix with the owner before them
   return lo;
 }
+// opts (all optional): `clean` = the work space of the NEXT call on this stream, whose histograms and flag words this launch
+// zeroes (2 * LOOKUP_BINS + 2 words at `clean`, the flag words first in clean_flag): no memset launches; `status` = where the
+// call's verdict goes (0 ok, 1 an input not in the table, 2 table not a range table), e.g. mapped host memory; mont: the
+// outputs in Montgomery form (otherwise canonical small integers, which the caller converts)
+struct LookupWriteOpts {
+  uint32_t* clean;
+  uint32_t* clean_flag;
+  uint32_t* status;
+  uint32_t mont;
+};
 __global__ void __launch_bounds__(256) lookup_permute_write(size_t rows, const uint32_t* __restrict__ work,
                                                             const uint32_t* __restrict__ flag, fp_words* __restrict__ out_a,
-                                                            fp_words* __restrict__ out_s) {
+                                                            fp_words* __restrict__ out_s, LookupWriteOpts o) {
   side_kernel_prio();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows || flag[0]) return;   // flagged inputs: the caller discards the outputs
+  if (o.clean) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < 2 * (size_t)LOOKUP_BINS; j += step) o.clean[j] = 0u;
+    if (i < 2) o.clean_flag[i] = 0u;
+  }
+  const uint32_t verdict = flag[0];
+  if (o.status && i == 0) {
+    *reinterpret_cast<volatile uint32_t*>(o.status) = verdict;
+    __threadfence_system();
+  }
+  if (i >= rows || verdict) return;   // flagged inputs: the caller discards the outputs
   const uint32_t bound = min(flag[1] + 1, LOOKUP_BINS);
   const uint32_t* hist_a = work;
   const uint32_t *pre_a = work + 2 * LOOKUP_BINS, *pre_rep = work + 3 * LOOKUP_BINS, *pre_left = work + 4 * LOOKUP_BINS,
@@ -1048,6 +1087,15 @@ __global__ void __launch_bounds__(256) lookup_permute_write(size_t rows, const u
   uint32_t s = v;
   const uint32_t within = (uint32_t)i - pre_a[v];
   if (within) s = bin_of(pre_left, left, pre_rep[v] + within - 1, bound);
+  if (o.mont) {   // v * 2^256 mod r: what fr_montgomery(.., to_mont) makes of the canonical words
+    f29 a = f29_zero(), b = f29_zero();
+    a.l[0] = v;   // v, s < 2^16: one limb
+    b.l[0] = s;
+    const f29 k = f29_const<P>(P::r517);
+    f29_store_canonical<P>(out_a + i, f29_mul<P>(a, k));
+    f29_store_canonical<P>(out_s + i, f29_mul<P>(b, k));
+    return;
+  }
   fp_words w;   // canonical small integers; the caller converts both columns to Montgomery form
   w.q[0] = make_uint4(v, 0, 0, 0);
   w.q[1] = make_uint4(0, 0, 0, 0);
@@ -1067,7 +1115,22 @@ hipError_t poly_lookup_permute_small(const fp_words* d_input, const fp_words* d_
   const unsigned blocks = (unsigned)((rows + 255) / 256);
   lookup_permute_hist<<<blocks, 256, 0, stream>>>(d_input, d_table, rows, d_work, d_flag);
   lookup_permute_scan<<<1, 1024, 0, stream>>>(d_work, d_flag, (uint32_t)rows);
-  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_flag, d_permuted_input, d_permuted_table);
+  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_flag, d_permuted_input, d_permuted_table, LookupWriteOpts{nullptr, nullptr, nullptr, 0u});
+  return hipGetLastError();
+}
+// the same without memsets, conversions or a copy back: d_work / d_flag must arrive zeroed (the previous call's write pass did it,
+// or the allocation), d_next_work / d_next_flag are zeroed for the next call, *d_status receives the verdict, the outputs are
+// Montgomery words
+hipError_t poly_lookup_permute_small_chained(const fp_words* d_input, const fp_words* d_table, size_t rows, uint32_t* d_work,
+                                             uint32_t* d_flag, uint32_t* d_next_work, uint32_t* d_next_flag, fp_words* d_permuted_input,
+                                             fp_words* d_permuted_table, uint32_t* d_status, hipStream_t stream) {
+  if (!rows) return hipSuccess;
+  if (rows >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  lookup_permute_hist<<<blocks, 256, 0, stream>>>(d_input, d_table, rows, d_work, d_flag);
+  lookup_permute_scan<<<1, 1024, 0, stream>>>(d_work, d_flag, (uint32_t)rows);
+  lookup_permute_write<<<blocks, 256, 0, stream>>>(rows, d_work, d_flag, d_permuted_input, d_permuted_table,
+                                                   LookupWriteOpts{d_next_work, d_next_flag, d_status, 1u});
   return hipGetLastError();
 }
 

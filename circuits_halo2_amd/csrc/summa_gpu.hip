@@ -181,6 +181,18 @@ struct Context {
   uint32_t blob_next = 0;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
+  // page-locked host memory mapped into the device: small results the host waits for anyway (evaluations, a remainder, a
+  // verdict) are written there by the kernel that produces them -- no copy kernel, no second wait
+  static constexpr size_t MAIL_BYTES = 4096;
+  uint8_t* h_mail = nullptr;
+  uint8_t* d_mail = nullptr;
+  // sg_lookup_permute_small_async_dev: two work spaces per caller stream; the write pass of one call zeroes the other's
+  // histograms for the next call (no memset launches)
+  struct LookupWork {
+    DevBuf<uint32_t> buf;
+    uint32_t next = 0;
+  };
+  std::map<hipStream_t, LookupWork> lookup_work;
 };
 
 // What every lane shares: the device index, the SRS cache (read-only after upload / precompute) and the runtime
@@ -281,6 +293,8 @@ void destroy_context(Context* c) {
   c->scratch.release();
   for (auto& kv : c->ntt_scratch) kv.second.release();
   for (auto& kv : c->stream_scratch) kv.second.release();
+  for (auto& kv : c->lookup_work) kv.second.buf.release();
+  if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->d_consts) (void)hipFree(c->d_consts);
   c->stream = nullptr;   // one of g_lane_main: destroyed with the others at sg_shutdown
   delete c;
@@ -400,6 +414,19 @@ int ntt_dev(const fp_words* in, size_t in_len, fp_words* out, uint32_t log_n, co
   hipError_t e = c.ntt.transform(in, in_len, out, scratch, log_n, omega, scale, pre3, post3, s);
   if (e != hipSuccess) return hip_fail("ntt", e);
   return SG_OK;
+}
+
+hipError_t mailbox(uint8_t** host, uint8_t** dev) {
+  Context& c = *g_ctx;
+  if (!c.h_mail) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c.h_mail), Context::MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c.d_mail), c.h_mail, 0);
+    if (e != hipSuccess) return e;
+  }
+  *host = c.h_mail;
+  *dev = c.d_mail;
+  return hipSuccess;
 }
 
 hipError_t scratch_for(hipStream_t s, int slot, size_t bytes, uint8_t** out) {
@@ -2050,6 +2077,41 @@ int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t
   if (h_flag == 1) return fail(SG_ERR_WITNESS, "sg_lookup_permute_small: an input value is not in the table");
   return SG_OK;
 }
+int sg_lookup_permute_small_async_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                      void* d_permuted_table, void* d_status, void* stream) {
+  if (!d_status || (rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table)))
+    return fail(SG_ERR_INVALID, "sg_lookup_permute_small_async: null argument");
+  if (rows == 0) return SG_OK;
+  LOCKED_CTX();
+  hipStream_t s = pick_stream(stream);
+  Context::LookupWork& lw = g_ctx->lookup_work[s];
+  constexpr size_t ONE = LOOKUP_PERMUTE_WORK + 16;   // words per work space, the two flag words behind the tables
+  if (!lw.buf.p) {
+    hipError_t e = lw.buf.reserve(2 * ONE);
+    if (e == hipSuccess) e = hipMemsetAsync(lw.buf.p, 0, lw.buf.cap * sizeof(uint32_t), s);   // once per stream; afterwards every call cleans for the next
+    if (e != hipSuccess) return hip_fail("lookup permutation work space", e);
+    lw.next = 0;
+  }
+  uint32_t* work = lw.buf.p + lw.next * ONE;
+  uint32_t* other = lw.buf.p + (lw.next ^ 1u) * ONE;
+  lw.next ^= 1u;
+  hipError_t e = poly_lookup_permute_small_chained(static_cast<const fp_words*>(d_input), static_cast<const fp_words*>(d_table), rows, work,
+                                                   work + LOOKUP_PERMUTE_WORK, other, other + LOOKUP_PERMUTE_WORK,
+                                                   static_cast<fp_words*>(d_permuted_input), static_cast<fp_words*>(d_permuted_table),
+                                                   static_cast<uint32_t*>(d_status), s);
+  if (e != hipSuccess) return hip_fail("lookup permutation", e);
+  return SG_OK;
+}
+int sg_fr_flag_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_flag, void* stream) {
+  if (!d_flag || (m && !d_cols) || m > 16) return fail(SG_ERR_INVALID, "sg_fr_flag_noncanonical: bad argument");
+  for (uint32_t j = 0; j < m; j++)
+    if (n && !d_cols[j]) return fail(SG_ERR_INVALID, "sg_fr_flag_noncanonical: null column");
+  if (n >= (1ull << 32)) return fail(SG_ERR_INVALID, "sg_fr_flag_noncanonical: column too long");
+  LOCKED_CTX();
+  hipError_t e = poly_flag_noncanonical(reinterpret_cast<const fp_words* const*>(d_cols), m, n, static_cast<uint32_t*>(d_flag), pick_stream(stream));
+  if (e != hipSuccess) return hip_fail("flag_noncanonical", e);
+  return SG_OK;
+}
 int sg_fr_random_dev(const uint8_t key[32], uint64_t stream_id, void* d_out, size_t n, void* stream) {
   if (!key || (n && !d_out)) return fail(SG_ERR_INVALID, "sg_fr_random: null argument");
   LOCKED_CTX();
@@ -2116,16 +2178,20 @@ int sg_fr_eval_poly_batch_dev(const void* const* d_polys, size_t n, const uint8_
   hipError_t e = g_ctx->scratch.reserve((EVAL_BATCH_MAX * (blocks + 1)) * 32);
   if (e != hipSuccess) return hip_fail("eval_poly work space", e);
   fp_words* partial = reinterpret_cast<fp_words*>(g_ctx->scratch.p);
-  fp_words* d_out = partial + EVAL_BATCH_MAX * blocks;
+  // the values land in page-locked host memory the last kernel writes directly: the host waits for the stream once and reads them
+  uint8_t *h_mail = nullptr, *d_mail = nullptr;
+  e = mailbox(&h_mail, &d_mail);
+  if (e != hipSuccess) return hip_fail("eval_poly mailbox", e);
+  static_assert(EVAL_BATCH_MAX * 32 <= Context::MAIL_BYTES, "the mailbox holds one batch of evaluations");
   hipStream_t s = pick_stream(stream);
   for (uint32_t first = 0; first < m; first += EVAL_BATCH_MAX) {
     const uint32_t cnt = std::min<uint32_t>(EVAL_BATCH_MAX, m - first);
     words8 xs[EVAL_BATCH_MAX];
     std::memcpy(xs, points + 32 * (size_t)first, 32 * (size_t)cnt);
-    e = poly_eval_batch(reinterpret_cast<const fp_words* const*>(d_polys + first), xs, cnt, n, partial, d_out, s);
+    e = poly_eval_batch(reinterpret_cast<const fp_words* const*>(d_polys + first), xs, cnt, n, partial, reinterpret_cast<fp_words*>(d_mail), s);
+    if (e == hipSuccess) e = host_wait_stream(s);   // synchronises: scratch and mailbox are reused
     if (e != hipSuccess) return hip_fail("eval_poly_batch", e);
-    int rc = download(out + 32 * (size_t)first, d_out, 32 * (size_t)cnt, s);  // synchronises: scratch is reused
-    if (rc != SG_OK) return rc;
+    std::memcpy(out + 32 * (size_t)first, h_mail, 32 * (size_t)cnt);
   }
   return SG_OK;
 }
@@ -2230,6 +2296,12 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
 int sg_grand_products_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
                           const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
                           uint32_t k, size_t usable_rows, void* const* d_z, void* stream) {
+  return sg_grand_products_closing_dev(d_values, d_sigma, chunk_cols, n_chunks, d_lookup_cols, n_lookups, beta, gamma, k, usable_rows, d_z,
+                                       nullptr, stream);
+}
+int sg_grand_products_closing_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
+                                  const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
+                                  uint32_t k, size_t usable_rows, void* const* d_z, void* d_closing, void* stream) {
   if (!beta || !gamma || !d_z || (n_chunks && (!d_values || !d_sigma || !chunk_cols)) || (n_lookups && !d_lookup_cols))
     return fail(SG_ERR_INVALID, "sg_grand_products: null argument");
   if (n_chunks + n_lookups == 0) return SG_OK;
@@ -2268,6 +2340,8 @@ int sg_grand_products_dev(const void* const* d_values, const void* const* d_sigm
     if (!d_z[p]) return fail(SG_ERR_INVALID, "sg_grand_products: null output");
     outs.z[p] = static_cast<fp_words*>(d_z[p]);
   }
+  outs.closing = static_cast<fp_words*>(d_closing);
+  outs.closing_row = (uint32_t)usable_rows;
   hipStream_t s = pick_stream(stream);
   uint8_t *modb = nullptr, *tmpb = nullptr;
   hipError_t e = scratch_for(s, 1, grand_products_mod_elems(n, n_chunks + n_lookups) * 32 + 64, &modb);
@@ -2314,12 +2388,34 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
   hipError_t e = scratch_for(s, 0, 1025 * 32 + 64, &tb);
   if (e != hipSuccess) return hip_fail("kate_division work space", e);
   fp_words* tmp = reinterpret_cast<fp_words*>(tb);
-  e = poly_kate_division(static_cast<const fp_words*>(d_a), n, bw, tmp, static_cast<fp_words*>(d_q),
-                         remainder_out ? tmp + 1024 : nullptr, s);
-  // asynchronous unless the caller wants the remainder on the host
-  if (e == hipSuccess && remainder_out) {
-    e = host_copy_d2h(remainder_out, tmp + 1024, 32, s);
+  uint8_t *h_mail = nullptr, *d_mail = nullptr;
+  if (remainder_out) {
+    e = mailbox(&h_mail, &d_mail);
+    if (e != hipSuccess) return hip_fail("kate_division mailbox", e);
   }
+  e = poly_kate_division(static_cast<const fp_words*>(d_a), n, bw, tmp, static_cast<fp_words*>(d_q),
+                         remainder_out ? reinterpret_cast<fp_words*>(d_mail) : nullptr, s);
+  // asynchronous unless the caller wants the remainder on the host (written by the kernel into mapped host memory)
+  if (e == hipSuccess && remainder_out) {
+    e = host_wait_stream(s);
+    if (e == hipSuccess) std::memcpy(remainder_out, h_mail, 32);
+  }
+  if (e != hipSuccess) return hip_fail("kate_division", e);
+  return SG_OK;
+}
+int sg_fr_kate_division_rem_dev(const void* d_a, size_t n, const uint8_t b[32], void* d_q, void* d_remainder, void* stream) {
+  if (!b || !d_remainder || (n && (!d_a || !d_q))) return fail(SG_ERR_INVALID, "sg_fr_kate_division_rem: null argument");
+  if (n == 0 || n > (1ull << 21)) return fail(SG_ERR_INVALID, "sg_fr_kate_division_rem: between 1 and 2^21 coefficients");
+  if (d_a == d_q) return fail(SG_ERR_INVALID, "sg_fr_kate_division_rem: the quotient must not alias the input");
+  LOCKED_CTX();
+  words8 bw;
+  std::memcpy(&bw, b, 32);
+  hipStream_t s = pick_stream(stream);
+  uint8_t* tb = nullptr;
+  hipError_t e = scratch_for(s, 0, 1025 * 32 + 64, &tb);
+  if (e != hipSuccess) return hip_fail("kate_division work space", e);
+  e = poly_kate_division(static_cast<const fp_words*>(d_a), n, bw, reinterpret_cast<fp_words*>(tb), static_cast<fp_words*>(d_q),
+                         static_cast<fp_words*>(d_remainder), s);
   if (e != hipSuccess) return hip_fail("kate_division", e);
   return SG_OK;
 }
@@ -2634,6 +2730,13 @@ static int quotient_gates_impl(void* d_values, const sg_graph* graph, const void
   for (const void* c : cols)
     if (!c) return fail(SG_ERR_INVALID, "sg_quotient_gates: null column");
   hipStream_t s = pick_stream(stream);
+  {
+    hipError_t ev = hipSuccess;
+    if (gates_run_by_value(prog, cols.data(), static_cast<fp_words*>(d_values), k, ext_k, s, cosets, &ev)) {
+      if (ev != hipSuccess) return hip_fail("quotient_gates", ev);
+      return SG_OK;
+    }
+  }
   // program + column pointers + constants travel as one small blob.  Ring of page-locked host / device buffer pairs, each
   // guarded by an event recorded after the kernel that reads it: the call is asynchronous (no host wait unless the ring
   // has wrapped onto a launch that is still running)

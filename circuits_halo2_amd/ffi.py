@@ -24,7 +24,7 @@ EXPORTS = [
     "sg_divide_by_vanishing_poly_dev", "sg_domain_constant", "sg_g1_fixed_base_mul", "sg_g1_fixed_base_mul_dev", "sg_g2_generator_mul", "sg_pairing_check", "sg_pairing_check_slow", "sg_keccak256", "sg_kzg_setup", "sg_kzg_setup_dev", "sg_g1_fft_dev", "sg_g1_to_lagrange",
     "sg_fr_to_montgomery_dev", "sg_fr_from_montgomery_dev", "sg_fr_random_dev", "sg_fr_random_batch_dev", "sg_lookup_permute_small_dev", "sg_fr_eval_poly", "sg_fr_eval_poly_dev", "sg_fr_eval_poly_batch_dev",
     "sg_fr_batch_invert_dev", "sg_fr_prefix_product_dev", "sg_fr_mul_dev", "sg_fr_kate_division_dev", "sg_fr_kate_division_batch_dev", "sg_fr_count_noncanonical_dev", "sg_fr_lincomb_dev", "sg_fr_lincomb_low_dev", "sg_permutation_product_dev",
-    "sg_lookup_product_dev", "sg_grand_products_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_fr_lincomb_sets_dev", "sg_quotient_numerator_cosets_dev", "sg_set_param", "sg_get_param", "sg_msm_launch_log", "sg_abi_version", "sg_time_ntt_dev",
+    "sg_lookup_product_dev", "sg_grand_products_dev", "sg_quotient_permutation_dev", "sg_quotient_lookup_dev", "sg_quotient_gates_dev", "sg_mst_leaves_dev", "sg_mst_level_dev", "sg_mst_build_dev", "sg_mst_inclusion_witness_dev", "sg_msm_g1_dev_timed", "sg_commit_dev_timed", "sg_fr_lincomb_sets_dev", "sg_quotient_numerator_cosets_dev", "sg_fr_flag_noncanonical_dev", "sg_lookup_permute_small_async_dev", "sg_grand_products_closing_dev", "sg_fr_kate_division_rem_dev", "sg_set_param", "sg_get_param", "sg_msm_launch_log", "sg_abi_version", "sg_time_ntt_dev",
 ]
 
 

@@ -279,6 +279,13 @@ int sg_fr_from_montgomery_dev(const void* d_in, void* d_out, size_t n, void* str
  * in the table.  Synchronises the stream (the status is known on return). */
 int sg_lookup_permute_small_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
                                 void* d_permuted_table, void* stream);
+/* The same without the wait: *d_status (u32 in device-visible memory, e.g. mapped page-locked host memory) receives 0 (done), 1
+ * (an input value is not in the table: what the call above reports as SG_ERR_WITNESS) or 2 (not a range table: SG_ERR_UNSUPPORTED)
+ * when the kernels have run; the outputs are Montgomery words and valid only under status 0.  No memset, conversion or copy
+ * launches (the write pass cleans the work space of the next call on the stream).  A prover that knows its table is a range
+ * table (a property of the proving key) issues this, goes on, and looks at the status where it waits anyway.  Asynchronous. */
+int sg_lookup_permute_small_async_dev(const void* d_input, const void* d_table, size_t rows, void* d_permuted_input,
+                                      void* d_permuted_table, void* d_status, void* stream);
 /* n uniform field elements written to d_out (blinding rows, the random polynomial of create_proof -- upstream draws
  * them from `OsRng`; here the OS supplies a 32-byte key per proof and ChaCha20, RFC 8439's block function, expands it
  * on the device): element i = the first 32 bytes of block(key, counter = i, nonce = (attempt, stream_id)) with the top
@@ -329,6 +336,12 @@ int sg_lookup_product_dev(const void* d_input, const void* d_table, const void* 
 int sg_grand_products_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
                           const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
                           uint32_t k, size_t usable_rows, void* const* d_z, void* stream);
+/* The same; additionally d_closing[p] (32 B each, device-visible memory, may be NULL) <- z_p[usable_rows] for every product p,
+ * written by the kernels that produce that row: the value a satisfied argument ends on is 1, and a prover that checks it reads
+ * mapped host memory after its next wait instead of issuing copies. */
+int sg_grand_products_closing_dev(const void* const* d_values, const void* const* d_sigma, const uint32_t* chunk_cols, uint32_t n_chunks,
+                                  const void* const* d_lookup_cols, uint32_t n_lookups, const uint8_t beta[32], const uint8_t gamma[32],
+                                  uint32_t k, size_t usable_rows, void* const* d_z, void* d_closing, void* stream);
 /* out[i] = a[i] * b[i] */
 int sg_fr_mul_dev(const void* d_a, const void* d_b, size_t n, void* d_out, void* stream);
 
@@ -343,10 +356,18 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
  * instead of a chain, and all sets go in one batch.  Remainders are not returned.  Complete on return. */
 int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
                                   void* stream);
+/* sg_fr_kate_division_dev with the remainder a(b) (32 B, Montgomery) written to device-visible memory d_remainder by the kernel
+ * instead of being returned: asynchronous on `stream` (a prover checks the remainder of its final division after the next
+ * commitment has been issued, not before). */
+int sg_fr_kate_division_rem_dev(const void* d_a, size_t n, const uint8_t b[32], void* d_q, void* d_remainder, void* stream);
 /* Range check of caller-supplied columns: *d_count (u32 in device memory) = number of elements of the m <= 16 columns (n each)
  * whose 32-byte word value is >= r (halo2curves never produces such words; `Fr::from_repr` refuses them [UPSTREAM]).
  * Asynchronous on `stream`. */
 int sg_fr_count_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_count, void* stream);
+/* The same check without a counter: *d_flag (u32) is set to 1 when any such element exists and left alone otherwise -- the caller
+ * clears it beforehand.  d_flag may be page-locked host memory mapped into the device (hipHostMalloc(.., hipHostMallocMapped)):
+ * then the check costs one kernel, no memset and no copy back, and the host reads the word after any later wait on `stream`. */
+int sg_fr_flag_noncanonical_dev(const void* const* d_cols, uint32_t m, size_t n, void* d_flag, void* stream);
 /* out[i] = sum_j coeffs[j] * polys[j][i], 1 <= m <= 32 (the random linear combinations of the multi-open) */
 int sg_fr_lincomb_dev(const void* const* d_polys, const uint8_t* coeffs, uint32_t m, size_t n, void* d_out, void* stream);
 /* the same plus a polynomial of n_low <= 8 coefficients given by value (32 B Montgomery each): out[i] += low[i] for i < n_low.
@@ -548,7 +569,9 @@ int sg_get_param(const char* name, int* value);
 int sg_msm_launch_log(uint32_t* out_words, size_t cap_records, size_t* n_records);
 /* ABI revision of this header: bumped whenever a struct that a caller allocates grows or an entry point's meaning changes.
  *   2 (round 4): sg_msm_timings gained `order_ms` (44 bytes; accumulate_ms excludes the wait in the accumulation chain)
- *   3 (round 5): sg_get_param, sg_msm_launch_log, sg_abi_version added; nothing removed or resized
+ *   3 (round 5): added sg_get_param, sg_msm_launch_log, sg_abi_version, sg_fr_lincomb_sets_dev, sg_quotient_numerator_cosets_dev,
+ *     sg_fr_flag_noncanonical_dev, sg_lookup_permute_small_async_dev, sg_grand_products_closing_dev, sg_fr_kate_division_rem_dev;
+ *     nothing removed or resized
  * A binding built against revision r must refuse a library whose sg_abi_version() < r. */
 #define SG_ABI_VERSION 3
 int sg_abi_version(void);

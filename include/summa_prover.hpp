@@ -486,7 +486,9 @@ struct Session {
   std::multimap<size_t, void*> pool;          // freed columns are kept for the next proof (hipMalloc / hipFree synchronise the device)
   uint64_t* pinned = nullptr;
   size_t pinned_cap = 0;
-  uint64_t* pinned_small = nullptr;           // 8 rows of page-locked memory for values read back asynchronously (checked where the host waits anyway)
+  uint64_t* pinned_small = nullptr;           // 8 rows of page-locked memory, mapped into the device: small values the kernels write
+                                              // there themselves (checked where the host waits anyway; no copy launches)
+  uint8_t* pinned_small_dev = nullptr;        // ... its device address
   ~Session() {   // no HIP calls here (see Orphans)
     Orphans& o = orphans();
     std::lock_guard<std::mutex> lk(o.mu);
@@ -647,6 +649,7 @@ inline std::vector<RotationSet> rotation_sets() {  // nu order; polynomials in i
 
 struct ProvingKey {
   std::vector<uint64_t> table_rows;  // the lookup table column (fixed 4), canonical limbs of the usable rows (host copy)
+  bool table_is_range = false;       // ... every usable row below 2^16: the device-side permutation applies (known with the key)
   uint32_t k = 0;
   size_t n = 0, usable = 0;
   uint64_t srs = 0;
@@ -715,6 +718,9 @@ struct ProvingKey {
       d2h(table_rows.data(), canon.p, 32 * n);
     }
     ck(sg_stream_wait(main_stream()), "sync");
+    table_is_range = true;
+    for (size_t i = 0; i < usable; i++)
+      table_is_range = table_is_range && table_rows[4 * i] < (1u << 16) && !(table_rows[4 * i + 1] | table_rows[4 * i + 2] | table_rows[4 * i + 3]);
   }
 };
 
@@ -729,8 +735,18 @@ inline void os_random(uint8_t* out, size_t bytes) {
 
 inline uint64_t* pinned_small_rows() {   // 8 rows, allocated once per session
   uint64_t*& p = session().pinned_small;
-  if (!p) hk(hipHostMalloc(reinterpret_cast<void**>(&p), 32 * 8), "hipHostMalloc");
+  if (!p) {
+    hk(hipHostMalloc(reinterpret_cast<void**>(&p), 32 * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    hk(hipHostGetDevicePointer(reinterpret_cast<void**>(&session().pinned_small_dev), p, 0), "hipHostGetDevicePointer");
+  }
   return p;
+}
+// rows of that block: 0 .. 2 the grand products' closing values, 3 the remainder of the final division, 4 two status words
+// (range check of the advice columns, lookup permutation)
+enum { MAIL_CLOSING = 0, MAIL_REMAINDER = 3, MAIL_STATUS = 4 };
+inline uint8_t* pinned_small_dev_row(uint32_t row) {
+  pinned_small_rows();
+  return session().pinned_small_dev + 32 * row;
 }
 inline uint64_t* pinned_rows(size_t rows) {  // page-locked host staging, grown on demand, kept (per thread)
   uint64_t*& p = session().pinned;
@@ -955,10 +971,14 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   };
 
   // -- 1: advice
-  DevCol noncanonical(1);   // device counter of the range check, read after the commitments (where the host waits anyway)
+  // status words in mapped page-locked memory, written by the kernels themselves and looked at after the commitments (where the
+  // host waits anyway): the range check of the advice columns, the verdict of the lookup permutation
+  volatile uint32_t* status = reinterpret_cast<volatile uint32_t*>(pinned_small_rows() + 4 * MAIL_STATUS);
+  uint8_t* status_dev = pinned_small_dev_row(MAIL_STATUS);
+  status[0] = status[1] = 0;
   if (opt.sanity_checks) {
     const void* cols[3] = {advice[0].p, advice[1].p, advice[2].p};
-    ck(sg_fr_count_noncanonical_dev(cols, 3, n, noncanonical.p, main_stream()), "range check of the advice columns");
+    ck(sg_fr_flag_noncanonical_dev(cols, 3, n, status_dev, main_stream()), "range check of the advice columns");
   }
   rand_rows({{&advice[0], u, n - u}, {&advice[1], u, n - u}, {&advice[2], u, n - u}});
   DevCol instance_col(n);
@@ -996,7 +1016,9 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
                            zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, main_stream()), "lookup input");
   DevCol pin(n), ptab(n);
-  const int prc = sg_lookup_permute_small_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, main_stream());   // range tables: on the device
+  // range tables (a property of the key): on the device, nothing waited for -- the verdict lands in status[1]
+  const int prc = pk.table_is_range ? sg_lookup_permute_small_async_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, status_dev + 4, main_stream())
+                                    : SG_ERR_UNSUPPORTED;
   if (prc == SG_ERR_UNSUPPORTED) {   // general tables: sort on the host, as upstream does
     DevCol canon(n);
     uint64_t* stage = pinned_rows(3 * n);   // page-locked staging: the three 32 n-byte transfers run at link speed
@@ -1029,11 +1051,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   } else {
     pts = commit_points({advice[0].p, advice[1].p, advice[2].p, pin.p, ptab.p}, {1 | SP, 1 | SP, 1 | SP, 2 | SP, 2 | SP});
   }
-  if (opt.sanity_checks) {
-    uint32_t bad = 0;
-    d2h(&bad, noncanonical.p, 4);
-    if (bad) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
-  }
+  // (the commitment job has waited for the stream: the status words are final)
+  if (status[1] == 1) throw WitnessError("lookup input value not in the table");
+  if (status[1]) throw std::runtime_error("lookup permutation: the key's table is not a range table after all");
+  if (opt.sanity_checks && status[0]) throw WitnessError("advice words >= r (not canonical Montgomery field elements)");
   mark("1: commitments back");
   for (int i = 0; i < 3; i++) tr.write_point(pts.data() + 64 * i);
   const Fr theta = tr.squeeze();
@@ -1071,15 +1092,12 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     }
     void* lookup_cols[4] = {inp.p, pk.fixed_lag[4].p, pin.p, ptab.p};
     void* z_out[3] = {zs[0].p, zs[1].p, lz.p};
-    ck(sg_grand_products_dev(all_vals.data(), all_sig.data(), chunk_cols, 2, lookup_cols, 1, beta.bytes(), gamma.bytes(), k, u, z_out,
-                             main_stream()), "grand products");
+    // z0[u], z1[u], lz[u] land in mapped host memory, written by the kernels that produce the row: looked at when the commitments are back
+    ck(sg_grand_products_closing_dev(all_vals.data(), all_sig.data(), chunk_cols, 2, lookup_cols, 1, beta.bytes(), gamma.bytes(), k, u, z_out,
+                                     opt.sanity_checks ? pinned_small_dev_row(MAIL_CLOSING) : nullptr, main_stream()), "grand products");
     mark("3: grand products enqueued");
   }
-  uint64_t* closing = pinned_small_rows();   // z1[u], lz[u]: read back asynchronously, looked at when the commitments are back
-  if (opt.sanity_checks) {
-    hk(hipMemcpyAsync(closing, zs[1].at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
-    hk(hipMemcpyAsync(closing + 4, lz.at(u), 32, hipMemcpyDeviceToHost, main_stream()), "D2H");
-  }
+  uint64_t* closing = pinned_small_rows() + 4 * MAIL_CLOSING;
   rand_rows({{&zs[0], u + 1, n - u - 1}, {&zs[1], u + 1, n - u - 1}, {&lz, u + 1, n - u - 1}});
   draws += 1;                                // draw 9, the random polynomial, was made in phase 1
   std::vector<DevCol> co3, ex3;
@@ -1095,11 +1113,11 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     commit_batch({zs[0].p, zs[1].p, lz.p, random_poly.p}, {2, 2, 2, 0});
   }
   mark("3: commitments back");
-  if (opt.sanity_checks) {   // the copies above precede the commitment job on the main stream: complete by now
+  if (opt.sanity_checks) {   // the kernels that wrote them precede the commitment job on the main stream: complete by now
     Fr last;
-    std::memcpy(last.l, closing, 32);
+    std::memcpy(last.l, closing + 4, 32);         // z1[u]: the permutation's last chunk
     if (last != Fr::one()) throw WitnessError("permutation argument not satisfied by the assignment");
-    std::memcpy(last.l, closing + 4, 32);
+    std::memcpy(last.l, closing + 8, 32);         // lz[u]
     if (last != Fr::one()) throw WitnessError("lookup argument not satisfied by the assignment");
   }
   const Fr y = tr.squeeze();
@@ -1359,12 +1377,17 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   DevCol l_poly(n), w2(n);
   ck(sg_fr_lincomb_low_dev(lp.data(), coeffs[0].bytes(), (uint32_t)lp.size(), n, low[0].bytes(), (uint32_t)low.size(), l_poly.p,
                            main_stream()), "L lincomb");
-  Fr rem;
-  ck(sg_fr_kate_division_dev(l_poly.p, n, mu.bytes(), w2.p, reinterpret_cast<uint8_t*>(rem.l), main_stream()), "final division");
-  if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");
+  // the remainder L(mu) goes to mapped host memory and is looked at once W' is back: the commitment job is issued behind the
+  // division without a host wait in between (a non-zero remainder is a bug in this driver, not an input error)
+  ck(sg_fr_kate_division_rem_dev(l_poly.p, n, mu.bytes(), w2.p, pinned_small_dev_row(MAIL_REMAINDER), main_stream()), "final division");
   mark("6: final quotient enqueued, commit issued");
   commit_batch({w2.p}, {0});
   mark("6: W' back");
+  {
+    Fr rem;
+    std::memcpy(rem.l, pinned_small_rows() + 4 * MAIL_REMAINDER, 32);
+    if (!rem.is_zero()) throw std::runtime_error("multi-open linearisation does not vanish at mu");
+  }
   lap("6_multiopen");
   return tr.proof;
 }

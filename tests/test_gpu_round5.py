@@ -224,3 +224,100 @@ def test_batch_restores_the_parameters_it_found(gpu):
     finally:
         ffi.set_param("host.wait_sleep_us", 0)
         ffi.set_param("commit.combine_wait_us", 300)
+
+
+def _canon_small(values):
+    """Montgomery device column of small integers"""
+    import torch
+    from circuits_halo2_amd.arithmetic import fr_to_montgomery
+    a = np.zeros((len(values), 32), dtype=np.uint8)
+    v = np.asarray(values, dtype=np.uint64)
+    for b in range(4):
+        a[:, b] = (v >> (8 * b)) & 0xff
+    return fr_to_montgomery(torch.from_numpy(a.reshape(-1)).cuda())
+
+
+def test_lookup_permutation_without_waits_matches_the_waiting_one(gpu):
+    """sg_lookup_permute_small_async_dev: same A', S' (Montgomery words) as sg_lookup_permute_small_dev, call after call on one stream
+    (every call cleans the work space of the next), a rejected input in between included; the verdict arrives in the status word"""
+    import ctypes as C
+    import torch
+    from circuits_halo2_amd import ffi
+    L = ffi.lib()
+    rows = 3000
+    rng = np.random.default_rng(5)
+    table = _canon_small(np.arange(rows) % 256)
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+
+    def both(values):
+        inp = _canon_small(values)
+        outs = [torch.zeros(32 * rows, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        status.zero_()
+        ffi.check(L.sg_lookup_permute_small_async_dev(ffi.dev_ptr(inp), ffi.dev_ptr(table), C.c_size_t(rows), ffi.dev_ptr(outs[0]), ffi.dev_ptr(outs[1]),
+                                                      C.c_void_p(status.data_ptr()), ffi.current_stream_ptr()))
+        torch.cuda.synchronize()
+        verdict = int(status[0].item())
+        rc = L.sg_lookup_permute_small_dev(ffi.dev_ptr(inp), ffi.dev_ptr(table), C.c_size_t(rows), ffi.dev_ptr(outs[2]), ffi.dev_ptr(outs[3]),
+                                           ffi.current_stream_ptr())
+        return verdict, rc, outs
+
+    for trial in range(3):
+        verdict, rc, outs = both(rng.integers(0, 256, rows))
+        assert verdict == 0 and rc == 0
+        assert (outs[0] == outs[2]).all() and (outs[1] == outs[3]).all() and outs[0].any()
+    bad = rng.integers(0, 256, rows)
+    bad[17] = 300                                   # not in the table
+    verdict, rc, _ = both(bad)
+    assert verdict == 1 and rc != 0
+    verdict, rc, outs = both(rng.integers(0, 256, rows))     # the call after a rejected one starts clean
+    assert verdict == 0 and rc == 0 and (outs[0] == outs[2]).all() and (outs[1] == outs[3]).all()
+
+
+def test_flag_noncanonical_closing_values_and_asynchronous_remainder(gpu):
+    """the three small entry points that spare a proof its copy launches: a range check that only raises a flag, grand products that
+    also leave z_p[usable] where the caller says, a Kate division whose remainder stays on the device"""
+    import ctypes as C
+    import torch
+    from circuits_halo2_amd import ffi
+    L = ffi.lib()
+    k, n = 10, 1 << 10
+    u = n - 6
+    cols = [_rand_fr(40 + j, n) for j in range(3)]
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pc = (C.c_void_p * 3)(*[c.data_ptr() for c in cols])
+    ffi.check(L.sg_fr_flag_noncanonical_dev(pc, C.c_uint32(3), C.c_size_t(n), C.c_void_p(flag.data_ptr()), ffi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    cols[1][32 * 77:32 * 78] = 0xff                 # 2^256 - 1 >= r
+    ffi.check(L.sg_fr_flag_noncanonical_dev(pc, C.c_uint32(3), C.c_size_t(n), C.c_void_p(flag.data_ptr()), ffi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    # grand products: two permutation chunks (4 + 2 columns) and one lookup, closing = z_p[u]
+    vals = [_rand_fr(60 + j, n) for j in range(6)]
+    sig = [_rand_fr(70 + j, n) for j in range(6)]
+    look = [_rand_fr(80 + j, n) for j in range(4)]
+    beta, gamma = _scalar(90), _scalar(91)
+    pv, ps = (C.c_void_p * 6)(*[v.data_ptr() for v in vals]), (C.c_void_p * 6)(*[v.data_ptr() for v in sig])
+    pl = (C.c_void_p * 4)(*[v.data_ptr() for v in look])
+    chunk = (C.c_uint32 * 2)(4, 2)
+    zs = [torch.zeros(32 * n, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    zs2 = [torch.zeros(32 * n, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    closing = torch.zeros(3 * 32, dtype=torch.uint8, device="cuda")
+    pz, pz2 = (C.c_void_p * 3)(*[z.data_ptr() for z in zs]), (C.c_void_p * 3)(*[z.data_ptr() for z in zs2])
+    ffi.check(L.sg_grand_products_closing_dev(pv, ps, chunk, C.c_uint32(2), pl, C.c_uint32(1), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)),
+                                              C.c_uint32(k), C.c_size_t(u), pz, C.c_void_p(closing.data_ptr()), ffi.current_stream_ptr()))
+    ffi.check(L.sg_grand_products_dev(pv, ps, chunk, C.c_uint32(2), pl, C.c_uint32(1), ffi.ptr(ffi.u8(beta)), ffi.ptr(ffi.u8(gamma)),
+                                      C.c_uint32(k), C.c_size_t(u), pz2, ffi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    for p in range(3):
+        assert (zs[p] == zs2[p]).all()
+        assert (closing[32 * p:32 * p + 32] == zs[p][32 * u:32 * u + 32]).all() and closing[32 * p:32 * p + 32].any()
+    # Kate division: the remainder on the device = the remainder handed back
+    a, b = _rand_fr(95, n), _scalar(96)
+    q1, q2 = torch.zeros(32 * n, dtype=torch.uint8, device="cuda"), torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    rem_dev = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    rem = np.zeros(32, dtype=np.uint8)
+    ffi.check(L.sg_fr_kate_division_rem_dev(ffi.dev_ptr(a), C.c_size_t(n), ffi.ptr(ffi.u8(b)), ffi.dev_ptr(q1), ffi.dev_ptr(rem_dev), ffi.current_stream_ptr()))
+    ffi.check(L.sg_fr_kate_division_dev(ffi.dev_ptr(a), C.c_size_t(n), ffi.ptr(ffi.u8(b)), ffi.dev_ptr(q2), ffi.ptr(rem), ffi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    assert (q1 == q2).all() and (rem_dev.cpu().numpy() == rem).all() and rem.any()
