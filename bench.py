@@ -812,6 +812,27 @@ def _main():
     run_steps(2, 1)
     dt_seq, _ = timed(args.steps, 1)
     fs.partial["sequential_ms_per_step"] = dt_seq / args.steps * 1e3
+    # N > 1: what ONE blocking point-sharded MSM costs end to end -- the shard's MSM, ONE collective of its own, the host sum of N
+    # points (distributed.sharded_msm) -- beside the amortised exchange of the timed region: the latency point of a scaling run
+    percall = None
+    if world > 1:
+        from circuits_halo2_amd.distributed import sharded_msm
+        calls = max(3, min(args.steps, 10))
+        sharded_msm(scal, bases)
+        _beat("per-call sharded MSM", 75.0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            p_call = sharded_msm(scal, bases)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt_call = _all_max(time.perf_counter() - t0, world, coll_dev)
+        assert (p_call == result).all(), "the per-call exchange must give the point of the amortised one"
+        percall = {"ms_per_msm": dt_call / calls * 1e3, "calls": calls, "points_per_gpu": n, "value": world * n * calls / dt_call,
+                   "note": "one collective (all_gather of N x 64 B) per MSM, nothing in flight beside it: the latency an unmodified caller of a "
+                           "point-sharded best_multiexp sees at this N; `value` amortises the exchange over the timed region instead"}
+        fs.partial["per_call_sharded_msm_ms"] = percall["ms_per_msm"]
     pool.shutdown()
     _beat("extras", args.wall_limit)
     phase_reps = None
@@ -841,6 +862,12 @@ def _main():
             "sequential": {"ms_per_step": dt_seq / args.steps * 1e3, "value": world * n * args.steps / dt_seq,
                            "note": "the same steps strictly one after the other (--in-flight 1): the latency of one MSM"},
         }
+        if world > 1:
+            # what the collectives library itself saw (the driver's "did RCCL see N ranks" check): the process group's size and backend
+            line["config"]["ranks_seen_by_process_group"] = dist.get_world_size()
+            line["config"]["rccl_ranks_seen"] = dist.get_world_size() if args.backend == "nccl" else None
+            line["config"]["per_call_sharded_msm_ms"] = percall["ms_per_msm"]
+            line["sharded_msm_per_call"] = percall
         # ---- roofline of the dominant kernel (msm_accumulate), HIP events on its stream
         reps = phase_reps
         acc_ms = float(np.mean([r["accumulate_ms"] for r in reps]))

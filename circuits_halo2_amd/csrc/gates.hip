@@ -528,17 +528,18 @@ bool gates_run_by_value(const GateProgram& p, const void* const* cols, fp_words*
   a.blockmask = ((uint64_t)1 << a.ext_k) - 1;
   const unsigned blocks = (unsigned)((n_ext + 255) / 256);
   bool done = false;
-  auto launch = [&](auto tag) {
+  auto launch = [&](auto tag, const char* name) {
     using PROG = decltype(tag);
     if (done || !is_program<PROG>(p)) return;
     done = true;
+    if (std::getenv("SG_GATES_DEBUG")) std::fprintf(stderr, "gates: ahead-of-time program %s (arguments by value), %u blocks\n", name, blocks);
     gates_fixed_value_kernel<PROG><<<blocks, 256, 0, stream>>>(a);
   };
-  launch(MstLookupInput{});
-  launch(MstGatesNc2{});
-  launch(MstGatesNc1{});
-  launch(MstGatesNc3{});
-  launch(MstGatesNc4{});
+  launch(MstLookupInput{}, "MstLookupInput");
+  launch(MstGatesNc2{}, "MstGatesNc2");
+  launch(MstGatesNc1{}, "MstGatesNc1");
+  launch(MstGatesNc3{}, "MstGatesNc3");
+  launch(MstGatesNc4{}, "MstGatesNc4");
   if (done) *err = hipGetLastError();
   return done;
 }

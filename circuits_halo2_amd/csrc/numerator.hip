@@ -13,6 +13,9 @@
 // runs the kernels one after the other for anything else.  Constants and column pointers travel as kernel arguments.
 #include "numerator.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "gates_device.cuh"
 #include "quotient_device.cuh"
 #include "side_prio.cuh"
@@ -68,16 +71,16 @@ __global__ void __launch_bounds__(256) numerator_fused_kernel(NumeratorArgs a) {
 template <class F>
 static bool for_known_pair(const GateProgram& g, const GateProgram& in, F&& f) {
   if (!is_program<MstLookupInput>(in)) return false;
-  if (is_program<MstGatesNc2>(g)) return f(MstGatesNc2{}), true;
-  if (is_program<MstGatesNc1>(g)) return f(MstGatesNc1{}), true;
-  if (is_program<MstGatesNc3>(g)) return f(MstGatesNc3{}), true;
-  if (is_program<MstGatesNc4>(g)) return f(MstGatesNc4{}), true;
+  if (is_program<MstGatesNc2>(g)) return f(MstGatesNc2{}, 2), true;
+  if (is_program<MstGatesNc1>(g)) return f(MstGatesNc1{}, 1), true;
+  if (is_program<MstGatesNc3>(g)) return f(MstGatesNc3{}, 3), true;
+  if (is_program<MstGatesNc4>(g)) return f(MstGatesNc4{}, 4), true;
   return false;
 }
 bool numerator_fused_available(const GateProgram& gates, const GateProgram& lookup_input) {
   if (gates.const_words.size() / 8 > NUM_MAX_CONSTS || lookup_input.const_words.size() / 8 > NUM_MAX_INPUT_CONSTS) return false;
   if (gates.n_columns > NUM_MAX_COLS || lookup_input.n_columns != gates.n_columns) return false;
-  return for_known_pair(gates, lookup_input, [](auto) {});
+  return for_known_pair(gates, lookup_input, [](auto, int) {});
 }
 hipError_t numerator_fused(const GateProgram& gates, const GateProgram& lookup_input, NumeratorArgs& a, hipStream_t stream) {
   if (!numerator_fused_available(gates, lookup_input) || a.perm.cosets == 0 || a.perm.ext_k != a.perm.k || a.look.ext_k != a.look.k)
@@ -88,8 +91,10 @@ hipError_t numerator_fused(const GateProgram& gates, const GateProgram& lookup_i
   std::memcpy(a.input_consts, lookup_input.const_words.data(), lookup_input.const_words.size() * sizeof(uint32_t));
   const size_t n_ext = (size_t)a.perm.cosets << a.perm.k;
   const unsigned blocks = (unsigned)((n_ext + 255) / 256);
-  for_known_pair(gates, lookup_input, [&](auto tag) {
+  for_known_pair(gates, lookup_input, [&](auto tag, int nc) {
     using G = decltype(tag);
+    if (std::getenv("SG_GATES_DEBUG"))
+      std::fprintf(stderr, "gates: ahead-of-time program MstGatesNc%d inside the one-pass numerator, %u blocks\n", nc, blocks);
     numerator_fused_kernel<G, MstLookupInput><<<blocks, 256, 0, stream>>>(a);
   });
   return hipGetLastError();

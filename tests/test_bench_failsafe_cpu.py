@@ -102,3 +102,59 @@ def test_parent_of_a_bare_multi_rank_launch_reports_failed_ranks():
     assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-800:])
     line = json.loads(lines[0])
     assert line["value"] is None and line["error"] and line["n_gpus"] == 2
+
+
+EIGHT_RANK_WORKER = r'''
+import os, sys, time, types, datetime
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+args = types.SimpleNamespace(gpus=world, steps=20, warmup=5)
+fs = bench._FS = bench.FailSafe(rank, args, 60.0)
+fs.arm()
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
+# the timing collectives of the bench at the size of a whole node: max over ranks, sums over ranks
+assert bench._all_max(0.25 + rank, world, "cpu") == 0.25 + (world - 1)
+assert bench._all_sum([1.0, rank, 2.0 * rank], world, "cpu") == [float(world), world * (world - 1) / 2, float(world * (world - 1))]
+fs.partial["value"] = 6.0e9
+if sys.argv[1] == "straggler" and rank == 5:
+    time.sleep(30)                                  # never joins the next collective
+bench._beat("a step's collective", 1.5)             # per-step allowance, as bench.timed() sets one around every collective
+dist.barrier()
+if sys.argv[1] == "ok":
+    if rank == 0:
+        fs.emit({"metric": "msm_points_per_sec", "value": 6.0e9, "n_gpus": world})
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def _run_eight(tmp_path, mode, port):
+    script = tmp_path / "eight.py"
+    script.write_text(EIGHT_RANK_WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script), mode], env=env, capture_output=True, text=True, timeout=300)
+    return r, [ln for ln in r.stdout.splitlines() if ln.startswith("{")], time.time() - t0
+
+
+def test_eight_ranks_one_line(tmp_path):
+    """the bench's timing collectives and its one-JSON-line contract with eight ranks (gloo on the CPU: the size the driver's
+    scaling run uses, rehearsed without the hardware)"""
+    r, lines, _ = _run_eight(tmp_path, "ok", 29611)
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    assert json.loads(lines[0])["n_gpus"] == 8
+
+
+def test_eight_ranks_a_straggler_costs_an_error_line_within_the_step_allowance(tmp_path):
+    """rank 5 of 8 never reaches a step's collective: the other ranks' watchdogs end them after the step's allowance (not after the
+    process group's timeout), rank 0 prints the ONE error line with what had been measured, the launcher returns non-zero"""
+    r, lines, took = _run_eight(tmp_path, "straggler", 29621)
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "a step's collective" in line["error"] and line["partial"]["value"] == 6.0e9 and line["n_gpus"] == 8
+    assert took < 60, took

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the point-sharded MSM driver (circuits_halo2_amd/distributed.py).
+"""world_size-2 and -8 gloo tests of the point-sharded MSM driver (circuits_halo2_amd/distributed.py).
 The collective logic (shard -> partial -> all_gather -> sum of partials) is the product's;
 the per-shard MSM is injected, and on this GPU-less box the injected callable is the CPU
 oracle, so the test checks the N > 1 exchange path end to end without a GPU."""
@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -43,15 +44,18 @@ print("rank", rank, "ok")
 '''
 
 
-def test_point_sharded_msm_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_point_sharded_msm_gloo(tmp_path, world):
+    """world 8 = the size the driver's scaling run uses (one rank per GPU of a node): shard bounds, the all_gather of eight partials
+    and the host sum of eight points, rehearsed without the hardware"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29533 + 10 * world), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 BATCH_WORKER = r'''
@@ -123,15 +127,16 @@ print("rank", rank, "ok")
 '''
 
 
-def test_proof_batch_scheduler_gloo_world2(tmp_path):
-    """bookkeeping of the proof-level batch driver (circuits_halo2_amd/batch.py) with two ranks: the setup broadcast,
+@pytest.mark.parametrize("world", [2, 8])
+def test_proof_batch_scheduler_gloo(tmp_path, world):
+    """bookkeeping of the proof-level batch driver (circuits_halo2_amd/batch.py) with two and with eight ranks: the setup broadcast,
     the round-robin deal, proofs in flight per rank, error isolation, the gather -- with stand-in provers (the real
     prover needs the GPU; tests/test_gpu_batch.py runs it)"""
     script = tmp_path / "batch_worker.py"
     script.write_text(BATCH_WORKER)
     env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29534 + 10 * world), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world

@@ -194,6 +194,10 @@ def _run_bench(extra, timeout=1100):
 
 
 def _check_two_rank_line(line, backend_word):
+    # what the collectives library saw, and the blocking point-sharded MSM beside the amortised exchange (round 5)
+    assert line["config"]["ranks_seen_by_process_group"] == 2 and line["config"]["per_call_sharded_msm_ms"] > 0
+    assert line["config"]["rccl_ranks_seen"] == (2 if backend_word == "nccl" else None)
+    assert line["sharded_msm_per_call"]["calls"] >= 3 and line["sharded_msm_per_call"]["ms_per_msm"] >= line["ms_per_step"] * 0.5
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["sharding"].startswith("point-sharded") and backend_word in line["config"]["backend"]
     b = line["batch_k17"]
@@ -218,6 +222,26 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal():
     x2 = _check_two_rank_line(two, "gloo")
     one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch-proofs", "0", "--no-cpu", "--log-n", "20", "--strong-only"])
     assert one["msm_strong_scaling_2^23"]["result_x"] == x2 and one["msm_strong_scaling_2^23"]["points_per_gpu"] == 1 << 23
+
+
+def test_four_rank_rehearsal_on_one_gpu():
+    """the bare launch with FOUR ranks sharing the one GPU (gloo; the GPU boxes of this pool allow six processes on a card, so the
+    eight of a whole node are rehearsed on the CPU: tests/test_distributed_cpu.py, test_bench_failsafe_cpu.py): the users of the
+    batch dealt over four ranks, the setup broadcast to three receivers, max-over-ranks timing, the watchdog's per-step
+    allowance under four-fold contention for the device, and still ONE JSON line; the strong-scaling MSM cut in four gives the
+    point it gives cut in two or not at all"""
+    line = _run_bench(["--gpus", "4", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch-proofs", "8", "--batch-repeats", "1",
+                       "--batch-in-flight", "2", "--no-cpu", "--log-n", "20"])
+    assert line["n_gpus"] == 4 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["ranks_seen_by_process_group"] == 4 and line["config"]["rccl_ranks_seen"] is None
+    assert line["config"]["per_call_sharded_msm_ms"] > 0
+    b = line["batch_k17"]
+    assert b["n_gpus"] == 4 and b["proofs_total"] == 8 and b["errors"] == 0 and b["verified_sample"] is True
+    assert all(r["proofs"] == 8 and r["errors"] == 0 for r in b["repeats"])          # dealt 2 + 2 + 2 + 2, every rank counted
+    st = line["msm_strong_scaling_2^23"]
+    assert st["n_gpus"] == 4 and st["points_per_gpu"] == 1 << 21 and st["every_rank_partial_equals_inner_product_times_G"] is True
+    one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch-proofs", "0", "--no-cpu", "--log-n", "20", "--strong-only"])
+    assert one["msm_strong_scaling_2^23"]["result_x"] == st["result_x"]
 
 
 def test_a_rank_killed_mid_batch_costs_an_error_line_not_the_run():

@@ -1,6 +1,7 @@
 #!/bin/bash
 # persistent msm_accumulate: waves per SIMD (msm.acc_waves: 8 = one ticket per wave / grid = tasks, 3 = full file, 2 = room for others, 0 = auto)
 # against steps in flight; headline points/s, one-at-a-time ms, accumulate ms
+set -euo pipefail
 for rep in 1 2; do
 for w in 8 3 2 0; do
   for f in 3 4; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # hardware queues (GPU_MAX_HW_QUEUES; HIP's default is 4, streams are assigned round-robin): single proof, batch of proofs
+set -euo pipefail
 mkdir -p gpurun_out/r03g
 python - <<'PY'
 import os, sys

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: ab_inflight.sh <steps> "<in-flight list>" cfg1 cfg2 ...
+set -euo pipefail
 steps=$1; fl=$2; shift; shift
 for rep in 1 2; do
 for cfg in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: ab_quick_headline.sh <steps> cfg1 cfg2 ... : headline line fields for each SG_PARAMS setting, in-flight 3, twice
+set -euo pipefail
 steps=$1; shift
 for rep in 1 2; do
 for cfg in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # wave priority 3 for every kernel but msm_accumulate (side_prio) x the accumulation's waves per SIMD x steps in flight: headline, proof, batch
+set -euo pipefail
 for rep in 1 2; do
 for cfg in "side_prio=0,msm.acc_waves=3,msm.red_lean=0" "side_prio=1" "side_prio=1,msm.acc_waves=3,msm.red_lean=0" "side_prio=1,msm.red_lean=0"; do
   for f in 3 4 6; do

@@ -1,4 +1,6 @@
+#!/bin/bash
 # the batch extra three times in a row (default hardware queues): stability of proofs/s at 1..4 proofs in flight
+set -euo pipefail
 for i in 1 2 3; do
   python bench.py --no-cpu --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys

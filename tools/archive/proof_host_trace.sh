@@ -1,5 +1,6 @@
 #!/bin/bash
 # the compiled prover's own host timeline (SG_PROVER_TRACE) of the last of a few proofs at k = 17
+set -euo pipefail
 mkdir -p gpurun_out/r03g
 [ -f gpurun_out/r03g/bundle17.bin ] || python - <<'PY'
 import os, sys

@@ -1,4 +1,6 @@
+#!/bin/bash
 # proofs per second of the batch extra under different numbers of HIP hardware queues (GPU_MAX_HW_QUEUES)
+set -euo pipefail
 for q in 4 8 16 32; do
   echo "== GPU_MAX_HW_QUEUES=$q"
   GPU_MAX_HW_QUEUES=$q python bench.py --no-cpu --steps 5 --warmup 1 2>/dev/null | python -c "
