@@ -802,7 +802,8 @@ def _main():
     fs.partial.update({"value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": world})
     # the SAME regime once more, untimed, with every step's own HIP events (sg_msm_timings: the chained accumulation launch from
     # behind its wait for the previous one): the per-kernel figure of the regime `value` is quoted on, for `roofline`
-    if rank == 0 and in_flight > 1:
+    # (every rank runs it -- the region ends in the ranks' collective -- rank 0 reports its own launches)
+    if in_flight > 1:
         pipelined_timings = []
         run_steps(max(args.steps, 2 * in_flight), in_flight)
         pipelined_reps, pipelined_timings = pipelined_timings[in_flight:], None    # (the first ones start on an idle device)

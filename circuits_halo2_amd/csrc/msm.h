@@ -35,6 +35,7 @@ struct MsmConfig {
   uint32_t prefold_quad_buckets = 1u << 15;  // ... with a quad per bucket up to this many buckets in the job, one lane per bucket beyond
   uint32_t acc_chain = 1;      // accumulations of different jobs run one after the other (each waits for the previous launch's event)
   uint32_t red_lean = 1;       // level-0 bucket reduction within 168 registers (fits beside a polite accumulation): 0 never, 1 when other jobs are in flight, 2 always
+  uint32_t fused_frontend = 1; // two-pass sort: scans and task histogram inside the sort's own kernels (msm_fine_sort_fused), 0: the launches of rounds 1-4
   uint32_t acc_trace = 0;      // debug: msm_accumulate records when each wave starts and leaves; finish() prints the percentiles to stderr
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };
@@ -147,7 +148,7 @@ class MsmEngine {
     hipStream_t stream = nullptr;
     uint8_t* out = nullptr;
     MsmTimings* tm = nullptr;
-    bool trivial = false, all_zero = false, fixed = false;
+    bool trivial = false, all_zero = false, fixed = false, fe = false;
     uint32_t red2d = 0;  // 0: scan-based reduction, 1: 2-D with host weights, 2: 2-D with device weights
     uint32_t n_tab = 0;
     uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0, acc_threads = 0;
@@ -165,7 +166,7 @@ class MsmEngine {
   DevBuf<uint32_t> thist_;
   DevBuf<uint32_t> sorted_, counts_, off_, ntask_[2], toff_[2], hist_, bsum_, meta_;
   DevBuf<xyzz29_mem> partial_[2], red_a_[2], red_s_[2], red_r_[2];
-  DevBuf<uint32_t> win_words_;
+  DevBuf<uint32_t> win_words_, fe_, tbase_;
   DevBuf<uint64_t> trace_;
   DevBuf<uint32_t> part_entry_, ccnt_, coff_;  // two-pass sort: partitioned entries, coarse-bin counts / offsets
   DevBuf<uint16_t> part_fine_;

@@ -131,10 +131,22 @@ __global__ void __launch_bounds__(1024) msm_hist(const int16_t* __restrict__ dig
 // bases come from LDS, then a second sweep writes the prefixes (a column is P strided loads;
 // one thread per bucket made this the slowest kernel of a small MSM).
 static constexpr uint32_t HP_BUCKETS = 32, HP_GROUPS = 8;
+// Round 5 (`fe` != nullptr, coarse bins of the two-pass sort, NB <= FE_MAX_BINS): the workgroup that finishes LAST (a counter in
+// device memory, as msm_scan_sums does for its block sums) also scans the bin totals -- coff[g] = entries before bin g and
+// tbase[g] = task slots before bin g, a bin of F buckets and E entries owning F + (E >> log_L) slots (an upper bound of its
+// sum_f ceil(c_f / L) tasks) -- which used to be a launch of its own (msm_scan_small / msm_scan_sums + msm_scan_write).
+static constexpr uint32_t FE_MAX_BINS = 4096;
+struct FrontEndScan {
+  uint32_t* done;    // counter of finished workgroups (zero between launches), nullptr: no scan here
+  uint32_t* coff;    // [NB + 1]
+  uint32_t* tbase;   // [NB + 1]
+  uint32_t F, log_L;
+};
 __global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hist, uint32_t P, uint32_t nbw, uint32_t NB,
-                                                       uint32_t* __restrict__ counts) {
+                                                       uint32_t* __restrict__ counts, FrontEndScan fe) {
   side_kernel_prio();
   __shared__ uint32_t s_sum[HP_GROUPS][HP_BUCKETS];
+  __shared__ uint32_t s_last;
   const uint32_t bx = threadIdx.x % HP_BUCKETS, gy = threadIdx.x / HP_BUCKETS;
   const uint32_t g = blockIdx.x * HP_BUCKETS + bx;  // global bucket id = j*nbw + b
   const bool live = g < NB;
@@ -149,13 +161,55 @@ __global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hi
   __syncthreads();
   uint32_t run = 0;
   for (uint32_t q = 0; q < gy; q++) run += s_sum[q][bx];
-  if (!live) return;
-  for (uint32_t p = lo; p < hi; p++) {
-    uint32_t v = col[(size_t)p * nbw];
-    col[(size_t)p * nbw] = run;
-    run += v;
+  if (live) {
+    for (uint32_t p = lo; p < hi; p++) {
+      uint32_t v = col[(size_t)p * nbw];
+      col[(size_t)p * nbw] = run;
+      run += v;
+    }
+    if (gy == HP_GROUPS - 1) counts[g] = run;
   }
-  if (gy == HP_GROUPS - 1) counts[g] = run;
+  if (!fe.done) return;
+  __syncthreads();                       // (every thread of the workgroup reaches this: the early return above is gone)
+  if (threadIdx.x == 0) {
+    __threadfence();                     // this workgroup's totals are visible device-wide before it counts as done
+    s_last = atomicAdd(fe.done, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // the last workgroup: exclusive scans over the NB <= 4096 bin totals, 16 per thread
+  __shared__ uint32_t s_a[256], s_t[256];
+  const uint32_t tid = threadIdx.x, per_t = (NB + 255) / 256, b0 = min(tid * per_t, NB), b1 = min(b0 + per_t, NB);
+  const volatile uint32_t* vc = counts;  // written by other workgroups of this launch
+  uint32_t a = 0, t = 0;
+  for (uint32_t q = b0; q < b1; q++) {
+    const uint32_t v = vc[q];
+    a += v;
+    t += fe.F + (v >> fe.log_L);
+  }
+  s_a[tid] = a; s_t[tid] = t;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t xa = 0, xt = 0;
+    if (tid >= d) { xa = s_a[tid - d]; xt = s_t[tid - d]; }
+    __syncthreads();
+    s_a[tid] += xa; s_t[tid] += xt;
+    __syncthreads();
+  }
+  uint32_t ra = s_a[tid] - a, rt = s_t[tid] - t;
+  for (uint32_t q = b0; q < b1; q++) {
+    const uint32_t v = vc[q];
+    fe.coff[q] = ra;
+    fe.tbase[q] = rt;
+    ra += v;
+    rt += fe.F + (v >> fe.log_L);
+  }
+  if (tid == 255) {
+    fe.coff[NB] = s_a[255];
+    fe.tbase[NB] = s_t[255];
+    *fe.done = 0;                        // ready for the next launch on this stream
+  }
 }
 
 // ------------------------------------------------------------------ 3: scans (multi-block)
@@ -465,6 +519,160 @@ __global__ void __launch_bounds__(512) msm_fine_sort(const uint32_t* __restrict_
   }
 }
 
+// Round 5: pass 2 that also closes the front end.  A workgroup owns a coarse bin whose entry offset (coff) and task-slot base
+// (tbase) are known from the coarse scan, so everything the bucket-level scans produced is local to it: off[b] = start +
+// exclusive count prefix, ntask[b] = ceil(c / L), toff[b] = tbase + exclusive task prefix (the task index space has gaps at
+// the end of every bin: consumers only ever index partial[toff[b] + seg]).  What is global -- the number of tasks, the
+// largest bucket, the histogram of task lengths that orders the tasks longest first -- goes through a handful of atomics,
+// and the workgroup that finishes last turns the histogram into the scatter's cursors, hands the totals to the host and
+// resets the counters: msm_scan_sums, msm_scan_write, msm_task_hist and msm_task_scan are gone from the job's chain.
+//   fe words: [0] finished workgroups, [1] tasks, [2] largest count, [FE_HIST + k] tasks of (clamped) length k,
+//             [FE_CURSOR + k] (out) position of the first task of length k in `order` (descending lengths)
+static constexpr uint32_t TASK_BINS_FE = 257;     // = TASK_BINS (defined with the task ordering below)
+static constexpr uint32_t FE_HIST = 8, FE_CURSOR = FE_HIST + TASK_BINS_FE, FE_WORDS = FE_CURSOR + TASK_BINS_FE;
+struct FrontEndOut {
+  uint32_t* off;
+  uint32_t* ntask;
+  uint32_t* toff;
+  const uint32_t* tbase;
+  uint32_t* fe;
+  uint32_t* meta;                 // [0] entries, [1] tasks, [2] largest count; [ticket_word] <- 0
+  volatile uint32_t* host_meta;   // the same three for the host (mapped page-locked memory)
+  uint32_t log_L, NB, NBc, ticket_word;
+};
+__global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __restrict__ part_entry,
+                                                           const uint16_t* __restrict__ part_fine,
+                                                           const uint32_t* __restrict__ coff,
+                                                           const uint32_t* __restrict__ ccnt, uint32_t B, uint32_t shift,
+                                                           uint32_t nbw, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ sorted, FrontEndOut o) {
+  side_kernel_prio();
+  extern __shared__ uint32_t s_mem[];
+  __shared__ uint32_t s_th[TASK_BINS_FE];
+  __shared__ uint32_t s_red[2];   // tasks of the bin, largest count
+  __shared__ uint32_t s_last;
+  const uint32_t F = 1u << shift, tid = threadIdx.x, nthr = blockDim.x;
+  uint32_t* s_cnt = s_mem;        // [F] counts, then cursors
+  uint32_t* s_ofs = s_cnt + F;    // [F] exclusive offsets
+  uint32_t* s_part = s_ofs + F;   // [nthr] scan scratch
+  uint32_t* s_out = s_part + nthr;  // [SORT_TILE]
+  const uint32_t start = coff[blockIdx.x], E = ccnt[blockIdx.x];
+  const uint32_t set = blockIdx.x / B, bin = blockIdx.x - set * B;
+  const uint32_t Lm1 = (1u << o.log_L) - 1, full_bin = min(1u << o.log_L, TASK_BINS_FE - 1);
+  for (uint32_t f = tid; f < F; f += nthr) s_cnt[f] = 0;
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = 0;
+  if (tid < 2) s_red[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < E; i += nthr) atomicAdd(&s_cnt[part_fine[start + i] & (F - 1)], 1u);
+  __syncthreads();
+  // exclusive scans over F (entries and tasks): contiguous share per thread + Hillis-Steele over the shares
+  const uint32_t per = (F + nthr - 1) / nthr, f0 = min(tid * per, F), f1 = min(f0 + per, F);
+  uint32_t a = 0, t = 0, mx = 0;
+  for (uint32_t f = f0; f < f1; f++) {
+    const uint32_t c = s_cnt[f];
+    a += c;
+    t += (c + Lm1) >> o.log_L;
+    mx = max(mx, c);
+    // task lengths: nfull tasks of exactly L entries and at most one shorter one
+    const uint32_t nfull = c >> o.log_L, rem = c - (nfull << o.log_L);
+    if (nfull) atomicAdd(&s_th[full_bin], nfull);
+    if (rem) atomicAdd(&s_th[min(rem, TASK_BINS_FE - 1)], 1u);
+  }
+  s_part[tid] = a;
+  __syncthreads();
+  for (uint32_t dd = 1; dd < nthr; dd <<= 1) {
+    uint32_t u = tid >= dd ? s_part[tid - dd] : 0;
+    __syncthreads();
+    s_part[tid] += u;
+    __syncthreads();
+  }
+  uint32_t run = s_part[tid] - a;
+  __syncthreads();
+  s_part[tid] = t;
+  __syncthreads();
+  for (uint32_t dd = 1; dd < nthr; dd <<= 1) {
+    uint32_t u = tid >= dd ? s_part[tid - dd] : 0;
+    __syncthreads();
+    s_part[tid] += u;
+    __syncthreads();
+  }
+  uint32_t trun = o.tbase[blockIdx.x] + s_part[tid] - t;
+  if (t) atomicAdd(&s_red[0], t);
+  if (mx) atomicMax(&s_red[1], mx);
+  const size_t b_first = (size_t)set * nbw + (size_t)bin * F;
+  uint32_t* cout = counts + b_first;
+  for (uint32_t f = f0; f < f1; f++) {
+    const uint32_t c = s_cnt[f], nt = (c + Lm1) >> o.log_L;
+    cout[f] = c;
+    s_ofs[f] = run;
+    o.off[b_first + f] = start + run;
+    o.ntask[b_first + f] = nt;
+    o.toff[b_first + f] = trun;
+    run += c;
+    trun += nt;
+  }
+  __syncthreads();
+  for (uint32_t f = tid; f < F; f += nthr) s_cnt[f] = s_ofs[f];   // cursors
+  __syncthreads();
+  if (E <= SORT_TILE) {
+    for (uint32_t i = tid; i < E; i += nthr) {
+      const uint32_t pos = atomicAdd(&s_cnt[part_fine[start + i] & (F - 1)], 1u);
+      s_out[pos] = part_entry[start + i];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < E; i += nthr) sorted[start + i] = s_out[i];
+  } else {  // oversized bin (skewed scalars): place directly; the region belongs to this workgroup alone
+    for (uint32_t i = tid; i < E; i += nthr) {
+      const uint32_t pos = atomicAdd(&s_cnt[part_fine[start + i] & (F - 1)], 1u);
+      sorted[start + pos] = part_entry[start + i];
+    }
+  }
+  // the bin's share of the global figures, then: was this the last workgroup?
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr)
+    if (s_th[k]) atomicAdd(o.fe + FE_HIST + k, s_th[k]);
+  if (tid == 0) {
+    if (s_red[0]) atomicAdd(o.fe + 1, s_red[0]);
+    if (s_red[1]) atomicMax(o.fe + 2, s_red[1]);
+  }
+  __threadfence();                       // every lane's atomics are performed device-wide before the workgroup counts as done
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(o.fe, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // the last workgroup: cursors of the task order (descending lengths), totals out, counters back to zero
+  volatile uint32_t* vf = o.fe;
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = vf[FE_HIST + k];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t pos = 0;
+    for (int k = (int)TASK_BINS_FE - 1; k >= 0; k--) {   // 257 serial steps on one lane: ~1 us
+      const uint32_t v = s_th[k];
+      s_th[k] = pos;
+      pos += v;
+    }
+    const uint32_t entries = coff[o.NBc], tasks = vf[1], largest = vf[2];
+    o.off[o.NB] = entries;
+    o.toff[o.NB] = o.tbase[o.NBc];
+    o.meta[0] = entries;
+    o.meta[1] = tasks;
+    o.meta[2] = largest;
+    o.meta[o.ticket_word] = 0;          // msm_accumulate's task counter (next launch on this stream)
+    if (o.host_meta) {
+      o.host_meta[0] = entries;
+      o.host_meta[1] = tasks;
+      o.host_meta[2] = largest;
+      __threadfence_system();
+    }
+    vf[0] = 0; vf[1] = 0; vf[2] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) {
+    o.fe[FE_CURSOR + k] = s_th[k];
+    o.fe[FE_HIST + k] = 0;
+  }
+}
+
 // ------------------------------------------------------------------ 4: accumulate / merge
 __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff, uint32_t NB, uint32_t t) {
   uint32_t lo = 0, hi = NB;  // invariant: toff[lo] <= t < toff[hi]
@@ -480,6 +688,7 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* __restrict__ toff
 // a wave waits for its largest bucket, ~30 % of the lanes' time idle).
 static constexpr uint32_t ACC_TICKET = 8;          // word of meta_ that holds msm_accumulate's task counter
 static constexpr uint32_t TASK_BINS = 257;        // task length clamped to 256
+static_assert(TASK_BINS == TASK_BINS_FE, "one histogram of task lengths");
 // buckets per workgroup in the ordering passes: ~128 workgroups, 256 .. 8192 buckets each
 static inline uint32_t task_block_for(uint32_t NB, uint32_t nbins) {
   const uint32_t max_blk = std::min<uint32_t>(128, (32 * 1024) / nbins);  // msm_task_scan: nbins * nblk <= 32 Ki
@@ -562,6 +771,48 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
   for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = thist[k * gridDim.x + blockIdx.x];
   __syncthreads();
   const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1);
+  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+    uint32_t b = blockIdx.x * task_block + q;
+    if (b < NB) {
+      uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
+      if (nfull) {
+        uint32_t pos = atomicAdd(&s_c[full_bin], nfull);
+        for (uint32_t seg = 0; seg < nfull; seg++) order[pos + seg] = make_uint2(b, seg);
+      }
+      if (rem) {
+        uint32_t pos = atomicAdd(&s_c[min(rem, TASK_BINS - 1)], 1u);
+        order[pos] = make_uint2(b, nfull);
+      }
+    }
+  }
+}
+
+// the same after msm_fine_sort_fused: the workgroup counts its tasks per length, reserves their positions in `order` with one
+// atomic per length on the cursors the front end left (fe + FE_CURSOR), then places them -- msm_task_hist and msm_task_scan
+// are not needed.  (Tasks of one length come in the order the reservations happen to be served: which lane runs which task is
+// free, the sums are the same.)
+__global__ void __launch_bounds__(256) msm_task_scatter_reserve(const uint32_t* __restrict__ cnt, uint32_t NB,
+                                                                uint32_t log_L, uint32_t task_block,
+                                                                uint32_t* __restrict__ cursor, uint2* __restrict__ order) {
+  side_kernel_prio();
+  __shared__ uint32_t s_c[TASK_BINS];
+  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = 0;
+  __syncthreads();
+  const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1);
+  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+    uint32_t b = blockIdx.x * task_block + q;
+    if (b < NB) {
+      uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
+      if (nfull) atomicAdd(&s_c[full_bin], nfull);
+      if (rem) atomicAdd(&s_c[min(rem, TASK_BINS - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) {
+    const uint32_t mine = s_c[k];
+    s_c[k] = mine ? atomicAdd(cursor + k, mine) : 0u;
+  }
+  __syncthreads();
   for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
     uint32_t b = blockIdx.x * task_block + q;
     if (b < NB) {
@@ -1295,7 +1546,7 @@ void MsmEngine::release() {
       e = nullptr;
     }
   }
-  win_words_.release(); trace_.release(); part_entry_.release(); part_fine_.release(); ccnt_.release(); coff_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
+  fe_.release(); tbase_.release(); win_words_.release(); trace_.release(); part_entry_.release(); part_fine_.release(); ccnt_.release(); coff_.release(); dig_.release(); thist_.release(); order_.release(); sorted_.release(); counts_.release(); off_.release(); hist_.release(); bsum_.release(); meta_.release();
   for (int i = 0; i < 2; i++) {
     ntask_[i].release(); toff_[i].release(); partial_[i].release(); red_a_[i].release(); red_s_[i].release(); red_r_[i].release();
   }
@@ -1633,22 +1884,39 @@ hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars,
   if (tm) SG_TRY(hipEventRecord(j.ev[1], stream));
   if (two_pass) {
     const uint32_t NBc = sets * B;
+    // round 5: the scans and the task-length histogram ride on the sort's own kernels (msm_hist_prefix's and
+    // msm_fine_sort_fused's last workgroups): five launches fewer per job
+    j.fe = cfg_.fused_frontend && NBc <= FE_MAX_BINS;
+    FrontEndScan fe_scan{nullptr, nullptr, nullptr, 0u, 0u};
+    if (j.fe) {
+      const uint32_t* before = fe_.p;
+      SG_TRY(fe_.reserve(FE_WORDS));
+      if (fe_.p != before) SG_TRY(hipMemsetAsync(fe_.p, 0, fe_.cap * sizeof(uint32_t), stream));   // counters and histogram start at zero; every job leaves them there
+      SG_TRY(tbase_.reserve((size_t)NBc + 1));
+      fe_scan = FrontEndScan{fe_.p + 3, coff_.p, tbase_.p, 1u << shift, j.log_L};
+    }
     msm_hist<<<dim3(W, P), 1024, B * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, B, shift, hist_.p);
     msm_hist_prefix<<<(NBc + HP_BUCKETS - 1) / HP_BUCKETS, HP_BUCKETS * HP_GROUPS, 0, stream>>>(
-        hist_.p, j.fixed ? W1 * P : P, B, NBc, ccnt_.p);
+        hist_.p, j.fixed ? W1 * P : P, B, NBc, ccnt_.p, fe_scan);
     // bin offsets (the task outputs of this scan are scratch)
-    SG_TRY(launch_scan(ccnt_.p, NBc, j.log_L, coff_.p, ntask_[1].p, toff_[1].p, bsum_.p, meta_.p, stream));
+    if (!j.fe) SG_TRY(launch_scan(ccnt_.p, NBc, j.log_L, coff_.p, ntask_[1].p, toff_[1].p, bsum_.p, meta_.p, stream));
     msm_partition<<<dim3(W, P), 1024, (3 * B + SORT_TILE) * sizeof(uint32_t) + SORT_TILE * sizeof(uint16_t), stream>>>(
         dig_.p, (uint32_t)n, chunk, B, shift, hist_.p, coff_.p, j.fixed ? W1 : 0u, j.n_tab, part_entry_.p, part_fine_.p);
     const uint32_t F = 1u << shift, fs_threads = 512;
-    msm_fine_sort<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
-        part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p);
-    SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
+    if (j.fe) {
+      msm_fine_sort_fused<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
+          part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p,
+          FrontEndOut{off_.p, ntask_[0].p, toff_[0].p, tbase_.p, fe_.p, meta_.p, d_hmeta_, j.log_L, NB, NBc, ACC_TICKET});
+    } else {
+      msm_fine_sort<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
+          part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p);
+      SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
+    }
     SG_TRY(hipEventRecord(ev_meta_, stream));
   } else {
     msm_hist<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, 0, hist_.p);
     msm_hist_prefix<<<(NB + HP_BUCKETS - 1) / HP_BUCKETS, HP_BUCKETS * HP_GROUPS, 0, stream>>>(
-        hist_.p, j.fixed ? W1 * P : P, nbw, NB, counts_.p);
+        hist_.p, j.fixed ? W1 * P : P, nbw, NB, counts_.p, FrontEndScan{nullptr, nullptr, nullptr, 0u, 0u});
     SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
     SG_TRY(hipEventRecord(ev_meta_, stream));
     uint32_t log_R = std::min<uint32_t>(cfg_.log_scatter_rounds, c - 1);
@@ -1692,15 +1960,20 @@ hipError_t MsmEngine::enqueue_back_impl() {
   // accumulation launch without the counters; the host reads them (for the merge rounds) while that launch runs
   const uint32_t ntasks_ub = (uint32_t)(std::min<size_t>(NB, j.entries) + (j.entries >> log_L));
   // bucket b owns cur[toff_[lvl][b] .. +ntask_[lvl][b])
-  SG_TRY(partial_[0].reserve(ntasks_ub));
+  // (fused front end: a bucket's task slots start at its coarse bin's base, with gaps at the end of every bin)
+  SG_TRY(partial_[0].reserve(j.fe ? (size_t)NB + (j.entries >> log_L) + 1 : (size_t)ntasks_ub));
   {
     const uint32_t nbins = std::min<uint32_t>(1u << log_L, TASK_BINS - 1) + 1;  // task lengths 0 .. L
     const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
-    SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
     SG_TRY(order_.reserve(ntasks_ub));
-    msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
-    msm_task_scan<<<1, 256, 0, stream>>>(thist_.p, tblk, nbins, meta_.p + ACC_TICKET);
-    msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
+    if (j.fe) {
+      msm_task_scatter_reserve<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, fe_.p + FE_CURSOR, order_.p);
+    } else {
+      SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
+      msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
+      msm_task_scan<<<1, 256, 0, stream>>>(thist_.p, tblk, nbins, meta_.p + ACC_TICKET);
+      msm_task_scatter<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p, order_.p);
+    }
   }
   const uint32_t at = cfg_.acc_threads ? cfg_.acc_threads : 128;  // measured: 128 beats 256 by 5 % at 2^20 (finer-grained tail), 64 loses in fixed mode
   // persistent launch: `waves` per SIMD on every CU (3 fill the register file)
