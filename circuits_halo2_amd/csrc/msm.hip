@@ -526,10 +526,14 @@ __global__ void __launch_bounds__(512) msm_fine_sort(const uint32_t* __restrict_
 // largest bucket, the histogram of task lengths that orders the tasks longest first -- goes through a handful of atomics,
 // and the workgroup that finishes last turns the histogram into the scatter's cursors, hands the totals to the host and
 // resets the counters: msm_scan_sums, msm_scan_write, msm_task_hist and msm_task_scan are gone from the job's chain.
-//   fe words: [0] finished workgroups, [1] tasks, [2] largest count, [FE_HIST + k] tasks of (clamped) length k,
-//             [FE_CURSOR + k] (out) position of the first task of length k in `order` (descending lengths)
+//   fe words: [0] finished workgroups of msm_fine_sort_fused, [3] of msm_hist_prefix, [FE_CURSOR + k] (out) position of the first
+//             task of length k in `order` (descending lengths); and in FE_REPL replicas (workgroup w adds to replica w % FE_REPL:
+//             thousands of workgroups adding to ONE word per length cost a millisecond of serialised atomics):
+//             [FE_TASKS + r] tasks, [FE_MAX + r] largest count, [FE_HIST + r * TASK_BINS + k] tasks of (clamped) length k
 static constexpr uint32_t TASK_BINS_FE = 257;     // = TASK_BINS (defined with the task ordering below)
-static constexpr uint32_t FE_HIST = 8, FE_CURSOR = FE_HIST + TASK_BINS_FE, FE_WORDS = FE_CURSOR + TASK_BINS_FE;
+static constexpr uint32_t FE_REPL = 64;
+static constexpr uint32_t FE_CURSOR = 8, FE_TASKS = FE_CURSOR + TASK_BINS_FE, FE_MAX = FE_TASKS + FE_REPL, FE_HIST = FE_MAX + FE_REPL,
+                          FE_WORDS = FE_HIST + FE_REPL * TASK_BINS_FE;
 struct FrontEndOut {
   uint32_t* off;
   uint32_t* ntask;
@@ -627,12 +631,13 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
       sorted[start + pos] = part_entry[start + i];
     }
   }
-  // the bin's share of the global figures, then: was this the last workgroup?
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr)
-    if (s_th[k]) atomicAdd(o.fe + FE_HIST + k, s_th[k]);
+  // the bin's share of the global figures (into this workgroup's replica), then: was this the last workgroup?
+  const uint32_t repl = blockIdx.x % FE_REPL, nbins = full_bin + 1;
+  for (uint32_t k = tid; k < nbins; k += nthr)
+    if (s_th[k]) atomicAdd(o.fe + FE_HIST + repl * TASK_BINS_FE + k, s_th[k]);
   if (tid == 0) {
-    if (s_red[0]) atomicAdd(o.fe + 1, s_red[0]);
-    if (s_red[1]) atomicMax(o.fe + 2, s_red[1]);
+    if (s_red[0]) atomicAdd(o.fe + FE_TASKS + repl, s_red[0]);
+    if (s_red[1]) atomicMax(o.fe + FE_MAX + repl, s_red[1]);
   }
   __threadfence();                       // every lane's atomics are performed device-wide before the workgroup counts as done
   __syncthreads();
@@ -640,9 +645,26 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  // the last workgroup: cursors of the task order (descending lengths), totals out, counters back to zero
+  // the last workgroup: the replicas summed (and zeroed for the next job), cursors of the task order (descending lengths), totals out
   volatile uint32_t* vf = o.fe;
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = vf[FE_HIST + k];
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) {
+    uint32_t sum = 0;
+    if (k < nbins)
+      for (uint32_t r = 0; r < FE_REPL; r++) {
+        sum += vf[FE_HIST + r * TASK_BINS_FE + k];
+        vf[FE_HIST + r * TASK_BINS_FE + k] = 0;
+      }
+    s_th[k] = sum;
+  }
+  if (tid < 2) s_red[tid] = 0;
+  __syncthreads();
+  if (tid < FE_REPL) {
+    const uint32_t tk = vf[FE_TASKS + tid], mxr = vf[FE_MAX + tid];
+    vf[FE_TASKS + tid] = 0;
+    vf[FE_MAX + tid] = 0;
+    if (tk) atomicAdd(&s_red[0], tk);
+    if (mxr) atomicMax(&s_red[1], mxr);
+  }
   __syncthreads();
   if (tid == 0) {
     uint32_t pos = 0;
@@ -651,7 +673,7 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
       s_th[k] = pos;
       pos += v;
     }
-    const uint32_t entries = coff[o.NBc], tasks = vf[1], largest = vf[2];
+    const uint32_t entries = coff[o.NBc], tasks = s_red[0], largest = s_red[1];
     o.off[o.NB] = entries;
     o.toff[o.NB] = o.tbase[o.NBc];
     o.meta[0] = entries;
@@ -664,13 +686,10 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
       o.host_meta[2] = largest;
       __threadfence_system();
     }
-    vf[0] = 0; vf[1] = 0; vf[2] = 0;
+    vf[0] = 0;
   }
   __syncthreads();
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) {
-    o.fe[FE_CURSOR + k] = s_th[k];
-    o.fe[FE_HIST + k] = 0;
-  }
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) o.fe[FE_CURSOR + k] = s_th[k];
 }
 
 // ------------------------------------------------------------------ 4: accumulate / merge

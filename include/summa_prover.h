@@ -32,6 +32,15 @@ extern "C" {
  * What may vary without touching the library, because it arrives as DATA: k; the contents of every fixed / permutation column
  * (LEVELS, N_BYTES, the floor plan); the gate program and the lookup's input expression (N_CURRENCIES changes the number of sum
  * gates: any program over these columns with rotations in {-1, 0, 1} is accepted); the verifying key's digest.
+ * Said once more, parameter by parameter of `MstInclusionCircuit<LEVELS, N_CURRENCIES, N_BYTES>`:
+ *   LEVELS        data.  It only moves rows of the floor plan (fixed / permutation column contents) and the minimal k.
+ *   N_BYTES       data.  The range check decomposes into N_BYTES lookups of ONE 8-bit table: more used rows, the same 256-entry
+ *                 table column (a range table: the device-side lookup permutation applies; a table with values >= 2^16 would take
+ *                 the host sort, as upstream does).
+ *   N_CURRENCIES  data, with a fast path: it changes the gate program (one sum gate and one Poseidon input per currency) and the
+ *                 number of instances.  Any count proves through the gate interpreter; for 1 .. 4 the library holds the lowered
+ *                 programs as straight-line kernels (csrc/gates_mst_programs.inc) and the quotient numerator runs as ONE pass
+ *                 (sg_quotient_numerator_cosets_dev) -- same proof bytes, fewer launches.
  * What would break it (a change of `ConstraintSystem` that needs the C++ driver in include/summa_prover.hpp rebuilt, not data):
  * another number of advice / fixed / permutation columns (SP_NUM_* below are compile-time), a second lookup or a lookup with
  * several input expressions (theta would have to be squeezed BEFORE the permuted columns are committed: the driver commits them

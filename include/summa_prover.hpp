@@ -980,7 +980,10 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     const void* cols[3] = {advice[0].p, advice[1].p, advice[2].p};
     ck(sg_fr_flag_noncanonical_dev(cols, 3, n, status_dev, main_stream()), "range check of the advice columns");
   }
-  rand_rows({{&advice[0], u, n - u}, {&advice[1], u, n - u}, {&advice[2], u, n - u}});
+  // blinding rows of the three advice columns AND of the two permuted lookup columns (draws 1 .. 5, in upstream's order) in one
+  // launch: the permutation kernels below write rows below `u` only
+  DevCol pin(n), ptab(n);
+  rand_rows({{&advice[0], u, n - u}, {&advice[1], u, n - u}, {&advice[2], u, n - u}, {&pin, u, n - u}, {&ptab, u, n - u}});
   DevCol instance_col(n);
   if (instances.size() <= 8) {   // the column = its few values then zeros: one launch, the values travel as kernel arguments
     ck(sg_fr_lincomb_low_dev(nullptr, nullptr, 0, n, instances.empty() ? nullptr : instances[0].bytes(), (uint32_t)instances.size(),
@@ -1015,7 +1018,6 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   DevCol inp(n);   // (not cleared: the input program writes every row and reads no previous value)
   ck(sg_quotient_gates_dev(inp.p, &g_in, fixed_lag_p.data(), NUM_FIXED, adv_lag_p.data(), NUM_ADVICE, inst_lag_p.data(), 1, nullptr, 0,
                            zero.bytes(), zero.bytes(), zero.bytes(), zero.bytes(), k, k, main_stream()), "lookup input");
-  DevCol pin(n), ptab(n);
   // range tables (a property of the key): on the device, nothing waited for -- the verdict lands in status[1]
   const int prc = pk.table_is_range ? sg_lookup_permute_small_async_dev(inp.p, pk.fixed_lag[4].p, u, pin.p, ptab.p, status_dev + 4, main_stream())
                                     : SG_ERR_UNSUPPORTED;
@@ -1035,7 +1037,6 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   } else {
     ck(prc, "lookup permutation");
   }
-  rand_rows({{&pin, u, n - u}, {&ptab, u, n - u}});
   // sorted columns: long constant runs -> difference form (sg_commit, basis 2)
   mark("1: lookup columns ready, commit [a0 a1 a2 a' s'] issued");
   // (the random polynomial rides along: see where it is drawn)
