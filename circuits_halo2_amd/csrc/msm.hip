@@ -167,26 +167,34 @@ __global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hi
       col[(size_t)p * nbw] = run;
       run += v;
     }
-    if (gy == HP_GROUPS - 1) counts[g] = run;
+    if (gy == HP_GROUPS - 1) {
+      if (fe.done) {   // a returning exchange: performed at the memory side once the value is back (no release fence needed below)
+        const uint32_t was = atomicExch(&counts[g], run);
+        asm volatile("" ::"v"(was));
+      } else {
+        counts[g] = run;
+      }
+    }
   }
   if (!fe.done) return;
   __syncthreads();                       // (every thread of the workgroup reaches this: the early return above is gone)
-  if (threadIdx.x == 0) {
-    __threadfence();                     // this workgroup's totals are visible device-wide before it counts as done
-    s_last = atomicAdd(fe.done, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
+  if (threadIdx.x == 0) s_last = atomicAdd(fe.done, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  // the last workgroup: exclusive scans over the NB <= 4096 bin totals, 16 per thread
+  // the last workgroup: exclusive scans over the NB <= 4096 bin totals, 16 per thread (atomic reads of what the other
+  // workgroups' exchanges left)
   __shared__ uint32_t s_a[256], s_t[256];
   const uint32_t tid = threadIdx.x, per_t = (NB + 255) / 256, b0 = min(tid * per_t, NB), b1 = min(b0 + per_t, NB);
-  const volatile uint32_t* vc = counts;  // written by other workgroups of this launch
+  uint32_t vals[FE_MAX_BINS / 256];
   uint32_t a = 0, t = 0;
-  for (uint32_t q = b0; q < b1; q++) {
-    const uint32_t v = vc[q];
-    a += v;
-    t += fe.F + (v >> fe.log_L);
+#pragma unroll
+  for (uint32_t q = 0; q < FE_MAX_BINS / 256; q++) vals[q] = (b0 + q < b1) ? atomicAdd(&counts[b0 + q], 0u) : 0u;   // all in flight together
+#pragma unroll
+  for (uint32_t q = 0; q < FE_MAX_BINS / 256; q++) {
+    if (b0 + q < b1) {
+      a += vals[q];
+      t += fe.F + (vals[q] >> fe.log_L);
+    }
   }
   s_a[tid] = a; s_t[tid] = t;
   __syncthreads();
@@ -198,17 +206,19 @@ __global__ void __launch_bounds__(256) msm_hist_prefix(uint32_t* __restrict__ hi
     __syncthreads();
   }
   uint32_t ra = s_a[tid] - a, rt = s_t[tid] - t;
-  for (uint32_t q = b0; q < b1; q++) {
-    const uint32_t v = vc[q];
-    fe.coff[q] = ra;
-    fe.tbase[q] = rt;
-    ra += v;
-    rt += fe.F + (v >> fe.log_L);
+#pragma unroll
+  for (uint32_t q = 0; q < FE_MAX_BINS / 256; q++) {
+    if (b0 + q < b1) {
+      fe.coff[b0 + q] = ra;
+      fe.tbase[b0 + q] = rt;
+      ra += vals[q];
+      rt += fe.F + (vals[q] >> fe.log_L);
+    }
   }
   if (tid == 255) {
     fe.coff[NB] = s_a[255];
     fe.tbase[NB] = s_t[255];
-    *fe.done = 0;                        // ready for the next launch on this stream
+    atomicExch(fe.done, 0u);             // ready for the next launch on this stream
   }
 }
 
@@ -632,36 +642,34 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
     }
   }
   // the bin's share of the global figures (into this workgroup's replica), then: was this the last workgroup?
+  // RETURNING atomics: the value is back when the operation has been performed at the memory side, so waiting for the returns
+  // orders them before the arrival count below WITHOUT a release fence -- a fence here writes back the L2 of the XCD, and this
+  // kernel has just filled it with sorted entries: one write-back per workgroup cost a millisecond (profiles/r05_sweeps/frontend_fence.txt)
   const uint32_t repl = blockIdx.x % FE_REPL, nbins = full_bin + 1;
+  uint32_t sink = 0;
   for (uint32_t k = tid; k < nbins; k += nthr)
-    if (s_th[k]) atomicAdd(o.fe + FE_HIST + repl * TASK_BINS_FE + k, s_th[k]);
+    if (s_th[k]) sink += atomicAdd(o.fe + FE_HIST + repl * TASK_BINS_FE + k, s_th[k]);
   if (tid == 0) {
-    if (s_red[0]) atomicAdd(o.fe + FE_TASKS + repl, s_red[0]);
-    if (s_red[1]) atomicMax(o.fe + FE_MAX + repl, s_red[1]);
+    if (s_red[0]) sink += atomicAdd(o.fe + FE_TASKS + repl, s_red[0]);
+    if (s_red[1]) sink += atomicMax(o.fe + FE_MAX + repl, s_red[1]);
   }
-  __threadfence();                       // every lane's atomics are performed device-wide before the workgroup counts as done
+  asm volatile("" ::"v"(sink));          // (the returns are consumed: the wait for them cannot be dropped)
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(o.fe, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  // the last workgroup: the replicas summed (and zeroed for the next job), cursors of the task order (descending lengths), totals out
-  volatile uint32_t* vf = o.fe;
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) {
-    uint32_t sum = 0;
-    if (k < nbins)
-      for (uint32_t r = 0; r < FE_REPL; r++) {
-        sum += vf[FE_HIST + r * TASK_BINS_FE + k];
-        vf[FE_HIST + r * TASK_BINS_FE + k] = 0;
-      }
-    s_th[k] = sum;
-  }
+  // the last workgroup: the replicas summed and zeroed for the next job (atomic exchanges: coherent reads of what the other
+  // workgroups' atomics left), cursors of the task order (descending lengths), totals out
+  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = 0;
   if (tid < 2) s_red[tid] = 0;
   __syncthreads();
+  for (uint32_t idx = tid; idx < nbins * FE_REPL; idx += nthr) {
+    const uint32_t k = idx % nbins, r = idx / nbins;
+    const uint32_t v = atomicExch(o.fe + FE_HIST + r * TASK_BINS_FE + k, 0u);
+    if (v) atomicAdd(&s_th[k], v);
+  }
   if (tid < FE_REPL) {
-    const uint32_t tk = vf[FE_TASKS + tid], mxr = vf[FE_MAX + tid];
-    vf[FE_TASKS + tid] = 0;
-    vf[FE_MAX + tid] = 0;
+    const uint32_t tk = atomicExch(o.fe + FE_TASKS + tid, 0u), mxr = atomicExch(o.fe + FE_MAX + tid, 0u);
     if (tk) atomicAdd(&s_red[0], tk);
     if (mxr) atomicMax(&s_red[1], mxr);
   }
@@ -686,7 +694,7 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
       o.host_meta[2] = largest;
       __threadfence_system();
     }
-    vf[0] = 0;
+    atomicExch(o.fe, 0u);
   }
   __syncthreads();
   for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) o.fe[FE_CURSOR + k] = s_th[k];

@@ -40,29 +40,34 @@ __device__ __forceinline__ void eval_poly_block(const fp_words* __restrict__ c, 
   const uint32_t tid = threadIdx.x;
   f29 x = f29_words_to_r261<P>(xw.l);
   for (uint32_t k = 0; k < log_stride; k++) x = f29_sqr<P>(x);   // x^(2^log_stride)
-  const uint32_t first = (blockIdx.x * EV_THREADS + tid) * EV_CH;
-  f29 acc = f29_zero();
-  if (first < n) {
-    uint32_t last = min(n, first + EV_CH);
-    acc = f29_load_r256<P>(c + last - 1);               // any 256-bit word value: bound < 6
-    for (uint32_t i = last - 1; i-- > first;)
-      acc = f29_mul_add<P>(acc, x, f29_load_r256<P>(c + i));   // acc x + c_i in one chain: < 8 * 2 / 170 + 1 + 6 < 8
-  }
-#pragma unroll
-  for (int q = 0; q < 9; q++) sh[tid][q] = acc.l[q];
-  __syncthreads();
-  // pairwise fold with x^(CH * 2^l) at level l.  The eight powers are computed once per workgroup (lane l squares its way up:
-  // every lane doing all eight squarings was more work than the fold itself) and the sums stay lazy: the bound grows by 2 per
-  // level (< 8 + 16 after eight), well inside what the next product takes, so only the last value is reduced.
-  __shared__ uint32_t s_xp[8][9];
-  if (tid < 8) {
+  // Round 5: a workgroup's EV_CH * 256 coefficients are read COALESCED -- thread t takes the elements t, t + 256, t + 512, ...
+  // of the block and runs Horner in y = x^256 over them; the fold below then pairs neighbours with x, x^2, x^4, ... x^128.
+  // (Sixteen CONSECUTIVE coefficients per thread made every load instruction touch 64 different 512-byte-strided sectors: 42 % VALU
+  // busy at a fifth of the memory rate, profiles/r05a_proof_budget.json.)  The powers x^(2^l), l = 0 .. 8, come from nine lanes.
+  __shared__ uint32_t s_xp[9][9];
+  if (tid < 9) {
     f29 xp = x;
-    for (uint32_t k = 1; k < EV_CH; k <<= 1) xp = f29_sqr<P>(xp);
     for (uint32_t l = 0; l < tid; l++) xp = f29_sqr<P>(xp);
 #pragma unroll
     for (int q = 0; q < 9; q++) s_xp[tid][q] = xp.l[q];
   }
   __syncthreads();
+  f29 y;
+#pragma unroll
+  for (int q = 0; q < 9; q++) y.l[q] = s_xp[8][q];
+  const uint32_t base = blockIdx.x * EV_THREADS * EV_CH + tid;
+  f29 acc = f29_zero();
+  if (base < n) {
+    // the highest element of this thread's column that exists, then down in steps of 256
+    uint32_t j = min(EV_CH - 1, (n - 1 - base) / EV_THREADS);
+    acc = f29_load_r256<P>(c + base + j * EV_THREADS);               // any 256-bit word value: bound < 6
+    while (j-- > 0) acc = f29_mul_add<P>(acc, y, f29_load_r256<P>(c + base + j * EV_THREADS));   // acc y + c_i in one chain: < 8 * 2 / 170 + 1 + 6 < 8
+  }
+#pragma unroll
+  for (int q = 0; q < 9; q++) sh[tid][q] = acc.l[q];
+  __syncthreads();
+  // pairwise fold with x^(2^l) at level l; the sums stay lazy: the bound grows by 2 per level (< 8 + 16 after eight), well inside
+  // what the next product takes, so only the last value is reduced.
   uint32_t level = 0;
   for (uint32_t s = 1; s < EV_THREADS; s <<= 1, level++) {
     if ((tid & (2 * s - 1)) == 0) {
