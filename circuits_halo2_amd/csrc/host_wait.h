@@ -19,31 +19,43 @@ inline std::atomic<int>& host_wait_sleep_us() {
   static std::atomic<int> v{0};
   return v;
 }
-inline void host_wait_nap(int us) {
-  static thread_local bool slack_set = false;
-  if (!slack_set) {   // the default timer slack of 50 us would be added to every nap
-    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
-    slack_set = true;
+// The naps want a timer slack of 1 us (the default of 50 us would be added to every one of them).  The waiting threads are the
+// CALLER'S -- halo2's / rayon's workers calling through the shim -- so the slack is the caller's property: it is lowered for the
+// length of ONE wait and put back before the wait returns (two prctl calls per wait that naps at all, none for a wait that
+// finds its event complete).
+struct HostNapSlack {
+  long saved = -1;
+  void nap(int us) {
+    if (saved < 0) {
+      saved = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+      if (saved < 0) saved = 0;      // (0 = "the thread's default" when it is written back)
+      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    }
+    struct timespec ts = {0, (long)us * 1000L};
+    (void)nanosleep(&ts, nullptr);
   }
-  struct timespec ts = {0, (long)us * 1000L};
-  (void)nanosleep(&ts, nullptr);
-}
+  ~HostNapSlack() {
+    if (saved >= 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)saved, 0UL, 0UL, 0UL);
+  }
+};
 inline hipError_t host_wait_event(hipEvent_t e) {
   const int us = host_wait_sleep_us().load(std::memory_order_relaxed);
   if (us <= 0) return hipEventSynchronize(e);
+  HostNapSlack slack;
   for (;;) {
     const hipError_t q = hipEventQuery(e);
     if (q != hipErrorNotReady) return q;
-    host_wait_nap(us);
+    slack.nap(us);
   }
 }
 inline hipError_t host_wait_stream(hipStream_t s) {
   const int us = host_wait_sleep_us().load(std::memory_order_relaxed);
   if (us <= 0) return hipStreamSynchronize(s);
+  HostNapSlack slack;
   for (;;) {
     const hipError_t q = hipStreamQuery(s);
     if (q != hipErrorNotReady) return q;
-    host_wait_nap(us);
+    slack.nap(us);
   }
 }
 

@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
   __syncthreads();
   if (tid == 0) {
     uint32_t pos = 0;
-    for (int k = (int)TASK_BINS_FE - 1; k >= 0; k--) {   // 257 serial steps on one lane: ~1 us
+    for (int k = (int)nbins - 1; k >= 0; k--) {   // the lengths in use only (L + 1 <= 65 as a rule): a dependent LDS chain on one lane
       const uint32_t v = s_th[k];
       s_th[k] = pos;
       pos += v;
