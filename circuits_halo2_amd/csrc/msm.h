@@ -149,6 +149,7 @@ class MsmEngine {
     uint8_t* out = nullptr;
     MsmTimings* tm = nullptr;
     bool trivial = false, all_zero = false, fixed = false, fe = false;
+    uint32_t fe_parity = 0, NBc = 0;   // fused front end: which replica set of fe_ this job uses; coarse bins of the job
     uint32_t red2d = 0;  // 0: scan-based reduction, 1: 2-D with host weights, 2: 2-D with device weights
     uint32_t n_tab = 0;
     uint32_t c = 0, nbw = 0, NB = 0, log_L = 0, log_G = 0, log_N = 0, blocks = 0, ntasks = 0, max_cnt = 0, acc_threads = 0;
@@ -158,6 +159,7 @@ class MsmEngine {
   Job job_;
   const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs
   uint64_t diff_mask_ = 0;             // likewise
+  uint32_t fe_parity_ = 0;             // fused front end: replica set of the most recent job (alternates)
   hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
   hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;

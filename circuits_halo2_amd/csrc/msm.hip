@@ -533,26 +533,28 @@ __global__ void __launch_bounds__(512) msm_fine_sort(const uint32_t* __restrict_
 // (tbase) are known from the coarse scan, so everything the bucket-level scans produced is local to it: off[b] = start +
 // exclusive count prefix, ntask[b] = ceil(c / L), toff[b] = tbase + exclusive task prefix (the task index space has gaps at
 // the end of every bin: consumers only ever index partial[toff[b] + seg]).  What is global -- the number of tasks, the
-// largest bucket, the histogram of task lengths that orders the tasks longest first -- goes through a handful of atomics,
-// and the workgroup that finishes last turns the histogram into the scatter's cursors, hands the totals to the host and
-// resets the counters: msm_scan_sums, msm_scan_write, msm_task_hist and msm_task_scan are gone from the job's chain.
-//   fe words: [0] finished workgroups of msm_fine_sort_fused, [3] of msm_hist_prefix, [FE_CURSOR + k] (out) position of the first
-//             task of length k in `order` (descending lengths); and in FE_REPL replicas (workgroup w adds to replica w % FE_REPL:
-//             thousands of workgroups adding to ONE word per length cost a millisecond of serialised atomics):
-//             [FE_TASKS + r] tasks, [FE_MAX + r] largest count, [FE_HIST + r * TASK_BINS + k] tasks of (clamped) length k
+// largest bucket, the histogram of task lengths that orders the tasks longest first -- leaves the workgroup as fire-and-forget
+// atomics into one of FE_REPL replicas (thousands of workgroups adding to ONE word per length cost a millisecond of serialised
+// atomics) and is summed by the NEXT kernel of the job (msm_task_scatter_reserve), where the kernel boundary has made it
+// complete: no workgroup waits for a return value or for another workgroup, and there is no release fence -- in this kernel a
+// fence writes back an L2 that has just been filled with sorted entries, once per workgroup: a millisecond
+// (profiles/r05_sweeps/frontend.txt has all three measurements).  msm_scan_sums, msm_scan_write, msm_task_hist and msm_task_scan
+// are gone from the job's chain.
+//   fe words: [3] finished workgroups of msm_hist_prefix, [FE_CURSOR + k] the scatter's running position inside the tasks of
+//   length k (zero at its start), and two SETS of replicas, used by alternate jobs of the engine (a job's sort zeroes the other
+//   set for the next job): per replica r of set p at FE_SET + p * FE_SET_WORDS + r * FE_ROW: [0] tasks, [1] largest count,
+//   [2 + k] tasks of (clamped) length k
 static constexpr uint32_t TASK_BINS_FE = 257;     // = TASK_BINS (defined with the task ordering below)
 static constexpr uint32_t FE_REPL = 64;
-static constexpr uint32_t FE_CURSOR = 8, FE_TASKS = FE_CURSOR + TASK_BINS_FE, FE_MAX = FE_TASKS + FE_REPL, FE_HIST = FE_MAX + FE_REPL,
-                          FE_WORDS = FE_HIST + FE_REPL * TASK_BINS_FE;
+static constexpr uint32_t FE_CURSOR = 8, FE_ROW = TASK_BINS_FE + 2, FE_SET_WORDS = FE_REPL * FE_ROW, FE_SET = FE_CURSOR + TASK_BINS_FE,
+                          FE_WORDS = FE_SET + 2 * FE_SET_WORDS;
 struct FrontEndOut {
   uint32_t* off;
   uint32_t* ntask;
   uint32_t* toff;
   const uint32_t* tbase;
   uint32_t* fe;
-  uint32_t* meta;                 // [0] entries, [1] tasks, [2] largest count; [ticket_word] <- 0
-  volatile uint32_t* host_meta;   // the same three for the host (mapped page-locked memory)
-  uint32_t log_L, NB, NBc, ticket_word;
+  uint32_t log_L, parity;
 };
 __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __restrict__ part_entry,
                                                            const uint16_t* __restrict__ part_fine,
@@ -564,7 +566,6 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
   extern __shared__ uint32_t s_mem[];
   __shared__ uint32_t s_th[TASK_BINS_FE];
   __shared__ uint32_t s_red[2];   // tasks of the bin, largest count
-  __shared__ uint32_t s_last;
   const uint32_t F = 1u << shift, tid = threadIdx.x, nthr = blockDim.x;
   uint32_t* s_cnt = s_mem;        // [F] counts, then cursors
   uint32_t* s_ofs = s_cnt + F;    // [F] exclusive offsets
@@ -573,13 +574,23 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
   const uint32_t start = coff[blockIdx.x], E = ccnt[blockIdx.x];
   const uint32_t set = blockIdx.x / B, bin = blockIdx.x - set * B;
   const uint32_t Lm1 = (1u << o.log_L) - 1, full_bin = min(1u << o.log_L, TASK_BINS_FE - 1);
+  // housekeeping for the jobs to come: the other replica set and the scatter's cursors back to zero (whoever used them last
+  // has finished: same stream)
+  {
+    uint32_t* other = o.fe + FE_SET + (o.parity ^ 1u) * FE_SET_WORDS;
+    for (uint32_t row = blockIdx.x; row < FE_REPL; row += gridDim.x)
+      for (uint32_t k = tid; k < FE_ROW; k += nthr) other[row * FE_ROW + k] = 0;
+    if (blockIdx.x == 0)
+      for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) o.fe[FE_CURSOR + k] = 0;
+  }
   for (uint32_t f = tid; f < F; f += nthr) s_cnt[f] = 0;
   for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = 0;
   if (tid < 2) s_red[tid] = 0;
   __syncthreads();
   for (uint32_t i = tid; i < E; i += nthr) atomicAdd(&s_cnt[part_fine[start + i] & (F - 1)], 1u);
   __syncthreads();
-  // exclusive scans over F (entries and tasks): contiguous share per thread + Hillis-Steele over the shares
+  // exclusive scans over F (entries and tasks): contiguous share per thread + ONE Hillis-Steele over the shares, the two sums
+  // packed in a 64-bit word
   const uint32_t per = (F + nthr - 1) / nthr, f0 = min(tid * per, F), f1 = min(f0 + per, F);
   uint32_t a = 0, t = 0, mx = 0;
   for (uint32_t f = f0; f < f1; f++) {
@@ -592,25 +603,17 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
     if (nfull) atomicAdd(&s_th[full_bin], nfull);
     if (rem) atomicAdd(&s_th[min(rem, TASK_BINS_FE - 1)], 1u);
   }
-  s_part[tid] = a;
+  uint64_t* s_part64 = reinterpret_cast<uint64_t*>(s_part);   // [nthr] 64-bit: the scratch area is followed by s_out, which is not in use yet
+  s_part64[tid] = ((uint64_t)t << 32) | a;
   __syncthreads();
   for (uint32_t dd = 1; dd < nthr; dd <<= 1) {
-    uint32_t u = tid >= dd ? s_part[tid - dd] : 0;
+    uint64_t u = tid >= dd ? s_part64[tid - dd] : 0;
     __syncthreads();
-    s_part[tid] += u;
-    __syncthreads();
-  }
-  uint32_t run = s_part[tid] - a;
-  __syncthreads();
-  s_part[tid] = t;
-  __syncthreads();
-  for (uint32_t dd = 1; dd < nthr; dd <<= 1) {
-    uint32_t u = tid >= dd ? s_part[tid - dd] : 0;
-    __syncthreads();
-    s_part[tid] += u;
+    s_part64[tid] += u;
     __syncthreads();
   }
-  uint32_t trun = o.tbase[blockIdx.x] + s_part[tid] - t;
+  uint32_t run = (uint32_t)s_part64[tid] - a;
+  uint32_t trun = o.tbase[blockIdx.x] + (uint32_t)(s_part64[tid] >> 32) - t;
   if (t) atomicAdd(&s_red[0], t);
   if (mx) atomicMax(&s_red[1], mx);
   const size_t b_first = (size_t)set * nbw + (size_t)bin * F;
@@ -626,6 +629,16 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
     trun += nt;
   }
   __syncthreads();
+  // the bin's share of the global figures: fire and forget
+  {
+    uint32_t* mine = o.fe + FE_SET + o.parity * FE_SET_WORDS + (blockIdx.x % FE_REPL) * FE_ROW;
+    for (uint32_t k = tid; k <= full_bin; k += nthr)
+      if (s_th[k]) atomicAdd(mine + 2 + k, s_th[k]);
+    if (tid == 0) {
+      if (s_red[0]) atomicAdd(mine, s_red[0]);
+      if (s_red[1]) atomicMax(mine + 1, s_red[1]);
+    }
+  }
   for (uint32_t f = tid; f < F; f += nthr) s_cnt[f] = s_ofs[f];   // cursors
   __syncthreads();
   if (E <= SORT_TILE) {
@@ -641,63 +654,6 @@ __global__ void __launch_bounds__(512) msm_fine_sort_fused(const uint32_t* __res
       sorted[start + pos] = part_entry[start + i];
     }
   }
-  // the bin's share of the global figures (into this workgroup's replica), then: was this the last workgroup?
-  // RETURNING atomics: the value is back when the operation has been performed at the memory side, so waiting for the returns
-  // orders them before the arrival count below WITHOUT a release fence -- a fence here writes back the L2 of the XCD, and this
-  // kernel has just filled it with sorted entries: one write-back per workgroup cost a millisecond (profiles/r05_sweeps/frontend_fence.txt)
-  const uint32_t repl = blockIdx.x % FE_REPL, nbins = full_bin + 1;
-  uint32_t sink = 0;
-  for (uint32_t k = tid; k < nbins; k += nthr)
-    if (s_th[k]) sink += atomicAdd(o.fe + FE_HIST + repl * TASK_BINS_FE + k, s_th[k]);
-  if (tid == 0) {
-    if (s_red[0]) sink += atomicAdd(o.fe + FE_TASKS + repl, s_red[0]);
-    if (s_red[1]) sink += atomicMax(o.fe + FE_MAX + repl, s_red[1]);
-  }
-  asm volatile("" ::"v"(sink));          // (the returns are consumed: the wait for them cannot be dropped)
-  __syncthreads();
-  if (tid == 0) s_last = atomicAdd(o.fe, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  // the last workgroup: the replicas summed and zeroed for the next job (atomic exchanges: coherent reads of what the other
-  // workgroups' atomics left), cursors of the task order (descending lengths), totals out
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) s_th[k] = 0;
-  if (tid < 2) s_red[tid] = 0;
-  __syncthreads();
-  for (uint32_t idx = tid; idx < nbins * FE_REPL; idx += nthr) {
-    const uint32_t k = idx % nbins, r = idx / nbins;
-    const uint32_t v = atomicExch(o.fe + FE_HIST + r * TASK_BINS_FE + k, 0u);
-    if (v) atomicAdd(&s_th[k], v);
-  }
-  if (tid < FE_REPL) {
-    const uint32_t tk = atomicExch(o.fe + FE_TASKS + tid, 0u), mxr = atomicExch(o.fe + FE_MAX + tid, 0u);
-    if (tk) atomicAdd(&s_red[0], tk);
-    if (mxr) atomicMax(&s_red[1], mxr);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t pos = 0;
-    for (int k = (int)nbins - 1; k >= 0; k--) {   // the lengths in use only (L + 1 <= 65 as a rule): a dependent LDS chain on one lane
-      const uint32_t v = s_th[k];
-      s_th[k] = pos;
-      pos += v;
-    }
-    const uint32_t entries = coff[o.NBc], tasks = s_red[0], largest = s_red[1];
-    o.off[o.NB] = entries;
-    o.toff[o.NB] = o.tbase[o.NBc];
-    o.meta[0] = entries;
-    o.meta[1] = tasks;
-    o.meta[2] = largest;
-    o.meta[o.ticket_word] = 0;          // msm_accumulate's task counter (next launch on this stream)
-    if (o.host_meta) {
-      o.host_meta[0] = entries;
-      o.host_meta[1] = tasks;
-      o.host_meta[2] = largest;
-      __threadfence_system();
-    }
-    atomicExch(o.fe, 0u);
-  }
-  __syncthreads();
-  for (uint32_t k = tid; k < TASK_BINS_FE; k += nthr) o.fe[FE_CURSOR + k] = s_th[k];
 }
 
 // ------------------------------------------------------------------ 4: accumulate / merge
@@ -814,19 +770,44 @@ __global__ void __launch_bounds__(256) msm_task_scatter(const uint32_t* __restri
   }
 }
 
-// the same after msm_fine_sort_fused: the workgroup counts its tasks per length, reserves their positions in `order` with one
-// atomic per length on the cursors the front end left (fe + FE_CURSOR), then places them -- msm_task_hist and msm_task_scan
-// are not needed.  (Tasks of one length come in the order the reservations happen to be served: which lane runs which task is
-// free, the sums are the same.)
+// the same after msm_fine_sort_fused: every workgroup first sums the replicas of the task-length histogram the sort left (the
+// kernel boundary made them complete) into the positions at which each length starts in `order` (descending lengths), counts
+// its own tasks per length, reserves their positions with one atomic per length on the running cursors, and places them --
+// msm_task_hist and msm_task_scan are not needed.  Workgroup 0 also hands the job's totals to the accumulation and to the host.
+// (Tasks of one length come in the order the reservations happen to be served: which lane runs which task is free, the sums
+// are the same.)
+struct FrontEndTotals {
+  uint32_t* fe;
+  const uint32_t* coff;           // [NBc]: entries of the job
+  const uint32_t* tbase;          // [NBc]: task slots of the job
+  uint32_t* off;                  // off[NB] <- entries
+  uint32_t* toff;                 // toff[NB] <- task slots
+  uint32_t* meta;                 // [0] entries, [1] tasks, [2] largest count; [ticket_word] <- 0
+  volatile uint32_t* host_meta;   // the same three for the host (mapped page-locked memory)
+  uint32_t NBc, parity, ticket_word;
+};
 __global__ void __launch_bounds__(256) msm_task_scatter_reserve(const uint32_t* __restrict__ cnt, uint32_t NB,
-                                                                uint32_t log_L, uint32_t task_block,
-                                                                uint32_t* __restrict__ cursor, uint2* __restrict__ order) {
+                                                                uint32_t log_L, uint32_t task_block, FrontEndTotals ft,
+                                                                uint2* __restrict__ order) {
   side_kernel_prio();
-  __shared__ uint32_t s_c[TASK_BINS];
-  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) s_c[k] = 0;
+  __shared__ uint32_t s_c[TASK_BINS], s_tot[TASK_BINS], s_red[2];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1), nbins = full_bin + 1;
+  const uint32_t* set = ft.fe + FE_SET + ft.parity * FE_SET_WORDS;
+  for (uint32_t k = tid; k < TASK_BINS; k += blockDim.x) { s_c[k] = 0; s_tot[k] = 0; }
+  if (tid < 2) s_red[tid] = 0;
   __syncthreads();
-  const uint32_t full_bin = min(1u << log_L, TASK_BINS - 1);
-  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+  for (uint32_t idx = tid; idx < nbins * FE_REPL; idx += blockDim.x) {
+    const uint32_t k = idx % nbins, r = idx / nbins;
+    const uint32_t v = set[r * FE_ROW + 2 + k];
+    if (v) atomicAdd(&s_tot[k], v);
+  }
+  if (blockIdx.x == 0 && tid < FE_REPL) {
+    const uint32_t tk = set[tid * FE_ROW], mxr = set[tid * FE_ROW + 1];
+    if (tk) atomicAdd(&s_red[0], tk);
+    if (mxr) atomicMax(&s_red[1], mxr);
+  }
+  for (uint32_t q = tid; q < task_block; q += blockDim.x) {
     uint32_t b = blockIdx.x * task_block + q;
     if (b < NB) {
       uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
@@ -835,12 +816,30 @@ __global__ void __launch_bounds__(256) msm_task_scatter_reserve(const uint32_t* 
     }
   }
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < TASK_BINS; k += blockDim.x) {
+  if (blockIdx.x == 0 && tid == 0) {
+    const uint32_t entries = ft.coff[ft.NBc], tasks = s_red[0], largest = s_red[1];
+    ft.off[NB] = entries;
+    ft.toff[NB] = ft.tbase[ft.NBc];
+    ft.meta[0] = entries;
+    ft.meta[1] = tasks;
+    ft.meta[2] = largest;
+    ft.meta[ft.ticket_word] = 0;          // msm_accumulate's task counter (the next launch on this stream)
+    if (ft.host_meta) {
+      ft.host_meta[0] = entries;
+      ft.host_meta[1] = tasks;
+      ft.host_meta[2] = largest;
+      __threadfence_system();
+    }
+  }
+  // position of this workgroup's tasks of length k: every longer task first, then what other workgroups reserved before
+  for (uint32_t k = tid; k < nbins; k += blockDim.x) {
+    uint32_t base = 0;
+    for (uint32_t k2 = k + 1; k2 < nbins; k2++) base += s_tot[k2];
     const uint32_t mine = s_c[k];
-    s_c[k] = mine ? atomicAdd(cursor + k, mine) : 0u;
+    s_c[k] = base + (mine ? atomicAdd(ft.fe + FE_CURSOR + k, mine) : 0u);
   }
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < task_block; q += blockDim.x) {
+  for (uint32_t q = tid; q < task_block; q += blockDim.x) {
     uint32_t b = blockIdx.x * task_block + q;
     if (b < NB) {
       uint32_t cv = cnt[b], nfull = cv >> log_L, rem = cv - (nfull << log_L);
@@ -1931,15 +1930,18 @@ hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars,
         dig_.p, (uint32_t)n, chunk, B, shift, hist_.p, coff_.p, j.fixed ? W1 : 0u, j.n_tab, part_entry_.p, part_fine_.p);
     const uint32_t F = 1u << shift, fs_threads = 512;
     if (j.fe) {
-      msm_fine_sort_fused<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
+      fe_parity_ ^= 1u;
+      j.fe_parity = fe_parity_;
+      j.NBc = NBc;
+      msm_fine_sort_fused<<<NBc, fs_threads, (2 * F + 2 * fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
           part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p,
-          FrontEndOut{off_.p, ntask_[0].p, toff_[0].p, tbase_.p, fe_.p, meta_.p, d_hmeta_, j.log_L, NB, NBc, ACC_TICKET});
+          FrontEndOut{off_.p, ntask_[0].p, toff_[0].p, tbase_.p, fe_.p, j.log_L, j.fe_parity});
     } else {
       msm_fine_sort<<<NBc, fs_threads, (2 * F + fs_threads + SORT_TILE) * sizeof(uint32_t), stream>>>(
           part_entry_.p, part_fine_.p, coff_.p, ccnt_.p, B, shift, nbw, counts_.p, sorted_.p);
       SG_TRY(launch_scan(counts_.p, NB, j.log_L, off_.p, ntask_[0].p, toff_[0].p, bsum_.p, meta_.p, stream, d_hmeta_));
     }
-    SG_TRY(hipEventRecord(ev_meta_, stream));
+    if (!j.fe) SG_TRY(hipEventRecord(ev_meta_, stream));   // (fused front end: the totals come with the task order, enqueue_back)
   } else {
     msm_hist<<<dim3(W, P), 1024, nbw * sizeof(uint32_t), stream>>>(dig_.p, (uint32_t)n, chunk, nbw, 0, hist_.p);
     msm_hist_prefix<<<(NB + HP_BUCKETS - 1) / HP_BUCKETS, HP_BUCKETS * HP_GROUPS, 0, stream>>>(
@@ -1994,7 +1996,10 @@ hipError_t MsmEngine::enqueue_back_impl() {
     const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
     SG_TRY(order_.reserve(ntasks_ub));
     if (j.fe) {
-      msm_task_scatter_reserve<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, fe_.p + FE_CURSOR, order_.p);
+      msm_task_scatter_reserve<<<tblk, 256, 0, stream>>>(
+          counts_.p, NB, log_L, tb,
+          FrontEndTotals{fe_.p, coff_.p, tbase_.p, off_.p, toff_[0].p, meta_.p, d_hmeta_, j.NBc, j.fe_parity, ACC_TICKET}, order_.p);
+      SG_TRY(hipEventRecord(ev_meta_, stream));
     } else {
       SG_TRY(thist_.reserve((size_t)TASK_BINS * tblk));
       msm_task_hist<<<tblk, 256, 0, stream>>>(counts_.p, NB, log_L, tb, thist_.p);
