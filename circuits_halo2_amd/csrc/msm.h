@@ -35,7 +35,7 @@ struct MsmConfig {
   uint32_t prefold_quad_buckets = 1u << 15;  // ... with a quad per bucket up to this many buckets in the job, one lane per bucket beyond
   uint32_t acc_chain = 1;      // accumulations of different jobs run one after the other (each waits for the previous launch's event)
   uint32_t red_lean = 1;       // level-0 bucket reduction within 168 registers (fits beside a polite accumulation): 0 never, 1 when other jobs are in flight, 2 always
-  uint32_t fused_frontend = 1; // two-pass sort: scans and task histogram inside the sort's own kernels (msm_fine_sort_fused), 0: the launches of rounds 1-4
+  uint32_t fused_frontend = 1; // two-pass sort: scans and task histogram inside the sort's own kernels (msm_fine_sort_fused): 0 never (the launches of rounds 1-4), 1 when no other job is in flight, 2 always
   uint32_t acc_trace = 0;      // debug: msm_accumulate records when each wave starts and leaves; finish() prints the percentiles to stderr
   uint32_t quad = 1;           // quad-cooperative point additions in merge / reduction: 0 never, 1 auto, 2 always
 };

@@ -1912,7 +1912,11 @@ hipError_t MsmEngine::enqueue_front_fused_impl(const fp_words* const* d_scalars,
     const uint32_t NBc = sets * B;
     // round 5: the scans and the task-length histogram ride on the sort's own kernels (msm_hist_prefix's and
     // msm_fine_sort_fused's last workgroups): five launches fewer per job
-    j.fe = cfg_.fused_frontend && NBc <= FE_MAX_BINS;
+    // ... for a job that has the device to itself (a blocking MSM 1.73 -> 1.70 ms, a proof's commitment jobs 26 launches
+    // fewer); with other jobs in flight the separate small kernels slip in beside the running accumulation more easily than one
+    // heavier sort pass does (three MSMs in flight: 770 -> 745 M points/s with the fused form, profiles/r05_sweeps/frontend.txt):
+    // 1 = by that rule, 2 = always, 0 = never
+    j.fe = NBc <= FE_MAX_BINS && (cfg_.fused_frontend == 2 || (cfg_.fused_frontend == 1 && !others_in_flight()));
     FrontEndScan fe_scan{nullptr, nullptr, nullptr, 0u, 0u};
     if (j.fe) {
       const uint32_t* before = fe_.p;

@@ -475,7 +475,7 @@ int apply_param(Context& c, const std::string& s, int value) {
     if (e == hipSuccess) e = abi_set_side_prio(on);
     if (e != hipSuccess) return hip_fail("side_prio", e);
   }
-  else if (s == "msm.fused_frontend") c.msm.config().fused_frontend = c.msm_b.config().fused_frontend = value ? 1u : 0u;
+  else if (s == "msm.fused_frontend") c.msm.config().fused_frontend = c.msm_b.config().fused_frontend = (uint32_t)std::min(2, std::max(0, value));
   else if (s == "msm.acc_trace") c.msm.config().acc_trace = c.msm_b.config().acc_trace = value ? 1u : 0u;
   else if (s == "msm.acc_chain") c.msm.config().acc_chain = c.msm_b.config().acc_chain = value ? 1u : 0u;
   else if (s == "msm.red_lean") c.msm.config().red_lean = c.msm_b.config().red_lean = (uint32_t)std::max(0, std::min(2, value));

@@ -555,7 +555,9 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *     generic / fixed-base jobs -- default: 3 (a full register file) for a generic job that has the device to itself, 2 (a
  *     third of the file left to other kernels) when other jobs are in flight and for fixed-base jobs; 8: one ticket per wave;
  *   "msm.acc_chain" (1 | 0): accumulations of different calls run one after the other;
- *   "msm.red_lean" (0 | 1 | 2): the bucket reduction's 168-register twin never / when other jobs are in flight / always. */
+ *   "msm.red_lean" (0 | 1 | 2): the bucket reduction's 168-register twin never / when other jobs are in flight / always;
+ *   "msm.fused_frontend" (0 | 1 | 2): the scans and the task-length histogram of a job inside its sort's own kernels (five launches
+ *     fewer) never / when the job has the device to itself (default) / always. */
 int sg_set_param(const char* name, int value);
 /* Reads a parameter back (so that a caller that changes a process-wide one for the length of a job can restore what it found):
  * the process-wide ones ("lanes", "commit.*", "host.wait_sleep_us", "msm.host_chunks") return their live value, the per-lane
