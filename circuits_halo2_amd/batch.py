@@ -303,6 +303,12 @@ def prove_batch(tree, user_indices, params, pk, levels: int, flavour: str = "evm
         # of 1 / 2 / 5 ms all land within the run-to-run spread, 249-266 proofs/s)
         scope["commit.combine_target"] = int(os.environ.get("SUMMA_COMBINE_TARGET", in_flight))
         scope["commit.combine_wait_us"] = int(os.environ.get("SUMMA_COMBINE_WAIT_US", 5000))
+        # two fused jobs side by side (round 5): one job's sort front end, bucket reduction and host tail run under the other's
+        # accumulation -- with one runner an accumulation is on the device half of the time only (profiles/r04_sweeps/
+        # batch_concurrency_64_end_of_round.txt).  Measured at 64 in flight: 249-256 -> 272-274 proofs/s on a whole host, 272 on a 1/8
+        # share of it (profiles/r05_sweeps/batch_knobs.txt); with few proofs in flight jobs of two runners are too small to pay
+        if in_flight >= 16 or "SUMMA_COMBINE_RUNNERS" in os.environ:
+            scope["commit.combine_runners"] = int(os.environ.get("SUMMA_COMBINE_RUNNERS", 2))
     # with several proofs in flight most worker threads are waiting for the device most of the time: they poll and SLEEP
     # (sg_set_param "host.wait_sleep_us") instead of polling and yielding -- the same proofs per second on a whole host, a
     # fifth more on a 1/8 share of it (what a rank gets when eight share a node), 13 -> 8 ms of CPU per proof

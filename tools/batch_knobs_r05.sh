@@ -11,7 +11,7 @@ out="gpurun_out/${tag}_batch_knobs.txt"
 touch "$out"
 for cfg in ${CONFIGS:-64:1:0 64:2:0}; do
   IFS=: read -r inflight runners share <<< "$cfg"
-  line=$(GPU_MAX_HW_QUEUES="${HWQ:-4}" SG_PARAMS="commit.combine_runners=$runners${EXTRA_PARAMS:+,$EXTRA_PARAMS}" python bench.py --gpus 1 --batch-only --cpu-share "$share" --batch-proofs 1024 --batch-repeats 2 --no-cpu \
+  line=$(GPU_MAX_HW_QUEUES="${HWQ:-4}" SUMMA_COMBINE_RUNNERS="$runners" SG_PARAMS="${EXTRA_PARAMS:-}" python bench.py --gpus 1 --batch-only --cpu-share "$share" --batch-proofs 1024 --batch-repeats 2 --no-cpu \
          --batch-in-flight "$inflight" --wall-limit 250 2>/dev/null | tail -1)
   HWQ="${HWQ:-4}" EXTRA_PARAMS="${EXTRA_PARAMS:-}" python - "$cfg" "$line" >> "$out" <<'PY'
 import json, sys
