@@ -1341,6 +1341,7 @@ def _main():
         line["config"]["proofs_per_s_1024"] = (batch_line or {}).get("proofs_per_s")
         line["config"]["proofs_per_s_1024_errors"] = (batch_line or {}).get("errors")
         line["config"]["sequential_ms_per_step"] = line["sequential"]["ms_per_step"]
+        dump_acc_log("the whole run")      # (a profile of this process holds every launch up to here)
         if batch_line and "roofline" in batch_line:
             bb = committed_batch_budget()
             if bb and bb.get("issue_floor_ms_per_proof") and batch_line.get("proofs_per_s"):

@@ -77,9 +77,12 @@ elif glob.glob(os.path.join(src, "*", "*_results.db")):
     rows = sorted(rocpd_rows(src, "kernels"), key=lambda r: r["start"])
     log = acc_log_for(src)
     n_acc = sum(1 for r in rows if r["name"].split("(")[0] == "sg::msm_accumulate")
-    exact = log is not None and len(log) == n_acc
+    # the log covers the launches up to the moment it was written: record i = i-th launch for as many records as it holds (the
+    # grids must agree, which is checked launch by launch below); launches beyond it fall back to the heuristic and say so
+    exact = log is not None and 0 < len(log) <= n_acc
     attribution["kernel_trace"] = {"method": "library launch log (exact: record i = i-th chained launch)" if exact else "preceding msm_digits on the queue (heuristic)",
-                                   "launches_in_trace": n_acc, "records_in_log": None if log is None else len(log)}
+                                   "launches_in_trace": n_acc, "records_in_log": None if log is None else len(log),
+                                   "launches_beyond_the_log": (n_acc - len(log)) if exact else None}
     seen = 0
     for r in rows:
         name, grid = r["name"].split("(")[0], int(r["grid_x"]) * int(r["grid_y"]) * int(r["grid_z"])
@@ -88,7 +91,7 @@ elif glob.glob(os.path.join(src, "*", "*_results.db")):
         if name == "sg::msm_digits":
             last_digits[r["queue_id"]] = grid
         elif name == "sg::msm_accumulate":
-            if exact:
+            if exact and seen < len(log):
                 rec = log[seen]
                 assert rec["threads"] == grid, (seen, rec, grid)     # the log and the trace describe the same launch
                 acc_jobs[(grid, job_key(rec), rec["jobs_in_flight"])].append(dur)
@@ -103,7 +106,7 @@ for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         crow = sorted(rocpd_rows(f"{src}_{kind}", "counters_collection"), key=lambda r: r["start"])
         log = acc_log_for(f"{src}_{kind}")
         n_acc = sum(1 for r in crow if r["counter_name"] == ctr and r["kernel_name"].split("(")[0] == "sg::msm_accumulate")
-        exact = log is not None and len(log) == n_acc
+        exact = log is not None and 0 < len(log) <= n_acc
         attribution[kind] = {"method": "library launch log (exact)" if exact else "preceding msm_digits on the queue (heuristic)",
                              "launches_in_pass": n_acc, "records_in_log": None if log is None else len(log)}
         seen = 0
@@ -114,7 +117,7 @@ for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             if r["counter_name"] == ctr:
                 agg[(name, grid)].append(float(r["value"]))
                 if name == "sg::msm_accumulate":
-                    job = job_key(log[seen]) if exact else last_digits.get(r['queue_id'], 0)
+                    job = job_key(log[seen]) if (exact and seen < len(log)) else last_digits.get(r['queue_id'], 0)
                     agg[(name, f"{grid}@job{job}")].append(float(r["value"]))
                     seen += 1
         for (k, g), v in agg.items():

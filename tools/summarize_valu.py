@@ -20,7 +20,7 @@ log = json.load(open(log_path))["launches"] if os.path.exists(log_path) else Non
 rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
 first_counter = rows[0]["Counter_Name"] if rows else None
 n_acc = sum(1 for r in rows if r["Counter_Name"] == first_counter and r["Kernel_Name"].split("(")[0].replace("void ", "") == "sg::msm_accumulate")
-exact = log is not None and len(log) == n_acc
+exact = log is not None and 0 < len(log) <= n_acc
 seen = -1
 for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -31,7 +31,7 @@ for r in rows:
     if name == "sg::msm_accumulate":   # launches of different jobs can share a grid: also keyed by the job
         if r["Counter_Name"] == first_counter:
             seen += 1
-        if exact:
+        if exact and seen < len(log):
             rec = log[seen]
             job = rec["n"] if rec["M"] == 1 else f"{rec['M']}x{rec['n']}"
         else:
