@@ -1095,7 +1095,17 @@ __device__ __forceinline__ xyzz29 wg_sum(uint32_t n, F get, xyzz29_mem* lds) {
   constexpr uint32_t NL = 256 / Q;  // logical threads
   const uint32_t lt = threadIdx.x / Q, role = threadIdx.x % Q;
   xyzz29 acc = xyzz29_identity();
-  for (uint32_t e = lt; e < n; e += NL) add_q<Q>(acc, get(e), role);
+  // (the next element is in flight while the addition runs: a logical thread adds two to four elements, and every load it waited
+  // for was a microsecond of a chain that is nothing but latency -- 62 % of these kernels' wave cycles were parked, profiles/r05z_proof_budget.json)
+  uint32_t e = lt;
+  xyzz29 nxt = xyzz29_identity();
+  if (e < n) nxt = get(e);
+  while (e < n) {
+    const xyzz29 cur = nxt;
+    e += NL;
+    if (e < n) nxt = get(e);
+    add_q<Q>(acc, cur, role);
+  }
   if (role == 0) xyzz29_store(&lds[lt], acc);
   __syncthreads();
   tree_sum<Q>(lds, NL, lt, role, true);
@@ -2000,6 +2010,8 @@ hipError_t MsmEngine::enqueue_back_impl() {
     const uint32_t tb = task_block_for(NB, nbins), tblk = (NB + tb - 1) / tb;
     SG_TRY(order_.reserve(ntasks_ub));
     if (j.fe) {
+      // (no scan over bins x workgroups to keep small any more: more, smaller workgroups -- the pass is latency, not work)
+      const uint32_t tb = NB >= (1u << 16) ? 512u : 256u, tblk = (NB + tb - 1) / tb;
       msm_task_scatter_reserve<<<tblk, 256, 0, stream>>>(
           counts_.p, NB, log_L, tb,
           FrontEndTotals{fe_.p, coff_.p, tbase_.p, off_.p, toff_[0].p, meta_.p, d_hmeta_, j.NBc, j.fe_parity, ACC_TICKET}, order_.p);

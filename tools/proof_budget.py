@@ -110,7 +110,7 @@ def main():
     launches = []
     job = -1
     lincomb_i = 0
-    lincomb_inputs = [0, 5, 2, 21, 1, 2, 1, 11, 6]    # instance column, h, the five rotation sets, f, L (include/summa_prover.hpp)
+    lincomb_inputs = [0, 11, 6]    # lincomb_kernel launches of a proof: instance column, f, L (include/summa_prover.hpp; the rotation sets are lincomb_sets_kernel)
     for i, d in enumerate(trace):
         rec = dict(d)
         for pname, (proof, same) in passes.items():
@@ -158,6 +158,10 @@ def main():
             return M * n * 2 * W + 6 * E, "digits in, 6 B (bucket, ref) pairs out"
         if nm == "sg::msm_fine_sort":
             return 6 * E + 4 * E, "pairs in, 4 B refs out"
+        if nm == "sg::msm_fine_sort_fused":
+            return 6 * E + 4 * E + 16 * NB, "pairs in, 4 B refs out, four words per bucket out (count, offset, tasks, task slot); entries = the job's nominal W x n"
+        if nm == "sg::msm_task_scatter_reserve":
+            return 8 * NB + 8 * T, "bucket counts in (two passes), task table out"
         if nm in ("sg::msm_hist_prefix", "sg::msm_scan_blocks", "sg::msm_scan_sums", "sg::msm_scan_write", "sg::msm_scan_small", "sg::msm_task_scan"):
             return 8 * NB, "bucket counters in and out"
         if nm == "sg::msm_task_hist":
@@ -174,6 +178,11 @@ def main():
             return 3 * 96 * M * 16, "window sums to the host"
         if nm == "sg::ntt_pass":
             return 2 * g * 2 * R, "2 elements per thread x (32 B in + 32 B out); inter-pass twiddle tables (32 B per element of the passes that have one) not counted"
+        if nm.startswith("sg::numerator_fused_kernel"):
+            return NE * R * (9 + 3 + 1 + 2 + 6 + 3 + 3 + 1), ("5n rows x (9 fixed + 3 advice + instance columns of the gate programs, 2 z, 6 sigma, 3 selector "
+                                                               "columns, lz / a' / s', values out) x 32 B: every column once")
+        if nm == "sg::lincomb_sets_kernel":
+            return N * R * (31 + 5), "31 inputs + 5 outputs x n x 32 B"
         if nm == "sg::quot_perm_kernel":
             return NE * R * (2 + 6 + 6 + 3 + 1 + 1), "5n rows x (2 z + 6 columns + 6 sigma + 3 selector columns + values in + values out) x 32 B"
         if nm == "sg::quot_lookup_kernel":
