@@ -1095,17 +1095,9 @@ __device__ __forceinline__ xyzz29 wg_sum(uint32_t n, F get, xyzz29_mem* lds) {
   constexpr uint32_t NL = 256 / Q;  // logical threads
   const uint32_t lt = threadIdx.x / Q, role = threadIdx.x % Q;
   xyzz29 acc = xyzz29_identity();
-  // (the next element is in flight while the addition runs: a logical thread adds two to four elements, and every load it waited
-  // for was a microsecond of a chain that is nothing but latency -- 62 % of these kernels' wave cycles were parked, profiles/r05z_proof_budget.json)
-  uint32_t e = lt;
-  xyzz29 nxt = xyzz29_identity();
-  if (e < n) nxt = get(e);
-  while (e < n) {
-    const xyzz29 cur = nxt;
-    e += NL;
-    if (e < n) nxt = get(e);
-    add_q<Q>(acc, cur, role);
-  }
+  // (round 5: loading the next element while the addition runs was measured and is slower -- 366 -> 406 us of line sums per proof:
+  // 185 registers instead of 149, and the loads of a quad's two to four elements are back to back anyway)
+  for (uint32_t e = lt; e < n; e += NL) add_q<Q>(acc, get(e), role);
   if (role == 0) xyzz29_store(&lds[lt], acc);
   __syncthreads();
   tree_sum<Q>(lds, NL, lt, role, true);

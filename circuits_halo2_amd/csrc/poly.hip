@@ -965,36 +965,40 @@ __device__ __forceinline__ bool small_canonical(const fp_words* p, uint32_t* v) 
   *v = w[0];
   return !(w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) && w[0] < LOOKUP_BINS;
 }
+// Round 5: values below LOOKUP_LDS_BINS (every value of an 8-bit range table) are counted in the workgroup's LDS first and reach
+// the global bins with one atomic per value the workgroup has seen -- most rows of a range check hold the same value (unused
+// rows: 0), and 2 048 waves adding to ONE global word, even with one atomic per wave, were 44 us at 4 % VALU busy
+// (profiles/r05z_proof_budget.json)
+static constexpr uint32_t LOOKUP_LDS_BINS = 256;
 __global__ void __launch_bounds__(256) lookup_permute_hist(const fp_words* __restrict__ input, const fp_words* __restrict__ table,
                                                            size_t rows, uint32_t* __restrict__ work, uint32_t* __restrict__ flag) {
   side_kernel_prio();
+  __shared__ uint32_t s_a[LOOKUP_LDS_BINS], s_t[LOOKUP_LDS_BINS], s_max;
+  s_a[threadIdx.x] = 0;
+  s_t[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  uint32_t a, t;
-  if (!small_canonical(table + i, &t)) {
-    atomicMax(flag, 2u);
-    return;
-  }
-  // most rows of a range check hold the same value (unused rows: 0): lanes that agree with the first active lane
-  // are counted with one atomic per wave
-  auto count = [&](uint32_t* bins, uint32_t v) {
-    const uint32_t lead = __builtin_amdgcn_readfirstlane(v);
-    const uint64_t same = __ballot(v == lead);
-    if (v == lead) {
-      if ((uint32_t)__lane_id() == (uint32_t)__ffsll((long long)same) - 1) atomicAdd(&bins[lead], (uint32_t)__popcll(same));
+  if (i < rows) {
+    uint32_t a, t;
+    if (!small_canonical(table + i, &t)) {
+      atomicMax(flag, 2u);
     } else {
-      atomicAdd(&bins[v], 1u);
+      if (t < LOOKUP_LDS_BINS) atomicAdd(&s_t[t], 1u);
+      else atomicAdd(&work[LOOKUP_BINS + t], 1u);
+      atomicMax(&s_max, t);   // highest table value: bounds the scans and searches below (a range table uses 256 of the 65536 bins)
+      if (!small_canonical(input + i, &a)) {
+        atomicMax(flag, 1u);
+      } else {
+        if (a < LOOKUP_LDS_BINS) atomicAdd(&s_a[a], 1u);
+        else atomicAdd(&work[a], 1u);
+      }
     }
-  };
-  count(work + LOOKUP_BINS, t);
-  // highest table value: bounds the scans and searches below (a range table uses 256 of the 65536 bins); the plain
-  // read only filters -- the maximum itself is maintained atomically
-  if (t > *reinterpret_cast<volatile uint32_t*>(flag + 1)) atomicMax(flag + 1, t);
-  if (!small_canonical(input + i, &a)) {
-    atomicMax(flag, 1u);
-    return;
   }
-  count(work, a);
+  __syncthreads();
+  if (s_a[threadIdx.x]) atomicAdd(&work[threadIdx.x], s_a[threadIdx.x]);
+  if (s_t[threadIdx.x]) atomicAdd(&work[LOOKUP_BINS + threadIdx.x], s_t[threadIdx.x]);
+  if (threadIdx.x == 0 && s_max > *reinterpret_cast<volatile uint32_t*>(flag + 1)) atomicMax(flag + 1, s_max);
 }
 // one workgroup: three exclusive prefix sums over the bins (input counts, repeated rows, leftover table values)
 __global__ void __launch_bounds__(1024) lookup_permute_scan(uint32_t* __restrict__ work, uint32_t* __restrict__ flag, uint32_t rows) {
