@@ -14,8 +14,9 @@ export TMPDIR=/tmp
 tag="${TAG:-r05z}"
 work="gpurun_out/${tag}_profiles"
 mkdir -p "$work"
+t0=$(date +%s)
 python bench.py --steps 20 --warmup 5 > "$work/bench.json" 2> "$work/bench.err"
-echo "bench done"
+echo "bench done in $(( $(date +%s) - t0 )) s (the driver's whole-run clock: headline + every extra)" | tee "$work/${tag}_bench_wall_clock.txt"
 rocprofv3 --kernel-trace --stats -d "gpurun_out/prof_${tag}" -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extras --acc-log "gpurun_out/prof_${tag}_acclog.json" > "$work/bench_under_rocprof.json" 2> "$work/rocprof.err"
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE -d "gpurun_out/prof_${tag}_fetch" -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-extras --acc-log "gpurun_out/prof_${tag}_fetch_acclog.json" > /dev/null 2>> "$work/rocprof.err"
