@@ -166,6 +166,30 @@ extern "C" {
     pub fn sg_collect_retired() -> c_int;
     pub fn sg_set_param(name: *const c_char, value: c_int) -> c_int;
     pub fn sg_get_param(name: *const c_char, value: *mut c_int) -> c_int;
+    // round 5: a proof without copy launches -- small results land in memory the caller names (page-locked, mapped into the device)
+    pub fn sg_fr_flag_noncanonical_dev(d_cols: *const *const c_void, m: u32, n: size_t, d_flag: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn sg_lookup_permute_small_async_dev(
+        d_input: *const c_void,
+        d_table: *const c_void,
+        rows: size_t,
+        d_permuted_input: *mut c_void,
+        d_permuted_table: *mut c_void,
+        d_status: *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn sg_fr_kate_division_rem_dev(d_a: *const c_void, n: size_t, b: *const u8, d_q: *mut c_void, d_remainder: *mut c_void, stream: *mut c_void) -> c_int;
+    // ... and the rotation sets' combinations of the multi-open in one launch
+    pub fn sg_fr_lincomb_sets_dev(
+        d_polys: *const *const c_void,
+        coeffs: *const u8,
+        set_sizes: *const u32,
+        n_sets: u32,
+        n: size_t,
+        lows: *const u8,
+        n_lows: *const u32,
+        d_outs: *const *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
     // revision of include/summa_gpu.h the library was built from (SG_ABI_VERSION); this file is written against 3
     pub fn sg_abi_version() -> c_int;
 }

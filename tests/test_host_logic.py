@@ -354,3 +354,31 @@ def test_sp_key_create_refuses_programs_outside_the_constraint_system_shape():
     for needle, edit in cases.items():
         rc, msg = create(tampered(edit))
         assert rc == -1 and "does not fit" in msg and needle in msg, (needle, rc, msg)
+
+
+def test_process_wide_parameters_read_back_and_a_batch_restores_what_it_found():
+    """sg_get_param / sg_abi_version and batch._ParamScope need no device: the process-wide parameters (combiner, sleeping waits) are
+    plain atomics of the library.  A batch's settings are put back to what the CALLER had set when the last batch of the process
+    ends, not to built-in defaults (advisor, round 4)."""
+    from circuits_halo2_amd import batch as B, ffi
+    assert ffi.lib().sg_abi_version() == 3
+    ffi.set_param("host.wait_sleep_us", 25)
+    ffi.set_param("commit.combine_wait_us", 777)
+    try:
+        assert ffi.get_param("host.wait_sleep_us") == 25 and ffi.get_param("commit.combine_runners") == 1
+        outer = B._ParamScope({"host.wait_sleep_us": 50, "commit.combine_wait_us": 5000, "commit.combine_runners": 2})
+        outer.enter()
+        inner = B._ParamScope({"commit.combine_wait_us": 2000})
+        inner.enter()
+        assert ffi.get_param("commit.combine_wait_us") == 2000 and ffi.get_param("host.wait_sleep_us") == 50
+        outer.leave()                       # the first batch ends while the second still runs: nothing is restored yet
+        assert ffi.get_param("host.wait_sleep_us") == 50 and ffi.get_param("commit.combine_runners") == 2
+        inner.leave()
+        assert ffi.get_param("host.wait_sleep_us") == 25 and ffi.get_param("commit.combine_wait_us") == 777
+        assert ffi.get_param("commit.combine_runners") == 1
+    finally:
+        ffi.set_param("host.wait_sleep_us", 0)
+        ffi.set_param("commit.combine_wait_us", 300)
+    import pytest
+    with pytest.raises(ffi.SummaGpuError):
+        ffi.get_param("no.such.parameter")
