@@ -1094,6 +1094,8 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     void* lookup_cols[4] = {inp.p, pk.fixed_lag[4].p, pin.p, ptab.p};
     void* z_out[3] = {zs[0].p, zs[1].p, lz.p};
     // z0[u], z1[u], lz[u] land in mapped host memory, written by the kernels that produce the row: looked at when the commitments are back
+    // (cleared first: a value left by an earlier proof of this thread must never pass for this proof's)
+    std::memset(pinned_small_rows() + 4 * MAIL_CLOSING, 0, 3 * 32);
     ck(sg_grand_products_closing_dev(all_vals.data(), all_sig.data(), chunk_cols, 2, lookup_cols, 1, beta.bytes(), gamma.bytes(), k, u, z_out,
                                      opt.sanity_checks ? pinned_small_dev_row(MAIL_CLOSING) : nullptr, main_stream()), "grand products");
     mark("3: grand products enqueued");
@@ -1380,6 +1382,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
                            main_stream()), "L lincomb");
   // the remainder L(mu) goes to mapped host memory and is looked at once W' is back: the commitment job is issued behind the
   // division without a host wait in between (a non-zero remainder is a bug in this driver, not an input error)
+  std::memset(pinned_small_rows() + 4 * MAIL_REMAINDER, 0xff, 32);   // (not a remainder any kernel writes: a stale zero cannot pass)
   ck(sg_fr_kate_division_rem_dev(l_poly.p, n, mu.bytes(), w2.p, pinned_small_dev_row(MAIL_REMAINDER), main_stream()), "final division");
   mark("6: final quotient enqueued, commit issued");
   commit_batch({w2.p}, {0});
