@@ -2019,7 +2019,14 @@ hipError_t MsmEngine::enqueue_back_impl() {
   // persistent launch: `waves` per SIMD on every CU (3 fill the register file)
   // ... three fill the register file (a job that has the device to itself); two leave a third of it to the kernels of other
   // streams, which run at wave priority 3 (side_kernel_prio): the other jobs in flight, a proof's transforms under its commitments
-  const uint32_t waves = j.fixed ? (cfg_.acc_waves_fixed ? cfg_.acc_waves_fixed : 2)
+  // Round 5, fixed-base jobs: three waves when the job is several ROUNDS of tasks on a two-wave launch (the five dense quotient
+  // pieces of a proof: 330 K tasks on 131 072 lanes) -- the counters show the two-wave launch issuing 61 % of the time where
+  // three waves issue 87 %, and nothing runs beside that job (the evaluations wait for its challenge); a job of ONE round
+  // (a single polynomial: W, W') keeps two: its time is the length of one task, which a third wave per SIMD only stretches
+  // (k = 17 proof, phase 4 2.03 -> 1.90 ms, phase 6 1.20 -> 1.26 with three waves everywhere; profiles/r05_sweeps/accumulate_waves_fixed.txt)
+  const uint32_t lanes2 = cus_ * 4u * 64u * 2u;
+  const uint32_t waves_fixed_auto = ntasks_ub >= 3u * lanes2 ? 3u : 2u;
+  const uint32_t waves = j.fixed ? (cfg_.acc_waves_fixed ? cfg_.acc_waves_fixed : waves_fixed_auto)
                                  : (cfg_.acc_waves ? cfg_.acc_waves : (others_in_flight() ? 2 : 3));
   const uint32_t wg_all = (ntasks_ub + at - 1) / at;
   const uint32_t wg = waves >= 8 ? wg_all : std::min<uint32_t>(wg_all, cus_ * (waves * 4 * 64 / at));
