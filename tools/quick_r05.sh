@@ -24,7 +24,6 @@ prover.export_bundle(sys.argv[1], params, pk, adv, c.instances()[0])
 print("bundle written")
 PY
 CP="$GRAFT_REPO_ROOT/tools/create_proof_cpp"
-for v in "${VARIANTS:-default}"; do :; done
 "$CP" "$work/bundle17.bin" "$work/proof.bin" 30 | tee "gpurun_out/${tag}_create_proof_cpp.json"
 SG_PROVER_SERIAL=1 "$CP" "$work/bundle17.bin" "$work/proof.bin" 30 | tee "gpurun_out/${tag}_create_proof_cpp_serial.json"
 if [ -n "${AB_PARAMS:-}" ]; then   # e.g. AB_PARAMS="quotient.fused_numerator=0 ntt.coset_scale_pass=1"
