@@ -17,6 +17,7 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 #endif
 
 static constexpr uint32_t MSM_LOG_FUSE_ENTRIES_DEFAULT = 27;
+static constexpr uint32_t MSM_TINY_MAX = 64;   // MSMs of at most this many points run as ONE launch (MsmEngine::run_tiny)
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 2 single / - 4 fused, clamped to [4, 16])
   uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
@@ -114,6 +115,8 @@ class MsmEngine {
   // d_scalars: n x 32 B Montgomery Fr, d_bases: n x 64 B affine; result: 64 B affine on the host
   hipError_t run(const fp_words* d_scalars, const g1_affine_mem* d_bases, size_t n, hipStream_t stream, uint8_t out_affine[64],
                  MsmTimings* tm);
+  // n <= MSM_TINY_MAX points from HOST memory (the verifier's 37): one launch, no staging copy, result on return (msm.hip)
+  hipError_t run_tiny(const uint8_t* h_scalars, const uint8_t* h_bases, size_t n, hipStream_t stream, uint8_t out_affine[64]);
   // the same in three phases, so that two engines on two streams can overlap one MSM's
   // latency-bound tail with the next MSM's sort/accumulate (sg_msm_g1_batch):
   //   enqueue_front: digits .. counting sort (+ async copy of the task counters)
@@ -164,7 +167,7 @@ class MsmEngine {
   const FixedTable* fixed_ = nullptr;  // set only while enqueue_front_fixed runs
   uint64_t diff_mask_ = 0;             // likewise
   uint32_t fe_parity_ = 0;             // fused front end: replica set of the most recent job (alternates)
-  hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr;
+  hipEvent_t ev_meta_ = nullptr, ev_done_ = nullptr, ev_acc_ = nullptr, ev_tiny_ = nullptr;
   hipStream_t tail_stream_ = nullptr;  // optional high-priority stream for reduce + export
   MsmConfig cfg_;
   DevBuf<int16_t> dig_;
@@ -181,6 +184,8 @@ class MsmEngine {
   size_t h_win_cap_ = 0;
   uint32_t* h_win_ = nullptr;    // W x 3 x 32 words: canonical XYZZ of (A, S, T) per window; written by the export kernels through d_hwin_
   uint32_t* d_hwin_ = nullptr;
+  uint8_t* h_tiny_ = nullptr;    // run_tiny: scalars, points (read by the kernel) and the window sums (written by it), mapped
+  uint8_t* d_tiny_ = nullptr;
 };
 
 // one msm_accumulate launch as the engine issued it (parameter "msm.acc_log"; sg_msm_launch_log)

@@ -1582,11 +1582,14 @@ void MsmEngine::release() {
   ev_acc_ = nullptr;
   if (ev_meta_) (void)hipEventDestroy(ev_meta_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
-  ev_meta_ = ev_done_ = nullptr;
+  if (ev_tiny_) (void)hipEventDestroy(ev_tiny_);
+  ev_meta_ = ev_done_ = ev_tiny_ = nullptr;
   if (h_meta_) (void)hipHostFree(h_meta_);
   if (h_win_) (void)hipHostFree(h_win_);
+  if (h_tiny_) (void)hipHostFree(h_tiny_);
   h_meta_ = nullptr;
   h_win_ = nullptr;
+  h_tiny_ = d_tiny_ = nullptr;
 }
 
 // Window size, from the measured sweeps (profiles/r01_sweeps/sweep_c2.txt): a single MSM is
@@ -2317,6 +2320,148 @@ hipError_t MsmEngine::run(const fp_words* d_scalars, const g1_affine_mem* d_base
   SG_TRY(enqueue_front(d_scalars, d_bases, n, stream, out_affine, tm));
   SG_TRY(enqueue_back());
   return finish();
+}
+
+// ------------------------------------------------------------------ a handful of points: ONE launch
+// The verifier's left-hand side is an MSM of 37 points (csrc/verifier_abi.hip), once per proof served: through the engine above it
+// is eleven launches, three staging copies and two host waits for 2 368 point additions -- in a batch of proofs a third of all
+// MSM launches.  n <= MSM_TINY_MAX goes through one kernel instead: workgroup = window (c = 4: 64 windows of 8 buckets, the
+// engine's own window plan and digit rule), one wave each.  Lane i derives the digit of scalar i; lane b < 8 gathers bucket b + 1
+// (a scan of the n digits in LDS: 4.6 mixed additions on average at n = 37); the weighted sum sum_b (b + 1) B_b is a suffix scan
+// over the eight lanes and a tree sum of the suffix sums (6 dependent additions instead of 16 running-sum steps); lane 0 writes the
+// window's sum, canonical, into mapped host memory.  Scalars and points are READ from mapped host memory (6 KB: no staging
+// copy); the host tail is the engine's (terms at their bit offsets, one double-and-add sweep).
+__global__ void __launch_bounds__(64) msm_tiny_kernel(const fp_words* __restrict__ scalars, const g1_affine_mem* __restrict__ bases,
+                                                      uint32_t n, WindowPlan wp, uint32_t* __restrict__ out_words) {
+  side_kernel_prio();
+  __shared__ int s_dig[MSM_TINY_MAX];
+  __shared__ uint32_t s_pt[MSM_TINY_MAX][16];
+  __shared__ xyzz29_mem s_x[8];
+  const uint32_t w = blockIdx.x, t = threadIdx.x, W = wp.W;
+  if (t < n) {
+    words8 s;
+    {
+      f29 k = f29_zero();   // canonical scalar = s~ * 2^5 * 2^-261 (msm_digits)
+      k.l[0] = 32;
+      f29_to_words(f29_cond_sub_p<Fr29>(f29_mul<Fr29>(f29_load_r256<Fr29>(scalars + t), k)), s.l);
+    }
+    uint32_t off = 0;
+    {
+      // s += K = sum_{j < W-1} 2^(o_j + w_j - 1): every window's digit becomes independent of its neighbours
+      uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t o = 0;
+      for (uint32_t j = 0; j + 1 < W; j++) {
+        const uint32_t bit = o + wp.width[j] - 1;
+        const uint32_t m = 1u << (bit & 31), q = bit >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; i++) kk[i] |= (q == (uint32_t)i) ? m : 0u;
+        if (j < w) off += wp.width[j];
+        o += wp.width[j];
+      }
+      uint32_t carry = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint64_t v = (uint64_t)s.l[q] + kk[q] + carry;
+        s.l[q] = (uint32_t)v;
+        carry = (uint32_t)(v >> 32);
+      }
+    }
+    const uint32_t width = wp.width[w], q = off >> 5, r = off & 31;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      lo = (q == (uint32_t)i) ? s.l[i] : lo;
+      hi = (q + 1 == (uint32_t)i) ? s.l[i] : hi;
+    }
+    const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> r) & ((1u << width) - 1);
+    s_dig[t] = (w + 1 < W) ? (int)v - (int)(1u << (width - 1)) : (int)v;
+    const uint4* src = bases[t].q;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint4 x = src[i];
+      s_pt[t][4 * i] = x.x; s_pt[t][4 * i + 1] = x.y; s_pt[t][4 * i + 2] = x.z; s_pt[t][4 * i + 3] = x.w;
+    }
+  }
+  __syncthreads();
+  xyzz29 acc = xyzz29_identity();
+  if (t < 8) {
+    for (uint32_t i = 0; i < n; i++) {
+      const int d = s_dig[i];
+      if ((d < 0 ? -d : d) != (int)t + 1) continue;
+      affine29 p = affine29_from_words(s_pt[i]);
+      if (d < 0) affine29_negate(p);
+      xyzz29_madd(acc, p);
+    }
+  }
+  // R_b = sum_{b' >= b} B_b' (three steps), then sum_b R_b = sum_b (b + 1) B_b (three steps)
+  for (uint32_t step = 1; step < 8; step <<= 1) {
+    if (t < 8) xyzz29_store(s_x + t, acc);
+    __syncthreads();
+    if (t + step < 8) xyzz29_add(acc, xyzz29_load(s_x + t + step));
+    __syncthreads();
+  }
+  for (uint32_t step = 4; step >= 1; step >>= 1) {
+    if (t < 8) xyzz29_store(s_x + t, acc);
+    __syncthreads();
+    if (t < step) xyzz29_add(acc, xyzz29_load(s_x + t + step));
+    __syncthreads();
+  }
+  if (t == 0) {
+    uint32_t wd[32];
+    xyzz29_to_words(acc, wd);
+#pragma unroll
+    for (int i = 0; i < 32; i++) out_words[32 * w + i] = wd[i];
+  }
+}
+
+hipError_t MsmEngine::run_tiny(const uint8_t* h_scalars, const uint8_t* h_bases, size_t n, hipStream_t stream, uint8_t out_affine[64]) {
+  if (n == 0) {
+    std::memset(out_affine, 0, 64);
+    return hipSuccess;
+  }
+  if (n > MSM_TINY_MAX) return hipErrorInvalidValue;
+  constexpr size_t IN_BYTES = MSM_TINY_MAX * (32 + 64), OUT_WORDS = 64 * 32;
+  if (!h_tiny_) {
+    SG_TRY(hipHostMalloc(&h_tiny_, IN_BYTES + OUT_WORDS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    SG_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_tiny_), h_tiny_, 0));
+  }
+  if (!ev_tiny_) SG_TRY(hipEventCreateWithFlags(&ev_tiny_, hipEventDisableTiming));
+  // (the buffer is this engine's, and the previous call waited for its kernel: nothing reads it now)
+  std::memcpy(h_tiny_, h_scalars, 32 * n);
+  std::memcpy(h_tiny_ + 32 * MSM_TINY_MAX, h_bases, 64 * n);
+  const WindowPlan wp = make_window_plan(4);
+  uint32_t* h_out = reinterpret_cast<uint32_t*>(h_tiny_ + IN_BYTES);
+  msm_tiny_kernel<<<wp.W, 64, 0, stream>>>(reinterpret_cast<const fp_words*>(d_tiny_),
+                                           reinterpret_cast<const g1_affine_mem*>(d_tiny_ + 32 * MSM_TINY_MAX), (uint32_t)n, wp,
+                                           reinterpret_cast<uint32_t*>(d_tiny_ + IN_BYTES));
+  SG_TRY(hipGetLastError());
+  SG_TRY(hipEventRecord(ev_tiny_, stream));
+  SG_TRY(host_wait_event(ev_tiny_));
+  using namespace host;
+  // window sums at their bit offsets, one double-and-add sweep from the top bit (as finish() does)
+  int head[255], next[64];
+  for (auto& h : head) h = -1;
+  uint32_t o = 0, top = 0;
+  for (uint32_t w = 0; w < wp.W; w++) {
+    next[w] = head[o];
+    head[o] = (int)w;
+    top = o;
+    o += wp.width[w];
+  }
+  Jac total = Jac::identity();
+  for (int bit = (int)top; bit >= 0; bit--) {
+    total = jac_double(total);
+    for (int id = head[bit]; id >= 0; id = next[id]) {
+      Fq x, y, zz, zzz;
+      std::memcpy(x.v, h_out + 32 * id, 32);
+      std::memcpy(y.v, h_out + 32 * id + 8, 32);
+      std::memcpy(zz.v, h_out + 32 * id + 16, 32);
+      std::memcpy(zzz.v, h_out + 32 * id + 24, 32);
+      total = jac_add(total, jac_from_xyzz(x, y, zz, zzz));
+    }
+  }
+  jac_to_affine_bytes(total, out_affine);
+  return hipSuccess;
 }
 
 // points[i] on y^2 = x^3 + 3 (or the identity, 64 zero bytes)?  *bad counts the points that are not

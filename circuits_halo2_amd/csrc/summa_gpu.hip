@@ -710,6 +710,7 @@ int sg_msm_g1_dev(const void* d_scalars, const void* d_bases, size_t n, void* st
 // chunks lose: every job brings its own latency chains, and small kernels beside an accumulation run slowly).
 static constexpr size_t MSM_HOST_SPLIT_MIN = (size_t)1 << 18;
 static std::atomic<int> g_host_chunks{0};
+static std::atomic<int> g_msm_tiny_max{(int)MSM_TINY_MAX};   // "msm.tiny_max": host-pointer MSMs of at most this many points run as one launch
 static int msm_host_chunked(const uint8_t* scalars, const uint8_t* bases_host, const g1_affine_mem* d_bases_resident, size_t n,
                             uint8_t out_affine[64]) {
   Context& c = *g_ctx;
@@ -813,6 +814,11 @@ static int msm_host_chunked(const uint8_t* scalars, const uint8_t* bases_host, c
 int sg_msm_g1(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out_affine[64]) {
   if (!out_affine || (n && (!scalars || !bases))) return fail(SG_ERR_INVALID, "sg_msm_g1: null argument");
   LOCKED_CTX();
+  if (n && n <= (size_t)g_msm_tiny_max.load()) {   // a handful of points (the verifier's 37): one launch, no staging (MsmEngine::run_tiny)
+    const hipError_t e = g_ctx->msm.run_tiny(scalars, bases, n, g_ctx->stream, out_affine);
+    if (e != hipSuccess) return hip_fail("msm (one launch)", e);
+    return SG_OK;
+  }
   return msm_host_chunked(scalars, bases, nullptr, n, out_affine);
 }
 
@@ -3046,6 +3052,10 @@ int sg_set_param(const char* name, int value) {
     g_host_chunks.store(std::min(value, 8));
     return SG_OK;
   }
+  if (s == "msm.tiny_max") {   // sg_msm_g1 of at most this many points is ONE launch (0: always the engine's pipeline; at most 64)
+    g_msm_tiny_max.store(std::min(value, (int)MSM_TINY_MAX));
+    return SG_OK;
+  }
   if (s == "host.wait_sleep_us") {   // how host threads wait for the device (csrc/host_wait.h): 0 = the runtime's wait, > 0 = poll and sleep
     host_wait_sleep_us().store(std::min(value, 1000));
     return SG_OK;
@@ -3098,6 +3108,7 @@ int sg_get_param(const char* name, int* value) {
   else if (s == "commit.combine_target") *value = g_comb.target.load();
   else if (s == "commit.combine_runners") *value = g_comb.max_runners.load();
   else if (s == "msm.host_chunks") *value = g_host_chunks.load();
+  else if (s == "msm.tiny_max") *value = g_msm_tiny_max.load();
   else if (s == "host.wait_sleep_us") *value = host_wait_sleep_us().load();
   else if (s == "lanes") *value = g_lane_count.load();
   else {

@@ -98,6 +98,8 @@ const char* sg_version(void);
 /* ---- M1: halo2_proofs::arithmetic::best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1
  * (reached via ParamsKZG::commit / commit_lagrange).  upstream asserts
  * coeffs.len() == bases.len(); here a single n covers both.  n = 0 yields the identity.
+ * sg_msm_g1 with n <= 64 (parameter "msm.tiny_max") is one kernel launch and one host wait -- what the verifier's 37-point
+ * left-hand side needs once per proof served.
  * sg_msm_g1_dev returns the point, i.e. it is complete on return: its kernels run on the calling lane's own stream, ordered
  * after whatever `stream` holds at the time of the call (the lanes' streams are on distinct hardware queues, so calls from
  * several threads overlap whatever streams the callers use: DESIGN.md section 4.4). */
@@ -540,6 +542,11 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  * "host.wait_sleep_us" (0 | 1..1000: see sg_stream_wait; process-wide, takes effect at once),
  * "msm.host_chunks" (0 = by size | 1..8: the host-pointer entry points sg_msm_g1 / sg_commit cut inputs of 2^18 pairs and more into
  *   that many chunks, which run as jobs on two engines while the next chunk is uploaded; default 2),
+ * "msm.tiny_max" (0..64, default 64: sg_msm_g1 of at most this many points -- the verifier's 37 -- is ONE launch that reads its
+ *   inputs from mapped host memory instead of eleven launches and three staging copies; 0: always the engine's pipeline),
+ * "msm.log_fuse_entries" (16..30, default 27; 0 = the default: a fused job -- sg_msm_g1_batch*, sg_commit_batch*, the commit
+ *   combiner -- holds at most 2^x (window, scalar) entries = 64 polynomials of 2^17 rows over a 16-window table; larger batches
+ *   are cut into several jobs),
  * "msm.acc_trace" (0 | 1: debug -- every wave of msm_accumulate records when it starts and leaves; the job's host tail prints the
  *   percentiles to stderr: tools/acc_trace.sh, profiles/r04_sweeps/accumulate_tail.txt),
  * "ntt.coset_scale_pass" (0 | 1: A-B aid -- sg_coeff_to_cosets_batch_dev multiplies by the coset shifts inside the first NTT pass
@@ -560,7 +567,7 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *     fewer) never / when the job has the device to itself (default) / always. */
 int sg_set_param(const char* name, int value);
 /* Reads a parameter back (so that a caller that changes a process-wide one for the length of a job can restore what it found):
- * the process-wide ones ("lanes", "commit.*", "host.wait_sleep_us", "msm.host_chunks") return their live value, the per-lane
+ * the process-wide ones ("lanes", "commit.*", "host.wait_sleep_us", "msm.host_chunks", "msm.tiny_max") return their live value, the per-lane
  * ones ("msm.*", "ntt.*", "side_prio") the value most recently set through sg_set_param, 0 when none was (built-in default). */
 int sg_get_param(const char* name, int* value);
 /* Profiling aid.  With parameter "msm.acc_log" = 1 (setting it clears the log) every msm_accumulate launch of the process is

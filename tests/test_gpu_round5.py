@@ -321,3 +321,63 @@ def test_flag_noncanonical_closing_values_and_asynchronous_remainder(gpu):
     ffi.check(L.sg_fr_kate_division_dev(ffi.dev_ptr(a), C.c_size_t(n), ffi.ptr(ffi.u8(b)), ffi.dev_ptr(q2), ffi.ptr(rem), ffi.current_stream_ptr()))
     torch.cuda.synchronize()
     assert (q1 == q2).all() and (rem_dev.cpu().numpy() == rem).all() and rem.any()
+
+
+def test_one_launch_msm_of_a_handful_of_points(gpu):
+    """sg_msm_g1 with at most 64 points (the verifier's 37) is ONE launch that reads its inputs from mapped host memory
+    (MsmEngine::run_tiny): against the oracle, against the engine's pipeline over the same inputs (device pointers, and the host
+    entry with "msm.tiny_max" = 0), on every special case of the group law a bucket or the suffix scan can meet -- one point many
+    times (P + P in a bucket, equal partial sums in the scan), P and -P cancelling, identity points, zero scalars, scalars at the
+    top of the range and straddling window boundaries, words >= r"""
+    import torch
+    from conftest import fr_np, point_np
+    from oracle import oracle as O, pyref as P
+    from circuits_halo2_amd import ffi
+    bases_all = O.fixed_base_mul(O.random_fr(77, 80), 4)          # 80 points x_i G
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def pipeline(sc, bs):
+        assert ffi.get_param("msm.tiny_max") == 64
+        ffi.set_param("msm.tiny_max", 0)
+        try:
+            return gpu.best_multiexp(sc, bs)
+        finally:
+            ffi.set_param("msm.tiny_max", 64)
+
+    for n in (1, 2, 3, 7, 8, 9, 31, 37, 63, 64, 65):
+        sc, bs = O.random_fr(500 + n, n), bases_all[:64 * n]
+        want = O.best_multiexp(sc, bs, 1)
+        assert (gpu.best_multiexp(sc, bs) == want).all(), n
+        assert (pipeline(sc, bs) == want).all(), n
+        assert (gpu.best_multiexp(dev(sc), dev(bs)) == want).all(), n
+    ident = np.zeros(64, dtype=np.uint8)
+    g = bases_all[:64]
+    gi = P.g1_from_bytes(g.tobytes())
+    neg = point_np(P.g1_neg(gi))
+    rng = np.random.default_rng(5)
+    for n in (16, 37, 64):
+        same = np.tile(g, n)
+        small = fr_np([int(v) for v in rng.integers(0, 4, size=n)])           # few distinct digits: deep equal buckets
+        x = O.random_fr(77, 80)[:32]                                           # the base is x G: sum_i s_i (x G) = ((sum s_i) x) G
+        scaled = lambda sc: O.fixed_base_mul(O.fr_dot(O.fr_dot(sc, fr_np([1] * n)), x), 1)
+        assert (gpu.best_multiexp(small, same) == scaled(small)).all()
+        rand = O.random_fr(900 + n, n)
+        assert (gpu.best_multiexp(rand, same) == scaled(rand)).all()
+        assert (gpu.best_multiexp(np.tile(rand[:32], n), same) == scaled(np.tile(rand[:32], n))).all()
+        alt = np.concatenate([g, neg] * (n // 2))
+        pairs = np.repeat(O.random_fr(950 + n, n // 2).reshape(-1, 32), 2, axis=0).reshape(-1)
+        assert not gpu.best_multiexp(pairs, alt).any()
+        assert not gpu.best_multiexp(fr_np([0] * n), bases_all[:64 * n]).any()
+        holes = bases_all[:64 * n].copy()
+        holes[64 * 3:64 * 5] = 0                                                # identity points among the bases
+        sc = O.random_fr(970 + n, n)
+        assert (gpu.best_multiexp(sc, holes) == O.best_multiexp(sc, holes, 1)).all()
+    vals = [P.R - 1, P.R - 2, (P.R - 1) // 2, 1 << 253, (1 << 128) - 1, 1 << 16, (1 << 16) - 1, 1 << 15, 65537, 2, 8, 7, 9, 1 << 4, (1 << 252) + 8]
+    bs = bases_all[:64 * len(vals)]
+    assert (gpu.best_multiexp(fr_np(vals), bs) == O.best_multiexp(fr_np(vals), bs, 1)).all()
+    assert (gpu.best_multiexp(fr_np([P.R - 1]), g) == neg).all()
+    assert (gpu.best_multiexp(fr_np([5, 1]), np.concatenate([ident, g])) == g).all()
+    # words that are not canonical Montgomery residues (>= r): both paths reduce them the same way
+    raw = np.full(32 * 5, 0xFF, dtype=np.uint8)
+    assert (gpu.best_multiexp(raw, bases_all[:64 * 5]) == pipeline(raw, bases_all[:64 * 5])).all()
+    assert (gpu.best_multiexp(raw, bases_all[:64 * 5]) == gpu.best_multiexp(dev(raw), dev(bases_all[:64 * 5]))).all()
