@@ -16,15 +16,18 @@ struct words8 {  // one field element as 8 LE u32 words (Montgomery-2^256), host
 };
 #endif
 
-static constexpr uint32_t MSM_LOG_FUSE_ENTRIES_DEFAULT = 27;
+static constexpr uint32_t MSM_LOG_FUSE_ENTRIES_GENERIC = 25, MSM_LOG_FUSE_ENTRIES_FIXED = 27;
 static constexpr uint32_t MSM_TINY_MAX = 64;   // MSMs of at most this many points run as ONE launch (MsmEngine::run_tiny)
 struct MsmConfig {
   uint32_t window_bits = 0;    // 0: choose from n (log2 n - 2 single / - 4 fused, clamped to [4, 16])
   uint32_t log_seg = 0;        // L = 2^log_seg entries per accumulation task; 0: choose from n
-  // fused batches hold at most 2^x (window, scalar) entries.  27 = 64 polynomials of 2^17 rows over a 16-window table in ONE job
-  // (round 5: with 25 a fused commitment job of a proof batch was cut into jobs of 16 polynomials, each with a sort front end,
-  // reduction and host tail of its own: 269-272 -> 292-294 proofs/s at 64 proofs in flight, profiles/r05_sweeps/batch_knobs.txt)
-  uint32_t log_fuse_entries = MSM_LOG_FUSE_ENTRIES_DEFAULT;
+  // fused batches hold at most 2^x (window, scalar) entries.  Fixed-base jobs (commitments): 27 = 64 polynomials of 2^17 rows over a
+  // 16-window table in ONE job (round 5: with 25 a fused commitment job of a proof batch was cut into jobs of 16 polynomials, each
+  // with a sort front end, reduction and host tail of its own: 269-272 -> 287-299 proofs/s at 64 proofs in flight,
+  // profiles/r05_sweeps/batch_knobs.txt).  Generic jobs (sg_msm_g1_batch*) stay at 25: their groups alternate between two engines,
+  // and eight MSMs of 2^20 run 6 % faster as four groups of two than as two of four (bench.py "batched": 1.45 against 1.54 ms per MSM)
+  uint32_t log_fuse_entries = MSM_LOG_FUSE_ENTRIES_GENERIC;
+  uint32_t log_fuse_entries_fixed = MSM_LOG_FUSE_ENTRIES_FIXED;
   uint32_t red_threads = 256;      // workgroup size of the level-0 bucket reduction (64, 128 or 256)
   uint32_t log_red_chunk = 0;  // G = 2^x buckets per thread in the bucket reduction; 0: auto
   uint32_t two_pass = 1;            // two-pass (coarse bin, in-LDS fine) sort: 0 never, 1 auto (>= 2^19 entries), 2 always

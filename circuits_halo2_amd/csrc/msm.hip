@@ -1768,7 +1768,7 @@ hipError_t MsmEngine::enqueue_front_fixed(const fp_words* const* d_scalars, cons
 size_t MsmEngine::max_fused_fixed(const FixedTable& tab, size_t n) const {
   if (n == 0) return MAX_FUSED;
   const size_t by_buckets = ((size_t)1 << 21) >> (tab.c - 1);
-  const size_t by_entries = ((size_t)1 << cfg_.log_fuse_entries) / std::max<size_t>(1, (size_t)tab.wp.W * n);
+  const size_t by_entries = ((size_t)1 << cfg_.log_fuse_entries_fixed) / std::max<size_t>(1, (size_t)tab.wp.W * n);
   return std::max<size_t>(1, std::min<size_t>(std::min(by_buckets, by_entries), MAX_FUSED));
 }
 

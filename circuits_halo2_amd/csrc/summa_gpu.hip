@@ -459,8 +459,10 @@ int download(uint8_t* host, const void* dev, size_t bytes, hipStream_t s) {
 int apply_param(Context& c, const std::string& s, int value) {
   if (s == "msm.window_bits") c.msm.config().window_bits = c.msm_b.config().window_bits = (uint32_t)value;
   else if (s == "msm.log_seg") c.msm.config().log_seg = c.msm_b.config().log_seg = (uint32_t)std::min(12, value);
-  else if (s == "msm.log_fuse_entries") {   // 0: the built-in default (what sg_get_param reports for a parameter never set)
-    c.msm.config().log_fuse_entries = c.msm_b.config().log_fuse_entries = value == 0 ? MSM_LOG_FUSE_ENTRIES_DEFAULT : (uint32_t)std::max(16, std::min(30, value));
+  else if (s == "msm.log_fuse_entries") {   // one value for generic and fixed-base jobs; 0: the built-in defaults (what sg_get_param reports for a parameter never set)
+    const uint32_t v = (uint32_t)std::max(16, std::min(30, value));
+    c.msm.config().log_fuse_entries = c.msm_b.config().log_fuse_entries = value == 0 ? MSM_LOG_FUSE_ENTRIES_GENERIC : v;
+    c.msm.config().log_fuse_entries_fixed = c.msm_b.config().log_fuse_entries_fixed = value == 0 ? MSM_LOG_FUSE_ENTRIES_FIXED : v;
   }
   else if (s == "msm.red_threads") { uint32_t v = value <= 64 ? 64 : value <= 128 ? 128 : 256; c.msm.config().red_threads = c.msm_b.config().red_threads = v; }
   else if (s == "msm.log_scatter_rounds") c.msm.config().log_scatter_rounds = c.msm_b.config().log_scatter_rounds = (uint32_t)std::min(6, std::max(0, value));

@@ -544,9 +544,9 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   that many chunks, which run as jobs on two engines while the next chunk is uploaded; default 2),
  * "msm.tiny_max" (0..64, default 64: sg_msm_g1 of at most this many points -- the verifier's 37 -- is ONE launch that reads its
  *   inputs from mapped host memory instead of eleven launches and three staging copies; 0: always the engine's pipeline),
- * "msm.log_fuse_entries" (16..30, default 27; 0 = the default: a fused job -- sg_msm_g1_batch*, sg_commit_batch*, the commit
- *   combiner -- holds at most 2^x (window, scalar) entries = 64 polynomials of 2^17 rows over a 16-window table; larger batches
- *   are cut into several jobs),
+ * "msm.log_fuse_entries" (16..30; 0 = the defaults: a fused job holds at most 2^x (window, scalar) entries -- 27 for fixed-base
+ *   jobs (sg_commit_batch*, the commit combiner: 64 polynomials of 2^17 rows over a 16-window table), 25 for generic ones
+ *   (sg_msm_g1_batch*); larger batches are cut into several jobs; a value set here applies to both kinds),
  * "msm.acc_trace" (0 | 1: debug -- every wave of msm_accumulate records when it starts and leaves; the job's host tail prints the
  *   percentiles to stderr: tools/acc_trace.sh, profiles/r04_sweeps/accumulate_tail.txt),
  * "ntt.coset_scale_pass" (0 | 1: A-B aid -- sg_coeff_to_cosets_batch_dev multiplies by the coset shifts inside the first NTT pass
