@@ -381,3 +381,38 @@ def test_one_launch_msm_of_a_handful_of_points(gpu):
     raw = np.full(32 * 5, 0xFF, dtype=np.uint8)
     assert (gpu.best_multiexp(raw, bases_all[:64 * 5]) == pipeline(raw, bases_all[:64 * 5])).all()
     assert (gpu.best_multiexp(raw, bases_all[:64 * 5]) == gpu.best_multiexp(dev(raw), dev(bases_all[:64 * 5]))).all()
+
+
+def test_fused_job_size_and_its_default(gpu):
+    """a batch of commitments over a precomputed table is cut into jobs of at most 2^x entries ("msm.log_fuse_entries"; the launch
+    log tells the jobs apart): the default holds the whole batch (up to 64 polynomials), a small cap cuts it, and 0 puts the
+    default back -- what a caller that saved sg_get_param's answer for a parameter never set writes on the way out"""
+    from circuits_halo2_amd import arithmetic as A, ffi
+    k, count = 12, 20
+    n = 1 << k
+    g = A.g1_fixed_base_mul(_rand_fr(11, n)).cpu().numpy()
+    params = gpu.ParamsKZG(k, g, g)
+    params.precompute()
+    cols = [_rand_fr(200 + i, n) for i in range(count)]
+
+    def jobs():
+        ffi.set_param("msm.acc_log", 1)
+        try:
+            pts = params.commit_batch(cols)
+            return [r["M"] for r in ffi.msm_launch_log() if r["fixed"] == 1], pts
+        finally:
+            ffi.set_param("msm.acc_log", 0)
+
+    try:
+        whole, want = jobs()
+        assert whole == [count]
+        ffi.set_param("msm.log_fuse_entries", 18)      # 2^18 / (22 windows x 2^12 rows) = 2 polynomials per job
+        cut, got = jobs()
+        assert sum(cut) == count and max(cut) <= 3 and len(cut) >= 7
+        assert all((a == b).all() for a, b in zip(got, want))
+        ffi.set_param("msm.log_fuse_entries", 0)
+        again, got = jobs()
+        assert again == [count] and all((a == b).all() for a, b in zip(got, want))
+    finally:
+        ffi.set_param("msm.log_fuse_entries", 0)
+        params.free()
