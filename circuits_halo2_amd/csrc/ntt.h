@@ -25,6 +25,7 @@ struct NttConfig {
   uint32_t big_threads = 512;
   uint32_t batch_min = 4;
   uint32_t big_log = 20;
+  uint32_t radix4 = 1;           // two DIT stages per sweep over the LDS tile ("ntt.radix4"; same words): 0 never, 1 the throughput shapes (batches of >= batch_min vectors, transforms of >= 2^big_log points), 2 always
 };
 
 #ifndef SG_WORDS8

@@ -48,6 +48,7 @@ struct PassArgs {
   uint32_t fold29;           // the data of this (last) pass carries a factor 2^29 (the plan's last twiddle table holds
                              // it): close with one Montgomery limb step instead of a product by 1^; post[] absorbs 2^-29
   uint32_t skip;             // leading DIT stages whose second operand is zero (zero-padded first pass): not executed
+  uint32_t radix4;           // two DIT stages per sweep over the tile (four elements per thread)
   uint32_t pre[3][8];        // Montgomery-2^256 words, converted once per workgroup
   uint32_t post[3][8];
   // batched launch (nbatch > 0): blockIdx.y selects the vector; same plan for all (small transforms are a chain
@@ -82,139 +83,15 @@ __device__ __forceinline__ f29 lds_get(const LdsTile& t, uint32_t i) {
 // One pass.  grid.x = number of tiles = (2^log_b / T) * A  where A = n / (B*R).
 // Dynamic LDS: (T*R + R/2 + 8) * 36 bytes.
 __global__ void __launch_bounds__(1024) ntt_pass(PassArgs p) {
-  side_kernel_prio();
-  extern __shared__ uint4 lds[];
-  typedef Fr29 P;
-  const fp_words* __restrict__ p_in = p.nbatch ? p.in_b[blockIdx.y] : p.in;
-  fp_words* __restrict__ p_out = p.nbatch ? p.out_b[blockIdx.y] : p.out;
-  const uint32_t R = 1u << p.log_r, T = 1u << p.log_t;
-  const uint32_t E = R << p.log_t, H = (R >> 1) + 8;  // twiddles + 6 converted constants
-  LdsTile d{lds, lds + E, reinterpret_cast<uint32_t*>(lds + 2 * E)};
-  uint4* wbase = lds + 2 * E + ((E + 3) >> 2);
-  LdsTile w{wbase, wbase + H, reinterpret_cast<uint32_t*>(wbase + 2 * H)};
-  const uint32_t CONST0 = R >> 1;  // w-tile slots CONST0.. hold pre[0..2], post[0..2] in the 2^261 domain
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-
-  const uint32_t tiles_per_row = 1u << (p.log_b - p.log_t);
-  const uint32_t a = blockIdx.x >> (p.log_b - p.log_t);  // outer index (Y only; 0 for X)
-  const uint32_t b0 = (blockIdx.x & (tiles_per_row - 1)) << p.log_t;
-  const size_t base = ((size_t)a << (p.log_b + p.log_r)) + b0;
-
-  // stage the local twiddles (already 2^261-domain words) and convert the scale constants
-  for (uint32_t k = tid; k < (R >> 1); k += nthr) lds_put(w, k, f29_load_r256<P>(p.tw_local + k));
-  if (tid < 6 && ((tid < 3) ? p.pre3 : p.post3)) {
-    const uint32_t* src = tid < 3 ? p.pre[tid] : p.post[tid - 3];
-    uint32_t tmp[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) tmp[i] = src[i];
-    f29 c = f29_words_to_r261<P>(tmp);
-    if (tid >= 3 && p.fold29) {   // c * 2^232 * 2^-261 = c * 2^-29
-      f29 k = f29_zero();
-      k.l[8] = 1;
-      c = f29_mul<P>(c, k);
-    }
-    lds_put(w, CONST0 + tid, c);
-  }
-  if (p.pre3) __syncthreads();
-  // load the tile: rows are bit-reversed on the way in so that the DIT stages below leave
-  // natural order
-  const uint32_t rshift = 32 - p.log_r;
-  if (p.skip) {
-    // zero-padded input (coeff_to_extended: 2^k coefficients in a 2^(k+3) transform): only rows r < R >> skip exist,
-    // they land on the positions that are multiples of 2^skip, and the first `skip` stages would only add zeros to
-    // them -- u + w*0, u - w*0 -- i.e. copy each value over its block of 2^skip positions.  Load them replicated.
-    const uint32_t keep = ~((1u << p.skip) - 1);
-    for (uint32_t e = tid; e < E; e += nthr) {
-      const uint32_t t = e & (T - 1), rr = e >> p.log_t;
-      const uint32_t r = __brev(rr & keep) >> rshift;
-      const size_t gi = base + t + ((size_t)r << p.log_b);
-      f29 v = f29_load_r256<P>(p_in + gi);
-      if (p.pre3) {
-        uint32_t m = (uint32_t)(gi % 3);
-        if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
-      }
-      lds_put(d, e, v);
-    }
-  } else {
-  for (uint32_t e = tid; e < E; e += nthr) {
-    uint32_t t = e & (T - 1), r = e >> p.log_t;
-    size_t gi = base + t + ((size_t)r << p.log_b);
-    f29 v;
-    if (gi < p.in_len) {
-      v = f29_load_r256<P>(p_in + gi);
-      if (p.pre3) {
-        uint32_t m = (uint32_t)(gi % 3);
-        if (m) v = f29_mul<P>(v, lds_get(w, CONST0 + m));
-      }
-      if (p.pre_tab) v = f29_mul<P>(v, f29_load_r256<P>(p.pre_tab_b[blockIdx.y] + gi));   // x~ * (c^gi)^ = (x c^gi)~, bound < 2
-    } else {
-      v = f29_zero();
-    }
-    uint32_t rr = p.log_r ? (__brev(r) >> rshift) : 0;
-    lds_put(d, (rr << p.log_t) + t, v);
-  }
-  }
-  __syncthreads();
-
-  // log2(R) radix-2 DIT stages, one butterfly per thread per sweep
-  for (uint32_t s = p.skip; s < p.log_r; s++) {
-    const uint32_t h = 1u << s;
-    for (uint32_t q = tid; q < (E >> 1); q += nthr) {
-      uint32_t t = q & (T - 1), pr = q >> p.log_t;
-      uint32_t j = pr & (h - 1), blk = pr >> s;
-      uint32_t row = (blk << (s + 1)) + j;
-      uint32_t i0 = (row << p.log_t) + t, i1 = i0 + (h << p.log_t);
-      f29 u = lds_get(d, i0);
-      f29 v = lds_get(d, i1);
-      if (s < 2 && j == 0) {
-        // w^0 butterflies of the first two stages skip the product (as best_fft does):
-        // bounds 1 -> 3 (stage 0) and 3 -> 7 (stage 1)
-        lds_put(d, i0, f29_add(u, v));
-        lds_put(d, i1, s == 0 ? f29_sub<P, 0>(u, v) : f29_sub<P, 1>(u, v));
-      } else {
-        v = f29_mul<P>(v, lds_get(w, j << (p.log_r - s - 1)));  // bound(v) <= 25, twiddle canonical
-        lds_put(d, i0, f29_add(u, v));
-        lds_put(d, i1, f29_sub<P, 0>(u, v));
-      }
-    }
-    __syncthreads();
-  }
-
-  // write back: one closing product per element (or, with nothing to multiply by, a product-free reduction), then the
-  // canonical 32-byte store
-  if (p.kind == 0) {
-    for (uint32_t e = tid; e < E; e += nthr) {
-      uint32_t t = e & (T - 1), r = e >> p.log_t;
-      size_t go = base + t + ((size_t)r << p.log_b);
-      f29 v = lds_get(d, e);
-      if (p.tw_pass) {
-        v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
-        if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
-      } else if (p.post3) {
-        v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
-      } else {
-        v = p.fold29 ? f29_mont_step<P>(v) : f29_reduce_small<P>(v);
-      }
-      f29_store_canonical<P>(p_out + go, v);
-    }
-  } else {
-    for (uint32_t e = tid; e < E; e += nthr) {
-      uint32_t r = e & (R - 1), t = e >> p.log_r;
-      uint32_t b = b0 + t;
-      uint32_t bp = (b >> p.sig_lo) + ((b & ((1u << p.sig_lo) - 1)) << p.sig_hi);
-      size_t go = ((size_t)bp << p.log_r) + r;
-      f29 v = lds_get(d, (r << p.log_t) + t);
-      if (p.tw_pass) {
-        v = f29_mul<P>(v, f29_load_r256<P>(p.tw_pass + go));
-        if (p.post3) v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
-      } else if (p.post3) {
-        v = f29_mul<P>(v, lds_get(w, CONST0 + 3 + (uint32_t)(go % 3)));
-      } else {
-        v = p.fold29 ? f29_mont_step<P>(v) : f29_reduce_small<P>(v);
-      }
-      f29_store_canonical<P>(p_out + go, v);
-    }
-  }
+#define SG_NTT_R4 0
+#include "ntt_pass_body.inc"
+#undef SG_NTT_R4
+}
+// the same pass with two DIT stages per sweep (four elements per thread: more registers, half the threads)
+__global__ void __launch_bounds__(512) ntt_pass_r4(PassArgs p) {
+#define SG_NTT_R4 1
+#include "ntt_pass_body.inc"
+#undef SG_NTT_R4
 }
 
 // tw[k] = (w^k)^ for k < count; w given as Montgomery-2^256 words
@@ -441,9 +318,16 @@ static hipError_t launch_pass(const NttConfig& cfg, PassArgs& a, uint32_t log_n,
   a.log_t = log_t;
   size_t E = (size_t)1 << (a.log_r + log_t);
   size_t lds = (E + ((size_t)1 << a.log_r) / 2 + 8) * 36 + 64;
-  uint32_t threads = (uint32_t)std::min<size_t>(max_threads, std::max<size_t>(64, E / 2));
+  // two stages per sweep: measured (profiles/r05_sweeps/ntt_radix4.txt) 3-6 % faster for the throughput shapes -- lone transforms
+  // of 2^20 points and more, the batched launches of a proof (25 coset blocks: 323 -> 310 us) --, 25 % slower for a lone 2^17
+  // transform (two launches at their latency floor, which want many threads)
+  const bool want_r4 = cfg.radix4 == 2 || (cfg.radix4 == 1 && big);
+  a.radix4 = want_r4 && a.log_r - a.skip >= 2 ? 1u : 0u;
+  // one butterfly (radix-4 sweeps: one group of four elements) per thread per sweep
+  uint32_t threads = (uint32_t)std::min<size_t>(a.radix4 ? std::min<uint32_t>(max_threads, 512u) : max_threads, std::max<size_t>(64, E / (a.radix4 ? 4 : 2)));
   uint32_t tiles = 1u << (log_n - a.log_r - log_t);
-  hipLaunchKernelGGL(ntt_pass, dim3(tiles, a.nbatch ? a.nbatch : 1), dim3(threads), lds, stream, a);
+  if (a.radix4) hipLaunchKernelGGL(ntt_pass_r4, dim3(tiles, a.nbatch ? a.nbatch : 1), dim3(threads), lds, stream, a);
+  else hipLaunchKernelGGL(ntt_pass, dim3(tiles, a.nbatch ? a.nbatch : 1), dim3(threads), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -527,8 +411,9 @@ hipError_t NttEngine::transform_batch(fp_words* const* a, uint32_t count, fp_wor
 
 hipError_t NttEngine::init() {
   // allow the large dynamic-LDS tiles (up to the full 160 KiB of a CU)
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             160 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_r4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
 }
 
 hipError_t NttEngine::transform(const fp_words* in, size_t in_len, fp_words* out, fp_words* scratch, uint32_t log_n,

@@ -500,6 +500,7 @@ int apply_param(Context& c, const std::string& s, int value) {
   else if (s == "ntt.big_threads") c.ntt.config().big_threads = (uint32_t)std::max(64, std::min(1024, value));
   else if (s == "ntt.batch_min") c.ntt.config().batch_min = (uint32_t)std::max(1, value);
   else if (s == "ntt.big_log") c.ntt.config().big_log = (uint32_t)std::max(1, value);
+  else if (s == "ntt.radix4") c.ntt.config().radix4 = value == 1 ? 2u : value == 2 ? 0u : 1u;   // 0: by size (default), 1: always, 2: never
   else if (s == "ntt.max_single_log") { c.ntt.config().max_single_log = (uint32_t)std::max(1, std::min(12, value)); c.ntt.clear(); }
   else if (s == "ntt.max_multi_log") { c.ntt.config().max_multi_log = (uint32_t)std::max(4, std::min(12, value)); c.ntt.clear(); }
   else return fail(SG_ERR_INVALID, "sg_set_param: unknown parameter");

@@ -549,6 +549,9 @@ int sg_commit_dev_timed(uint64_t srs_handle, int basis, const void* d_scalars, s
  *   (sg_msm_g1_batch*); larger batches are cut into several jobs; a value set here applies to both kinds),
  * "msm.acc_trace" (0 | 1: debug -- every wave of msm_accumulate records when it starts and leaves; the job's host tail prints the
  *   percentiles to stderr: tools/acc_trace.sh, profiles/r04_sweeps/accumulate_tail.txt),
+ * "ntt.radix4" (0 = by size, default | 1 always | 2 never: an NTT pass runs two butterfly stages per sweep over its LDS tile --
+ *   four elements per thread, half the barriers; same words; by size = transforms of 2^20 points and more and batched launches of
+ *   four vectors and more, where it is 3-6 % faster: profiles/r05_sweeps/ntt_radix4.txt),
  * "ntt.coset_scale_pass" (0 | 1: A-B aid -- sg_coeff_to_cosets_batch_dev multiplies by the coset shifts inside the first NTT pass
  *   (0, default) or in a pass of its own before the transforms (1, rounds 3-4); same results), "msm.acc_log" (see sg_msm_launch_log),
  * "debug.fail_next_fused_job" (test hook: the next FUSED job of the commit combiner reports SG_ERR_NOMEM without running, so that

@@ -416,3 +416,31 @@ def test_fused_job_size_and_its_default(gpu):
     finally:
         ffi.set_param("msm.log_fuse_entries", 0)
         params.free()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 12, 14, 17, 20])
+def test_ntt_with_two_stages_per_sweep_writes_the_same_words(gpu, log_n):
+    """"ntt.radix4" = 1 (every pass takes two DIT stages per sweep, four elements per thread: csrc/ntt_pass_body.inc) against 2
+    (never): forward and inverse transforms, one- two- and three-pass plans, odd and even stage counts, batched launches and the
+    coset transform with its table product on the load -- the same words (the oracle pins the default in tests/test_gpu_parity.py)"""
+    import torch
+    from circuits_halo2_amd import arithmetic as A, ffi
+    from circuits_halo2_amd.domain import EvaluationDomain
+    n = 1 << log_n
+    dom = EvaluationDomain(6, log_n)
+    cols = [_rand_fr(4000 + 10 * log_n + i, n) for i in range(5 if log_n <= 17 else 1)]
+
+    def run(mode):
+        ffi.set_param("ntt.radix4", mode)
+        try:
+            fwd = A.best_fft_batch([c.clone() for c in cols], dom.get_omega(), log_n)
+            inv = A.best_fft_batch([c.clone() for c in cols], dom.get_omega_inv(), log_n, dom.ifft_divisor())
+            one = dom.lagrange_to_coeff(cols[0].clone())
+            cos = dom.coeff_to_cosets_batch(cols) if log_n <= 17 else []
+            torch.cuda.synchronize()
+            return fwd + inv + [one] + cos
+        finally:
+            ffi.set_param("ntt.radix4", 0)
+
+    for a, b in zip(run(1), run(2)):
+        assert (a == b).all() and a.any()

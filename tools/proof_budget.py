@@ -178,6 +178,8 @@ def main():
             return 3 * 96 * M * 16, "window sums to the host"
         if nm == "sg::ntt_pass":
             return 2 * g * 2 * R, "2 elements per thread x (32 B in + 32 B out); inter-pass twiddle tables (32 B per element of the passes that have one) not counted"
+        if nm == "sg::ntt_pass_r4":   # two stages per sweep: four elements per thread
+            return 4 * g * 2 * R, "4 elements per thread x (32 B in + 32 B out); inter-pass twiddle tables (32 B per element of the passes that have one) not counted"
         if nm.startswith("sg::numerator_fused_kernel"):
             return NE * R * (9 + 3 + 1 + 2 + 6 + 3 + 3 + 1), ("5n rows x (9 fixed + 3 advice + instance columns of the gate programs, 2 z, 6 sigma, 3 selector "
                                                                "columns, lz / a' / s', values out) x 32 B: every column once")
