@@ -179,6 +179,11 @@ struct Context {
   static constexpr uint32_t BLOB_RING = 16;
   BlobSlot blob_ring[BLOB_RING];
   uint32_t blob_next = 0;
+  // sg_fr_kate_division_batch: the divisions' power tables (host-computed, 684 B each) on their way to the device -- a ring like
+  // the one above, so that the call returns without waiting for the stream
+  static constexpr uint32_t KATE_RING = 4;
+  BlobSlot kate_ring[KATE_RING];
+  uint32_t kate_next = 0;
   std::map<uint32_t, DomainConsts> consts;
   std::map<uint64_t, fp_words*> t_evals;  // key = k << 32 | ext_k
   // page-locked host memory mapped into the device: small results the host waits for anyway (evaluations, a remainder, a
@@ -295,6 +300,11 @@ void destroy_context(Context* c) {
   for (auto& kv : c->stream_scratch) kv.second.release();
   for (auto& kv : c->lookup_work) kv.second.buf.release();
   if (c->h_mail) (void)hipHostFree(c->h_mail);
+  for (auto& sl : c->kate_ring) {
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.dev) (void)hipFree(sl.dev);
+  }
   if (c->d_consts) (void)hipFree(c->d_consts);
   c->stream = nullptr;   // one of g_lane_main: destroyed with the others at sg_shutdown
   delete c;
@@ -2457,18 +2467,27 @@ int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_
   if (m == 0 || n == 0) return SG_OK;
   LOCKED_CTX();
   hipStream_t s = pick_stream(stream);
-  uint8_t *d_pw = nullptr, *d_tmp = nullptr;
-  hipError_t e = scratch_for(s, 5, kate_batch_powers_bytes(16), &d_pw);
-  if (e == hipSuccess) e = scratch_for(s, 6, kate_batch_tmp_elems(n, 16) * 32 + 64, &d_tmp);
+  uint8_t* d_tmp = nullptr;
+  hipError_t e = scratch_for(s, 6, kate_batch_tmp_elems(n, 16) * 32 + 64, &d_tmp);
   if (e != hipSuccess) return hip_fail("kate_division_batch work space", e);
   std::vector<words8> b(m);
   std::memcpy(b.data(), points, 32 * (size_t)m);
-  std::vector<uint8_t> h_pw(kate_batch_powers_bytes(m));
-  e = poly_kate_division_batch(reinterpret_cast<const fp_words* const*>(d_a), n, b.data(), m, reinterpret_cast<fp_words* const*>(d_q),
-                               h_pw.data(), d_pw, reinterpret_cast<fp_words*>(d_tmp), s);
-  // h_pw is a local: the (pageable) upload has been staged by the time hipMemcpyAsync returns only if it was synchronous;
-  // make sure before the buffer dies
-  if (e == hipSuccess) e = host_wait_stream(s);
+  // the power tables are computed on the host into page-locked memory of a ring slot and copied from there: asynchronous (the
+  // call used to wait for the whole stream so that a local staging buffer could die -- 0.16 ms of a proof with the device idle
+  // behind it); a slot is reused once the kernels that read it have run (an event; normally long complete)
+  Context::BlobSlot& slot = g_ctx->kate_ring[g_ctx->kate_next++ % Context::KATE_RING];
+  if (!slot.ev) e = hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming);
+  else if (hipEventQuery(slot.ev) != hipSuccess) e = host_wait_event(slot.ev);
+  if (e == hipSuccess && !slot.host) {
+    const size_t want = kate_batch_powers_bytes(16);
+    e = hipHostMalloc(reinterpret_cast<void**>(&slot.host), want, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&slot.dev), want);
+    if (e == hipSuccess) slot.cap = want;
+  }
+  if (e == hipSuccess)
+    e = poly_kate_division_batch(reinterpret_cast<const fp_words* const*>(d_a), n, b.data(), m, reinterpret_cast<fp_words* const*>(d_q),
+                                 slot.host, slot.dev, reinterpret_cast<fp_words*>(d_tmp), s);
+  if (e == hipSuccess) e = hipEventRecord(slot.ev, s);
   if (e != hipSuccess) return hip_fail("kate_division_batch", e);
   return SG_OK;
 }

@@ -355,7 +355,8 @@ int sg_fr_kate_division_dev(const void* d_a, size_t n, const uint8_t b[32], void
 /* m <= 16 exact divisions q_j = a_j / (X - points_j) of n coefficients each (n written per quotient, the last one 0), one
  * launch per scan step for all of them.  The multi-open's use: by partial fractions 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j),
  * so the divisions of a rotation set are independent divisions of the same polynomial (which vanishes on the whole set)
- * instead of a chain, and all sets go in one batch.  Remainders are not returned.  Complete on return. */
+ * instead of a chain, and all sets go in one batch.  Remainders are not returned.  Asynchronous on `stream` (`points` and the
+ * pointer arrays are read before the call returns; revisions 1-2 waited for the stream before returning). */
 int sg_fr_kate_division_batch_dev(const void* const* d_a, size_t n, const uint8_t* points, uint32_t m, void* const* d_q,
                                   void* stream);
 /* sg_fr_kate_division_dev with the remainder a(b) (32 B, Montgomery) written to device-visible memory d_remainder by the kernel
@@ -583,6 +584,7 @@ int sg_msm_launch_log(uint32_t* out_words, size_t cap_records, size_t* n_records
  *   2 (round 4): sg_msm_timings gained `order_ms` (44 bytes; accumulate_ms excludes the wait in the accumulation chain)
  *   3 (round 5): added sg_get_param, sg_msm_launch_log, sg_abi_version, sg_fr_lincomb_sets_dev, sg_quotient_numerator_cosets_dev,
  *     sg_fr_flag_noncanonical_dev, sg_lookup_permute_small_async_dev, sg_grand_products_closing_dev, sg_fr_kate_division_rem_dev;
+ *     sg_fr_kate_division_batch_dev no longer waits for the stream before it returns (it is asynchronous like its neighbours);
  *     nothing removed or resized
  * A binding built against revision r must refuse a library whose sg_abi_version() < r. */
 #define SG_ABI_VERSION 3

@@ -1226,6 +1226,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
   lap("5_evaluations");
   // -- 6: SHPLONK
   const Fr zeta = tr.squeeze(), nu = tr.squeeze_again();
+  mark("6: zeta, nu squeezed");
   const auto sets = rotation_sets();
   std::vector<DevCol> fs;
   std::vector<std::vector<Fr>> rs;
@@ -1256,6 +1257,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
       inv = inv * v;
     }
   }
+  mark("6: Lagrange denominators inverted");
   // r_i(X) through the set's (points, values) for every set first: host arithmetic on the evaluations alone.  r_i has at most
   // four coefficients: it enters the kernels BY VALUE (sg_fr_lincomb_low_dev), never as a column
   std::vector<std::vector<Fr>> zps(sets.size());
@@ -1289,6 +1291,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     }
     rs.push_back(rc);
   }
+  mark("6: r_i interpolated");
   {
     // f_i = q_i - r_i for all five sets in ONE launch (grid.y = set): q_i = the zeta-combination of the set's polynomials, r_i by value
     std::vector<void*> ps, outs;
@@ -1318,6 +1321,7 @@ std::vector<uint8_t> create_proof_with(const ProvingKey& pk, std::vector<DevCol>
     ck(sg_fr_lincomb_sets_dev(ps.data(), cs[0].bytes(), sizes.data(), (uint32_t)sets.size(), n, lows[0].bytes(), n_lows.data(), outs.data(),
                               main_stream()), "set lincombs");
   }
+  mark("6: set combinations enqueued");
   // f_i / Z_{S_i}: q_i - r_i vanishes on the whole set, and 1 / prod_j (X - p_j) = sum_j c_j / (X - p_j) with
   // c_j = 1 / prod_{t != j} (p_j - p_t) -- the Lagrange denominators already inverted above.  So every division of every
   // set is an independent exact Kate division: ONE batch (three launches for all eleven), and
